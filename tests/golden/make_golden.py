@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Imports ``lib.models.zf_unet``, ``lib.models.tiramisu``, ``lib.losses``, ``lib.metrics`` read-only from
+/root/reference (torch 2.10 CPU, fp32) and stores plain arrays (.npz) -- inputs, expected outputs,
+never module objects or source.  Weights are a closed-form fill (oracle.zf_unet_ref.closed_form_fill)
+so large configs need no weight payload.
+
+Fixtures
+  losses.npz          G6  every binary loss / metric value + d(loss)/d(logits) on a small random tensor,
+                          plus hand-derivable known answers
+  zf_unet_tiny.npz    G1  ZF_UNET(filters=4, dropout 0) B=2 64x64: eval/train logits, all losses, metrics,
+                          every parameter gradient of (B*bce_jaccard).backward(), BN running stats,
+                          5-step SGD(1e-3) loss trajectory
+  zf_unet_224.npz     G2+G3  ZF_UNET() default (filters=32, Dropout2d 0.2 replay tables captured from the
+                          reference's own RNG draw) B=4 224x224: loss / IoU / accuracy scalars, per-tensor
+                          gradient L2 norms, probed logits and gradient entries
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import numpy as np
+import torch
+
+from lib.models.zf_unet import ZF_UNET          # reference
+from lib import losses as ref_losses            # reference
+from lib import metrics as ref_metrics          # reference
+
+from oracle import zf_unet_ref, train_step_ref  # only for closed_form_fill / synthetic_batch (input makers)
+
+torch.set_num_threads(8)
+
+
+def ref_loss(name):
+    """torch_train.get_loss (torch_train.py:82-97) + the API-rot fix of SURVEY 8c."""
+    if name == 'bce':
+        c = ref_losses.BCEWithSigmoidLoss()
+        c.size_average, c.reduce = True, True
+    elif name == 'bce_jaccard':
+        c = ref_losses.BCEWithLogitsLossAndSmoothJaccard()
+        c.bce_loss.size_average, c.bce_loss.reduce = True, True
+    elif name == 'focal':
+        c = ref_losses.FocalLossBinary(size_average=False)
+        c.size_average, c.reduce = False, True
+    elif name == 'jaccard':
+        c = ref_losses.JaccardLoss()
+    elif name == 'smooth_jaccard':
+        c = ref_losses.SmoothJaccardLoss()
+    elif name == 'dice':
+        c = ref_losses.DiceLoss()
+    elif name == 'bce_dice':
+        b, d = ref_loss('bce'), ref_losses.DiceLoss()
+        return lambda o, t: (b(o, t) + d(o, t.float())) / 2.0
+    else:
+        raise ValueError(name)
+    if name in ('dice',):
+        return lambda o, t: c(o, t.float())
+    return c
+
+
+LOSS_NAMES = ['bce', 'jaccard', 'smooth_jaccard', 'dice', 'bce_jaccard', 'bce_dice', 'focal']
+
+
+def gen_losses():
+    g = torch.Generator().manual_seed(7)
+    x = (2.5 * torch.randn(2, 1, 24, 40, generator=g))
+    t = (torch.rand(2, 1, 24, 40, generator=g) > 0.6).long()
+    out = {'x': x.numpy(), 't': t.numpy()}
+    for name in LOSS_NAMES:
+        xx = x.clone().requires_grad_(True)
+        l = ref_loss(name)(xx, t)
+        (x.shape[0] * l).backward()
+        out['loss_' + name] = l.detach().numpy()
+        out['dx_' + name] = xx.grad.numpy()
+    out['iou'] = ref_metrics.JaccardScore()(x, t).numpy()
+    out['acc'] = ref_metrics.PixelAccuracy()(x, t).numpy()
+    # known answers: x = 0 everywhere, t = 1 -> bce = log(1.5) + log(2)
+    x0 = torch.zeros(1, 1, 4, 4)
+    t1 = torch.ones(1, 1, 4, 4).long()
+    t0 = torch.zeros(1, 1, 4, 4).long()
+    for tag, tt in (('ones', t1), ('zeros', t0)):
+        for name in LOSS_NAMES:
+            out['ka_%s_%s' % (tag, name)] = ref_loss(name)(x0, tt).numpy()
+        out['ka_%s_iou' % tag] = ref_metrics.JaccardScore()(x0, tt).numpy()
+    # accuracy edge: nothing matches -> the reference returns an integer zero (metrics.py:37-38)
+    xe = torch.full((1, 1, 2, 2), 3.0)
+    out['acc_nomatch'] = np.asarray(float(ref_metrics.PixelAccuracy()(xe, t0[:, :, :2, :2])))
+    np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
+    print('losses.npz', {k: float(v) for k, v in out.items() if k.startswith('loss_')})
+
+
+def fill_reference_model(model, seed):
+    sd = model.state_dict()
+    names = list(sd.keys())
+    zf_unet_ref.closed_form_fill(sd, seed)   # state_dict tensors alias the module's -> fills the model
+    return names
+
+
+def gen_tiny():
+    B, S, F = 2, 64, 4
+    m = ZF_UNET(dropout_val=0.0, filters=F)
+    names = fill_reference_model(m, seed=3.0)
+    assert names == list(zf_unet_ref.state_shapes(filters=F).keys()), 'state_dict layout drifted'
+    x, y = train_step_ref.synthetic_batch(B, S, seed=11)
+    out = {'x': x.numpy(), 'y': y.numpy()}
+    m.eval()
+    with torch.no_grad():
+        out['eval_logits'] = m(x).numpy()
+    m.train()
+    logits = m(x)                        # updates running stats once
+    out['train_logits'] = logits.detach().numpy()
+    for name in LOSS_NAMES:
+        out['loss_' + name] = ref_loss(name)(logits.detach(), y).numpy()
+    out['iou'] = ref_metrics.JaccardScore()(logits.detach(), y).numpy()
+    out['acc'] = ref_metrics.PixelAccuracy()(logits.detach(), y).numpy()
+    m.zero_grad()
+    l = ref_loss('bce_jaccard')(logits, y)
+    (B * l).backward()
+    for n, p in m.named_parameters():
+        out['grad/' + n] = p.grad.numpy().copy()
+    for n, b in m.named_buffers():
+        out['buf/' + n] = b.numpy().copy()
+    # per-loss gradient norms (full grads only for bce_jaccard above)
+    for name in ['bce', 'jaccard', 'dice', 'focal', 'bce_dice']:
+        m2 = ZF_UNET(dropout_val=0.0, filters=F)
+        fill_reference_model(m2, seed=3.0)
+        m2.train()
+        ll = ref_loss(name)(m2(x), y)
+        (B * ll).backward()
+        out['gradnorm_' + name] = np.array([p.grad.norm().item() for _, p in m2.named_parameters()])
+    # 5-step SGD trajectory from the filled state (fresh model: the forward above moved BN stats)
+    m3 = ZF_UNET(dropout_val=0.0, filters=F)
+    fill_reference_model(m3, seed=3.0)
+    m3.train()
+    opt = torch.optim.SGD(m3.parameters(), lr=1e-3)
+    crit = ref_loss('bce_jaccard')
+    traj = []
+    for _ in range(5):
+        opt.zero_grad()
+        ll = crit(m3(x), y)
+        (B * ll).backward()
+        opt.step()
+        traj.append(ll.item())
+    out['traj_bce_jaccard'] = np.array(traj)
+    for n, p in m3.state_dict().items():
+        out['after5/' + n] = p.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'zf_unet_tiny.npz'), **out)
+    print('zf_unet_tiny.npz traj', traj)
+
+
+def capture_dropout_tables(model, p):
+    """Forward hooks on every nn.Dropout2d: table[n,c] = 0 where the reference zeroed the channel."""
+    tables, hooks = {}, []
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            def hook(_m, inp, outp, name=name):
+                i = inp[0].detach().abs().flatten(2).sum(-1)
+                o = outp.detach().abs().flatten(2).sum(-1)
+                dropped = (o == 0) & (i > 0)
+                tables[name.rsplit('.', 1)[0]] = torch.where(dropped, torch.zeros_like(o),
+                                                             torch.full_like(o, 1.0 / (1.0 - p)))
+            hooks.append(mod.register_forward_hook(hook))
+    return tables, hooks
+
+
+def gen_224():
+    B, S = 4, 224
+    torch.manual_seed(2024)
+    m = ZF_UNET()                       # defaults: filters=32, dropout 0.2, BN
+    fill_reference_model(m, seed=1.0)
+    x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
+    m.train()
+    tables, hooks = capture_dropout_tables(m, 0.2)
+    logits = m(x)
+    for h in hooks:
+        h.remove()
+    l = ref_loss('bce_jaccard')(logits, y)
+    m.zero_grad()
+    (B * l).backward()
+    out = {'loss_bce_jaccard': l.detach().numpy(),
+           'loss_bce': ref_loss('bce')(logits.detach(), y).numpy(),
+           'loss_bce_dice': ref_loss('bce_dice')(logits.detach(), y).numpy(),
+           'iou': ref_metrics.JaccardScore()(logits.detach(), y).numpy(),
+           'acc': ref_metrics.PixelAccuracy()(logits.detach(), y).numpy()}
+    for k, v in tables.items():
+        out['drop/' + k] = v.numpy()
+    rng = np.random.RandomState(5)
+    flat = logits.detach().numpy().reshape(-1)
+    idx = rng.choice(flat.size, 2048, replace=False)
+    out['logit_idx'] = idx
+    out['logit_val'] = flat[idx]
+    out['logit_mean'] = np.asarray(flat.mean())
+    out['logit_std'] = np.asarray(flat.std())
+    pnames, norms = [], []
+    for n, p in m.named_parameters():
+        g = p.grad.numpy().reshape(-1)
+        pnames.append(n)
+        norms.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        k = min(64, g.size)
+        gi = rng.choice(g.size, k, replace=False)
+        out['gidx/' + n] = gi
+        out['gval/' + n] = g[gi]
+    out['grad_names'] = np.array(pnames)
+    out['grad_norms'] = np.array(norms)
+    for n, b in m.named_buffers():
+        if 'conv_224' in n or 'conv_7.' in n or 'up_conv_224' in n:
+            out['buf/' + n] = b.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'zf_unet_224.npz'), **out)
+    print('zf_unet_224.npz loss', float(l), 'iou', float(out['iou']))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['losses', 'tiny', '224']
+    if 'losses' in which:
+        gen_losses()
+    if 'tiny' in which:
+        gen_tiny()
+    if '224' in which:
+        gen_224()

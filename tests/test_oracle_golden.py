@@ -1,0 +1,124 @@
+"""Pin the oracle (oracle/*.py) against golden vectors emitted by the reference itself.
+
+Fixtures come from tests/golden/make_golden.py (imports /root/reference in the build container).
+Tolerances: the oracle and the reference both run torch-CPU fp32 kernels, so agreement is to fp32
+rounding (thread-count-dependent summation order allowed: 8-thread vs 1-thread differs by ~5e-7).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_ref, train_step_ref, zf_unet_ref
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+LOSS_NAMES = ['bce', 'jaccard', 'smooth_jaccard', 'dice', 'bce_jaccard', 'bce_dice', 'focal']
+
+
+@pytest.mark.parametrize('name', LOSS_NAMES)
+def test_loss_values_and_grads(golden_dir, name):
+    g = _load(golden_dir, 'losses.npz')
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    t = torch.from_numpy(g['t'])
+    l = losses_ref.LOSSES[name](x, t)
+    (x.shape[0] * l).backward()
+    np.testing.assert_allclose(l.item(), g['loss_' + name], rtol=2e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g['dx_' + name], rtol=2e-5, atol=1e-9)
+
+
+def test_metrics(golden_dir):
+    g = _load(golden_dir, 'losses.npz')
+    x, t = torch.from_numpy(g['x']), torch.from_numpy(g['t'])
+    np.testing.assert_allclose(losses_ref.jaccard_score(x, t).item(), g['iou'], rtol=2e-6)
+    np.testing.assert_allclose(losses_ref.pixel_accuracy(x, t).item(), g['acc'], rtol=1e-7)
+    assert float(g['acc_nomatch']) == 0.0
+    xe = torch.full((1, 1, 2, 2), 3.0)
+    assert losses_ref.pixel_accuracy(xe, torch.zeros(1, 1, 2, 2).long()).item() == 0.0
+
+
+@pytest.mark.parametrize('tag', ['ones', 'zeros'])
+def test_known_answers(golden_dir, tag):
+    g = _load(golden_dir, 'losses.npz')
+    x0 = torch.zeros(1, 1, 4, 4)
+    t = (torch.ones if tag == 'ones' else torch.zeros)(1, 1, 4, 4).long()
+    for name in LOSS_NAMES:
+        np.testing.assert_allclose(losses_ref.LOSSES[name](x0, t).item(), g['ka_%s_%s' % (tag, name)],
+                                   rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(losses_ref.jaccard_score(x0, t).item(), g['ka_%s_iou' % tag], rtol=2e-6)
+    if tag == 'ones':   # hand-derived: x=0,t=1 -> log(1+sigmoid(0)) - log(sigmoid(0)) = log(1.5)+log(2)
+        np.testing.assert_allclose(losses_ref.bce(x0, t).item(), np.log(1.5) + np.log(2.0), rtol=1e-6)
+
+
+def test_state_layout():
+    shapes = zf_unet_ref.state_shapes()
+    assert len(shapes) == 156                                       # SURVEY 5 probe
+    assert sum(zf_unet_ref.is_param(k) for k in shapes) == 90
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if zf_unet_ref.is_param(k))
+    assert n == 31454721                                            # SURVEY 8a a2 probe
+
+
+def test_zf_unet_tiny_forward(golden_dir):
+    g = _load(golden_dir, 'zf_unet_tiny.npz')
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    sd = zf_unet_ref.new_state(filters=4, seed=3.0)
+    with torch.no_grad():
+        ev = zf_unet_ref.forward(sd, x, train=False)
+    np.testing.assert_allclose(ev.numpy(), g['eval_logits'], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():
+        tr = zf_unet_ref.forward(sd, x, train=True)
+    np.testing.assert_allclose(tr.numpy(), g['train_logits'], rtol=1e-4, atol=2e-5)
+    for name in LOSS_NAMES:
+        np.testing.assert_allclose(losses_ref.LOSSES[name](tr, y).item(), g['loss_' + name], rtol=5e-6)
+    np.testing.assert_allclose(losses_ref.jaccard_score(tr, y).item(), g['iou'], rtol=5e-6)
+    np.testing.assert_allclose(losses_ref.pixel_accuracy(tr, y).item(), g['acc'], rtol=1e-6)
+    for k in sd:
+        if not zf_unet_ref.is_param(k):
+            np.testing.assert_allclose(sd[k].numpy(), g['buf/' + k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_zf_unet_tiny_grads_and_trajectory(golden_dir):
+    g = _load(golden_dir, 'zf_unet_tiny.npz')
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    sd = zf_unet_ref.new_state(filters=4, seed=3.0)
+    loss, _, grads = train_step_ref.loss_and_grads(sd, x, y, 'bce_jaccard')
+    np.testing.assert_allclose(loss.item(), g['loss_bce_jaccard'], rtol=5e-6)
+    for k, v in grads.items():
+        ref = g['grad/' + k]
+        # conv biases that feed a BatchNorm have an analytically ZERO gradient: both sides hold fp32
+        # summation noise (~1e-7) there, hence the absolute floor.
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(v.numpy() - ref).max() <= 2e-4 * scale + 2e-6, k
+    for name in ['bce', 'jaccard', 'dice', 'focal', 'bce_dice']:
+        sd2 = zf_unet_ref.new_state(filters=4, seed=3.0)
+        _, _, gr = train_step_ref.loss_and_grads(sd2, x, y, name)
+        norms = np.array([gr[k].norm().item() for k in gr])
+        np.testing.assert_allclose(norms, g['gradnorm_' + name], rtol=2e-4, atol=2e-6 * norms.max())
+    sd3 = zf_unet_ref.new_state(filters=4, seed=3.0)
+    traj = [train_step_ref.train_step(sd3, x, y, 'bce_jaccard', lr=1e-3)[0].item() for _ in range(5)]
+    np.testing.assert_allclose(traj, g['traj_bce_jaccard'], rtol=2e-5)
+    for k in sd3:
+        np.testing.assert_allclose(sd3[k].numpy().astype(np.float64), g['after5/' + k].astype(np.float64),
+                                   rtol=3e-4, atol=5e-5, err_msg=k)   # 5 chained fp32 steps
+
+
+def test_zf_unet_224_scalars(golden_dir):
+    """Config-1 shape (filters=32, B=4, 224x224, Dropout2d replayed from the reference's own draw)."""
+    g = _load(golden_dir, 'zf_unet_224.npz')
+    x, y = train_step_ref.synthetic_batch(4, 224, seed=1234)
+    sd = zf_unet_ref.new_state(filters=32, seed=1.0)
+    drop = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('drop/')}
+    assert len(drop) == 11
+    loss, logits, grads = train_step_ref.loss_and_grads(sd, x, y, 'bce_jaccard', drop=drop)
+    assert abs(loss.item() - float(g['loss_bce_jaccard'])) < 1e-5          # north_star tolerance
+    assert abs(losses_ref.jaccard_score(logits, y).item() - float(g['iou'])) < 1e-4
+    np.testing.assert_allclose(losses_ref.pixel_accuracy(logits, y).item(), g['acc'], atol=1e-4)
+    flat = logits.numpy().reshape(-1)
+    np.testing.assert_allclose(flat[g['logit_idx']], g['logit_val'], rtol=2e-3, atol=2e-4)
+    names = list(g['grad_names'])
+    norms = np.array([np.sqrt((grads[n].numpy().astype(np.float64) ** 2).sum()) for n in names])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-3, atol=2e-6 * norms.max())
