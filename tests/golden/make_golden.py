@@ -15,7 +15,7 @@ Fixtures
                           plus hand-derivable known answers
   zf_unet_tiny.npz    G1  ZF_UNET(filters=4, dropout 0) B=2 64x64: eval/train logits, all losses, metrics,
                           every parameter gradient of (B*bce_jaccard).backward(), BN running stats,
-                          5-step SGD(1e-3) loss trajectory
+                          state after one SGD(1e-3) step, 5-step loss trajectory
   zf_unet_224.npz     G2+G3  ZF_UNET() default (filters=32, Dropout2d 0.2 replay tables captured from the
                           reference's own RNG draw) B=4 224x224: loss / IoU / accuracy scalars, per-tensor
                           gradient L2 norms, probed logits and gradient entries
@@ -145,15 +145,16 @@ def gen_tiny():
     opt = torch.optim.SGD(m3.parameters(), lr=1e-3)
     crit = ref_loss('bce_jaccard')
     traj = []
-    for _ in range(5):
+    for it in range(5):
         opt.zero_grad()
         ll = crit(m3(x), y)
         (B * ll).backward()
         opt.step()
         traj.append(ll.item())
+        if it == 0:     # state after ONE step (later steps amplify fp32 noise through the 2x2-pixel BN)
+            for n, p in m3.state_dict().items():
+                out['after1/' + n] = p.numpy().copy()
     out['traj_bce_jaccard'] = np.array(traj)
-    for n, p in m3.state_dict().items():
-        out['after5/' + n] = p.numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'zf_unet_tiny.npz'), **out)
     print('zf_unet_tiny.npz traj', traj)
 

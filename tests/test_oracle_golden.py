@@ -99,11 +99,15 @@ def test_zf_unet_tiny_grads_and_trajectory(golden_dir):
         norms = np.array([gr[k].norm().item() for k in gr])
         np.testing.assert_allclose(norms, g['gradnorm_' + name], rtol=2e-4, atol=2e-6 * norms.max())
     sd3 = zf_unet_ref.new_state(filters=4, seed=3.0)
-    traj = [train_step_ref.train_step(sd3, x, y, 'bce_jaccard', lr=1e-3)[0].item() for _ in range(5)]
+    traj = []
+    for it in range(5):
+        traj.append(train_step_ref.train_step(sd3, x, y, 'bce_jaccard', lr=1e-3)[0].item())
+        if it == 0:
+            for k in sd3:
+                np.testing.assert_allclose(sd3[k].numpy().astype(np.float64),
+                                           g['after1/' + k].astype(np.float64),
+                                           rtol=1e-5, atol=2e-6, err_msg=k)
     np.testing.assert_allclose(traj, g['traj_bce_jaccard'], rtol=2e-5)
-    for k in sd3:
-        np.testing.assert_allclose(sd3[k].numpy().astype(np.float64), g['after5/' + k].astype(np.float64),
-                                   rtol=3e-4, atol=5e-5, err_msg=k)   # 5 chained fp32 steps
 
 
 def test_zf_unet_224_scalars(golden_dir):
