@@ -1,0 +1,184 @@
+/* segnb_hip.h -- C ABI of libsegnb_hip.so: the MI355X (gfx950) kernels behind the reference's
+ * training/inference hot path (torch_train.py:176-190 driving lib/models/<model>.py, lib/losses.py,
+ * lib/metrics.py).
+ *
+ * The reference has no FFI of its own for this path: every primitive below replaces a torch.nn /
+ * ATen(cuDNN) call the reference makes (cited per entry point).  The only native-op precedent in
+ * the reference is the `inplace_abn` backend contract (lib/modules/abn/functions.py:12-15, :81-118:
+ * functions return a success flag, the Python wrapper raises RuntimeError) -- the status-code
+ * convention here follows it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t (>0) or SEGNB_E_* (<0) otherwise; nothing
+ *     throws across the ABI; segnb_last_error() gives a thread-local message
+ *   - every function is asynchronous on the explicit `stream` (a hipStream_t), allocates nothing,
+ *     never synchronises: graph-capturable
+ *   - pointers are DEVICE pointers borrowed for the duration of the call unless marked host
+ *   - activations are NHWC ("pixel-major"), element type `dtype` (f32 or bf16), with an explicit
+ *     pixel stride `ld` (elements) so a tensor may be a channel slice of a wider concat buffer
+ *     (zero-copy torch.cat, lib/models/zf_unet.py:78-90).  Channel counts are padded to a multiple
+ *     of 8 (16-byte vectors); pad channels hold zeros.
+ *   - parameters / gradients / logits / targets cross the boundary in the reference's own layouts
+ *     (OIHW fp32 weights, NCHW fp32 logits, int64 targets).
+ */
+#ifndef SEGNB_HIP_H
+#define SEGNB_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* segnb_stream_t; /* hipStream_t */
+
+enum { SEGNB_F32 = 0, SEGNB_BF16 = 1 };
+enum { SEGNB_ACT_NONE = 0, SEGNB_ACT_RELU = 1, SEGNB_ACT_LEAKY = 2 };
+enum { SEGNB_E_BADARG = -1, SEGNB_E_UNSUPPORTED = -2 };
+
+#define SEGNB_MAX_TAPS 64
+
+const char* segnb_last_error(void);
+int segnb_version(void);
+/* number of CUs of the current device (grid sizing); <0 on error */
+int segnb_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generalised gather-convolution geometry.  One launch computes, for every image n and every
+ * (qh, qw) in [0,QH)x[0,QW):
+ *     out[n, qh*out_step + oh0, qw*out_step + ow0, co] =
+ *         bias[co] + sum_t sum_ci in[n, qh*in_step + dh[t], qw*in_step + dw[t], ci] * W[co][t][ci]
+ * (out-of-range input pixels read as zero).  With the right tap table this one form covers
+ *   nn.Conv2d fwd (any k/stride/pad; zf_unet.py:8, linknet.py:41, tiramisu.py:14),
+ *   its data gradient (stride 1: flipped taps; stride 2: one launch per output parity),
+ *   nn.ConvTranspose2d fwd (per output parity; linknet.py:16, tiramisu.py:65, unet16.py:38) and its
+ *   data gradient -- i.e. aten::convolution / convolution_backward(input) of the reference.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int N, Hi, Wi, Ci;   /* input  [N,Hi,Wi,Ci]  Ci % 8 == 0 */
+    int Ho, Wo, Co;      /* output [N,Ho,Wo,Co]  Co % 8 == 0 */
+    int ld_in, ld_out;   /* pixel strides in elements */
+    int QH, QW;          /* positions iterated per image */
+    int in_step, out_step;
+    int oh0, ow0;
+    int ntaps;
+    int dh[SEGNB_MAX_TAPS];
+    int dw[SEGNB_MAX_TAPS];
+} segnb_conv_geom;
+
+/* Implicit-GEMM forward on MFMA.  wpacked: [Co][ntaps*Ci] of `dtype` (segnb_pack_weight).
+ * bias: fp32 [bias_n] (the real, unpadded parameter; channels >= bias_n get 0) or NULL.  stats: fp64 [2][Co] (sum, sum of squares of the STORED outputs over all
+ * written pixels, accumulated atomically; caller zeroes) or NULL -- the BatchNorm batch statistics
+ * of nn.BatchNorm2d in training mode (zf_unet.py:9,15) fused into the conv epilogue. */
+int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                     const float* bias, int bias_n, void* out, double* stats, segnb_stream_t stream);
+
+/* Weight gradient (aten::convolution_backward weight part), same geometry as the fprop launch:
+ *   dwp[co][t][ci] += sum_{n,q} dout[n, oh(q), ow(q), co] * in[n, ih(q,t), iw(q,t), ci]
+ * dwp: fp32 [Co][ntaps*Ci], accumulated with fp32 atomics (split over pixel ranges); caller zeroes. */
+int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
+                     float* dwp, segnb_stream_t stream);
+
+/* Parameter-layout <-> packed-GEMM-layout.  Packed matrix is [Mp][ntaps][Cp]; element (mp,t,cp)
+ * maps to w[mmap[mp]*s_m + cmap[cp]*s_c + tap_off[t]] (maps are device int32 arrays, -1 = padding).
+ * tap_off is a HOST array of ntaps element offsets (kh*s_kh + kw*s_kw).
+ * segnb_unpack_wgrad CONSUMES dwp: it is zeroed as it is read, ready for the next step's atomics. */
+int segnb_pack_weight(const float* w, void* wpacked, int dtype, int Mp, int Cp, int ntaps,
+                      long long s_m, long long s_c, const int* tap_off_host, const int* mmap,
+                      const int* cmap, segnb_stream_t stream);
+int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long long s_m,
+                       long long s_c, const int* tap_off_host, const int* mmap, const int* cmap,
+                       int accumulate, segnb_stream_t stream);
+
+/* NCHW fp32 network input -> NHWC `dtype`, channels zero-padded to Cp (torch_train.py:177 hands the
+ * model a float32 [N,3,H,W] batch, lib/common.py:70). */
+int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out, int dtype, int Cp,
+                          int ld_out, segnb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm (+activation, +Dropout2d, +MaxPool2d(2), +nearest x2 upsample) -- the same 4-phase split
+ * as inplace_abn's mean_var / forward / edz_eydz / backward (lib/modules/abn/functions.py:81,94,112,118).
+ * ------------------------------------------------------------------------------------------- */
+
+/* stats [2][Cp] (from segnb_conv_fprop) -> per-channel affine + running-stat update.
+ * coef: fp32 [4][Cp] = scale(=gamma*invstd), beta, mean, invstd; z = (y - mean)*scale + beta.  Channels
+ * >= C get all-zero rows.  training != 0: batch stats, running_mean/var updated with `momentum`
+ * (unbiased var, nn.BatchNorm2d semantics), *nbt += 1, and `stats` is CONSUMED (re-zeroed for the next
+ * step).  training == 0: running stats (eval). */
+int segnb_bn_finalize(double* stats, int C, int Cp, double count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean,
+                      float* running_var, long long* nbt, int training, float* coef,
+                      segnb_stream_t stream);
+
+/* a = dropmul[n][c] * act((y - mean)*scale + beta).  coef may be NULL (identity affine).  dropmul: fp32
+ * [N][Cp] multiplier table (Dropout2d replay format; NULL = none).  Optional extra outputs:
+ * pool_out = MaxPool2d(2) of a (floor mode), up_out = nearest x2 upsample of a (each with its own ld).
+ * Replaces BatchNorm2d+ReLU (zf_unet.py:15-16), Dropout2d (:31), MaxPool2d (:41), Upsample (:42). */
+int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                     const float* coef, int act, float slope, const float* dropmul, void* out,
+                     int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
+                     segnb_stream_t stream);
+
+/* dz = act'(z) * dropmul * (g_direct + maxpool_bwd(g_pool) + upsample_bwd(g_up)); any source may be
+ * NULL.  Writes dz; accumulates sums[0][c] += sum dz, sums[1][c] += sum dz*yhat (fp64 [2][Cp]). */
+int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                            const float* coef, int act, float slope, const float* dropmul,
+                            const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
+                            const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
+                            segnb_stream_t stream);
+
+/* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
+ * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */
+int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,
+                          const float* coef, float* bcoef, float* dgamma, float* dbeta,
+                          int accumulate, segnb_stream_t stream);
+
+/* dy = bcoef0 * (dz - bcoef1 - yhat*bcoef2) written to dy (may alias dz);
+ * dbias[c] += sum dy (fp32 atomics; NULL to skip). */
+int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                       const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
+                       int ld_dy, float* dbias, int C, segnb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1x1 classifier head with a handful of classes (zf_unet.py:58,93; tiramisu.py:162; unet16.py:111):
+ * fp32 NCHW logits out, fp32 NCHW dlogits in.
+ * ------------------------------------------------------------------------------------------- */
+int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, const float* w,
+                   const float* bias, int K, float* logits, segnb_stream_t stream);
+/* da = dlogits . w ; dw (+)= dlogits^T . a ; db (+)= sum dlogits   (dw/db fp32 atomics; caller zeroes
+ * unless accumulating) */
+int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
+                   const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
+                   float* db, segnb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-pixel binary losses and metrics (lib/losses.py:7-101, lib/metrics.py:9-43).
+ *   loss = (w_bce*bce2 + w_focal*focal + w_jaccard*jaccard + w_sjaccard*smooth_jaccard + w_dice*dice)/norm
+ * bce2 is the reference's double-sigmoid BCE (losses.py:51-53).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float w_bce, w_focal, w_jaccard, w_sjaccard, w_dice;
+    float smooth;      /* SmoothJaccardLoss smooth (100) */
+    float eps;         /* 1e-7 of JaccardLoss / DiceLoss */
+    float norm;        /* divisor of the weighted sum */
+    int focal_mean;    /* FocalLossBinary size_average */
+} segnb_loss_spec;
+
+/* sums fp64 [8]: sum bce2, sum focal, sum p*t, sum p, sum t, #correct@0.5, #pixels, (unused);
+ * accumulated atomically, caller zeroes.  A data-parallel job all-reduces these 8 doubles. */
+int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, double* sums,
+                          segnb_stream_t stream);
+/* out fp32 [8]: loss, soft IoU (metrics.py:14-20), pixel accuracy, GI, GU, bce mean, -, - */
+int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, float* out,
+                            segnb_stream_t stream);
+/* dlogits = (*grad_out) * dloss/dlogits  (grad_out: device fp32 scalar, the (B*loss).backward() seed
+ * of torch_train.py:187-188) */
+int segnb_seg_loss_bwd(const float* logits, const long long* target, long long n,
+                       const double* sums, const float* fin, const segnb_loss_spec* spec,
+                       const float* grad_out, float* dlogits, segnb_stream_t stream);
+
+/* plain SGD p -= lr * g over a flat buffer (torch.optim.SGD of torch_train.py:71) */
+int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

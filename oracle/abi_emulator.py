@@ -1,0 +1,367 @@
+"""CPU emulator of the C ABI in include/segnb_hip.h.  TEST INFRASTRUCTURE ONLY.
+
+Each method restates, with torch-CPU ops on raw host memory, what the same-named entry point of
+libsegnb_hip.so is specified to compute.  Uses:
+  * tests/test_plan_cpu.py injects it (segnb._native.set_backend_for_testing) to run the product's HOST
+    logic -- tap tables, channel maps, concat wiring, backward routing, flat params -- on CPU against
+    the oracle (no GPU needed);
+  * tests/test_hip_ops.py (-m gpu) compares every HIP kernel with the matching method on random inputs.
+The product never imports this file and has no CPU path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _tdt(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _mem(ptr, numel, dtype):
+    """torch view of `numel` elements of raw host memory at address `ptr`."""
+    if isinstance(ptr, ctypes.c_void_p):
+        ptr = ptr.value
+    nbytes = numel * torch.empty((), dtype=dtype).element_size()
+    buf = (ctypes.c_char * nbytes).from_address(int(ptr))
+    return torch.frombuffer(buf, dtype=dtype)
+
+
+def _nhwc(ptr, N, H, W, C, ld, dtype):
+    """[N,H,W,C] strided view (pixel stride ld) of raw memory."""
+    npix = N * H * W
+    flat = _mem(ptr, (npix - 1) * ld + C, dtype)
+    return torch.as_strided(flat, (N, H, W, C), (H * W * ld, W * ld, ld, 1))
+
+
+def _geom(g):
+    if hasattr(g, 'contents'):
+        g = g.contents
+    return g
+
+
+def _ints(p, n):
+    if p is None:
+        return None
+    if isinstance(p, (list, tuple)):
+        return list(p)
+    return [int(p[i]) for i in range(n)]
+
+
+def _gather(X, g, t):
+    """[N,QH,QW,Ci] fp32: input pixels (qh*in_step+dh[t], qw*in_step+dw[t]), zero outside."""
+    N, Hi, Wi, Ci = X.shape
+    hi = torch.arange(g.QH) * g.in_step + g.dh[t]
+    wi = torch.arange(g.QW) * g.in_step + g.dw[t]
+    mh = (hi >= 0) & (hi < Hi)
+    mw = (wi >= 0) & (wi < Wi)
+    sub = X[:, hi.clamp(0, Hi - 1)][:, :, wi.clamp(0, Wi - 1)].float()
+    mask = (mh[:, None] & mw[None, :]).to(sub.dtype)
+    return sub * mask[None, :, :, None]
+
+
+class AbiEmulator(object):
+    # ------------------------------------------------------------------------------------------ conv
+    def segnb_conv_fprop(self, g, dtype, in_p, wp, bias, bias_n, out_p, stats, stream):
+        g = _geom(g)
+        dt = _tdt(dtype)
+        X = _nhwc(in_p, g.N, g.Hi, g.Wi, g.Ci, g.ld_in, dt)
+        O = _nhwc(out_p, g.N, g.Ho, g.Wo, g.Co, g.ld_out, dt)
+        Wm = _mem(wp, g.Co * g.ntaps * g.Ci, dt).view(g.Co, g.ntaps, g.Ci).float()
+        acc = torch.zeros(g.N, g.QH, g.QW, g.Co)
+        for t in range(g.ntaps):
+            acc += _gather(X, g, t) @ Wm[:, t, :].t()
+        if bias is not None and bias_n > 0:
+            b = torch.zeros(g.Co)
+            b[:bias_n] = _mem(bias, bias_n, torch.float32)
+            acc += b
+        stored = acc.to(dt)
+        oh = torch.arange(g.QH) * g.out_step + g.oh0
+        ow = torch.arange(g.QW) * g.out_step + g.ow0
+        O[:, oh[:, None], ow[None, :], :] = stored
+        if stats is not None:
+            S = _mem(stats, 2 * g.Co, torch.float64).view(2, g.Co)
+            v = stored.double().reshape(-1, g.Co)
+            S[0] += v.sum(0)
+            S[1] += (v * v).sum(0)
+        return 0
+
+    def segnb_conv_wgrad(self, g, dtype, in_p, dout_p, dwp, stream):
+        g = _geom(g)
+        dt = _tdt(dtype)
+        X = _nhwc(in_p, g.N, g.Hi, g.Wi, g.Ci, g.ld_in, dt)
+        D = _nhwc(dout_p, g.N, g.Ho, g.Wo, g.Co, g.ld_out, dt)
+        oh = torch.arange(g.QH) * g.out_step + g.oh0
+        ow = torch.arange(g.QW) * g.out_step + g.ow0
+        d = D[:, oh[:, None], ow[None, :], :].float().reshape(-1, g.Co)
+        G = _mem(dwp, g.Co * g.ntaps * g.Ci, torch.float32).view(g.Co, g.ntaps, g.Ci)
+        for t in range(g.ntaps):
+            G[:, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
+        return 0
+
+    def _maps(self, Mp, Cp, ntaps, tap_off, mmap, cmap):
+        mm = _mem(mmap, Mp, torch.int32).long()
+        cm = _mem(cmap, Cp, torch.int32).long()
+        to = torch.tensor(_ints(tap_off, ntaps), dtype=torch.long)
+        return mm, cm, to
+
+    def segnb_pack_weight(self, w, wp, dtype, Mp, Cp, ntaps, s_m, s_c, tap_off, mmap, cmap, stream):
+        mm, cm, to = self._maps(Mp, Cp, ntaps, tap_off, mmap, cmap)
+        idx = mm.clamp(min=0)[:, None, None] * s_m + to[None, :, None] + cm.clamp(min=0)[None, None, :] * s_c
+        valid = (mm >= 0)[:, None, None] & (cm >= 0)[None, None, :]
+        valid = valid.expand(Mp, ntaps, Cp)
+        n = int(idx[valid].max()) + 1 if valid.any() else 1
+        src = _mem(w, n, torch.float32)
+        vals = torch.where(valid, src[idx.clamp(max=n - 1)], torch.zeros(()))
+        _mem(wp, Mp * ntaps * Cp, _tdt(dtype)).view(Mp, ntaps, Cp).copy_(vals.to(_tdt(dtype)))
+        return 0
+
+    def segnb_unpack_wgrad(self, dwp, gw, Mp, Cp, ntaps, s_m, s_c, tap_off, mmap, cmap, accumulate, stream):
+        mm, cm, to = self._maps(Mp, Cp, ntaps, tap_off, mmap, cmap)
+        idx = mm.clamp(min=0)[:, None, None] * s_m + to[None, :, None] + cm.clamp(min=0)[None, None, :] * s_c
+        valid = ((mm >= 0)[:, None, None] & (cm >= 0)[None, None, :]).expand(Mp, ntaps, Cp)
+        src = _mem(dwp, Mp * ntaps * Cp, torch.float32).view(Mp, ntaps, Cp)
+        n = int(idx[valid].max()) + 1
+        dst = _mem(gw, n, torch.float32)
+        if accumulate:
+            dst.index_add_(0, idx[valid], src[valid])
+        else:
+            dst[idx[valid]] = src[valid]
+        src.zero_()
+        return 0
+
+    def segnb_pack_input_nchw(self, x, N, C, H, W, out, dtype, Cp, ld_out, stream):
+        X = _mem(x, N * C * H * W, torch.float32).view(N, C, H, W)
+        O = _nhwc(out, N, H, W, Cp, ld_out, _tdt(dtype))
+        O.zero_()
+        O[..., :C] = X.permute(0, 2, 3, 1).to(_tdt(dtype))
+        return 0
+
+    # ------------------------------------------------------------------------------------------ BN
+    def segnb_bn_finalize(self, stats, C, Cp, count, gamma, beta, eps, momentum, rm, rv, nbt, training, coef, stream):
+        co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+        co.zero_()
+        if training:
+            S = _mem(stats, 2 * Cp, torch.float64).view(2, Cp)
+            mu = S[0, :C] / count
+            var = (S[1, :C] / count - mu * mu).clamp(min=0)
+            if rm is not None:
+                RM, RV = _mem(rm, C, torch.float32), _mem(rv, C, torch.float32)
+                unb = var * count / (count - 1.0) if count > 1 else var
+                RM.copy_(((1 - momentum) * RM.double() + momentum * mu).float())
+                RV.copy_(((1 - momentum) * RV.double() + momentum * unb).float())
+            if nbt is not None:
+                _mem(nbt, 1, torch.int64).add_(1)
+            S.zero_()
+        else:
+            mu = _mem(rm, C, torch.float32).double()
+            var = _mem(rv, C, torch.float32).double()
+        invstd = (1.0 / torch.sqrt(var + eps)).float()
+        mean = mu.float()
+        g = _mem(gamma, C, torch.float32) if gamma is not None else torch.ones(C)
+        b = _mem(beta, C, torch.float32) if beta is not None else torch.zeros(C)
+        scale = g * invstd
+        co[0, :C], co[1, :C], co[2, :C], co[3, :C] = scale, b, mean, invstd
+        return 0
+
+    @staticmethod
+    def _act(z, act, slope):
+        if act == ACT_RELU:
+            return torch.relu(z)
+        if act == ACT_LEAKY:
+            return torch.where(z > 0, z, z * slope)
+        return z
+
+    @staticmethod
+    def _actgrad(z, act, slope):
+        if act == ACT_RELU:
+            return (z > 0).float()
+        if act == ACT_LEAKY:
+            return torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
+        return torch.ones_like(z)
+
+    def _activated(self, Y, Cp, coef, act, slope, dropmul, N, dt):
+        z = Y.float()
+        if coef is not None:
+            co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+            z = (z - co[2]) * co[0] + co[1]
+        a = self._act(z, act, slope)
+        dm = None
+        if dropmul is not None:
+            dm = _mem(dropmul, N * Cp, torch.float32).view(N, 1, 1, Cp)
+            a = a * dm
+        return z, a.to(dt), dm
+
+    def segnb_bn_act_fwd(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, pool_out,
+                         ld_pool, up_out, ld_up, stream):
+        dt = _tdt(dtype)
+        Y = _nhwc(y, N, H, W, Cp, ld_y, dt)
+        _, a, _ = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt)
+        if out is not None:
+            _nhwc(out, N, H, W, Cp, ld_out, dt).copy_(a)
+        if pool_out is not None:
+            Hp, Wp = H // 2, W // 2
+            p = a[:, :2 * Hp, :2 * Wp].float().reshape(N, Hp, 2, Wp, 2, Cp).amax(dim=(2, 4))
+            _nhwc(pool_out, N, Hp, Wp, Cp, ld_pool, dt).copy_(p.to(dt))
+        if up_out is not None:
+            U = _nhwc(up_out, N, 2 * H, 2 * W, Cp, ld_up, dt)
+            U.copy_(a.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2))
+        return 0
+
+    def segnb_bn_act_bwd_reduce(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd,
+                                g_pool, ld_gp, g_up, ld_gu, dz, ld_dz, sums, stream):
+        dt = _tdt(dtype)
+        Y = _nhwc(y, N, H, W, Cp, ld_y, dt)
+        z, a, dm = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt)
+        g = torch.zeros(N, H, W, Cp)
+        if g_direct is not None:
+            g += _nhwc(g_direct, N, H, W, Cp, ld_gd, dt).float()
+        if g_pool is not None:
+            Hp, Wp = H // 2, W // 2
+            GP = _nhwc(g_pool, N, Hp, Wp, Cp, ld_gp, dt).float()
+            win = a[:, :2 * Hp, :2 * Wp].float().reshape(N, Hp, 2, Wp, 2, Cp).permute(0, 1, 3, 5, 2, 4)
+            win = win.reshape(N, Hp, Wp, Cp, 4)
+            am = win.argmax(dim=-1)          # torch argmax returns the FIRST maximal index
+            onehot = torch.nn.functional.one_hot(am, 4).float() * GP[..., None]
+            onehot = onehot.reshape(N, Hp, Wp, Cp, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * Hp, 2 * Wp, Cp)
+            g[:, :2 * Hp, :2 * Wp] += onehot
+        if g_up is not None:
+            GU = _nhwc(g_up, N, 2 * H, 2 * W, Cp, ld_gu, dt).float()
+            # the kernel adds the four taps in this order
+            g = g + GU[:, 0::2, 0::2]
+            g = g + GU[:, 0::2, 1::2]
+            g = g + GU[:, 1::2, 0::2]
+            g = g + GU[:, 1::2, 1::2]
+        d = g * self._actgrad(z, act, slope)
+        if dm is not None:
+            d = g * dm * self._actgrad(z, act, slope)
+        d = d.to(dt)
+        _nhwc(dz, N, H, W, Cp, ld_dz, dt).copy_(d)
+        if sums is not None:
+            S = _mem(sums, 2 * Cp, torch.float64).view(2, Cp)
+            dd = d.double().reshape(-1, Cp)
+            S[0] += dd.sum(0)
+            if coef is not None:
+                co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+                yh = ((Y.float() - co[2]) * co[3]).double().reshape(-1, Cp)
+                S[1] += (dd * yh).sum(0)
+        return 0
+
+    def segnb_bn_bwd_finalize(self, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream):
+        S = _mem(sums, 2 * Cp, torch.float64).view(2, Cp)
+        co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+        bc = _mem(bcoef, 3 * Cp, torch.float32).view(3, Cp)
+        bc.zero_()
+        g = _mem(gamma, C, torch.float32) if gamma is not None else torch.ones(C)
+        bc[0, :C] = g * co[3, :C]
+        bc[1, :C] = (S[0, :C] / count).float()
+        bc[2, :C] = (S[1, :C] / count).float()
+        if dgamma is not None:
+            G = _mem(dgamma, C, torch.float32)
+            G.copy_((G if accumulate else 0) + S[1, :C].float())
+        if dbeta is not None:
+            B = _mem(dbeta, C, torch.float32)
+            B.copy_((B if accumulate else 0) + S[0, :C].float())
+        S.zero_()
+        return 0
+
+    def segnb_bn_bwd_apply(self, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, stream):
+        dt = _tdt(dtype)
+        Y = _nhwc(y, N, H, W, Cp, ld_y, dt).float()
+        D = _nhwc(dz, N, H, W, Cp, ld_dz, dt).float()
+        co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+        bc = _mem(bcoef, 3 * Cp, torch.float32).view(3, Cp)
+        yh = (Y - co[2]) * co[3]
+        out = (bc[0] * (D - bc[1] - yh * bc[2])).to(dt)
+        _nhwc(dy, N, H, W, Cp, ld_dy, dt).copy_(out)
+        if dbias is not None:
+            _mem(dbias, C, torch.float32).add_(out.float().reshape(-1, Cp).sum(0)[:C])
+        return 0
+
+    # ------------------------------------------------------------------------------------------ head
+    def segnb_head_fwd(self, dtype, a, ld_a, N, H, W, C, w, bias, K, logits, stream):
+        A = _nhwc(a, N, H, W, C, ld_a, _tdt(dtype)).float()
+        Wm = _mem(w, K * C, torch.float32).view(K, C)
+        out = A @ Wm.t()
+        if bias is not None:
+            out = out + _mem(bias, K, torch.float32)
+        _mem(logits, N * K * H * W, torch.float32).view(N, K, H, W).copy_(out.permute(0, 3, 1, 2))
+        return 0
+
+    def segnb_head_bwd(self, dtype, a, ld_a, N, H, W, C, Cp, w, K, dlogits, da, ld_da, dw, db, stream):
+        dt = _tdt(dtype)
+        A = _nhwc(a, N, H, W, C, ld_a, dt).float()
+        Wm = _mem(w, K * C, torch.float32).view(K, C)
+        DL = _mem(dlogits, N * K * H * W, torch.float32).view(N, K, H, W).permute(0, 2, 3, 1)
+        if da is not None:
+            DA = _nhwc(da, N, H, W, Cp, ld_da, dt)
+            DA.zero_()
+            DA[..., :C] = (DL @ Wm).to(dt)
+        if dw is not None:
+            _mem(dw, K * C, torch.float32).view(K, C).add_(DL.reshape(-1, K).t() @ A.reshape(-1, C))
+        if db is not None:
+            _mem(db, K, torch.float32).add_(DL.reshape(-1, K).sum(0))
+        return 0
+
+    # ------------------------------------------------------------------------------------------ loss
+    @staticmethod
+    def _terms(x, t):
+        ls = torch.nn.functional.logsigmoid(x)
+        p = torch.exp(ls)
+        e = -t * ls + torch.log1p(p)
+        de = (1 - p) * (p / (1 + p) - t)
+        pt = torch.exp(-e)
+        om = 1 - pt
+        f = om * om * e
+        df = (2 * om * pt * e + om * om) * de
+        return p, e, de, f, df
+
+    def segnb_seg_loss_reduce(self, logits, target, n, sums, stream):
+        x = _mem(logits, n, torch.float32)
+        t = _mem(target, n, torch.int64).float()
+        p, e, _, f, _ = self._terms(x, t)
+        S = _mem(sums, 8, torch.float64)
+        S[0] += e.double().sum()
+        S[1] += f.double().sum()
+        S[2] += (p * t).double().sum()
+        S[3] += p.double().sum()
+        S[4] += t.double().sum()
+        S[5] += ((p > 0.5) == (t != 0)).double().sum()
+        S[6] += float(n)
+        return 0
+
+    def segnb_seg_loss_finalize(self, sums, spec, out, stream):
+        sp = _geom(spec)
+        S = _mem(sums, 8, torch.float64).tolist()
+        n, I, U = S[6], S[2], S[3] + S[4]
+        bce = S[0] / n
+        focal = S[1] / n if sp.focal_mean else S[1]
+        eps, sm = float(sp.eps), float(sp.smooth)
+        Dj, Ds, Dd = U - I + eps, U - I + sm, U + eps
+        loss = (sp.w_bce * bce + sp.w_focal * focal + sp.w_jaccard * (1 - I / Dj) +
+                sp.w_sjaccard * (1 - (I + sm) / Ds) + sp.w_dice * (1 - 2 * I / Dd)) / sp.norm
+        GI = sp.w_jaccard * (-(U + eps) / Dj ** 2) + sp.w_sjaccard * (-(U + 2 * sm) / Ds ** 2) + sp.w_dice * (-2 / Dd)
+        GU = sp.w_jaccard * (I / Dj ** 2) + sp.w_sjaccard * ((I + sm) / Ds ** 2) + sp.w_dice * (2 * I / Dd ** 2)
+        _mem(out, 8, torch.float32).copy_(torch.tensor([loss, I / (U - I + 1e-7), S[5] / n, GI, GU, bce, n, 0.0]))
+        return 0
+
+    def segnb_seg_loss_bwd(self, logits, target, n, sums, fin, spec, grad_out, dlogits, stream):
+        sp = _geom(spec)
+        x = _mem(logits, n, torch.float32)
+        t = _mem(target, n, torch.int64).float()
+        F = _mem(fin, 8, torch.float32)
+        go = (float(_mem(grad_out, 1, torch.float32)[0]) if grad_out is not None else 1.0) / sp.norm
+        p, _, de, _, df = self._terms(x, t)
+        inv_n = 1.0 / float(F[6])
+        wf = sp.w_focal * inv_n if sp.focal_mean else sp.w_focal
+        dx = go * (sp.w_bce * inv_n * de + wf * df + p * (1 - p) * (t * float(F[3]) + float(F[4])))
+        _mem(dlogits, n, torch.float32).copy_(dx)
+        return 0
+
+    def segnb_sgd_step(self, p, g, n, lr, stream):
+        _mem(p, n, torch.float32).sub_(lr * _mem(g, n, torch.float32))
+        return 0

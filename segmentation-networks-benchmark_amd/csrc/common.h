@@ -1,0 +1,117 @@
+// Shared device/host helpers for libsegnb_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/segnb_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct bf16_t {
+    unsigned short bits;
+};
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing (never throw across the ABI)
+// ------------------------------------------------------------------------------------------------
+void segnb_set_error(const char* fmt, ...);
+
+#define SEGNB_CHECK_ARG(cond, msg)                                   \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            segnb_set_error("%s: bad argument: %s", __func__, msg);  \
+            return SEGNB_E_BADARG;                                   \
+        }                                                            \
+    } while (0)
+
+#define SEGNB_LAUNCH_CHECK()                                                                  \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) {                                                              \
+            segnb_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__));       \
+            return (int)e__;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+int segnb_num_cus();
+
+// ------------------------------------------------------------------------------------------------
+// element helpers: 8 channels per thread ("chunk8"), fp32 math
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float to_f32(bf16_t v) { return bf16_bits_to_f32(v.bits); }
+    __device__ static __forceinline__ bf16_t from_f32(float v) {
+        bf16_t r;
+        r.bits = f32_to_bf16_bits(v);
+        return r;
+    }
+    __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+
+// load / store 8 consecutive channels as fp32
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 u;
+    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+    u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+// value as it will read back from a T-typed store
+__device__ __forceinline__ float round_as(float v, const float*) { return v; }
+__device__ __forceinline__ float round_as(float v, const bf16_t*) {
+    return bf16_bits_to_f32(f32_to_bf16_bits(v));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

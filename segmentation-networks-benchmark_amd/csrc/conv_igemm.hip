@@ -1,0 +1,774 @@
+// Implicit-GEMM gather-convolution on MFMA for gfx950: forward / data-gradient (conv_fprop) and
+// weight-gradient (conv_wgrad), NHWC activations, no im2col buffer.
+//
+// Replaces aten::convolution / aten::convolution_backward as reached from nn.Conv2d /
+// nn.ConvTranspose2d in lib/models/zf_unet.py:8, linknet.py:12-21,41, tiramisu.py:14,65,
+// unet16.py:17,38 (cuDNN / oneDNN in the reference).
+//
+// GEMM view (fprop):  M = N*QH*QW pixels, N = Co, K = ntaps*Ci.
+//   A[m][k]  gathered on the fly: k -> (tap, ci), row m -> (n, qh, qw) -> input pixel, zero outside
+//   B[co][k] packed weights, K contiguous
+// Block = 256 threads = 4 waves; tile BM x BN; K step = 128 bytes of K per row (64 bf16 / 32 f32),
+// register-staged double-buffered LDS, rows padded to 144 B (conflict-free ds_read_b128).
+// Wave tile WM x WN out of v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (exact fp32).
+// Epilogue: +bias, round to T, per-channel sum / sum^2 of the stored values (BatchNorm batch
+// statistics), staged through LDS so global stores are 16-byte, pixel-contiguous.
+#include "common.h"
+
+namespace {
+
+constexpr int LDS_ROW = 144;  // 128 B of K + 16 B pad
+constexpr int NT = 256;       // threads per block
+
+struct FpropArgs {
+    segnb_conv_geom g;
+    const void* in;
+    const void* w;
+    const float* bias;
+    int bias_n;
+    void* out;
+    double* stats;
+    int M, Ktot, ksteps, MT, NTL, GM;
+};
+
+struct WgradArgs {
+    segnb_conv_geom g;
+    const void* in;
+    const void* dout;
+    float* dwp;
+    int M, Ktot, MT, NTL, S, steps_per_split, total_steps;
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+    // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD a contiguous range of
+    // logical tiles so neighbours (same pixels, different channel tile) hit one L2.  Bijective for any G.
+    const int q = G >> 3, r = G & 7, x = b & 7, j = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// acc[TM][TN] += A_tile(rows am0.., K step) * B_tile(rows bn0..)^T ; tiles are [rows][LDS_ROW] images
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_step(const unsigned char* __restrict__ sA,
+                                         const unsigned char* __restrict__ sB, int r, int h,
+                                         f32x16_t (&acc)[TM][TN]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + (32 * i + r) * LDS_ROW + kk * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + (32 * j + r) * LDS_ROW + kk * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        // fp32: lane (r,h) feeds k = 16h + 4q + e at sub-step (q,e) -- any K permutation is a valid
+        // contraction order as long as A and B agree; this one keeps the LDS reads 16-byte.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(sA + (32 * i + r) * LDS_ROW + h * 64 + q * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const float4*>(sB + (32 * j + r) * LDS_ROW + h * 64 + q * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+}
+
+template <int BM, int BN, typename T>
+constexpr int fprop_smem_bytes() {
+    return 2 * (BM + BN) * LDS_ROW + BM * 16 + 2 * BN * 4 + SEGNB_MAX_TAPS * 8;
+}
+
+// ================================================================================================
+// forward / data-gradient
+// ================================================================================================
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TILE_BYTES = (BM + BN) * LDS_ROW;
+    constexpr int OUT_ROW = BN * (int)sizeof(T) + 16;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
+    static_assert(BM * OUT_ROW <= 2 * TILE_BYTES, "staging fits");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sTiles = smem;
+    int4* sRow = reinterpret_cast<int4*>(smem + 2 * TILE_BYTES);
+    float* sStat = reinterpret_cast<float*>(sRow + BM);
+    int2* sTap = reinterpret_cast<int2*>(sStat + 2 * BN);
+
+    const segnb_conv_geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+    const int c = tid & 7, row0 = tid >> 3;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = L % a.NTL;
+    const int gq = L / a.NTL;
+    const int n_base = nt * BN;
+
+    const T* __restrict__ inT = reinterpret_cast<const T*>(a.in);
+    const T* __restrict__ wT = reinterpret_cast<const T*>(a.w);
+    T* __restrict__ outT = reinterpret_cast<T*>(a.out);
+
+    if (tid < g.ntaps) sTap[tid] = make_int2(g.dh[tid], g.dw[tid]);
+
+    const int QHW = g.QH * g.QW;
+    double st = 0.0;
+
+    for (int mt = gq; mt < a.MT; mt += a.GM) {
+        const int m_base = mt * BM;
+        __syncthreads();  // previous tile's staging / row table fully consumed
+        for (int rr = tid; rr < BM; rr += NT) {
+            const int m = m_base + rr;
+            int4 ri;
+            if (m < a.M) {
+                const int n = m / QHW;
+                const int rem = m - n * QHW;
+                const int qh = rem / g.QW;
+                const int qw = rem - qh * g.QW;
+                ri.x = n * (g.Hi * g.Wi);
+                ri.y = qh * g.in_step;
+                ri.z = qw * g.in_step;
+                ri.w = (n * g.Ho + qh * g.out_step + g.oh0) * g.Wo + qw * g.out_step + g.ow0;
+            } else {
+                ri.x = 0;
+                ri.y = -(1 << 28);
+                ri.z = -(1 << 28);
+                ri.w = -1;
+            }
+            sRow[rr] = ri;
+        }
+        if (tid < 2 * BN) sStat[tid] = 0.f;
+        __syncthreads();
+
+        int rn[AI], rh[AI], rw[AI];
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int4 ri = sRow[row0 + 32 * i];
+            rn[i] = ri.x;
+            rh[i] = ri.y;
+            rw[i] = ri.z;
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        uint4 ra[AI], rb[BI];
+        auto gload = [&](int s) {
+            const int k0 = s * BK + c * EPC;
+            const bool kok = k0 < a.Ktot;
+            const int tap = kok ? k0 / g.Ci : 0;
+            const int ci = k0 - tap * g.Ci;
+            const int2 t = sTap[tap];
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int hi = rh[i] + t.x, wi = rw[i] + t.y;
+                const bool ok = kok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    const long long off = (long long)(rn[i] + hi * g.Wi + wi) * g.ld_in + ci;
+                    v = *reinterpret_cast<const uint4*>(inT + off);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < BI; ++j) {
+                const int co = n_base + row0 + 32 * j;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kok && co < g.Co) v = *reinterpret_cast<const uint4*>(wT + (long long)co * a.Ktot + k0);
+                rb[j] = v;
+            }
+        };
+        auto lstore = [&](int buf) {
+            unsigned char* base = sTiles + buf * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                *reinterpret_cast<uint4*>(base + (row0 + 32 * i) * LDS_ROW + c * 16) = ra[i];
+#pragma unroll
+            for (int j = 0; j < BI; ++j)
+                *reinterpret_cast<uint4*>(base + (BM + row0 + 32 * j) * LDS_ROW + c * 16) = rb[j];
+        };
+
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int s = 0; s < a.ksteps; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < a.ksteps) gload(s + 1);
+            const unsigned char* sA = sTiles + buf * TILE_BYTES + (wr * WM) * LDS_ROW;
+            const unsigned char* sB = sTiles + buf * TILE_BYTES + (BM + wc * WN) * LDS_ROW;
+            mma_step<T, TM, TN>(sA, sB, r, h, acc);
+            if (s + 1 < a.ksteps) lstore(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: bias, round, stats, stage to LDS ------------------------------------------
+        unsigned char* sOut = sTiles;
+        float cs1[TN], cs2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wc * WN + 32 * j + r;
+            const int co = n_base + col;
+            const float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = wr * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const T tv = Elem<T>::from_f32(acc[i][j][e] + bv);
+                    *reinterpret_cast<T*>(sOut + row * OUT_ROW + col * (int)sizeof(T)) = tv;
+                    if (m_base + row < a.M) {
+                        const float vr = Elem<T>::to_f32(tv);
+                        s1 += vr;
+                        s2 += vr * vr;
+                    }
+                }
+            }
+            cs1[j] = s1;
+            cs2[j] = s2;
+        }
+        if (a.stats != nullptr) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float t1 = cs1[j] + __shfl_xor(cs1[j], 32);
+                const float t2 = cs2[j] + __shfl_xor(cs2[j], 32);
+                if (h == 0) {
+                    const int col = wc * WN + 32 * j + r;
+                    atomicAdd(&sStat[col], t1);
+                    atomicAdd(&sStat[BN + col], t2);
+                }
+            }
+        }
+        __syncthreads();
+        if (a.stats != nullptr && tid < 2 * BN) st += (double)sStat[tid];
+        constexpr int OC = BN / EPC;
+        for (int q = tid; q < BM * OC; q += NT) {
+            const int row = q / OC, cc = q - row * OC;
+            const int opix = sRow[row].w;
+            const int co = n_base + cc * EPC;
+            if (opix >= 0 && co < g.Co)
+                *reinterpret_cast<uint4*>(outT + (long long)opix * g.ld_out + co) =
+                    *reinterpret_cast<const uint4*>(sOut + row * OUT_ROW + cc * 16);
+        }
+    }
+    if (a.stats != nullptr && tid < 2 * BN) {
+        const int which = tid / BN, col = tid - which * BN;
+        const int co = n_base + col;
+        if (co < g.Co) atomicAdd(&a.stats[(long long)which * g.Co + co], st);
+    }
+}
+
+// ================================================================================================
+// weight gradient:  dW[co][k'] += sum_pixels dy[pix][co] * im2col(x)[pix][k']
+// GEMM view: M = Co, N = K' = ntaps*Ci, reduction over pixels (split across blocks, fp32 atomics).
+// Both operands are pixel-major in HBM but MFMA wants the reduction index contiguous per lane, so
+// the loader transposes EPC x EPC (8x8 bf16 / 4x4 f32) blocks in registers on the way into LDS.
+// ================================================================================================
+__device__ __forceinline__ void transpose_block(const uint4 (&in)[8], uint4 (&out)[8], bf16_t*) {
+    const unsigned* d = reinterpret_cast<const unsigned*>(in);  // d[p*4 + w]
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned lo = d[(2 * j) * 4 + (c >> 1)];
+            const unsigned hi = d[(2 * j + 1) * 4 + (c >> 1)];
+            o[j] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        out[c] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+__device__ __forceinline__ void transpose_block(const uint4 (&in)[4], uint4 (&out)[4], float*) {
+    out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+    out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+    out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+    out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BKP = 8 * EPC;               // pixels per K step
+    constexpr int ITEMS_A = (BM / EPC) * 8;    // (chunk column, pixel group) blocks of the dy tile
+    constexpr int ITEMS_B = (BN / EPC) * 8;
+    constexpr int ITEMS = ITEMS_A + ITEMS_B;
+    constexpr int IPT = (ITEMS + NT - 1) / NT;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TILE_BYTES = (BM + BN) * LDS_ROW;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sTiles = smem;
+
+    const segnb_conv_geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+
+    const int ntiles = a.MT * a.NTL;
+    const int split = blockIdx.x / ntiles;
+    const int tile = blockIdx.x - split * ntiles;
+    const int mtile = tile / a.NTL, ntile = tile - mtile * a.NTL;
+    const int mb = mtile * BM;   // co base
+    const int nb = ntile * BN;   // k' base
+
+    const T* __restrict__ inT = reinterpret_cast<const T*>(a.in);
+    const T* __restrict__ doT = reinterpret_cast<const T*>(a.dout);
+
+    // per-item constants
+    int it_rowbase[IPT];   // LDS row of channel 0 of this item (A rows first, then B rows)
+    int it_o[IPT];         // pixel group within the K step
+    int it_ch[IPT];        // channel / ci element offset in the source tensor, or -1 = nothing to load
+    int it_dh[IPT], it_dw[IPT];
+    bool it_isA[IPT];
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+        const int it = tid + u * NT;
+        it_rowbase[u] = -1;
+        it_ch[u] = -1;
+        it_o[u] = 0;
+        it_dh[u] = it_dw[u] = 0;
+        it_isA[u] = true;
+        if (it < ITEMS) {
+            const bool isA = it < ITEMS_A;
+            const int idx = isA ? it : it - ITEMS_A;
+            const int o = idx & 7, cc = idx >> 3;
+            it_isA[u] = isA;
+            it_o[u] = o;
+            if (isA) {
+                it_rowbase[u] = cc * EPC;
+                const int co = mb + cc * EPC;
+                it_ch[u] = (co < g.Co) ? co : -1;
+            } else {
+                it_rowbase[u] = BM + cc * EPC;
+                const int kp = nb + cc * EPC;
+                if (kp < a.Ktot) {
+                    const int tap = kp / g.Ci;
+                    it_ch[u] = kp - tap * g.Ci;
+                    it_dh[u] = g.dh[tap];
+                    it_dw[u] = g.dw[tap];
+                }
+            }
+        }
+    }
+
+    const int QHW = g.QH * g.QW;
+    const int step_begin = split * a.steps_per_split;
+    int step_end = step_begin + a.steps_per_split;
+    if (step_end > a.total_steps) step_end = a.total_steps;
+    const int nsteps = step_end - step_begin;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 regs[IPT][EPC];
+    auto gload = [&](int s) {
+        const int pix0 = (step_begin + s) * BKP;
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            int m = pix0 + it_o[u] * EPC;
+            int n = m / QHW;
+            int rem = m - n * QHW;
+            int qh = rem / g.QW;
+            int qw = rem - qh * g.QW;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (it_ch[u] >= 0 && m < a.M) {
+                    if (it_isA[u]) {
+                        const long long pix = (long long)(n * g.Ho + qh * g.out_step + g.oh0) * g.Wo +
+                                              qw * g.out_step + g.ow0;
+                        v = *reinterpret_cast<const uint4*>(doT + pix * g.ld_out + it_ch[u]);
+                    } else {
+                        const int hi = qh * g.in_step + it_dh[u], wi = qw * g.in_step + it_dw[u];
+                        if ((unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi) {
+                            const long long pix = (long long)(n * g.Hi + hi) * g.Wi + wi;
+                            v = *reinterpret_cast<const uint4*>(inT + pix * g.ld_in + it_ch[u]);
+                        }
+                    }
+                }
+                regs[u][e] = v;
+                ++m;
+                if (++qw == g.QW) {
+                    qw = 0;
+                    if (++qh == g.QH) {
+                        qh = 0;
+                        ++n;
+                    }
+                }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = sTiles + buf * TILE_BYTES;
+#pragma unroll
+        for (int u = 0; u < IPT; ++u) {
+            if (it_rowbase[u] >= 0) {
+                uint4 t[EPC];
+                transpose_block(regs[u], t, (T*)nullptr);
+#pragma unroll
+                for (int cidx = 0; cidx < EPC; ++cidx)
+                    *reinterpret_cast<uint4*>(base + (it_rowbase[u] + cidx) * LDS_ROW + it_o[u] * 16) = t[cidx];
+            }
+        }
+    };
+
+    if (nsteps > 0) {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nsteps) gload(s + 1);
+            const unsigned char* sA = sTiles + buf * TILE_BYTES + (wr * WM) * LDS_ROW;
+            const unsigned char* sB = sTiles + buf * TILE_BYTES + (BM + wc * WN) * LDS_ROW;
+            mma_step<T, TM, TN>(sA, sB, r, h, acc);
+            if (s + 1 < nsteps) lstore(buf ^ 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int kp = nb + wc * WN + 32 * j + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = mb + wr * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (co < g.Co && kp < a.Ktot) atomicAdd(&a.dwp[(long long)co * a.Ktot + kp], acc[i][j][e]);
+                }
+            }
+    }
+}
+
+// ================================================================================================
+// weight pack / gradient unpack
+// ================================================================================================
+struct PackArgs {
+    int Mp, Cp, ntaps;
+    long long s_m, s_c;
+    const int* mmap;
+    const int* cmap;
+    int tap_off[SEGNB_MAX_TAPS];
+};
+
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wp, const PackArgs p) {
+    const long long total = (long long)p.Mp * p.ntaps * p.Cp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % p.Cp);
+        const long long q = i / p.Cp;
+        const int t = (int)(q % p.ntaps);
+        const int mp = (int)(q / p.ntaps);
+        const int m = p.mmap[mp], c = p.cmap[cp];
+        float v = 0.f;
+        if (m >= 0 && c >= 0) v = w[m * p.s_m + c * p.s_c + p.tap_off[t]];
+        wp[i] = Elem<T>::from_f32(v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ gw, const PackArgs p,
+                                    int accumulate) {
+    const long long total = (long long)p.Mp * p.ntaps * p.Cp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % p.Cp);
+        const long long q = i / p.Cp;
+        const int t = (int)(q % p.ntaps);
+        const int mp = (int)(q / p.ntaps);
+        const int m = p.mmap[mp], c = p.cmap[cp];
+        if (m >= 0 && c >= 0) {
+            float* dst = gw + m * p.s_m + c * p.s_c + p.tap_off[t];
+            *dst = accumulate ? (*dst + dwp[i]) : dwp[i];
+        }
+        dwp[i] = 0.f;   // workspace is consumed: ready for the next step's atomics without a memset
+    }
+}
+
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W,
+                                  int Cp, int ld) {
+    // one thread per (pixel, 8-channel chunk); reads are W-contiguous per channel plane
+    const long long npix = (long long)N * H * W;
+    const int CPP = Cp / 8;
+    const long long total = npix * CPP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / CPP;
+        const int cc = (int)(i - pix * CPP);
+        const long long n = pix / ((long long)H * W);
+        const long long hw = pix - n * (long long)H * W;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = cc * 8 + e;
+            v[e] = ch < C ? x[(n * C + ch) * (long long)H * W + hw] : 0.f;
+        }
+        store8(out + pix * ld + cc * 8, v);
+    }
+}
+
+template <typename K>
+int set_smem(K kernel, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        segnb_set_error("hipFuncSetAttribute(%d bytes): %s", bytes, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_fprop(FpropArgs& a, hipStream_t stream) {
+    constexpr int smem = fprop_smem_bytes<BM, BN, T>();
+    static int attr_rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
+    if (attr_rc) return attr_rc;
+    a.MT = ceil_div(a.M, BM);
+    a.NTL = ceil_div(a.g.Co, BN);
+    const int cus = segnb_num_cus();
+    int per_cu = (160 * 1024) / smem;
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    int gm = (cus * per_cu) / a.NTL;
+    if (gm < 1) gm = 1;
+    if (gm > a.MT) gm = a.MT;
+    a.GM = gm;
+    const int grid = a.GM * a.NTL;
+    hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), smem, stream, a);
+    return 0;
+}
+
+template <typename T>
+int dispatch_fprop(FpropArgs& a, hipStream_t stream) {
+    const int Co = a.g.Co;
+    const long long M = a.M;
+    const int cus = segnb_num_cus();
+    const long long want = (long long)cus * 3 / 2;
+    if (Co <= 32) return launch_fprop<T, 128, 32, 32, 32>(a, stream);
+    if (Co <= 64) {
+        if ((M + 127) / 128 >= want) return launch_fprop<T, 128, 64, 64, 32>(a, stream);
+        return launch_fprop<T, 64, 64, 32, 32>(a, stream);
+    }
+    const long long t128 = ((M + 127) / 128) * ((Co + 127) / 128);
+    if (t128 >= want) return launch_fprop<T, 128, 128, 64, 64>(a, stream);
+    const long long t64 = ((M + 127) / 128) * ((Co + 63) / 64);
+    if (t64 >= want) return launch_fprop<T, 128, 64, 64, 32>(a, stream);
+    return launch_fprop<T, 64, 64, 32, 32>(a, stream);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+    constexpr int smem = 2 * (BM + BN) * LDS_ROW;
+    static int attr_rc = set_smem(conv_wgrad_kernel<T, BM, BN, WM, WN>, smem);
+    if (attr_rc) return attr_rc;
+    constexpr int BKP = 8 * Elem<T>::EPC;
+    a.MT = ceil_div(a.g.Co, BM);
+    a.NTL = ceil_div(a.Ktot, BN);
+    a.total_steps = ceil_div(a.M, BKP);
+    const int tiles = a.MT * a.NTL;
+    const int cus = segnb_num_cus();
+    int S = (cus * 2 + tiles - 1) / tiles;
+    if (S < 1) S = 1;
+    // keep at least 4 K steps per split so the pipeline prologue amortises
+    const int maxS = a.total_steps / 4 > 0 ? a.total_steps / 4 : 1;
+    if (S > maxS) S = maxS;
+    a.steps_per_split = ceil_div(a.total_steps, S);
+    a.S = ceil_div(a.total_steps, a.steps_per_split);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BM, BN, WM, WN>), dim3(tiles * a.S), dim3(NT), smem, stream, a);
+    return 0;
+}
+
+template <typename T>
+int dispatch_wgrad(WgradArgs& a, hipStream_t stream) {
+    const int Co = a.g.Co;
+    if (Co <= 32) return launch_wgrad<T, 32, 128, 32, 32>(a, stream);
+    if (Co <= 64) return launch_wgrad<T, 64, 128, 32, 64>(a, stream);
+    return launch_wgrad<T, 128, 128, 64, 64>(a, stream);
+}
+
+int check_geom(const segnb_conv_geom* g) {
+    SEGNB_CHECK_ARG(g != nullptr, "geom is NULL");
+    SEGNB_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= SEGNB_MAX_TAPS, "ntaps out of range");
+    SEGNB_CHECK_ARG(g->Ci > 0 && g->Ci % 8 == 0 && g->Co > 0 && g->Co % 8 == 0, "Ci/Co must be multiples of 8");
+    SEGNB_CHECK_ARG(g->ld_in % 8 == 0 && g->ld_out % 8 == 0 && g->ld_in >= g->Ci && g->ld_out >= g->Co,
+                    "ld must be a multiple of 8 and >= channels");
+    SEGNB_CHECK_ARG(g->N > 0 && g->QH > 0 && g->QW > 0 && g->Hi > 0 && g->Wi > 0 && g->Ho > 0 && g->Wo > 0,
+                    "empty tensor");
+    SEGNB_CHECK_ARG(g->in_step >= 1 && g->out_step >= 1, "steps must be >= 1");
+    SEGNB_CHECK_ARG((g->QH - 1) * g->out_step + g->oh0 < g->Ho && (g->QW - 1) * g->out_step + g->ow0 < g->Wo &&
+                        g->oh0 >= 0 && g->ow0 >= 0,
+                    "output positions exceed the output tensor");
+    SEGNB_CHECK_ARG((long long)g->N * g->Hi * g->Wi < (1ll << 31) && (long long)g->N * g->Ho * g->Wo < (1ll << 31),
+                    "pixel count exceeds int32");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                                const float* bias, int bias_n, void* out, double* stats,
+                                segnb_stream_t stream) {
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && wpacked && out, "NULL tensor");
+    FpropArgs a;
+    a.g = *g;
+    a.in = in;
+    a.w = wpacked;
+    a.bias = bias;
+    a.bias_n = bias_n;
+    a.out = out;
+    a.stats = stats;
+    a.M = g->N * g->QH * g->QW;
+    a.Ktot = g->ntaps * g->Ci;
+    int rc;
+    if (dtype == SEGNB_BF16) {
+        a.ksteps = ceil_div(a.Ktot, 64);
+        rc = dispatch_fprop<bf16_t>(a, (hipStream_t)stream);
+    } else if (dtype == SEGNB_F32) {
+        a.ksteps = ceil_div(a.Ktot, 32);
+        rc = dispatch_fprop<float>(a, (hipStream_t)stream);
+    } else {
+        segnb_set_error("segnb_conv_fprop: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    if (rc) return rc;
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
+                                float* dwp, segnb_stream_t stream) {
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
+    WgradArgs a;
+    a.g = *g;
+    a.in = in;
+    a.dout = dout;
+    a.dwp = dwp;
+    a.M = g->N * g->QH * g->QW;
+    a.Ktot = g->ntaps * g->Ci;
+    int rc;
+    if (dtype == SEGNB_BF16)
+        rc = dispatch_wgrad<bf16_t>(a, (hipStream_t)stream);
+    else if (dtype == SEGNB_F32)
+        rc = dispatch_wgrad<float>(a, (hipStream_t)stream);
+    else {
+        segnb_set_error("segnb_conv_wgrad: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    if (rc) return rc;
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fill_pack_args(PackArgs& p, int Mp, int Cp, int ntaps, long long s_m, long long s_c,
+                          const int* tap_off_host, const int* mmap, const int* cmap) {
+    SEGNB_CHECK_ARG(Mp > 0 && Cp > 0 && ntaps >= 1 && ntaps <= SEGNB_MAX_TAPS, "bad packed shape");
+    SEGNB_CHECK_ARG(tap_off_host && mmap && cmap, "NULL map");
+    p.Mp = Mp;
+    p.Cp = Cp;
+    p.ntaps = ntaps;
+    p.s_m = s_m;
+    p.s_c = s_c;
+    p.mmap = mmap;
+    p.cmap = cmap;
+    for (int t = 0; t < ntaps; ++t) p.tap_off[t] = tap_off_host[t];
+    return 0;
+}
+
+extern "C" int segnb_pack_weight(const float* w, void* wpacked, int dtype, int Mp, int Cp, int ntaps,
+                                 long long s_m, long long s_c, const int* tap_off_host, const int* mmap,
+                                 const int* cmap, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(w && wpacked, "NULL tensor");
+    PackArgs p;
+    if (int rc = fill_pack_args(p, Mp, Cp, ntaps, s_m, s_c, tap_off_host, mmap, cmap)) return rc;
+    const long long total = (long long)Mp * ntaps * Cp;
+    int grid = ceil_div(total, 256);
+    if (grid > 4096) grid = 4096;
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                           (bf16_t*)wpacked, p);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)wpacked, p);
+    else {
+        segnb_set_error("segnb_pack_weight: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long long s_m,
+                                  long long s_c, const int* tap_off_host, const int* mmap, const int* cmap,
+                                  int accumulate, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(dwp && gw, "NULL tensor");
+    PackArgs p;
+    if (int rc = fill_pack_args(p, Mp, Cp, ntaps, s_m, s_c, tap_off_host, mmap, cmap)) return rc;
+    const long long total = (long long)Mp * ntaps * Cp;
+    int grid = ceil_div(total, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwp, gw, p, accumulate);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out, int dtype, int Cp,
+                                     int ld_out, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(x && out, "NULL tensor");
+    SEGNB_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C && ld_out >= Cp && ld_out % 8 == 0,
+                    "bad shape");
+    const long long total = (long long)N * H * W * (Cp / 8);
+    int grid = ceil_div(total, 256);
+    if (grid > 8192) grid = 8192;
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(pack_input_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16_t*)out, N, C, H, W, Cp, ld_out);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (float*)out,
+                           N, C, H, W, Cp, ld_out);
+    else {
+        segnb_set_error("segnb_pack_input_nchw: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}

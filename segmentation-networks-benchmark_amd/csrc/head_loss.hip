@@ -1,0 +1,305 @@
+// 1x1 classifier head (few classes) and the per-pixel binary losses / metrics, gfx950.
+//
+// head : nn.Conv2d(filters, num_classes, 1) of lib/models/zf_unet.py:58,93 (tiramisu.py:162,
+//        unet16.py:111): NHWC activations in, fp32 NCHW logits out (the reference's output layout).
+// loss : lib/losses.py:7-101 and lib/metrics.py:9-43 -- one streaming pass produces every global
+//        sum any of the losses/metrics needs; a second pass writes d(loss)/d(logits).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 8;  // classes handled by the direct head kernels
+
+// ------------------------------------------------------------------------------------------------
+// head forward: one thread per pixel, weights in LDS
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, int ld_a, long long npix,
+                                                       long long hw, int C, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int K,
+                                                       float* __restrict__ logits) {
+    extern __shared__ float sw[];  // [K][C8]
+    const int C8 = (C + 7) & ~7;
+    for (int i = threadIdx.x; i < K * C8; i += blockDim.x) {
+        const int k = i / C8, c = i - k * C8;
+        sw[i] = c < C ? w[k * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix;
+         pix += (long long)gridDim.x * blockDim.x) {
+        float acc[MAXK];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
+        for (int c0 = 0; c0 < C8; c0 += 8) {
+            float v[8];
+            load8(a + pix * ld_a + c0, v);
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[k] = fmaf(v[e], sw[k * C8 + c0 + e], acc[k]);
+                }
+        }
+        const long long n = pix / hw, r = pix - n * hw;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) logits[(n * K + k) * hw + r] = acc[k] + (bias != nullptr ? bias[k] : 0.f);
+    }
+}
+
+// head backward: da[pix][c] = sum_k dl[pix][k] w[k][c]; dw[k][c] += sum_pix dl[pix][k] a[pix][c]; db[k] += sum dl
+// thread (tx = 8-channel chunk, ty = pixel lane), same mapping as the norm/act kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, int ld_a, long long npix,
+                                                       long long hw, int C, int Cp, const float* __restrict__ w,
+                                                       int K, const float* __restrict__ dl, T* __restrict__ da,
+                                                       int ld_da, float* __restrict__ dw, float* __restrict__ db,
+                                                       int CT) {
+    __shared__ float sred[MAXK * 32 * 8 + MAXK];
+    for (int i = threadIdx.x; i < MAXK * 32 * 8 + MAXK; i += blockDim.x) sred[i] = 0.f;
+    __syncthreads();
+    const int PY = 256 / CT;
+    const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const int cc = blockIdx.y * CT + tx;
+    const bool active = cc * 8 < Cp;
+    const int c0 = active ? cc * 8 : 0;
+    float wv[MAXK][8];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[k][e] = (k < K && c0 + e < C) ? w[k * C + c0 + e] : 0.f;
+    float gw[MAXK][8];
+    float gb[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        gb[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gw[k][e] = 0.f;
+    }
+    if (active)
+        for (long long pix = (long long)blockIdx.x * PY + ty; pix < npix; pix += (long long)gridDim.x * PY) {
+            const long long n = pix / hw, r = pix - n * hw;
+            float av[8], d[8];
+            load8(a + pix * ld_a + c0, av);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) {
+                    const float g = dl[(n * K + k) * hw + r];
+                    gb[k] += g;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        d[e] = fmaf(g, wv[k][e], d[e]);
+                        gw[k][e] = fmaf(g, av[e], gw[k][e]);
+                    }
+                }
+            if (da != nullptr) store8(da + pix * ld_da + c0, d);
+        }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&sred[(k * 32 + tx) * 8 + e], gw[k][e]);
+            if (tx == 0 && blockIdx.y == 0) atomicAdd(&sred[MAXK * 32 * 8 + k], gb[k]);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * CT * 8; i += blockDim.x) {
+        const int k = i / (CT * 8), idx = i - k * (CT * 8);
+        const int ch = blockIdx.y * CT * 8 + idx;
+        if (ch < C && dw != nullptr) atomicAdd(&dw[k * C + ch], sred[(k * 32 + idx / 8) * 8 + (idx & 7)]);
+    }
+    if (blockIdx.y == 0 && threadIdx.x < K && db != nullptr) atomicAdd(&db[threadIdx.x], sred[MAXK * 32 * 8 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses
+// ------------------------------------------------------------------------------------------------
+struct PixTerms {
+    float p;    // sigmoid(x)
+    float e;    // double-sigmoid BCE element:  -t*logsigmoid(x) + log(1 + sigmoid(x))      (losses.py:51-53)
+    float de;   // d e / d x = (1-p) * (p/(1+p) - t)
+    float f;    // focal element (1-pt)^2 * e, pt = exp(-e)                                   (losses.py:90-95)
+    float df;   // d f / d x
+};
+
+__device__ __forceinline__ PixTerms pix_terms(float x, float t) {
+    PixTerms o;
+    // logsigmoid(x) = min(x,0) - log1p(exp(-|x|)), as ATen computes it
+    const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+    const float p = expf(ls);
+    o.p = p;
+    o.e = -t * ls + log1pf(p);
+    o.de = (1.f - p) * (p / (1.f + p) - t);
+    const float pt = expf(-o.e);
+    const float om = 1.f - pt;
+    o.f = om * om * o.e;
+    o.df = (2.f * om * pt * o.e + om * om) * o.de;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ x,
+                                                          const long long* __restrict__ tg, long long n,
+                                                          double* __restrict__ sums) {
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        const float t = tg[i] != 0 ? 1.f : 0.f;
+        // the reference multiplies by target.float(): any integer label value; binary masks are 0/1
+        const float tf = (float)tg[i];
+        const PixTerms q = pix_terms(xv, tf);
+        s[0] += q.e;
+        s[1] += q.f;
+        s[2] += q.p * tf;
+        s[3] += q.p;
+        s[4] += tf;
+        s[5] += ((q.p > 0.5f) == (t != 0.f)) ? 1.0 : 0.0;
+    }
+    __shared__ double sh[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double v = wave_sum(s[k]);
+        if (lane == 0) sh[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        atomicAdd(&sums[threadIdx.x], v);
+    }
+    if (threadIdx.x == 6 && blockIdx.x == 0) atomicAdd(&sums[6], (double)n);
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, segnb_loss_spec sp, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double n = sums[6];
+    const double I = sums[2], U = sums[3] + sums[4];
+    const double bce = sums[0] / n;
+    const double focal = sp.focal_mean ? sums[1] / n : sums[1];
+    const double eps = (double)sp.eps, sm = (double)sp.smooth;
+    const double Dj = U - I + eps, Ds = U - I + sm, Dd = U + eps;
+    const double jac = 1.0 - I / Dj;
+    const double sjac = 1.0 - (I + sm) / Ds;
+    const double dice = 1.0 - 2.0 * I / Dd;
+    const double loss = ((double)sp.w_bce * bce + (double)sp.w_focal * focal + (double)sp.w_jaccard * jac +
+                         (double)sp.w_sjaccard * sjac + (double)sp.w_dice * dice) / (double)sp.norm;
+    // d(loss)/dI and d(loss)/dU of the region terms (before the 1/norm factor)
+    const double GI = (double)sp.w_jaccard * (-(U + eps) / (Dj * Dj)) + (double)sp.w_sjaccard * (-(U + 2.0 * sm) / (Ds * Ds)) +
+                      (double)sp.w_dice * (-2.0 / Dd);
+    const double GU = (double)sp.w_jaccard * (I / (Dj * Dj)) + (double)sp.w_sjaccard * ((I + sm) / (Ds * Ds)) +
+                      (double)sp.w_dice * (2.0 * I / (Dd * Dd));
+    out[0] = (float)loss;
+    out[1] = (float)(I / (U - I + 1e-7));   // JaccardScore, metrics.py:14-20
+    out[2] = (float)(sums[5] / n);          // PixelAccuracy, metrics.py:30-40
+    out[3] = (float)GI;
+    out[4] = (float)GU;
+    out[5] = (float)bce;
+    out[6] = (float)n;
+    out[7] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ tg,
+                                                       long long n, const float* __restrict__ fin, segnb_loss_spec sp,
+                                                       const float* __restrict__ grad_out, float* __restrict__ dx) {
+    const float go = (grad_out != nullptr ? grad_out[0] : 1.f) / sp.norm;
+    const float GI = fin[3], GU = fin[4];
+    const float inv_n = 1.f / fin[6];   // GLOBAL pixel count (== n on one GPU; all-reduced sums in a DP job)
+    const float wb = sp.w_bce * inv_n;
+    const float wf = sp.focal_mean ? sp.w_focal * inv_n : sp.w_focal;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float tf = (float)tg[i];
+        const PixTerms q = pix_terms(x[i], tf);
+        const float dp = q.p * (1.f - q.p);
+        dx[i] = go * (wb * q.de + wf * q.df + dp * (tf * GI + GU));
+    }
+}
+
+}  // namespace
+
+extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, const float* w,
+                              const float* bias, int K, float* logits, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(a && w && logits, "NULL tensor");
+    SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
+    SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ld_a % 8 == 0 && ld_a >= ((C + 7) & ~7), "bad shape");
+    const long long npix = (long long)N * H * W;
+    int grid = ceil_div(npix, 256);
+    if (grid > 4096) grid = 4096;
+    const int smem = K * ((C + 7) & ~7) * 4;
+    SEGNB_CHECK_ARG(smem <= 60 * 1024, "head too wide");
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(grid), dim3(256), smem, (hipStream_t)stream,
+                           (const bf16_t*)a, ld_a, npix, (long long)H * W, C, w, bias, K, logits);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const float*)a,
+                           ld_a, npix, (long long)H * W, C, w, bias, K, logits);
+    else {
+        segnb_set_error("segnb_head_fwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
+                              const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
+                              float* db, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(a && w && dlogits, "NULL tensor");
+    SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
+    SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Cp % 8 == 0 && Cp >= C, "bad shape");
+    const long long npix = (long long)N * H * W;
+    const int CPP = Cp / 8;
+    int ct = 1;
+    while (ct < CPP && ct < 32) ct <<= 1;
+    const int gy = ceil_div(CPP, ct);
+    const int py = 256 / ct;
+    long long gx = (npix + py - 1) / py;
+    if (gx > 2048 / gy) gx = 2048 / gy;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, ld_a,
+                           npix, (long long)H * W, C, Cp, w, K, dlogits, (bf16_t*)da, ld_da, dw, db, ct);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(head_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a, ld_a,
+                           npix, (long long)H * W, C, Cp, w, K, dlogits, (float*)da, ld_da, dw, db, ct);
+    else {
+        segnb_set_error("segnb_head_bwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, double* sums,
+                                     segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(logits && target && sums && n > 0, "bad arguments");
+    int grid = ceil_div(n, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, sums);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, float* out,
+                                       segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(sums && spec && out, "bad arguments");
+    SEGNB_CHECK_ARG(spec->norm != 0.f, "loss norm must be non-zero");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, *spec, out);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_bwd(const float* logits, const long long* target, long long n,
+                                  const double* sums, const float* fin, const segnb_loss_spec* spec,
+                                  const float* grad_out, float* dlogits, segnb_stream_t stream) {
+    (void)sums;
+    SEGNB_CHECK_ARG(logits && target && fin && spec && dlogits && n > 0, "bad arguments");
+    int grid = ceil_div(n, 256 * 4);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, fin, *spec,
+                       grad_out, dlogits);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,496 @@
+// BatchNorm / activation / Dropout2d / MaxPool2d(2) / nearest-x2 Upsample, fused, NHWC, gfx950.
+//
+// Replaces nn.BatchNorm2d + nn.ReLU (lib/models/zf_unet.py:9-10,15-16), nn.Dropout2d (:25,31),
+// nn.MaxPool2d(2) (:41), nn.Upsample(scale_factor=2) (:42) and torch.cat (:78-90, via `ld` slices)
+// and their autograd backward; the 4-phase split mirrors inplace_abn's
+// mean_var / forward / edz_eydz / backward (lib/modules/abn/functions.py:81,94,112,118).
+//
+// All kernels are HBM-bound streams: 16-byte vectors (8 channels per thread), one thread column per
+// 8-channel chunk so per-channel sums stay in registers, wave/LDS reduction, fp64 global atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+
+struct EwShape {
+    int N, H, W, Cp;
+    int CPP;  // 8-channel chunks per pixel
+    int CT;   // chunk columns per block (power of two <= 32)
+    int PY;   // pixel rows per block = 256 / CT
+};
+
+static EwShape make_shape(int N, int H, int W, int Cp) {
+    EwShape s;
+    s.N = N; s.H = H; s.W = W; s.Cp = Cp;
+    s.CPP = Cp / 8;
+    int ct = 1;
+    while (ct < s.CPP && ct < 32) ct <<= 1;
+    s.CT = ct;
+    s.PY = NTHR / ct;
+    return s;
+}
+
+static dim3 make_grid(const EwShape& s, long long items) {
+    const int gy = ceil_div(s.CPP, s.CT);
+    long long gx = (items + s.PY - 1) / s.PY;
+    long long cap = 4096 / gy;
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+    if (act == SEGNB_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == SEGNB_ACT_LEAKY) return z > 0.f ? z : z * slope;
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+    if (act == SEGNB_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == SEGNB_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, int Cp, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, long long* nbt,
+                                   int training, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training && nbt != nullptr) nbt[0] += 1;
+    if (c >= Cp) return;
+    float scale = 0.f, shift = 0.f, mean = 0.f, invstd = 0.f;
+    if (c < C) {
+        double mu, var;
+        if (training) {
+            mu = stats[c] / count;
+            var = stats[Cp + c] / count - mu * mu;
+            stats[c] = 0.0;
+            stats[Cp + c] = 0.0;
+            if (var < 0.0) var = 0.0;
+            if (running_mean != nullptr) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+            }
+        } else {
+            mu = (double)running_mean[c];
+            var = (double)running_var[c];
+        }
+        mean = (float)mu;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma != nullptr ? gamma[c] : 1.f;
+        const float b = beta != nullptr ? beta[c] : 0.f;
+        scale = g * invstd;
+        shift = b;   // z = (y - mean) * scale + beta : no cancellation between mean*scale and beta
+    }
+    coef[c] = scale;
+    coef[Cp + c] = shift;
+    coef[2 * Cp + c] = mean;
+    coef[3 * Cp + c] = invstd;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ y, int ld_y, EwShape s,
+                                                          const float* __restrict__ coef, int act, float slope,
+                                                          const float* __restrict__ dropmul, T* __restrict__ out,
+                                                          int ld_out, T* __restrict__ pool_out, int ld_pool,
+                                                          T* __restrict__ up_out, int ld_up) {
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    if (cc >= s.CPP) return;
+    const int c0 = cc * 8;
+    float sc[8], sh[8], mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = coef != nullptr ? coef[c0 + e] : 1.f;
+        sh[e] = coef != nullptr ? coef[s.Cp + c0 + e] : 0.f;
+        mu[e] = coef != nullptr ? coef[2 * s.Cp + c0 + e] : 0.f;
+    }
+    const int H2 = (s.H + 1) >> 1, W2 = (s.W + 1) >> 1;
+    const int Hp = s.H >> 1, Wp = s.W >> 1;
+    const long long nwin = (long long)s.N * H2 * W2;
+    for (long long win = (long long)blockIdx.x * s.PY + ty; win < nwin; win += (long long)gridDim.x * s.PY) {
+        const int n = (int)(win / (H2 * W2));
+        const int rem = (int)(win - (long long)n * (H2 * W2));
+        const int h2 = rem / W2, w2 = rem - h2 * W2;
+        float dm[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dm[e] = dropmul != nullptr ? dropmul[(long long)n * s.Cp + c0 + e] : 1.f;
+        float mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int hh = 2 * h2 + dy, ww = 2 * w2 + dx;
+                if (hh < s.H && ww < s.W) {
+                    const long long pix = ((long long)n * s.H + hh) * s.W + ww;
+                    float v[8];
+                    load8(y + pix * ld_y + c0, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope), out);
+                        mx[e] = fmaxf(mx[e], v[e]);
+                    }
+                    if (out != nullptr) store8(out + pix * ld_out + c0, v);
+                    if (up_out != nullptr) {
+                        const long long W2x = 2ll * s.W;
+                        const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
+                        store8(up_out + p00 * ld_up + c0, v);
+                        store8(up_out + (p00 + 1) * ld_up + c0, v);
+                        store8(up_out + (p00 + W2x) * ld_up + c0, v);
+                        store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
+                    }
+                }
+            }
+        if (pool_out != nullptr && h2 < Hp && w2 < Wp) {
+            const long long pp = ((long long)n * Hp + h2) * Wp + w2;
+            store8(pool_out + pp * ld_pool + c0, mx);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level per-channel reduction helper: thread (tx,ty) holds v[8] for chunk tx; result summed over
+// ty and atomically added (fp64) to dst[chan] for chan < Cp.
+__device__ __forceinline__ void block_channel_sum2(float (&a)[8], float (&b)[8], const EwShape& s, int tx,
+                                                   int chunk_base, double* __restrict__ dst0,
+                                                   double* __restrict__ dst1, float* sred) {
+    // sred: [2][CT*8] floats in LDS, zeroed by the caller before a __syncthreads()
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sred[tx * 8 + e], a[e]);
+        atomicAdd(&sred[s.CT * 8 + tx * 8 + e], b[e]);
+    }
+    __syncthreads();
+    const int nch = s.CT * 8;
+    for (int i = threadIdx.x; i < 2 * nch; i += NTHR) {
+        const int which = i / nch, idx = i - which * nch;
+        const int ch = chunk_base * 8 + idx;
+        if (ch < s.Cp) atomicAdd((which == 0 ? dst0 : dst1) + ch, (double)sred[i]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
+    const T* __restrict__ y, int ld_y, EwShape s, const float* __restrict__ coef, int act, float slope,
+    const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
+    int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums) {
+    __shared__ float sred[2 * 32 * 8];
+    for (int i = threadIdx.x; i < 2 * 32 * 8; i += NTHR) sred[i] = 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = coef != nullptr ? coef[c0 + e] : 1.f;
+        sh[e] = coef != nullptr ? coef[s.Cp + c0 + e] : 0.f;
+        mu[e] = coef != nullptr ? coef[2 * s.Cp + c0 + e] : 0.f;
+        is[e] = coef != nullptr ? coef[3 * s.Cp + c0 + e] : 0.f;
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+
+    const int H2 = (s.H + 1) >> 1, W2 = (s.W + 1) >> 1;
+    const int Hp = s.H >> 1, Wp = s.W >> 1;
+    const long long nwin = (long long)s.N * H2 * W2;
+    if (active)
+        for (long long win = (long long)blockIdx.x * s.PY + ty; win < nwin; win += (long long)gridDim.x * s.PY) {
+            const int n = (int)(win / (H2 * W2));
+            const int rem = (int)(win - (long long)n * (H2 * W2));
+            const int h2 = rem / W2, w2 = rem - h2 * W2;
+            float dm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dm[e] = dropmul != nullptr ? dropmul[(long long)n * s.Cp + c0 + e] : 1.f;
+            float yv[4][8], av[4][8];
+            bool valid[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int hh = 2 * h2 + (p >> 1), ww = 2 * w2 + (p & 1);
+                valid[p] = hh < s.H && ww < s.W;
+                if (valid[p]) {
+                    const long long pix = ((long long)n * s.H + hh) * s.W + ww;
+                    load8(y + pix * ld_y + c0, yv[p]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yv[p][e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    av[p][e] = round_as(dm[e] * act_fwd((yv[p][e] - mu[e]) * sc[e] + sh[e], act, slope), y);
+            }
+            // MaxPool2d backward: the gradient goes to the FIRST maximum of the window (scan order)
+            int amax[8];
+            float gp[8];
+            const bool pooled = g_pool != nullptr && h2 < Hp && w2 < Wp;
+            if (pooled) {
+                const long long pp = ((long long)n * Hp + h2) * Wp + w2;
+                load8(g_pool + pp * ld_gp + c0, gp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int am = 0;
+                    float m = av[0][e];
+#pragma unroll
+                    for (int p = 1; p < 4; ++p)
+                        if (av[p][e] > m) {
+                            m = av[p][e];
+                            am = p;
+                        }
+                    amax[e] = am;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (!valid[p]) continue;
+                const int hh = 2 * h2 + (p >> 1), ww = 2 * w2 + (p & 1);
+                const long long pix = ((long long)n * s.H + hh) * s.W + ww;
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = 0.f;
+                if (g_direct != nullptr) {
+                    float t[8];
+                    load8(g_direct + pix * ld_gd + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] += t[e];
+                }
+                if (pooled) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (amax[e] == p) g[e] += gp[e];
+                }
+                if (g_up != nullptr) {
+                    const long long W2x = 2ll * s.W;
+                    const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
+                    float t[8];
+                    load8(g_up + p00 * ld_gu + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] += t[e];
+                    load8(g_up + (p00 + 1) * ld_gu + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] += t[e];
+                    load8(g_up + (p00 + W2x) * ld_gu + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] += t[e];
+                    load8(g_up + (p00 + W2x + 1) * ld_gu + c0, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] += t[e];
+                }
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = (yv[p][e] - mu[e]) * sc[e] + sh[e];
+                    const float dv = round_as(g[e] * dm[e] * act_grad(z, act, slope), dz);
+                    d[e] = dv;
+                    s1[e] += dv;
+                    s2[e] += dv * ((yv[p][e] - mu[e]) * is[e]);
+                }
+                store8(dz + pix * ld_dz + c0, d);
+            }
+        }
+    if (sums != nullptr) block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, sums, sums + s.Cp, sred);
+}
+
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int Cp, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ coef,
+                                       float* __restrict__ bcoef, float* dgamma, float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    float a = 0.f, c1 = 0.f, c2 = 0.f;
+    if (c < C) {
+        const double sdz = sums[c], sdzy = sums[Cp + c];
+        sums[c] = 0.0;
+        sums[Cp + c] = 0.0;
+        const float g = gamma != nullptr ? gamma[c] : 1.f;
+        a = g * coef[3 * Cp + c];
+        c1 = (float)(sdz / count);
+        c2 = (float)(sdzy / count);
+        if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sdzy;
+        if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sdz;
+    }
+    bcoef[c] = a;
+    bcoef[Cp + c] = c1;
+    bcoef[2 * Cp + c] = c2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict__ y, int ld_y, EwShape s,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ bcoef,
+                                                            const T* __restrict__ dz, int ld_dz, T* __restrict__ dy,
+                                                            int ld_dy, float* __restrict__ dbias, int C) {
+    __shared__ float sred[32 * 8];
+    for (int i = threadIdx.x; i < 32 * 8; i += NTHR) sred[i] = 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    float mu[8], is[8], a[8], c1[8], c2[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mu[e] = coef[2 * s.Cp + c0 + e];
+        is[e] = coef[3 * s.Cp + c0 + e];
+        a[e] = bcoef[c0 + e];
+        c1[e] = bcoef[s.Cp + c0 + e];
+        c2[e] = bcoef[2 * s.Cp + c0 + e];
+        sb[e] = 0.f;
+    }
+    const long long npix = (long long)s.N * s.H * s.W;
+    if (active)
+        for (long long pix = (long long)blockIdx.x * s.PY + ty; pix < npix; pix += (long long)gridDim.x * s.PY) {
+            float yv[8], d[8];
+            load8(y + pix * ld_y + c0, yv);
+            load8(dz + pix * ld_dz + c0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yh = (yv[e] - mu[e]) * is[e];
+                d[e] = round_as(a[e] * (d[e] - c1[e] - yh * c2[e]), dy);
+                sb[e] += d[e];
+            }
+            store8(dy + pix * ld_dy + c0, d);
+        }
+    if (dbias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(&sred[tx * 8 + e], sb[e]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < s.CT * 8; i += NTHR) {
+            const int ch = blockIdx.y * s.CT * 8 + i;
+            if (ch < C) atomicAdd(&dbias[ch], sred[i]);
+        }
+    }
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long long n, float lr) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        pv.x -= lr * gv.x; pv.y -= lr * gv.y; pv.z -= lr * gv.z; pv.w -= lr * gv.w;
+        reinterpret_cast<float4*>(p)[i] = pv;
+    }
+    for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride)
+        p[i] -= lr * g[i];
+}
+
+int check_ew(int N, int H, int W, int Cp) {
+    SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "bad NHWC shape (Cp % 8 != 0?)");
+    SEGNB_CHECK_ARG((long long)N * H * W * 4 < (1ll << 31), "pixel count exceeds int32");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, long long* nbt, int training, float* coef,
+                                 segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(coef != nullptr && C > 0 && Cp >= C && Cp % 8 == 0, "bad channel counts");
+    SEGNB_CHECK_ARG(training ? stats != nullptr : (running_mean != nullptr && running_var != nullptr),
+                    "missing statistics source");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, Cp,
+                       count, gamma, beta, eps, momentum, running_mean, running_var, nbt, training, coef);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                                const float* coef, int act, float slope, const float* dropmul, void* out,
+                                int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
+                                segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const long long nwin = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const dim3 grid = make_grid(s, nwin);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           ld_y, s, coef, act, slope, dropmul, (bf16_t*)out, ld_out, (bf16_t*)pool_out, ld_pool,
+                           (bf16_t*)up_out, ld_up);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y, ld_y,
+                           s, coef, act, slope, dropmul, (float*)out, ld_out, (float*)pool_out, ld_pool,
+                           (float*)up_out, ld_up);
+    else {
+        segnb_set_error("segnb_bn_act_fwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                                       const float* coef, int act, float slope, const float* dropmul,
+                                       const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
+                                       const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
+                                       segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y != nullptr && dz != nullptr, "NULL tensor");
+    SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const long long nwin = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+    const dim3 grid = make_grid(s, nwin);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream,
+                           (const bf16_t*)y, ld_y, s, coef, act, slope, dropmul, (const bf16_t*)g_direct, ld_gd,
+                           (const bf16_t*)g_pool, ld_gp, (const bf16_t*)g_up, ld_gu, (bf16_t*)dz, ld_dz, sums);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream,
+                           (const float*)y, ld_y, s, coef, act, slope, dropmul, (const float*)g_direct, ld_gd,
+                           (const float*)g_pool, ld_gp, (const float*)g_up, ld_gu, (float*)dz, ld_dz, sums);
+    else {
+        segnb_set_error("segnb_bn_act_bwd_reduce: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,
+                                     const float* coef, float* bcoef, float* dgamma, float* dbeta,
+                                     int accumulate, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, (hipStream_t)stream, sums, C,
+                       Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                                  const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
+                                  int ld_dy, float* dbias, int C, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y && coef && bcoef && dz && dy, "NULL tensor");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
+                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C);
+    else {
+        segnb_set_error("segnb_bn_bwd_apply: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(p && g && n > 0, "bad arguments");
+    SEGNB_CHECK_ARG((((uintptr_t)p | (uintptr_t)g) & 15) == 0, "buffers must be 16-byte aligned");
+    int grid = ceil_div(n / 4 + 1, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, n, lr);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}

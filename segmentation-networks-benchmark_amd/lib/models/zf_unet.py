@@ -1,0 +1,287 @@
+"""ZF_UNET on the MI355X engine -- drop-in for the reference's ``lib.models.zf_unet``.
+
+Same public surface as /root/reference/lib/models/zf_unet.py:35-95: constructor signature
+``ZF_UNET(dropout_val=0.2, batch_norm=True, input_channels=3, num_classes=1, filters=32)``, attribute
+tree / ``state_dict`` keys (``conv_224.l1.conv.weight`` ... ``conv_final.bias``, 156 entries at the
+defaults), ``num_classes``, fp32 ``[N,3,H,W] -> [N,num_classes,H,W]`` logits, autograd through to
+every parameter.  Parameters are ordinary ``nn.Parameter``s created by ``nn.Conv2d`` /
+``nn.BatchNorm2d`` in the reference's construction order, so default initialisation under a given
+``torch.manual_seed`` matches the reference's bit for bit.
+
+Nothing here calls torch operators on the hot path: ``forward`` hands the batch to a static plan of
+libsegnb_hip.so launches (segnb.engine) -- implicit-GEMM MFMA convolutions with BatchNorm statistics in
+the epilogue, one fused BN+ReLU+Dropout2d+MaxPool/Upsample pass per conv writing straight into the
+decoder's concat buffers (no torch.cat), hand-written backward.
+"""
+import torch
+from torch import nn
+
+from segnb import _native as nv
+from segnb import convplan as cp
+from segnb.engine import ConvOp, FlatParams, Runtime, Stage, View
+
+ENCODER = ('conv_224', 'conv_112', 'conv_56', 'conv_28', 'conv_14', 'conv_7')
+DECODER = ('up_conv_14', 'up_conv_28', 'up_conv_56', 'up_conv_112', 'up_conv_224')
+
+
+class _ConvUnit(nn.Module):
+    """Parameter holder named like the reference's _Conv3BN (zf_unet.py:5-10): .conv, .bn, .activation"""
+
+    def __init__(self, cin, cout, bn):
+        super(_ConvUnit, self).__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1)
+        self.bn = nn.BatchNorm2d(cout) if bn else None
+        self.activation = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        raise RuntimeError('sub-blocks are parameter holders; run the whole ZF_UNET (fused HIP plan)')
+
+
+class _Block(nn.Module):
+    """Parameter holder named like _DoubleConvModule (zf_unet.py:20-25): .l1, .l2, .dropout"""
+
+    def __init__(self, cin, cout, dropout_val, bn):
+        super(_Block, self).__init__()
+        self.l1 = _ConvUnit(cin, cout, bn)
+        self.l2 = _ConvUnit(cout, cout, bn)
+        self.dropout = nn.Dropout2d(p=dropout_val)
+
+    def forward(self, x):
+        raise RuntimeError('sub-blocks are parameter holders; run the whole ZF_UNET (fused HIP plan)')
+
+
+class ZF_UNET(nn.Module):
+    def __init__(self, dropout_val=0.2, batch_norm=True, input_channels=3, num_classes=1, filters=32):
+        super(ZF_UNET, self).__init__()
+        self.num_classes = num_classes
+        self.pool = nn.MaxPool2d(2)
+        self.unpool = nn.Upsample(scale_factor=2)
+        f = filters
+        widths = [f, 2 * f, 4 * f, 8 * f, 16 * f, 32 * f]
+        cin = input_channels
+        for name, w in zip(ENCODER, widths):
+            setattr(self, name, _Block(cin, w, dropout_val, batch_norm))
+            cin = w
+        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+            setattr(self, name, _Block(widths[lvl + 1] + widths[lvl], widths[lvl], dropout_val, batch_norm))
+        self.conv_final = nn.Conv2d(f, num_classes, 1)
+        self._cfg = dict(dropout=float(dropout_val), bn=bool(batch_norm), cin=input_channels, widths=widths)
+        # engine state (not part of state_dict)
+        self.compute_dtype = 'bf16'     # 'bf16' = throughput path, 'f32' = exact-fp32 MFMA parity path
+        self._engine = None
+        self.dropout_override = None    # {block name: fp32 [N, C] multiplier table} -- Dropout2d replay
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in ('bf16', 'f32'):
+            raise ValueError("compute dtype must be 'bf16' or 'f32'")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._engine = None
+        return self
+
+    def _get_engine(self, device):
+        e = self._engine
+        if e is None or e.rt.device != device:
+            e = _ZFUnetPlan(self, device)
+            self._engine = e
+        return e
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self._cfg['cin']:
+            raise ValueError('expected input [N, %d, H, W], got %s' % (self._cfg['cin'], tuple(x.shape)))
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError('ZF_UNET needs H and W divisible by 32 (five 2x poolings), got %dx%d'
+                             % (x.shape[2], x.shape[3]))
+        eng = self._get_engine(x.device)
+        x = x.detach().contiguous().float()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _ZFUnetFn.apply(eng, x, *list(self.parameters()))
+        return eng.forward(x, self.training, False)
+
+
+class _ZFUnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        ctx.eng = eng
+        return eng.forward(x, eng.module.training, True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads = ctx.eng.backward(dlogits.contiguous().float())
+        return (None, None) + tuple(grads)
+
+
+class _ZFUnetPlan(object):
+    """Static launch plan of one ZF_UNET on one device."""
+
+    def __init__(self, module, device):
+        self.module = module
+        self.rt = rt = Runtime(device, module.compute_dtype)
+        self.flat = FlatParams(module)
+        self.flat.ensure(rt.device)
+        cfg = module._cfg
+        widths = cfg['widths']
+        self.widths = widths
+        self.wp = [cp.pad8(w) for w in widths]
+        self.cin_p = cp.pad8(cfg['cin'])
+        self.p_drop = cfg['dropout']
+        self.stages = {}
+        for i, name in enumerate(ENCODER):
+            blk = getattr(module, name)
+            seg1 = [(cfg['cin'], self.cin_p)] if i == 0 else [(widths[i - 1], self.wp[i - 1])]
+            self._add(name, blk, seg1, need_dgrad_l1=(i > 0))
+        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+            blk = getattr(module, name)
+            seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
+            self._add(name, blk, seg1, True)
+        self._bufs = {}
+        self._packed_key = None
+        self.fused_version = 0
+        self.K = module.num_classes
+
+    def _add(self, name, blk, seg1, need_dgrad_l1):
+        rt = self.rt
+        cout = blk.l1.conv.out_channels
+        c1 = ConvOp(rt, blk.l1.conv.weight, blk.l1.conv.bias, seg1, 1, 1, False, need_dgrad_l1)
+        c2 = ConvOp(rt, blk.l2.conv.weight, blk.l2.conv.bias, [(cout, cp.pad8(cout))], 1, 1, False, True)
+        self.stages[name] = (Stage(rt, c1, blk.l1.bn, nv.ACT_RELU, 0.0, name + '.l1'),
+                             Stage(rt, c2, blk.l2.bn, nv.ACT_RELU, 0.0, name + '.l2'))
+
+    # ---- buffers for one input geometry -------------------------------------------------------------
+    def buffers(self, N, H, W):
+        key = (N, H, W)
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        rt, wp = self.rt, self.wp
+        hs = [(H >> i, W >> i) for i in range(6)]
+        b = {'x': View.alloc(rt, N, H, W, self.cin_p)}
+        for i in range(6):
+            h, w = hs[i]
+            b['a1_%d' % i] = View.alloc(rt, N, h, w, wp[i])          # encoder l1 activated
+            b['da1_%d' % i] = View.alloc(rt, N, h, w, wp[i])
+            if i > 0:
+                b['p_%d' % i] = View.alloc(rt, N, h, w, wp[i - 1])   # pooled input of level i
+                b['dp_%d' % i] = View.alloc(rt, N, h, w, wp[i - 1])
+            if i < 5:
+                b['cat_%d' % i] = View.alloc(rt, N, h, w, wp[i + 1] + wp[i])   # [upsampled | skip]
+                b['dcat_%d' % i] = View.alloc(rt, N, h, w, wp[i + 1] + wp[i])
+                b['b1_%d' % i] = View.alloc(rt, N, h, w, wp[i])      # decoder l1 activated
+                b['db1_%d' % i] = View.alloc(rt, N, h, w, wp[i])
+        b['f0'] = View.alloc(rt, N, H, W, wp[0])
+        b['df0'] = View.alloc(rt, N, H, W, wp[0])
+        b['logits'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
+        b['drop'] = torch.ones((11, N, max(wp)), dtype=torch.float32, device=rt.device)
+        self._bufs[key] = b
+        return b
+
+    def _pack_if_needed(self, H, W):
+        key = (sum(p._version for p in self.module.parameters()), self.fused_version, H, W,
+               self.flat.flat_p.data_ptr())
+        if key == self._packed_key:
+            return
+        for i, name in enumerate(ENCODER):
+            for st in self.stages[name]:
+                st.conv.pack(H >> i, W >> i)
+        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+            for st in self.stages[name]:
+                st.conv.pack(H >> lvl, W >> lvl)
+        self._packed_key = key
+
+    def _dropout_tables(self, b, N, train):
+        """Per-block [N, Cp] multiplier tables (0 or 1/(1-p)); None when Dropout2d is inactive."""
+        names = ENCODER + DECODER
+        ov = self.module.dropout_override
+        if not train or (self.p_drop <= 0.0 and ov is None):
+            return {n: None for n in names}
+        out = {}
+        if ov is None:
+            d = b['drop']
+            d.bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
+        for k, n in enumerate(names):
+            Cp = self.stages[n][1].Cp
+            t = torch.ones((N, Cp), dtype=torch.float32, device=self.rt.device)
+            if ov is not None:
+                src = ov.get(n)
+                if src is None:
+                    out[n] = None
+                    continue
+                t[:, :src.shape[1]] = src.to(self.rt.device, torch.float32)
+            else:
+                t = b['drop'][k, :, :Cp].contiguous()
+            out[n] = t
+        return out
+
+    # ---- forward ---------------------------------------------------------------------------------------
+    def forward(self, x, train, need_grad):
+        rt = self.rt
+        self.flat.ensure(rt.device)
+        N, C, H, W = x.shape
+        b = self.buffers(N, H, W)
+        self._pack_if_needed(H, W)
+        drop = self._dropout_tables(b, N, train)
+        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, b['x'].ptr, rt.code, self.cin_p, b['x'].ld,
+                rt.stream)
+        wp = self.wp
+        cur = b['x']
+        for i, name in enumerate(ENCODER):
+            s1, s2 = self.stages[name]
+            s1.forward(cur, train, None, out=b['a1_%d' % i])
+            if i < 5:
+                skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
+                s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)])
+                cur = b['p_%d' % (i + 1)]
+            else:
+                s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]))
+        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+            s1, s2 = self.stages[name]
+            s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl])
+            if lvl > 0:
+                s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]))
+            else:
+                s2.forward(b['b1_0'], train, drop[name], out=b['f0'])
+        head = self.module.conv_final
+        logits = b['logits']
+        nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
+                nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+        self._last = (N, H, W) if need_grad else None
+        return logits.clone()
+
+    # ---- backward --------------------------------------------------------------------------------------
+    def backward(self, dlogits):
+        rt, flat, wp = self.rt, self.flat, self.wp
+        if self._last is None:
+            raise RuntimeError('backward without a grad-enabled forward')
+        N, H, W = self._last
+        b = self.buffers(N, H, W)
+        accumulate_in_place = flat.grads_alias()
+        if not accumulate_in_place:
+            flat.flat_g.zero_()
+        head = self.module.conv_final
+        nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
+                nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
+                nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
+        for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
+            s1, s2 = self.stages[name]
+            if lvl == 0:
+                s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'])
+            else:
+                s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl])
+            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl])
+        for i in (5, 4, 3, 2, 1, 0):
+            s1, s2 = self.stages[ENCODER[i]]
+            if i == 5:
+                s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'])
+            else:
+                s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
+                            dx=b['da1_%d' % i])
+            s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
+        self._after_backward()
+        if accumulate_in_place:
+            return [None for _ in self.module.parameters()]
+        return [flat.grad_of(p) for p in self.module.parameters()]
+
+    def _after_backward(self):
+        hook = getattr(self.module, '_grad_sync_hook', None)
+        if hook is not None:
+            hook(self.flat)

@@ -1,0 +1,348 @@
+"""Host-side execution engine: NHWC activation views, packed-weight convolution ops, fused
+conv->BatchNorm->activation stages, flat parameter/gradient storage.
+
+Everything here is plumbing around the C ABI (segnb._native): PyTorch supplies device memory and the
+stream; every FLOP and every byte moved on the hot path happens inside libsegnb_hip.so.  The same
+code drives any device the ABI backend can address, which is what lets tests check the plan logic
+(buffer wiring, tap tables, channel maps, backward routing) on CPU against an ABI emulator.
+"""
+import torch
+
+from . import _native as nv
+from . import convplan as cp
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Runtime(object):
+    """Per-model execution context: device, compute dtype, stream."""
+
+    def __init__(self, device, dtype='bf16'):
+        self.device = torch.device(device)
+        if dtype in ('bf16', torch.bfloat16):
+            self.code, self.tdtype = nv.BF16, torch.bfloat16
+        elif dtype in ('f32', 'fp32', torch.float32):
+            self.code, self.tdtype = nv.F32, torch.float32
+        else:
+            raise ValueError('dtype must be bf16 or f32, got %r' % (dtype,))
+
+    @property
+    def stream(self):
+        if self.device.type == 'cuda':
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def zeros(self, shape, dtype=None):
+        return torch.zeros(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def int32(self, values):
+        return torch.tensor(list(values), dtype=torch.int32, device=self.device)
+
+
+class View(object):
+    """[N, H, W, Cp] NHWC activation = channel slice [off, off+Cp) of a buffer with pixel stride ld."""
+    __slots__ = ('t', 'off', 'ld', 'N', 'H', 'W', 'Cp')
+
+    def __init__(self, t, N, H, W, Cp, ld=None, off=0):
+        self.t, self.N, self.H, self.W, self.Cp = t, N, H, W, Cp
+        self.ld = Cp if ld is None else ld
+        self.off = off
+
+    @staticmethod
+    def alloc(rt, N, H, W, Cp):
+        return View(rt.zeros((N, H, W, Cp)), N, H, W, Cp)
+
+    def slice(self, off, Cp):
+        return View(self.t, self.N, self.H, self.W, Cp, self.ld, self.off + off)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+    def dense(self):
+        """torch view [N,H,W,Cp] (debug / tests)."""
+        return self.t.view(self.N, self.H, self.W, self.ld)[..., self.off:self.off + self.Cp]
+
+
+def vptr(v):
+    return None if v is None else v.ptr
+
+
+def vld(v):
+    return 0 if v is None else v.ld
+
+
+class ConvOp(object):
+    """One nn.Conv2d / nn.ConvTranspose2d parameter set on the gather-conv kernels.
+
+    in_segments: [(real_channels, padded_channels), ...] -- the channel layout of the NHWC input view
+    (a torch.cat of padded slices); real channels of consecutive segments are consecutive in the
+    reference's weight tensor.
+    """
+
+    def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True):
+        self.rt = rt
+        self.weight, self.bias = weight, bias
+        self.stride, self.pad, self.transposed = stride, pad, transposed
+        self.need_dgrad = need_dgrad
+        if transposed:
+            self.Ci, self.Co, self.KH, self.KW = weight.shape
+            self.s_out, self.s_in = self.KH * self.KW, self.Co * self.KH * self.KW
+        else:
+            self.Co, self.Ci, self.KH, self.KW = weight.shape
+            self.s_out, self.s_in = self.Ci * self.KH * self.KW, self.KH * self.KW
+        assert sum(r for r, _ in in_segments) == self.Ci, (in_segments, self.Ci)
+        self.Cop = cp.pad8(self.Co)
+        imap = []
+        base = 0
+        for real, padded in in_segments:
+            assert padded % 8 == 0 and padded >= real
+            imap += [base + i for i in range(real)] + [-1] * (padded - real)
+            base += real
+        self.Cip = len(imap)
+        self.in_map = rt.int32(imap)
+        self.out_map = rt.int32(list(range(self.Co)) + [-1] * (self.Cop - self.Co))
+        self._plans = {}
+
+    # ---- per-input-size plan: launches, packed buffers -----------------------------------------
+    def plan(self, Hi, Wi):
+        key = (Hi, Wi)
+        p = self._plans.get(key)
+        if p is not None:
+            return p
+        rt = self.rt
+        p = {}
+        if self.transposed:
+            (Ho, Wo), fwd, full = cp.convt_fwd(Hi, Wi, self.KH, self.KW, self.stride, self.pad)
+            dg, dg_full = cp.convt_dgrad(Hi, Wi, self.KH, self.KW, self.stride, self.pad), True
+        else:
+            (Ho, Wo), fwd = cp.conv_fwd(Hi, Wi, self.KH, self.KW, self.stride, self.pad)
+            full = True
+            dg, dg_full = cp.conv_dgrad(Hi, Wi, self.KH, self.KW, self.stride, self.pad)
+        p['out_hw'] = (Ho, Wo)
+        p['fwd'], p['fwd_full'] = fwd, full
+        p['dg'], p['dg_full'] = dg, dg_full
+        p['wp_fwd'] = [rt.zeros((self.Cop, len(l.taps) * self.Cip)) for l in fwd]
+        p['tapoff_fwd'] = [nv.int_array([a * self.KW + b for (_, _, a, b) in l.taps]) for l in fwd]
+        if self.need_dgrad:
+            p['wp_dg'] = [rt.zeros((self.Cip, len(l.taps) * self.Cop)) for l in dg]
+            p['tapoff_dg'] = [nv.int_array([a * self.KW + b for (_, _, a, b) in l.taps]) for l in dg]
+        # weight-gradient workspace (fp32, packed like the forward matrix; zeroed here once, re-zeroed
+        # by segnb_unpack_wgrad each time it is consumed)
+        if self.transposed:
+            p['dwp'] = [rt.zeros((self.Cip, len(l.taps) * self.Cop), torch.float32) for l in dg]
+        else:
+            p['dwp'] = [rt.zeros((self.Cop, len(l.taps) * self.Cip), torch.float32) for l in fwd]
+        p['geoms'] = {}
+        self._plans[key] = p
+        return p
+
+    def out_hw(self, Hi, Wi):
+        return self.plan(Hi, Wi)['out_hw']
+
+    def _geom(self, p, tag, li, launch, N, Hi, Wi, Ci, ld_in, Ho, Wo, Co, ld_out):
+        key = (tag, li, N, ld_in, ld_out)
+        g = p['geoms'].get(key)
+        if g is None:
+            g = nv.ConvGeom()
+            g.N, g.Hi, g.Wi, g.Ci = N, Hi, Wi, Ci
+            g.Ho, g.Wo, g.Co = Ho, Wo, Co
+            g.ld_in, g.ld_out = ld_in, ld_out
+            g.QH, g.QW = launch.QH, launch.QW
+            g.in_step, g.out_step = launch.in_step, launch.out_step
+            g.oh0, g.ow0 = launch.oh0, launch.ow0
+            g.ntaps = len(launch.taps)
+            if g.ntaps > nv.MAX_TAPS:
+                raise ValueError('kernel has more than %d taps' % nv.MAX_TAPS)
+            for i, (dh, dw, _, _) in enumerate(launch.taps):
+                g.dh[i], g.dw[i] = dh, dw
+            p['geoms'][key] = g
+        return g
+
+    # ---- weight packing (every time the parameters changed) ---------------------------------------
+    def pack(self, Hi, Wi):
+        p, rt = self.plan(Hi, Wi), self.rt
+        w = self.weight.detach()
+        for li, l in enumerate(p['fwd']):
+            nv.call('segnb_pack_weight', nv.ptr(w), nv.ptr(p['wp_fwd'][li]), rt.code, self.Cop, self.Cip,
+                    len(l.taps), self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map),
+                    nv.ptr(self.in_map), rt.stream)
+        if self.need_dgrad:
+            for li, l in enumerate(p['dg']):
+                nv.call('segnb_pack_weight', nv.ptr(w), nv.ptr(p['wp_dg'][li]), rt.code, self.Cip, self.Cop,
+                        len(l.taps), self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map),
+                        nv.ptr(self.out_map), rt.stream)
+
+    # ---- kernels ------------------------------------------------------------------------------------
+    def fprop(self, xv, yv, stats=None):
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        assert xv.Cp == self.Cip and yv.Cp == self.Cop, (xv.Cp, self.Cip, yv.Cp, self.Cop)
+        assert (yv.H, yv.W) == p['out_hw']
+        if not p['fwd_full']:
+            yv.dense().zero_()
+        b = self.bias.detach() if self.bias is not None else None
+        for li, l in enumerate(p['fwd']):
+            g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+            nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
+                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream)
+
+    def dgrad(self, dyv, dxv):
+        p, rt = self.plan(dxv.H, dxv.W), self.rt
+        assert self.need_dgrad and dyv.Cp == self.Cop and dxv.Cp == self.Cip
+        if not p['dg_full']:
+            dxv.dense().zero_()
+        for li, l in enumerate(p['dg']):
+            g = self._geom(p, 'd', li, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+            nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0, dxv.ptr, None,
+                    rt.stream)
+
+    def wgrad(self, xv, dyv, grad_w):
+        """dW accumulated into grad_w (fp32, parameter layout)."""
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        gw = grad_w
+        if self.transposed:
+            # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
+            for li, l in enumerate(p['dg']):
+                g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
+                nv.call('segnb_conv_wgrad', g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), rt.stream)
+                nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
+                        self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
+                        rt.stream)
+            return
+        for li, l in enumerate(p['fwd']):
+            g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
+            nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]), rt.stream)
+            nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
+                    self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,
+                    rt.stream)
+
+
+class Stage(object):
+    """conv -> [BatchNorm2d] -> activation -> [Dropout2d multiplier] with optional fused MaxPool2d(2) /
+    nearest-x2 outputs.  (_Conv3BN of lib/models/zf_unet.py:5-17 plus the Dropout2d/pool/unpool that
+    follow it at :31,:41,:42.)"""
+
+    def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
+        self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
+        Cp = conv.Cop
+        self.C, self.Cp = conv.Co, Cp
+        self.stats = rt.zeros((2, Cp), torch.float64)     # consumed + re-zeroed by segnb_bn_finalize
+        self.sums = rt.zeros((2, Cp), torch.float64)      # consumed + re-zeroed by segnb_bn_bwd_finalize
+        self.coef = rt.zeros((4, Cp), torch.float32)
+        self.bcoef = rt.zeros((3, Cp), torch.float32)
+        self._bufs = {}
+
+    def buffers(self, N, Ho, Wo):
+        key = (N, Ho, Wo)
+        b = self._bufs.get(key)
+        if b is None:
+            b = {'y': View.alloc(self.rt, N, Ho, Wo, self.Cp), 'dz': View.alloc(self.rt, N, Ho, Wo, self.Cp)}
+            self._bufs[key] = b
+        return b
+
+    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None):
+        rt = self.rt
+        Ho, Wo = self.conv.out_hw(xv.H, xv.W)
+        b = self.buffers(xv.N, Ho, Wo)
+        yv = b['y']
+        use_batch_stats = self.bn is not None and train
+        self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
+        coef = None
+        if self.bn is not None:
+            bn = self.bn
+            nv.call('segnb_bn_finalize', nv.ptr(self.stats), self.C, self.Cp, float(xv.N * Ho * Wo),
+                    nv.ptr(bn.weight.detach()), nv.ptr(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
+                    nv.ptr(bn.running_mean), nv.ptr(bn.running_var), nv.ptr(bn.num_batches_tracked),
+                    1 if train else 0, nv.ptr(self.coef), rt.stream)
+            coef = self.coef
+        nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, xv.N, Ho, Wo, self.Cp, nv.ptr(coef), self.act,
+                self.slope, nv.ptr(dropmul), vptr(out), vld(out), vptr(pool_out), vld(pool_out), vptr(up_out),
+                vld(up_out), rt.stream)
+        self._saved = (xv, yv, dropmul, coef is not None)
+        return yv
+
+    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None):
+        """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
+        input gradient, or None (first layer)."""
+        rt = self.rt
+        xv, yv, dropmul, has_bn = self._saved
+        dz = self.buffers(yv.N, yv.H, yv.W)['dz']
+        coef = self.coef if has_bn else None
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
+                self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
+                vptr(g_up), vld(g_up), dz.ptr, dz.ld, nv.ptr(self.sums), rt.stream)
+        count = float(yv.N * yv.H * yv.W)
+        gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
+        if has_bn:
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count,
+                    nv.ptr(self.bn.weight.detach()), nv.ptr(self.coef), nv.ptr(self.bcoef),
+                    nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1, rt.stream)
+            nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(self.coef),
+                    nv.ptr(self.bcoef), dz.ptr, dz.ld, dz.ptr, dz.ld, nv.ptr(gbias), self.C, rt.stream)
+        else:
+            # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),
+                    nv.ptr(self.bcoef), None, nv.ptr(gbias), 1, rt.stream)
+        self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight))
+        if dx is not None:
+            self.conv.dgrad(dz, dx)
+        return dx
+
+
+class FlatParams(object):
+    """All parameters of a module as views of ONE fp32 buffer, all gradients as views of another
+    (one SGD kernel, one all-reduce bucket list, one memset).  nn.Parameter identity is preserved, so
+    torch.optim / state_dict / checkpoints see ordinary parameters (torch_train.py:375, :308-330)."""
+
+    def __init__(self, module):
+        self.module = module
+        self.flat_p = None
+        self.flat_g = None
+        self._off = {}
+
+    def ensure(self, device):
+        params = [p for p in self.module.parameters()]
+        ok = self.flat_p is not None and self.flat_p.device == device
+        if ok:
+            base = self.flat_p.data_ptr()
+            for p in params:
+                off = self._off.get(id(p))
+                if off is None or p.data_ptr() != base + 4 * off[0]:
+                    ok = False
+                    break
+        if ok:
+            return
+        total, offs = 0, {}
+        for p in params:
+            if p.dtype != torch.float32:
+                raise TypeError('parameters must be float32 (the reference trains in fp32)')
+            n = p.numel()
+            offs[id(p)] = (total, n)
+            total += (n + 3) // 4 * 4          # keep every view 16-byte aligned
+        flat_p = torch.zeros(total, dtype=torch.float32, device=device)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p in params:
+                off, n = offs[id(p)]
+                view = flat_p[off:off + n].view(p.shape)
+                view.copy_(p.data.to(device))
+                p.data = view
+        self.flat_p, self.flat_g, self._off = flat_p, flat_g, offs
+        self.total = total
+
+    def grad_of(self, p):
+        off, n = self._off[id(p)]
+        return self.flat_g[off:off + n].view(p.shape)
+
+    def grads_alias(self):
+        """True when every parameter's .grad is already a view of flat_g (accumulate in place)."""
+        base = self.flat_g.data_ptr()
+        for p in self.module.parameters():
+            g = p.grad
+            if g is None:
+                return False
+            off = self._off[id(p)][0]
+            if g.data_ptr() != base + 4 * off:
+                return False
+        return True
