@@ -1,0 +1,370 @@
+"""-m gpu: every HIP kernel behind the C ABI vs (a) the ABI emulator (oracle/abi_emulator.py) run on CPU
+copies of the same inputs and (b) where one exists, the torch-CPU fp32 operator the reference would have
+called.  Calls go through segnb._native (ctypes -> libsegnb_hip.so): no torch operator computes anything
+on the GPU side.
+
+Tolerances (written per check):
+  f32  path : exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) vs CPU fp32 -> summation-order noise, rtol 1e-4 on
+              the tensor scale
+  bf16 path : identical bf16 storage rounding on both sides, fp32 accumulation -> at most 1-2 bf16 ulps
+              (2^-8 relative) on individual elements after re-rounding
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import abi_emulator
+from segnb import _native as nv
+from segnb import convplan as cp
+from segnb.engine import ConvOp, Runtime, View
+
+pytestmark = pytest.mark.gpu
+
+EMU = abi_emulator.AbiEmulator()
+DTYPES = ['f32', 'bf16']
+
+
+def tol(dtype):
+    return dict(rtol=2e-2, atol=2e-2) if dtype == 'bf16' else dict(rtol=2e-4, atol=2e-4)
+
+
+def check(name, got, ref, dtype, scale=None):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    s = max(s, 1e-6)
+    t = tol(dtype)
+    err = (got - ref).abs()
+    bound = t['atol'] * s + t['rtol'] * ref.abs()
+    bad = err > bound
+    assert not bool(bad.any()), '%s [%s]: %d/%d elements off, max err %.3g (scale %.3g), first bad idx %s' % (
+        name, dtype, int(bad.sum()), bad.numel(), float(err.max()), s, bad.nonzero()[:4].tolist())
+
+
+class on_emulator(object):
+    def __enter__(self):
+        nv.set_backend_for_testing(EMU)
+
+    def __exit__(self, *a):
+        nv.set_backend_for_testing(None)
+
+
+def test_library_loads_and_reports_device():
+    lib = nv.load()
+    assert lib.segnb_version() >= 1
+    assert lib.segnb_device_cus() > 0
+
+
+def test_bad_arguments_raise_runtime_error():
+    g = nv.ConvGeom()           # all zeros -> rejected by check_geom, status -> RuntimeError
+    with pytest.raises(RuntimeError):
+        nv.call('segnb_conv_fprop', g, nv.F32, 1, 1, None, 0, 1, None, 0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolutions: forward, data gradient, weight gradient, for every flavour the four models use
+# ------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name,              N, H,  W,  segs(real,pad),        Co, k, s, p, transposed
+    ('3x3 first layer',  2, 20, 28, [(3, 8)],              32, 3, 1, 1, False),
+    ('3x3 32->32',       3, 17, 19, [(32, 32)],            32, 3, 1, 1, False),
+    ('3x3 concat pad',   2, 12, 12, [(12, 16), (6, 8)],    6,  3, 1, 1, False),
+    ('3x3 wide',         2, 14, 14, [(256, 256)],          192, 3, 1, 1, False),
+    ('3x3 deep 7x7',     4, 7,  7,  [(512, 512)],          256, 3, 1, 1, False),
+    ('1x1',              2, 9,  11, [(64, 64)],            16, 1, 1, 0, False),
+    ('7x7 s2 stem',      2, 32, 32, [(3, 8)],              64, 7, 2, 3, False),
+    ('3x3 s2',           2, 16, 18, [(64, 64)],            128, 3, 2, 1, False),
+    ('1x1 s2',           2, 16, 16, [(64, 64)],            128, 1, 2, 0, False),
+    ('3x3 p0',           1, 13, 13, [(32, 32)],            32, 3, 1, 0, False),
+    ('2x2 p1',           1, 11, 11, [(32, 32)],            8,  2, 1, 1, False),
+    ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
+    ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
+]
+
+
+def _run_conv(device, dtype, case, w, b, x_nchw, dy_nchw):
+    name, N, H, W, segs, Co, k, s, p, transposed = case
+    rt = Runtime(device, dtype)
+    wt = w.to(device)
+    bt = b.to(device)
+    op = ConvOp(rt, wt, bt, segs, s, p, transposed, need_dgrad=True)
+    op.pack(H, W)
+    Ho, Wo = op.out_hw(H, W)
+    # input view = channel slices of a wider buffer (exercises ld != C and padded concat segments)
+    ld_in = op.Cip + 8
+    xbuf = rt.zeros((N, H, W, ld_in))
+    xv = View(xbuf, N, H, W, op.Cip, ld_in, 8)
+    off, roff = 0, 0
+    dense = xv.dense()
+    for real, padded in segs:
+        dense[..., off:off + real] = x_nchw[:, roff:roff + real].permute(0, 2, 3, 1).to(device, rt.tdtype)
+        off += padded
+        roff += real
+    yv = View.alloc(rt, N, Ho, Wo, op.Cop)
+    stats = rt.zeros((2, op.Cop), torch.float64)
+    op.fprop(xv, yv, stats)
+    dyv = View.alloc(rt, N, Ho, Wo, op.Cop)
+    dyv.dense()[..., :Co] = dy_nchw.permute(0, 2, 3, 1).to(device, rt.tdtype)
+    dxv = View.alloc(rt, N, H, W, op.Cip)
+    op.dgrad(dyv, dxv)
+    gw = torch.zeros_like(wt)
+    op.wgrad(xv, dyv, gw)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    return (yv.dense().float().cpu(), stats.cpu(), dxv.dense().float().cpu(), gw.cpu(), segs, Co)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fprop_dgrad_wgrad(case, dtype):
+    name, N, H, W, segs, Co, k, s, p, transposed = case
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(hash(name) % 1000)
+    wshape = (Ci, Co, k, k) if transposed else (Co, Ci, k, k)
+    w = torch.randn(wshape, generator=gen) * (2.0 / (Ci * k * k)) ** 0.5
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, H, W, generator=gen)
+    if transposed:
+        Ho, Wo = cp.convt_out_size(H, k, s, p), cp.convt_out_size(W, k, s, p)
+    else:
+        Ho, Wo = cp.conv_out_size(H, k, s, p), cp.conv_out_size(W, k, s, p)
+    dy = torch.randn(N, Co, Ho, Wo, generator=gen)
+    if dtype == 'bf16':      # identical rounded operands on both sides and in the torch reference
+        w, x, dy = (t.bfloat16().float() for t in (w, x, dy))
+    y_g, st_g, dx_g, gw_g, _, _ = _run_conv('cuda', dtype, case, w, b, x, dy)
+    with on_emulator():
+        y_e, st_e, dx_e, gw_e, _, _ = _run_conv('cpu', dtype, case, w, b, x, dy)
+    # (a) HIP vs emulator, including pad channels (must be exactly zero on both)
+    check(name + ' y', y_g, y_e, dtype)
+    check(name + ' dx', dx_g, dx_e, dtype)
+    check(name + ' dW', gw_g, gw_e, dtype if dtype == 'f32' else 'f32', scale=float(gw_e.abs().max()) * (20 if dtype == 'bf16' else 1))
+    np.testing.assert_allclose(st_g.numpy(), st_e.numpy(), rtol=2e-3 if dtype == 'bf16' else 1e-5,
+                               atol=(2e-2 if dtype == 'bf16' else 1e-4) * float(st_e.abs().max()))
+    assert float(y_g[..., Co:].abs().max()) == 0.0 if y_g.shape[-1] > Co else True
+    # (b) HIP vs the torch operator the reference calls
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    if transposed:
+        yr = F.conv_transpose2d(xr, wr, b, stride=s, padding=p)
+    else:
+        yr = F.conv2d(xr, wr, b, stride=s, padding=p)
+    yr.backward(dy)
+    check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, dtype)
+    # dx: gather the real channels out of the padded segments
+    parts, off = [], 0
+    for real, padded in segs:
+        parts.append(dx_g[..., off:off + real])
+        off += padded
+    check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, dtype)
+    check(name + ' dW vs torch', gw_g, wr.grad, 'f32' if dtype == 'f32' else 'bf16', scale=float(wr.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------
+# BN + activation + dropout + pool + upsample, forward and backward
+# ------------------------------------------------------------------------------------------------------
+def _run_bn(device, dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors):
+    rt = Runtime(device, dtype)
+    Cp = cp.pad8(C)
+    y, gamma, beta, gd, gp, gu, drop = tensors
+    dev = rt.device
+    yv = View.alloc(rt, N, H, W, Cp)
+    yv.dense()[..., :C] = y.to(dev, rt.tdtype)
+    stats = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
+    yy = yv.dense().double()
+    stats[0] = yy.sum((0, 1, 2))
+    stats[1] = (yy * yy).sum((0, 1, 2))
+    coef = rt.zeros((4, Cp), torch.float32)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    g_, b_ = gamma.to(dev), beta.to(dev)
+    nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(b_), 1e-5, 0.1,
+            nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1, nv.ptr(coef), rt.stream)
+    dm = None
+    if use_drop:
+        dm = torch.ones(N, Cp, device=dev)
+        dm[:, :C] = drop.to(dev)
+    out = View.alloc(rt, N, H, W, Cp)
+    pool = View.alloc(rt, N, H // 2, W // 2, Cp) if use_pool else None
+    up = View.alloc(rt, N, 2 * H, 2 * W, Cp) if use_up else None
+    nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm), out.ptr,
+            out.ld, None if pool is None else pool.ptr, 0 if pool is None else pool.ld,
+            None if up is None else up.ptr, 0 if up is None else up.ld, rt.stream)
+    gdv = View.alloc(rt, N, H, W, Cp)
+    gdv.dense()[..., :C] = gd.to(dev, rt.tdtype)
+    gpv = gupv = None
+    if use_pool:
+        gpv = View.alloc(rt, N, H // 2, W // 2, Cp)
+        gpv.dense()[..., :C] = gp.to(dev, rt.tdtype)
+    if use_up:
+        gupv = View.alloc(rt, N, 2 * H, 2 * W, Cp)
+        gupv.dense()[..., :C] = gu.to(dev, rt.tdtype)
+    dz = View.alloc(rt, N, H, W, Cp)
+    sums = rt.zeros((2, Cp), torch.float64)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
+            gdv.ptr, gdv.ld, None if gpv is None else gpv.ptr, 0 if gpv is None else gpv.ld,
+            None if gupv is None else gupv.ptr, 0 if gupv is None else gupv.ld, dz.ptr, dz.ld, nv.ptr(sums),
+            rt.stream)
+    sums_copy = sums.clone()
+    bcoef = rt.zeros((3, Cp), torch.float32)
+    dgam, dbet, dbias = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(coef), nv.ptr(bcoef),
+            nv.ptr(dgam), nv.ptr(dbet), 0, rt.stream)
+    dyv = View.alloc(rt, N, H, W, Cp)
+    nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,
+            dyv.ptr, dyv.ld, nv.ptr(dbias), C, rt.stream)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    res = dict(coef=coef, rm=rm, rv=rv, nbt=nbt.float(), out=out.dense(), dz=dz.dense(), sums=sums_copy,
+               bcoef=bcoef, dgam=dgam, dbet=dbet, dy=dyv.dense(), dbias=dbias, stats_after=stats, sums_after=sums)
+    if pool is not None:
+        res['pool'] = pool.dense()
+    if up is not None:
+        res['up'] = up.dense()
+    return {k: v.detach().double().cpu() for k, v in res.items()}
+
+
+BN_CASES = [
+    # N, H,  W,  C,   act,          pool,  up,    drop
+    (2, 8,  8,  32,  nv.ACT_RELU,  True,  False, True),
+    (3, 7,  9,  20,  nv.ACT_RELU,  True,  False, False),     # odd sizes, padded channels (20 -> 24)
+    (2, 6,  10, 96,  nv.ACT_RELU,  False, True,  True),      # 12 chunks: not a power of two
+    (2, 12, 12, 264, nv.ACT_LEAKY, False, False, False),     # > 32 chunks: two chunk tiles
+    (1, 16, 16, 8,   nv.ACT_NONE,  True,  True,  False),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', BN_CASES, ids=[str(c[:4]) for c in BN_CASES])
+def test_bn_act_pool_upsample_fwd_bwd(case, dtype):
+    N, H, W, C, act, use_pool, use_up, use_drop = case
+    gen = torch.Generator().manual_seed(C + H)
+    y = torch.randn(N, H, W, C, generator=gen) * 2 + 0.5
+    tensors = (y, 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen),
+               torch.randn(N, H, W, C, generator=gen), torch.randn(N, H // 2, W // 2, C, generator=gen),
+               torch.randn(N, 2 * H, 2 * W, C, generator=gen),
+               (torch.rand(N, C, generator=gen) > 0.3).float() / 0.7)
+    g = _run_bn('cuda', dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
+    with on_emulator():
+        e = _run_bn('cpu', dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
+    for k in ('coef', 'rm', 'rv', 'nbt', 'bcoef'):
+        check(k, g[k], e[k], 'f32')
+    assert float(g['stats_after'].abs().max()) == 0.0 and float(g['sums_after'].abs().max()) == 0.0
+    for k in ('out', 'pool', 'up', 'dz', 'dy'):
+        if k in g:
+            check(k, g[k], e[k], dtype)
+    for k in ('sums', 'dgam', 'dbet'):
+        check(k, g[k], e[k], 'f32' if dtype == 'f32' else 'bf16')
+    check('dbias', g['dbias'], e['dbias'], dtype, scale=float(e['dz'].abs().sum((0, 1, 2)).max()))
+    if dtype == 'f32' and act == nv.ACT_RELU and not use_up:
+        # independent reference: torch autograd through BatchNorm2d(train) -> ReLU -> Dropout2d table -> pool
+        yt = y.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        gam, bet = tensors[1].clone().requires_grad_(True), tensors[2].clone().requires_grad_(True)
+        a = torch.relu(F.batch_norm(yt, None, None, gam, bet, True, 0.1, 1e-5))
+        if use_drop:
+            a = a * tensors[6][:, :, None, None]
+        loss = (a * tensors[3].permute(0, 3, 1, 2)).sum()
+        if use_pool:
+            loss = loss + (F.max_pool2d(a, 2) * tensors[4].permute(0, 3, 1, 2)).sum()
+        loss.backward()
+        check('out vs torch', g['out'][..., :C].permute(0, 3, 1, 2), a, 'f32')
+        check('dy vs torch', g['dy'][..., :C].permute(0, 3, 1, 2), yt.grad, 'f32')
+        check('dgamma vs torch', g['dgam'], gam.grad, 'f32')
+        check('dbeta vs torch', g['dbet'], bet.grad, 'f32')
+
+
+# ------------------------------------------------------------------------------------------------------
+# head, losses, SGD, input packing
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32, 1), (1, 9, 13, 20, 3), (2, 8, 8, 48, 2)])
+def test_head_fwd_bwd(shape, dtype):
+    N, H, W, C, K = shape
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(C)
+    a = torch.randn(N, H, W, C, generator=gen)
+    w = torch.randn(K, C, 1, 1, generator=gen) * 0.2
+    b = torch.randn(K, generator=gen)
+    dl = torch.randn(N, K, H, W, generator=gen)
+    if dtype == 'bf16':
+        a = a.bfloat16().float()
+
+    def run(device):
+        rt = Runtime(device, dtype)
+        av = View.alloc(rt, N, H, W, Cp)
+        av.dense()[..., :C] = a.to(rt.device, rt.tdtype)
+        wd, bd, dld = w.to(rt.device), b.to(rt.device), dl.to(rt.device)
+        logits = torch.zeros(N, K, H, W, device=rt.device)
+        nv.call('segnb_head_fwd', rt.code, av.ptr, av.ld, N, H, W, C, nv.ptr(wd), nv.ptr(bd), K, nv.ptr(logits),
+                rt.stream)
+        da = View.alloc(rt, N, H, W, Cp)
+        dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+        nv.call('segnb_head_bwd', rt.code, av.ptr, av.ld, N, H, W, C, Cp, nv.ptr(wd), K, nv.ptr(dld), da.ptr, da.ld,
+                nv.ptr(dw), nv.ptr(db), rt.stream)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return logits.cpu(), da.dense().float().cpu(), dw.cpu(), db.cpu()
+
+    lg, dag, dwg, dbg = run('cuda')
+    with on_emulator():
+        le, dae, dwe, dbe = run('cpu')
+    check('logits', lg, le, 'f32')
+    check('da', dag, dae, dtype)
+    check('dw', dwg, dwe, 'f32')
+    check('db', dbg, dbe, 'f32')
+    ar = a.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    out = F.conv2d(ar, wr, b)
+    out.backward(dl)
+    check('logits vs torch', lg, out, 'f32')
+    check('da vs torch', dag[..., :C].permute(0, 3, 1, 2), ar.grad, dtype)
+    check('dw vs torch', dwg, wr.grad, 'f32')
+
+
+LOSS_NAMES = ['bce', 'jaccard', 'smooth_jaccard', 'dice', 'bce_jaccard', 'bce_dice', 'focal']
+
+
+@pytest.mark.parametrize('name', LOSS_NAMES)
+def test_losses_vs_reference_golden(golden_dir, name):
+    """HIP loss kernels vs values + gradients produced by the REFERENCE's lib/losses.py (fixture)."""
+    import os
+    from lib import losses as L
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    x = torch.from_numpy(g['x']).cuda().requires_grad_(True)
+    t = torch.from_numpy(g['t']).cuda()
+    crit = {'bce': L.BCEWithSigmoidLoss, 'jaccard': L.JaccardLoss, 'smooth_jaccard': L.SmoothJaccardLoss,
+            'dice': L.DiceLoss, 'bce_jaccard': L.BCEWithLogitsLossAndSmoothJaccard, 'bce_dice': L.BCEAndDiceLoss,
+            'focal': lambda: L.FocalLossBinary(size_average=False)}[name]()
+    l = crit(x, t)
+    (x.shape[0] * l).backward()
+    assert abs(l.item() - float(g['loss_' + name])) <= 1e-5 * max(1.0, abs(float(g['loss_' + name])))
+    ref = g['dx_' + name]
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max())
+
+
+def test_metrics_vs_reference_golden(golden_dir):
+    import os
+    from lib.metrics import JaccardScore, PixelAccuracy
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    x, t = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['t']).cuda()
+    assert abs(JaccardScore()(x, t).item() - float(g['iou'])) < 1e-6
+    assert abs(PixelAccuracy()(x, t).item() - float(g['acc'])) < 1e-7
+    xe = torch.full((1, 1, 2, 2), 3.0).cuda()
+    assert PixelAccuracy()(xe, torch.zeros(1, 1, 2, 2).long().cuda()).item() == 0.0
+
+
+def test_sgd_and_input_pack():
+    gen = torch.Generator().manual_seed(0)
+    p = torch.randn(1000003 // 4 * 4 + 3, generator=gen)
+    g = torch.randn(p.numel(), generator=gen)
+    pd, gd = p.cuda(), g.cuda()
+    nv.call('segnb_sgd_step', nv.ptr(pd), nv.ptr(gd), p.numel(), 0.125, torch.cuda.current_stream().cuda_stream)
+    torch.testing.assert_close(pd.cpu(), p - 0.125 * g, rtol=1e-6, atol=1e-6)
+    x = torch.randn(3, 3, 10, 14, generator=gen)
+    for dtype, tdt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        rt = Runtime('cuda', dtype)
+        out = torch.full((3, 10, 14, 16), 7.0, dtype=tdt, device='cuda')
+        nv.call('segnb_pack_input_nchw', nv.ptr(x.cuda()), 3, 3, 10, 14, nv.ptr(out), rt.code, 8, 16, rt.stream)
+        torch.cuda.synchronize()
+        ref = x.permute(0, 2, 3, 1).to(tdt).float()
+        assert torch.equal(out[..., :3].float().cpu(), ref)
+        assert float(out[..., 3:8].abs().max()) == 0.0 and float((out[..., 8:] - 7).abs().max()) == 0.0

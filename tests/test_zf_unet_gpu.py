@@ -1,0 +1,208 @@
+"""-m gpu: end-to-end parity of the HIP path (lib.models.zf_unet.ZF_UNET + lib.losses on libsegnb_hip.so)
+against golden vectors produced by the REFERENCE itself (tests/golden/*.npz) and against the oracle.
+
+Tolerances are the north-star ones: |loss| <= 1e-5 and |soft IoU| < 1e-4 on the exact-fp32 path; the
+bf16 throughput path is reported against the same goldens with its own (stated) tolerances.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_ref, train_step_ref, zf_unet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(filters, dropout, seed, dtype):
+    from lib.models.zf_unet import ZF_UNET
+    m = ZF_UNET(dropout_val=dropout, filters=filters)
+    zf_unet_ref.closed_form_fill(m.state_dict(), seed)
+    m.set_compute_dtype(dtype)
+    return m.cuda()
+
+
+def test_native_library_is_what_runs():
+    from segnb import _native as nv
+    assert nv._test_backend is None
+    assert os.path.exists(nv.LIB_PATH)
+    nv.load()
+    with open('/proc/self/maps') as f:
+        assert 'libsegnb_hip.so' in f.read()
+
+
+def test_tiny_f32_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'zf_unet_tiny.npz'))
+    x, y = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['y']).cuda()
+    m = _model(4, 0.0, 3.0, 'f32')
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    np.testing.assert_allclose(ev.cpu().numpy(), g['eval_logits'], rtol=1e-4,
+                               atol=5e-4 * np.abs(g['eval_logits']).max())
+    m.train()
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore, PixelAccuracy
+    out = m(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['train_logits'], rtol=2e-3, atol=1e-3)
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y)
+    assert abs(loss.item() - float(g['loss_bce_jaccard'])) < 1e-5
+    assert abs(JaccardScore()(out, y).item() - float(g['iou'])) < 1e-4
+    assert abs(PixelAccuracy()(out, y).item() - float(g['acc'])) < 1e-4
+    (x.shape[0] * loss).backward()
+    for n, p in m.named_parameters():
+        ref = g['grad/' + n]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-3 * scale + 3e-6, (n, err, scale)
+    for n, b in m.named_buffers():
+        np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+def test_tiny_f32_training_steps_with_torch_sgd(golden_dir):
+    """torch_train.py:180-190 verbatim (zero_grad / forward / loss / (B*loss).backward() / optimizer.step())."""
+    g = np.load(os.path.join(golden_dir, 'zf_unet_tiny.npz'))
+    x, y = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['y']).cuda()
+    m = _model(4, 0.0, 3.0, 'f32')
+    m.train()
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    crit = BCEWithLogitsLossAndSmoothJaccard().cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    traj = []
+    for it in range(5):
+        opt.zero_grad()
+        out = m(x)
+        loss = crit(out, y)
+        (x.size(0) * loss).backward()
+        opt.step()
+        traj.append(loss.cpu().item())
+        if it == 0:
+            sd = m.state_dict()
+            for k in sd:
+                np.testing.assert_allclose(sd[k].cpu().numpy().astype(np.float64),
+                                           g['after1/' + k].astype(np.float64), rtol=2e-5, atol=3e-6, err_msg=k)
+    np.testing.assert_allclose(traj[:2], g['traj_bce_jaccard'][:2], rtol=1e-5)
+    np.testing.assert_allclose(traj, g['traj_bce_jaccard'], rtol=1e-3)
+
+
+def _run_224(dtype, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'zf_unet_224.npz'))
+    x, y = train_step_ref.synthetic_batch(4, 224, seed=1234)
+    x, y = x.cuda(), y.cuda()
+    m = _model(32, 0.2, 1.0, dtype)
+    m.dropout_override = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('drop/')}
+    m.train()
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore, PixelAccuracy
+    out = m(x)
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y)
+    iou, acc = JaccardScore()(out, y).item(), PixelAccuracy()(out, y).item()
+    (4 * loss).backward()
+    torch.cuda.synchronize()
+    return g, m, out.detach().cpu().numpy(), loss.item(), iou, acc
+
+
+def test_config1_224_f32_vs_reference_golden(golden_dir):
+    """BASELINE.json configs[0] shape: ZF_UNET() default, B=4, 224x224, Dropout2d draw replayed."""
+    g, m, logits, loss, iou, acc = _run_224('f32', golden_dir)
+    assert abs(loss - float(g['loss_bce_jaccard'])) < 1e-5, (loss, float(g['loss_bce_jaccard']))
+    assert abs(iou - float(g['iou'])) < 1e-4
+    assert abs(acc - float(g['acc'])) < 1e-4
+    np.testing.assert_allclose(logits.reshape(-1)[g['logit_idx']], g['logit_val'], rtol=2e-3, atol=5e-4)
+    names = list(g['grad_names'])
+    params = dict(m.named_parameters())
+    norms = np.array([np.sqrt((params[n].grad.double() ** 2).sum().item()) for n in names])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-3, atol=2e-6 * norms.max())
+    for n in names:
+        gv = params[n].grad.reshape(-1).cpu().numpy()[g['gidx/' + n]]
+        ref = g['gval/' + n]
+        scale = max(np.abs(ref).max(), float(g['grad_norms'][names.index(n)]) / np.sqrt(params[n].numel()), 1e-7)
+        assert np.abs(gv - ref).max() <= 5e-3 * scale + 2e-6, n
+    for n, b in m.named_buffers():
+        if 'buf/' + n in g.files:
+            np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5, err_msg=n)
+
+
+def test_config1_224_bf16_reported_deltas(golden_dir):
+    """bf16 throughput path against the same fp32 reference goldens.  SURVEY 7: the reference itself under
+    bf16 autocast moves the loss by 1.4e-5 and logits by up to 0.48, so this path is held to its own,
+    stated, tolerances: loss 2e-3, soft IoU 2e-3, gradient norms 5 %."""
+    g, m, logits, loss, iou, acc = _run_224('bf16', golden_dir)
+    print('bf16 deltas: loss %.3e  iou %.3e  acc %.3e' % (loss - float(g['loss_bce_jaccard']),
+                                                        iou - float(g['iou']), acc - float(g['acc'])))
+    assert abs(loss - float(g['loss_bce_jaccard'])) < 2e-3
+    assert abs(iou - float(g['iou'])) < 2e-3
+    assert abs(acc - float(g['acc'])) < 1e-2
+    names = list(g['grad_names'])
+    params = dict(m.named_parameters())
+    norms = np.array([np.sqrt((params[n].grad.double() ** 2).sum().item()) for n in names])
+    big = g['grad_norms'] > 1e-3 * g['grad_norms'].max()
+    np.testing.assert_allclose(norms[big], g['grad_norms'][big], rtol=5e-2)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_odd_filters_and_dropout_replay_vs_oracle(dtype):
+    B, S, F = 2, 64, 6
+    x, y = train_step_ref.synthetic_batch(B, S, seed=5)
+    sd = zf_unet_ref.new_state(filters=F, seed=2.0)
+    drop = zf_unet_ref.make_dropout_tables(F, B, 0.2, torch.Generator().manual_seed(3))
+    loss_ref, logits_ref, grads_ref = train_step_ref.loss_and_grads(sd, x, y, 'bce_dice', drop=drop)
+    m = _model(F, 0.2, 2.0, dtype)
+    m.dropout_override = drop
+    m.train()
+    from lib.losses import BCEAndDiceLoss
+    out = m(x.cuda())
+    loss = BCEAndDiceLoss()(out, y.cuda())
+    (B * loss).backward()
+    ltol, gtol = (1e-5, 1e-3) if dtype == 'f32' else (5e-3, 1e-1)
+    assert abs(loss.item() - loss_ref.item()) < ltol
+    for n, p in m.named_parameters():
+        ref = grads_ref[n].numpy()
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= gtol * scale + 3e-6, n
+
+
+def test_full_size_bs32_bf16_properties():
+    """BASELINE.json configs[1] (ZF_UNET 224x224 bf16 bs=32, BCE+Dice): size-independent properties --
+    finite outputs, run-to-run reproducible forward, BatchNorm bookkeeping, loss goes down under SGD."""
+    from lib.losses import BCEAndDiceLoss
+    from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(0)
+    m = ZF_UNET().cuda()
+    m.train()
+    x, y = train_step_ref.synthetic_batch(32, 224, seed=1234)
+    x, y = x.cuda(), y.cuda()
+    crit = BCEAndDiceLoss()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    m.dropout_override = {}            # Dropout2d off for the reproducibility check
+    with torch.no_grad():
+        a = m(x).clone()
+        b = m(x).clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), 'forward is not run-to-run reproducible'
+    assert int(m.conv_224.l1.bn.num_batches_tracked) == 2
+    m.dropout_override = None
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = crit(m(x), y)
+        (x.size(0) * loss).backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    for p in m.parameters():
+        assert torch.isfinite(p.grad).all()
+
+
+def test_eval_matches_train_statistics_path():
+    """validate() path (torch_train.py:248-265): no-grad eval forward uses running statistics."""
+    m = _model(8, 0.0, 4.0, 'f32')
+    x, _ = train_step_ref.synthetic_batch(2, 64, seed=9)
+    sd = zf_unet_ref.new_state(filters=8, seed=4.0)
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    ref = zf_unet_ref.forward(sd, x, train=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-4 * float(ref.abs().max()))
