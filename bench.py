@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: images/sec of the full training step
+(torch_train.py:180-190: zero_grad -> model(x) -> loss -> (B*loss).backward() -> optimizer.step()) for
+ZF_UNET 224x224, bs=32 per GPU, bf16 compute, BCE+Dice, synthetic tiles resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  Besides the throughput it carries
+  roofline     : the dominant kernel (the implicit-GEMM convolution) timed live with HIP events on its launch
+                 stream during the timed region: achieved = algorithmic FLOPs / event time, against the dense
+                 bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline : the oracle's CPU restatement of the same step (oracle/train_step_ref.py, kind "port") on this
+                 box's host cores, bounded sample (B=4, a few steps) -- a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, 'segmentation-networks-benchmark_amd'), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+GFLOP_PER_IMAGE_224 = 79.26     # conv MACs only, fwd + dgrad + wgrad, no dgrad for the first conv
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle train step (torch-CPU fp32, all host cores) on B=4 224x224: images/s."""
+    from oracle import train_step_ref, zf_unet_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    B, S = 4, 224
+    x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
+    sd = zf_unet_ref.default_init_state(filters=32, seed=0)
+    train_step_ref.train_step(sd, x, y, 'bce_dice', lr=1e-3)       # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 20):
+        train_step_ref.train_step(sd, x, y, 'bce_dice', lr=1e-3)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle/train_step_ref.train_step, ZF_UNET fp32 B=4 224x224 bce_dice SGD, %d steps after '
+                      '1 warm-up, torch %s CPU' % (n, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--loss', default='bce_dice', choices=['bce_dice', 'bce_jaccard', 'bce'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    from segnb import dist as sdist
+    from segnb import engine, optim
+    from segnb import _native as nv
+    from lib.models.zf_unet import ZF_UNET
+    from lib import losses as L
+
+    sdist.init_from_env()
+    ws, rank = sdist.world(), sdist.rank()
+    if ws != max(1, args.gpus) and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, ws), file=sys.stderr)
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) if ws > 1 else 0)
+    torch.cuda.set_device(dev)
+    nv.load()
+
+    torch.manual_seed(0)
+    model = ZF_UNET().set_compute_dtype(args.dtype).to(dev).train()
+    crit = {'bce_dice': L.BCEAndDiceLoss, 'bce_jaccard': L.BCEWithLogitsLossAndSmoothJaccard,
+            'bce': L.BCEWithSigmoidLoss}[args.loss]()
+    opt = optim.SGD(model.parameters(), lr=1e-3)
+    dp = sdist.DataParallel(model)
+    B, S = args.batch, args.size
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, S, S, generator=g).to(dev)
+    y = (torch.rand(B, 1, S, S, generator=g) > 0.7).long().to(dev)
+
+    def step():
+        opt.zero_grad()
+        out = model(x)
+        loss = crit(out, y)
+        (x.size(0) * loss).backward()
+        opt.step()
+        return loss
+
+    loss = step()                          # builds the plan, flat buffers
+    dp.broadcast_parameters(model._engine.flat)
+    for _ in range(max(0, args.warmup - 1)):
+        loss = step()
+    torch.cuda.synchronize()
+
+    timer = None
+    if not args.no_kernel_timer:
+        timer = engine.KernelTimer()
+        engine.TIMER = timer
+    if ws > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    engine.TIMER = None
+    if ws > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    value = ws * B * args.steps / dt
+    gflop_img = GFLOP_PER_IMAGE_224 * (S / 224.0) ** 2
+    peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
+    out = {
+        'metric': 'images/sec/GPU (fwd+bwd) ZF_UNET 224x224 bs=32; 1/2/4/8-GPU scaling',
+        'value': round(value, 2), 'unit': 'images/s', 'per_gpu': round(value / ws, 2),
+        'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'ZF_UNET %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, Dropout2d 0.2, train step '
+                               'torch_train.py:180-190 (configs[1])' % (S, S, args.dtype, B, args.loss),
+                   'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
+        'final_loss': round(final_loss, 6),
+        'step_mfma_frac': round(value / ws * gflop_img / 1e3 / peak, 4),
+    }
+    if timer is not None:
+        summ = timer.summary()
+        dom = max(summ, key=lambda k: summ[k][1])
+        n, tot_ms, tot_fl = summ[dom]
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        out['roofline'] = {'kernel': dom + '_kernel', 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                           'launches_per_step': n // args.steps,
+                           'avg_launch_us': round(tot_ms / n * 1e3, 2),
+                           'flops_per_launch': round(tot_fl / n),
+                           'share_of_step': round(tot_ms / (dt * 1e3), 4)}
+        out['kernels'] = {k: {'launches_per_step': v[0] // args.steps, 'ms_per_step': round(v[1] / args.steps, 3),
+                              'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+    if ws == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

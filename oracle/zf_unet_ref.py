@@ -91,6 +91,32 @@ def closed_form_fill(sd, seed=0.0):
     return sd
 
 
+def default_init_state(filters=32, input_channels=3, num_classes=1, batch_norm=True, seed=0):
+    """State dict with torch's DEFAULT initialisation, bit-identical to ``torch.manual_seed(seed);
+    ZF_UNET(filters=...)`` of the reference: the reference creates, in this order, two
+    nn.Conv2d(cin, cout, 3, padding=1) per block (zf_unet.py:8,23-24; blocks in the order of :44-56) and
+    the 1x1 head (:58); BatchNorm2d / Dropout2d / pooling draw nothing from the RNG.
+    tests/golden/make_golden.py asserts the equality against the imported reference."""
+    sd = {}
+    torch.manual_seed(seed)
+    for blk, (cin, cout) in block_channels(filters, input_channels).items():
+        for l, ci in (('l1', cin), ('l2', cout)):
+            conv = torch.nn.Conv2d(ci, cout, 3, padding=1)
+            p = '%s.%s.' % (blk, l)
+            sd[p + 'conv.weight'] = conv.weight.detach().clone()
+            sd[p + 'conv.bias'] = conv.bias.detach().clone()
+            if batch_norm:
+                sd[p + 'bn.weight'] = torch.ones(cout)
+                sd[p + 'bn.bias'] = torch.zeros(cout)
+                sd[p + 'bn.running_mean'] = torch.zeros(cout)
+                sd[p + 'bn.running_var'] = torch.ones(cout)
+                sd[p + 'bn.num_batches_tracked'] = torch.zeros((), dtype=torch.int64)
+    head = torch.nn.Conv2d(filters, num_classes, 1)
+    sd['conv_final.weight'] = head.weight.detach().clone()
+    sd['conv_final.bias'] = head.bias.detach().clone()
+    return sd
+
+
 def new_state(filters=32, input_channels=3, num_classes=1, batch_norm=True, seed=0.0):
     sd = {}
     for name, shape in state_shapes(filters, input_channels, num_classes, batch_norm).items():

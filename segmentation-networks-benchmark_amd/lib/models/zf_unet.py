@@ -136,7 +136,6 @@ class _ZFUnetPlan(object):
             self._add(name, blk, seg1, True)
         self._bufs = {}
         self._packed_key = None
-        self.fused_version = 0
         self.K = module.num_classes
 
     def _add(self, name, blk, seg1, need_dgrad_l1):
@@ -176,7 +175,7 @@ class _ZFUnetPlan(object):
         return b
 
     def _pack_if_needed(self, H, W):
-        key = (sum(p._version for p in self.module.parameters()), self.fused_version, H, W,
+        key = (sum(p._version for p in self.module.parameters()), self.flat.version, H, W,
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return
@@ -254,9 +253,7 @@ class _ZFUnetPlan(object):
             raise RuntimeError('backward without a grad-enabled forward')
         N, H, W = self._last
         b = self.buffers(N, H, W)
-        accumulate_in_place = flat.grads_alias()
-        if not accumulate_in_place:
-            flat.flat_g.zero_()
+        accumulate_in_place = flat.begin_backward()
         head = self.module.conv_final
         nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
                 nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
@@ -277,9 +274,10 @@ class _ZFUnetPlan(object):
                             dx=b['da1_%d' % i])
             s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
         self._after_backward()
-        if accumulate_in_place:
-            return [None for _ in self.module.parameters()]
-        return [flat.grad_of(p) for p in self.module.parameters()]
+        # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not
+        # returned through autograd, so they never get cloned and a flat optimizer / all-reduce can run)
+        flat.publish_grads(accumulate_in_place)
+        return [None for _ in self.module.parameters()]
 
     def _after_backward(self):
         hook = getattr(self.module, '_grad_sync_hook', None)

@@ -1,0 +1,124 @@
+"""Pure data parallelism over the GPUs of one node: one process per GPU, torch.distributed with backend
+"nccl" (= RCCL over xGMI on ROCm); "gloo" on CPU for tests.
+
+The reference is single-GPU (no DataParallel/DDP anywhere on its main path), so the exchange is
+new: per step
+  * ONE SUM all-reduce of the flat fp32 gradient buffer (bucketed, issued on a side stream as soon as the
+    backward plan has finished the bucket's layers).  SUM, not mean: the reference seeds backward with
+    batch_size * loss (torch_train.py:187-188), so per-GPU gradients are already sums over local samples.
+  * one 8-double all-reduce of the loss kernel's global sums, so Jaccard/Dice (and the reported loss) are
+    computed over the GLOBAL batch exactly as the reference computes them over its whole batch tensor
+    (lib/losses.py:39-42).
+BatchNorm statistics stay per GPU (what nn.BatchNorm2d does under any torch DP; InPlaceABNSync is unused).
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+from . import seglosses
+
+
+def world():
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def rank():
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or td.is_initialized():
+        return
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    td.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+
+
+class DataParallel(object):
+    """Attach gradient / loss-sum synchronisation to a segnb-engine model (in place; returns the model).
+
+    bucket_bytes: all-reduce granularity.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): large
+    buckets keep every link busy; the default 32 MiB gives ZF_UNET (125.8 MB of fp32 gradients) 4 buckets.
+    """
+
+    def __init__(self, model, bucket_bytes=32 << 20):
+        self.model = model
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.ws = world()
+        self._synced = False
+        self._comm_stream = None
+        model._grad_sync_hook = self.sync_grads
+        model._grad_ready_hook = self.grads_ready
+        self._pending = []
+        self._done_upto = None
+        if self.ws > 1:
+            seglosses.sums_allreduce_hook = self._allreduce_sums
+            seglosses.grad_scale = float(self.ws)
+
+    def __call__(self, *a, **k):
+        return self.model(*a, **k)
+
+    # ---- parameters ------------------------------------------------------------------------------------
+    def broadcast_parameters(self, flat):
+        if self.ws > 1 and not self._synced:
+            td.broadcast(flat.flat_p, src=0)
+            for b in self.model.buffers():
+                td.broadcast(b, src=0)
+            flat.version += 1
+        self._synced = True
+
+    # ---- loss sums -------------------------------------------------------------------------------------
+    def _allreduce_sums(self, sums):
+        td.all_reduce(sums, op=td.ReduceOp.SUM)
+
+    # ---- gradients -------------------------------------------------------------------------------------
+    def _stream(self, flat):
+        if not flat.flat_g.is_cuda:
+            return None
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=flat.flat_g.device)
+        return self._comm_stream
+
+    def grads_ready(self, flat, lo):
+        """Called by the backward plan when every gradient at flat offset >= lo is final (the plan runs
+        decoder -> encoder, i.e. from the END of the flat buffer towards its start).  Launches the
+        all-reduce of every full bucket that became ready, on the side stream."""
+        if self.ws <= 1:
+            return
+        hi = flat.total if self._done_upto is None else self._done_upto
+        while hi - lo >= self.bucket_elems or (lo == 0 and hi > 0):
+            start = max(lo, hi - self.bucket_elems) if lo > 0 else max(0, hi - self.bucket_elems)
+            self._launch(flat, start, hi)
+            hi = start
+            if hi == 0:
+                break
+        self._done_upto = hi
+
+    def _launch(self, flat, start, end):
+        chunk = flat.flat_g[start:end]
+        cs = self._stream(flat)
+        if cs is None:
+            self._pending.append(td.all_reduce(chunk, op=td.ReduceOp.SUM, async_op=True))
+            return
+        cs.wait_stream(torch.cuda.current_stream(flat.flat_g.device))
+        with torch.cuda.stream(cs):
+            td.all_reduce(chunk, op=td.ReduceOp.SUM)
+
+    def sync_grads(self, flat):
+        """End of backward: reduce whatever is left, then make the compute stream wait for the collectives."""
+        if self.ws <= 1:
+            return
+        self.grads_ready(flat, 0)
+        self._done_upto = None
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        cs = self._stream(flat)
+        if cs is not None:
+            torch.cuda.current_stream(flat.flat_g.device).wait_stream(cs)

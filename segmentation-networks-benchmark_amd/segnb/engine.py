@@ -15,6 +15,40 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+class KernelTimer(object):
+    """Optional per-launch timing of the convolution kernels with HIP events on the launch stream
+    (bench.py's live roofline measurement).  Off unless bench.py installs one in ``engine.TIMER``."""
+
+    def __init__(self):
+        self.records = []      # (label, algorithmic_flops, start_event, end_event)
+
+    def launch(self, label, flops, fn):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.append((label, flops, a, b))
+
+    def summary(self):
+        """{label: (launches, total_ms, total_flops)} -- call after a device synchronize."""
+        out = {}
+        for label, flops, a, b in self.records:
+            n, ms, fl = out.get(label, (0, 0.0, 0.0))
+            out[label] = (n + 1, ms + a.elapsed_time(b), fl + flops)
+        return out
+
+
+TIMER = None
+
+
+def _timed(label, flops, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.launch(label, flops, fn)
+
+
 class Runtime(object):
     """Per-model execution context: device, compute dtype, stream."""
 
@@ -184,8 +218,9 @@ class ConvOp(object):
         b = self.bias.detach() if self.bias is not None else None
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
-            nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
-                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream)
+            _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
+                                   self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream))
 
     def dgrad(self, dyv, dxv):
         p, rt = self.plan(dxv.H, dxv.W), self.rt
@@ -194,8 +229,9 @@ class ConvOp(object):
             dxv.dense().zero_()
         for li, l in enumerate(p['dg']):
             g = self._geom(p, 'd', li, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
-            nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0, dxv.ptr, None,
-                    rt.stream)
+            _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
+                                   dxv.ptr, None, rt.stream))
 
     def wgrad(self, xv, dyv, grad_w):
         """dW accumulated into grad_w (fp32, parameter layout)."""
@@ -212,7 +248,9 @@ class ConvOp(object):
             return
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
-            nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]), rt.stream)
+            _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]),
+                                   rt.stream))
             nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
                     self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,
                     rt.stream)
@@ -295,11 +333,14 @@ class FlatParams(object):
     (one SGD kernel, one all-reduce bucket list, one memset).  nn.Parameter identity is preserved, so
     torch.optim / state_dict / checkpoints see ordinary parameters (torch_train.py:375, :308-330)."""
 
+    registry = {}      # id(parameter) -> FlatParams owning it (lets segnb.optim find the flat buffers)
+
     def __init__(self, module):
         self.module = module
         self.flat_p = None
         self.flat_g = None
         self._off = {}
+        self.version = 0   # bumped by in-place updates that bypass torch's version counters (fused SGD)
 
     def ensure(self, device):
         params = [p for p in self.module.parameters()]
@@ -330,6 +371,9 @@ class FlatParams(object):
                 p.data = view
         self.flat_p, self.flat_g, self._off = flat_p, flat_g, offs
         self.total = total
+        self.version += 1
+        for p in params:
+            FlatParams.registry[id(p)] = self
 
     def grad_of(self, p):
         off, n = self._off[id(p)]
@@ -346,3 +390,25 @@ class FlatParams(object):
             if g.data_ptr() != base + 4 * off:
                 return False
         return True
+
+    def begin_backward(self):
+        """Decide how this backward meets existing .grad tensors.  Returns True when the kernels should
+        accumulate on top of flat_g (every .grad already aliases it: find_optimal_lr never zeroes grads,
+        lib/train_utils.py:54-65; zero_grad(set_to_none=False) zeroes them in place); otherwise flat_g is
+        cleared first."""
+        if self.grads_alias():
+            return True
+        self.flat_g.zero_()
+        return False
+
+    def publish_grads(self, accumulated_in_place):
+        """Make parameter.grad reflect flat_g: install views where .grad is None, add into foreign ones."""
+        if accumulated_in_place:
+            return
+        base = self.flat_g.data_ptr()
+        for p in self.module.parameters():
+            view = self.grad_of(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != base + 4 * self._off[id(p)][0]:
+                p.grad.add_(view)

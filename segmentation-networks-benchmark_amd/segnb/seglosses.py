@@ -31,6 +31,8 @@ def _stream(t):
 
 # optional hook: a data-parallel job all-reduces the 8 global sums here (segnb.dist installs it)
 sums_allreduce_hook = None
+# data-parallel: the backward seed is B_local; the global-batch loss needs B_total = B_local * world
+grad_scale = 1.0
 
 
 def _prep(logits, target):
@@ -70,6 +72,8 @@ class SegLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         x, t, sums, fin = ctx.saved_tensors
         g = gout.detach().contiguous().float()
+        if grad_scale != 1.0:
+            g = g * grad_scale
         dx = torch.empty_like(x)
         cs = _cspec(ctx.spec)
         nv.call('segnb_seg_loss_bwd', nv.ptr(x), nv.ptr(t), x.numel(), nv.ptr(sums), nv.ptr(fin), cs, nv.ptr(g),

@@ -7,8 +7,8 @@ Run in the build container only (``/root/reference`` does not exist on the GPU b
 
 Imports ``lib.models.zf_unet``, ``lib.models.tiramisu``, ``lib.losses``, ``lib.metrics`` read-only from
 /root/reference (torch 2.10 CPU, fp32) and stores plain arrays (.npz) -- inputs, expected outputs,
-never module objects or source.  Weights are a closed-form fill (oracle.zf_unet_ref.closed_form_fill)
-so large configs need no weight payload.
+never module objects or source.  Weights are torch's default initialisation under a fixed manual_seed (reproduced bit for bit by
+oracle.zf_unet_ref.default_init_state), so large configs need no weight payload.
 
 Fixtures
   losses.npz          G6  every binary loss / metric value + d(loss)/d(logits) on a small random tensor,
@@ -99,18 +99,24 @@ def gen_losses():
     print('losses.npz', {k: float(v) for k, v in out.items() if k.startswith('loss_')})
 
 
-def fill_reference_model(model, seed):
-    sd = model.state_dict()
-    names = list(sd.keys())
-    zf_unet_ref.closed_form_fill(sd, seed)   # state_dict tensors alias the module's -> fills the model
-    return names
+def make_reference_model(seed, **kw):
+    """The reference model with torch's default initialisation under manual_seed(seed).  (An earlier
+    closed-form sin() fill made the net pathologically ill-conditioned: the reference's own fp32 loss sat
+    1e-5 from its fp64 value; default init sits 4e-8 from it.)  Also checks that the oracle's
+    default_init_state reproduces these weights bit for bit."""
+    torch.manual_seed(seed)
+    m = ZF_UNET(**kw)
+    sd = m.state_dict()
+    o = zf_unet_ref.default_init_state(filters=kw.get('filters', 32), seed=seed)
+    assert list(o.keys()) == list(sd.keys()), 'state_dict layout drifted'
+    assert all(torch.equal(o[k], sd[k]) for k in sd), 'default init not reproduced'
+    return m
 
 
 def gen_tiny():
     B, S, F = 2, 64, 4
-    m = ZF_UNET(dropout_val=0.0, filters=F)
-    names = fill_reference_model(m, seed=3.0)
-    assert names == list(zf_unet_ref.state_shapes(filters=F).keys()), 'state_dict layout drifted'
+    m = make_reference_model(3, dropout_val=0.0, filters=F)
+    assert list(m.state_dict().keys()) == list(zf_unet_ref.state_shapes(filters=F).keys())
     x, y = train_step_ref.synthetic_batch(B, S, seed=11)
     out = {'x': x.numpy(), 'y': y.numpy()}
     m.eval()
@@ -132,15 +138,13 @@ def gen_tiny():
         out['buf/' + n] = b.numpy().copy()
     # per-loss gradient norms (full grads only for bce_jaccard above)
     for name in ['bce', 'jaccard', 'dice', 'focal', 'bce_dice']:
-        m2 = ZF_UNET(dropout_val=0.0, filters=F)
-        fill_reference_model(m2, seed=3.0)
+        m2 = make_reference_model(3, dropout_val=0.0, filters=F)
         m2.train()
         ll = ref_loss(name)(m2(x), y)
         (B * ll).backward()
         out['gradnorm_' + name] = np.array([p.grad.norm().item() for _, p in m2.named_parameters()])
     # 5-step SGD trajectory from the filled state (fresh model: the forward above moved BN stats)
-    m3 = ZF_UNET(dropout_val=0.0, filters=F)
-    fill_reference_model(m3, seed=3.0)
+    m3 = make_reference_model(3, dropout_val=0.0, filters=F)
     m3.train()
     opt = torch.optim.SGD(m3.parameters(), lr=1e-3)
     crit = ref_loss('bce_jaccard')
@@ -176,11 +180,10 @@ def capture_dropout_tables(model, p):
 
 def gen_224():
     B, S = 4, 224
-    torch.manual_seed(2024)
-    m = ZF_UNET()                       # defaults: filters=32, dropout 0.2, BN
-    fill_reference_model(m, seed=1.0)
+    m = make_reference_model(1)         # defaults: filters=32, dropout 0.2, BN
     x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
     m.train()
+    torch.manual_seed(2024)             # the Dropout2d draw
     tables, hooks = capture_dropout_tables(m, 0.2)
     logits = m(x)
     for h in hooks:
@@ -216,6 +219,24 @@ def gen_224():
     for n, b in m.named_buffers():
         if 'conv_224' in n or 'conv_7.' in n or 'up_conv_224' in n:
             out['buf/' + n] = b.numpy().copy()
+    # the same step by the reference in float64 (Dropout2d modules swapped for the captured tables):
+    # tells how far the reference's OWN fp32 arithmetic sits from the exact value
+    class _Replay(torch.nn.Module):
+        def __init__(self, table):
+            super().__init__()
+            self.table = table
+
+        def forward(self, t):
+            return t * self.table[:, :, None, None]
+    m64 = make_reference_model(1).double().train()
+    for k, v in tables.items():
+        getattr(m64, k).dropout = _Replay(v.double())
+    with torch.no_grad():
+        l64 = m64(x.double())
+    out['loss_bce_jaccard_fp64'] = ref_loss('bce_jaccard')(l64, y).numpy()
+    out['iou_fp64'] = ref_metrics.JaccardScore()(l64, y).numpy()
+    out['logit_val_fp64'] = l64.numpy().reshape(-1)[idx]
+    print('fp32 - fp64 loss of the reference itself: %.3e' % (float(l) - float(out['loss_bce_jaccard_fp64'])))
     np.savez_compressed(os.path.join(HERE, 'zf_unet_224.npz'), **out)
     print('zf_unet_224.npz loss', float(l), 'iou', float(out['iou']))
 

@@ -65,7 +65,7 @@ def test_state_layout():
 def test_zf_unet_tiny_forward(golden_dir):
     g = _load(golden_dir, 'zf_unet_tiny.npz')
     x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
-    sd = zf_unet_ref.new_state(filters=4, seed=3.0)
+    sd = zf_unet_ref.default_init_state(filters=4, seed=3)
     with torch.no_grad():
         ev = zf_unet_ref.forward(sd, x, train=False)
     np.testing.assert_allclose(ev.numpy(), g['eval_logits'], rtol=1e-4, atol=2e-5)
@@ -84,7 +84,7 @@ def test_zf_unet_tiny_forward(golden_dir):
 def test_zf_unet_tiny_grads_and_trajectory(golden_dir):
     g = _load(golden_dir, 'zf_unet_tiny.npz')
     x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
-    sd = zf_unet_ref.new_state(filters=4, seed=3.0)
+    sd = zf_unet_ref.default_init_state(filters=4, seed=3)
     loss, _, grads = train_step_ref.loss_and_grads(sd, x, y, 'bce_jaccard')
     np.testing.assert_allclose(loss.item(), g['loss_bce_jaccard'], rtol=5e-6)
     for k, v in grads.items():
@@ -94,11 +94,11 @@ def test_zf_unet_tiny_grads_and_trajectory(golden_dir):
         scale = max(np.abs(ref).max(), 1e-6)
         assert np.abs(v.numpy() - ref).max() <= 2e-4 * scale + 2e-6, k
     for name in ['bce', 'jaccard', 'dice', 'focal', 'bce_dice']:
-        sd2 = zf_unet_ref.new_state(filters=4, seed=3.0)
+        sd2 = zf_unet_ref.default_init_state(filters=4, seed=3)
         _, _, gr = train_step_ref.loss_and_grads(sd2, x, y, name)
         norms = np.array([gr[k].norm().item() for k in gr])
         np.testing.assert_allclose(norms, g['gradnorm_' + name], rtol=2e-4, atol=2e-6 * norms.max())
-    sd3 = zf_unet_ref.new_state(filters=4, seed=3.0)
+    sd3 = zf_unet_ref.default_init_state(filters=4, seed=3)
     traj = []
     for it in range(5):
         traj.append(train_step_ref.train_step(sd3, x, y, 'bce_jaccard', lr=1e-3)[0].item())
@@ -114,7 +114,7 @@ def test_zf_unet_224_scalars(golden_dir):
     """Config-1 shape (filters=32, B=4, 224x224, Dropout2d replayed from the reference's own draw)."""
     g = _load(golden_dir, 'zf_unet_224.npz')
     x, y = train_step_ref.synthetic_batch(4, 224, seed=1234)
-    sd = zf_unet_ref.new_state(filters=32, seed=1.0)
+    sd = zf_unet_ref.default_init_state(filters=32, seed=1)
     drop = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('drop/')}
     assert len(drop) == 11
     loss, logits, grads = train_step_ref.loss_and_grads(sd, x, y, 'bce_jaccard', drop=drop)

@@ -25,9 +25,9 @@ def emulated_abi():
 
 def _model(filters, dropout, seed, dtype='f32'):
     from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(int(seed))       # same construction order as the reference -> identical default init
     m = ZF_UNET(dropout_val=dropout, filters=filters)
     m.set_compute_dtype(dtype)
-    zf_unet_ref.closed_form_fill(m.state_dict(), seed)
     return m
 
 
@@ -107,7 +107,7 @@ def test_dropout_replay_and_odd_filters():
     Dropout2d multiplier table replayed on both sides."""
     B, S, F = 2, 64, 6     # 64 -> 2x2 bottleneck (32 would leave BatchNorm 2 samples per channel)
     x, y = train_step_ref.synthetic_batch(B, S, seed=5)
-    sd = zf_unet_ref.new_state(filters=F, seed=2.0)
+    sd = zf_unet_ref.default_init_state(filters=F, seed=2)
     gen = torch.Generator().manual_seed(3)
     drop = zf_unet_ref.make_dropout_tables(F, B, 0.2, gen)
     loss_ref, logits_ref, grads_ref = train_step_ref.loss_and_grads(sd, x, y, 'bce_dice', drop=drop)

@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 def _model(filters, dropout, seed, dtype):
     from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(int(seed))       # same construction order as the reference -> identical default init
     m = ZF_UNET(dropout_val=dropout, filters=filters)
-    zf_unet_ref.closed_form_fill(m.state_dict(), seed)
     m.set_compute_dtype(dtype)
     return m.cuda()
 
@@ -145,7 +145,7 @@ def test_config1_224_bf16_reported_deltas(golden_dir):
 def test_odd_filters_and_dropout_replay_vs_oracle(dtype):
     B, S, F = 2, 64, 6
     x, y = train_step_ref.synthetic_batch(B, S, seed=5)
-    sd = zf_unet_ref.new_state(filters=F, seed=2.0)
+    sd = zf_unet_ref.default_init_state(filters=F, seed=2)
     drop = zf_unet_ref.make_dropout_tables(F, B, 0.2, torch.Generator().manual_seed(3))
     loss_ref, logits_ref, grads_ref = train_step_ref.loss_and_grads(sd, x, y, 'bce_dice', drop=drop)
     m = _model(F, 0.2, 2.0, dtype)
@@ -200,7 +200,7 @@ def test_eval_matches_train_statistics_path():
     """validate() path (torch_train.py:248-265): no-grad eval forward uses running statistics."""
     m = _model(8, 0.0, 4.0, 'f32')
     x, _ = train_step_ref.synthetic_batch(2, 64, seed=9)
-    sd = zf_unet_ref.new_state(filters=8, seed=4.0)
+    sd = zf_unet_ref.default_init_state(filters=8, seed=4)
     m.eval()
     with torch.no_grad():
         out = m(x.cuda())
