@@ -34,7 +34,11 @@ GFLOP_PER_IMAGE_224 = 79.26     # conv MACs only, fwd + dgrad + wgrad
 def cpu_baseline(seconds_budget=20.0):
     """Oracle train step (torch-CPU fp32, all host cores) on B=4 224x224: images/s."""
     from oracle import train_step_ref, zf_unet_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 32)))    # beyond ~32 threads oneDNN slows down on this problem size
     B, S = 4, 224
     x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
     sd = zf_unet_ref.default_init_state(filters=32, seed=0)

@@ -37,6 +37,8 @@ void segnb_set_error(const char* fmt, ...);
     } while (0)
 
 int segnb_num_cus();
+// fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
+int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // element helpers: 8 channels per thread ("chunk8"), fp32 math

@@ -13,6 +13,8 @@
 // Wave tile WM x WN out of v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (exact fp32).
 // Epilogue: +bias, round to T, per-channel sum / sum^2 of the stored values (BatchNorm batch
 // statistics), staged through LDS so global stores are 16-byte, pixel-contiguous.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -686,9 +688,17 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     a.M = g->N * g->QH * g->QW;
     a.Ktot = g->ntaps * g->Ci;
     int rc;
-    if (dtype == SEGNB_BF16)
+    if (dtype == SEGNB_BF16) {
+        // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
+        static const bool general_only = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
+        rc = general_only ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, (hipStream_t)stream);
+        if (rc == 1) {
+            SEGNB_LAUNCH_CHECK();
+            return 0;
+        }
+        if (rc != 0) return rc;
         rc = dispatch_wgrad<bf16_t>(a, (hipStream_t)stream);
-    else if (dtype == SEGNB_F32)
+    } else if (dtype == SEGNB_F32)
         rc = dispatch_wgrad<float>(a, (hipStream_t)stream);
     else {
         segnb_set_error("segnb_conv_wgrad: unknown dtype %d", dtype);

@@ -77,6 +77,13 @@ CONV_CASES = [
     ('1x1 s2',           2, 16, 16, [(64, 64)],            128, 1, 2, 0, False),
     ('3x3 p0',           1, 13, 13, [(32, 32)],            32, 3, 1, 0, False),
     ('2x2 p1',           1, 11, 11, [(32, 32)],            8,  2, 1, 1, False),
+    # stride-1 3x3 shapes that take the transposing-LDS-read weight-gradient kernel (wgrad_s1.hip)
+    ('3x3 s1x9 thin',    2, 21, 37, [(32, 32)],            32, 3, 1, 1, False),
+    ('3x3 s1x9 thin cat', 1, 16, 56, [(64, 64), (30, 32)], 24, 3, 1, 1, False),
+    ('3x3 s1x9 thin p0', 1, 30, 30, [(16, 16)],            32, 3, 1, 0, False),
+    ('3x3 s1x9 64x64',   2, 10, 36, [(80, 80)],            72, 3, 1, 1, False),
+    ('3x3 s1x9 64x64 b', 1, 28, 28, [(128, 128)],          128, 3, 1, 1, False),
+    ('3x3 s1x9 w16',     3, 14, 14, [(96, 96)],            160, 3, 1, 1, False),
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
 ]
