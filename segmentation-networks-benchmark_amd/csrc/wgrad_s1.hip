@@ -22,8 +22,17 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((address_space(3))) bf16x4_t* lds_bf16x4_ptr;
+
+// 8 consecutive reduction-index (pixel) values of one channel per lane = one MFMA operand fragment:
+// two transposing reads of 4 pixel rows each.  (Keep the bf16-typed builtin + shufflevector: assembling the
+// fragment element by element from the v4i16 form is mis-lowered by hipcc 7.2 -- half the elements dropped.)
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* p, int row4_bytes) {
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + row4_bytes));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 struct WgS1Args {
     const bf16_t* x;
@@ -155,25 +164,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s1x9_kernel(const WgS1Args 
             const int s = s0 * KSPLIT + kpart;
             const int rr = s / SEGS, cs = (s - rr * SEGS) * 16;
             const unsigned char* pa = sY + a_off + (rr * WT + cs) * SY;
-            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa));
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + 4 * SY));
-            bf16x8_t af;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                af[e] = __builtin_bit_cast(__bf16, a0[e]);
-                af[4 + e] = __builtin_bit_cast(__bf16, a1[e]);
-            }
+            const bf16x8_t af = tr_frag(pa, 4 * SY);
             const unsigned char* pb = sX + b_off + (rr * XC + cs) * SX;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + tap_off[t]));
-                const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pb + tap_off[t] + 4 * SX));
-                bf16x8_t bfr;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bfr[e] = __builtin_bit_cast(__bf16, b0[e]);
-                    bfr[4 + e] = __builtin_bit_cast(__bf16, b1[e]);
-                }
+                const bf16x8_t bfr = tr_frag(pb + tap_off[t], 4 * SX);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
             }
         }
