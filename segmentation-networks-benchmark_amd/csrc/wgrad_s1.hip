@@ -180,6 +180,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s1x9_kernel(const WgS1Args 
     }
 
     // D[i = co][j = ci]: lane holds column ci = lane&31, rows co = (e&3) + 8*(e>>2) + 4*h
+    if (KSPLIT > 1) {
+        // the waves hold partial sums of the SAME 32x32x9 tile: merge them in LDS (tiles are dead by now: the
+        // loop ended on a barrier), one atomic per element per block instead of four
+        float* sAcc = reinterpret_cast<float*>(smem);          // [9][16][64] floats = 36 KB
+        for (int w = 1; w < KSPLIT; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float* dst = sAcc + (t * 16 + e) * 64 + lane;
+                        *dst = (w == 1) ? acc[t][e] : (*dst + acc[t][e]);
+                    }
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] += sAcc[(t * 16 + e) * 64 + lane];
+    }
     const int ci = ci0 + sci * 32 + (lane & 31);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -207,8 +229,10 @@ int launch_s1(WgS1Args& a, hipStream_t stream) {
     const int ncot = (a.Co + BCO - 1) / BCO;
     a.TCI_TILES = (a.Ci + BCI - 1) / BCI;
     const int tiles = ncot * a.TCI_TILES;
-    int S = (segnb_num_cus() * 4 + tiles - 1) / tiles;
-    if (S > a.IT) S = a.IT;
+    // two resident blocks per CU; every block ends with an atomic merge of its whole [BCO][9*BCI] partial, so
+    // keep the pixel split coarse: at least 6 iterations per block
+    int S = (segnb_num_cus() * 2 + tiles - 1) / tiles;
+    if (S > a.IT / 6) S = a.IT / 6;
     if (S < 1) S = 1;
     a.its_per_split = (a.IT + S - 1) / S;
     S = (a.IT + a.its_per_split - 1) / a.its_per_split;
