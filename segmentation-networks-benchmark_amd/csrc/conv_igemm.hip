@@ -662,6 +662,14 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     a.Ktot = g->ntaps * g->Ci;
     int rc;
     if (dtype == SEGNB_BF16) {
+        // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
+        static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
+        rc = general_only ? 0 : segnb_fprop_s1_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
+        if (rc == 1) {
+            SEGNB_LAUNCH_CHECK();
+            return 0;
+        }
+        if (rc != 0) return rc;
         a.ksteps = ceil_div(a.Ktot, 64);
         rc = dispatch_fprop<bf16_t>(a, (hipStream_t)stream);
     } else if (dtype == SEGNB_F32) {
