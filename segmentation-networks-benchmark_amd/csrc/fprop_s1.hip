@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
     }
     const int b_base = (wn * C::WN + r) * SB + h * 16;
 
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = (a.dh[t] * XC + a.dw[t]) * SX;
+
     double st = 0.0;
     const int nsteps = a.NCH * 9;
 
@@ -168,36 +172,39 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
         lstore_x();
         lstore_b(0);
         __syncthreads();
-        for (int step = 0; step < nsteps; ++step) {
-            const int c = step / 9, t = step - c * 9;
-            const int buf = step & 1;
-            const bool more = step + 1 < nsteps;
-            const bool new_chunk = more && t == 8;
-            if (more) gload_b(step + 1);
-            if (new_chunk) gload_x(c + 1);
-            const int toff = (a.dh[t] * XC + a.dw[t]) * SX;
-            const unsigned char* pb = sB + buf * C::B_BYTES + b_base;
+        for (int c = 0; c < a.NCH; ++c) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                bf16x8_t af[TM], bfr[TN];
+            for (int t = 0; t < 9; ++t) {          // unrolled: tap offsets are registers, not per-step kernarg loads
+                const int step = c * 9 + t;
+                const int buf = (c + t) & 1;       // == step & 1
+                const bool more = step + 1 < nsteps;
+                const bool new_chunk = (t == 8) && more;
+                if (more) gload_b(step + 1);
+                if (new_chunk) gload_x(c + 1);
+                const unsigned char* pa = sX + toff[t];
+                const unsigned char* pb = sB + buf * C::B_BYTES + b_base;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8_t*>(sX + a_base[i] + toff + kk * 32);
+                for (int kk = 0; kk < KK; ++kk) {
+                    bf16x8_t af[TM], bfr[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bfr[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * SB + kk * 32);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8_t*>(pa + a_base[i] + kk * 32);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        bfr[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * SB + kk * 32);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+                if (more) lstore_b(buf ^ 1);
+                if (new_chunk) {
+                    __syncthreads();            // every wave is done with the current x tile
+                    lstore_x();
+                }
+                __syncthreads();
             }
-            if (more) lstore_b(buf ^ 1);
-            if (new_chunk) {
-                __syncthreads();            // every wave is done with the current x tile
-                lstore_x();
-            }
-            __syncthreads();
         }
 
         // ---- epilogue ---------------------------------------------------------------------------------

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the convolution kernels on the ZF_UNET bs=32 224x224 shapes (kernel tuning aid).
+
+    python tools/layer_bench.py [--reps 20] [--batch 32] [--size 224] [--what fprop,dgrad,wgrad]
+
+Each line: layer, shape, time per launch (HIP events on the launch stream, mean of `reps` back-to-back
+launches) and algorithmic TFLOP/s.  SEGNB_FPROP_GENERAL=1 / SEGNB_WGRAD_GENERAL=1 select the general gather
+kernels for an A/B in a second process."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'segmentation-networks-benchmark_amd'))
+sys.path.insert(0, ROOT)
+import torch
+
+from segnb import convplan as cp
+from segnb.engine import ConvOp, Runtime, View
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--what', default='fprop,dgrad,wgrad')
+    ap.add_argument('--dtype', default='bf16')
+    args = ap.parse_args()
+    rt = Runtime('cuda', args.dtype)
+    f, N, S = 32, args.batch, args.size
+    w = [f, 2 * f, 4 * f, 8 * f, 16 * f, 32 * f]
+    layers = []
+    cin = 3
+    for i in range(6):
+        layers.append(('enc%d.l1' % i, S >> i, [(cin, cp.pad8(cin))], w[i]))
+        layers.append(('enc%d.l2' % i, S >> i, [(w[i], w[i])], w[i]))
+        cin = w[i]
+    for lvl in (4, 3, 2, 1, 0):
+        layers.append(('dec%d.l1' % lvl, S >> lvl, [(w[lvl + 1], w[lvl + 1]), (w[lvl], w[lvl])], w[lvl]))
+        layers.append(('dec%d.l2' % lvl, S >> lvl, [(w[lvl], w[lvl])], w[lvl]))
+    tot = {}
+    for name, hw, segs, co in layers:
+        ci = sum(r for r, _ in segs)
+        wt = torch.randn(co, ci, 3, 3, device='cuda') * 0.05
+        op = ConvOp(rt, wt, torch.zeros(co, device='cuda'), segs, 1, 1, False, True)
+        op.pack(hw, hw)
+        xv = View.alloc(rt, N, hw, hw, op.Cip)
+        xv.t.normal_()
+        yv = View.alloc(rt, N, hw, hw, op.Cop)
+        dyv = View.alloc(rt, N, hw, hw, op.Cop)
+        dyv.t.normal_()
+        dxv = View.alloc(rt, N, hw, hw, op.Cip)
+        gw = torch.zeros_like(wt)
+        stats = rt.zeros((2, op.Cop), torch.float64)
+        flops = 2.0 * N * hw * hw * 9 * ci * co
+        line = '%-9s %4dx%-4d %4d->%-4d' % (name, hw, hw, ci, co)
+        for what in args.what.split(','):
+            fn = {'fprop': lambda: op.fprop(xv, yv, stats), 'dgrad': lambda: op.dgrad(dyv, dxv),
+                  'wgrad': lambda: op.wgrad(xv, dyv, gw)}[what]
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / args.reps * 1e3
+            tot[what] = tot.get(what, 0.0) + us
+            line += '  %s %7.1f us %6.0f TF' % (what, us, flops / us / 1e6)
+        print(line)
+    print('totals (us): ' + '  '.join('%s %.0f' % kv for kv in tot.items()))
+
+
+if __name__ == '__main__':
+    main()
