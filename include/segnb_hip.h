@@ -35,6 +35,10 @@ enum { SEGNB_ACT_NONE = 0, SEGNB_ACT_RELU = 1, SEGNB_ACT_LEAKY = 2 };
 enum { SEGNB_E_BADARG = -1, SEGNB_E_UNSUPPORTED = -2 };
 
 #define SEGNB_MAX_TAPS 64
+/* Per-channel accumulators (`stats` of segnb_conv_fprop, `sums` of segnb_bn_act_bwd_reduce) are kept in
+ * SEGNB_STAT_REPLICAS interleaved copies, [replica][2][Cp] fp64, so that the hundreds of workgroups that end
+ * with an atomic add per channel do not serialise on one address; the finalize calls sum and re-zero them. */
+#define SEGNB_STAT_REPLICAS 16
 
 const char* segnb_last_error(void);
 int segnb_version(void);
@@ -65,7 +69,7 @@ typedef struct {
 } segnb_conv_geom;
 
 /* Implicit-GEMM forward on MFMA.  wpacked: [Co][ntaps*Ci] of `dtype` (segnb_pack_weight).
- * bias: fp32 [bias_n] (the real, unpadded parameter; channels >= bias_n get 0) or NULL.  stats: fp64 [2][Co] (sum, sum of squares of the STORED outputs over all
+ * bias: fp32 [bias_n] (the real, unpadded parameter; channels >= bias_n get 0) or NULL.  stats: fp64 [SEGNB_STAT_REPLICAS][2][Co] (sum, sum of squares of the STORED outputs over all
  * written pixels, accumulated atomically; caller zeroes) or NULL -- the BatchNorm batch statistics
  * of nn.BatchNorm2d in training mode (zf_unet.py:9,15) fused into the conv epilogue. */
 int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
@@ -98,7 +102,7 @@ int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out,
  * as inplace_abn's mean_var / forward / edz_eydz / backward (lib/modules/abn/functions.py:81,94,112,118).
  * ------------------------------------------------------------------------------------------- */
 
-/* stats [2][Cp] (from segnb_conv_fprop) -> per-channel affine + running-stat update.
+/* stats [SEGNB_STAT_REPLICAS][2][Cp] (from segnb_conv_fprop) -> per-channel affine + running-stat update.
  * coef: fp32 [4][Cp] = scale(=gamma*invstd), beta, mean, invstd; z = (y - mean)*scale + beta.  Channels
  * >= C get all-zero rows.  training != 0: batch stats, running_mean/var updated with `momentum`
  * (unbiased var, nn.BatchNorm2d semantics), *nbt += 1, and `stats` is CONSUMED (re-zeroed for the next
@@ -118,7 +122,8 @@ int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, in
                      segnb_stream_t stream);
 
 /* dz = act'(z) * dropmul * (g_direct + maxpool_bwd(g_pool) + upsample_bwd(g_up)); any source may be
- * NULL.  Writes dz; accumulates sums[0][c] += sum dz, sums[1][c] += sum dz*yhat (fp64 [2][Cp]). */
+ * NULL.  Writes dz; accumulates sums[r][0][c] += sum dz, sums[r][1][c] += sum dz*yhat
+ * (fp64 [SEGNB_STAT_REPLICAS][2][Cp]). */
 int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                             const float* coef, int act, float slope, const float* dropmul,
                             const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,

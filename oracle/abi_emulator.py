@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 F32, BF16 = 0, 1
+REPL = 16      # SEGNB_STAT_REPLICAS
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
@@ -84,7 +85,7 @@ class AbiEmulator(object):
         ow = torch.arange(g.QW) * g.out_step + g.ow0
         O[:, oh[:, None], ow[None, :], :] = stored
         if stats is not None:
-            S = _mem(stats, 2 * g.Co, torch.float64).view(2, g.Co)
+            S = _mem(stats, REPL * 2 * g.Co, torch.float64).view(REPL, 2, g.Co)[0]
             v = stored.double().reshape(-1, g.Co)
             S[0] += v.sum(0)
             S[1] += (v * v).sum(0)
@@ -146,7 +147,8 @@ class AbiEmulator(object):
         co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
         co.zero_()
         if training:
-            S = _mem(stats, 2 * Cp, torch.float64).view(2, Cp)
+            SR = _mem(stats, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)
+            S = SR.sum(0)
             mu = S[0, :C] / count
             var = (S[1, :C] / count - mu * mu).clamp(min=0)
             if rm is not None:
@@ -156,7 +158,7 @@ class AbiEmulator(object):
                 RV.copy_(((1 - momentum) * RV.double() + momentum * unb).float())
             if nbt is not None:
                 _mem(nbt, 1, torch.int64).add_(1)
-            S.zero_()
+            SR.zero_()
         else:
             mu = _mem(rm, C, torch.float32).double()
             var = _mem(rv, C, torch.float32).double()
@@ -242,7 +244,7 @@ class AbiEmulator(object):
         d = d.to(dt)
         _nhwc(dz, N, H, W, Cp, ld_dz, dt).copy_(d)
         if sums is not None:
-            S = _mem(sums, 2 * Cp, torch.float64).view(2, Cp)
+            S = _mem(sums, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)[0]
             dd = d.double().reshape(-1, Cp)
             S[0] += dd.sum(0)
             if coef is not None:
@@ -252,7 +254,8 @@ class AbiEmulator(object):
         return 0
 
     def segnb_bn_bwd_finalize(self, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream):
-        S = _mem(sums, 2 * Cp, torch.float64).view(2, Cp)
+        SR = _mem(sums, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)
+        S = SR.sum(0)
         co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
         bc = _mem(bcoef, 3 * Cp, torch.float32).view(3, Cp)
         bc.zero_()
@@ -266,7 +269,7 @@ class AbiEmulator(object):
         if dbeta is not None:
             B = _mem(dbeta, C, torch.float32)
             B.copy_((B if accumulate else 0) + S[0, :C].float())
-        S.zero_()
+        SR.zero_()
         return 0
 
     def segnb_bn_bwd_apply(self, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, stream):

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     if (a.stats != nullptr && tid < 2 * BN) {
         const int which = tid / BN, col = tid - which * BN;
         const int co = n_base + col;
-        if (co < g.Co) atomicAdd(&a.stats[(long long)which * g.Co + co], st);
+        if (co < g.Co) atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * g.Co + co], st);
     }
 }
 

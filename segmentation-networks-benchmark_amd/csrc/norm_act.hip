@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int NTHR = 256;
+constexpr int REPL = SEGNB_STAT_REPLICAS;
 
 struct EwShape {
     int N, H, W, Cp;
@@ -39,6 +40,8 @@ static dim3 make_grid(const EwShape& s, long long items, int max_blocks = 2048) 
     long long cap = max_blocks / gy;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
+    const long long want = (items + 4ll * s.PY - 1) / (4ll * s.PY);     // >= 4 items per thread
+    if (gx > want) gx = want;
     if (gx < 1) gx = 1;
     return dim3((unsigned)gx, (unsigned)gy);
 }
@@ -66,10 +69,15 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, int Cp, do
     if (c < C) {
         double mu, var;
         if (training) {
-            mu = stats[c] / count;
-            var = stats[Cp + c] / count - mu * mu;
-            stats[c] = 0.0;
-            stats[Cp + c] = 0.0;
+            double s1 = 0.0, s2 = 0.0;
+            for (int rp = 0; rp < REPL; ++rp) {
+                s1 += stats[(rp * 2) * Cp + c];
+                s2 += stats[(rp * 2 + 1) * Cp + c];
+                stats[(rp * 2) * Cp + c] = 0.0;
+                stats[(rp * 2 + 1) * Cp + c] = 0.0;
+            }
+            mu = s1 / count;
+            var = s2 / count - mu * mu;
             if (var < 0.0) var = 0.0;
             if (running_mean != nullptr) {
                 const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -331,7 +339,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) s2[e] = 0.f;
         }
-        block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, sums, sums + s.Cp, sred);
+        double* rep = sums + (long long)(blockIdx.x % REPL) * 2 * s.Cp;
+        block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + s.Cp, sred);
     }
 }
 
@@ -342,9 +351,13 @@ __global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int Cp,
     if (c >= Cp) return;
     float a = 0.f, c1 = 0.f, c2 = 0.f;
     if (c < C) {
-        const double sdz = sums[c], sdzy = sums[Cp + c];
-        sums[c] = 0.0;
-        sums[Cp + c] = 0.0;
+        double sdz = 0.0, sdzy = 0.0;
+        for (int rp = 0; rp < REPL; ++rp) {
+            sdz += sums[(rp * 2) * Cp + c];
+            sdzy += sums[(rp * 2 + 1) * Cp + c];
+            sums[(rp * 2) * Cp + c] = 0.0;
+            sums[(rp * 2 + 1) * Cp + c] = 0.0;
+        }
         const float g = gamma != nullptr ? gamma[c] : 1.f;
         a = g * coef[3 * Cp + c];
         c1 = (float)(sdz / count);

@@ -12,6 +12,7 @@ from . import _native as nv
 from . import convplan as cp
 
 BN_EPS = 1e-5
+STAT_REPLICAS = 16     # SEGNB_STAT_REPLICAS
 BN_MOMENTUM = 0.1
 
 
@@ -265,8 +266,8 @@ class Stage(object):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
         Cp = conv.Cop
         self.C, self.Cp = conv.Co, Cp
-        self.stats = rt.zeros((2, Cp), torch.float64)     # consumed + re-zeroed by segnb_bn_finalize
-        self.sums = rt.zeros((2, Cp), torch.float64)      # consumed + re-zeroed by segnb_bn_bwd_finalize
+        self.stats = rt.zeros((STAT_REPLICAS, 2, Cp), torch.float64)   # consumed + re-zeroed by segnb_bn_finalize
+        self.sums = rt.zeros((STAT_REPLICAS, 2, Cp), torch.float64)    # consumed + re-zeroed by segnb_bn_bwd_finalize
         self.coef = rt.zeros((4, Cp), torch.float32)
         self.bcoef = rt.zeros((3, Cp), torch.float32)
         self._bufs = {}
@@ -316,8 +317,11 @@ class Stage(object):
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count,
                     nv.ptr(self.bn.weight.detach()), nv.ptr(self.coef), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1, rt.stream)
+            # d(loss)/d(conv bias) under training-mode BatchNorm is identically zero (BN subtracts the batch mean):
+            # sum(dy) = A*(sum dz - n*mean(dz) - mean(dz*yhat)*sum(yhat)) = 0.  The reference's fp32 value is pure
+            # summation noise (~1e-7 of the weight-gradient scale); the flat gradient buffer already holds 0.
             nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(self.coef),
-                    nv.ptr(self.bcoef), dz.ptr, dz.ld, dz.ptr, dz.ld, nv.ptr(gbias), self.C, rt.stream)
+                    nv.ptr(self.bcoef), dz.ptr, dz.ld, dz.ptr, dz.ld, None, self.C, rt.stream)
         else:
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),

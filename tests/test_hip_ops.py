@@ -108,7 +108,7 @@ def _run_conv(device, dtype, case, w, b, x_nchw, dy_nchw):
         off += padded
         roff += real
     yv = View.alloc(rt, N, Ho, Wo, op.Cop)
-    stats = rt.zeros((2, op.Cop), torch.float64)
+    stats = rt.zeros((16, 2, op.Cop), torch.float64)       # SEGNB_STAT_REPLICAS copies
     op.fprop(xv, yv, stats)
     dyv = View.alloc(rt, N, Ho, Wo, op.Cop)
     dyv.dense()[..., :Co] = dy_nchw.permute(0, 2, 3, 1).to(device, rt.tdtype)
@@ -118,7 +118,7 @@ def _run_conv(device, dtype, case, w, b, x_nchw, dy_nchw):
     op.wgrad(xv, dyv, gw)
     if device != 'cpu':
         torch.cuda.synchronize()
-    return (yv.dense().float().cpu(), stats.cpu(), dxv.dense().float().cpu(), gw.cpu(), segs, Co)
+    return (yv.dense().float().cpu(), stats.sum(0).cpu(), dxv.dense().float().cpu(), gw.cpu(), segs, Co)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -176,10 +176,10 @@ def _run_bn(device, dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
     dev = rt.device
     yv = View.alloc(rt, N, H, W, Cp)
     yv.dense()[..., :C] = y.to(dev, rt.tdtype)
-    stats = torch.zeros(2, Cp, dtype=torch.float64, device=dev)
+    stats = torch.zeros(16, 2, Cp, dtype=torch.float64, device=dev)
     yy = yv.dense().double()
-    stats[0] = yy.sum((0, 1, 2))
-    stats[1] = (yy * yy).sum((0, 1, 2))
+    stats[3, 0] = yy.sum((0, 1, 2))        # any replica: the finalize sums them
+    stats[11, 1] = (yy * yy).sum((0, 1, 2))
     coef = rt.zeros((4, Cp), torch.float32)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
@@ -206,12 +206,12 @@ def _run_bn(device, dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
         gupv = View.alloc(rt, N, 2 * H, 2 * W, Cp)
         gupv.dense()[..., :C] = gu.to(dev, rt.tdtype)
     dz = View.alloc(rt, N, H, W, Cp)
-    sums = rt.zeros((2, Cp), torch.float64)
+    sums = rt.zeros((16, 2, Cp), torch.float64)
     nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
             gdv.ptr, gdv.ld, None if gpv is None else gpv.ptr, 0 if gpv is None else gpv.ld,
             None if gupv is None else gupv.ptr, 0 if gupv is None else gupv.ld, dz.ptr, dz.ld, nv.ptr(sums),
             rt.stream)
-    sums_copy = sums.clone()
+    sums_copy = sums.sum(0)
     bcoef = rt.zeros((3, Cp), torch.float32)
     dgam, dbet, dbias = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(coef), nv.ptr(bcoef),

@@ -52,7 +52,7 @@ def main():
         dyv.t.normal_()
         dxv = View.alloc(rt, N, hw, hw, op.Cip)
         gw = torch.zeros_like(wt)
-        stats = rt.zeros((2, op.Cop), torch.float64)
+        stats = rt.zeros((16, 2, op.Cop), torch.float64)
         flops = 2.0 * N * hw * hw * 9 * ci * co
         line = '%-9s %4dx%-4d %4d->%-4d' % (name, hw, hw, ci, co)
         for what in args.what.split(','):
