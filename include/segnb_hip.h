@@ -92,6 +92,17 @@ int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long lo
                        long long s_c, const int* tap_off_host, const int* mmap, const int* cmap,
                        int accumulate, segnb_stream_t stream);
 
+/* Batched forms: one launch for every weight matrix of a model (one for every gradient).  `jobs` is a DEVICE
+ * array of njobs records, each segnb_pack_job_bytes() long:
+ *   { const float* param_or_grad; void* packed; const int* mmap; const int* cmap; int64 s_m, s_c;
+ *     int32 Mp, Cp, ntaps, dtype, block_start, pad; int32 tap_off[SEGNB_MAX_TAPS]; }
+ * sorted by block_start, job k owning blocks [block_start_k, block_start_{k+1}) of
+ * segnb_pack_elems_per_block() packed elements each.  unpack ADDS into the gradient and re-zeroes the workspace. */
+int segnb_pack_job_bytes(void);
+int segnb_pack_elems_per_block(void);
+int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
+int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
+
 /* NCHW fp32 network input -> NHWC `dtype`, channels zero-padded to Cp (torch_train.py:177 hands the
  * model a float32 [N,3,H,W] batch, lib/common.py:70). */
 int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out, int dtype, int Cp,

@@ -135,6 +135,36 @@ class AbiEmulator(object):
         src.zero_()
         return 0
 
+    # batched forms: decode the device job table (segnb.engine.PACK_JOB_DTYPE) and run the single-job methods
+    JOB_BYTES, ELEMS_PER_BLOCK = 328, 2048
+
+    def segnb_pack_job_bytes(self):
+        return self.JOB_BYTES
+
+    def segnb_pack_elems_per_block(self):
+        return self.ELEMS_PER_BLOCK
+
+    def _jobs(self, jobs, njobs):
+        raw = bytes((ctypes.c_char * (njobs * self.JOB_BYTES)).from_address(int(jobs)))
+        dt = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
+                       ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
+                       ('block_start', '<i4'), ('pad', '<i4'), ('tap_off', '<i4', (64,))])
+        return np.frombuffer(raw, dtype=dt)
+
+    def segnb_pack_weight_multi(self, jobs, njobs, total_blocks, stream):
+        for j in self._jobs(jobs, njobs):
+            self.segnb_pack_weight(int(j['w']), int(j['packed']), int(j['dtype']), int(j['Mp']), int(j['Cp']),
+                                   int(j['ntaps']), int(j['s_m']), int(j['s_c']),
+                                   [int(v) for v in j['tap_off'][:int(j['ntaps'])]], int(j['mmap']), int(j['cmap']), stream)
+        return 0
+
+    def segnb_unpack_wgrad_multi(self, jobs, njobs, total_blocks, stream):
+        for j in self._jobs(jobs, njobs):
+            self.segnb_unpack_wgrad(int(j['packed']), int(j['w']), int(j['Mp']), int(j['Cp']), int(j['ntaps']),
+                                    int(j['s_m']), int(j['s_c']), [int(v) for v in j['tap_off'][:int(j['ntaps'])]],
+                                    int(j['mmap']), int(j['cmap']), 1, stream)
+        return 0
+
     def segnb_pack_input_nchw(self, x, N, C, H, W, out, dtype, Cp, ld_out, stream):
         X = _mem(x, N * C * H * W, torch.float32).view(N, C, H, W)
         O = _nhwc(out, N, H, W, Cp, ld_out, _tdt(dtype))

@@ -524,6 +524,70 @@ __global__ void unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__
     }
 }
 
+// ---- batched forms: ONE launch packs every weight matrix of a model (or unpacks every gradient) --------
+// job table in device memory (built once by the host, pointers are stable); block -> job by binary search
+struct __attribute__((aligned(8))) PackJob {
+    const float* w;          // pack: fp32 parameter (source);  unpack: fp32 gradient (destination)
+    void* packed;            // pack: destination (dtype);      unpack: fp32 workspace (source, re-zeroed)
+    const int* mmap;
+    const int* cmap;
+    long long s_m, s_c;
+    int Mp, Cp, ntaps, dtype;
+    int block_start;         // first block of this job; jobs sorted by it
+    int pad_;
+    int tap_off[SEGNB_MAX_TAPS];
+};
+constexpr int PACK_ELEMS_PER_BLOCK = 2048;
+
+__device__ __forceinline__ int find_job(const PackJob* jobs, int njobs, int b) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
+    const long long total = (long long)j.Mp * j.ntaps * j.Cp;
+    const long long base = (long long)(blockIdx.x - j.block_start) * PACK_ELEMS_PER_BLOCK;
+    for (int k = threadIdx.x; k < PACK_ELEMS_PER_BLOCK; k += 256) {
+        const long long i = base + k;
+        if (i >= total) break;
+        const int cp = (int)(i % j.Cp);
+        const long long q = i / j.Cp;
+        const int t = (int)(q % j.ntaps);
+        const int mp = (int)(q / j.ntaps);
+        const int m = j.mmap[mp], c = j.cmap[cp];
+        float v = 0.f;
+        if (m >= 0 && c >= 0) v = j.w[m * j.s_m + c * j.s_c + j.tap_off[t]];
+        if (j.dtype == SEGNB_BF16)
+            reinterpret_cast<bf16_t*>(j.packed)[i] = Elem<bf16_t>::from_f32(v);
+        else
+            reinterpret_cast<float*>(j.packed)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
+    const long long total = (long long)j.Mp * j.ntaps * j.Cp;
+    const long long base = (long long)(blockIdx.x - j.block_start) * PACK_ELEMS_PER_BLOCK;
+    float* dwp = reinterpret_cast<float*>(j.packed);
+    float* gw = const_cast<float*>(j.w);
+    for (int k = threadIdx.x; k < PACK_ELEMS_PER_BLOCK; k += 256) {
+        const long long i = base + k;
+        if (i >= total) break;
+        const int cp = (int)(i % j.Cp);
+        const long long q = i / j.Cp;
+        const int t = (int)(q % j.ntaps);
+        const int mp = (int)(q / j.ntaps);
+        const int m = j.mmap[mp], c = j.cmap[cp];
+        if (m >= 0 && c >= 0) gw[m * j.s_m + c * j.s_c + j.tap_off[t]] += dwp[i];
+        dwp[i] = 0.f;
+    }
+}
+
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W,
                                   int Cp, int ld) {
@@ -765,6 +829,25 @@ extern "C" int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int nta
     int grid = ceil_div(total, 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwp, gw, p, accumulate);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+extern "C" int segnb_pack_elems_per_block(void) { return PACK_ELEMS_PER_BLOCK; }
+
+extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
+    hipLaunchKernelGGL(unpack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

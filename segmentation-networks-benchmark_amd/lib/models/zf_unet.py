@@ -18,7 +18,7 @@ from torch import nn
 
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.engine import ConvOp, FlatParams, Runtime, Stage, View
+from segnb.engine import ConvOp, FlatParams, PackTable, Runtime, Stage, View
 
 ENCODER = ('conv_224', 'conv_112', 'conv_56', 'conv_28', 'conv_14', 'conv_7')
 DECODER = ('up_conv_14', 'up_conv_28', 'up_conv_56', 'up_conv_112', 'up_conv_224')
@@ -135,6 +135,7 @@ class _ZFUnetPlan(object):
             seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
             self._add(name, blk, seg1, True)
         self._bufs = {}
+        self._pack_tables = {}
         self._packed_key = None
         self.K = module.num_classes
 
@@ -145,6 +146,8 @@ class _ZFUnetPlan(object):
         c2 = ConvOp(rt, blk.l2.conv.weight, blk.l2.conv.bias, [(cout, cp.pad8(cout))], 1, 1, False, True)
         self.stages[name] = (Stage(rt, c1, blk.l1.bn, nv.ACT_RELU, 0.0, name + '.l1'),
                              Stage(rt, c2, blk.l2.bn, nv.ACT_RELU, 0.0, name + '.l2'))
+        for st in self.stages[name]:
+            st.defer_unpack = True         # one batched unpack at the end of backward()
 
     # ---- buffers for one input geometry -------------------------------------------------------------
     def buffers(self, N, H, W):
@@ -170,44 +173,68 @@ class _ZFUnetPlan(object):
         b['f0'] = View.alloc(rt, N, H, W, wp[0])
         b['df0'] = View.alloc(rt, N, H, W, wp[0])
         b['logits'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
-        b['drop'] = torch.ones((11, N, max(wp)), dtype=torch.float32, device=rt.device)
+        sizes = [(n, self.stages[n][1].Cp) for n in ENCODER + DECODER]
+        b['drop_flat'] = torch.ones(sum(N * c for _, c in sizes), dtype=torch.float32, device=rt.device)
+        b['drop'], off = {}, 0
+        for n, c in sizes:
+            b['drop'][n] = b['drop_flat'][off:off + N * c].view(N, c)
+            off += N * c
         self._bufs[key] = b
         return b
+
+    def _conv_sizes(self, H, W):
+        """(ConvOp, input height, input width) of every convolution of the net."""
+        out = []
+        for i, name in enumerate(ENCODER):
+            out += [(st.conv, H >> i, W >> i) for st in self.stages[name]]
+        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+            out += [(st.conv, H >> lvl, W >> lvl) for st in self.stages[name]]
+        return out
+
+    def _tables(self, H, W):
+        """One-launch weight pack / gradient unpack tables for this input size (rebuilt if the flat parameter
+        buffers were re-created)."""
+        key = (H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr())
+        t = self._pack_tables.get((H, W))
+        if t is None or t[0] != key:
+            pj, uj = [], []
+            for conv, h, w in self._conv_sizes(H, W):
+                pj += conv.pack_jobs(h, w)
+                uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
+            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi'),
+                 PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi'))
+            self._pack_tables[(H, W)] = t
+        return t
 
     def _pack_if_needed(self, H, W):
         key = (sum(p._version for p in self.module.parameters()), self.flat.version, H, W,
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return
-        for i, name in enumerate(ENCODER):
-            for st in self.stages[name]:
-                st.conv.pack(H >> i, W >> i)
-        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
-            for st in self.stages[name]:
-                st.conv.pack(H >> lvl, W >> lvl)
+        self._tables(H, W)[1].run()
         self._packed_key = key
 
     def _dropout_tables(self, b, N, train):
-        """Per-block [N, Cp] multiplier tables (0 or 1/(1-p)); None when Dropout2d is inactive."""
+        """Per-block [N, Cp] multiplier tables (0 or 1/(1-p)); None when Dropout2d is inactive.  All eleven
+        tables live in one buffer drawn by ONE bernoulli launch per step (lib/models/zf_unet.py:25,31 draws
+        one Dropout2d mask per block)."""
         names = ENCODER + DECODER
         ov = self.module.dropout_override
         if not train or (self.p_drop <= 0.0 and ov is None):
             return {n: None for n in names}
-        out = {}
+        tabs = b['drop']                         # {name: fp32 [N, Cp] view of one flat buffer}
         if ov is None:
-            d = b['drop']
-            d.bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
-        for k, n in enumerate(names):
-            Cp = self.stages[n][1].Cp
-            t = torch.ones((N, Cp), dtype=torch.float32, device=self.rt.device)
-            if ov is not None:
-                src = ov.get(n)
-                if src is None:
-                    out[n] = None
-                    continue
-                t[:, :src.shape[1]] = src.to(self.rt.device, torch.float32)
-            else:
-                t = b['drop'][k, :, :Cp].contiguous()
+            b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
+            return tabs
+        out = {}
+        for n in names:
+            src = ov.get(n)
+            if src is None:
+                out[n] = None
+                continue
+            t = tabs[n]
+            t.fill_(1.0)
+            t[:, :src.shape[1]] = src.to(self.rt.device, torch.float32)
             out[n] = t
         return out
 
@@ -273,6 +300,7 @@ class _ZFUnetPlan(object):
                 s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
                             dx=b['da1_%d' % i])
             s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
+        self._tables(H, W)[2].run()          # every packed weight-gradient workspace -> flat gradient buffer
         self._after_backward()
         # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not
         # returned through autograd, so they never get cloned and a flat optimizer / all-reduce can run)

@@ -47,6 +47,8 @@ SIGNATURES = {
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, _P],
     'segnb_pack_weight': [_P, _P, c_int, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, _P],
     'segnb_unpack_wgrad': [_P, _P, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, c_int, _P],
+    'segnb_pack_weight_multi': [_P, c_int, c_int, _P],
+    'segnb_unpack_wgrad_multi': [_P, c_int, c_int, _P],
     'segnb_pack_input_nchw': [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P],
     'segnb_bn_finalize': [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P],
     'segnb_bn_act_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P,
@@ -63,7 +65,7 @@ SIGNATURES = {
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_elems_per_block': (c_int, []), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None
@@ -114,6 +116,13 @@ def call(name, *args):
         msg = lib.segnb_last_error()
         raise RuntimeError('HIP error encountered in %s (status %d): %s'
                            % (name, rc, msg.decode() if msg else ''))
+
+
+def query(name):
+    """Plain int-returning ABI query (no status convention)."""
+    if _test_backend is not None:
+        return getattr(_test_backend, name)()
+    return getattr(load(), name)()
 
 
 def ptr(t, offset_elems=0):

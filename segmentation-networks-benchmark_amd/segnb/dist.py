@@ -30,7 +30,8 @@ def rank():
 def init_from_env(backend=None):
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or td.is_initialized():
+    # a 1-rank group is only useful to exercise the collective path on a single GPU (SEGNB_DP_FORCE=1)
+    if td.is_initialized() or (ws <= 1 and not os.environ.get('SEGNB_DP_FORCE')) or 'RANK' not in os.environ:
         return
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -51,13 +52,14 @@ class DataParallel(object):
         self.model = model
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.ws = world()
+        self.active = self.ws > 1 or (bool(os.environ.get('SEGNB_DP_FORCE')) and td.is_initialized())
         self._synced = False
         self._comm_stream = None
         model._grad_sync_hook = self.sync_grads
         model._grad_ready_hook = self.grads_ready
         self._pending = []
         self._done_upto = None
-        if self.ws > 1:
+        if self.active:
             seglosses.sums_allreduce_hook = self._allreduce_sums
             seglosses.grad_scale = float(self.ws)
 
@@ -66,7 +68,7 @@ class DataParallel(object):
 
     # ---- parameters ------------------------------------------------------------------------------------
     def broadcast_parameters(self, flat):
-        if self.ws > 1 and not self._synced:
+        if self.active and not self._synced:
             td.broadcast(flat.flat_p, src=0)
             for b in self.model.buffers():
                 td.broadcast(b, src=0)
@@ -89,7 +91,7 @@ class DataParallel(object):
         """Called by the backward plan when every gradient at flat offset >= lo is final (the plan runs
         decoder -> encoder, i.e. from the END of the flat buffer towards its start).  Launches the
         all-reduce of every full bucket that became ready, on the side stream."""
-        if self.ws <= 1:
+        if not self.active:
             return
         hi = flat.total if self._done_upto is None else self._done_upto
         while hi - lo >= self.bucket_elems or (lo == 0 and hi > 0):
@@ -112,7 +114,7 @@ class DataParallel(object):
 
     def sync_grads(self, flat):
         """End of backward: reduce whatever is left, then make the compute stream wait for the collectives."""
-        if self.ws <= 1:
+        if not self.active:
             return
         self.grads_ready(flat, 0)
         self._done_upto = None

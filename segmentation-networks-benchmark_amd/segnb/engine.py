@@ -6,6 +6,7 @@ stream; every FLOP and every byte moved on the hot path happens inside libsegnb_
 code drives any device the ABI backend can address, which is what lets tests check the plan logic
 (buffer wiring, tap tables, channel maps, backward routing) on CPU against an ABI emulator.
 """
+import numpy as np
 import torch
 
 from . import _native as nv
@@ -209,6 +210,38 @@ class ConvOp(object):
                         len(l.taps), self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map),
                         nv.ptr(self.out_map), rt.stream)
 
+    def pack_jobs(self, Hi, Wi):
+        """Job records (PackTable) equivalent to pack(Hi, Wi)."""
+        p, rt = self.plan(Hi, Wi), self.rt
+        w = self.weight.detach()
+        jobs = []
+        for li, l in enumerate(p['fwd']):
+            jobs.append(dict(w=w, packed=p['wp_fwd'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
+                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code,
+                             tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+        if self.need_dgrad:
+            for li, l in enumerate(p['dg']):
+                jobs.append(dict(w=w, packed=p['wp_dg'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
+                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code,
+                                 tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+        return jobs
+
+    def unpack_jobs(self, Hi, Wi, grad_w):
+        """Job records equivalent to the segnb_unpack_wgrad calls of wgrad(); use with wgrad(..., unpack=False)."""
+        p = self.plan(Hi, Wi)
+        jobs = []
+        if self.transposed:
+            for li, l in enumerate(p['dg']):
+                jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
+                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32,
+                                 tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+        else:
+            for li, l in enumerate(p['fwd']):
+                jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
+                                 s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=nv.F32,
+                                 tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+        return jobs
+
     # ---- kernels ------------------------------------------------------------------------------------
     def fprop(self, xv, yv, stats=None):
         p, rt = self.plan(xv.H, xv.W), self.rt
@@ -234,8 +267,9 @@ class ConvOp(object):
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
                                    dxv.ptr, None, rt.stream))
 
-    def wgrad(self, xv, dyv, grad_w):
-        """dW accumulated into grad_w (fp32, parameter layout)."""
+    def wgrad(self, xv, dyv, grad_w, unpack=True):
+        """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
+        workspace for a later batched segnb_unpack_wgrad_multi (unpack_jobs)."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         gw = grad_w
         if self.transposed:
@@ -243,18 +277,52 @@ class ConvOp(object):
             for li, l in enumerate(p['dg']):
                 g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
                 nv.call('segnb_conv_wgrad', g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), rt.stream)
-                nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
-                        self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
-                        rt.stream)
+                if unpack:
+                    nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
+                            self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
+                            rt.stream)
             return
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
                    lambda: nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]),
                                    rt.stream))
-            nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
-                    self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,
-                    rt.stream)
+            if unpack:
+                nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
+                        self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,
+                        rt.stream)
+
+
+PACK_JOB_DTYPE = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
+                           ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
+                           ('block_start', '<i4'), ('pad', '<i4'), ('tap_off', '<i4', (nv.MAX_TAPS,))])
+
+
+class PackTable(object):
+    """Device-side job table for segnb_pack_weight_multi / segnb_unpack_wgrad_multi: every weight matrix of a
+    model packed (or every gradient unpacked) by ONE launch.  jobs: dicts with the fields of PACK_JOB_DTYPE
+    (tensors for the pointer fields)."""
+
+    def __init__(self, rt, jobs, entry):
+        assert PACK_JOB_DTYPE.itemsize == nv.query('segnb_pack_job_bytes'), 'PackJob layout drifted from the ABI'
+        per_block = nv.query('segnb_pack_elems_per_block')
+        tab = np.zeros(len(jobs), dtype=PACK_JOB_DTYPE)
+        blocks = 0
+        self._keep = []
+        for k, j in enumerate(jobs):
+            for f in ('w', 'packed', 'mmap', 'cmap'):
+                tab[k][f] = j[f].data_ptr()
+                self._keep.append(j[f])
+            for f in ('s_m', 's_c', 'Mp', 'Cp', 'ntaps', 'dtype'):
+                tab[k][f] = j[f]
+            tab[k]['tap_off'][:len(j['tap_off'])] = j['tap_off']
+            tab[k]['block_start'] = blocks
+            blocks += (j['Mp'] * j['ntaps'] * j['Cp'] + per_block - 1) // per_block
+        self.rt, self.entry, self.n, self.blocks = rt, entry, len(jobs), blocks
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
+
+    def run(self):
+        nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
 
 
 class Stage(object):
@@ -264,6 +332,7 @@ class Stage(object):
 
     def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
+        self.defer_unpack = False     # True: the model plan runs one batched unpack at the end of backward
         Cp = conv.Cop
         self.C, self.Cp = conv.Co, Cp
         self.stats = rt.zeros((STAT_REPLICAS, 2, Cp), torch.float64)   # consumed + re-zeroed by segnb_bn_finalize
@@ -326,7 +395,7 @@ class Stage(object):
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),
                     nv.ptr(self.bcoef), None, nv.ptr(gbias), 1, rt.stream)
-        self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight))
+        self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=not self.defer_unpack)
         if dx is not None:
             self.conv.dgrad(dz, dx)
         return dx

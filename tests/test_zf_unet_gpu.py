@@ -239,3 +239,22 @@ def test_eval_matches_train_statistics_path():
         out = m(x.cuda())
     ref = zf_unet_ref.forward(sd, x, train=False)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-4 * float(ref.abs().max()))
+
+
+def test_bench_runs_over_rccl_single_rank():
+    """The N > 1 launch line of bench.py (torch.distributed.run, backend nccl = RCCL) with ONE rank and the
+    collective path forced on: the bucketed gradient all-reduce on the side stream, the loss-sum all-reduce and
+    the parameter broadcast all execute on this GPU.  (Multi-rank numerics: tests/test_dist_cpu.py.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEGNB_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', '29731', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3',
+           '--warmup', '2', '--batch', '4', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 1 and res['value'] > 0 and np.isfinite(res['final_loss'])
