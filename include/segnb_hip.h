@@ -96,10 +96,12 @@ int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long lo
  * array of njobs records, each segnb_pack_job_bytes() long:
  *   { const float* param_or_grad; void* packed; const int* mmap; const int* cmap; int64 s_m, s_c;
  *     int32 Mp, Cp, ntaps, dtype, block_start, pad; int32 tap_off[SEGNB_MAX_TAPS]; }
- * sorted by block_start, job k owning blocks [block_start_k, block_start_{k+1}) of
- * segnb_pack_elems_per_block() packed elements each.  unpack ADDS into the gradient and re-zeroes the workspace. */
+ * sorted by block_start; job k owns blocks [block_start_k, block_start_k + segnb_pack_job_blocks(...)) (LDS-tiled
+ * transposes: both the parameter side and the packed side are accessed in contiguous runs).
+ * segnb_pack_job_blocks returns -1 for kernels wider than 3x3 (use the single-job calls for those).
+ * unpack ADDS into the gradient and re-zeroes the workspace. */
 int segnb_pack_job_bytes(void);
-int segnb_pack_elems_per_block(void);
+int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, long long s_c);
 int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 

@@ -136,13 +136,17 @@ class AbiEmulator(object):
         return 0
 
     # batched forms: decode the device job table (segnb.engine.PACK_JOB_DTYPE) and run the single-job methods
-    JOB_BYTES, ELEMS_PER_BLOCK = 328, 2048
+    JOB_BYTES = 328
 
     def segnb_pack_job_bytes(self):
         return self.JOB_BYTES
 
-    def segnb_pack_elems_per_block(self):
-        return self.ELEMS_PER_BLOCK
+    def segnb_pack_job_blocks(self, Mp, Cp, ntaps, s_m, s_c):
+        if min(s_m, s_c) > 9 or ntaps > 9:
+            return -1
+        if s_c < s_m:
+            return (Cp + 255) // 256 * Mp
+        return (Mp + 7) // 8 * ((Cp + 63) // 64)
 
     def _jobs(self, jobs, njobs):
         raw = bytes((ctypes.c_char * (njobs * self.JOB_BYTES)).from_address(int(jobs)))

@@ -537,7 +537,6 @@ struct __attribute__((aligned(8))) PackJob {
     int pad_;
     int tap_off[SEGNB_MAX_TAPS];
 };
-constexpr int PACK_ELEMS_PER_BLOCK = 2048;
 
 __device__ __forceinline__ int find_job(const PackJob* jobs, int njobs, int b) {
     int lo = 0, hi = njobs - 1;
@@ -548,43 +547,109 @@ __device__ __forceinline__ int find_job(const PackJob* jobs, int njobs, int b) {
     return lo;
 }
 
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
-    const long long total = (long long)j.Mp * j.ntaps * j.Cp;
-    const long long base = (long long)(blockIdx.x - j.block_start) * PACK_ELEMS_PER_BLOCK;
-    for (int k = threadIdx.x; k < PACK_ELEMS_PER_BLOCK; k += 256) {
-        const long long i = base + k;
-        if (i >= total) break;
-        const int cp = (int)(i % j.Cp);
-        const long long q = i / j.Cp;
-        const int t = (int)(q % j.ntaps);
-        const int mp = (int)(q / j.ntaps);
-        const int m = j.mmap[mp], c = j.cmap[cp];
-        float v = 0.f;
-        if (m >= 0 && c >= 0) v = j.w[m * j.s_m + c * j.s_c + j.tap_off[t]];
-        if (j.dtype == SEGNB_BF16)
-            reinterpret_cast<bf16_t*>(j.packed)[i] = Elem<bf16_t>::from_f32(v);
-        else
-            reinterpret_cast<float*>(j.packed)[i] = v;
+// Tiled through LDS so that BOTH sides are coalesced.  The parameter tensor has the tap index fastest
+// (stride 1) and one of the two channel indices at stride T_src = min(s_m, s_c) ("fast" channel), the other at
+// a large stride ("slow" channel).  A tile = SLOW x FAST channels x all taps:
+//   parameter side : for each slow index a run of FAST*T_src contiguous floats
+//   packed side    : [mp][t][cp], contiguous along cp
+// fwd pack  (rows = co slow, cols = ci fast): tile 1 x 256   -> packed runs of 256 elements
+// dgrad pack (rows = ci fast, cols = co slow): tile 8 x 64   -> packed runs of 64 elements
+struct TileGeom {
+    int fast_is_c;      // 1: cp indexes the fast channel (fwd layout), 0: mp does (dgrad layout)
+    int F, S;           // tile extents along fast / slow packed index
+    int nF, nS;         // tiles along each
+    int Tsrc;           // taps in the parameter tensor (KH*KW)
+};
+
+__device__ __forceinline__ TileGeom tile_geom(const PackJob& j) {
+    TileGeom g;
+    g.fast_is_c = j.s_c < j.s_m;
+    g.Tsrc = (int)(g.fast_is_c ? j.s_c : j.s_m);
+    if (g.fast_is_c) {
+        g.F = 256; g.S = 1;
+        g.nF = (j.Cp + g.F - 1) / g.F; g.nS = j.Mp;
+    } else {
+        g.F = 8; g.S = 64;
+        g.nF = (j.Mp + g.F - 1) / g.F; g.nS = (j.Cp + g.S - 1) / g.S;
     }
+    return g;
 }
 
-__global__ __launch_bounds__(256) void unpack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+constexpr int PACK_LDS_FLOATS = 256 * 9 > 64 * 8 * 9 ? 256 * 9 : 64 * 8 * 9;   // 4608
+
+// is_pack: parameter -> packed (round to dtype); else packed fp32 workspace -> += gradient, workspace zeroed
+template <bool IS_PACK>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[PACK_LDS_FLOATS];
     const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
-    const long long total = (long long)j.Mp * j.ntaps * j.Cp;
-    const long long base = (long long)(blockIdx.x - j.block_start) * PACK_ELEMS_PER_BLOCK;
-    float* dwp = reinterpret_cast<float*>(j.packed);
-    float* gw = const_cast<float*>(j.w);
-    for (int k = threadIdx.x; k < PACK_ELEMS_PER_BLOCK; k += 256) {
-        const long long i = base + k;
-        if (i >= total) break;
-        const int cp = (int)(i % j.Cp);
-        const long long q = i / j.Cp;
-        const int t = (int)(q % j.ntaps);
-        const int mp = (int)(q / j.ntaps);
+    const TileGeom g = tile_geom(j);
+    const int tb = blockIdx.x - j.block_start;
+    const int tf = tb % g.nF, ts = tb / g.nF;
+    const int f0 = tf * g.F, s0 = ts * g.S;
+    const int run = g.F * g.Tsrc;                    // contiguous floats per slow index on the parameter side
+    const int Mp = j.Mp, Cp = j.Cp, nt = j.ntaps;
+    float* param = const_cast<float*>(j.w);
+    const int n_param = g.S * run;
+
+    auto param_off = [&](int sl, int fa) -> long long {      // element offset of (slow, fast, tap 0) or -1
+        const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
+        const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
+        if (mp >= Mp || cp >= Cp) return -1;
         const int m = j.mmap[mp], c = j.cmap[cp];
-        if (m >= 0 && c >= 0) gw[m * j.s_m + c * j.s_c + j.tap_off[t]] += dwp[i];
-        dwp[i] = 0.f;
+        if (m < 0 || c < 0) return -1;
+        return m * j.s_m + c * j.s_c;
+    };
+
+    if (IS_PACK) {
+        // parameter -> LDS, in parameter order (coalesced along the fast channel and the taps)
+        for (int i = threadIdx.x; i < n_param; i += 256) {
+            const int sl = i / run, r = i - sl * run;
+            const int fa = r / g.Tsrc, tp = r - fa * g.Tsrc;
+            const long long off = param_off(sl, fa);
+            tile[i] = off >= 0 ? param[off + tp] : 0.f;
+        }
+        __syncthreads();
+        // LDS -> packed, in packed order
+        const int n_packed = g.S * g.F * nt;
+        for (int i = threadIdx.x; i < n_packed; i += 256) {
+            int sl, fa, t;
+            if (g.fast_is_c) { fa = i % g.F; t = (i / g.F) % nt; sl = i / (g.F * nt); }
+            else             { sl = i % g.S; t = (i / g.S) % nt; fa = i / (g.S * nt); }
+            const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
+            const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
+            if (mp < Mp && cp < Cp) {
+                const float v = tile[sl * run + fa * g.Tsrc + j.tap_off[t]];
+                const long long di = ((long long)mp * nt + t) * Cp + cp;
+                if (j.dtype == SEGNB_BF16)
+                    reinterpret_cast<bf16_t*>(j.packed)[di] = Elem<bf16_t>::from_f32(v);
+                else
+                    reinterpret_cast<float*>(j.packed)[di] = v;
+            }
+        }
+    } else {
+        float* dwp = reinterpret_cast<float*>(j.packed);
+        for (int i = threadIdx.x; i < n_param; i += 256) tile[i] = 0.f;
+        __syncthreads();
+        const int n_packed = g.S * g.F * nt;
+        for (int i = threadIdx.x; i < n_packed; i += 256) {
+            int sl, fa, t;
+            if (g.fast_is_c) { fa = i % g.F; t = (i / g.F) % nt; sl = i / (g.F * nt); }
+            else             { sl = i % g.S; t = (i / g.S) % nt; fa = i / (g.S * nt); }
+            const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
+            const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
+            if (mp < Mp && cp < Cp) {
+                const long long di = ((long long)mp * nt + t) * Cp + cp;
+                tile[sl * run + fa * g.Tsrc + j.tap_off[t]] = dwp[di];      // taps are distinct: no collisions
+                dwp[di] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_param; i += 256) {
+            const int sl = i / run, r = i - sl * run;
+            const int fa = r / g.Tsrc, tp = r - fa * g.Tsrc;
+            const long long off = param_off(sl, fa);
+            if (off >= 0) param[off + tp] += tile[i];
+        }
     }
 }
 
@@ -834,11 +899,21 @@ extern "C" int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int nta
 }
 
 extern "C" int segnb_pack_job_bytes(void) { return (int)sizeof(PackJob); }
-extern "C" int segnb_pack_elems_per_block(void) { return PACK_ELEMS_PER_BLOCK; }
+
+// number of blocks (tiles) a job occupies -- the host needs it to fill PackJob.block_start
+extern "C" int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, long long s_c) {
+    PackJob j;
+    j.Mp = Mp; j.Cp = Cp; j.ntaps = ntaps; j.s_m = s_m; j.s_c = s_c;
+    const bool fast_is_c = s_c < s_m;
+    const long long tsrc = fast_is_c ? s_c : s_m;
+    if (tsrc > 9 || ntaps > 9) return -1;           // tiled kernel sized for <= 3x3
+    if (fast_is_c) return ((Cp + 255) / 256) * Mp;
+    return ((Mp + 7) / 8) * ((Cp + 63) / 64);
+}
 
 extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
-    hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_tiled_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs);
     SEGNB_LAUNCH_CHECK();
     return 0;
@@ -846,7 +921,7 @@ extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_bl
 
 extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
-    hipLaunchKernelGGL(unpack_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_tiled_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs);
     SEGNB_LAUNCH_CHECK();
     return 0;

@@ -159,36 +159,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_s1x9_kernel(const WgS1Args 
     __syncthreads();
     for (int it = it_begin; it < it_end; ++it) {
         if (it + 1 < it_end) gload(it + 1);
-        // software pipeline over the flattened (slab, tap) sequence: the transposing reads of the NEXT fragment are
-        // issued before the current MFMA, so LDS latency hides behind the matrix pipe
-        constexpr int NS = NSLAB / KSPLIT;
-        auto slab_a = [&](int s0) {
-            const int s = s0 * KSPLIT + kpart;
-            const int rr = s / SEGS, cs = (s - rr * SEGS) * 16;
-            return sY + a_off + (rr * WT + cs) * SY;
-        };
-        auto slab_b = [&](int s0) {
-            const int s = s0 * KSPLIT + kpart;
-            const int rr = s / SEGS, cs = (s - rr * SEGS) * 16;
-            return sX + b_off + (rr * XC + cs) * SX;
-        };
-        bf16x8_t af = tr_frag(slab_a(0), 4 * SY);
-        bf16x8_t bcur = tr_frag(slab_b(0) + tap_off[0], 4 * SX);
 #pragma unroll
-        for (int s0 = 0; s0 < NS; ++s0) {
-            const unsigned char* pb = slab_b(s0);
+        for (int s0 = 0; s0 < NSLAB / KSPLIT; ++s0) {
+            const int s = s0 * KSPLIT + kpart;
+            const int rr = s / SEGS, cs = (s - rr * SEGS) * 16;
+            const unsigned char* pa = sY + a_off + (rr * WT + cs) * SY;
+            const bf16x8_t af = tr_frag(pa, 4 * SY);
+            const unsigned char* pb = sX + b_off + (rr * XC + cs) * SX;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                bf16x8_t bnext = bcur, anext = af;
-                if (t < 8) {
-                    bnext = tr_frag(pb + tap_off[t + 1], 4 * SX);
-                } else if (s0 + 1 < NS) {
-                    anext = tr_frag(slab_a(s0 + 1), 4 * SY);
-                    bnext = tr_frag(slab_b(s0 + 1) + tap_off[0], 4 * SX);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bcur, acc[t], 0, 0, 0);
-                bcur = bnext;
-                af = anext;
+                const bf16x8_t bfr = tr_frag(pb + tap_off[t], 4 * SX);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
             }
         }
         __syncthreads();                    // everyone done reading this iteration's tiles

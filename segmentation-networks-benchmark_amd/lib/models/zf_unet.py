@@ -201,8 +201,8 @@ class _ZFUnetPlan(object):
             for conv, h, w in self._conv_sizes(H, W):
                 pj += conv.pack_jobs(h, w)
                 uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
-            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi'),
-                 PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi'))
+            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
+                 PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
             self._pack_tables[(H, W)] = t
         return t
 

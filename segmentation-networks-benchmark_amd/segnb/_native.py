@@ -65,7 +65,7 @@ SIGNATURES = {
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_elems_per_block': (c_int, []), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None
@@ -118,11 +118,11 @@ def call(name, *args):
                            % (name, rc, msg.decode() if msg else ''))
 
 
-def query(name):
+def query(name, *args):
     """Plain int-returning ABI query (no status convention)."""
     if _test_backend is not None:
-        return getattr(_test_backend, name)()
-    return getattr(load(), name)()
+        return getattr(_test_backend, name)(*args)
+    return getattr(load(), name)(*args)
 
 
 def ptr(t, offset_elems=0):

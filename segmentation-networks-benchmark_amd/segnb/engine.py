@@ -303,26 +303,42 @@ class PackTable(object):
     model packed (or every gradient unpacked) by ONE launch.  jobs: dicts with the fields of PACK_JOB_DTYPE
     (tensors for the pointer fields)."""
 
-    def __init__(self, rt, jobs, entry):
+    def __init__(self, rt, jobs, entry, single_entry):
         assert PACK_JOB_DTYPE.itemsize == nv.query('segnb_pack_job_bytes'), 'PackJob layout drifted from the ABI'
-        per_block = nv.query('segnb_pack_elems_per_block')
-        tab = np.zeros(len(jobs), dtype=PACK_JOB_DTYPE)
+        rows, self.singles, self._keep = [], [], []
         blocks = 0
-        self._keep = []
-        for k, j in enumerate(jobs):
+        for j in jobs:
+            nb = nv.query('segnb_pack_job_blocks', j['Mp'], j['Cp'], j['ntaps'], j['s_m'], j['s_c'])
+            if nb < 0:                       # kernels wider than 3x3: per-job launch
+                self.singles.append(j)
+                continue
+            row = np.zeros((), dtype=PACK_JOB_DTYPE)
             for f in ('w', 'packed', 'mmap', 'cmap'):
-                tab[k][f] = j[f].data_ptr()
+                row[f] = j[f].data_ptr()
                 self._keep.append(j[f])
             for f in ('s_m', 's_c', 'Mp', 'Cp', 'ntaps', 'dtype'):
-                tab[k][f] = j[f]
-            tab[k]['tap_off'][:len(j['tap_off'])] = j['tap_off']
-            tab[k]['block_start'] = blocks
-            blocks += (j['Mp'] * j['ntaps'] * j['Cp'] + per_block - 1) // per_block
-        self.rt, self.entry, self.n, self.blocks = rt, entry, len(jobs), blocks
-        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
+                row[f] = j[f]
+            row['tap_off'][:len(j['tap_off'])] = j['tap_off']
+            row['block_start'] = blocks
+            blocks += nb
+            rows.append(row)
+        self.rt, self.entry, self.single_entry, self.n, self.blocks = rt, entry, single_entry, len(rows), blocks
+        self.table = None
+        if rows:
+            tab = np.array(rows, dtype=PACK_JOB_DTYPE)
+            self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
 
     def run(self):
-        nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
+        if self.table is not None:
+            nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
+        for j in self.singles:
+            tap = nv.int_array(j['tap_off'])
+            if self.single_entry == 'segnb_pack_weight':
+                nv.call('segnb_pack_weight', nv.ptr(j['w']), nv.ptr(j['packed']), j['dtype'], j['Mp'], j['Cp'],
+                        j['ntaps'], j['s_m'], j['s_c'], tap, nv.ptr(j['mmap']), nv.ptr(j['cmap']), self.rt.stream)
+            else:
+                nv.call('segnb_unpack_wgrad', nv.ptr(j['packed']), nv.ptr(j['w']), j['Mp'], j['Cp'], j['ntaps'],
+                        j['s_m'], j['s_c'], tap, nv.ptr(j['mmap']), nv.ptr(j['cmap']), 1, self.rt.stream)
 
 
 class Stage(object):

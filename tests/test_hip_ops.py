@@ -375,3 +375,57 @@ def test_sgd_and_input_pack():
         ref = x.permute(0, 2, 3, 1).to(tdt).float()
         assert torch.equal(out[..., :3].float().cpu(), ref)
         assert float(out[..., 3:8].abs().max()) == 0.0 and float((out[..., 8:] - 7).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_batched_pack_unpack_equals_single_job_calls(dtype):
+    """segnb_pack_weight_multi / segnb_unpack_wgrad_multi (LDS-tiled, one launch for many matrices) vs the
+    single-job entry points, bit for bit, incl. padded concat channel maps and a 4x4 kernel (falls back)."""
+    from segnb.engine import PackTable
+    rt = Runtime('cuda', dtype)
+    gen = torch.Generator().manual_seed(1)
+    specs = [([(3, 8)], 32, 3, False), ([(12, 16), (6, 8)], 6, 3, False), ([(300, 304)], 70, 3, False),
+             ([(64, 64), (32, 32)], 40, 3, False), ([(32, 32)], 32, 4, True)]
+    ops, pj, uj, grads = [], [], [], []
+    for segs, co, k, tr in specs:
+        ci = sum(r for r, _ in segs)
+        w = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=gen).cuda()
+        op = ConvOp(rt, w, None, segs, 2 if tr else 1, 1, tr, True)
+        op.plan(16, 16)
+        g = torch.randn(w.shape, generator=gen).cuda()
+        ops.append(op)
+        grads.append(g)
+        pj += op.pack_jobs(16, 16)
+        uj += op.unpack_jobs(16, 16, g)
+    # pack: single-job reference
+    for op in ops:
+        op.pack(16, 16)
+    ref = [[t.clone() for t in op.plan(16, 16)['wp_fwd'] + op.plan(16, 16).get('wp_dg', [])] for op in ops]
+    for op in ops:
+        for t in op.plan(16, 16)['wp_fwd'] + op.plan(16, 16).get('wp_dg', []):
+            t.fill_(7.0)
+    PackTable(rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
+    torch.cuda.synchronize()
+    for op, r in zip(ops, ref):
+        for t, rr in zip(op.plan(16, 16)['wp_fwd'] + op.plan(16, 16).get('wp_dg', []), r):
+            assert torch.equal(t, rr)
+    # unpack: workspace -> gradient (+=), workspace re-zeroed
+    expect = []
+    for op, g in zip(ops, grads):
+        p = op.plan(16, 16)
+        for d in p['dwp']:
+            d.copy_(torch.randn(d.shape, generator=gen))
+        saved = [d.clone() for d in p['dwp']]
+        g0 = g.clone()
+        for job in op.unpack_jobs(16, 16, g0):
+            nv.call('segnb_unpack_wgrad', nv.ptr(job['packed']), nv.ptr(job['w']), job['Mp'], job['Cp'], job['ntaps'],
+                    job['s_m'], job['s_c'], nv.int_array(job['tap_off']), nv.ptr(job['mmap']), nv.ptr(job['cmap']), 1,
+                    rt.stream)
+        expect.append(g0)
+        for d, sv in zip(p['dwp'], saved):
+            d.copy_(sv)
+    PackTable(rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad').run()
+    torch.cuda.synchronize()
+    for op, g, e in zip(ops, grads, expect):
+        torch.testing.assert_close(g, e, rtol=0, atol=0)
+        assert all(float(d.abs().max()) == 0.0 for d in op.plan(16, 16)['dwp'])

