@@ -65,6 +65,8 @@ def main():
     ap.add_argument('--loss', default='bce_dice', choices=['bce_dice', 'bce_jaccard', 'bce'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the whole training step from one captured HIP graph (auto: on for 1 GPU)')
     args = ap.parse_args()
 
     from segnb import dist as sdist
@@ -92,6 +94,16 @@ def main():
     x = torch.randn(B, 3, S, S, generator=g).to(dev)
     y = (torch.rand(B, 1, S, S, generator=g) > 0.7).long().to(dev)
 
+    def step_keep_grads():
+        # zero_grad(set_to_none=False) semantics without touching .grad objects: the backward plan clears the
+        # flat gradient buffer itself when every .grad already aliases it
+        model._engine.flat.flat_g.zero_()
+        out = model(x)
+        loss = crit(out, y)
+        (x.size(0) * loss).backward()
+        opt.step()
+        return loss
+
     def step():
         opt.zero_grad()
         out = model(x)
@@ -106,25 +118,49 @@ def main():
         loss = step()
     torch.cuda.synchronize()
 
-    timer = None
-    if not args.no_kernel_timer:
-        timer = engine.KernelTimer()
-        engine.TIMER = timer
+    # ---- whole-step HIP graph: ~300 kernel launches per step are replayed from ONE graph launch ----------------
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and ws == 1)
+    graph = None
+    if use_graph:
+        opt.zero_grad(set_to_none=False)          # keep parameter.grad as views of the flat gradient buffer
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step_keep_grads()
+        torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+            return static_loss
+        return step()
+
     if ws > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run_step()
     torch.cuda.synchronize()
     if ws > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    engine.TIMER = None
     if ws > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- live per-kernel timing (HIP events on the launch stream).  Event records cannot sit inside a replayed
+    # graph, so when the timed region ran from the graph the same step is run eagerly right after it, with the
+    # events around every convolution launch; without a graph the events are recorded in the timed region itself.
+    timer = None
+    if not args.no_kernel_timer:
+        timer = engine.KernelTimer()
+        engine.TIMER = timer
+        timer_steps = min(args.steps, 5)
+        for _ in range(timer_steps):
+            loss_t = step()
+        torch.cuda.synchronize()
+        engine.TIMER = None
     final_loss = float(loss.item())
 
     if rank != 0:
@@ -142,7 +178,7 @@ def main():
         'config': {'workload': 'ZF_UNET %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, Dropout2d 0.2, train step '
                                'torch_train.py:180-190 (configs[1])' % (S, S, args.dtype, B, args.loss),
                    'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
-        'final_loss': round(final_loss, 6),
+        'final_loss': round(final_loss, 6), 'hip_graph': bool(graph is not None),
         'step_mfma_frac': round(value / ws * gflop_img / 1e3 / peak, 4),
     }
     if timer is not None:
@@ -152,11 +188,11 @@ def main():
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out['roofline'] = {'kernel': dom + '_kernel', 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
-                           'launches_per_step': n // args.steps,
+                           'launches_per_step': n // timer_steps,
                            'avg_launch_us': round(tot_ms / n * 1e3, 2),
                            'flops_per_launch': round(tot_fl / n),
-                           'share_of_step': round(tot_ms / (dt * 1e3), 4)}
-        out['kernels'] = {k: {'launches_per_step': v[0] // args.steps, 'ms_per_step': round(v[1] / args.steps, 3),
+                           'share_of_step': round((tot_ms / timer_steps) / (dt * 1e3 / args.steps), 4)}
+        out['kernels'] = {k: {'launches_per_step': v[0] // timer_steps, 'ms_per_step': round(v[1] / timer_steps, 3),
                               'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
     if ws == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
