@@ -125,14 +125,16 @@ int segnb_bn_finalize(double* stats, int C, int Cp, double count, const float* g
                       float* running_var, long long* nbt, int training, float* coef,
                       segnb_stream_t stream);
 
-/* a = dropmul[n][c] * act((y - mean)*scale + beta).  coef may be NULL (identity affine).  dropmul: fp32
+/* a = dropmul[n][c] * act((y - mean)*scale + beta + res).  res: optional residual input added BEFORE the
+ * activation (the identity branch of a ResNet BasicBlock, linknet.py:45-48 via torchvision resnet34), NULL = none.
+ *   coef may be NULL (identity affine).  dropmul: fp32
  * [N][Cp] multiplier table (Dropout2d replay format; NULL = none).  Optional extra outputs:
  * pool_out = MaxPool2d(2) of a (floor mode), up_out = nearest x2 upsample of a (each with its own ld).
  * Replaces BatchNorm2d+ReLU (zf_unet.py:15-16), Dropout2d (:31), MaxPool2d (:41), Upsample (:42). */
 int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                      const float* coef, int act, float slope, const float* dropmul, void* out,
-                     int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
-                     segnb_stream_t stream);
+                     int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up, const void* res,
+                     int ld_res, segnb_stream_t stream);
 
 /* dz = act'(z) * dropmul * (g_direct + maxpool_bwd(g_pool) + upsample_bwd(g_up)); any source may be
  * NULL.  Writes dz; accumulates sums[r][0][c] += sum dz, sums[r][1][c] += sum dz*yhat
@@ -141,7 +143,8 @@ int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, in
                             const float* coef, int act, float slope, const float* dropmul,
                             const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
                             const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
-                            segnb_stream_t stream);
+                            const void* res, int ld_res, segnb_stream_t stream);
+/* (with a residual input, dz is also the gradient of the residual branch) */
 
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */
@@ -154,6 +157,23 @@ int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float
 int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                        const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
                        int ld_dy, float* dbias, int C, segnb_stream_t stream);
+
+/* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a */
+int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,
+              int H, int W, int Cp, segnb_stream_t stream);
+/* stats[r][0][c] += sum x, stats[r][1][c] += sum x^2 of an arbitrary NHWC tensor: batch statistics for a
+ * PRE-activation BatchNorm (tiramisu.py:12,50), same replicated layout as the conv epilogue's */
+int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats,
+                   segnb_stream_t stream);
+/* nn.MaxPool2d(k, stride, pad), floor mode (resnet stem maxpool 3x3 s2 p1, linknet.py:44) and its backward
+ * (gradient to the first maximum of each window) */
+int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
+                      int pad, void* out, int ld_out, segnb_stream_t stream);
+int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
+                      int Cp, int k, int stride, int pad, void* dx, int ld_dx, segnb_stream_t stream);
+/* NHWC `dtype` -> fp32 NCHW (logits of a head that is not a 1x1 conv: linknet.py:62) */
+int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
+                           segnb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 1x1 classifier head with a handful of classes (zf_unet.py:58,93; tiramisu.py:162; unet16.py:111):

@@ -220,11 +220,13 @@ class AbiEmulator(object):
             return torch.where(z > 0, torch.ones_like(z), torch.full_like(z, slope))
         return torch.ones_like(z)
 
-    def _activated(self, Y, Cp, coef, act, slope, dropmul, N, dt):
+    def _activated(self, Y, Cp, coef, act, slope, dropmul, N, dt, res=None):
         z = Y.float()
         if coef is not None:
             co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
             z = (z - co[2]) * co[0] + co[1]
+        if res is not None:
+            z = z + res.float()
         a = self._act(z, act, slope)
         dm = None
         if dropmul is not None:
@@ -233,10 +235,11 @@ class AbiEmulator(object):
         return z, a.to(dt), dm
 
     def segnb_bn_act_fwd(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, pool_out,
-                         ld_pool, up_out, ld_up, stream):
+                         ld_pool, up_out, ld_up, res, ld_res, stream):
         dt = _tdt(dtype)
         Y = _nhwc(y, N, H, W, Cp, ld_y, dt)
-        _, a, _ = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt)
+        R = _nhwc(res, N, H, W, Cp, ld_res, dt) if res is not None else None
+        _, a, _ = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt, R)
         if out is not None:
             _nhwc(out, N, H, W, Cp, ld_out, dt).copy_(a)
         if pool_out is not None:
@@ -249,10 +252,11 @@ class AbiEmulator(object):
         return 0
 
     def segnb_bn_act_bwd_reduce(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd,
-                                g_pool, ld_gp, g_up, ld_gu, dz, ld_dz, sums, stream):
+                                g_pool, ld_gp, g_up, ld_gu, dz, ld_dz, sums, res, ld_res, stream):
         dt = _tdt(dtype)
         Y = _nhwc(y, N, H, W, Cp, ld_y, dt)
-        z, a, dm = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt)
+        R = _nhwc(res, N, H, W, Cp, ld_res, dt) if res is not None else None
+        z, a, dm = self._activated(Y, Cp, coef, act, slope, dropmul, N, dt, R)
         g = torch.zeros(N, H, W, Cp)
         if g_direct is not None:
             g += _nhwc(g_direct, N, H, W, Cp, ld_gd, dt).float()
@@ -317,6 +321,42 @@ class AbiEmulator(object):
         _nhwc(dy, N, H, W, Cp, ld_dy, dt).copy_(out)
         if dbias is not None:
             _mem(dbias, C, torch.float32).add_(out.float().reshape(-1, Cp).sum(0)[:C])
+        return 0
+
+    # ------------------------------------------------------------------------------------------ generic NHWC ops
+    def segnb_add(self, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream):
+        dt = _tdt(dtype)
+        r = (_nhwc(a, N, H, W, Cp, ld_a, dt).float() + _nhwc(b, N, H, W, Cp, ld_b, dt).float()).to(dt)
+        _nhwc(out, N, H, W, Cp, ld_out, dt).copy_(r)
+        return 0
+
+    def segnb_bn_stats(self, dtype, x, ld, N, H, W, Cp, stats, stream):
+        v = _nhwc(x, N, H, W, Cp, ld, _tdt(dtype)).double().reshape(-1, Cp)
+        S = _mem(stats, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)[0]
+        S[0] += v.sum(0)
+        S[1] += (v * v).sum(0)
+        return 0
+
+    def segnb_maxpool_fwd(self, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, stream):
+        dt = _tdt(dtype)
+        X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2)
+        P = torch.nn.functional.max_pool2d(X, k, stride, pad)
+        _nhwc(out, N, P.shape[2], P.shape[3], Cp, ld_out, dt).copy_(P.permute(0, 2, 3, 1).to(dt))
+        return 0
+
+    def segnb_maxpool_bwd(self, dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, stream):
+        dt = _tdt(dtype)
+        with torch.enable_grad():      # called from inside autograd.Function.backward (grad mode off there)
+            X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+            P = torch.nn.functional.max_pool2d(X, k, stride, pad)
+            G = _nhwc(g_out, N, P.shape[2], P.shape[3], Cp, ld_go, dt).float().permute(0, 3, 1, 2)
+            P.backward(G)
+        _nhwc(dx, N, H, W, Cp, ld_dx, dt).copy_(X.grad.permute(0, 2, 3, 1).to(dt))
+        return 0
+
+    def segnb_nhwc_to_nchw_f32(self, dtype, a, ld, N, H, W, C, out, stream):
+        A = _nhwc(a, N, H, W, C, ld, _tdt(dtype)).float()
+        _mem(out, N * C * H * W, torch.float32).view(N, C, H, W).copy_(A.permute(0, 3, 1, 2))
         return 0
 
     # ------------------------------------------------------------------------------------------ head

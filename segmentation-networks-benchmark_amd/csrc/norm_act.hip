@@ -107,7 +107,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ coef, int act, float slope,
                                                           const float* __restrict__ dropmul, T* __restrict__ out,
                                                           int ld_out, T* __restrict__ pool_out, int ld_pool,
-                                                          T* __restrict__ up_out, int ld_up) {
+                                                          T* __restrict__ up_out, int ld_up,
+                                                          const T* __restrict__ res, int ld_res) {
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     if (cc >= s.CPP) return;
@@ -139,11 +140,17 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
                 const int hh = 2 * h2 + dy, ww = 2 * w2 + dx;
                 if (hh < s.H && ww < s.W) {
                     const long long pix = ((long long)n * s.H + hh) * s.W + ww;
-                    float v[8];
+                    float v[8], rv[8];
                     load8(y + pix * ld_y + c0, v);
+                    if (res != nullptr) {
+                        load8(res + pix * ld_res + c0, rv);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope), out);
+                        v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
                         mx[e] = fmaxf(mx[e], v[e]);
                     }
                     if (out != nullptr) store8(out + pix * ld_out + c0, v);
@@ -193,7 +200,7 @@ __device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc
                                           const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_up,
                                           int ld_gu, long long pix, long long up00, long long up_row, int c0,
                                           float (&g)[8], T* __restrict__ dz, int ld_dz, float (&s1)[8],
-                                          float (&s2)[8]) {
+                                          float (&s2)[8], const T* __restrict__ res, int ld_res) {
     if (HAS_D) {
         float t[8];
         load8(g_direct + pix * ld_gd + c0, t);
@@ -215,11 +222,17 @@ __device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] += t[e];
     }
-    float d[8];
+    float d[8], rv[8];
+    if (res != nullptr) {
+        load8(res + pix * ld_res + c0, rv);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float yc = yv[e] - mu[e];
-        const float z = yc * sc[e] + sh[e];
+        const float z = yc * sc[e] + sh[e] + rv[e];
         const float dv = round_as(g[e] * dm[e] * act_grad(z, act, slope), dz);
         d[e] = dv;
         s1[e] += dv;
@@ -232,7 +245,8 @@ template <typename T, bool HAS_D, bool HAS_P, bool HAS_U>
 __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const T* __restrict__ y, int ld_y, EwShape s, const float* __restrict__ coef, int act, float slope,
     const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
-    int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums) {
+    int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums,
+    const T* __restrict__ res, int ld_res) {
     __shared__ float sred[2 * 32 * 8];
     for (int i = threadIdx.x; i < 2 * 32 * 8; i += NTHR) sred[i] = 0.f;
     __syncthreads();
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                     for (int e = 0; e < 8; ++e) g[e] = (pooled && ((amax >> (2 * e)) & 3u) == (unsigned)p) ? gp[e] : 0.f;
                     bwd_pixel<T, HAS_D, HAS_U>(yv[p], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
                                                ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz,
-                                               ld_dz, s1, s2);
+                                               ld_dz, s1, s2, res, ld_res);
                 }
             }
         } else {
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                 load8(y + pix * ld_y + c0, yv);
                 bwd_pixel<T, HAS_D, HAS_U>(yv, sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
                                            ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz, ld_dz,
-                                           s1, s2);
+                                           s1, s2, res, ld_res);
             }
         }
     }
@@ -431,6 +445,154 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, l
         p[i] -= lr * g[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// small generic NHWC ops for the other model families (LinkNet34 / FCDenseNet / UNet16)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHR) void add_kernel(const T* __restrict__ a, int ld_a, const T* __restrict__ b, int ld_b,
+                                                   T* __restrict__ out, int ld_out, long long npix, int CPP) {
+    const long long total = npix * CPP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / CPP;
+        const int c0 = (int)(i - pix * CPP) * 8;
+        float x[8], yv[8];
+        load8(a + pix * ld_a + c0, x);
+        load8(b + pix * ld_b + c0, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += yv[e];
+        store8(out + pix * ld_out + c0, x);
+    }
+}
+
+// per-channel sum / sum of squares of an NHWC tensor (BatchNorm statistics of an arbitrary input:
+// pre-activation BatchNorm of tiramisu.py:12,50)
+template <typename T>
+__global__ __launch_bounds__(NTHR) void bn_stats_kernel(const T* __restrict__ x, int ld, EwShape s,
+                                                        double* __restrict__ stats) {
+    __shared__ float sred[2 * 32 * 8];
+    for (int i = threadIdx.x; i < 2 * 32 * 8; i += NTHR) sred[i] = 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    const long long npix = (long long)s.N * s.H * s.W;
+    if (active)
+        for (long long pix = (long long)blockIdx.x * s.PY + ty; pix < npix; pix += (long long)gridDim.x * s.PY) {
+            float v[8];
+            load8(x + pix * ld + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] += v[e];
+                s2[e] += v[e] * v[e];
+            }
+        }
+    double* rep = stats + (long long)(blockIdx.x % REPL) * 2 * s.Cp;
+    block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + s.Cp, sred);
+}
+
+// MaxPool2d(k, stride, pad) forward (floor mode) and its gather-form backward: every input pixel checks the
+// (up to ceil(k/stride)^2) windows that contain it and takes the window's gradient if it is that window's
+// FIRST maximum in scan order (torch's tie rule).
+template <typename T>
+__global__ __launch_bounds__(NTHR) void maxpool_fwd_kernel(const T* __restrict__ x, int ld_x, int N, int H, int W, int CPP,
+                                                           int k, int st, int pd, int Ho, int Wo, T* __restrict__ out,
+                                                           int ld_out) {
+    const long long total = (long long)N * Ho * Wo * CPP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CPP) * 8;
+        long long q = i / CPP;
+        const int wo = (int)(q % Wo);
+        q /= Wo;
+        const int ho = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) {
+                const int hi = ho * st - pd + a, wi = wo * st - pd + b;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                    float v[8];
+                    load8(x + (((long long)n * H + hi) * W + wi) * ld_x + c0, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            }
+        store8(out + (((long long)n * Ho + ho) * Wo + wo) * ld_out + c0, m);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHR) void maxpool_bwd_kernel(const T* __restrict__ x, int ld_x, const T* __restrict__ go,
+                                                           int ld_go, int N, int H, int W, int CPP, int k, int st,
+                                                           int pd, int Ho, int Wo, T* __restrict__ dx, int ld_dx) {
+    const long long total = (long long)N * H * W * CPP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CPP) * 8;
+        long long q = i / CPP;
+        const int w = (int)(q % W);
+        q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        float me[8], g[8];
+        load8(x + (((long long)n * H + h) * W + w) * ld_x + c0, me);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        // windows (ho, wo) with ho*st - pd <= h <= ho*st - pd + k - 1
+        int ho_lo = (h + pd - k + st) / st;
+        if (h + pd - k + 1 < 0) ho_lo = 0;
+        int wo_lo = (w + pd - k + st) / st;
+        if (w + pd - k + 1 < 0) wo_lo = 0;
+        const int ho_hi = min((h + pd) / st, Ho - 1), wo_hi = min((w + pd) / st, Wo - 1);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                // is (h, w) the first maximum of window (ho, wo)?
+                bool win[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) win[e] = true;
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b < k; ++b) {
+                        const int hi = ho * st - pd + a, wi = wo * st - pd + b;
+                        if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+                        if (hi == h && wi == w) continue;
+                        const bool before = hi < h || (hi == h && wi < w);
+                        float v[8];
+                        load8(x + (((long long)n * H + hi) * W + wi) * ld_x + c0, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (before ? v[e] >= me[e] : v[e] > me[e]) win[e] = false;
+                    }
+                float gv[8];
+                load8(go + (((long long)n * Ho + ho) * Wo + wo) * ld_go + c0, gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (win[e]) g[e] += gv[e];
+            }
+        store8(dx + (((long long)n * H + h) * W + w) * ld_dx + c0, g);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ a, int ld, int N, int H, int W, int C,
+                                        float* __restrict__ out) {
+    const long long total = (long long)N * C * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % ((long long)H * W);
+        const long long q = i / ((long long)H * W);
+        const int c = (int)(q % C);
+        const long long n = q / C;
+        out[i] = Elem<T>::to_f32(a[(n * H * W + hw) * ld + c]);
+    }
+}
+
 int check_ew(int N, int H, int W, int Cp) {
     SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cp > 0 && Cp % 8 == 0, "bad NHWC shape (Cp % 8 != 0?)");
     SEGNB_CHECK_ARG((long long)N * H * W * 4 < (1ll << 31), "pixel count exceeds int32");
@@ -454,8 +616,8 @@ extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, con
 
 extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                 const float* coef, int act, float slope, const float* dropmul, void* out,
-                                int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
-                                segnb_stream_t stream) {
+                                int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up, const void* res,
+                                int ld_res, segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
@@ -464,11 +626,11 @@ extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H
     if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, act, slope, dropmul, (bf16_t*)out, ld_out, (bf16_t*)pool_out, ld_pool,
-                           (bf16_t*)up_out, ld_up);
+                           (bf16_t*)up_out, ld_up, (const bf16_t*)res, ld_res);
     else if (dtype == SEGNB_F32)
         hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y, ld_y,
                            s, coef, act, slope, dropmul, (float*)out, ld_out, (float*)pool_out, ld_pool,
-                           (float*)up_out, ld_up);
+                           (float*)up_out, ld_up, (const float*)res, ld_res);
     else {
         segnb_set_error("segnb_bn_act_fwd: unknown dtype %d", dtype);
         return SEGNB_E_BADARG;
@@ -481,10 +643,11 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
                                        const float* coef, int act, float slope, const float* dropmul,
                                        const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
                                        const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
-                                       segnb_stream_t stream) {
+                                       const void* res, int ld_res, segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && dz != nullptr, "NULL tensor");
     SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
+    SEGNB_CHECK_ARG(!(res && g_pool), "residual input and pooled gradient cannot be combined");
     const EwShape s = make_shape(N, H, W, Cp);
     const bool hd = g_direct != nullptr, hp = g_pool != nullptr, hu = g_up != nullptr;
     const long long items = hp ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
@@ -493,7 +656,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
 #define SEGNB_RED(TT, D, P, U)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U>), grid, dim3(NTHR), 0, (hipStream_t)stream,          \
                        (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
-                       (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums)
+                       (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res)
 #define SEGNB_RED_ALL(TT)                                                       \
     switch (variant) {                                                          \
         case 1: SEGNB_RED(TT, true, false, false); break;                       \
@@ -555,6 +718,97 @@ extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, s
     int grid = ceil_div(n / 4 + 1, 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, n, lr);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+#define SEGNB_DISPATCH_T(CALL_BF16, CALL_F32, NAME)                 \
+    if (dtype == SEGNB_BF16) {                                      \
+        CALL_BF16;                                                  \
+    } else if (dtype == SEGNB_F32) {                                \
+        CALL_F32;                                                   \
+    } else {                                                        \
+        segnb_set_error(NAME ": unknown dtype %d", dtype);          \
+        return SEGNB_E_BADARG;                                      \
+    }
+
+extern "C" int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,
+                         int H, int W, int Cp, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(a && b && out, "NULL tensor");
+    const long long npix = (long long)N * H * W;
+    int grid = ceil_div(npix * (Cp / 8), NTHR);
+    if (grid > 4096) grid = 4096;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)a, ld_a,
+                           (const bf16_t*)b, ld_b, (bf16_t*)out, ld_out, npix, Cp / 8),
+        hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)a, ld_a,
+                           (const float*)b, ld_b, (float*)out, ld_out, npix, Cp / 8),
+        "segnb_add")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats,
+                              segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(x && stats, "NULL tensor");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x, ld, s, stats),
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)x, ld, s, stats),
+        "segnb_bn_stats")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
+                                 int pad, void* out, int ld_out, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(x && out && k >= 1 && stride >= 1 && pad >= 0 && pad < k, "bad pooling arguments");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    SEGNB_CHECK_ARG(Ho > 0 && Wo > 0, "empty pooled output");
+    int grid = ceil_div((long long)N * Ho * Wo * (Cp / 8), NTHR);
+    if (grid > 8192) grid = 8192;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)out, ld_out),
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)x,
+                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)out, ld_out),
+        "segnb_maxpool_fwd")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
+                                 int Cp, int k, int stride, int pad, void* dx, int ld_dx, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(x && g_out && dx && k >= 1 && stride >= 1 && pad >= 0 && pad < k, "bad pooling arguments");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    int grid = ceil_div((long long)N * H * W * (Cp / 8), NTHR);
+    if (grid > 8192) grid = 8192;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           ld_x, (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx),
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)x,
+                           ld_x, (const float*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)dx, ld_dx),
+        "segnb_maxpool_bwd")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
+                                      segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(a && out && N > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "bad arguments");
+    int grid = ceil_div((long long)N * C * H * W, 256);
+    if (grid > 8192) grid = 8192;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)a, ld, N, H, W, C, out),
+        hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)a, ld, N, H, W, C, out),
+        "segnb_nhwc_to_nchw_f32")
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

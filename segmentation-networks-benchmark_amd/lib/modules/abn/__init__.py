@@ -1,0 +1,104 @@
+"""In-Place Activated BatchNorm on the MI355X kernels -- drop-in for the reference's ``lib.modules.abn``
+(/root/reference/lib/modules/abn/bn.py:23-103, functions.py:62-122).
+
+The reference delegates to the un-vendored ``inplace_abn`` CUDA extension (functions.py:1: mean_var / forward /
+edz_eydz / backward).  Here the same four phases are segnb_bn_stats + segnb_bn_finalize / segnb_bn_act_fwd /
+segnb_bn_act_bwd_reduce / segnb_bn_bwd_apply.  Inside LinkNet34 the module is only a parameter holder (the
+executor fuses BN + LeakyReLU behind each convolution); called on its own it runs the kernels on an NHWC copy.
+
+Parity note: whether the backend applies gamma or |gamma|+eps cannot be determined from the reference;
+this implementation uses the standard affine gamma (identical at the gamma = 1 initialisation).
+``InPlaceABNSync`` is instantiated by no model in the reference and is not provided.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from segnb import _native as nv
+from segnb import convplan as cp
+
+ACT_LEAKY_RELU, ACT_ELU, ACT_NONE = 'leaky_relu', 'elu', 'none'
+
+
+class ABN(nn.Sequential):
+    """BatchNorm2d + activation as two torch modules (bn.py:23-44)."""
+
+    def __init__(self, num_features, activation=nn.ReLU(inplace=True), **kwargs):
+        super(ABN, self).__init__(OrderedDict([('bn', nn.BatchNorm2d(num_features, **kwargs)), ('act', activation)]))
+
+
+class _ABNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, slope):
+        N, C, H, W = x.shape
+        Cp = cp.pad8(C)
+        dev, st = x.device, (torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
+        y = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=dev)
+        y[..., :C] = x.detach().permute(0, 2, 3, 1)
+        stats = torch.zeros((16, 2, Cp), dtype=torch.float64, device=dev)
+        coef = torch.zeros((4, Cp), dtype=torch.float32, device=dev)
+        if training:
+            nv.call('segnb_bn_stats', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(stats), st)
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(weight.detach()),
+                nv.ptr(bias.detach()), eps, momentum, nv.ptr(running_mean), nv.ptr(running_var), None,
+                1 if training else 0, nv.ptr(coef), st)
+        out = torch.empty_like(y)
+        nv.call('segnb_bn_act_fwd', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(out), Cp,
+                None, 0, None, 0, None, 0, st)
+        ctx.save_for_backward(y, coef, weight)
+        ctx.cfg = (N, C, H, W, Cp, act, slope)
+        return out[..., :C].permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, coef, weight = ctx.saved_tensors
+        N, C, H, W, Cp, act, slope = ctx.cfg
+        dev, st = y.device, (torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0)
+        g = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=dev)
+        g[..., :C] = gout.detach().permute(0, 2, 3, 1)
+        dz = torch.empty_like(g)
+        sums = torch.zeros((16, 2, Cp), dtype=torch.float64, device=dev)
+        bcoef = torch.zeros((3, Cp), dtype=torch.float32, device=dev)
+        dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
+        dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+        nv.call('segnb_bn_act_bwd_reduce', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(g),
+                Cp, None, 0, None, 0, nv.ptr(dz), Cp, nv.ptr(sums), None, 0, st)
+        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(weight.detach()), nv.ptr(coef),
+                nv.ptr(bcoef), nv.ptr(dgamma), nv.ptr(dbeta), 0, st)
+        nv.call('segnb_bn_bwd_apply', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dz), Cp,
+                nv.ptr(dz), Cp, None, C, st)
+        return dz[..., :C].permute(0, 3, 1, 2).contiguous(), dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class InPlaceABN(nn.Module):
+    """InPlace Activated Batch Normalization (bn.py:47-103): parameters weight/bias, buffers running_mean/var."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation='leaky_relu', slope=0.01):
+        super(InPlaceABN, self).__init__()
+        if not affine:
+            raise NotImplementedError('affine=False is used by no model in the reference')
+        if activation not in (ACT_LEAKY_RELU, ACT_NONE):
+            raise NotImplementedError("activation %r: the reference's models use only 'leaky_relu'" % (activation,))
+        self.num_features, self.affine, self.eps, self.momentum = num_features, affine, eps, momentum
+        self.activation, self.slope = activation, slope
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+
+    def reset_parameters(self):
+        nn.init.constant_(self.running_mean, 0)
+        nn.init.constant_(self.running_var, 1)
+        nn.init.constant_(self.weight, 1)
+        nn.init.constant_(self.bias, 0)
+
+    def forward(self, x):
+        act = nv.ACT_LEAKY if self.activation == ACT_LEAKY_RELU else nv.ACT_NONE
+        return _ABNFn.apply(x.float(), self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                            self.momentum, self.eps, act, self.slope)
+
+    def __repr__(self):
+        return '%s(%d, eps=%g, momentum=%g, affine=%s, activation=%s slope=%g)' % (
+            self.__class__.__name__, self.num_features, self.eps, self.momentum, self.affine, self.activation,
+            self.slope)

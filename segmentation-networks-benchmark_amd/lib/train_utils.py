@@ -1,0 +1,104 @@
+"""Training helpers -- drop-in for the reference's ``lib.train_utils`` (/root/reference/lib/train_utils.py:14-125):
+``AverageMeter``, ``find_optimal_lr``, ``auto_file``, ``PRCurveMeter`` with the same names, signatures and
+results.  ``PRCurveMeter.update`` is one device histogram instead of 127 host passes over the prediction map."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+
+class AverageMeter(object):
+    """Running value / sum / count / average (train_utils.py:14-33)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return '%.3f' % self.avg
+
+
+def find_optimal_lr(model, criterion, optimizer, dataloader):
+    """LR range test (train_utils.py:36-69): 30 steps, lr = 1e-8 * 2^i, the step body of the training loop.
+    Like the reference it never zeroes gradients between steps (they accumulate) and applies the schedule
+    through LambdaLR (so the optimizer's base lr multiplies the table, as there)."""
+    from torch.optim.lr_scheduler import LambdaLR
+    lrs = np.array([1e-8 * 2.0 ** i for i in range(30)], dtype=np.float32)
+    loss = np.zeros_like(lrs)
+    scheduler = LambdaLR(optimizer, lr_lambda=lambda i: float(lrs[min(i, len(lrs) - 1)]))
+    device = next(model.parameters()).device
+    with torch.set_grad_enabled(True):
+        model.train()
+        it = iter(dataloader)
+        for i in range(len(lrs)):
+            if i > 0:
+                scheduler.step()
+            x, y = next(it)
+            x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+            batch_loss = criterion(model(x), y)
+            (x.size(0) * batch_loss).backward()
+            optimizer.step()
+            loss[i] = batch_loss.cpu().item()
+    return lrs, loss
+
+
+def auto_file(filename, where='.'):
+    """Locate a uniquely named file below `where` (train_utils.py:72-89)."""
+    direct = os.path.join(where, filename)
+    if os.path.isfile(direct):
+        return filename
+    hits = list(glob.iglob(os.path.join(where, '**', filename), recursive=True))
+    if not hits:
+        raise FileNotFoundError('Given file could not be found with recursive search:' + filename)
+    if len(hits) > 1:
+        raise FileNotFoundError('More than one file matches given filename. Please specify it explicitly' + filename)
+    return hits[0]
+
+
+class PRCurveMeter(object):
+    """Confusion counts at n_thresholds probability thresholds arange(0, 1, 1/n) (train_utils.py:92-131)."""
+
+    def __init__(self, n_thresholds=127):
+        self.n_thresholds = n_thresholds
+        self.k = 2
+        self.thresholds = np.arange(0., 1., 1. / n_thresholds, dtype=np.float32)
+        self.tp = np.zeros(n_thresholds, dtype=np.uint64)
+        self.tn = np.zeros(n_thresholds, dtype=np.uint64)
+        self.fp = np.zeros(n_thresholds, dtype=np.uint64)
+        self.fn = np.zeros(n_thresholds, dtype=np.uint64)
+
+    def reset(self):
+        for a in (self.tp, self.tn, self.fp, self.fn):
+            a.fill(0)
+
+    def update(self, y_pred, y_true):
+        p = torch.sigmoid(y_pred.detach().float()).reshape(-1)
+        t = (y_true.reshape(-1) != 0)
+        thr = torch.from_numpy(self.thresholds).to(p.device)
+        # number of thresholds strictly below p  ==  number of thresholds the pixel is predicted positive at
+        b = torch.bucketize(p, thr, right=False)
+        n = self.n_thresholds
+        hp = torch.bincount(b[t], minlength=n + 1).double()       # positives per bucket
+        hn = torch.bincount(b[~t], minlength=n + 1).double()
+        # predicted positive at threshold i  <=>  bucket > i
+        tp = hp.flip(0).cumsum(0).flip(0)[1:]
+        fp = hn.flip(0).cumsum(0).flip(0)[1:]
+        self.tp += tp.cpu().numpy().astype(np.uint64)
+        self.fp += fp.cpu().numpy().astype(np.uint64)
+        self.fn += (hp.sum() - tp).cpu().numpy().astype(np.uint64)
+        self.tn += (hn.sum() - fp).cpu().numpy().astype(np.uint64)
+
+    def precision(self):
+        return np.divide(self.tp, self.tp + self.fp)
+
+    def recall(self):
+        return np.divide(self.tp, self.tp + self.fn)

@@ -52,9 +52,14 @@ SIGNATURES = {
     'segnb_pack_input_nchw': [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P],
     'segnb_bn_finalize': [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P],
     'segnb_bn_act_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P,
-                         c_int, _P, c_int, _P],
+                         c_int, _P, c_int, _P, c_int, _P],
     'segnb_bn_act_bwd_reduce': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int,
-                                _P, c_int, _P, c_int, _P, c_int, _P, _P],
+                                _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P],
+    'segnb_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    'segnb_bn_stats': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    'segnb_maxpool_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    'segnb_maxpool_bwd': [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    'segnb_nhwc_to_nchw_f32': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_bn_bwd_finalize': [_P, c_int, c_int, c_double, _P, _P, _P, _P, _P, c_int, _P],
     'segnb_bn_bwd_apply': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int,
                            _P],

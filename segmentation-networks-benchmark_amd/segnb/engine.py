@@ -117,8 +117,11 @@ class ConvOp(object):
     reference's weight tensor.
     """
 
-    def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True):
+    def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True,
+                 out_hw=None):
         self.rt = rt
+        self.out_hw_override = out_hw      # transposed conv only: crop the output at the bottom/right
+                                           # (center_crop of tiramisu.py:86-90 always has offset 0)
         self.weight, self.bias = weight, bias
         self.stride, self.pad, self.transposed = stride, pad, transposed
         self.need_dgrad = need_dgrad
@@ -151,6 +154,11 @@ class ConvOp(object):
         p = {}
         if self.transposed:
             (Ho, Wo), fwd, full = cp.convt_fwd(Hi, Wi, self.KH, self.KW, self.stride, self.pad)
+            if self.out_hw_override is not None:
+                Hc, Wc = self.out_hw_override(Hi, Wi) if callable(self.out_hw_override) else self.out_hw_override
+                assert Hc <= Ho and Wc <= Wo, 'crop must not exceed the transposed-conv output'
+                fwd, full = cp._scatter_phases(Hc, Wc, Hi, Wi, self.KH, self.KW, self.stride, self.pad)
+                Ho, Wo = Hc, Wc
             dg, dg_full = cp.convt_dgrad(Hi, Wi, self.KH, self.KW, self.stride, self.pad), True
         else:
             (Ho, Wo), fwd = cp.conv_fwd(Hi, Wi, self.KH, self.KW, self.stride, self.pad)
@@ -382,7 +390,7 @@ class Stage(object):
             coef = self.coef
         nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, xv.N, Ho, Wo, self.Cp, nv.ptr(coef), self.act,
                 self.slope, nv.ptr(dropmul), vptr(out), vld(out), vptr(pool_out), vld(pool_out), vptr(up_out),
-                vld(up_out), rt.stream)
+                vld(up_out), None, 0, rt.stream)
         self._saved = (xv, yv, dropmul, coef is not None)
         return yv
 
@@ -395,7 +403,7 @@ class Stage(object):
         coef = self.coef if has_bn else None
         nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                 self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
-                vptr(g_up), vld(g_up), dz.ptr, dz.ld, nv.ptr(self.sums), rt.stream)
+                vptr(g_up), vld(g_up), dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
         if has_bn:

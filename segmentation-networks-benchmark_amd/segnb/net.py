@@ -1,0 +1,377 @@
+"""Define-by-run executor over the C-ABI primitives, with automatic backward.
+
+A model's ``_build(tape, x)`` is ordinary imperative code that calls the layer helpers below (conv_unit,
+bn_act, maxpool, add, concat, head_1x1 ...).  Every helper launches its forward kernels immediately and
+records a backward closure on the tape; ``Tape.backward`` runs the closures in reverse.  Buffers, packed
+weights and tap tables are cached per call site (the graphs are static), so steady-state steps allocate nothing.
+
+Gradients of multi-consumer tensors (ResNet identity branches, dense concatenations, skip adds) are combined by
+``contribute``: the first consumer's gradient buffer is adopted as is, later ones are added in place
+(segnb_add).  torch.cat is zero-copy as in the ZF_UNET plan: producers write into channel slices of one buffer.
+
+Used by lib.models.{unet16, linknet, tiramisu}; ZF_UNET keeps its hand-scheduled plan (fused pool/upsample
+routing, batched pack/unpack).
+"""
+import torch
+from torch import nn
+
+from . import _native as nv
+from . import convplan as cp
+from .engine import BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, Runtime, View, vld, vptr
+
+
+class Act(object):
+    """Activation tensor: forward view + gradient view accumulated during backward."""
+    __slots__ = ('v', 'g', 'needs_grad')
+
+    def __init__(self, v, needs_grad=True):
+        self.v, self.g, self.needs_grad = v, None, needs_grad
+
+
+class Tape(object):
+    def __init__(self, module, device, dtype):
+        self.module = module
+        self.rt = Runtime(device, dtype)
+        self.flat = FlatParams(module)
+        self.flat.ensure(self.rt.device)
+        self._cache = {}
+        self._packed_key = None
+        self.back = []
+
+    # ---- per-step bookkeeping ------------------------------------------------------------------------------
+    def begin(self, train, need_grad):
+        self.flat.ensure(self.rt.device)
+        self.train, self.need_grad = train, need_grad
+        self.back, self._seq = [], 0
+        key = (sum(p._version for p in self.module.parameters()), self.flat.version, self.flat.flat_p.data_ptr())
+        self.repack = key != self._packed_key
+        self._packed_key = key
+
+    def site(self, tag):
+        """Call-site identity = position in the (static) build order."""
+        self._seq += 1
+        return '%s#%d' % (tag, self._seq)
+
+    def cached(self, key, make):
+        v = self._cache.get(key)
+        if v is None:
+            v = make()
+            self._cache[key] = v
+        return v
+
+    def view(self, key, N, H, W, Cp):
+        return self.cached((key, N, H, W, Cp), lambda: View.alloc(self.rt, N, H, W, Cp))
+
+    def small(self, key, shape, dtype):
+        return self.cached((key, tuple(shape)), lambda: self.rt.zeros(shape, dtype))
+
+    def record(self, fn):
+        if self.need_grad:
+            self.back.append(fn)
+
+    def contribute(self, act, gview):
+        if not act.needs_grad:
+            return
+        if act.g is None:
+            act.g = gview
+        else:
+            v = act.g
+            nv.call('segnb_add', self.rt.code, v.ptr, v.ld, gview.ptr, gview.ld, v.ptr, v.ld, v.N, v.H, v.W, v.Cp,
+                    self.rt.stream)
+
+    def backward(self):
+        for fn in reversed(self.back):
+            fn()
+        self.back = []
+
+    def dropout_table(self, site, N, Cp, p):
+        """fp32 [N, Cp] Dropout2d multipliers (0 or 1/(1-p)) drawn on the device; None when inactive."""
+        if not self.train or p <= 0.0:
+            return None
+        t = self.small(site + '/drop', (N, Cp), torch.float32)
+        t.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+        return t
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layer helpers
+# ------------------------------------------------------------------------------------------------------------
+def _bn_fields(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, getattr(bn, 'num_batches_tracked', None),
+            float(getattr(bn, 'eps', BN_EPS)), float(getattr(bn, 'momentum', BN_MOMENTUM) or BN_MOMENTUM))
+
+
+def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=False, bn=None, act=nv.ACT_RELU,
+              slope=0.01, dropmul=None, out=None, pool=False, pool_out=None, res=None, out_hw=None, tag='conv'):
+    """conv / conv-transpose -> [BatchNorm] -> (+res) -> activation -> [Dropout2d multipliers] [-> MaxPool2d(2)].
+
+    out: optional View to write the activated output into (a slice of a concat buffer).
+    Returns Act, or (Act, pooled Act) when pool is set."""
+    rt = tape.rt
+    site = tape.site(tag)
+    conv = tape.cached(site + '/op', lambda: ConvOp(rt, weight, bias, in_segments, stride, pad, transposed,
+                                                    need_dgrad=x.needs_grad, out_hw=out_hw))
+    xv = x.v
+    if tape.repack:
+        conv.pack(xv.H, xv.W)
+    Ho, Wo = conv.out_hw(xv.H, xv.W)
+    N, Cp, C = xv.N, conv.Cop, conv.Co
+    y = tape.view(site + '/y', N, Ho, Wo, Cp)
+    stats = tape.small(site + '/stats', (STAT_REPLICAS, 2, Cp), torch.float64)
+    coef_buf = tape.small(site + '/coef', (4, Cp), torch.float32)
+    has_bn = bn is not None
+    use_batch_stats = has_bn and tape.train
+    conv.fprop(xv, y, stats if use_batch_stats else None)
+    coef = None
+    if has_bn:
+        gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
+                nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
+                nv.ptr(coef_buf), rt.stream)
+        coef = coef_buf
+    ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
+    pv = (pool_out if pool_out is not None else tape.view(site + '/p', N, Ho // 2, Wo // 2, Cp)) if pool else None
+    nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+            ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
+            0 if res is None else res.v.ld, rt.stream)
+    oa = Act(ov)
+    pa = Act(pv) if pool else None
+
+    def backward():
+        if oa.g is None and (pa is None or pa.g is None):
+            return
+        flat = tape.flat
+        dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
+        sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+        bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
+        gp = pa.g if pa is not None else None
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
+                nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, dz.ptr, dz.ld, nv.ptr(sums),
+                None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
+        count = float(N * Ho * Wo)
+        dy = dz
+        if has_bn:
+            gamma = bn.weight
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, nv.ptr(gamma.detach()), nv.ptr(coef_buf),
+                    nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
+            if res is not None:             # dz is also the residual branch's gradient: keep it intact
+                dy = tape.view(site + '/dy', N, Ho, Wo, Cp)
+            nv.call('segnb_bn_bwd_apply', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef_buf), nv.ptr(bcoef),
+                    dz.ptr, dz.ld, dy.ptr, dy.ld, None, C, rt.stream)
+        else:
+            gb = flat.grad_of(bias) if bias is not None else None
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, None, nv.ptr(coef_buf), nv.ptr(bcoef),
+                    None, nv.ptr(gb), 1, rt.stream)
+        if res is not None:
+            tape.contribute(res, dz)
+        conv.wgrad(xv, dy, flat.grad_of(weight))
+        if x.needs_grad:
+            dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
+            conv.dgrad(dy, dx)
+            tape.contribute(x, dx)
+
+    tape.record(backward)
+    return (oa, pa) if pool else oa
+
+
+def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
+    """PRE-activation BatchNorm + activation of an arbitrary tensor (tiramisu.py:12-13, 50-51)."""
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    N, H, W, Cp = xv.N, xv.H, xv.W, xv.Cp
+    gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+    C = gamma.numel()
+    stats = tape.small(site + '/stats', (STAT_REPLICAS, 2, Cp), torch.float64)
+    coef = tape.small(site + '/coef', (4, Cp), torch.float32)
+    if tape.train:
+        nv.call('segnb_bn_stats', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
+    nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(beta.detach()),
+            eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0, nv.ptr(coef), rt.stream)
+    ov = tape.view(site + '/a', N, H, W, Cp)
+    nv.call('segnb_bn_act_fwd', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None, ov.ptr, ov.ld,
+            None, 0, None, 0, None, 0, rt.stream)
+    oa = Act(ov)
+
+    def backward():
+        if oa.g is None:
+            return
+        flat = tape.flat
+        dz = tape.view(site + '/dz', N, H, W, Cp)
+        sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+        bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
+                oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(coef),
+                nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
+        nv.call('segnb_bn_bwd_apply', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,
+                dz.ptr, dz.ld, None, C, rt.stream)
+        tape.contribute(x, dz)
+
+    tape.record(backward)
+    return oa
+
+
+def maxpool(tape, x, k, stride, pad, tag='pool'):
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    Ho, Wo = (xv.H + 2 * pad - k) // stride + 1, (xv.W + 2 * pad - k) // stride + 1
+    ov = tape.view(site + '/o', xv.N, Ho, Wo, xv.Cp)
+    nv.call('segnb_maxpool_fwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride, pad, ov.ptr, ov.ld,
+            rt.stream)
+    oa = Act(ov)
+
+    def backward():
+        if oa.g is None or not x.needs_grad:
+            return
+        dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
+        nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, oa.g.ptr, oa.g.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride,
+                pad, dx.ptr, dx.ld, rt.stream)
+        tape.contribute(x, dx)
+
+    tape.record(backward)
+    return oa
+
+
+def add(tape, a, b, tag='add'):
+    """out = a + b (linknet.py:77-79); both inputs receive the output gradient unchanged."""
+    rt, av, bv = tape.rt, a.v, b.v
+    site = tape.site(tag)
+    ov = tape.view(site + '/o', av.N, av.H, av.W, av.Cp)
+    nv.call('segnb_add', rt.code, av.ptr, av.ld, bv.ptr, bv.ld, ov.ptr, ov.ld, av.N, av.H, av.W, av.Cp, rt.stream)
+    oa = Act(ov)
+
+    def backward():
+        if oa.g is None:
+            return
+        # two consumers of the same buffer: the second contribution must not alias the first adopter
+        tape.contribute(a, oa.g)
+        if b.g is None and b.needs_grad:
+            gb = tape.view(site + '/gb', av.N, av.H, av.W, av.Cp)
+            gb.dense().copy_(oa.g.dense())
+            b.g = gb
+        else:
+            tape.contribute(b, oa.g)
+
+    tape.record(backward)
+    return oa
+
+
+def concat(tape, pieces, cat_view):
+    """pieces: [(Act, channel offset)] already WRITTEN into slices of cat_view (zero-copy torch.cat)."""
+    ca = Act(cat_view)
+
+    def backward():
+        if ca.g is None:
+            return
+        for act, off in pieces:
+            tape.contribute(act, ca.g.slice(off, act.v.Cp))
+
+    tape.record(backward)
+    return ca
+
+
+def head_1x1(tape, x, weight, bias, dlogits_ref, tag='head'):
+    """1x1 classifier -> fp32 NCHW logits (unet16.py:111, tiramisu.py:162-164)."""
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    K, C = weight.shape[0], weight.shape[1]
+    logits = tape.cached((site, xv.N, xv.H, xv.W), lambda: torch.zeros((xv.N, K, xv.H, xv.W), dtype=torch.float32,
+                                                                       device=rt.device))
+    nv.call('segnb_head_fwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, nv.ptr(weight.detach()),
+            nv.ptr(bias.detach()), K, nv.ptr(logits), rt.stream)
+
+    def backward():
+        flat = tape.flat
+        da = tape.view(site + '/da', xv.N, xv.H, xv.W, xv.Cp)
+        nv.call('segnb_head_bwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, xv.Cp, nv.ptr(weight.detach()), K,
+                nv.ptr(dlogits_ref[0]), da.ptr, da.ld, nv.ptr(flat.grad_of(weight)), nv.ptr(flat.grad_of(bias)),
+                rt.stream)
+        tape.contribute(x, da)
+
+    tape.record(backward)
+    return logits
+
+
+def head_from_act(tape, x, K, dlogits_ref, tag='headconv'):
+    """An activation tensor whose first K channels ARE the logits (head that is a general conv, linknet.py:62):
+    NHWC -> fp32 NCHW forward, fp32 NCHW gradient -> NHWC backward."""
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    logits = tape.cached((site, xv.N, xv.H, xv.W), lambda: torch.zeros((xv.N, K, xv.H, xv.W), dtype=torch.float32,
+                                                                       device=rt.device))
+    nv.call('segnb_nhwc_to_nchw_f32', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, K, nv.ptr(logits), rt.stream)
+
+    def backward():
+        g = tape.view(site + '/g', xv.N, xv.H, xv.W, xv.Cp)
+        nv.call('segnb_pack_input_nchw', nv.ptr(dlogits_ref[0]), xv.N, K, xv.H, xv.W, g.ptr, rt.code, xv.Cp, g.ld,
+                rt.stream)
+        tape.contribute(x, g)
+
+    tape.record(backward)
+    return logits
+
+
+# ------------------------------------------------------------------------------------------------------------
+# nn.Module base
+# ------------------------------------------------------------------------------------------------------------
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        ctx.net = net
+        return net._run(x, True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.net._run_backward(dlogits.contiguous().float())
+        return (None, None) + tuple(None for _ in ctx.net.parameters())
+
+
+class HipNet(nn.Module):
+    """Base of the executor-driven models: subclasses implement ``_build(tape, x_act, dlogits_ref) -> logits``."""
+
+    def _init_engine(self, in_channels):
+        self.compute_dtype = 'bf16'
+        self._tape = None
+        self._in_channels = in_channels
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in ('bf16', 'f32'):
+            raise ValueError("compute dtype must be 'bf16' or 'f32'")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._tape = None
+        return self
+
+    def _check_input(self, x):
+        if x.dim() != 4 or x.shape[1] != self._in_channels:
+            raise ValueError('expected input [N, %d, H, W], got %s' % (self._in_channels, tuple(x.shape)))
+
+    def forward(self, x):
+        self._check_input(x)
+        x = x.detach().contiguous().float()
+        if self._tape is None or self._tape.rt.device != x.device:
+            self._tape = Tape(self, x.device, self.compute_dtype)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _NetFn.apply(self, x, *list(self.parameters()))
+        return self._run(x, False)
+
+    def _run(self, x, need_grad):
+        tape = self._tape
+        tape.begin(self.training, need_grad)
+        N, C, H, W = x.shape
+        cin_p = cp.pad8(C)
+        xin = tape.view('input', N, H, W, cin_p)
+        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, xin.ptr, tape.rt.code, cin_p, xin.ld, tape.rt.stream)
+        self._dlogits = [None]
+        logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
+        return logits.clone()
+
+    def _run_backward(self, dlogits):
+        tape = self._tape
+        self._dlogits[0] = dlogits
+        acc = tape.flat.begin_backward()
+        tape.backward()
+        hook = getattr(self, '_grad_sync_hook', None)
+        if hook is not None:
+            hook(tape.flat)
+        tape.flat.publish_grads(acc)

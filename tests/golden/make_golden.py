@@ -16,6 +16,7 @@ Fixtures
   zf_unet_tiny.npz    G1  ZF_UNET(filters=4, dropout 0) B=2 64x64: eval/train logits, all losses, metrics,
                           every parameter gradient of (B*bce_jaccard).backward(), BN running stats,
                           state after one SGD(1e-3) step, 5-step loss trajectory
+  tiramisu_small.npz  G5  small FCDenseNet (reference tiramisu.py) 2x3x36x44: logits, loss, all gradients, buffers
   zf_unet_224.npz     G2+G3  ZF_UNET() default (filters=32, Dropout2d 0.2 replay tables captured from the
                           reference's own RNG draw) B=4 224x224: loss / IoU / accuracy scalars, per-tensor
                           gradient L2 norms, probed logits and gradient entries
@@ -241,11 +242,51 @@ def gen_224():
     print('zf_unet_224.npz loss', float(l), 'iou', float(out['iou']))
 
 
+TIRAMISU_CFG = dict(in_channels=3, down_blocks=(2, 3), up_blocks=(3, 2), bottleneck_layers=2, growth_rate=8,
+                    out_chans_first_conv=16, n_classes=1)
+
+
+def gen_tiramisu():
+    """G5: a small FCDenseNet (same block structure as FCDenseNet103, growth 8) on 2x3x36x44: odd pooled sizes
+    (36 -> 18 -> 9, 44 -> 22 -> 11) exercise MaxPool floor mode and center_crop of the 2h+1 ConvTranspose
+    output.  Dropout2d p set to 0 on the reference instance."""
+    from lib.models.tiramisu import FCDenseNet
+    torch.manual_seed(11)
+    m = FCDenseNet(**TIRAMISU_CFG)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 36, 44, generator=g)
+    y = (torch.rand(2, 1, 36, 44, generator=g) > 0.7).long()
+    out = {'x': x.numpy(), 'y': y.numpy()}
+    for k, v in m.state_dict().items():
+        out['sd/' + k] = v.numpy().copy()
+    m.train()
+    logits = m(x)
+    out['train_logits'] = logits.detach().numpy()
+    l = ref_loss('bce_jaccard')(logits, y)
+    out['loss_bce_jaccard'] = l.detach().numpy()
+    out['iou'] = ref_metrics.JaccardScore()(logits.detach(), y).numpy()
+    (2 * l).backward()
+    for n, p in m.named_parameters():
+        out['grad/' + n] = p.grad.numpy().copy()
+    for n, b in m.named_buffers():
+        out['buf/' + n] = b.numpy().copy()
+    m.eval()
+    with torch.no_grad():
+        out['eval_logits'] = m(x).numpy()
+    np.savez_compressed(os.path.join(HERE, 'tiramisu_small.npz'), **out)
+    print('tiramisu_small.npz loss', float(l), 'params', sum(p.numel() for p in m.parameters()))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu']
     if 'losses' in which:
         gen_losses()
     if 'tiny' in which:
         gen_tiny()
     if '224' in which:
         gen_224()
+    if 'tiramisu' in which:
+        gen_tiramisu()

@@ -1,0 +1,123 @@
+"""Shared checks for the executor-driven models (UNet16, LinkNet34, FCDenseNet): product (on `device`, through
+the C ABI) vs the oracle restatements.  The fp32 comparison is noise-aware: the oracle is run in fp64 too, and the
+product's error is bounded by the fp32 oracle's own distance from fp64 (deep BN nets at random init amplify fp32
+summation noise by orders of magnitude on the way back to the first layers)."""
+import warnings
+
+import numpy as np
+import torch
+
+from oracle import linknet_ref, losses_ref, tiramisu_ref, unet16_ref
+
+TIRAMISU_CFG = dict(in_channels=3, down_blocks=(2, 3), up_blocks=(3, 2), bottleneck_layers=2, growth_rate=8,
+                    out_chans_first_conv=16, n_classes=1)
+
+
+def _oracle_grads(forward, sd, pnames, x, y, dtype, B):
+    leaves = {}
+    for k, v in sd.items():
+        if k in pnames:
+            leaves[k] = v.clone().to(dtype).requires_grad_(True)
+        else:
+            leaves[k] = v.clone().to(dtype) if v.is_floating_point() else v.clone()
+    logits = forward(leaves, x.to(dtype))
+    loss = losses_ref.bce_jaccard(logits, y)
+    (B * loss).backward()
+    return logits.detach(), loss.item(), {k: leaves[k].grad.double() for k in pnames}
+
+
+def check_against_oracle(model, forward, x, y, device, dtype='f32', min_cos=0.99999):
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    B = x.shape[0]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pnames = set(n for n, _ in model.named_parameters())
+    lo32, loss32, g32 = _oracle_grads(forward, sd, pnames, x, y, torch.float32, B)
+    lo64, loss64, g64 = _oracle_grads(forward, sd, pnames, x, y, torch.float64, B)
+    model.set_compute_dtype(dtype)
+    model.to(device).train()
+    out = model(x.to(device))
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y.to(device))
+    (B * loss).backward()
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    scale = float(lo64.abs().max())
+    lerr = float((out.detach().cpu().double() - lo64).abs().max())
+    if dtype == 'f32':
+        assert lerr <= 1e-4 * scale + 5 * float((lo32.double() - lo64).abs().max()), ('logits', lerr, scale)
+        assert abs(loss.item() - loss64) < 1e-5
+    else:
+        assert abs(loss.item() - loss64) < 5e-3
+    got = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
+    ga = torch.cat([got[n].reshape(-1) for n in sorted(pnames)])
+    gr = torch.cat([g64[n].reshape(-1) for n in sorted(pnames)])
+    cos = float((ga * gr).sum() / (ga.norm() * gr.norm()))
+    if dtype == 'f32':
+        for n in pnames:
+            s = float(g64[n].abs().max())
+            if s < 1e-7 * float(gr.abs().max()):
+                continue                                     # analytically-zero gradients (conv bias under BN)
+            e_prod = float((got[n] - g64[n]).abs().max()) / s
+            e_ref = float((g32[n] - g64[n]).abs().max()) / s
+            assert e_prod <= 5 * e_ref + 2e-3, (n, e_prod, e_ref)
+        assert cos > min_cos, cos
+    else:
+        assert np.isfinite(cos) and cos > 0.5, cos
+    return cos
+
+
+def make_unet16():
+    from lib.models.unet16 import UNet16
+    torch.manual_seed(0)
+    m = UNet16(num_filters=8)
+    g = torch.Generator().manual_seed(1)
+    return m, unet16_ref.forward, torch.randn(2, 3, 32, 64, generator=g), (torch.rand(2, 1, 32, 64, generator=g) > 0.7).long()
+
+
+def make_linknet(size=64):
+    from lib.models.linknet import LinkNet34
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = LinkNet34()
+    m.finaldrop1.p = 0.0
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, size, size + 32, generator=g)
+    y = (torch.rand(2, 1, size, size + 32, generator=g) > 0.7).long()
+    return m, (lambda sd, xx: linknet_ref.forward(sd, xx, True)), x, y
+
+
+def make_tiramisu(golden):
+    from lib.models.tiramisu import FCDenseNet
+    m = FCDenseNet(**TIRAMISU_CFG)
+    m.load_state_dict({k[3:]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith('sd/')})
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    fwd = lambda sd, xx: tiramisu_ref.forward(sd, xx, TIRAMISU_CFG['down_blocks'], TIRAMISU_CFG['up_blocks'],
+                                              TIRAMISU_CFG['bottleneck_layers'], True)
+    return m, fwd, torch.from_numpy(golden['x']), torch.from_numpy(golden['y'])
+
+
+def check_tiramisu_golden(model, golden, device, dtype='f32'):
+    """FCDenseNet vs the fixture produced by the REFERENCE's lib/models/tiramisu.py."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    x, y = torch.from_numpy(golden['x']), torch.from_numpy(golden['y'])
+    model.set_compute_dtype(dtype)
+    model.to(device).train()
+    out = model(x.to(device))
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y.to(device))
+    (2 * loss).backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), golden['train_logits'], rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(golden['loss_bce_jaccard'])) < 1e-5
+    gmax = max(np.abs(golden['grad/' + n]).max() for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        ref = golden['grad/' + n]
+        if np.abs(ref).max() < 1e-6 * gmax:
+            continue
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, n
+    for n, b in model.named_buffers():
+        np.testing.assert_allclose(b.cpu().numpy(), golden['buf/' + n], rtol=1e-4, atol=1e-5, err_msg=n)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x.to(device))
+    np.testing.assert_allclose(ev.cpu().numpy(), golden['eval_logits'], rtol=1e-3, atol=1e-4)

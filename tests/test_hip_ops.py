@@ -195,7 +195,7 @@ def _run_bn(device, dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
     up = View.alloc(rt, N, 2 * H, 2 * W, Cp) if use_up else None
     nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm), out.ptr,
             out.ld, None if pool is None else pool.ptr, 0 if pool is None else pool.ld,
-            None if up is None else up.ptr, 0 if up is None else up.ld, rt.stream)
+            None if up is None else up.ptr, 0 if up is None else up.ld, None, 0, rt.stream)
     gdv = View.alloc(rt, N, H, W, Cp)
     gdv.dense()[..., :C] = gd.to(dev, rt.tdtype)
     gpv = gupv = None
@@ -210,7 +210,7 @@ def _run_bn(device, dtype, N, H, W, C, act, use_pool, use_up, use_drop, tensors)
     nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
             gdv.ptr, gdv.ld, None if gpv is None else gpv.ptr, 0 if gpv is None else gpv.ld,
             None if gupv is None else gupv.ptr, 0 if gupv is None else gupv.ld, dz.ptr, dz.ld, nv.ptr(sums),
-            rt.stream)
+            None, 0, rt.stream)
     sums_copy = sums.sum(0)
     bcoef = rt.zeros((3, Cp), torch.float32)
     dgam, dbet, dbias = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)

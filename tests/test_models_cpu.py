@@ -1,0 +1,98 @@
+"""UNet16 / LinkNet34 / FCDenseNet plans (segnb.net executor + lib.models.*) on CPU through the ABI emulator:
+pins the host logic of the three model families (geometry of stride-2 / transposed / 7x7 / 2x2 convs, residual
+and skip-add gradient routing, dense-block buffers, center_crop, InPlaceABN holders, state_dict layouts)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import model_checks as mc
+from oracle import abi_emulator, tiramisu_ref, losses_ref
+from segnb import _native as nv
+
+
+@pytest.fixture(autouse=True)
+def emulated_abi():
+    nv.set_backend_for_testing(abi_emulator.AbiEmulator())
+    yield
+    nv.set_backend_for_testing(None)
+
+
+def test_tiramisu_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'tiramisu_small.npz'))
+    sd = {k[3:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith('sd/')}
+    leaves = {k: (v.requires_grad_(True) if ('running' not in k and v.is_floating_point()) else v) for k, v in sd.items()}
+    cfg = mc.TIRAMISU_CFG
+    out = tiramisu_ref.forward(leaves, torch.from_numpy(g['x']), cfg['down_blocks'], cfg['up_blocks'],
+                               cfg['bottleneck_layers'], True)
+    np.testing.assert_allclose(out.detach().numpy(), g['train_logits'], rtol=1e-5, atol=1e-6)
+    loss = losses_ref.bce_jaccard(out, torch.from_numpy(g['y']))
+    assert abs(loss.item() - float(g['loss_bce_jaccard'])) < 1e-6
+    (2 * loss).backward()
+    gmax = max(np.abs(g['grad/' + k]).max() for k in leaves if leaves[k].requires_grad)
+    for k, v in leaves.items():
+        if v.requires_grad and np.abs(g['grad/' + k]).max() > 1e-6 * gmax:
+            np.testing.assert_allclose(v.grad.numpy(), g['grad/' + k], rtol=1e-3, atol=1e-6 * gmax, err_msg=k)
+
+
+def test_tiramisu_product_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'tiramisu_small.npz'))
+    m, _, _, _ = mc.make_tiramisu(g)
+    mc.check_tiramisu_golden(m, g, 'cpu')
+
+
+def test_tiramisu_state_dict_and_factories():
+    from lib.models.tiramisu import FCDenseNet67, FCDenseNet103
+    m = FCDenseNet103(n_classes=1)
+    assert sum(p.numel() for p in m.parameters()) == 9319521      # = the reference's FCDenseNet103(1) (probe; SURVEY 8a a4: ~9.3 M)
+    assert 'denseBlocksDown.0.layers.0.norm.weight' in m.state_dict()
+    assert 'transUpBlocks.4.convTrans.weight' in m.state_dict()
+    assert FCDenseNet67(n_classes=1).num_classes == 1
+
+
+def test_unet16_vs_oracle():
+    m, fwd, x, y = mc.make_unet16()
+    assert 'encoder.28.weight' in m.state_dict() and 'conv5.4.weight' in m.state_dict()
+    assert 'center.block.1.weight' in m.state_dict() and 'dec1.conv.bias' in m.state_dict()
+    mc.check_against_oracle(m, fwd, x, y, 'cpu')
+
+
+def test_unet16_default_parameter_count():
+    from lib.models.unet16 import UNet16
+    assert sum(p.numel() for p in UNet16().parameters()) == 32202337
+
+
+def test_linknet34_vs_oracle():
+    m, fwd, x, y = mc.make_linknet()
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 21794721
+    for k in ('firstconv.weight', 'firstbn.num_batches_tracked', 'encoder2.0.downsample.0.weight',
+              'encoder4.2.bn2.running_var', 'decoder4.abn1.running_mean', 'decoder1.deconv2.weight',
+              'finalconv3.bias'):
+        assert k in sd, k
+    assert 'decoder4.abn1.num_batches_tracked' not in sd               # InPlaceABN has no such buffer (bn.py:77-78)
+    mc.check_against_oracle(m, fwd, x, y, 'cpu', min_cos=0.9999)
+
+
+def test_inplace_abn_module_standalone():
+    """lib.modules.abn.InPlaceABN called on its own == BatchNorm2d(train) + LeakyReLU(0.01), fwd and bwd."""
+    from lib.modules.abn import InPlaceABN
+    torch.manual_seed(3)
+    x = torch.randn(3, 12, 9, 7)
+    abn = InPlaceABN(12)
+    bn = torch.nn.BatchNorm2d(12)
+    with torch.no_grad():
+        abn.weight.copy_(1 + 0.2 * torch.randn(12)); abn.bias.copy_(0.1 * torch.randn(12))
+        bn.weight.copy_(abn.weight); bn.bias.copy_(abn.bias)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = abn(xa)
+    yb = torch.nn.functional.leaky_relu(bn(xb), 0.01)
+    r = torch.randn_like(ya)
+    (ya * r).sum().backward()
+    (yb * r).sum().backward()
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.weight.grad, bn.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.bias.grad, bn.bias.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.running_var, bn.running_var, rtol=1e-5, atol=1e-6)

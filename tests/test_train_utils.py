@@ -1,0 +1,94 @@
+"""lib.train_utils / torch_train harness: host logic vs direct restatements of the reference's arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import abi_emulator
+from segnb import _native as nv
+
+
+@pytest.fixture(autouse=True)
+def emulated_abi():
+    nv.set_backend_for_testing(abi_emulator.AbiEmulator())
+    yield
+    nv.set_backend_for_testing(None)
+
+
+def test_average_meter():
+    from lib.train_utils import AverageMeter
+    m = AverageMeter()
+    m.update(2.0)
+    m.update(4.0, n=3)
+    assert m.val == 4.0 and m.count == 4 and abs(m.avg - 3.5) < 1e-12 and str(m) == '3.500'
+
+
+def test_pr_curve_meter_matches_threshold_loop():
+    """The reference loops over 127 thresholds and bincounts (train_utils.py:109-125); same counts."""
+    from lib.train_utils import PRCurveMeter
+    g = torch.Generator().manual_seed(0)
+    logits = 3 * torch.randn(2, 1, 24, 17, generator=g)
+    y = (torch.rand(2, 1, 24, 17, generator=g) > 0.6).long()
+    m = PRCurveMeter()
+    m.update(logits, y)
+    m.update(logits * 0.5, y)
+    tp = np.zeros(127, np.uint64)
+    tn, fp, fn = tp.copy(), tp.copy(), tp.copy()
+    for lg in (logits, logits * 0.5):
+        p = torch.sigmoid(lg).numpy().reshape(-1)
+        t = y.numpy().reshape(-1).astype(np.int64)
+        for i, v in enumerate(np.arange(0., 1., 1. / 127, dtype=np.float32)):
+            pred = (p > v).astype(np.int64)
+            conf = np.bincount(pred + 2 * t, minlength=4).reshape(2, 2).astype(np.uint64)
+            tp[i] += conf[1, 1]
+            tn[i] += conf[0, 0]
+            fp[i] += conf[0, 1]
+            fn[i] += conf[1, 0]
+    for a, b in ((m.tp, tp), (m.tn, tn), (m.fp, fp), (m.fn, fn)):
+        assert np.array_equal(a, b)
+    assert m.precision().shape == (127,) and m.recall().shape == (127,)
+
+
+def test_auto_file(tmp_path):
+    from lib.train_utils import auto_file
+    (tmp_path / 'a' / 'b').mkdir(parents=True)
+    (tmp_path / 'a' / 'b' / 'w.pth').write_text('x')
+    assert auto_file('w.pth', str(tmp_path)).endswith('a/b/w.pth')
+    with pytest.raises(FileNotFoundError):
+        auto_file('missing.pth', str(tmp_path))
+    (tmp_path / 'a' / 'w.pth').write_text('y')
+    with pytest.raises(FileNotFoundError):
+        auto_file('w.pth', str(tmp_path))
+
+
+def test_factories_and_train_validate_loop():
+    import torch_train as TT
+    for key in ('jaccard', 'bce_jaccard', 'focal', 'bce'):          # the reference's keys (torch_train.py:82-97)
+        TT.get_loss(key)
+    with pytest.raises(ValueError):
+        TT.get_loss('nope')
+    with pytest.raises(ValueError):
+        TT.get_model('nope')
+    with pytest.raises(ValueError):
+        TT.get_optimizer('nope', [], 0.1)
+    from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(0)
+    model = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    data = [(torch.randn(2, 3, 32, 32), (torch.rand(2, 1, 32, 32) > 0.7).long()) for _ in range(3)]
+    opt = TT.get_optimizer('sgd', model.parameters(), 1e-3)
+    losses, scores = TT.train(model, TT.get_loss('bce_jaccard'), opt, data, metrics=TT.default_metrics())
+    assert losses.count == 3 and np.isfinite(losses.avg) and 0 <= scores['iou'].avg <= 1
+    vl, vs = TT.validate(model, TT.get_loss('bce_jaccard'), data, metrics=TT.default_metrics())
+    assert vl.count == 3 and np.isfinite(vl.avg)
+
+
+def test_find_optimal_lr_accumulates_like_reference():
+    from lib.models.zf_unet import ZF_UNET
+    from lib.losses import BCEWithSigmoidLoss
+    from lib.train_utils import find_optimal_lr
+    torch.manual_seed(0)
+    model = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    batch = (torch.randn(2, 3, 32, 32), (torch.rand(2, 1, 32, 32) > 0.7).long())
+    opt = torch.optim.SGD(model.parameters(), lr=1.0)
+    lrs, loss = find_optimal_lr(model, BCEWithSigmoidLoss(), opt, [batch] * 30)
+    assert lrs.shape == (30,) and abs(lrs[0] - 1e-8) < 1e-12 and abs(lrs[-1] / lrs[0] - 2.0 ** 29) < 1e3
+    assert np.all(np.isfinite(loss)) and loss.shape == (30,)
