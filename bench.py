@@ -54,6 +54,20 @@ def cpu_baseline(seconds_budget=20.0):
                       '1 warm-up, torch %s CPU' % (n, torch.__version__)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs of this same command, summarised by tools/pmc_traffic.py with the gfx950 corrections of
+    MI355X_MICROARCH.md); None when no such profile is committed.  Counters cannot be read from inside the run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                          'r*_pmc_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        k = json.load(fh).get('kernels', {}).get(kernel)
+    return None if k is None else k['traffic_bytes_per_launch']
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -187,7 +201,8 @@ def main():
         n, tot_ms, tot_fl = summ[dom]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out['roofline'] = {'kernel': dom + '_kernel', 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
-                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           'traffic': pmc_traffic(dom + '_kernel'),
                            'launches_per_step': n // timer_steps,
                            'avg_launch_us': round(tot_ms / n * 1e3, 2),
                            'flops_per_launch': round(tot_fl / n),

@@ -96,7 +96,7 @@ __device__ __forceinline__ void mma_step(const unsigned char* __restrict__ sA,
 
 template <int BM, int BN, typename T>
 constexpr int fprop_smem_bytes() {
-    return 2 * (BM + BN) * LDS_ROW + BM * 16 + 2 * BN * 4 + SEGNB_MAX_TAPS * 8;
+    return 2 * (BM + BN) * LDS_ROW + BM * 16 + 4 * 2 * BN * 4 + SEGNB_MAX_TAPS * 8;
 }
 
 // ================================================================================================
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     unsigned char* sTiles = smem;
     int4* sRow = reinterpret_cast<int4*>(smem + 2 * TILE_BYTES);
     float* sStat = reinterpret_cast<float*>(sRow + BM);
-    int2* sTap = reinterpret_cast<int2*>(sStat + 2 * BN);
+    int2* sTap = reinterpret_cast<int2*>(sStat + 4 * 2 * BN);      // sStat: one [2*BN] row per wave row
 
     const segnb_conv_geom& g = a.g;
     const int tid = threadIdx.x;
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
             }
             sRow[rr] = ri;
         }
-        if (tid < 2 * BN) sStat[tid] = 0.f;
         __syncthreads();
 
         int rn[AI], rh[AI], rw[AI];
@@ -265,14 +264,18 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
                 const float t1 = cs1[j] + __shfl_xor(cs1[j], 32);
                 const float t2 = cs2[j] + __shfl_xor(cs2[j], 32);
                 if (h == 0) {
+                    // one slot per (wave row, column), summed below in a fixed order: reproducible statistics
                     const int col = wc * WN + 32 * j + r;
-                    atomicAdd(&sStat[col], t1);
-                    atomicAdd(&sStat[BN + col], t2);
+                    sStat[wr * 2 * BN + col] = t1;
+                    sStat[wr * 2 * BN + BN + col] = t2;
                 }
             }
         }
         __syncthreads();
-        if (a.stats != nullptr && tid < 2 * BN) st += (double)sStat[tid];
+        if (a.stats != nullptr && tid < 2 * BN) {
+#pragma unroll
+            for (int q = 0; q < BM / WM; ++q) st += (double)sStat[q * 2 * BN + tid];
+        }
         constexpr int OC = BN / EPC;
         for (int q = tid; q < BM * OC; q += NT) {
             const int row = q / OC, cc = q - row * OC;

@@ -51,7 +51,7 @@ struct FpS1Cfg {
     static constexpr int TILE_BYTES = X_BYTES + 2 * B_BYTES;
     static constexpr int STAGE_BYTES = BM * OUT_ROW;
     static constexpr int MAIN_BYTES = TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES;
-    static constexpr int SMEM = MAIN_BYTES + BM * 4 + 2 * BN * 4;
+    static constexpr int SMEM = MAIN_BYTES + BM * 4 + WAVES_M * 2 * BN * 4;   // + one stats slot row per wave row
     static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == 4, "wave tiling");
 };
 
@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
             const int ho = h0 + rr / WT, wo = w0 + rr % WT;
             sPix[rr] = (ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
         }
-        if (tid < 2 * BN) sStat[tid] = 0.f;
 
         f32x16_t acc[TM][TN];
 #pragma unroll
@@ -238,14 +237,19 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
                 const float t1 = cs1[j] + __shfl_xor(cs1[j], 32);
                 const float t2 = cs2[j] + __shfl_xor(cs2[j], 32);
                 if (h == 0) {
+                    // one slot per (wave row, column): plain stores, summed below in a fixed order, so the
+                    // statistics (and everything after them) are reproducible run to run
                     const int col = wn * C::WN + 32 * j + r;
-                    atomicAdd(&sStat[col], t1);
-                    atomicAdd(&sStat[BN + col], t2);
+                    sStat[wm * 2 * BN + col] = t1;
+                    sStat[wm * 2 * BN + BN + col] = t2;
                 }
             }
         }
         __syncthreads();
-        if (a.stats != nullptr && tid < 2 * BN) st += (double)sStat[tid];
+        if (a.stats != nullptr && tid < 2 * BN) {
+#pragma unroll
+            for (int q = 0; q < WAVES_M; ++q) st += (double)sStat[q * 2 * BN + tid];
+        }
         constexpr int OC = BN / 8;
         for (int q = tid; q < BM * OC; q += 256) {
             const int row = q / OC, cc = q - row * OC;

@@ -173,22 +173,38 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // block-level per-channel reduction helper: thread (tx,ty) holds v[8] for chunk tx; result summed over
-// ty and atomically added (fp64) to dst[chan] for chan < Cp.
+// ty and atomically added (fp64) to dst[chan] for chan < Cp.  Deterministic: butterfly over the lanes of a
+// wave that share tx, one LDS slot per wave, fixed-order fp64 sum over the waves (only the final fp64 atomics
+// across blocks are unordered: 1e-16 relative).
+constexpr int SRED_FLOATS = (NTHR / 64) * 2 * 32 * 8;
 __device__ __forceinline__ void block_channel_sum2(float (&a)[8], float (&b)[8], const EwShape& s, int tx,
                                                    int chunk_base, double* __restrict__ dst0,
                                                    double* __restrict__ dst1, float* sred) {
-    // sred: [2][CT*8] floats in LDS, zeroed by the caller before a __syncthreads()
+    // sred: [NTHR/64][2][CT*8] floats in LDS
+    for (int off = s.CT; off < 64; off <<= 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sred[tx * 8 + e], a[e]);
-        atomicAdd(&sred[s.CT * 8 + tx * 8 + e], b[e]);
+        for (int e = 0; e < 8; ++e) {
+            a[e] += __shfl_xor(a[e], off);
+            b[e] += __shfl_xor(b[e], off);
+        }
+    }
+    const int nch = s.CT * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < s.CT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sred[wave * 2 * nch + tx * 8 + e] = a[e];
+            sred[wave * 2 * nch + nch + tx * 8 + e] = b[e];
+        }
     }
     __syncthreads();
-    const int nch = s.CT * 8;
     for (int i = threadIdx.x; i < 2 * nch; i += NTHR) {
         const int which = i / nch, idx = i - which * nch;
         const int ch = chunk_base * 8 + idx;
-        if (ch < s.Cp) atomicAdd((which == 0 ? dst0 : dst1) + ch, (double)sred[i]);
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; ++w) t += (double)sred[w * 2 * nch + i];
+        if (ch < s.Cp) atomicAdd((which == 0 ? dst0 : dst1) + ch, t);
     }
 }
 
@@ -247,9 +263,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
     int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums,
     const T* __restrict__ res, int ld_res) {
-    __shared__ float sred[2 * 32 * 8];
-    for (int i = threadIdx.x; i < 2 * 32 * 8; i += NTHR) sred[i] = 0.f;
-    __syncthreads();
+    __shared__ float sred[SRED_FLOATS];
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;
@@ -470,9 +484,7 @@ __global__ __launch_bounds__(NTHR) void add_kernel(const T* __restrict__ a, int 
 template <typename T>
 __global__ __launch_bounds__(NTHR) void bn_stats_kernel(const T* __restrict__ x, int ld, EwShape s,
                                                         double* __restrict__ stats) {
-    __shared__ float sred[2 * 32 * 8];
-    for (int i = threadIdx.x; i < 2 * 32 * 8; i += NTHR) sred[i] = 0.f;
-    __syncthreads();
+    __shared__ float sred[SRED_FLOATS];
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;

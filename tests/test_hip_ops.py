@@ -429,3 +429,108 @@ def test_batched_pack_unpack_equals_single_job_calls(dtype):
     for op, g, e in zip(ops, grads, expect):
         torch.testing.assert_close(g, e, rtol=0, atol=0)
         assert all(float(d.abs().max()) == 0.0 for d in op.plan(16, 16)['dwp'])
+
+
+# ------------------------------------------------------------------------------------------------------
+# kernels added for LinkNet34 / FCDenseNet / UNet16: add, bn_stats, general max-pool, NHWC->NCHW, residual BN
+# ------------------------------------------------------------------------------------------------------
+def _view_from(rt, t_nhwc, Cp, slack=0):
+    """NHWC host tensor -> device View with padded channels inside a wider (ld = Cp + slack) buffer."""
+    N, H, W, C = t_nhwc.shape
+    buf = rt.zeros((N, H, W, Cp + slack), rt.tdtype)
+    v = View(buf, N, H, W, Cp, Cp + slack, 0)
+    v.dense()[..., :C] = t_nhwc.to(rt.device, rt.tdtype)
+    return v
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 9, 7, 20), (1, 32, 32, 64), (3, 5, 5, 264)])
+def test_add_bn_stats_nhwc_to_nchw(shape, dtype):
+    N, H, W, C = shape
+    rt = Runtime('cuda', dtype)
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(C)
+    a, b = torch.randn(N, H, W, C, generator=gen), torch.randn(N, H, W, C, generator=gen)
+    av, bv = _view_from(rt, a, Cp, slack=16), _view_from(rt, b, Cp)
+    ov = _view_from(rt, torch.zeros(N, H, W, C), Cp, slack=8)
+    nv.call('segnb_add', rt.code, av.ptr, av.ld, bv.ptr, bv.ld, ov.ptr, ov.ld, N, H, W, Cp, rt.stream)
+    ar, br = a.to(rt.tdtype).float(), b.to(rt.tdtype).float()
+    ref = (ar + br).to(rt.tdtype).float()
+    got = ov.dense().float().cpu()
+    assert torch.equal(got[..., :C], ref), 'add must be bit-exact (one rounding of an fp32 sum)'
+    assert float(got[..., C:].abs().max()) == 0.0 if Cp > C else True
+    # bn_stats: fp64 sums of the stored values over 16 replicas
+    stats = rt.zeros((16, 2, Cp), torch.float64)
+    nv.call('segnb_bn_stats', rt.code, av.ptr, av.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
+    s = stats.sum(0).cpu()
+    ad = ar.double().reshape(-1, C)
+    # per-thread fp32 partial sums, fp64 across threads/blocks: 1e-6 of the absolute sums
+    assert float((s[0, :C] - ad.sum(0)).abs().max()) <= 2e-6 * float(ad.abs().sum(0).max())
+    assert float((s[1, :C] - (ad * ad).sum(0)).abs().max()) <= 2e-6 * float((ad * ad).sum(0).max())
+    # NHWC -> NCHW fp32 (real channels only)
+    out = rt.zeros((N, C, H, W), torch.float32)
+    nv.call('segnb_nhwc_to_nchw_f32', rt.code, av.ptr, av.ld, N, H, W, C, nv.ptr(out), rt.stream)
+    assert torch.equal(out.cpu(), ar.permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 3, 2, 1), (1, 15, 11, 24, 3, 2, 1), (2, 8, 10, 16, 2, 2, 0),
+                                  (1, 9, 9, 8, 3, 1, 1)])
+def test_maxpool_general_fwd_bwd(case, dtype):
+    N, H, W, C, k, s, p = case
+    rt = Runtime('cuda', dtype)
+    gen = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, H, W, C, generator=gen).to(rt.tdtype).float()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    pr = F.max_pool2d(xr, k, s, p)
+    Ho, Wo = pr.shape[2:]
+    g = torch.randn(N, Ho, Wo, C, generator=gen).to(rt.tdtype).float()
+    pr.backward(g.permute(0, 3, 1, 2))
+    xv, gv = _view_from(rt, x, C, slack=8), _view_from(rt, g, C)
+    ov, dxv = View.alloc(rt, N, Ho, Wo, C), View.alloc(rt, N, H, W, C)
+    nv.call('segnb_maxpool_fwd', rt.code, xv.ptr, xv.ld, N, H, W, C, k, s, p, ov.ptr, ov.ld, rt.stream)
+    nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, gv.ptr, gv.ld, N, H, W, C, k, s, p, dxv.ptr, dxv.ld,
+            rt.stream)
+    assert torch.equal(ov.dense().float().cpu().permute(0, 3, 1, 2), pr.detach())
+    # overlapping windows sum several gradients into one input: one rounding (bf16) / summation order (f32)
+    check('maxpool dx', dxv.dense().permute(0, 3, 1, 2), xr.grad, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_act_with_residual_input(dtype):
+    """BasicBlock tail: relu(bn(y) + res); dz is the gradient of both the BN output and the residual branch."""
+    N, H, W, C = 2, 10, 6, 40
+    rt = Runtime('cuda', dtype)
+    gen = torch.Generator().manual_seed(5)
+    q = lambda t: t.to(rt.tdtype).float()
+    y, r, gd = (q(torch.randn(N, H, W, C, generator=gen)) for _ in range(3))
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=gen), 0.2 * torch.randn(C, generator=gen)
+    yv, rv, gv = _view_from(rt, y, C), _view_from(rt, r, C, slack=8), _view_from(rt, gd, C)
+    stats = rt.zeros((16, 2, C), torch.float64)
+    nv.call('segnb_bn_stats', rt.code, yv.ptr, yv.ld, N, H, W, C, nv.ptr(stats), rt.stream)
+    coef = rt.zeros((4, C), torch.float32)
+    rm, rvv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    g_, b_ = gamma.cuda(), beta.cuda()
+    nv.call('segnb_bn_finalize', nv.ptr(stats), C, C, float(N * H * W), nv.ptr(g_), nv.ptr(b_), 1e-5, 0.1,
+            nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), 1, nv.ptr(coef), rt.stream)
+    out, dz = View.alloc(rt, N, H, W, C), View.alloc(rt, N, H, W, C)
+    nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, N, H, W, C, nv.ptr(coef), nv.ACT_RELU, 0.0, None, out.ptr,
+            out.ld, None, 0, None, 0, rv.ptr, rv.ld, rt.stream)
+    sums = rt.zeros((16, 2, C), torch.float64)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, C, nv.ptr(coef), nv.ACT_RELU, 0.0, None,
+            gv.ptr, gv.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), rv.ptr, rv.ld, rt.stream)
+    # torch reference
+    yt = y.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    rt_ = r.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    a = torch.relu(F.batch_norm(yt, None, None, gamma, beta, True, 0.1, 1e-5) + rt_)
+    a.backward(gd.permute(0, 3, 1, 2))
+    check('res out', out.dense().permute(0, 3, 1, 2), a, dtype)
+    # dz == d/d(res); elements within rounding of the ReLU kink may flip: compare where |pre-activation| is clear
+    pre = (F.batch_norm(yt, None, None, gamma, beta, True, 0.1, 1e-5) + rt_).detach()
+    clear = pre.abs() > (0.05 if dtype == 'bf16' else 1e-4)
+    got = dz.dense().float().cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got[clear], rt_.grad[clear])
+    S = sums.sum(0).cpu()
+    assert abs(float(S[0].sum()) - float(rt_.grad.double().sum())) <= (0.05 if dtype == 'bf16' else 1e-3) * \
+        float(rt_.grad.abs().sum()) / 10

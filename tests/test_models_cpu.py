@@ -96,3 +96,14 @@ def test_inplace_abn_module_standalone():
     torch.testing.assert_close(abn.weight.grad, bn.weight.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(abn.bias.grad, bn.bias.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(abn.running_var, bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_replay_harness_self_consistent(golden_dir):
+    """tests/abi_replay.py (the teacher-forced GPU parity harness) replaying the emulator against itself."""
+    import abi_replay
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    g = np.load(os.path.join(golden_dir, 'tiramisu_small.npz'))
+    _, _, x, y = mc.make_tiramisu(g)
+    n, rep = abi_replay.replay(lambda: mc.make_tiramisu(g)[0], x, y, BCEWithLogitsLossAndSmoothJaccard(), 'f32',
+                               device='cpu')
+    assert n > 200 and not rep, rep[:5]

@@ -1,0 +1,68 @@
+"""Summarise rocprofv3 PMC passes (one pass per counter: FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes for gfx950: both counters are in
+KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced reads, so it is DOUBLED; WRITE_SIZE is
+exact for 16-byte-per-lane stores and float atomics.  traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged
+per launch of each kernel family (template arguments stripped).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    name = name.split('(')[0]
+    name = re.sub(r'<.*', '', name)
+    name = name.replace('void ', '').strip()
+    return name.split('::')[-1]
+
+
+def read_counter(directory, counter):
+    per = defaultdict(lambda: [0, 0.0])
+    files = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)
+    if not files:
+        raise SystemExit('no *counter_collection.csv under %s' % directory)
+    for f in files:
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != counter:
+                    continue
+                fam = family(row['Kernel_Name'])
+                per[fam][0] += 1
+                per[fam][1] += float(row['Counter_Value'])
+    return per
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fe, wr = read_counter(fetch_dir, 'FETCH_SIZE'), read_counter(write_dir, 'WRITE_SIZE')
+    res = {}
+    for fam in sorted(set(fe) | set(wr)):
+        nf, f = fe.get(fam, [0, 0.0])
+        nw, w = wr.get(fam, [0, 0.0])
+        f_launch = f / nf if nf else 0.0
+        w_launch = w / nw if nw else 0.0
+        res[fam] = {'launches_fetch_pass': nf, 'launches_write_pass': nw,
+                    'FETCH_SIZE_KiB_per_launch_raw': round(f_launch, 2),
+                    'WRITE_SIZE_KiB_per_launch': round(w_launch, 2),
+                    'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
+    doc = {'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
+                   'separate --pmc passes; average over all launches of the kernel family in the profiled command',
+           'kernels': res}
+    with open(out, 'w') as fh:
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    for fam, v in sorted(res.items(), key=lambda kv: -kv[1]['traffic_bytes_per_launch'] * kv[1]['launches_fetch_pass']):
+        print('%-40s n=%5d  %10.1f MB/launch' % (fam, v['launches_fetch_pass'], v['traffic_bytes_per_launch'] / 1e6))
+
+
+if __name__ == '__main__':
+    main()
