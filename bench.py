@@ -202,7 +202,7 @@ def main():
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out['roofline'] = {'kernel': dom + '_kernel', 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           'traffic': pmc_traffic(dom + '_kernel'),
+                           'traffic': pmc_traffic(dom),
                            'launches_per_step': n // timer_steps,
                            'avg_launch_us': round(tot_ms / n * 1e3, 2),
                            'flops_per_launch': round(tot_fl / n),

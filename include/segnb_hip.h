@@ -76,15 +76,23 @@ int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const 
                      const float* bias, int bias_n, void* out, double* stats, segnb_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward weight part), same geometry as the fprop launch:
- *   dwp[co][t][ci] += sum_{n,q} dout[n, oh(q), ow(q), co] * in[n, ih(q,t), iw(q,t), ci]
- * dwp: fp32 [Co][ntaps*Ci], accumulated with fp32 atomics (split over pixel ranges); caller zeroes. */
+ *   sum_s dwp[s][co][t][ci] (+)= sum_{n,q} dout[n, oh(q), ow(q), co] * in[n, ih(q,t), iw(q,t), ci]
+ * dwp: fp32 workspace of nslab = segnb_conv_wgrad_slabs(g, dtype) slabs [Co][ntaps*Ci]; the result is slab 0.
+ *   nslab == 1 : accumulated with fp32 atomics (split over pixel ranges) into a workspace the caller zeroed
+ *                (segnb_unpack_wgrad re-zeroes it);
+ *   nslab  > 1 : every slab is OVERWRITTEN with the partial sum of one pixel range by plain stores (global float
+ *                atomics run at ~1.3 TB/s chip-wide on MI355X -- measured as a 58 us floor per layer), then
+ *                slab 0 += slabs 1.. in a fixed order (bitwise reproducible); slabs 1.. are scratch.
+ * The slab count depends on the channel counts, the tap set and the output width -- not on the batch or the
+ * height -- so a workspace can be sized once per convolution and input width. */
+int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype);
 int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
-                     float* dwp, segnb_stream_t stream);
+                     float* dwp, int nslab, segnb_stream_t stream);
 
 /* Parameter-layout <-> packed-GEMM-layout.  Packed matrix is [Mp][ntaps][Cp]; element (mp,t,cp)
  * maps to w[mmap[mp]*s_m + cmap[cp]*s_c + tap_off[t]] (maps are device int32 arrays, -1 = padding).
  * tap_off is a HOST array of ntaps element offsets (kh*s_kh + kw*s_kw).
- * segnb_unpack_wgrad CONSUMES dwp: it is zeroed as it is read, ready for the next step's atomics. */
+ * segnb_unpack_wgrad CONSUMES dwp (slab 0): it is zeroed as it is read, ready for the next step's atomics. */
 int segnb_pack_weight(const float* w, void* wpacked, int dtype, int Mp, int Cp, int ntaps,
                       long long s_m, long long s_c, const int* tap_off_host, const int* mmap,
                       const int* cmap, segnb_stream_t stream);
@@ -99,7 +107,7 @@ int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long lo
  * sorted by block_start; job k owns blocks [block_start_k, block_start_k + segnb_pack_job_blocks(...)) (LDS-tiled
  * transposes: both the parameter side and the packed side are accessed in contiguous runs).
  * segnb_pack_job_blocks returns -1 for kernels wider than 3x3 (use the single-job calls for those).
- * unpack ADDS into the gradient and re-zeroes the workspace. */
+ * unpack ADDS into the gradient and re-zeroes the workspace (slab 0). */
 int segnb_pack_job_bytes(void);
 int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, long long s_c);
 int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);

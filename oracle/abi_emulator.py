@@ -91,7 +91,19 @@ class AbiEmulator(object):
             S[1] += (v * v).sum(0)
         return 0
 
-    def segnb_conv_wgrad(self, g, dtype, in_p, dout_p, dwp, stream):
+    # slab count of the emulated device: stride-1 3x3 bf16 launches write EMU_SLABS partial slabs (the HIP library
+    # derives its count from the CU count); everything else accumulates into one zeroed slab
+    EMU_SLABS = 3
+
+    def segnb_conv_wgrad_slabs(self, g, dtype):
+        g = _geom(g)
+        s1 = (g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.oh0 == 0 and g.ow0 == 0 and g.QH == g.Ho
+              and g.QW == g.Wo and max(g.dh) - min(g.dh) == 2 and max(g.dw) - min(g.dw) == 2)
+        return self.EMU_SLABS if (s1 and dtype == 1) else 1
+
+    def segnb_conv_wgrad(self, g, dtype, in_p, dout_p, dwp, nslab, stream):
+        if nslab != self.segnb_conv_wgrad_slabs(g, dtype):
+            return 1
         g = _geom(g)
         dt = _tdt(dtype)
         X = _nhwc(in_p, g.N, g.Hi, g.Wi, g.Ci, g.ld_in, dt)
@@ -99,9 +111,12 @@ class AbiEmulator(object):
         oh = torch.arange(g.QH) * g.out_step + g.oh0
         ow = torch.arange(g.QW) * g.out_step + g.ow0
         d = D[:, oh[:, None], ow[None, :], :].float().reshape(-1, g.Co)
-        G = _mem(dwp, g.Co * g.ntaps * g.Ci, torch.float32).view(g.Co, g.ntaps, g.Ci)
+        G = _mem(dwp, nslab * g.Co * g.ntaps * g.Ci, torch.float32).view(nslab, g.Co, g.ntaps, g.Ci)
+        if nslab > 1:
+            G[0].zero_()                   # slabs are overwritten, the result is slab 0 ...
+            G[1:].fill_(float('nan'))      # ... and the others are scratch: poison them
         for t in range(g.ntaps):
-            G[:, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
+            G[0, :, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
         return 0
 
     def _maps(self, Mp, Cp, ntaps, tap_off, mmap, cmap):

@@ -40,7 +40,9 @@ int segnb_num_cus();
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);
-int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, hipStream_t stream);
+int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
+                       hipStream_t stream);
+int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 
 // ------------------------------------------------------------------------------------------------
 // element helpers: 8 channels per thread ("chunk8"), fp32 math

@@ -816,10 +816,25 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     return 0;
 }
 
+static bool wgrad_general_only() {
+    static const bool v = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
+    return v;
+}
+
+extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
+    if (check_geom(g)) return -1;
+    if (dtype == SEGNB_BF16 && !wgrad_general_only()) {
+        const int s = segnb_wgrad_s1_slabs(g);
+        if (s > 0) return s;
+    }
+    return 1;
+}
+
 extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
-                                float* dwp, segnb_stream_t stream) {
+                                float* dwp, int nslab, segnb_stream_t stream) {
     if (int rc = check_geom(g)) return rc;
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
+    SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     WgradArgs a;
     a.g = *g;
     a.in = in;
@@ -830,8 +845,7 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        static const bool general_only = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
-        rc = general_only ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, (hipStream_t)stream);
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;

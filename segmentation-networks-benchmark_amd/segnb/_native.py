@@ -44,7 +44,7 @@ _P = c_void_p
 # name -> argtypes (all return int status)
 SIGNATURES = {
     'segnb_conv_fprop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, _P],
-    'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, _P],
+    'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_pack_weight': [_P, _P, c_int, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, _P],
     'segnb_unpack_wgrad': [_P, _P, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, c_int, _P],
     'segnb_pack_weight_multi': [_P, c_int, c_int, _P],
@@ -70,7 +70,7 @@ SIGNATURES = {
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

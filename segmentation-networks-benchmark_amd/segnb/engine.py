@@ -172,12 +172,20 @@ class ConvOp(object):
         if self.need_dgrad:
             p['wp_dg'] = [rt.zeros((self.Cip, len(l.taps) * self.Cop)) for l in dg]
             p['tapoff_dg'] = [nv.int_array([a * self.KW + b for (_, _, a, b) in l.taps]) for l in dg]
-        # weight-gradient workspace (fp32, packed like the forward matrix; zeroed here once, re-zeroed
-        # by segnb_unpack_wgrad each time it is consumed)
+        # weight-gradient workspace (fp32, packed like the forward matrix): nslab partial slabs per launch, as
+        # many as segnb_conv_wgrad_slabs asks for (a property of the channel counts, taps and width -- not of the
+        # batch).  The result is always slab 0 (zeroed here once, re-zeroed by segnb_unpack_wgrad when consumed);
+        # slabs 1.. are scratch for the partial sums of the pixel ranges.
         if self.transposed:
-            p['dwp'] = [rt.zeros((self.Cip, len(l.taps) * self.Cop), torch.float32) for l in dg]
+            geoms = [self._make_geom(l, 1, Ho, Wo, self.Cop, self.Cop, Hi, Wi, self.Cip, self.Cip) for l in dg]
+            p['nslab'] = [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms]
+            p['dwp'] = [rt.zeros((n, self.Cip, len(l.taps) * self.Cop), torch.float32)
+                        for n, l in zip(p['nslab'], dg)]
         else:
-            p['dwp'] = [rt.zeros((self.Cop, len(l.taps) * self.Cip), torch.float32) for l in fwd]
+            geoms = [self._make_geom(l, 1, Hi, Wi, self.Cip, self.Cip, Ho, Wo, self.Cop, self.Cop) for l in fwd]
+            p['nslab'] = [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms]
+            p['dwp'] = [rt.zeros((n, self.Cop, len(l.taps) * self.Cip), torch.float32)
+                        for n, l in zip(p['nslab'], fwd)]
         p['geoms'] = {}
         self._plans[key] = p
         return p
@@ -189,19 +197,23 @@ class ConvOp(object):
         key = (tag, li, N, ld_in, ld_out)
         g = p['geoms'].get(key)
         if g is None:
-            g = nv.ConvGeom()
-            g.N, g.Hi, g.Wi, g.Ci = N, Hi, Wi, Ci
-            g.Ho, g.Wo, g.Co = Ho, Wo, Co
-            g.ld_in, g.ld_out = ld_in, ld_out
-            g.QH, g.QW = launch.QH, launch.QW
-            g.in_step, g.out_step = launch.in_step, launch.out_step
-            g.oh0, g.ow0 = launch.oh0, launch.ow0
-            g.ntaps = len(launch.taps)
-            if g.ntaps > nv.MAX_TAPS:
-                raise ValueError('kernel has more than %d taps' % nv.MAX_TAPS)
-            for i, (dh, dw, _, _) in enumerate(launch.taps):
-                g.dh[i], g.dw[i] = dh, dw
-            p['geoms'][key] = g
+            g = p['geoms'][key] = self._make_geom(launch, N, Hi, Wi, Ci, ld_in, Ho, Wo, Co, ld_out)
+        return g
+
+    @staticmethod
+    def _make_geom(launch, N, Hi, Wi, Ci, ld_in, Ho, Wo, Co, ld_out):
+        g = nv.ConvGeom()
+        g.N, g.Hi, g.Wi, g.Ci = N, Hi, Wi, Ci
+        g.Ho, g.Wo, g.Co = Ho, Wo, Co
+        g.ld_in, g.ld_out = ld_in, ld_out
+        g.QH, g.QW = launch.QH, launch.QW
+        g.in_step, g.out_step = launch.in_step, launch.out_step
+        g.oh0, g.ow0 = launch.oh0, launch.ow0
+        g.ntaps = len(launch.taps)
+        if g.ntaps > nv.MAX_TAPS:
+            raise ValueError('kernel has more than %d taps' % nv.MAX_TAPS)
+        for i, (dh, dw, _, _) in enumerate(launch.taps):
+            g.dh[i], g.dw[i] = dh, dw
         return g
 
     # ---- weight packing (every time the parameters changed) ---------------------------------------
@@ -284,7 +296,8 @@ class ConvOp(object):
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
                 g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
-                nv.call('segnb_conv_wgrad', g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), rt.stream)
+                nv.call('segnb_conv_wgrad', g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li],
+                        rt.stream)
                 if unpack:
                     nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
                             self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
@@ -294,7 +307,7 @@ class ConvOp(object):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
                    lambda: nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]),
-                                   rt.stream))
+                                   p['nslab'][li], rt.stream))
             if unpack:
                 nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
                         self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,

@@ -63,8 +63,11 @@ class _Recorder(object):
         return ('full', t.detach().clone().cpu())
 
 
-def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0):
+def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
     ref, got = ref.double(), got.double().cpu()
+    if name == 'segnb_conv_wgrad' and pos == 4:
+        # the result is slab 0; the other slabs are scratch (and their COUNT differs between emulator and device)
+        ref, got = ref.view(nslab[0], -1)[0], got.view(nslab[1], -1)[0]
     if ref.dtype == torch.float64 and ref.numel() % (2 * abi_emulator.REPL) == 0 and name in _REPLICATED.get(pos, ()):
         ref, got = ref.view(abi_emulator.REPL, -1).sum(0), got.view(abi_emulator.REPL, -1).sum(0)
     scale = float(ref.abs().max())
@@ -115,22 +118,26 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda', flip_ops=('segnb_bn_
             pre = [(p, rec.snap(t, name, False)) for p, t in targs]
             orig_call(name, *args)
             post = [(p, rec.snap(t, name, True)) for p, t in targs]
-            rec.calls.append((name, pre, post))
+            rec.calls.append((name, pre, post, [a if isinstance(a, int) else None for a in args]))
             return
         idx = len(rec.calls)
-        rname, rpre, rpost = rec.forced[idx]
+        rname, rpre, rpost, _ = rec.forced[idx]
         assert rname == name, 'call %d: emulator ran %s, product runs %s' % (idx, rname, name)
         for (p, t), (rp, (kind, rt)) in zip(targs, rpre):
             assert p == rp, (idx, name, p, rp)
             if kind == 'full':
-                assert t.numel() == rt.numel(), (idx, name, p)
+                if t.numel() != rt.numel():
+                    # the weight-gradient workspace: slab counts differ between emulator and device; its
+                    # pre-state is (consumed) zeros or dead partials on both sides
+                    assert name in ('segnb_conv_wgrad', 'segnb_unpack_wgrad') and p in (0, 4), (idx, name, p)
+                    continue
                 t.copy_(rt.to(t.device))
         orig_call(name, *args)
         tol = 2e-2 if dtype == 'bf16' else 2e-4
         for (p, t), (rp, (kind, rt)) in zip(targs, rpost):
             loose = name in flip_ops
-            if kind == 'skip':
-                continue
+            if kind == 'skip' or (name == 'segnb_unpack_wgrad' and p == 0):
+                continue            # (the workspace after an unpack: zeros or dead partials, slab counts differ)
             if kind == 'sum':
                 got = rec.checksum(t)
                 if float((got - rt).abs().max()) > 5 * tol * float(rt[1]) + 1e-30:
@@ -143,12 +150,13 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda', flip_ops=('segnb_bn_
                 # 1e-6 of sum|dz| (dz = argument 17 of the same call)
                 dz = [r for q, (k, r) in rpost if q == 17 and k == 'full']
                 atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
+            nslab = (rec.forced[idx][3][5], args[5]) if name == 'segnb_conv_wgrad' else (1, 1)
             ok, bad, worst = _cmp(name, p, rt, t, tol * (5 if loose and rt.dtype == torch.float64 else 1),
-                                  3 if loose else 0, atol)
+                                  3 if loose else 0, atol, nslab)
             if not ok:
                 rec.report.append('#%d %s arg %d: %d/%d elements beyond %.0e of max (worst %s)' % (
                     idx, name, p, bad, t.numel(), tol, worst))
-        rec.calls.append((name, None, None))
+        rec.calls.append((name, None, None, None))
 
     nv.ptr = ptr
     nv.call = call

@@ -409,7 +409,7 @@ def test_batched_pack_unpack_equals_single_job_calls(dtype):
     for op, r in zip(ops, ref):
         for t, rr in zip(op.plan(16, 16)['wp_fwd'] + op.plan(16, 16).get('wp_dg', []), r):
             assert torch.equal(t, rr)
-    # unpack: workspace -> gradient (+=), workspace re-zeroed
+    # unpack: workspace (slab 0) -> gradient (+=), workspace re-zeroed
     expect = []
     for op, g in zip(ops, grads):
         p = op.plan(16, 16)
@@ -428,7 +428,7 @@ def test_batched_pack_unpack_equals_single_job_calls(dtype):
     torch.cuda.synchronize()
     for op, g, e in zip(ops, grads, expect):
         torch.testing.assert_close(g, e, rtol=0, atol=0)
-        assert all(float(d.abs().max()) == 0.0 for d in op.plan(16, 16)['dwp'])
+        assert all(float(d[0].abs().max()) == 0.0 for d in op.plan(16, 16)['dwp'])     # slab 0 consumed
 
 
 # ------------------------------------------------------------------------------------------------------

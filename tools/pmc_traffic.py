@@ -20,6 +20,7 @@ from collections import defaultdict
 
 
 def family(name):
+    name = name.replace('(anonymous namespace)::', '')
     name = name.split('(')[0]
     name = re.sub(r'<.*', '', name)
     name = name.replace('void ', '').strip()
@@ -55,6 +56,19 @@ def main():
                     'FETCH_SIZE_KiB_per_launch_raw': round(f_launch, 2),
                     'WRITE_SIZE_KiB_per_launch': round(w_launch, 2),
                     'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
+    # ABI-level groups (bench.py times launches per C-ABI entry point: segnb_conv_fprop = image-tile + general kernel)
+    groups = {'conv_fprop': ('conv_fprop_kernel', 'conv_fprop_s1x9_kernel'),
+              'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_s1x9_kernel')}
+    for gname, fams in groups.items():
+        nf = sum(fe.get(f, [0, 0.0])[0] for f in fams)
+        nw = sum(wr.get(f, [0, 0.0])[0] for f in fams)
+        if nf and nw:
+            f_launch = sum(fe.get(f, [0, 0.0])[1] for f in fams) / nf
+            w_launch = sum(wr.get(f, [0, 0.0])[1] for f in fams) / nw
+            res[gname] = {'launches_fetch_pass': nf, 'launches_write_pass': nw,
+                          'FETCH_SIZE_KiB_per_launch_raw': round(f_launch, 2),
+                          'WRITE_SIZE_KiB_per_launch': round(w_launch, 2),
+                          'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
     doc = {'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
                    'separate --pmc passes; average over all launches of the kernel family in the profiled command',
            'kernels': res}
