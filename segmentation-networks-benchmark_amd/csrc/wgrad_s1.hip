@@ -119,23 +119,40 @@ constexpr int lds_stride(int channels) {
     return s;
 }
 
-template <int BCO, int BCI, int R, int WT>
+// Tile shapes.  FLAT = false: R rows x WT columns of one image (+ halo).  FLAT = true (small square images,
+// WT = H = W of 7 or 14): R whole images per iteration in the PADDED-ROW FLATTENING -- output pixel (h, w) sits at
+// position p = h*(W+2) + w of a dy tile with two zero columns per row, input pixel (h + dh, w + dw) at position
+// p + dh*(W+2) + dw of the zero-padded x image, so a tap is still one constant LDS offset, a K slab is any 16
+// consecutive positions, and a 7-pixel row no longer wastes 9 of the 16 pixels of a slab.
+template <int R, int WT, bool FLAT>
+struct WgTile {
+    static constexpr int W2 = WT + 2;
+    static constexpr int PD = FLAT ? (WT * W2 + 15) / 16 * 16 : R * WT;        // dy positions per image / tile
+    static constexpr int XT = FLAT ? PD + 2 * W2 + 2 : (R + 2) * (WT + 2);      // x positions per image / tile
+    static constexpr int XROWS = FLAT ? R * XT : XT, YROWS = FLAT ? R * PD : PD;
+    static constexpr int NSLAB = YROWS / 16;
+    static constexpr int SEGS = FLAT ? PD / 16 : WT / 16;                       // slabs per dy "row"
+    static constexpr int YSTEP = FLAT ? PD : WT, XSTEP = FLAT ? XT : WT + 2;    // positions between those rows
+};
+
+template <int BCO, int BCI, int R, int WT, bool FLAT = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args a) {
+    using TL = WgTile<R, WT, FLAT>;
     constexpr int TCO = BCO / 32, TCI = BCI / 32;
     constexpr int NSUB = TCO * TCI;
     static_assert(NSUB == 1 || NSUB == 4, "tile is 32x32 or 64x64");
     constexpr int KSPLIT = 4 / NSUB;
-    constexpr int XR = R + 2, XC = WT + 2;
+    constexpr int XC = FLAT ? TL::W2 : WT + 2;
     constexpr int SX = lds_stride(BCI), SY = lds_stride(BCO);
-    constexpr int NSLAB = R * WT / 16;
-    constexpr int SEGS = WT / 16;
-    constexpr int XCH = XR * XC * (BCI / 8);        // 16-byte chunks of the x tile
-    constexpr int YCH = R * WT * (BCO / 8);
+    constexpr int NSLAB = TL::NSLAB;
+    constexpr int SEGS = TL::SEGS;
+    constexpr int XCH = TL::XROWS * (BCI / 8);      // 16-byte chunks of the x tile
+    constexpr int YCH = TL::YROWS * (BCO / 8);
     constexpr int XPT = (XCH + 255) / 256, YPT = (YCH + 255) / 256;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
-    unsigned char* sY = smem + XR * XC * SX;
+    unsigned char* sY = smem + TL::XROWS * SX;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks b, b+8, ... share an XCD (round-robin dispatch) and so an L2: give each XCD a contiguous range of
@@ -167,6 +184,35 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
 
     uint4 rx[XPT], ry[YPT];
     auto gload = [&](int it) {
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int u = 0; u < XPT; ++u) {
+                const int c = tid + u * 256;
+                const int row = c / (BCI / 8), cc = c - row * (BCI / 8);
+                const int g = row / TL::XT, q = row - g * TL::XT;
+                const int n = it * R + g;
+                const int hi = q / TL::W2 + a.dhmin, wi = q % TL::W2 + a.dwmin;
+                const int ch = ci0 + cc * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < XCH && n < a.N && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+                    v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + ch);
+                rx[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < YPT; ++u) {
+                const int c = tid + u * 256;
+                const int row = c / (BCO / 8), cc = c - row * (BCO / 8);
+                const int g = row / TL::PD, pp = row - g * TL::PD;
+                const int n = it * R + g;
+                const int ho = pp / TL::W2, wo = pp % TL::W2;
+                const int ch = co0 + cc * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < YCH && n < a.N && ch < a.Co && ho < a.H && wo < a.W)
+                    v = *reinterpret_cast<const uint4*>(a.dy + ((long long)(n * a.H + ho) * a.W + wo) * a.ld_dy + ch);
+                ry[u] = v;
+            }
+            return;
+        }
         const int n = it / (a.HB * a.WB);
         const int rem = it - n * (a.HB * a.WB);
         const int hb = rem / a.WB, wb = rem - hb * a.WB;
@@ -245,16 +291,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
     // a multiple of SEGS, so the kpart part of the offset is the same for every s0: folded into va / vb.
     static_assert(KSPLIT == 1 || KSPLIT % SEGS == 0, "slab -> (row, segment) split");
     const int krow = kpart / SEGS, kseg = kpart - krow * SEGS;
-    const unsigned va = lds_addr(sY + a_off) + (unsigned)((krow * WT + kseg * 16) * SY);
+    const unsigned va = lds_addr(sY + a_off) + (unsigned)((krow * TL::YSTEP + kseg * 16) * SY);
     unsigned vb[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) vb[t] = lds_addr(sX + b_off + tap_off[t]) + (unsigned)((krow * XC + kseg * 16) * SX);
+    for (int t = 0; t < 9; ++t) vb[t] = lds_addr(sX + b_off + tap_off[t]) + (unsigned)((krow * TL::XSTEP + kseg * 16) * SX);
     for (int it = it_begin; it < it_end; ++it) {
         if (it + 1 < it_end) gload(it + 1);
         bf16x4_t fa[2][2], fb[2][9][2];
         SEGNB_TR_READ2(fa[0][0], fa[0][1], va, 0, 4 * SY);          // prologue: slab 0 -> fragment set 0
         wg_first<0, SX>(fb[0], vb);
-        wg_slabs<0, SPW, KSPLIT, SEGS, WT, XC, SX, SY>(acc, fa, fb, va, vb);
+        wg_slabs<0, SPW, KSPLIT, SEGS, TL::YSTEP, TL::XSTEP, SX, SY>(acc, fa, fb, va, vb);
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before anyone reads the accumulators
         __syncthreads();                    // everyone done reading this iteration's tiles
         if (it + 1 < it_end) {
@@ -326,11 +372,13 @@ int s1_slabs(int tiles) {
     return S < 1 ? 1 : S;
 }
 
-template <int BCO, int BCI, int R, int WT>
+template <int BCO, int BCI, int R, int WT, bool FLAT = false>
 int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
-    constexpr int smem = (R + 2) * (WT + 2) * lds_stride(BCI) + R * WT * lds_stride(BCO);
+    using TL = WgTile<R, WT, FLAT>;
+    constexpr int smem = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
+    static_assert(smem <= 160 * 1024, "tiles fit the LDS");
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) segnb_set_error("wgrad_s1 hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -338,7 +386,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     if (attr_rc) return attr_rc;
     a.HB = (a.H + R - 1) / R;
     a.WB = (a.W + WT - 1) / WT;
-    a.IT = a.N * a.HB * a.WB;
+    a.IT = FLAT ? (a.N + R - 1) / R : a.N * a.HB * a.WB;         // FLAT: R whole images per iteration
     const int ncot = (a.Co + BCO - 1) / BCO;
     a.TCI_TILES = (a.Ci + BCI - 1) / BCI;
     const int tiles = ncot * a.TCI_TILES;
@@ -350,7 +398,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     }
     a.its_per_split = (a.IT + S - 1) / S;
     a.slab_stride = (long long)a.Co * a.Ktot;
-    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT>), dim3(tiles * S), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>), dim3(tiles * S), dim3(256), smem, stream, a);
     if (S > 1) {
         const long long total = a.slab_stride;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp, total,
@@ -361,7 +409,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
 
 // tile configuration of the fast path for a geometry: 0 = not handled here (general kernel, one slab)
 struct S1Choice {
-    int cfg;        // 1: 32x32 R8 WT32, 2: 64x64 R4 WT32, 3: 64x64 R8 WT16
+    int cfg;        // 1: 32x32 R8 WT32, 2: 64x64 R4 WT32, 3: 64x64 R8 WT16, 4: flat 7x7 x4 images, 5: flat 14x14
     int bco, bci;
 };
 S1Choice s1_choose(const segnb_conv_geom* g) {
@@ -382,8 +430,12 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
         c = {1, 32, 32};
     } else if (g->Wo > 16) {
         c = {2, 64, 64};
+    } else if (g->Wo == 14 && g->Ho == 14) {
+        c = {5, 64, 64};
     } else if (g->Wo >= 12) {
         c = {3, 64, 64};
+    } else if (g->Wo == 7 && g->Ho == 7) {
+        c = {4, 64, 64};
     }
     return c;
 }
@@ -423,6 +475,8 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     int rc;
     if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream);
     else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream);
-    else rc = launch_s1<64, 64, 8, 16>(a, nslab, stream);
+    else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream);
+    else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream);
+    else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream);
     return rc ? rc : 1;
 }
