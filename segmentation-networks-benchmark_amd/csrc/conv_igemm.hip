@@ -31,6 +31,7 @@ struct FpropArgs {
     void* out;
     double* stats;
     int M, Ktot, ksteps, MT, NTL, GM;
+    unsigned in_bytes, w_bytes;          // extents of the two buffers (buffer-load bounds checks)
 };
 
 struct WgradArgs {
@@ -40,6 +41,17 @@ struct WgradArgs {
     float* dwp;
     int M, Ktot, MT, NTL, S, steps_per_split, total_steps;
 };
+
+// buffer descriptor over [base, base + bytes): raw buffer (stride 0), loads beyond `bytes` return zeros
+constexpr unsigned OOB_OFFSET = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ int xcd_remap(int b, int G) {
     // blocks b, b+8, ... share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -140,6 +152,14 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
 
     const int QHW = g.QH * g.QW;
     double st = 0.0;
+    const __amdgpu_buffer_rsrc_t rsrc_in = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.w, a.w_bytes);
+    unsigned b_off[BI];                 // weight rows of this thread: byte offset of (co, k = c*EPC), constant
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int co = n_base + row0 + 32 * j;
+        b_off[j] = co < g.Co ? (unsigned)(co * a.Ktot + c * EPC) * (unsigned)sizeof(T) : OOB_OFFSET;
+    }
 
     for (int mt = gq; mt < a.MT; mt += a.GM) {
         const int m_base = mt * BM;
@@ -183,30 +203,38 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        // Loads go through buffer descriptors: a 32-bit byte offset per lane, a wave-uniform scalar offset per K
+        // step, and the hardware bounds check -- a row outside the image (or a channel tile outside Co) gets an
+        // offset beyond the buffer and reads back zeros, with no branch and no register clearing.  This thread's
+        // 16-byte chunk walks K as (tap, channel): tracked incrementally, the gather offsets of the AI rows are
+        // recomputed only when the tap changes.  (The previous form -- division of k by Ci, bounds tests, 64-bit
+        // addresses and zero fills for every row of every K step -- issued 9 VALU instructions per MFMA.)
         uint4 ra[AI], rb[BI];
-        auto gload = [&](int s) {
-            const int k0 = s * BK + c * EPC;
-            const bool kok = k0 < a.Ktot;
-            const int tap = kok ? k0 / g.Ci : 0;
-            const int ci = k0 - tap * g.Ci;
-            const int2 t = sTap[tap];
+        int k_tap = 0, k_ci = c * EPC;                      // this thread's chunk of K step 0
+        while (k_ci >= g.Ci) { k_ci -= g.Ci; ++k_tap; }
+        unsigned a_off[AI];
+        auto set_tap = [&]() {
+            const int2 t = sTap[k_tap < g.ntaps ? k_tap : 0];
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int hi = rh[i] + t.x, wi = rw[i] + t.y;
-                const bool ok = kok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    const long long off = (long long)(rn[i] + hi * g.Wi + wi) * g.ld_in + ci;
-                    v = *reinterpret_cast<const uint4*>(inT + off);
-                }
-                ra[i] = v;
+                const bool ok = k_tap < g.ntaps && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                a_off[i] = ok ? (unsigned)((rn[i] + hi * g.Wi + wi) * g.ld_in) * (unsigned)sizeof(T) : OOB_OFFSET;
             }
+        };
+        set_tap();
+        auto gload = [&](int s) {
 #pragma unroll
-            for (int j = 0; j < BI; ++j) {
-                const int co = n_base + row0 + 32 * j;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (kok && co < g.Co) v = *reinterpret_cast<const uint4*>(wT + (long long)co * a.Ktot + k0);
-                rb[j] = v;
+            for (int i = 0; i < AI; ++i) ra[i] = buf_load16(rsrc_in, a_off[i] + (unsigned)k_ci * (unsigned)sizeof(T), 0);
+            const unsigned kb = (unsigned)(s * BK) * (unsigned)sizeof(T);          // wave-uniform
+            const bool kok = s * BK + c * EPC < a.Ktot;                             // false only in a ragged last step
+#pragma unroll
+            for (int j = 0; j < BI; ++j) rb[j] = buf_load16(rsrc_w, kok ? b_off[j] : OOB_OFFSET, kb);
+            // advance this thread's chunk by one K step
+            k_ci += BK;
+            if (k_ci >= g.Ci) {
+                do { k_ci -= g.Ci; ++k_tap; } while (k_ci >= g.Ci);
+                set_tap();
             }
         };
         auto lstore = [&](int buf) {
@@ -786,6 +814,14 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     a.g = *g;
     a.in = in;
     a.w = wpacked;
+    {
+        const long long esz = dtype == SEGNB_BF16 ? 2 : 4;
+        const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * esz;
+        const long long wb = (long long)g->Co * g->ntaps * g->Ci * esz;
+        SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+        a.in_bytes = (unsigned)inb;
+        a.w_bytes = (unsigned)wb;
+    }
     a.bias = bias;
     a.bias_n = bias_n;
     a.out = out;
