@@ -307,12 +307,12 @@ int dispatch_fs1(FpS1Args& a, hipStream_t stream) {
         // row segments, one barrier per step) measure 20-25 % faster than the image-tile form here
         return NOT_HANDLED;
     }
-    if (a.W > 8) {
-        const long long its = (long long)a.N * ((a.H + 7) / 8);
-        if (a.Co <= 64 || its * ((a.Co + 127) / 128) < cus) return launch_fs1<64, 8, 16, 2, BKC>(a, stream);
-        return launch_fs1<128, 8, 16, 2, BKC>(a, stream);
-    }
-    return launch_fs1<128, 8, 8, 1, BKC>(a, stream);
+    // measured per layer on MI355X (tools/layer_bench.py, after the general kernel got buffer-descriptor gathers):
+    //   8 < W <= 16 : 64-channel tiles here (2 blocks / CU) beat both the 128-channel tiles (-20 %) and the general
+    //                 kernel, except for very wide outputs (Co > 1024: the data gradient of a concat layer)
+    //   W <= 8      : the general kernel's flattened 128x128 tiles are 25 % faster than 8x8 image tiles
+    if (a.W > 8 && a.Co <= 1024) return launch_fs1<64, 8, 16, 2, BKC>(a, stream);
+    return NOT_HANDLED;
 }
 
 }  // namespace
