@@ -114,11 +114,55 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
     if (cc >= s.CPP) return;
     const int c0 = cc * 8;
     float sc[8], sh[8], mu[8];
+    if (coef != nullptr) {          // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
+        load8(coef + c0, sc);
+        load8(coef + s.Cp + c0, sh);
+        load8(coef + 2 * s.Cp + c0, mu);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = coef != nullptr ? coef[c0 + e] : 1.f;
-        sh[e] = coef != nullptr ? coef[s.Cp + c0 + e] : 0.f;
-        mu[e] = coef != nullptr ? coef[2 * s.Cp + c0 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = 1.f;
+            sh[e] = 0.f;
+            mu[e] = 0.f;
+        }
+    }
+    if (pool_out == nullptr) {
+        // no pooling: consecutive threads take consecutive pixels, so every load / store instruction of a wave
+        // covers one contiguous run (the 2x2-window walk below touches half of every 128-byte line per instruction)
+        // (check_ew guarantees 4*N*H*W < 2^31: 32-bit pixel indices, no 64-bit divisions in the loop)
+        const int npix = s.N * s.H * s.W, hw = s.H * s.W;
+        const bool need_n = dropmul != nullptr || up_out != nullptr;
+        for (int pix = blockIdx.x * s.PY + ty; pix < npix; pix += gridDim.x * s.PY) {
+            const int n = need_n ? pix / hw : 0;
+            float dm[8], v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+            if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
+            load8(y + (long long)pix * ld_y + c0, v);
+            if (res != nullptr) {
+                float rv[8];
+                load8(res + (long long)pix * ld_res + c0, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope), out);
+            }
+            if (out != nullptr) store8(out + (long long)pix * ld_out + c0, v);
+            if (up_out != nullptr) {
+                const int rem = pix - n * hw;
+                const int hh = rem / s.W, ww = rem - hh * s.W;
+                const long long W2x = 2ll * s.W;
+                const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
+                store8(up_out + p00 * ld_up + c0, v);
+                store8(up_out + (p00 + 1) * ld_up + c0, v);
+                store8(up_out + (p00 + W2x) * ld_up + c0, v);
+                store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
+            }
+        }
+        return;
     }
     const int H2 = (s.H + 1) >> 1, W2 = (s.W + 1) >> 1;
     const int Hp = s.H >> 1, Wp = s.W >> 1;
@@ -129,7 +173,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
         const int h2 = rem / W2, w2 = rem - h2 * W2;
         float dm[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dm[e] = dropmul != nullptr ? dropmul[(long long)n * s.Cp + c0 + e] : 1.f;
+        for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+        if (dropmul != nullptr) load8(dropmul + (long long)n * s.Cp + c0, dm);
         float mx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
@@ -269,11 +314,17 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const bool active = cc < s.CPP;
     const int c0 = active ? cc * 8 : 0;
     float sc[8], sh[8], mu[8];
+    if (coef != nullptr) {          // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
+        load8(coef + c0, sc);
+        load8(coef + s.Cp + c0, sh);
+        load8(coef + 2 * s.Cp + c0, mu);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = coef != nullptr ? coef[c0 + e] : 1.f;
-        sh[e] = coef != nullptr ? coef[s.Cp + c0 + e] : 0.f;
-        mu[e] = coef != nullptr ? coef[2 * s.Cp + c0 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = 1.f;
+            sh[e] = 0.f;
+            mu[e] = 0.f;
+        }
     }
     float s1[8], s2[8];
 #pragma unroll
@@ -292,7 +343,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                 const int h2 = rem / W2, w2 = rem - h2 * W2;
                 float dm[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dm[e] = dropmul != nullptr ? dropmul[(long long)n * s.Cp + c0 + e] : 1.f;
+                for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+        if (dropmul != nullptr) load8(dropmul + (long long)n * s.Cp + c0, dm);
                 float yv[4][8];
                 bool valid[4];
 #pragma unroll
@@ -340,19 +392,20 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                 }
             }
         } else {
-            const long long npix = (long long)s.N * s.H * s.W;
-            const long long hw = (long long)s.H * s.W;
-            for (long long pix = (long long)blockIdx.x * s.PY + ty; pix < npix; pix += (long long)gridDim.x * s.PY) {
-                const int n = (int)(pix / hw);
-                const int rem = (int)(pix - n * hw);
-                const int hh = rem / s.W, ww = rem - hh * s.W;
+            const int npix = s.N * s.H * s.W, hw = s.H * s.W;      // 32-bit: check_ew bounds 4*N*H*W < 2^31
+            const bool need_n = dropmul != nullptr || HAS_U;
+            for (int pix = blockIdx.x * s.PY + ty; pix < npix; pix += gridDim.x * s.PY) {
+                const int n = need_n ? pix / hw : 0;
+                const int rem = pix - n * hw;
+                const int hh = HAS_U ? rem / s.W : 0, ww = HAS_U ? rem - hh * s.W : 0;
                 float dm[8], yv[8], g[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    dm[e] = dropmul != nullptr ? dropmul[(long long)n * s.Cp + c0 + e] : 1.f;
+                    dm[e] = 1.f;
                     g[e] = 0.f;
                 }
-                load8(y + pix * ld_y + c0, yv);
+                if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
+                load8(y + (long long)pix * ld_y + c0, yv);
                 bwd_pixel<T, HAS_D, HAS_U>(yv, sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
                                            ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz, ld_dz,
                                            s1, s2, res, ld_res);
@@ -633,8 +686,8 @@ extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
-    const long long nwin = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
-    const dim3 grid = make_grid(s, nwin);
+    const long long items = pool_out != nullptr ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
+    const dim3 grid = make_grid(s, items, pool_out != nullptr ? 2048 : 4096);
     if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, act, slope, dropmul, (bf16_t*)out, ld_out, (bf16_t*)pool_out, ld_pool,
