@@ -96,14 +96,26 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
 
     double st = 0.0;
     const int nsteps = a.NCH * 9;
+    float bias_r[TN];                   // this lane's output channels are fixed for the whole block
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n_base + wn * C::WN + 32 * j + r;
+        bias_r[j] = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+    }
 
-    for (int it = gq; it < a.IT; it += a.GM) {
-        const int n = it / (a.HB * a.WB);
+    // coordinates of the tile whose operands are being LOADED (one tile ahead of the one being computed at the end
+    // of an iteration: the first x chunk and weight step of the next tile are requested before the epilogue, so
+    // their latency -- an HBM round trip per tile, 12-25 tiles per block on the 224x224 layers -- hides behind it)
+    int n = 0, h0 = 0, w0 = 0;
+    auto set_tile = [&](int it) {
+        n = it / (a.HB * a.WB);
         const int rem = it - n * (a.HB * a.WB);
         const int hb = rem / a.WB, wb = rem - hb * a.WB;
-        const int h0 = hb * R, w0 = wb * WT;
-
-        uint4 rx[XPT], rb[BPT];
+        h0 = hb * R;
+        w0 = wb * WT;
+    };
+    uint4 rx[XPT], rb[BPT];
+    if (gq < a.IT) set_tile(gq);
         auto gload_x = [&](int c) {
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
@@ -152,6 +164,11 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
             }
         };
 
+    if (gq < a.IT) {
+        gload_x(0);
+        gload_b(0);
+    }
+    for (int it = gq; it < a.IT; it += a.GM) {
         __syncthreads();        // previous tile's staging area / pixel table consumed
         for (int rr = tid; rr < BM; rr += 256) {
             const int ho = h0 + rr / WT, wo = w0 + rr % WT;
@@ -166,9 +183,7 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        gload_x(0);
-        gload_b(0);
-        lstore_x();
+        lstore_x();             // requested before the previous tile's epilogue (or above, for the first tile)
         lstore_b(0);
         __syncthreads();
         for (int c = 0; c < a.NCH; ++c) {
@@ -206,13 +221,19 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
             }
         }
 
+        if (it + a.GM < a.IT) {          // next tile's first operands: in flight during the epilogue
+            set_tile(it + a.GM);
+            gload_x(0);
+            gload_b(0);
+        }
+
         // ---- epilogue ---------------------------------------------------------------------------------
         float cs1[TN], cs2[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * C::WN + 32 * j + r;
             const int co = n_base + col;
-            const float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+            const float bv = bias_r[j];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {

@@ -69,10 +69,19 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int C, int Cp, do
     if (c < C) {
         double mu, var;
         if (training) {
-            double s1 = 0.0, s2 = 0.0;
+            // all 32 loads first, then the 32 zero stores: interleaved, every store fences the next load behind
+            // it (same array) and the kernel is a chain of 16 round trips
+            double v1[REPL], v2[REPL];
+#pragma unroll
             for (int rp = 0; rp < REPL; ++rp) {
-                s1 += stats[(rp * 2) * Cp + c];
-                s2 += stats[(rp * 2 + 1) * Cp + c];
+                v1[rp] = stats[(rp * 2) * Cp + c];
+                v2[rp] = stats[(rp * 2 + 1) * Cp + c];
+            }
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int rp = 0; rp < REPL; ++rp) {
+                s1 += v1[rp];
+                s2 += v2[rp];
                 stats[(rp * 2) * Cp + c] = 0.0;
                 stats[(rp * 2 + 1) * Cp + c] = 0.0;
             }
@@ -432,10 +441,17 @@ __global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int Cp,
     if (c >= Cp) return;
     float a = 0.f, c1 = 0.f, c2 = 0.f;
     if (c < C) {
-        double sdz = 0.0, sdzy = 0.0;
+        double v1[REPL], v2[REPL];          // loads first, zero stores after (see bn_finalize_kernel)
+#pragma unroll
         for (int rp = 0; rp < REPL; ++rp) {
-            sdz += sums[(rp * 2) * Cp + c];
-            sdzy += sums[(rp * 2 + 1) * Cp + c];
+            v1[rp] = sums[(rp * 2) * Cp + c];
+            v2[rp] = sums[(rp * 2 + 1) * Cp + c];
+        }
+        double sdz = 0.0, sdzy = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            sdz += v1[rp];
+            sdzy += v2[rp];
             sums[(rp * 2) * Cp + c] = 0.0;
             sums[(rp * 2 + 1) * Cp + c] = 0.0;
         }
@@ -673,7 +689,7 @@ extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, con
     SEGNB_CHECK_ARG(coef != nullptr && C > 0 && Cp >= C && Cp % 8 == 0, "bad channel counts");
     SEGNB_CHECK_ARG(training ? stats != nullptr : (running_mean != nullptr && running_var != nullptr),
                     "missing statistics source");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, Cp,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, stats, C, Cp,
                        count, gamma, beta, eps, momentum, running_mean, running_var, nbt, training, coef);
     SEGNB_LAUNCH_CHECK();
     return 0;
@@ -750,7 +766,7 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
                                      const float* coef, float* bcoef, float* dgamma, float* dbeta,
                                      int accumulate, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 256)), dim3(256), 0, (hipStream_t)stream, sums, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, sums, C,
                        Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate);
     SEGNB_LAUNCH_CHECK();
     return 0;
