@@ -608,10 +608,14 @@ __device__ __forceinline__ TileGeom tile_geom(const PackJob& j) {
 
 constexpr int PACK_LDS_FLOATS = 256 * 9 > 64 * 8 * 9 ? 256 * 9 : 64 * 8 * 9;   // 4608
 
-// is_pack: parameter -> packed (round to dtype); else packed fp32 workspace -> += gradient, workspace zeroed
+// is_pack: parameter -> packed (round to dtype); else packed fp32 workspace -> += gradient, workspace zeroed.
+// The channel maps of the tile are staged in LDS once (a map lookup per element made every parameter access the
+// tail of a dependent-load chain) and the packed side moves 16 bytes per lane (8 bf16 / 4 fp32 along the
+// contiguous channel index; channel counts are padded to multiples of 8).
 template <bool IS_PACK>
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[PACK_LDS_FLOATS];
+    __shared__ long long sFast[256], sSlow[64];         // element offset of each fast / slow channel of the tile, -1 = pad
     const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
     const TileGeom g = tile_geom(j);
     const int tb = blockIdx.x - j.block_start;
@@ -621,15 +625,39 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
     const int Mp = j.Mp, Cp = j.Cp, nt = j.ntaps;
     float* param = const_cast<float*>(j.w);
     const int n_param = g.S * run;
-
+    {
+        const int* fmap = g.fast_is_c ? j.cmap : j.mmap;
+        const int* smap = g.fast_is_c ? j.mmap : j.cmap;
+        const int nfast = g.fast_is_c ? Cp : Mp, nslow = g.fast_is_c ? Mp : Cp;
+        const long long fstride = g.fast_is_c ? j.s_c : j.s_m, sstride = g.fast_is_c ? j.s_m : j.s_c;
+        for (int i = threadIdx.x; i < g.F; i += 256) {
+            const int v = f0 + i < nfast ? fmap[f0 + i] : -1;
+            sFast[i] = v >= 0 ? v * fstride : -1;
+        }
+        for (int i = threadIdx.x; i < g.S; i += 256) {
+            const int v = s0 + i < nslow ? smap[s0 + i] : -1;
+            sSlow[i] = v >= 0 ? v * sstride : -1;
+        }
+    }
+    __syncthreads();
     auto param_off = [&](int sl, int fa) -> long long {      // element offset of (slow, fast, tap 0) or -1
-        const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
-        const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
-        if (mp >= Mp || cp >= Cp) return -1;
-        const int m = j.mmap[mp], c = j.cmap[cp];
-        if (m < 0 || c < 0) return -1;
-        return m * j.s_m + c * j.s_c;
+        const long long a = sSlow[sl], b = sFast[fa];
+        return (a < 0 || b < 0) ? -1 : a + b;
     };
+    // packed side: [mp][t][cp]; groups of 8 consecutive cp (one 16-byte bf16 vector / two fp32 vectors)
+    const int ncp = g.fast_is_c ? g.F : g.S;             // cp extent of the tile (multiple of 8)
+    const int nmp = g.fast_is_c ? g.S : g.F;
+    const int groups = nmp * nt * (ncp / 8);
+    auto group = [&](int gi, int& mpl, int& t, int& cpl) {       // tile-local (mp, tap, first cp) of group gi
+        cpl = (gi % (ncp / 8)) * 8;
+        t = (gi / (ncp / 8)) % nt;
+        mpl = gi / ((ncp / 8) * nt);
+    };
+    auto tile_idx = [&](int mpl, int t, int cpl) {               // LDS index of packed element (mp, t, cp)
+        const int sl = g.fast_is_c ? mpl : cpl, fa = g.fast_is_c ? cpl : mpl;
+        return sl * run + fa * g.Tsrc + j.tap_off[t];
+    };
+    const int cp_step = g.fast_is_c ? g.Tsrc : run;              // LDS stride between consecutive cp
 
     if (IS_PACK) {
         // parameter -> LDS, in parameter order (coalesced along the fast channel and the taps)
@@ -640,38 +668,40 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
             tile[i] = off >= 0 ? param[off + tp] : 0.f;
         }
         __syncthreads();
-        // LDS -> packed, in packed order
-        const int n_packed = g.S * g.F * nt;
-        for (int i = threadIdx.x; i < n_packed; i += 256) {
-            int sl, fa, t;
-            if (g.fast_is_c) { fa = i % g.F; t = (i / g.F) % nt; sl = i / (g.F * nt); }
-            else             { sl = i % g.S; t = (i / g.S) % nt; fa = i / (g.S * nt); }
-            const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
-            const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
+        // LDS -> packed, 8 consecutive cp per lane
+        for (int gi = threadIdx.x; gi < groups; gi += 256) {
+            int mpl, t, cpl;
+            group(gi, mpl, t, cpl);
+            const int mp = (g.fast_is_c ? s0 : f0) + mpl, cp = (g.fast_is_c ? f0 : s0) + cpl;
             if (mp < Mp && cp < Cp) {
-                const float v = tile[sl * run + fa * g.Tsrc + j.tap_off[t]];
+                float v[8];
+                const int base = tile_idx(mpl, t, cpl);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tile[base + k * cp_step];
                 const long long di = ((long long)mp * nt + t) * Cp + cp;
                 if (j.dtype == SEGNB_BF16)
-                    reinterpret_cast<bf16_t*>(j.packed)[di] = Elem<bf16_t>::from_f32(v);
+                    store8(reinterpret_cast<bf16_t*>(j.packed) + di, v);
                 else
-                    reinterpret_cast<float*>(j.packed)[di] = v;
+                    store8(reinterpret_cast<float*>(j.packed) + di, v);
             }
         }
     } else {
         float* dwp = reinterpret_cast<float*>(j.packed);
         for (int i = threadIdx.x; i < n_param; i += 256) tile[i] = 0.f;
         __syncthreads();
-        const int n_packed = g.S * g.F * nt;
-        for (int i = threadIdx.x; i < n_packed; i += 256) {
-            int sl, fa, t;
-            if (g.fast_is_c) { fa = i % g.F; t = (i / g.F) % nt; sl = i / (g.F * nt); }
-            else             { sl = i % g.S; t = (i / g.S) % nt; fa = i / (g.S * nt); }
-            const int mp = g.fast_is_c ? s0 + sl : f0 + fa;
-            const int cp = g.fast_is_c ? f0 + fa : s0 + sl;
+        for (int gi = threadIdx.x; gi < groups; gi += 256) {
+            int mpl, t, cpl;
+            group(gi, mpl, t, cpl);
+            const int mp = (g.fast_is_c ? s0 : f0) + mpl, cp = (g.fast_is_c ? f0 : s0) + cpl;
             if (mp < Mp && cp < Cp) {
                 const long long di = ((long long)mp * nt + t) * Cp + cp;
-                tile[sl * run + fa * g.Tsrc + j.tap_off[t]] = dwp[di];      // taps are distinct: no collisions
-                dwp[di] = 0.f;
+                float v[8];
+                load8(dwp + di, v);
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store8(dwp + di, z);                                  // workspace consumed
+                const int base = tile_idx(mpl, t, cpl);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tile[base + k * cp_step] = v[k];      // taps are distinct: no collisions
             }
         }
         __syncthreads();
