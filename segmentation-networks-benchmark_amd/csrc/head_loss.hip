@@ -77,16 +77,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
         for (int e = 0; e < 8; ++e) gw[k][e] = 0.f;
     }
     if (active)
-        for (long long pix = (long long)blockIdx.x * PY + ty; pix < npix; pix += (long long)gridDim.x * PY) {
-            const long long n = pix / hw, r = pix - n * hw;
+        for (int pix = blockIdx.x * PY + ty; pix < (int)npix; pix += gridDim.x * PY) {     // npix < 2^31 (checked)
+            const int n = pix / (int)hw, r = pix - n * (int)hw;
             float av[8], d[8];
-            load8(a + pix * ld_a + c0, av);
+            load8(a + (long long)pix * ld_a + c0, av);
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[e] = 0.f;
 #pragma unroll
             for (int k = 0; k < MAXK; ++k)
                 if (k < K) {
-                    const float g = dl[(n * K + k) * hw + r];
+                    const float g = dl[((long long)n * K + k) * hw + r];
                     gb[k] += g;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
                         gw[k][e] = fmaf(g, av[e], gw[k][e]);
                     }
                 }
-            if (da != nullptr) store8(da + pix * ld_da + c0, d);
+            if (da != nullptr) store8(da + (long long)pix * ld_da + c0, d);
         }
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
@@ -249,6 +249,7 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
     SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
     SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Cp % 8 == 0 && Cp >= C, "bad shape");
     const long long npix = (long long)N * H * W;
+    SEGNB_CHECK_ARG(npix < (1ll << 30), "pixel count exceeds the 32-bit index range");
     const int CPP = Cp / 8;
     int ct = 1;
     while (ct < CPP && ct < 32) ct <<= 1;

@@ -46,15 +46,17 @@ static dim3 make_grid(const EwShape& s, long long items, int max_blocks = 2048) 
     return dim3((unsigned)gx, (unsigned)gy);
 }
 
+// Branch-free activations: none / ReLU / LeakyReLU are all "negative side scaled by s" with s = 1 / 0 / slope (a
+// switch on `act` per element compiled to two scalar branches per element -- 153 branches in the pooled backward
+// kernel -- with the loads fenced between them).  "+ 0.f" turns ReLU's -0.0 into torch's +0.0.
+__device__ __forceinline__ float act_neg_scale(int act, float slope) {
+    return act == SEGNB_ACT_RELU ? 0.f : (act == SEGNB_ACT_LEAKY ? slope : 1.f);
+}
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
-    if (act == SEGNB_ACT_RELU) return z > 0.f ? z : 0.f;
-    if (act == SEGNB_ACT_LEAKY) return z > 0.f ? z : z * slope;
-    return z;
+    return (z > 0.f ? z : z * act_neg_scale(act, slope)) + 0.f;
 }
 __device__ __forceinline__ float act_grad(float z, int act, float slope) {
-    if (act == SEGNB_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-    if (act == SEGNB_ACT_LEAKY) return z > 0.f ? 1.f : slope;
-    return 1.f;
+    return z > 0.f ? 1.f : act_neg_scale(act, slope);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,53 +175,58 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
         }
         return;
     }
-    const int H2 = (s.H + 1) >> 1, W2 = (s.W + 1) >> 1;
+    // pooling: a thread owns one pixel COLUMN of a row pair (2 pixels), so the loads / stores of a wave are
+    // contiguous runs of a row; the 2x2 window maximum meets its horizontal partner (lane ^ CT: the row is walked
+    // over an even padded width) through one cross-lane exchange.  (A thread per 2x2 window touched half of every
+    // 128-byte line per instruction.)
+    const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
     const int Hp = s.H >> 1, Wp = s.W >> 1;
-    const long long nwin = (long long)s.N * H2 * W2;
-    for (long long win = (long long)blockIdx.x * s.PY + ty; win < nwin; win += (long long)gridDim.x * s.PY) {
-        const int n = (int)(win / (H2 * W2));
-        const int rem = (int)(win - (long long)n * (H2 * W2));
-        const int h2 = rem / W2, w2 = rem - h2 * W2;
+    const int nitems = s.N * H2 * We;
+    for (int it = blockIdx.x * s.PY + ty; it < nitems; it += gridDim.x * s.PY) {
+        const int n = it / (H2 * We);
+        const int rem = it - n * (H2 * We);
+        const int h2 = rem / We, w = rem - h2 * We;
         float dm[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) dm[e] = 1.f;
-        if (dropmul != nullptr) load8(dropmul + (long long)n * s.Cp + c0, dm);
+        if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
         float mx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < 2; ++dy) {
+            const int hh = 2 * h2 + dy;
+            if (hh < s.H && w < s.W) {
+                const long long pix = ((long long)n * s.H + hh) * s.W + w;
+                float v[8], rv[8];
+                load8(y + pix * ld_y + c0, v);
+                if (res != nullptr) {
+                    load8(res + pix * ld_res + c0, rv);
+                } else {
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int hh = 2 * h2 + dy, ww = 2 * w2 + dx;
-                if (hh < s.H && ww < s.W) {
-                    const long long pix = ((long long)n * s.H + hh) * s.W + ww;
-                    float v[8], rv[8];
-                    load8(y + pix * ld_y + c0, v);
-                    if (res != nullptr) {
-                        load8(res + pix * ld_res + c0, rv);
-                    } else {
+                    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                }
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
-                        mx[e] = fmaxf(mx[e], v[e]);
-                    }
-                    if (out != nullptr) store8(out + pix * ld_out + c0, v);
-                    if (up_out != nullptr) {
-                        const long long W2x = 2ll * s.W;
-                        const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
-                        store8(up_out + p00 * ld_up + c0, v);
-                        store8(up_out + (p00 + 1) * ld_up + c0, v);
-                        store8(up_out + (p00 + W2x) * ld_up + c0, v);
-                        store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
+                    mx[e] = fmaxf(mx[e], v[e]);
+                }
+                if (out != nullptr) store8(out + pix * ld_out + c0, v);
+                if (up_out != nullptr) {
+                    const long long W2x = 2ll * s.W;
+                    const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * w;
+                    store8(up_out + p00 * ld_up + c0, v);
+                    store8(up_out + (p00 + 1) * ld_up + c0, v);
+                    store8(up_out + (p00 + W2x) * ld_up + c0, v);
+                    store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
                 }
             }
-        if (pool_out != nullptr && h2 < Hp && w2 < Wp) {
-            const long long pp = ((long long)n * Hp + h2) * Wp + w2;
+        }
+        // horizontal partner: columns w and w^1 are lanes l and l^CT of one wave (items are walked in pairs)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], s.CT));
+        if ((w & 1) == 0 && h2 < Hp && (w >> 1) < Wp) {
+            const long long pp = ((long long)n * Hp + h2) * Wp + (w >> 1);
             store8(pool_out + pp * ld_pool + c0, mx);
         }
     }
@@ -342,62 +349,69 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
 
     if (active) {
         if (HAS_P) {
-            // 2x2 windows: MaxPool2d backward routes the pooled gradient to the FIRST maximum (scan order)
-            const int H2 = (s.H + 1) >> 1, W2 = (s.W + 1) >> 1;
+            // 2x2 windows: MaxPool2d backward routes the pooled gradient to the FIRST maximum (scan order).  A thread
+            // owns one pixel column of a row pair (contiguous loads / stores per wave); the activations of the other
+            // column of its window come from lane ^ CT (items are walked over an even padded width, in pairs)
+            const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
             const int Hp = s.H >> 1, Wp = s.W >> 1;
-            const long long nwin = (long long)s.N * H2 * W2;
-            for (long long win = (long long)blockIdx.x * s.PY + ty; win < nwin; win += (long long)gridDim.x * s.PY) {
-                const int n = (int)(win / (H2 * W2));
-                const int rem = (int)(win - (long long)n * (H2 * W2));
-                const int h2 = rem / W2, w2 = rem - h2 * W2;
+            const int nitems = s.N * H2 * We;
+            for (int it = blockIdx.x * s.PY + ty; it < nitems; it += gridDim.x * s.PY) {
+                const int n = it / (H2 * We);
+                const int rem = it - n * (H2 * We);
+                const int h2 = rem / We, w = rem - h2 * We;
+                const int dx = w & 1, w2 = w >> 1;
                 float dm[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dm[e] = 1.f;
-        if (dropmul != nullptr) load8(dropmul + (long long)n * s.Cp + c0, dm);
-                float yv[4][8];
-                bool valid[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int hh = 2 * h2 + (p >> 1), ww = 2 * w2 + (p & 1);
-                    valid[p] = hh < s.H && ww < s.W;
-                    if (valid[p]) {
-                        load8(y + (((long long)n * s.H + hh) * s.W + ww) * ld_y + c0, yv[p]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) yv[p][e] = 0.f;
-                    }
-                }
+                if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
+                // every load of the item is requested up front (y, the direct gradient and the pooled gradient):
+                // one memory round trip per item instead of two
+                float yv[2][8], av[2][8], gd[2][8], gp[8];
+                bool valid[2];
                 const bool pooled = h2 < Hp && w2 < Wp;
-                float gp[8];
-                unsigned amax = 0;       // 2 bits per channel
-                if (pooled) {
-                    load8(g_pool + (((long long)n * Hp + h2) * Wp + w2) * ld_gp + c0, gp);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        int am = 0;
-                        float m = round_as(dm[e] * act_fwd((yv[0][e] - mu[e]) * sc[e] + sh[e], act, slope), y);
+                for (int r = 0; r < 2; ++r) {
+                    const int hh = 2 * h2 + r;
+                    valid[r] = hh < s.H && w < s.W;
 #pragma unroll
-                        for (int p = 1; p < 4; ++p) {
-                            const float av = round_as(dm[e] * act_fwd((yv[p][e] - mu[e]) * sc[e] + sh[e], act, slope), y);
-                            if (av > m) {
-                                m = av;
-                                am = p;
-                            }
-                        }
-                        amax |= (unsigned)am << (2 * e);
+                    for (int e = 0; e < 8; ++e) yv[r][e] = gd[r][e] = 0.f;
+                    if (valid[r]) {
+                        const long long pix = ((long long)n * s.H + hh) * s.W + w;
+                        load8(y + pix * ld_y + c0, yv[r]);
+                        if (HAS_D) load8(g_direct + pix * ld_gd + c0, gd[r]);
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (!valid[p]) continue;
-                    const int hh = 2 * h2 + (p >> 1), ww = 2 * w2 + (p & 1);
-                    const long long pix = ((long long)n * s.H + hh) * s.W + ww;
-                    float g[8];
+                for (int e = 0; e < 8; ++e) gp[e] = 0.f;
+                if (pooled) load8(g_pool + (((long long)n * Hp + h2) * Wp + w2) * ld_gp + c0, gp);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = (pooled && ((amax >> (2 * e)) & 3u) == (unsigned)p) ? gp[e] : 0.f;
-                    bwd_pixel<T, HAS_D, HAS_U>(yv[p], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
-                                               ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz,
-                                               ld_dz, s1, s2, res, ld_res);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        av[r][e] = round_as(dm[e] * act_fwd((yv[r][e] - mu[e]) * sc[e] + sh[e], act, slope), y);
+                float gtop[8], gbot[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ptop = __shfl_xor(av[0][e], s.CT), pbot = __shfl_xor(av[1][e], s.CT);
+                    // window in scan order: (0,0) (0,1) (1,0) (1,1); this lane's pixels are positions dx and 2+dx
+                    const float a0 = dx ? ptop : av[0][e], a1 = dx ? av[0][e] : ptop;
+                    const float a2 = dx ? pbot : av[1][e], a3 = dx ? av[1][e] : pbot;
+                    int am = 0;
+                    float m = a0;
+                    if (a1 > m) { m = a1; am = 1; }
+                    if (a2 > m) { m = a2; am = 2; }
+                    if (a3 > m) { m = a3; am = 3; }
+                    gtop[e] = ((pooled && am == dx) ? gp[e] : 0.f) + gd[0][e];
+                    gbot[e] = ((pooled && am == 2 + dx) ? gp[e] : 0.f) + gd[1][e];
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (!valid[r]) continue;
+                    const int hh = 2 * h2 + r;
+                    const long long pix = ((long long)n * s.H + hh) * s.W + w;
+                    bwd_pixel<T, false, HAS_U>(yv[r], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
+                                               ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * w, up_row, c0,
+                                               r == 0 ? gtop : gbot, dz, ld_dz, s1, s2, res, ld_res);
                 }
             }
         } else {
@@ -702,7 +716,8 @@ extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
-    const long long items = pool_out != nullptr ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
+    // pooling: one item per pixel column of a row pair, over an even padded width
+    const long long items = pool_out != nullptr ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
     const dim3 grid = make_grid(s, items, pool_out != nullptr ? 2048 : 4096);
     if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
@@ -731,7 +746,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
     SEGNB_CHECK_ARG(!(res && g_pool), "residual input and pooled gradient cannot be combined");
     const EwShape s = make_shape(N, H, W, Cp);
     const bool hd = g_direct != nullptr, hp = g_pool != nullptr, hu = g_up != nullptr;
-    const long long items = hp ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W;
+    const long long items = hp ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
     const dim3 grid = make_grid(s, items);
     const int variant = (hd ? 1 : 0) | (hp ? 2 : 0) | (hu ? 4 : 0);
 #define SEGNB_RED(TT, D, P, U)                                                                                      \

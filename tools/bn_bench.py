@@ -66,6 +66,7 @@ def main():
                                  dz.ptr, dz.ld, dz.ptr, dz.ld, None, C, rt.stream)
         cases = [('fwd', fwd(o=out), 2.0), ('fwd+pool+drop', fwd(o=out, p=pool, d=drop), 2.25),
                  ('red(d)', red(gd=g), 3.0), ('red(d+pool)', red(gd=g, gpp=gp, d=drop), 3.25), ('apply', apply_, 3.0)]
+        cases += [('red(pool)', red(gpp=gp), 2.25), ('red(d+pool,nodrop)', red(gd=g, gpp=gp), 3.25)]
         if up is not None:
             cases += [('fwd(up)', fwd(u=up, d=drop), 5.0), ('red(up)', red(guu=gu, d=drop), 6.0)]
         line = '%3dx%-3d C=%-4d' % (hw, hw, C)
