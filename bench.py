@@ -215,4 +215,9 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _td
+        if _td.is_available() and _td.is_initialized():
+            _td.destroy_process_group()
