@@ -154,6 +154,26 @@ int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, in
                             const void* res, int ld_res, segnb_stream_t stream);
 /* (with a residual input, dz is also the gradient of the residual branch) */
 
+/* segnb_bn_finalize + segnb_bn_act_fwd in ONE launch (training mode): every block derives the coefficients of its
+ * channels from `stats`; the first block column also writes `coef` (for the backward pass), updates the running
+ * statistics / *nbt and zeroes `bwd_sums_to_clear` (this layer's backward accumulators, NULL to skip).  `stats` is
+ * NOT consumed here -- other blocks are still reading it: segnb_bn_bwd_apply_fused of the same layer clears it (a
+ * caller that runs no backward must clear it itself before the next forward).  count = N*H*W. */
+int segnb_bn_fwd_fused(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                       const double* stats, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, long long* nbt, float* coef,
+                       double* bwd_sums_to_clear, int act, float slope, const float* dropmul, void* out,
+                       int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up, const void* res,
+                       int ld_res, segnb_stream_t stream);
+
+/* segnb_bn_bwd_finalize + segnb_bn_bwd_apply in ONE launch: bcoef from `sums` per block, the first block column
+ * writes bcoef / dgamma / dbeta and zeroes `fwd_stats_to_clear` (the forward statistics of this layer, NULL to
+ * skip).  `sums` is NOT consumed here: the next segnb_bn_fwd_fused of the layer clears it. */
+int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                             const float* coef, const double* sums, const float* gamma, float* bcoef,
+                             float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
+                             const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream);
+
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */
 int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,

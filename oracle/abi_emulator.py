@@ -339,6 +339,30 @@ class AbiEmulator(object):
         return 0
 
     # ------------------------------------------------------------------------------------------ generic NHWC ops
+    def segnb_bn_fwd_fused(self, dtype, y, ld_y, N, H, W, C, Cp, stats, gamma, beta, eps, momentum, rm, rv, nbt, coef,
+                           clear_sums, act, slope, dropmul, out, ld_out, pool_out, ld_pool, up_out, ld_up, res, ld_res,
+                           stream):
+        """finalize + act_fwd; the forward statistics are left as they are, the backward sums are cleared."""
+        keep = _mem(stats, REPL * 2 * Cp, torch.float64).clone()
+        rc = self.segnb_bn_finalize(stats, C, Cp, float(N * H * W), gamma, beta, eps, momentum, rm, rv, nbt, 1, coef,
+                                    stream)
+        _mem(stats, REPL * 2 * Cp, torch.float64).copy_(keep)
+        if clear_sums is not None:
+            _mem(clear_sums, REPL * 2 * Cp, torch.float64).zero_()
+        return rc or self.segnb_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out,
+                                           pool_out, ld_pool, up_out, ld_up, res, ld_res, stream)
+
+    def segnb_bn_bwd_apply_fused(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                 accumulate, clear_stats, dz, ld_dz, dy, ld_dy, stream):
+        keep = _mem(sums, REPL * 2 * Cp, torch.float64).clone()
+        rc = self.segnb_bn_bwd_finalize(sums, C, Cp, float(N * H * W), gamma, coef, bcoef, dgamma, dbeta, accumulate,
+                                        stream)
+        _mem(sums, REPL * 2 * Cp, torch.float64).copy_(keep)
+        if clear_stats is not None:
+            _mem(clear_stats, REPL * 2 * Cp, torch.float64).zero_()
+        return rc or self.segnb_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, None, C,
+                                             stream)
+
     def segnb_add(self, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream):
         dt = _tdt(dtype)
         r = (_nhwc(a, N, H, W, Cp, ld_a, dt).float() + _nhwc(b, N, H, W, Cp, ld_b, dt).float()).to(dt)

@@ -60,56 +60,78 @@ __device__ __forceinline__ float act_grad(float z, int act, float slope) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, int Cp, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, long long* nbt,
-                                   int training, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && training && nbt != nullptr) nbt[0] += 1;
-    if (c >= Cp) return;
-    float scale = 0.f, shift = 0.f, mean = 0.f, invstd = 0.f;
-    if (c < C) {
-        double mu, var;
-        if (training) {
-            // all 32 loads first, then the 32 zero stores: interleaved, every store fences the next load behind
-            // it (same array) and the kernel is a chain of 16 round trips
-            double v1[REPL], v2[REPL];
+// per-channel forward coefficients from the replicated statistics (training) or the running statistics (eval);
+// `update` = this thread owns the channel's side effects (running statistics)
+struct BnFwdParams {
+    const double* stats;        // [REPL][2][Cp]; read-only in the fused kernel
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    long long* nbt;
+    int C, training;
+    float* coef;                // [4][Cp] out
+    double* zero_buf;           // fused only: the BACKWARD accumulators of this layer, cleared for this step
+};
+
+__device__ __forceinline__ void bn_fwd_coef(const BnFwdParams& p, int Cp, int c, bool update, float& scale,
+                                            float& shift, float& mean, float& invstd) {
+    scale = shift = mean = invstd = 0.f;
+    if (c >= p.C) return;
+    double mu, var;
+    if (p.training) {
+        double v1[REPL], v2[REPL];
 #pragma unroll
-            for (int rp = 0; rp < REPL; ++rp) {
-                v1[rp] = stats[(rp * 2) * Cp + c];
-                v2[rp] = stats[(rp * 2 + 1) * Cp + c];
-            }
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int rp = 0; rp < REPL; ++rp) {
-                s1 += v1[rp];
-                s2 += v2[rp];
-                stats[(rp * 2) * Cp + c] = 0.0;
-                stats[(rp * 2 + 1) * Cp + c] = 0.0;
-            }
-            mu = s1 / count;
-            var = s2 / count - mu * mu;
-            if (var < 0.0) var = 0.0;
-            if (running_mean != nullptr) {
-                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
-                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
-            }
-        } else {
-            mu = (double)running_mean[c];
-            var = (double)running_var[c];
+        for (int rp = 0; rp < REPL; ++rp) {
+            v1[rp] = p.stats[(rp * 2) * Cp + c];
+            v2[rp] = p.stats[(rp * 2 + 1) * Cp + c];
         }
-        mean = (float)mu;
-        invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma != nullptr ? gamma[c] : 1.f;
-        const float b = beta != nullptr ? beta[c] : 0.f;
-        scale = g * invstd;
-        shift = b;   // z = (y - mean) * scale + beta : no cancellation between mean*scale and beta
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            s1 += v1[rp];
+            s2 += v2[rp];
+        }
+        mu = s1 / p.count;
+        var = s2 / p.count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        if (update && p.running_mean != nullptr) {
+            const double unb = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+            p.running_mean[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_mean[c] + (double)p.momentum * mu);
+            p.running_var[c] = (float)((1.0 - (double)p.momentum) * (double)p.running_var[c] + (double)p.momentum * unb);
+        }
+    } else {
+        mu = (double)p.running_mean[c];
+        var = (double)p.running_var[c];
     }
-    coef[c] = scale;
-    coef[Cp + c] = shift;
-    coef[2 * Cp + c] = mean;
-    coef[3 * Cp + c] = invstd;
+    mean = (float)mu;
+    invstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float g = p.gamma != nullptr ? p.gamma[c] : 1.f;
+    const float b = p.beta != nullptr ? p.beta[c] : 0.f;
+    scale = g * invstd;
+    shift = b;   // z = (y - mean) * scale + beta : no cancellation between mean*scale and beta
+}
+
+__global__ void bn_finalize_kernel(const BnFwdParams p, int Cp) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && p.training && p.nbt != nullptr) p.nbt[0] += 1;
+    if (c >= Cp) return;
+    float scale, shift, mean, invstd;
+    bn_fwd_coef(p, Cp, c, true, scale, shift, mean, invstd);
+    if (p.training && c < p.C) {            // the stand-alone finalize CONSUMES the statistics
+        double* st = const_cast<double*>(p.stats);
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            st[(rp * 2) * Cp + c] = 0.0;
+            st[(rp * 2 + 1) * Cp + c] = 0.0;
+        }
+    }
+    p.coef[c] = scale;
+    p.coef[Cp + c] = shift;
+    p.coef[2 * Cp + c] = mean;
+    p.coef[3 * Cp + c] = invstd;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -119,13 +141,54 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ dropmul, T* __restrict__ out,
                                                           int ld_out, T* __restrict__ pool_out, int ld_pool,
                                                           T* __restrict__ up_out, int ld_up,
-                                                          const T* __restrict__ res, int ld_res) {
+                                                          const T* __restrict__ res, int ld_res, const BnFwdParams fp) {
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
-    if (cc >= s.CPP) return;
-    const int c0 = cc * 8;
+    const int c0 = cc < s.CPP ? cc * 8 : 0;
     float sc[8], sh[8], mu[8];
-    if (coef != nullptr) {          // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
+    if (fp.coef != nullptr) {
+        // fused finalize: every block derives the coefficients of its CT*8 channels from the statistics (one
+        // channel per thread, through LDS); the blocks of column 0 also publish them for the backward pass, update
+        // the running statistics and clear this layer's BACKWARD accumulators.  The forward statistics are left
+        // intact -- other blocks are still reading them -- and are cleared by segnb_bn_bwd_apply_fused.
+        __shared__ float scoef[3][32 * 8];
+        const int nch = s.CT * 8;
+        if ((int)threadIdx.x < nch) {
+            const int c = blockIdx.y * nch + threadIdx.x;
+            float scale = 0.f, shift = 0.f, mean = 0.f, invstd = 0.f;
+            if (c < s.Cp) {
+                const bool owner = blockIdx.x == 0;
+                bn_fwd_coef(fp, s.Cp, c, owner, scale, shift, mean, invstd);
+                if (owner) {
+                    fp.coef[c] = scale;
+                    fp.coef[s.Cp + c] = shift;
+                    fp.coef[2 * s.Cp + c] = mean;
+                    fp.coef[3 * s.Cp + c] = invstd;
+                    if (fp.zero_buf != nullptr) {
+#pragma unroll
+                        for (int rp = 0; rp < REPL; ++rp) {
+                            fp.zero_buf[(rp * 2) * s.Cp + c] = 0.0;
+                            fp.zero_buf[(rp * 2 + 1) * s.Cp + c] = 0.0;
+                        }
+                    }
+                    if (c == 0 && fp.training && fp.nbt != nullptr) fp.nbt[0] += 1;
+                }
+            }
+            scoef[0][threadIdx.x] = scale;
+            scoef[1][threadIdx.x] = shift;
+            scoef[2][threadIdx.x] = mean;
+        }
+        __syncthreads();
+        if (cc >= s.CPP) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = scoef[0][tx * 8 + e];
+            sh[e] = scoef[1][tx * 8 + e];
+            mu[e] = scoef[2][tx * 8 + e];
+        }
+    } else if (cc >= s.CPP) {
+        return;
+    } else if (coef != nullptr) {   // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
         load8(coef + c0, sc);
         load8(coef + s.Cp + c0, sh);
         load8(coef + 2 * s.Cp + c0, mu);
@@ -448,37 +511,60 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, int C, int Cp, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ coef,
-                                       float* __restrict__ bcoef, float* dgamma, float* dbeta, int accumulate) {
+struct BnBwdParams {
+    const double* sums;         // [REPL][2][Cp]: sum dz, sum dz*yhat; read-only in the fused kernel
+    double count;
+    const float* gamma;
+    float* dgamma;
+    float* dbeta;
+    int C, accumulate;
+    float* bcoef;               // [3][Cp] out
+    double* zero_buf;           // fused only: the FORWARD statistics of this layer, cleared for the next step
+};
+
+// bcoef = (gamma*invstd, mean(dz), mean(dz*yhat)); `update` = this thread owns dgamma / dbeta of the channel
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdParams& p, const float* __restrict__ coef, int Cp, int c,
+                                            bool update, float& a, float& c1, float& c2) {
+    a = c1 = c2 = 0.f;
+    if (c >= p.C) return;
+    double v1[REPL], v2[REPL];          // loads first (see bn_fwd_coef)
+#pragma unroll
+    for (int rp = 0; rp < REPL; ++rp) {
+        v1[rp] = p.sums[(rp * 2) * Cp + c];
+        v2[rp] = p.sums[(rp * 2 + 1) * Cp + c];
+    }
+    double sdz = 0.0, sdzy = 0.0;
+#pragma unroll
+    for (int rp = 0; rp < REPL; ++rp) {
+        sdz += v1[rp];
+        sdzy += v2[rp];
+    }
+    const float g = p.gamma != nullptr ? p.gamma[c] : 1.f;
+    a = g * coef[3 * Cp + c];
+    c1 = (float)(sdz / p.count);
+    c2 = (float)(sdzy / p.count);
+    if (update) {
+        if (p.dgamma != nullptr) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sdzy;
+        if (p.dbeta != nullptr) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sdz;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const BnBwdParams p, const float* __restrict__ coef, int Cp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cp) return;
-    float a = 0.f, c1 = 0.f, c2 = 0.f;
-    if (c < C) {
-        double v1[REPL], v2[REPL];          // loads first, zero stores after (see bn_finalize_kernel)
+    float a, c1, c2;
+    bn_bwd_coef(p, coef, Cp, c, true, a, c1, c2);
+    if (c < p.C) {                      // the stand-alone finalize CONSUMES the sums
+        double* sm = const_cast<double*>(p.sums);
 #pragma unroll
         for (int rp = 0; rp < REPL; ++rp) {
-            v1[rp] = sums[(rp * 2) * Cp + c];
-            v2[rp] = sums[(rp * 2 + 1) * Cp + c];
+            sm[(rp * 2) * Cp + c] = 0.0;
+            sm[(rp * 2 + 1) * Cp + c] = 0.0;
         }
-        double sdz = 0.0, sdzy = 0.0;
-#pragma unroll
-        for (int rp = 0; rp < REPL; ++rp) {
-            sdz += v1[rp];
-            sdzy += v2[rp];
-            sums[(rp * 2) * Cp + c] = 0.0;
-            sums[(rp * 2 + 1) * Cp + c] = 0.0;
-        }
-        const float g = gamma != nullptr ? gamma[c] : 1.f;
-        a = g * coef[3 * Cp + c];
-        c1 = (float)(sdz / count);
-        c2 = (float)(sdzy / count);
-        if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sdzy;
-        if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sdz;
     }
-    bcoef[c] = a;
-    bcoef[Cp + c] = c1;
-    bcoef[2 * Cp + c] = c2;
+    p.bcoef[c] = a;
+    p.bcoef[Cp + c] = c1;
+    p.bcoef[2 * Cp + c] = c2;
 }
 
 template <typename T>
@@ -486,22 +572,52 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ coef,
                                                             const float* __restrict__ bcoef,
                                                             const T* __restrict__ dz, int ld_dz, T* __restrict__ dy,
-                                                            int ld_dy, float* __restrict__ dbias, int C) {
+                                                            int ld_dy, float* __restrict__ dbias, int C,
+                                                            const BnBwdParams bp) {
     __shared__ float sred[32 * 8];
+    __shared__ float sb3[3][32 * 8];
     for (int i = threadIdx.x; i < 32 * 8; i += NTHR) sred[i] = 0.f;
-    __syncthreads();
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;
     const int c0 = active ? cc * 8 : 0;
+    if (bp.bcoef != nullptr) {
+        // fused finalize (mirror of the forward kernel): every block derives (a, c1, c2) of its channels from the
+        // sums; the blocks of column 0 publish them, write dgamma / dbeta and clear this layer's FORWARD statistics
+        const int nch = s.CT * 8;
+        if ((int)threadIdx.x < nch) {
+            const int c = blockIdx.y * nch + threadIdx.x;
+            float a = 0.f, c1 = 0.f, c2 = 0.f;
+            if (c < s.Cp) {
+                const bool owner = blockIdx.x == 0;
+                bn_bwd_coef(bp, coef, s.Cp, c, owner, a, c1, c2);
+                if (owner) {
+                    bp.bcoef[c] = a;
+                    bp.bcoef[s.Cp + c] = c1;
+                    bp.bcoef[2 * s.Cp + c] = c2;
+                    if (bp.zero_buf != nullptr) {
+#pragma unroll
+                        for (int rp = 0; rp < REPL; ++rp) {
+                            bp.zero_buf[(rp * 2) * s.Cp + c] = 0.0;
+                            bp.zero_buf[(rp * 2 + 1) * s.Cp + c] = 0.0;
+                        }
+                    }
+                }
+            }
+            sb3[0][threadIdx.x] = a;
+            sb3[1][threadIdx.x] = c1;
+            sb3[2][threadIdx.x] = c2;
+        }
+    }
+    __syncthreads();
     float mu[8], is[8], a[8], c1[8], c2[8], sb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         mu[e] = coef[2 * s.Cp + c0 + e];
         is[e] = coef[3 * s.Cp + c0 + e];
-        a[e] = bcoef[c0 + e];
-        c1[e] = bcoef[s.Cp + c0 + e];
-        c2[e] = bcoef[2 * s.Cp + c0 + e];
+        a[e] = bp.bcoef != nullptr ? sb3[0][tx * 8 + e] : bcoef[c0 + e];
+        c1[e] = bp.bcoef != nullptr ? sb3[1][tx * 8 + e] : bcoef[s.Cp + c0 + e];
+        c2[e] = bp.bcoef != nullptr ? sb3[2][tx * 8 + e] : bcoef[2 * s.Cp + c0 + e];
         sb[e] = 0.f;
     }
     const long long npix = (long long)s.N * s.H * s.W;
@@ -703,16 +819,43 @@ extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, con
     SEGNB_CHECK_ARG(coef != nullptr && C > 0 && Cp >= C && Cp % 8 == 0, "bad channel counts");
     SEGNB_CHECK_ARG(training ? stats != nullptr : (running_mean != nullptr && running_var != nullptr),
                     "missing statistics source");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, stats, C, Cp,
-                       count, gamma, beta, eps, momentum, running_mean, running_var, nbt, training, coef);
+    BnFwdParams fp = {stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, training, coef, nullptr};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, fp, Cp);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
+
+static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
+                             int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
+                             int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
+                             const char* who, segnb_stream_t stream);
 
 extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                 const float* coef, int act, float slope, const float* dropmul, void* out,
                                 int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up, const void* res,
                                 int ld_res, segnb_stream_t stream) {
+    BnFwdParams fp = {};
+    return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, pool_out, ld_pool,
+                             up_out, ld_up, res, ld_res, fp, "segnb_bn_act_fwd", stream);
+}
+
+extern "C" int segnb_bn_fwd_fused(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                  const double* stats, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, long long* nbt,
+                                  float* coef, double* bwd_sums_to_clear, int act, float slope, const float* dropmul,
+                                  void* out, int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
+                                  const void* res, int ld_res, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(stats != nullptr && coef != nullptr && C > 0 && Cp >= C, "missing statistics / coefficient buffer");
+    BnFwdParams fp = {stats, (double)N * H * W, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, 1, coef,
+                      bwd_sums_to_clear};
+    return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, nullptr, act, slope, dropmul, out, ld_out, pool_out, ld_pool,
+                             up_out, ld_up, res, ld_res, fp, "segnb_bn_fwd_fused", stream);
+}
+
+static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
+                             int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
+                             int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
+                             const char* who, segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
@@ -722,13 +865,13 @@ extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H
     if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, act, slope, dropmul, (bf16_t*)out, ld_out, (bf16_t*)pool_out, ld_pool,
-                           (bf16_t*)up_out, ld_up, (const bf16_t*)res, ld_res);
+                           (bf16_t*)up_out, ld_up, (const bf16_t*)res, ld_res, fp);
     else if (dtype == SEGNB_F32)
         hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y, ld_y,
                            s, coef, act, slope, dropmul, (float*)out, ld_out, (float*)pool_out, ld_pool,
-                           (float*)up_out, ld_up, (const float*)res, ld_res);
+                           (float*)up_out, ld_up, (const float*)res, ld_res, fp);
     else {
-        segnb_set_error("segnb_bn_act_fwd: unknown dtype %d", dtype);
+        segnb_set_error("%s: unknown dtype %d", who, dtype);
         return SEGNB_E_BADARG;
     }
     SEGNB_LAUNCH_CHECK();
@@ -781,8 +924,29 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
                                      const float* coef, float* bcoef, float* dgamma, float* dbeta,
                                      int accumulate, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, sums, C,
-                       Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate);
+    BnBwdParams bp = {sums, count, gamma, dgamma, dbeta, C, accumulate, bcoef, nullptr};
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, bp, coef, Cp);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
+                               const float* bcoef, const void* dz, int ld_dz, void* dy, int ld_dy, float* dbias, int C,
+                               const BnBwdParams& bp, const char* who, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y && coef && (bcoef || bp.bcoef) && dz && dy, "NULL tensor");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W, 1536);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
+                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp);
+    else {
+        segnb_set_error("%s: unknown dtype %d", who, dtype);
+        return SEGNB_E_BADARG;
+    }
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
@@ -790,22 +954,19 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
 extern "C" int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                   const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
                                   int ld_dy, float* dbias, int C, segnb_stream_t stream) {
-    if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y && coef && bcoef && dz && dy, "NULL tensor");
-    const EwShape s = make_shape(N, H, W, Cp);
-    const dim3 grid = make_grid(s, (long long)N * H * W, 1536);
-    if (dtype == SEGNB_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
-                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C);
-    else if (dtype == SEGNB_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
-                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C);
-    else {
-        segnb_set_error("segnb_bn_bwd_apply: unknown dtype %d", dtype);
-        return SEGNB_E_BADARG;
-    }
-    SEGNB_LAUNCH_CHECK();
-    return 0;
+    BnBwdParams bp = {};
+    return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, bp,
+                               "segnb_bn_bwd_apply", stream);
+}
+
+extern "C" int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                        const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                        float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
+                                        const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(sums != nullptr && bcoef != nullptr && C > 0 && Cp >= C, "missing sums / coefficient buffer");
+    BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
+    return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, dz, ld_dz, dy, ld_dy, nullptr, C, bp,
+                               "segnb_bn_bwd_apply_fused", stream);
 }
 
 extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream) {

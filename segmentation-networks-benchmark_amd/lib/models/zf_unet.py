@@ -252,20 +252,20 @@ class _ZFUnetPlan(object):
         cur = b['x']
         for i, name in enumerate(ENCODER):
             s1, s2 = self.stages[name]
-            s1.forward(cur, train, None, out=b['a1_%d' % i])
+            s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad)
             if i < 5:
                 skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
-                s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)])
+                s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
                 cur = b['p_%d' % (i + 1)]
             else:
-                s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]))
+                s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad)
         for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
             s1, s2 = self.stages[name]
-            s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl])
+            s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
             if lvl > 0:
-                s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]))
+                s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad)
             else:
-                s2.forward(b['b1_0'], train, drop[name], out=b['f0'])
+                s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
         head = self.module.conv_final
         logits = b['logits']
         nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],

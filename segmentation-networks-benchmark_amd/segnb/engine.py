@@ -370,6 +370,12 @@ class Stage(object):
     def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
         self.defer_unpack = False     # True: the model plan runs one batched unpack at the end of backward
+        # BatchNorm finalize folded into the activation / apply passes (segnb_bn_fwd_fused / _bwd_apply_fused): saves
+        # two 5 us launches per layer, but every block of the big kernel then starts with the same dependent
+        # statistics loads -- measured neutral on MI355X (7.47 vs 7.39 ms/step), so off by default
+        self.fuse_finalize = False
+        self._stats_stale = False
+        self._fused_fwd = False
         Cp = conv.Cop
         self.C, self.Cp = conv.Co, Cp
         self.stats = rt.zeros((STAT_REPLICAS, 2, Cp), torch.float64)   # consumed + re-zeroed by segnb_bn_finalize
@@ -386,14 +392,33 @@ class Stage(object):
             self._bufs[key] = b
         return b
 
-    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None):
+    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True):
         rt = self.rt
         Ho, Wo = self.conv.out_hw(xv.H, xv.W)
         b = self.buffers(xv.N, Ho, Wo)
         yv = b['y']
         use_batch_stats = self.bn is not None and train
+        if use_batch_stats and self._stats_stale:
+            # the previous training-mode forward was fused (statistics left unconsumed) and no backward cleared them
+            self.stats.zero_()
+            self._stats_stale = False
         self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
         coef = None
+        fused = use_batch_stats and self.fuse_finalize and need_grad
+        if fused:
+            # finalize folded into the activation pass (one launch less per layer and direction); the statistics are
+            # cleared by this layer's backward (segnb_bn_bwd_apply_fused), the backward sums here
+            bn = self.bn
+            nv.call('segnb_bn_fwd_fused', rt.code, yv.ptr, yv.ld, xv.N, Ho, Wo, self.C, self.Cp, nv.ptr(self.stats),
+                    nv.ptr(bn.weight.detach()), nv.ptr(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
+                    nv.ptr(bn.running_mean), nv.ptr(bn.running_var), nv.ptr(bn.num_batches_tracked),
+                    nv.ptr(self.coef), nv.ptr(self.sums), self.act, self.slope, nv.ptr(dropmul), vptr(out), vld(out),
+                    vptr(pool_out), vld(pool_out), vptr(up_out), vld(up_out), None, 0, rt.stream)
+            self._stats_stale = True
+            self._saved = (xv, yv, dropmul, True)
+            self._fused_fwd = True
+            return yv
+        self._fused_fwd = False
         if self.bn is not None:
             bn = self.bn
             nv.call('segnb_bn_finalize', nv.ptr(self.stats), self.C, self.Cp, float(xv.N * Ho * Wo),
@@ -419,7 +444,13 @@ class Stage(object):
                 vptr(g_up), vld(g_up), dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
-        if has_bn:
+        if has_bn and self._fused_fwd:
+            nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
+                    nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
+                    nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,
+                    nv.ptr(self.stats), dz.ptr, dz.ld, dz.ptr, dz.ld, rt.stream)
+            self._stats_stale = False
+        elif has_bn:
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count,
                     nv.ptr(self.bn.weight.detach()), nv.ptr(self.coef), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1, rt.stream)

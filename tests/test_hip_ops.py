@@ -282,6 +282,70 @@ def test_bn_act_pool_upsample_fwd_bwd(case, dtype):
         check('dbeta vs torch', g['dbet'], bet.grad, 'f32')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', BN_CASES[:4], ids=[str(c[:4]) for c in BN_CASES[:4]])
+def test_bn_fused_finalize_equals_separate_launches(case, dtype):
+    """segnb_bn_fwd_fused / segnb_bn_bwd_apply_fused == finalize + pass, bit for bit; and the accumulator hand-over:
+    the forward clears the backward sums, the backward clears the forward statistics."""
+    N, H, W, C, act, use_pool, use_up, use_drop = case
+    rt = Runtime('cuda', dtype)
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(C + H + 7)
+    yv = _view_from(rt, torch.randn(N, H, W, C, generator=gen) * 2 + 0.5, Cp)
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(C, generator=gen)).cuda()
+    dm = None
+    if use_drop:
+        dm = torch.ones(N, Cp, device='cuda')
+        dm[:, :C] = ((torch.rand(N, C, generator=gen) > 0.3).float() / 0.7).cuda()
+    gd = _view_from(rt, torch.randn(N, H, W, C, generator=gen), Cp)
+    res = {}
+    for fused in (False, True):
+        stats = rt.zeros((16, 2, Cp), torch.float64)
+        nv.call('segnb_bn_stats', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
+        stats0 = stats.clone()
+        sums = rt.zeros((16, 2, Cp), torch.float64)
+        sums.fill_(123.0 if fused else 0.0)         # the fused forward must clear them
+        coef, bcoef = rt.zeros((4, Cp), torch.float32), rt.zeros((3, Cp), torch.float32)
+        rm, rvv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+        out = View.alloc(rt, N, H, W, Cp)
+        pool = View.alloc(rt, N, H // 2, W // 2, Cp) if use_pool else None
+        up = View.alloc(rt, N, 2 * H, 2 * W, Cp) if use_up else None
+        tail = (act, 0.01, nv.ptr(dm), out.ptr, out.ld, None if pool is None else pool.ptr,
+                0 if pool is None else pool.ld, None if up is None else up.ptr, 0 if up is None else up.ld, None, 0,
+                rt.stream)
+        if fused:
+            nv.call('segnb_bn_fwd_fused', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(stats), nv.ptr(gamma),
+                    nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums), *tail)
+            assert torch.equal(stats, stats0) and float(sums.abs().max()) == 0.0
+        else:
+            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(gamma), nv.ptr(beta), 1e-5, 0.1,
+                    nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), 1, nv.ptr(coef), rt.stream)
+            nv.call('segnb_bn_act_fwd', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), *tail)
+        dz = View.alloc(rt, N, H, W, Cp)
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
+                gd.ptr, gd.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+        dgam, dbet = torch.ones(C, device='cuda'), torch.ones(C, device='cuda')     # accumulate on top of 1
+        dy = View.alloc(rt, N, H, W, Cp)
+        if fused:
+            nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums),
+                    nv.ptr(gamma), nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), dz.ptr, dz.ld, dy.ptr,
+                    dy.ld, rt.stream)
+            assert float(stats.abs().max()) == 0.0
+        else:
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma), nv.ptr(coef),
+                    nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, rt.stream)
+            nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr,
+                    dz.ld, dy.ptr, dy.ld, None, C, rt.stream)
+        torch.cuda.synchronize()
+        res[fused] = dict(coef=coef, bcoef=bcoef, rm=rm, rv=rvv, nbt=nbt, out=out.dense(), dy=dy.dense(), dgam=dgam,
+                          dbet=dbet, pool=None if pool is None else pool.dense(), up=None if up is None else up.dense())
+    for k, v in res[False].items():
+        if v is not None:
+            assert torch.equal(v, res[True][k]), k
+
+
 # ------------------------------------------------------------------------------------------------------
 # head, losses, SGD, input packing
 # ------------------------------------------------------------------------------------------------------
