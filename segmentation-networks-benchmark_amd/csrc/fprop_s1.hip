@@ -324,6 +324,8 @@ int dispatch_fs1(FpS1Args& a, hipStream_t stream) {
         if (a.Co <= 32) return launch_fs1<32, 8, 32, 4, BKC>(a, stream);
         const long long its = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 31) / 32);
         if (a.Co <= 64 || its * ((a.Co + 127) / 128) < cus) return launch_fs1<64, 4, 32, 2, BKC>(a, stream);
+        // thin-input data gradients of the concat layers (32 -> 96 @224^2, 64 -> 192 @112^2): 96-channel tiles
+        if (a.Ci <= 64 && a.Co % 96 == 0) return launch_fs1<96, 8, 32, 4, BKC>(a, stream);
         // wide layers on >= 28-pixel rows: the general gather kernel's flattened-pixel 128x128 tiles (no partial
         // row segments, one barrier per step) measure 20-25 % faster than the image-tile form here
         return NOT_HANDLED;

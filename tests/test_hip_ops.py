@@ -84,6 +84,8 @@ CONV_CASES = [
     ('3x3 s1x9 64x64',   2, 10, 36, [(80, 80)],            72, 3, 1, 1, False),
     ('3x3 s1x9 64x64 b', 1, 28, 28, [(128, 128)],          128, 3, 1, 1, False),
     ('3x3 s1x9 w16',     3, 14, 14, [(96, 96)],            160, 3, 1, 1, False),
+    ('3x3 s1x9 co96',    1, 20, 40, [(32, 32)],            96, 3, 1, 1, False),      # 96-channel output tiles
+    ('3x3 s1x9 co192',   1, 18, 36, [(64, 64)],            192, 3, 1, 1, False),
     ('3x3 s1x9 flat7',   6, 7, 7,   [(96, 96)],            72, 3, 1, 1, False),      # 4 images / iteration, ragged N
     ('3x3 s1x9 flat7 cat', 5, 7, 7, [(64, 64), (40, 40)],  136, 3, 1, 1, False),
     ('3x3 s1x9 flat14',  2, 14, 14, [(64, 64)],            64, 3, 1, 1, False),
