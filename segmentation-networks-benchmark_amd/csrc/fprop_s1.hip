@@ -36,7 +36,7 @@ __device__ __forceinline__ int xcd_remap_s1(int b, int G) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
-template <int BN, int R, int WT, int WAVES_M, int BKC>
+template <int BN, int R, int WT, int WAVES_M, int BKC, int TPS>
 struct FpS1Cfg {
     static constexpr int BM = R * WT;
     static constexpr int WAVES_N = 4 / WAVES_M;
@@ -46,7 +46,7 @@ struct FpS1Cfg {
     static constexpr int SX = BKC * 2 + 16;          // x tile row (one pixel) in bytes
     static constexpr int SB = BKC * 2 + 16;          // weight tile row (one output channel)
     static constexpr int X_BYTES = XR * XC * SX;
-    static constexpr int B_BYTES = BN * SB;
+    static constexpr int B_BYTES = TPS * BN * SB;      // weight tile of one step = TPS taps
     static constexpr int OUT_ROW = BN * 2 + 16;
     static constexpr int TILE_BYTES = X_BYTES + 2 * B_BYTES;
     static constexpr int STAGE_BYTES = BM * OUT_ROW;
@@ -55,13 +55,18 @@ struct FpS1Cfg {
     static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == 4, "wave tiling");
 };
 
-template <int BN, int R, int WT, int WAVES_M, int BKC>
+// TPS = taps per barrier step (1 or 3): the 32-channel tiles (4 MFMAs per wave and tap) take a whole kernel row of
+// taps per step, three barriers per channel chunk instead of nine (-10 % on the 224x224 layers; with 64-channel
+// tiles the tripled weight buffers cost the second resident block and lose 40 %)
+template <int BN, int R, int WT, int WAVES_M, int BKC, int TPS>
 __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) {
-    using C = FpS1Cfg<BN, R, WT, WAVES_M, BKC>;
+    using C = FpS1Cfg<BN, R, WT, WAVES_M, BKC, TPS>;
+    constexpr int SPC = 9 / TPS;                        // steps per channel chunk
+    static_assert(TPS == 1 || TPS == 3, "taps per step");
     constexpr int BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC, SX = C::SX, SB = C::SB;
     constexpr int XCH = C::XR * XC * (BKC / 8);         // 16-byte chunks of the x tile
     constexpr int XPT = (XCH + 255) / 256;
-    constexpr int BCH = BN * (BKC / 8);
+    constexpr int BCH = TPS * BN * (BKC / 8);
     constexpr int BPT = (BCH + 255) / 256;
     constexpr int KK = BKC / 16;
     constexpr int OUT_ROW = C::OUT_ROW;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
     for (int t = 0; t < 9; ++t) toff[t] = (a.dh[t] * XC + a.dw[t]) * SX;
 
     double st = 0.0;
-    const int nsteps = a.NCH * 9;
+    const int nsteps = a.NCH * SPC;
     float bias_r[TN];                   // this lane's output channels are fixed for the whole block
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -141,15 +146,16 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
             }
         };
         auto gload_b = [&](int step) {
-            const int c = step / 9, t = step - c * 9;
+            const int c = step / SPC, t0 = (step - c * SPC) * TPS;
 #pragma unroll
             for (int u = 0; u < BPT; ++u) {
                 const int q = tid + u * 256;
-                const int row = q / (BKC / 8), cc = q - row * (BKC / 8);
+                const int krow = q / (BKC / 8), cc = q - krow * (BKC / 8);      // krow = tap-in-step * BN + channel row
+                const int k = krow / BN, row = krow - k * BN;
                 const int co = n_base + row, ch = c * BKC + cc * 8;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (q < BCH && co < a.Co && ch < a.Ci)
-                    v = *reinterpret_cast<const uint4*>(a.w + (long long)co * a.Ktot + t * a.Ci + ch);
+                    v = *reinterpret_cast<const uint4*>(a.w + (long long)co * a.Ktot + (t0 + k) * a.Ci + ch);
                 rb[u] = v;
             }
         };
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
             for (int u = 0; u < BPT; ++u) {
                 const int q = tid + u * 256;
                 if (q < BCH) {
-                    const int row = q / (BKC / 8), cc = q - row * (BKC / 8);
-                    *reinterpret_cast<uint4*>(sB + buf * C::B_BYTES + row * SB + cc * 16) = rb[u];
+                    const int krow = q / (BKC / 8), cc = q - krow * (BKC / 8);
+                    *reinterpret_cast<uint4*>(sB + buf * C::B_BYTES + krow * SB + cc * 16) = rb[u];
                 }
             }
         };
@@ -188,29 +194,32 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
         __syncthreads();
         for (int c = 0; c < a.NCH; ++c) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {          // unrolled: tap offsets are registers, not per-step kernarg loads
-                const int step = c * 9 + t;
-                const int buf = (c + t) & 1;       // == step & 1
+            for (int ts = 0; ts < SPC; ++ts) {     // unrolled: tap offsets are registers, not per-step kernarg loads
+                const int step = c * SPC + ts;
+                const int buf = (c + ts) & 1;      // == step & 1 (SPC is odd)
                 const bool more = step + 1 < nsteps;
-                const bool new_chunk = (t == 8) && more;
+                const bool new_chunk = (ts == SPC - 1) && more;
                 if (more) gload_b(step + 1);
                 if (new_chunk) gload_x(c + 1);
-                const unsigned char* pa = sX + toff[t];
-                const unsigned char* pb = sB + buf * C::B_BYTES + b_base;
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk) {
-                    bf16x8_t af[TM], bfr[TN];
+                for (int k = 0; k < TPS; ++k) {
+                    const unsigned char* pa = sX + toff[ts * TPS + k];
+                    const unsigned char* pb = sB + buf * C::B_BYTES + k * BN * SB + b_base;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[i] = *reinterpret_cast<const bf16x8_t*>(pa + a_base[i] + kk * 32);
+                    for (int kk = 0; kk < KK; ++kk) {
+                        bf16x8_t af[TM], bfr[TN];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bfr[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * SB + kk * 32);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i)
+                            af[i] = *reinterpret_cast<const bf16x8_t*>(pa + a_base[i] + kk * 32);
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                            bfr[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 32 * SB + kk * 32);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
                 }
                 if (more) lstore_b(buf ^ 1);
                 if (new_chunk) {
@@ -288,11 +297,11 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
     }
 }
 
-template <int BN, int R, int WT, int WAVES_M, int BKC>
+template <int BN, int R, int WT, int WAVES_M, int BKC, int TPS = 1>
 int launch_fs1(FpS1Args& a, hipStream_t stream) {
-    using C = FpS1Cfg<BN, R, WT, WAVES_M, BKC>;
+    using C = FpS1Cfg<BN, R, WT, WAVES_M, BKC, TPS>;
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_s1x9_kernel<BN, R, WT, WAVES_M, BKC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_s1x9_kernel<BN, R, WT, WAVES_M, BKC, TPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) segnb_set_error("fprop_s1 hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -310,7 +319,7 @@ int launch_fs1(FpS1Args& a, hipStream_t stream) {
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    hipLaunchKernelGGL((conv_fprop_s1x9_kernel<BN, R, WT, WAVES_M, BKC>), dim3(a.GM * a.NTL), dim3(256), C::SMEM,
+    hipLaunchKernelGGL((conv_fprop_s1x9_kernel<BN, R, WT, WAVES_M, BKC, TPS>), dim3(a.GM * a.NTL), dim3(256), C::SMEM,
                        stream, a);
     return 0;
 }
@@ -321,7 +330,7 @@ template <int BKC>
 int dispatch_fs1(FpS1Args& a, hipStream_t stream) {
     const int cus = segnb_num_cus();
     if (a.W > 16) {
-        if (a.Co <= 32) return launch_fs1<32, 8, 32, 4, BKC>(a, stream);
+        if (a.Co <= 32) return launch_fs1<32, 8, 32, 4, BKC, 3>(a, stream);
         const long long its = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 31) / 32);
         if (a.Co <= 64 || its * ((a.Co + 127) / 128) < cus) return launch_fs1<64, 4, 32, 2, BKC>(a, stream);
         // thin-input data gradients of the concat layers (32 -> 96 @224^2, 64 -> 192 @112^2): 96-channel tiles
