@@ -119,6 +119,26 @@ int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out,
                           int ld_out, segnb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tiled inference: ImageSlicer.split / merge of lib/tiles.py:99-161, the D4 test-time
+ * augmentation of lib/augmentations.py:476-511 and the sigmoid of inria_submit.py:249.
+ * crops_xy: device int32 [ntiles][2] = (x, y) of each tile in the PADDED image (ImageSlicer.crops), a regular grid of
+ * pitch `step`, nx tiles per row.  Items are numbered item = tile*8 + k, k = index into tta_d4_aug's 8 transforms.
+ * ------------------------------------------------------------------------------------------- */
+
+/* out[b][c][r][s] (NCHW fp32, b = item first_item + b) = transform k of tile `tile` of the reflect-101 padded
+ * image (fp32 HWC, already normalised): the batch inria_submit.predict_tiled feeds the model with. */
+int segnb_tiles_gather(const float* image, int H, int W, int C, int margin_top, int margin_left,
+                       const int* crops_xy, int first_item, int count, int S, float* out,
+                       segnb_stream_t stream);
+
+/* logits: fp32 [ntiles*8][K][S][S] (model outputs of every item).  out: fp32 [H][W][K] = merge(deaug(sigmoid)):
+ * per tile the mean over the 8 un-transformed predictions (float32, the reference's order), then the weighted
+ * mean over the tiles covering a pixel (float64, tile order) with weight[S][S] (fp64: pyramid or ones), cropped. */
+int segnb_tiles_merge(const float* logits, int K, int S, const int* crops_xy, int ntiles, int step, int nx,
+                      int ny, const double* weight, int H, int W, int margin_top, int margin_left, float* out,
+                      segnb_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BatchNorm (+activation, +Dropout2d, +MaxPool2d(2), +nearest x2 upsample) -- the same 4-phase split
  * as inplace_abn's mean_var / forward / edz_eydz / backward (lib/modules/abn/functions.py:81,94,112,118).
  * ------------------------------------------------------------------------------------------- */

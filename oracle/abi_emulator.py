@@ -363,6 +363,50 @@ class AbiEmulator(object):
         return rc or self.segnb_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, None, C,
                                              stream)
 
+    # ------------------------------------------------------------------------------------------ tiles
+    @staticmethod
+    def _d4(k, t):
+        """element k of tta_d4_aug applied to an [..., S, S] tensor (rot90 counter-clockwise, then fliplr)"""
+        t = torch.rot90(t, k & 3, dims=(-2, -1))
+        return torch.flip(t, dims=(-1,)) if k >= 4 else t
+
+    def segnb_tiles_gather(self, image, H, W, C, mt, ml, crops, first, count, S, out, stream):
+        img = _mem(image, H * W * C, torch.float32).view(H, W, C)
+        cr = _mem(crops, 2 * ((first + count + 7) // 8), torch.int32).view(-1, 2)
+        O = _mem(out, count * C * S * S, torch.float32).view(count, C, S, S)
+        ys, xs = torch.arange(S), torch.arange(S)
+        for b in range(count):
+            tile, k = (first + b) >> 3, (first + b) & 7
+            yy = (int(cr[tile, 1]) + ys - mt).abs()
+            yy = torch.where(yy >= H, 2 * H - 2 - yy, yy)
+            xx = (int(cr[tile, 0]) + xs - ml).abs()
+            xx = torch.where(xx >= W, 2 * W - 2 - xx, xx)
+            t = img[yy][:, xx].permute(2, 0, 1)                       # [C, S, S]
+            O[b] = self._d4(k, t)
+        return 0
+
+    def segnb_tiles_merge(self, logits, K, S, crops, ntiles, step, nx, ny, weight, H, W, mt, ml, out, stream):
+        L = _mem(logits, ntiles * 8 * K * S * S, torch.float32).view(ntiles, 8, K, S, S)
+        cr = _mem(crops, 2 * ntiles, torch.int32).view(ntiles, 2)
+        Wt = _mem(weight, S * S, torch.float64).view(S, S)
+        Hp = int(cr[:, 1].max()) + S
+        Wp = int(cr[:, 0].max()) + S
+        acc = torch.zeros(K, Hp, Wp, dtype=torch.float64)
+        norm = torch.zeros(Hp, Wp, dtype=torch.float64)
+        for t in range(ntiles):
+            p = torch.sigmoid(L[t])
+            s = torch.zeros(K, S, S)
+            for k in range(8):                                        # undo transform k: fliplr first, then rot back
+                u = torch.flip(p[k], dims=(-1,)) if k >= 4 else p[k]
+                s = s + torch.rot90(u, -(k & 3), dims=(-2, -1))
+            v = s * 0.125
+            x, y = int(cr[t, 0]), int(cr[t, 1])
+            acc[:, y:y + S, x:x + S] += v.double() * Wt
+            norm[y:y + S, x:x + S] += Wt
+        res = (acc / norm.clamp(min=2.220446049250313e-16)).float()
+        _mem(out, H * W * K, torch.float32).view(H, W, K).copy_(res[:, mt:mt + H, ml:ml + W].permute(1, 2, 0))
+        return 0
+
     def segnb_add(self, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream):
         dt = _tdt(dtype)
         r = (_nhwc(a, N, H, W, Cp, ld_a, dt).float() + _nhwc(b, N, H, W, Cp, ld_b, dt).float()).to(dt)

@@ -280,8 +280,42 @@ def gen_tiramisu():
     print('tiramisu_small.npz loss', float(l), 'params', sum(p.numel() for p in m.parameters()))
 
 
+def gen_tiles():
+    """lib/tiles.py: pyramid weights, margins / crops and merge() of several image shapes, plus the D4 TTA pair of
+    lib/augmentations.py:476-511 (copied as DATA: inputs and outputs).  lib.tiles imports cv2 at module level and
+    cv2 is not installed: an EMPTY placeholder module (one constant, no function) makes the import succeed; split()
+    and cut_patch(), the only cv2 users, are therefore NOT exercised here."""
+    import types
+    cv2 = types.ModuleType('cv2')
+    cv2.BORDER_REFLECT101 = 4
+    sys.modules.setdefault('cv2', cv2)
+    from lib import tiles as ref_tiles
+    out = {}
+    for k, (w, h) in enumerate([(8, 8), (16, 12), (33, 33), (64, 64)]):
+        W, Dc, De = ref_tiles.compute_patch_weight_loss(w, h)
+        out['pw%d/wh' % k] = np.array([w, h])
+        out['pw%d/W' % k], out['pw%d/Dc' % k], out['pw%d/De' % k] = W, Dc, De
+    cases = [((60, 75, 3), 32, 16, 0, 'pyramid'), ((64, 64), 32, 32, 0, 'mean'), ((70, 90, 1), 40, 20, 5, 'mean'),
+             ((97, 120, 2), 32, 16, 0, 'pyramid')]
+    rng = np.random.RandomState(7)
+    for k, (shape, ts, step, margin, weight) in enumerate(cases):
+        sl = ref_tiles.ImageSlicer(shape, ts, step, margin, weight)
+        ch = 1 if len(shape) == 2 else shape[2]
+        tiles = rng.rand(len(sl.crops), ts, ts, ch).astype(np.float32)
+        out['sl%d/args' % k] = np.array(list(shape) + [0] * (3 - len(shape)) + [len(shape), ts, step, margin,
+                                                                                 weight == 'pyramid'])
+        out['sl%d/crops' % k] = np.array(sl.crops)
+        out['sl%d/margins' % k] = np.array([sl.margin_left, sl.margin_right, sl.margin_top, sl.margin_bottom])
+        out['sl%d/tiles' % k] = tiles
+        out['sl%d/merged' % k] = sl.merge(list(tiles), dtype=np.float32)      # (2-D tiles break the reference's merge)
+    np.savez_compressed(os.path.join(HERE, 'tiles.npz'), **out)
+    print('tiles.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles']
+    if 'tiles' in which:
+        gen_tiles()
     if 'losses' in which:
         gen_losses()
     if 'tiny' in which:

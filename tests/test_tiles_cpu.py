@@ -1,0 +1,112 @@
+"""lib.tiles / lib.augmentations / segnb.tiled: oracle and product vs the reference golden
+(tests/golden/tiles.npz, made from /root/reference/lib/tiles.py), identities, and the device data flow on the ABI
+emulator."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import abi_emulator, tiles_ref
+from segnb import _native as nv
+
+
+@pytest.fixture(autouse=True)
+def emulated_abi():
+    nv.set_backend_for_testing(abi_emulator.AbiEmulator())
+    yield
+    nv.set_backend_for_testing(None)
+
+
+def _cases(g):
+    k = 0
+    while 'sl%d/args' % k in g.files:
+        a = g['sl%d/args' % k]
+        nd = int(a[3])
+        yield k, tuple(int(v) for v in a[:nd]), int(a[4]), int(a[5]), int(a[6]), 'pyramid' if a[7] else 'mean'
+        k += 1
+
+
+@pytest.mark.parametrize('impl', ['oracle', 'product'])
+def test_weights_crops_merge_vs_reference_golden(golden_dir, impl):
+    if impl == 'oracle':
+        mod = tiles_ref
+    else:
+        import lib.tiles as mod
+    g = np.load(os.path.join(golden_dir, 'tiles.npz'))
+    k = 0
+    while 'pw%d/wh' % k in g.files:
+        w, h = (int(v) for v in g['pw%d/wh' % k])
+        W, Dc, De = mod.compute_patch_weight_loss(w, h)
+        for got, name in ((W, 'W'), (Dc, 'Dc'), (De, 'De')):
+            np.testing.assert_allclose(got, g['pw%d/%s' % (k, name)], rtol=1e-13, atol=0)
+        k += 1
+    for k, shape, ts, step, margin, weight in _cases(g):
+        sl = mod.ImageSlicer(shape, ts, step, margin, weight)
+        assert np.array_equal(np.array(sl.crops), g['sl%d/crops' % k])
+        assert [sl.margin_left, sl.margin_right, sl.margin_top, sl.margin_bottom] == g['sl%d/margins' % k].tolist()
+        merged = sl.merge(list(g['sl%d/tiles' % k]), dtype=np.float32)
+        np.testing.assert_allclose(merged, g['sl%d/merged' % k], rtol=1e-6, atol=1e-7)
+
+
+def test_split_merge_identity_and_errors():
+    from lib.tiles import ImageSlicer
+    rng = np.random.RandomState(0)
+    img = rng.rand(70, 95, 3).astype(np.float32)
+    for weight in ('mean', 'pyramid'):
+        sl = ImageSlicer(img.shape, 32, 16, weight=weight)
+        tiles = sl.split(img)
+        assert len(tiles) == len(sl.crops) and tiles[0].shape == (32, 32, 3)
+        np.testing.assert_allclose(sl.merge(tiles), img, rtol=1e-6, atol=1e-6)
+        assert np.array_equal(sl.cut_patch(img, 3), tiles[3])
+        ref = tiles_ref.ImageSlicer(img.shape, 32, 16, weight=weight).split(img)
+        assert all(np.array_equal(a, b) for a, b in zip(tiles, ref))
+    with pytest.raises(ValueError):
+        ImageSlicer(img.shape, 32, 0)
+    with pytest.raises(ValueError):
+        ImageSlicer(img.shape, 32, 33)
+    with pytest.raises(ValueError):
+        ImageSlicer((70, 95), 32, 16, image_margin=3)
+    with pytest.raises(ValueError):
+        ImageSlicer(img.shape, 32, 16).merge([img])
+
+
+def test_tta_d4_roundtrip():
+    from lib.augmentations import tta_d4_aug, tta_d4_deaug
+    rng = np.random.RandomState(1)
+    imgs = [rng.rand(12, 12, 2).astype(np.float32) for _ in range(3)]
+    aug = tta_d4_aug(imgs)
+    assert len(aug) == 24
+    for a, b in zip(aug, tiles_ref.tta_d4_aug(imgs)):
+        assert np.array_equal(a, b)
+    for a, b in zip(tta_d4_deaug(aug), imgs):
+        np.testing.assert_allclose(a, b, rtol=1e-6)
+
+
+class _Lin(torch.nn.Module):
+    """a stand-in "model" with orientation-dependent output: 1x1 mix of the channels + a position ramp"""
+
+    def __init__(self, S):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([0.7, -1.1, 0.4]))
+        self.register_buffer('ramp', torch.linspace(-1, 1, S)[None, None, :, None] * 0.5 +
+                             torch.linspace(-0.3, 0.6, S)[None, None, None, :])
+
+    def forward(self, x):
+        return (x * self.w[None, :, None, None]).sum(1, keepdim=True) + self.ramp
+
+
+@pytest.mark.parametrize('shape', [(50, 71, 3), (33, 32, 3)])
+def test_predict_tiled_device_flow_on_emulator(shape):
+    """segnb.tiled.predict_tiled (gather / merge through the ABI, here the emulator) == the oracle's restatement of
+    inria_submit.predict_tiled with the same model."""
+    from segnb.tiled import predict_tiled
+    rng = np.random.RandomState(2)
+    img = rng.randn(*shape).astype(np.float32)
+    S = 16
+    model = _Lin(S)
+    got = predict_tiled(img, model, S, batch_size=5)
+    with torch.no_grad():
+        ref = tiles_ref.predict_tiled(img, lambda x: model(torch.from_numpy(x)).numpy(), S, 5)
+    assert got.shape == (shape[0], shape[1], 1)
+    np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=2e-6, atol=2e-7)
