@@ -264,6 +264,14 @@ int segnb_seg_loss_bwd(const float* logits, const long long* target, long long n
 /* plain SGD p -= lr * g over a flat buffer (torch.optim.SGD of torch_train.py:71) */
 int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream);
 
+/* torch.optim.RMSprop(lr, alpha, eps) -- v = alpha*v + (1-alpha)*g^2; p -= lr*g/(sqrt(v)+eps) -- and
+ * torch.optim.Adam(lr, betas, eps) at step number `step` (1-based; bias corrections computed on the host in fp64)
+ * over flat buffers: get_optimizer('rms' | 'adam'), torch_train.py:73-77.  State buffers are caller-owned. */
+int segnb_rmsprop_step(float* p, const float* g, float* square_avg, long long n, float lr, float alpha,
+                       float eps, segnb_stream_t stream);
+int segnb_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                    float beta1, float beta2, float eps, int step, segnb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -525,3 +525,17 @@ class AbiEmulator(object):
     def segnb_sgd_step(self, p, g, n, lr, stream):
         _mem(p, n, torch.float32).sub_(lr * _mem(g, n, torch.float32))
         return 0
+
+    def segnb_rmsprop_step(self, p, g, sq, n, lr, alpha, eps, stream):
+        P, G, V = (_mem(t, n, torch.float32) for t in (p, g, sq))
+        V.mul_(alpha).addcmul_(G, G, value=1 - alpha)
+        P.addcdiv_(G, V.sqrt().add_(eps), value=-lr)
+        return 0
+
+    def segnb_adam_step(self, p, g, m, v, n, lr, beta1, beta2, eps, step, stream):
+        P, G, M, V = (_mem(t, n, torch.float32) for t in (p, g, m, v))
+        M.lerp_(G, 1 - beta1)
+        V.mul_(beta2).addcmul_(G, G, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        P.addcdiv_(M, (V.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+        return 0

@@ -969,6 +969,55 @@ extern "C" int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int 
                                "segnb_bn_bwd_apply_fused", stream);
 }
 
+// torch.optim.RMSprop (alpha, eps; no momentum / centering / weight decay) and torch.optim.Adam (betas, eps; no
+// amsgrad / weight decay) over the flat buffers: get_optimizer('rms' | 'adam') of torch_train.py:73-77
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long long n,
+                               float lr, float alpha, float eps) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float v = alpha * sq[i] + (1.f - alpha) * gi * gi;
+        sq[i] = v;
+        p[i] -= lr * gi / (sqrtf(v) + eps);
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float step_size, float beta1, float beta2,
+                            float inv_sqrt_bc2, float eps) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;         // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int segnb_rmsprop_step(float* p, const float* g, float* square_avg, long long n, float lr, float alpha,
+                                  float eps, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(p && g && square_avg && n > 0, "bad arguments");
+    int grid = ceil_div(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, square_avg, n, lr, alpha, eps);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                               float beta1, float beta2, float eps, int step, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    int grid = ceil_div(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, n,
+                       (float)((double)lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(p && g && n > 0, "bad arguments");
     SEGNB_CHECK_ARG((((uintptr_t)p | (uintptr_t)g) & 15) == 0, "buffers must be 16-byte aligned");

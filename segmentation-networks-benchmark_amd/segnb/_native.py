@@ -75,6 +75,8 @@ SIGNATURES = {
     'segnb_seg_loss_finalize': [_P, ctypes.POINTER(LossSpec), _P, _P],
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
+    'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
+    'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
 PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 

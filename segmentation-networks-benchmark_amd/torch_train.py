@@ -19,9 +19,9 @@ def get_optimizer(optimizer_name, model_parameters, learning_rate):
     if name == 'sgd':
         return segnb_optim.SGD(model_parameters, lr=learning_rate)     # torch.optim.SGD with a one-launch step
     if name == 'rms':
-        return torch.optim.RMSprop(model_parameters, lr=learning_rate)
+        return segnb_optim.RMSprop(model_parameters, lr=learning_rate)
     if name == 'adam':
-        return torch.optim.Adam(model_parameters, lr=learning_rate)
+        return segnb_optim.Adam(model_parameters, lr=learning_rate)
     raise ValueError(optimizer_name)
 
 

@@ -603,3 +603,25 @@ def test_bn_act_with_residual_input(dtype):
     S = sums.sum(0).cpu()
     assert abs(float(S[0].sum()) - float(rt_.grad.double().sum())) <= (0.05 if dtype == 'bf16' else 1e-3) * \
         float(rt_.grad.abs().sum()) / 10
+
+
+@pytest.mark.parametrize('name', ['rms', 'adam'])
+def test_flat_rmsprop_adam_kernels_vs_torch(name):
+    gen = torch.Generator().manual_seed(11)
+    n = 100003
+    p0 = torch.randn(n, generator=gen)
+    ref_p = p0.clone().requires_grad_(True)
+    ref = (torch.optim.RMSprop if name == 'rms' else torch.optim.Adam)([ref_p], lr=1e-2)
+    p = p0.cuda()
+    s1, s2 = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 4):
+        g = torch.randn(n, generator=gen) * (10.0 ** torch.randint(-3, 2, (n,), generator=gen).float())
+        ref_p.grad = g.clone()
+        ref.step()
+        gd = g.cuda()
+        if name == 'rms':
+            nv.call('segnb_rmsprop_step', nv.ptr(p), nv.ptr(gd), nv.ptr(s1), n, 1e-2, 0.99, 1e-8, 0)
+        else:
+            nv.call('segnb_adam_step', nv.ptr(p), nv.ptr(gd), nv.ptr(s1), nv.ptr(s2), n, 1e-2, 0.9, 0.999, 1e-8, step, 0)
+        torch.cuda.synchronize()
+        assert torch.allclose(p.cpu(), ref_p.detach(), rtol=2e-5, atol=1e-6), (name, step)

@@ -92,3 +92,32 @@ def test_find_optimal_lr_accumulates_like_reference():
     lrs, loss = find_optimal_lr(model, BCEWithSigmoidLoss(), opt, [batch] * 30)
     assert lrs.shape == (30,) and abs(lrs[0] - 1e-8) < 1e-12 and abs(lrs[-1] / lrs[0] - 2.0 ** 29) < 1e3
     assert np.all(np.isfinite(loss)) and loss.shape == (30,)
+
+
+@pytest.mark.parametrize('name', ['sgd', 'rms', 'adam'])
+def test_flat_optimizers_match_torch(name):
+    """segnb.optim.{SGD,RMSprop,Adam}: one launch over the flat buffers == torch.optim on the same gradients."""
+    import copy
+    import torch_train as TT
+    from lib.models.zf_unet import ZF_UNET
+    from lib.losses import BCEWithSigmoidLoss
+    torch.manual_seed(0)
+    model = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    x, y = torch.randn(2, 3, 32, 32), (torch.rand(2, 1, 32, 32) > 0.7).long()
+    opt = TT.get_optimizer(name, model.parameters(), 1e-2)
+    ref_params = None
+    ref_opt = None
+    for it in range(3):
+        opt.zero_grad()
+        loss = BCEWithSigmoidLoss()(model(x), y)
+        (2 * loss).backward()
+        if ref_params is None:                  # torch optimizer over detached copies, fed the SAME gradients
+            ref_params = [p.detach().clone().requires_grad_(True) for p in model.parameters()]
+            ref_opt = {'sgd': torch.optim.SGD, 'rms': torch.optim.RMSprop, 'adam': torch.optim.Adam}[name](ref_params, lr=1e-2)
+        for rp, p in zip(ref_params, model.parameters()):
+            rp.grad = p.grad.detach().clone()
+        opt.step()
+        ref_opt.step()
+        for rp, p in zip(ref_params, model.parameters()):
+            assert torch.allclose(p.detach(), rp.detach(), rtol=1e-5, atol=1e-6), (name, it)
+    assert getattr(opt, '_segnb_state', None) is not None or name == 'sgd'
