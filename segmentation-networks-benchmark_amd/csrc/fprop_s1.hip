@@ -330,11 +330,13 @@ template <int BKC>
 int dispatch_fs1(FpS1Args& a, hipStream_t stream) {
     const int cus = segnb_num_cus();
     if (a.W > 16) {
-        if (a.Co <= 32) return launch_fs1<32, 8, 32, 4, BKC, 3>(a, stream);
+        // thin inputs (the 224x224 / 112x112 levels and their concat data gradients): measured per layer, the image
+        // tile wins whatever the output width -- 32-channel tiles for Ci <= 32 (32 -> 96: 224 -> 202 us), 64-channel
+        // tiles for Ci <= 64 on >= 112-pixel rows (64 -> 192: 176 -> 150 us); 96-channel tiles were slower than both
+        if (a.Co <= 32 || a.Ci <= 32) return launch_fs1<32, 8, 32, 4, BKC, 3>(a, stream);
         const long long its = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 31) / 32);
-        if (a.Co <= 64 || its * ((a.Co + 127) / 128) < cus) return launch_fs1<64, 4, 32, 2, BKC>(a, stream);
-        // thin-input data gradients of the concat layers (32 -> 96 @224^2, 64 -> 192 @112^2): 96-channel tiles
-        if (a.Ci <= 64 && a.Co % 96 == 0) return launch_fs1<96, 8, 32, 4, BKC>(a, stream);
+        if (a.Co <= 64 || its * ((a.Co + 127) / 128) < cus || (a.Ci <= 64 && a.W >= 112))
+            return launch_fs1<64, 4, 32, 2, BKC>(a, stream);
         // wide layers on >= 28-pixel rows: the general gather kernel's flattened-pixel 128x128 tiles (no partial
         // row segments, one barrier per step) measure 20-25 % faster than the image-tile form here
         return NOT_HANDLED;
