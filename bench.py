@@ -80,7 +80,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the whole training step from one captured HIP graph (auto: on for 1 GPU)')
+                    help='replay the whole training step from one captured HIP graph (auto = off: eager launches overlap the weight-gradient stream better)')
     args = ap.parse_args()
 
     from segnb import dist as sdist
@@ -133,7 +133,10 @@ def main():
     torch.cuda.synchronize()
 
     # ---- whole-step HIP graph: ~300 kernel launches per step are replayed from ONE graph launch ----------------
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and ws == 1)
+    # 'auto' = eager launches: the weight gradients run on a second stream beside the data-gradient chain
+    # (segnb.engine.Runtime.fork_side), which the eager path overlaps well (6.95 ms/step) while the same step replayed
+    # from one HIP graph measured 7.5 ms (7.4 without the second stream); the host needs 4.6 ms to enqueue a step
+    use_graph = args.graph == 'on'
     graph = None
     if use_graph:
         opt.zero_grad(set_to_none=False)          # keep parameter.grad as views of the flat gradient buffer

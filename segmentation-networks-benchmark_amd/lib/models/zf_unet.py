@@ -300,6 +300,7 @@ class _ZFUnetPlan(object):
                 s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
                             dx=b['da1_%d' % i])
             s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
+        rt.join_side()                        # the weight gradients ran on the side stream
         self._tables(H, W)[2].run()          # every packed weight-gradient workspace -> flat gradient buffer
         self._after_backward()
         # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not

@@ -6,6 +6,8 @@ stream; every FLOP and every byte moved on the hot path happens inside libsegnb_
 code drives any device the ABI backend can address, which is what lets tests check the plan logic
 (buffer wiring, tap tables, channel maps, backward routing) on CPU against an ABI emulator.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -71,6 +73,34 @@ class Runtime(object):
 
     def zeros(self, shape, dtype=None):
         return torch.zeros(shape, dtype=dtype or self.tdtype, device=self.device)
+
+    # ---- second stream for the weight gradients ------------------------------------------------------------
+    # wgrad(l) and dgrad(l) both only READ dy(l), and nothing consumes dW before the end of backward: the weight
+    # gradients run on a side stream, forked after each layer's BatchNorm-apply and joined once before the batched
+    # unpack.  Neither kernel family fills a CU alone (one wgrad block = 4 waves / 64 KB LDS, two dgrad blocks =
+    # 8 waves / 148 KB), so the hardware co-schedules them.  Captured into the step's HIP graph as a parallel branch.
+    overlap_wgrad = os.environ.get('SEGNB_OVERLAP_WGRAD', '1') != '0'
+
+    def side_stream(self):
+        if self.device.type != 'cuda' or not self.overlap_wgrad:
+            return None
+        s = getattr(self, '_side', None)
+        if s is None:
+            s = self._side = torch.cuda.Stream(device=self.device)
+        return s
+
+    def fork_side(self):
+        """-> side stream (made to wait for everything issued so far on the current stream) or None"""
+        s = self.side_stream()
+        if s is not None:
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            self._side_busy = True
+        return s
+
+    def join_side(self):
+        if getattr(self, '_side_busy', False):
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_busy = False
 
     def int32(self, values):
         return torch.tensor(list(values), dtype=torch.int32, device=self.device)
@@ -463,7 +493,12 @@ class Stage(object):
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),
                     nv.ptr(self.bcoef), None, nv.ptr(gbias), 1, rt.stream)
-        self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=not self.defer_unpack)
+        side = rt.fork_side() if (self.defer_unpack and dx is not None) else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False)
+        else:
+            self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=not self.defer_unpack)
         if dx is not None:
             self.conv.dgrad(dz, dx)
         return dx
