@@ -191,20 +191,48 @@ class _ZFUnetPlan(object):
             out += [(st.conv, H >> lvl, W >> lvl) for st in self.stages[name]]
         return out
 
+    # gradient groups in the order backward finishes them = from the END of the flat parameter buffer: the decoder
+    # (+ head), the two deepest encoder blocks (71 MB of the 126 MB of gradients), the rest.  Each group is unpacked
+    # as soon as its weight gradients exist (on the side stream, beside the remaining backward) and handed to the
+    # data-parallel hook, so its all-reduce overlaps the rest of backward.
+    UNPACK_GROUPS = ((2 * len(ENCODER), None), (8, 2 * len(ENCODER)), (0, 8))       # conv index ranges
+
     def _tables(self, H, W):
-        """One-launch weight pack / gradient unpack tables for this input size (rebuilt if the flat parameter
-        buffers were re-created)."""
+        """One-launch weight pack table and per-group gradient unpack tables for this input size (rebuilt if the
+        flat parameter buffers were re-created).  -> (key, pack, (unpack_dec, unpack_deep, unpack_rest), (lo, lo))"""
         key = (H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr())
         t = self._pack_tables.get((H, W))
         if t is None or t[0] != key:
-            pj, uj = [], []
-            for conv, h, w in self._conv_sizes(H, W):
+            convs = self._conv_sizes(H, W)
+            pj = []
+            for conv, h, w in convs:
                 pj += conv.pack_jobs(h, w)
-                uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
-            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
-                 PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
+            unpacks, los = [], []
+            for a, b in self.UNPACK_GROUPS:
+                uj = []
+                for conv, h, w in convs[a:b]:
+                    uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
+                unpacks.append(PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
+                los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
+            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'), tuple(unpacks),
+                 tuple(los))
             self._pack_tables[(H, W)] = t
         return t
+
+    def _unpack_group(self, H, W, gi):
+        """Unpack gradient group gi behind its weight gradients (side stream when there is one) and tell the
+        data-parallel hook that everything from its first flat offset on is final."""
+        rt = self.rt
+        _, _, unpacks, los = self._tables(H, W)
+        side = rt.side_stream() if getattr(rt, '_side_busy', False) else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                unpacks[gi].run()
+        else:
+            unpacks[gi].run()
+        hook = getattr(self.module, '_grad_ready_hook', None)
+        if hook is not None and gi < 2:
+            hook(self.flat, los[gi], (side,) if side is not None else ())
 
     def _pack_if_needed(self, H, W):
         key = (sum(p._version for p in self.module.parameters()), self.flat.version, H, W,
@@ -292,7 +320,10 @@ class _ZFUnetPlan(object):
             else:
                 s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl])
             s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl])
+        self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
         for i in (5, 4, 3, 2, 1, 0):
+            if i == 3:
+                self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
             s1, s2 = self.stages[ENCODER[i]]
             if i == 5:
                 s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'])
@@ -301,7 +332,7 @@ class _ZFUnetPlan(object):
                             dx=b['da1_%d' % i])
             s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
         rt.join_side()                        # the weight gradients ran on the side stream
-        self._tables(H, W)[2].run()          # every packed weight-gradient workspace -> flat gradient buffer
+        self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
         self._after_backward()
         # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not
         # returned through autograd, so they never get cloned and a flat optimizer / all-reduce can run)

@@ -87,12 +87,14 @@ class DataParallel(object):
             self._comm_stream = torch.cuda.Stream(device=flat.flat_g.device)
         return self._comm_stream
 
-    def grads_ready(self, flat, lo):
+    def grads_ready(self, flat, lo, producers=()):
         """Called by the backward plan when every gradient at flat offset >= lo is final (the plan runs
         decoder -> encoder, i.e. from the END of the flat buffer towards its start).  Launches the
-        all-reduce of every full bucket that became ready, on the side stream."""
+        all-reduce of every full bucket that became ready, on the communication stream, which waits for the
+        current stream and for `producers` (other streams that wrote part of those gradients)."""
         if not self.active:
             return
+        self._producers = tuple(producers)
         hi = flat.total if self._done_upto is None else self._done_upto
         while hi - lo >= self.bucket_elems or (lo == 0 and hi > 0):
             start = max(lo, hi - self.bucket_elems) if lo > 0 else max(0, hi - self.bucket_elems)
@@ -109,6 +111,8 @@ class DataParallel(object):
             self._pending.append(td.all_reduce(chunk, op=td.ReduceOp.SUM, async_op=True))
             return
         cs.wait_stream(torch.cuda.current_stream(flat.flat_g.device))
+        for ps in getattr(self, '_producers', ()):
+            cs.wait_stream(ps)
         with torch.cuda.stream(cs):
             td.all_reduce(chunk, op=td.ReduceOp.SUM)
 
@@ -116,7 +120,7 @@ class DataParallel(object):
         """End of backward: reduce whatever is left, then make the compute stream wait for the collectives."""
         if not self.active:
             return
-        self.grads_ready(flat, 0)
+        self.grads_ready(flat, 0)          # (the plan joined its side stream before calling: no other producers)
         self._done_upto = None
         for w in self._pending:
             w.wait()
