@@ -44,6 +44,11 @@ const char* segnb_last_error(void);
 int segnb_version(void);
 /* number of CUs of the current device (grid sizing); <0 on error */
 int segnb_device_cus(void);
+/* Kernel-selection knobs for A/B measurements and tests (results never depend on them beyond rounding order):
+ *   "fprop_dma"      0 = never use the direct-to-LDS 3x3 pipeline (fprop_dma.hip), 1 = use it where it applies
+ *   "fprop_dma_cfg"  -1 = automatic tile configuration, n >= 0 = force configuration n
+ * Defaults come from the environment variables SEGNB_FPROP_DMA / SEGNB_FPROP_DMA_CFG.  Not thread-safe. */
+int segnb_tune(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Generalised gather-convolution geometry.  One launch computes, for every image n and every

@@ -522,6 +522,10 @@ class AbiEmulator(object):
         _mem(dlogits, n, torch.float32).copy_(dx)
         return 0
 
+    def segnb_tune(self, key, value):
+        """kernel-selection knobs have no meaning on the CPU restatement"""
+        return 0
+
     def segnb_sgd_step(self, p, g, n, lr, stream):
         _mem(p, n, torch.float32).sub_(lr * _mem(g, n, torch.float32))
         return 0

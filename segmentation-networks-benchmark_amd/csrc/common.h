@@ -37,9 +37,15 @@ void segnb_set_error(const char* fmt, ...);
     } while (0)
 
 int segnb_num_cus();
+int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
+int segnb_knob_fprop_dma_cfg();
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);
+// direct-to-LDS pipeline for Ci % 64 == 0 (fprop_dma.hip): 1 = handled, 0 = not applicable, else error
+int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
+                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
+                        hipStream_t stream);
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
                        hipStream_t stream);
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);

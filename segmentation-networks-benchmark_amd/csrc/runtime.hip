@@ -1,5 +1,6 @@
 // Error plumbing and device queries for libsegnb_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -31,4 +32,36 @@ extern "C" int segnb_device_cus(void) {
         return -1;
     }
     return segnb_num_cus();
+}
+
+// ---- tuning knobs (A/B measurements and tests; defaults come from the environment once) ------------------------
+static int g_fprop_dma = -2;       // -2 = not initialised, 0 = off, 1 = on
+static int g_fprop_dma_cfg = -2;   // -1 = automatic, >= 0 forced configuration
+
+int segnb_knob_fprop_dma() {
+    if (g_fprop_dma == -2) {
+        const char* e = getenv("SEGNB_FPROP_DMA");
+        g_fprop_dma = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_dma;
+}
+int segnb_knob_fprop_dma_cfg() {
+    if (g_fprop_dma_cfg == -2) {
+        const char* e = getenv("SEGNB_FPROP_DMA_CFG");
+        g_fprop_dma_cfg = e ? atoi(e) : -1;
+    }
+    return g_fprop_dma_cfg;
+}
+extern "C" int segnb_tune(const char* key, int value) {
+    SEGNB_CHECK_ARG(key != nullptr, "NULL key");
+    if (strcmp(key, "fprop_dma") == 0) {
+        g_fprop_dma = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "fprop_dma_cfg") == 0) {
+        g_fprop_dma_cfg = value < 0 ? -1 : value;
+        return 0;
+    }
+    segnb_set_error("segnb_tune: unknown key '%s'", key);
+    return SEGNB_E_BADARG;
 }

@@ -625,3 +625,51 @@ def test_flat_rmsprop_adam_kernels_vs_torch(name):
             nv.call('segnb_adam_step', nv.ptr(p), nv.ptr(gd), nv.ptr(s1), nv.ptr(s2), n, 1e-2, 0.9, 0.999, 1e-8, step, 0)
         torch.cuda.synchronize()
         assert torch.allclose(p.cpu(), ref_p.detach(), rtol=2e-5, atol=1e-6), (name, step)
+
+
+# ------------------------------------------------------------------------------------------------------
+# direct-to-LDS 3x3 pipeline (fprop_dma.hip): every tile configuration, ragged tiles, sliced tensors
+# ------------------------------------------------------------------------------------------------------
+DMA_CASES = [
+    # name,            N, H,  W,  segs,                     Co
+    ('dma 64->64',     2, 21, 37, [(64, 64)],               64),      # ragged rows and columns of every tile shape
+    ('dma 128->136',   1, 28, 28, [(128, 128)],             136),     # two channel tiles, the second mostly padding
+    ('dma cat 192->64', 3, 14, 14, [(128, 128), (64, 64)],  64),      # three channel chunks (tile seams in the ring)
+    ('dma 64->24',     5, 9,  50, [(64, 64)],               24),      # more tiles than one block round, thin output
+]
+
+
+@pytest.mark.parametrize('cfg', range(8))
+@pytest.mark.parametrize('case', DMA_CASES, ids=[c[0] for c in DMA_CASES])
+def test_conv_fprop_dma_configs(case, cfg):
+    name, N, H, W, segs, Co = case
+    full = (name, N, H, W, segs, Co, 3, 1, 1, False)
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(7 + cfg)
+    w = (torch.randn((Co, Ci, 3, 3), generator=gen) * (2.0 / (Ci * 9)) ** 0.5).bfloat16().float()
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, H, W, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=gen).bfloat16().float()
+    nv.call('segnb_tune', b'fprop_dma', 1)
+    nv.call('segnb_tune', b'fprop_dma_cfg', cfg)
+    try:
+        y_g, st_g, dx_g, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+        y_g2, st_g2, _, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    finally:
+        nv.call('segnb_tune', b'fprop_dma_cfg', -1)
+    with on_emulator():
+        y_e, st_e, dx_e, _, _, _ = _run_conv('cpu', 'bf16', full, w, b, x, dy)
+    check(name + ' y', y_g, y_e, 'bf16')
+    check(name + ' dx', dx_g, dx_e, 'bf16')
+    np.testing.assert_allclose(st_g.numpy(), st_e.numpy(), rtol=2e-3, atol=2e-2 * float(st_e.abs().max()))
+    assert float(y_g[..., Co:].abs().max()) == 0.0 if y_g.shape[-1] > Co else True
+    assert torch.equal(y_g, y_g2)                                  # same bits run to run
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b, padding=1)
+    yr.backward(dy)
+    check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    parts, off = [], 0
+    for real, padded in segs:
+        parts.append(dx_g[..., off:off + real])
+        off += padded
+    check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')

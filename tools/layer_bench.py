@@ -26,8 +26,16 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--what', default='fprop,dgrad,wgrad')
     ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--dma', type=int, default=None, help='segnb_tune fprop_dma (0/1)')
+    ap.add_argument('--cfg', type=int, default=None, help='segnb_tune fprop_dma_cfg')
+    ap.add_argument('--only', default='', help='comma-separated layer names')
     args = ap.parse_args()
     rt = Runtime('cuda', args.dtype)
+    from segnb import _native as nv
+    if args.dma is not None:
+        nv.call('segnb_tune', b'fprop_dma', args.dma)
+    if args.cfg is not None:
+        nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
     f, N, S = 32, args.batch, args.size
     w = [f, 2 * f, 4 * f, 8 * f, 16 * f, 32 * f]
     layers = []
@@ -40,7 +48,10 @@ def main():
         layers.append(('dec%d.l1' % lvl, S >> lvl, [(w[lvl + 1], w[lvl + 1]), (w[lvl], w[lvl])], w[lvl]))
         layers.append(('dec%d.l2' % lvl, S >> lvl, [(w[lvl], w[lvl])], w[lvl]))
     tot = {}
+    only = [s for s in args.only.split(',') if s]
     for name, hw, segs, co in layers:
+        if only and name not in only:
+            continue
         ci = sum(r for r, _ in segs)
         wt = torch.randn(co, ci, 3, 3, device='cuda') * 0.05
         op = ConvOp(rt, wt, torch.zeros(co, device='cuda'), segs, 1, 1, False, True)
