@@ -39,6 +39,7 @@ void segnb_set_error(const char* fmt, ...);
 int segnb_num_cus();
 int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();
+int segnb_knob_fprop_dma_dbg();
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);

@@ -1,5 +1,5 @@
-// Stride-1 3x3 convolution forward / data-gradient (bf16), gfx950 -- the direct-to-LDS pipeline behind
-// segnb_conv_fprop for layers with Ci % 64 == 0 (aten::convolution / convolution_backward(input) of
+// Stride-1 3x3 convolution forward / data-gradient (bf16), gfx950 -- the direct-to-LDS, wave-specialised pipeline
+// behind segnb_conv_fprop for layers with Ci % 64 == 0 (aten::convolution / convolution_backward(input) of
 // lib/models/zf_unet.py:8 and the other 3x3 stride-1 convolutions of lib/models/*).
 //
 // fprop_s1.hip stages both operands through registers with one or two barriers per tap and exposes a global-load
@@ -7,17 +7,31 @@
 // Here NOTHING passes through registers on its way to LDS:
 //   * the input halo tile (R+2) x (WT+2) pixels x 64 channels and the weight tile BN x 64 channels of ONE tap are
 //     fetched by `buffer_load_dwordx4 ... lds` (LDS-DMA): one wave-instruction moves 8 rows x 128 B = whole cache
-//     lines, out-of-image pixels / out-of-range channels are the descriptor's range check (zeros land in LDS);
+//     lines, out-of-image pixels / out-of-range channels are the descriptor's range check (zeros land in LDS --
+//     tools/probe_dma.hip);
 //   * rows are 128 B with no padding (the DMA destination is lane-linear), bank conflicts are removed by an XOR
 //     swizzle applied to the SOURCE address: the 16-byte slot q of row p holds channel chunk q ^ ((p >> 1) & 7), so
 //     the sixteen lanes of a ds_read_b128 group (rows distinct mod 16) hit sixteen distinct bank quads;
-//   * weights run through a ring of NB one-tap stages fetched three taps ahead, the halo tile is double buffered
+//   * weights run through a ring of four one-tap stages fetched three taps ahead, the halo tile is double buffered
 //     and fetched one 64-channel chunk ahead (across tile boundaries: the block is persistent and the stream of
-//     (tile, chunk, tap) steps never drains); every step ends with a COUNTED s_waitcnt vmcnt(N) -- the fetches of
-//     the last two steps stay in flight -- and one raw s_barrier;
+//     (tile, chunk, tap) steps never drains); every tap ends with a COUNTED s_waitcnt vmcnt(N) -- this tap's fetches
+//     stay in flight -- and one raw s_barrier;
 //   * accumulators are TRANSPOSED (MFMA A operand = weights, B operand = pixels): a lane ends up with four
 //     consecutive channels of one pixel per register quad, so the epilogue stages bf16 quads with ds_write_b64, and
 //     the BatchNorm statistics are taken by the threads of the coalesced store pass (fixed channel chunk per thread).
+//
+// WAVE SPECIALISATION.  Waves 0..3 (one per SIMD) only read fragments and issue MFMAs; waves 4..7 (their SIMD
+// partners) only issue the fetches, wait for them, and run the epilogue's store pass.  What was measured on the way
+// (uniform 8-wave forms of the same pipeline, timing builds with fetches / MFMAs / reads / epilogue removed):
+//   * an LDS-DMA instruction costs its wave 60-180 issue cycles, ~2.7 of them per tap and wave: 10-20 % of the kernel
+//     when every wave pays that between its MFMAs;
+//   * a ping-pong split of each tap (fetch + read phase vs MFMA phase, the two waves of a SIMD one phase apart) did
+//     not help: the memory phase (fetches, ~50 address VALU, 16 reads and their latency) is longer than 16 MFMAs;
+//   * pinning the issue order (reads of K slice kk+1 before the MFMAs of slice kk) by volatile asm is necessary --
+//     the compiler sinks every read next to its MFMA -- but was not sufficient on its own.
+// Here the matrix pipe of a SIMD belongs to ONE wave with a 128 x 64 or 64 x 64 accumulator tile: 32 / 16 MFMAs per
+// tap against 24 / 16 fragment reads issued one K slice ahead (the first slice of a tap during the last slice of the
+// tap before it, across the barrier), tap addresses precomputed per lane, while the partner's fetches issue in the gaps.
 #include "common.h"
 
 #include <utility>
@@ -49,6 +63,7 @@ struct FdArgs {
     int dhmin, dwmin;
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
+    int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA, 8 no epilogue
 };
 
 constexpr unsigned OOB = 0x80000000u;
@@ -80,61 +95,85 @@ __device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const i32
 // LDS-only barrier: __syncthreads() would also wait for the global stores of the epilogue and for every DMA in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#define FD_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define FD_MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void step_sync() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BN_, int R_, int WT_, int NW_, int WAVES_M_>
-struct FdCfg {
-    static constexpr int BN = BN_, R = R_, WT = WT_, NW = NW_, WAVES_M = WAVES_M_;
-    static constexpr int NB = 4;                         // weight ring stages (one tap each)
-    static constexpr int NT = NW * 64;
+template <int BN_, int R_, int WT_, int CW_M_>
+struct WsCfg {
+    static constexpr int BN = BN_, R = R_, WT = WT_;
+    static constexpr int NB = 4;
+    static constexpr int NT = 512, NCW = 4, NLW = 4;
     static constexpr int BM = R * WT;
-    static constexpr int WAVES_N = NW / WAVES_M;
+    static constexpr int WAVES_M = CW_M_, WAVES_N = NCW / CW_M_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int XR = R + 2, XC = WT + 2, NPIX = XR * XC;
-    static constexpr int APIECES = (NPIX + 7) / 8;       // 1-KiB pieces of 8 halo pixels x 128 B
+    static constexpr int APIECES = (NPIX + 7) / 8;
     static constexpr int A_BYTES = APIECES * 1024;
-    static constexpr int APW = (APIECES + NW - 1) / NW;  // pieces per wave and chunk
-    static constexpr int A_STEPS = 6;                    // issued during taps 0..5 of the previous chunk
+    static constexpr int APW = (APIECES + NLW - 1) / NLW;
+    static constexpr int A_STEPS = 5;
     static constexpr int APS = (APW + A_STEPS - 1) / A_STEPS;
     static constexpr int BPIECES = BN / 8;
     static constexpr int B_STAGE = BN * 128;
-    static constexpr int BPW = BPIECES / NW;
+    static constexpr int BPW = BPIECES / NLW;
     static constexpr int OUT_ROW = BN * 2 + 16;
-    static constexpr int NPASS = (BM * OUT_ROW + A_BYTES - 1) / A_BYTES;     // epilogue passes through one A buffer
-    static constexpr int EPR = ((BM / 32 + NPASS - 1) / NPASS) * 32;         // rows per pass (whole MFMA row tiles)
+    static constexpr int NPASS = (BM * OUT_ROW + A_BYTES - 1) / A_BYTES;
+    static constexpr int EPR = ((BM / 32 + NPASS - 1) / NPASS) * 32;
     static constexpr int OC = BN / 8;
     static constexpr int OFF_B = 2 * A_BYTES;
     static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;
     static constexpr int OFF_PIX = OFF_DUMMY + 1024;
     static constexpr int OFF_BIAS = OFF_PIX + BM * 4;
     static constexpr int SMEM = OFF_BIAS + BN * 4;
-    static constexpr int RED_BYTES = NT * 16 * 8;        // final statistics reduction (after the pipeline drained)
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == NW, "wave tiling");
-    static_assert(BPIECES % NW == 0, "weight pieces per wave");
+    static constexpr int RED_BYTES = NLW * 64 * 16 * 8;
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == NCW, "wave tiling");
+    static_assert(BPIECES % NLW == 0, "weight pieces per loader wave");
     static_assert(EPR * OUT_ROW <= A_BYTES, "epilogue staging fits one halo buffer");
-    static_assert(NT % OC == 0, "fixed channel chunk per store thread");
+    static_assert((NLW * 64) % OC == 0 && NLW * 64 >= 2 * BN, "store pass / statistics threads");
     static_assert(RED_BYTES <= OFF_DUMMY, "statistics reduction scratch");
     static_assert(SMEM <= 160 * 1024, "LDS");
+    static_assert(TM + TN <= 6, "fragment wait statement");
 };
 
+// counted LDS wait naming a fragment set of NF registers
+template <int N, int NF>
+__device__ __forceinline__ void ws_wait(bf16x8_t (&f)[NF]) {
+    if constexpr (NF == 6)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
+    else if constexpr (NF == 5)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N));
+    else if constexpr (NF == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+    else if constexpr (NF == 3)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
+    else {
+        static_assert(NF == 2, "fragment set");
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
+    }
+}
+
 template <class C>
-__global__ __launch_bounds__(C::NT) void conv_fprop_dma_kernel(const FdArgs a) {
-    constexpr int BN = C::BN, R = C::R, WT = C::WT, NW = C::NW, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
-    constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC;
-    constexpr int OUT_ROW = C::OUT_ROW;
+__global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
+    constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
+    constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
+    constexpr int OUT_ROW = C::OUT_ROW, NF = TM + TN;
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     int* sPix = reinterpret_cast<int*>(smem + C::OFF_PIX);
     float* sBias = reinterpret_cast<float*>(smem + C::OFF_BIAS);
-    const unsigned lds0 = (unsigned)(size_t)smem;       // LDS byte address of the array (DMA destinations)
+    const unsigned lds0 = (unsigned)(size_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const bool loader = wave >= C::NCW;
+    const int lw = wave - C::NCW;                                   // loader index 0..3
+    const int wm = (wave & 3) / C::WAVES_N, wn = (wave & 3) % C::WAVES_N;
 
     const int L = xcd_remap_fd(blockIdx.x, gridDim.x);
     const int nt = L % a.NTL, gq = L / a.NTL;
@@ -148,35 +187,15 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_dma_kernel(const FdArgs a) {
         sBias[c] = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
     }
 
-    // ---- per-lane constants ---------------------------------------------------------------------------------
-    // weight pieces of this wave: piece = wave * BPW + pb covers rows 8*piece .. +7 of the BN x 128 B stage
+    // ---- loader-side per-lane constants --------------------------------------------------------------------
     unsigned b_voff[BPW];
 #pragma unroll
     for (int pb = 0; pb < BPW; ++pb) {
-        const int row = (wave * BPW + pb) * 8 + (lane >> 3);
+        const int row = ((lw & 3) * BPW + pb) * 8 + (lane >> 3);
         const int q = lane & 7;
         const int co = n_base + row;
         b_voff[pb] = co < a.Co ? (unsigned)co * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
     }
-    // fragment read offsets.  Row p of a tile, chunk k (16 B) lives at p*128 + ((k ^ ((p>>1)&7)) * 16); with
-    // k = 2*kk + h:  (p*128 | ((p & 12) << 3) | (((h ^ (p >> 1)) & 1) << 4)) ^ (kk << 5)
-    int b_rd[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn * C::WN + 32 * j + r;
-        b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
-    }
-    int a_pix[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = wm * C::WM + 32 * i + r;
-        a_pix[i] = (m / WT) * XC + (m % WT);
-    }
-    int tsh[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) tsh[t] = a.dh[t] * XC + a.dw[t];
-
-    // halo pieces of this wave: piece = wave + NW * pa; per-lane source offset of the tile being FETCHED
     unsigned a_voff[APW];
     auto set_fetch_tile = [&](int it) {
         const bool live = it < a.IT;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_dma_kernel(const FdArgs a) {
         const int h0 = hb * R + a.dhmin, w0 = wb * WT + a.dwmin;
 #pragma unroll
         for (int pa = 0; pa < APW; ++pa) {
-            const int pix = (wave + NW * pa) * 8 + (lane >> 3);
+            const int pix = ((lw & 3) + NLW * pa) * 8 + (lane >> 3);
             const int q = lane & 7;
             const int xr = pix / XC, xc = pix - xr * XC;
             const int hi = h0 + xr, wi = w0 + xc;
@@ -196,199 +215,244 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_dma_kernel(const FdArgs a) {
                             : OOB;
         }
     };
-    // issue this wave's halo pieces [p0, p1) of channel chunk c into buffer `buf`
     auto fetch_a = [&](int p0, int p1, int c, int buf) {
 #pragma unroll
         for (int pa = 0; pa < APW; ++pa) {
             if (pa >= p0 && pa < p1) {
-                const int piece = wave + NW * pa;
+                const int piece = (lw & 3) + NLW * pa;
                 const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
                 dma16(dst, a_voff[pa], rs_x, (unsigned)c * 128u);
             }
         }
     };
-    // issue this wave's pieces of the weight tile (chunk c, tap t) into ring stage `stage`
     auto fetch_b = [&](int c, int t, int stage) {
         const unsigned soff = (unsigned)(t * a.Ci + c * 64) * 2u;
 #pragma unroll
         for (int pb = 0; pb < BPW; ++pb)
-            dma16(lds0 + C::OFF_B + stage * C::B_STAGE + (wave * BPW + pb) * 1024, b_voff[pb], rs_w, soff);
+            dma16(lds0 + C::OFF_B + stage * C::B_STAGE + ((lw & 3) * BPW + pb) * 1024, b_voff[pb], rs_w, soff);
     };
 
-    // store-pass threads keep one 8-channel chunk: statistics of the stored values (fp32 per tile, fp64 across tiles)
-    double d1[8], d2[8];
+    // ---- compute-side per-lane constants: fragment offsets (see the uniform kernel for the swizzle) -----------
+    int b_rd[TN];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d1[e] = d2[e] = 0.0;
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * C::WN + 32 * j + r;
+        b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
+    }
+    int a_rd[9][TM];                    // per tap and row tile, buffer 0 (kept for the whole kernel)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = wm * C::WM + 32 * i + r;
+            const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
+            int v = (p << 7) + ((p & 12) << 3) + (((h ^ (p >> 1)) & 1) << 4);
+            asm volatile("" : "+v"(v));
+            a_rd[t][i] = v;
+        }
 
-    // ---- pipeline prologue: halo chunk 0 of the first tile, weight taps 0..2 --------------------------------
+    // ---- pipeline prologue ----------------------------------------------------------------------------------
     int it = gq;
-    set_fetch_tile(it);
-    fetch_a(0, APW, 0, 0);
-    {
-        // taps 0..2 of chunk 0 (NCH >= 1, 9 taps per chunk)
+    if (loader) {
+        set_fetch_tile(it);
+        fetch_a(0, APW, 0, 0);
         fetch_b(0, 0, 0);
         fetch_b(0, 1, 1);
         fetch_b(0, 2, 2);
     }
-    int cg = 0;                         // chunks done by this block: halo buffer = cg & 1, ring stage of tap t = (cg + t) & 3
+    int cg = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (; it < a.IT; it += a.GM) {
-        // output pixel index per tile row (-1 = outside)
-        {
-            const int n = it / (a.HB * a.WB);
-            const int rem = it - n * (a.HB * a.WB);
-            const int hb = rem / a.WB, wb = rem - hb * a.WB;
-            for (int rr = tid; rr < BM; rr += NT) {
-                const int ho = hb * R + rr / WT, wo = wb * WT + rr % WT;
-                sPix[rr] = (ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
-            }
-        }
-        f32x16_t acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        for (int c = 0; c < a.NCH; ++c, ++cg) {
-            const bool last = c + 1 == a.NCH;
-            const int cn = last ? 0 : c + 1;                    // chunk whose halo tile is fetched during this one
-            if (last) set_fetch_tile(it + a.GM);
-            const int abuf = cg & 1;
-            const int a_base = abuf * C::A_BYTES;
-            static_for<9>([&](auto t_c) {
-                constexpr int t = decltype(t_c)::value;
-                // ---- fetches of this step: weights three taps ahead, a slice of the next halo chunk
-                {
-                    constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
-                    const int cf = t + 3 < 9 ? c : cn;
-                    fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
-                    if constexpr (t < C::A_STEPS) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
-                }
-                // ---- tap t of chunk c
-                const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
-                int av[TM], bv[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int p = a_pix[i] + tsh[t];
-                    av[i] = a_base + (p << 7) + ((p & 12) << 3) + (((h ^ (p >> 1)) & 1) << 4);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = b_rd[j] + bstage;
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    bf16x8_t af[TM], bfr[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(smem + (av[i] ^ (kk << 5)));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(smem + (bv[j] ^ (kk << 5)));
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                // everything but the fetches of the last two steps has landed; then every wave is past its reads
-                constexpr int NA_T = (t < C::A_STEPS ? APS : 0) + ((t >= 1 && t - 1 < C::A_STEPS) ? APS : 0);
-                step_sync<2 * BPW + NA_T>();
-            });
-        }
-
-        // ---- epilogue: the halo buffer of the last chunk is free (the other one is being filled) -------------
-        unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
-        float s1[8], s2[8];
+    // Two programs with the same barrier sequence.  (One tile loop with role branches inside keeps the accumulators AND
+    // the store-pass statistics live everywhere: 256 registers + scratch spills.)
+    if (loader) {
+        // ================= fetch stream + store pass =================
+        const int ltid = tid - C::NCW * 64;            // 0..255
+        constexpr int LT = NLW * 64;
+        float s1[8], s2[8];                            // statistics of the stored values: one 8-channel chunk per thread
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-#pragma unroll
-        for (int pass = 0; pass < C::NPASS; ++pass) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * C::WM + 32 * i + r;
-                if ((wm * C::WM + 32 * i) / C::EPR == pass) {             // wave-uniform: EPR is a multiple of 32
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
-                            const float4 bv4 = *reinterpret_cast<const float4*>(sBias + col);
-                            uint2 pk;
-                            pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
-                            pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
-                            *reinterpret_cast<uint2*>(sOut + (row - pass * C::EPR) * OUT_ROW + col * 2) = pk;
-                        }
-                    }
+        for (; it < a.IT; it += a.GM) {
+            {
+                const int n = it / (a.HB * a.WB);
+                const int rem = it - n * (a.HB * a.WB);
+                const int hb = rem / a.WB, wb = rem - hb * a.WB;
+                for (int rr = ltid; rr < BM; rr += LT) {
+                    const int ho = hb * R + rr / WT, wo = wb * WT + rr % WT;
+                    sPix[rr] = (ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
                 }
             }
-            lds_barrier();
-            const int cc = tid % OC;
-            const int co = n_base + cc * 8;
-            for (int rl = tid / OC; rl < C::EPR; rl += NT / OC) {
-                const int row = pass * C::EPR + rl;
-                if (row < BM) {
-                    const int opix = sPix[row];
-                    if (opix >= 0 && co < a.Co) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(sOut + rl * OUT_ROW + cc * 16);
-                        *reinterpret_cast<uint4*>(a.out + (long long)opix * a.ld_out + co) = v;
-                        if (a.stats != nullptr) {
-                            float f[8];
-                            f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-                            f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-                            f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-                            f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+            for (int c = 0; c < a.NCH; ++c, ++cg) {
+                const bool last = c + 1 == a.NCH;
+                const int cn = last ? 0 : c + 1;
+                if (last) set_fetch_tile(it + a.GM);
+                const int abuf = cg & 1;
+                static_for<9>([&](auto t_c) {
+                    constexpr int t = decltype(t_c)::value;
+                    constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
+                    const int cf = t + 3 < 9 ? c : cn;
+                    if (!(a.dbg & 1)) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
+                    if constexpr (t < C::A_STEPS)
+                        if (!(a.dbg & 2)) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
+                    // the operands of tap t+2 (fetched during tap t-1) have landed: only this tap's fetches stay in flight
+                    constexpr int NA_T = t < C::A_STEPS ? APS : 0;
+                    step_sync<BPW + NA_T>();
+                });
+            }
+            const unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                s1[e] += f[e];
-                                s2[e] += f[e] * f[e];
+            for (int pass = 0; pass < C::NPASS; ++pass) {
+                lds_barrier();                          // the matrix waves staged this pass
+                const int cc = ltid % OC;
+                const int co = n_base + cc * 8;
+                if (!(a.dbg & 8))
+                for (int rl = ltid / OC; rl < C::EPR; rl += LT / OC) {
+                    const int row = pass * C::EPR + rl;
+                    if (row < BM) {
+                        const int opix = sPix[row];
+                        if (opix >= 0 && co < a.Co) {
+                            const uint4 v = *reinterpret_cast<const uint4*>(sOut + rl * OUT_ROW + cc * 16);
+                            *reinterpret_cast<uint4*>(a.out + (long long)opix * a.ld_out + co) = v;
+                            if (a.stats != nullptr) {
+                                float f[8];
+                                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+                                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+                                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+                                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    s1[e] += f[e];
+                                    s2[e] += f[e] * f[e];
+                                }
                             }
                         }
                     }
                 }
+                lds_barrier();                          // staging area free again
             }
-            lds_barrier();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // look-ahead fetches of the (absent) next tile
+        lds_barrier();
         if (a.stats != nullptr) {
+            double* red = reinterpret_cast<double*>(smem);    // [LT][16]
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                d1[e] += (double)s1[e];
-                d2[e] += (double)s2[e];
+                red[ltid * 16 + e] = (double)s1[e];
+                red[ltid * 16 + 8 + e] = (double)s2[e];
             }
         }
-    }
-
-    // ---- statistics: fixed-order block reduction, one fp64 atomic per channel and block -----------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // look-ahead fetches of the (absent) next tile
-    __syncthreads();
-    if (a.stats != nullptr) {
-        double* red = reinterpret_cast<double*>(smem);    // [NT][16]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[tid * 16 + e] = d1[e];
-            red[tid * 16 + 8 + e] = d2[e];
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, col = tid - which * BN;
+        lds_barrier();
+        if (a.stats != nullptr && ltid < 2 * BN) {
+            const double* red = reinterpret_cast<const double*>(smem);
+            const int which = ltid / BN, col = ltid - which * BN;
             const int cc = col >> 3, e = col & 7;
             double s = 0.0;
-            for (int k = 0; k < NT / OC; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
+            for (int k = 0; k < LT / OC; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
             const int co = n_base + col;
             if (co < a.Co)
                 atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], s);
         }
+    } else {
+        // ================= matrix stream =================
+        // K slice 0 of every tap is requested during the LAST slice of the tap before it (the fetch waves guarantee a
+        // tap's operands one barrier early), so no tap starts with an exposed LDS round trip; the slice stays in
+        // flight across the barrier and across the epilogue.
+        bf16x8_t fr[2][NF];
+        if (!(a.dbg & 4)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) FD_READ(fr[0][j], b_rd[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) FD_READ(fr[0][TN + i], a_rd[0][i]);
+        }
+        for (; it < a.IT; it += a.GM) {
+            f32x16_t acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int c = 0; c < a.NCH; ++c, ++cg) {
+                const int a_base = (cg & 1) * C::A_BYTES;
+                static_for<9>([&](auto t_c) {
+                    constexpr int t = decltype(t_c)::value;
+                    constexpr int tn = t == 8 ? 0 : t + 1;
+                    const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
+                    int ad[NF];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ad[j] = b_rd[j] + bstage;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) ad[TN + i] = a_rd[t][i] + a_base;
+                    if (!(a.dbg & 4)) {
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            if (kk < 3) {
+#pragma unroll
+                                for (int q = 0; q < NF; ++q) ad[q] ^= (kk ^ (kk + 1)) << 5;      // slice kk -> kk + 1
+                            } else {
+                                const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
+                                const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) ad[j] = b_rd[j] + bnext;
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) ad[TN + i] = a_rd[tn][i] + anext;
+                            }
+#pragma unroll
+                            for (int q = 0; q < NF; ++q) FD_READ(fr[(kk + 1) & 1][q], ad[q]);
+                            ws_wait<NF>(fr[kk & 1]);
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) FD_MFMA(acc[i][j], fr[kk & 1][j], fr[kk & 1][TN + i]);
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    raw_barrier();
+                });
+            }
+            // The slice requested for the next tile's first tap must have LANDED before the epilogue: its destination
+            // registers count as written for the compiler, which is free to move them around in the code below -- a
+            // copy taken before the data arrives is a stale register (seen as run-to-run differences at bs=32).
+            ws_wait<0>(fr[0]);
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before the epilogue reads them
+            unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
+#pragma unroll
+            for (int pass = 0; pass < C::NPASS; ++pass) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * C::WM + 32 * i + r;
+                    if ((wm * C::WM + 32 * i) / C::EPR == pass) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
+                                const float4 bv4 = *reinterpret_cast<const float4*>(sBias + col);
+                                uint2 pk;
+                                pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
+                                pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
+                                *reinterpret_cast<uint2*>(sOut + (row - pass * C::EPR) * OUT_ROW + col * 2) = pk;
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                lds_barrier();
+            }
+        }
+        raw_barrier();
+        raw_barrier();
     }
 }
 
 template <class C>
-int launch_fd(FdArgs& a, hipStream_t stream) {
+int launch_ws(FdArgs& a, hipStream_t stream) {
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_dma_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) segnb_set_error("fprop_dma hipFuncSetAttribute: %s", hipGetErrorString(e));
+        if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }();
     if (attr_rc) return attr_rc;
@@ -397,14 +461,11 @@ int launch_fd(FdArgs& a, hipStream_t stream) {
     a.IT = a.N * a.HB * a.WB;
     a.NTL = (a.Co + C::BN - 1) / C::BN;
     a.NCH = a.Ci / 64;
-    int per_cu = (160 * 1024) / C::SMEM;
-    if (per_cu > 2) per_cu = 2;
-    if (per_cu < 1) per_cu = 1;
-    int gm = (segnb_num_cus() * per_cu) / a.NTL;
+    int gm = segnb_num_cus() / a.NTL;
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    hipLaunchKernelGGL((conv_fprop_dma_kernel<C>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    hipLaunchKernelGGL((conv_fprop_ws_kernel<C>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     return 0;
 }
 
@@ -414,22 +475,18 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
     // A/B testing (segnb_tune / environment): "fprop_dma" = 0 disables this path, "fprop_dma_cfg" forces a configuration
     int cfg = segnb_knob_fprop_dma_cfg();
     if (cfg < 0) {
-        if (a.W >= 24)
-            cfg = a.Co > 64 ? 0 : 2;
-        else if (a.W > 8)
-            cfg = a.Co > 64 ? 4 : 6;
-        else
-            return NOT_HANDLED;
+        // measured per ZF_UNET layer at bs=32 (tools/layer_bench.py --cfg): 64-channel output tiles win on every level
+        // from 14x14 to 112x112 -- twice the tiles of the 128-channel form on layers that have only 200-800 of them;
+        // 16 x 16 pixel tiles tie or beat 8 x 32 except for the widest data gradients.  Outputs of <= 32 channels
+        // (half of every tile padding) and 7x7 images stay with fprop_s1 / the general kernel.
+        if (a.Co <= 32 || a.W <= 8) return NOT_HANDLED;
+        cfg = (a.W >= 48 && a.Co >= 3 * a.Ci) ? 2 : 3;
     }
     switch (cfg) {
-        case 0: return launch_fd<FdCfg<128, 8, 32, 8, 4>>(a, stream);
-        case 1: return launch_fd<FdCfg<128, 4, 32, 4, 2>>(a, stream);
-        case 2: return launch_fd<FdCfg<64, 8, 32, 8, 4>>(a, stream);
-        case 3: return launch_fd<FdCfg<64, 4, 32, 4, 2>>(a, stream);
-        case 4: return launch_fd<FdCfg<128, 16, 16, 8, 4>>(a, stream);
-        case 5: return launch_fd<FdCfg<128, 8, 16, 4, 2>>(a, stream);
-        case 6: return launch_fd<FdCfg<64, 16, 16, 8, 4>>(a, stream);
-        case 7: return launch_fd<FdCfg<64, 8, 16, 4, 2>>(a, stream);
+        case 0: return launch_ws<WsCfg<128, 8, 32, 2>>(a, stream);
+        case 1: return launch_ws<WsCfg<128, 16, 16, 2>>(a, stream);
+        case 2: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
+        case 3: return launch_ws<WsCfg<64, 16, 16, 4>>(a, stream);
         default: return NOT_HANDLED;
     }
 }
@@ -468,6 +525,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.dh[t] = g->dh[t] - dhmin;
         a.dw[t] = g->dw[t] - dwmin;
     }
+    a.dbg = segnb_knob_fprop_dma_dbg();
     const int rc = dispatch_fd(a, stream);
     if (rc == NOT_HANDLED) return 0;
     return rc ? rc : 1;

@@ -52,6 +52,8 @@ int segnb_knob_fprop_dma_cfg() {
     }
     return g_fprop_dma_cfg;
 }
+static int g_fprop_dma_dbg = 0;
+int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
     SEGNB_CHECK_ARG(key != nullptr, "NULL key");
     if (strcmp(key, "fprop_dma") == 0) {
@@ -60,6 +62,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_dma_cfg") == 0) {
         g_fprop_dma_cfg = value < 0 ? -1 : value;
+        return 0;
+    }
+    if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero
+        g_fprop_dma_dbg = value;
         return 0;
     }
     segnb_set_error("segnb_tune: unknown key '%s'", key);

@@ -28,12 +28,15 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--dma', type=int, default=None, help='segnb_tune fprop_dma (0/1)')
     ap.add_argument('--cfg', type=int, default=None, help='segnb_tune fprop_dma_cfg')
+    ap.add_argument('--dbg', type=int, default=None, help='segnb_tune fprop_dma_dbg (timing builds)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     args = ap.parse_args()
     rt = Runtime('cuda', args.dtype)
     from segnb import _native as nv
     if args.dma is not None:
         nv.call('segnb_tune', b'fprop_dma', args.dma)
+    if args.dbg is not None:
+        nv.call('segnb_tune', b'fprop_dma_dbg', args.dbg)
     if args.cfg is not None:
         nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
     f, N, S = 32, args.batch, args.size
