@@ -47,6 +47,8 @@ int segnb_device_cus(void);
 /* Kernel-selection knobs for A/B measurements and tests (results never depend on them beyond rounding order):
  *   "fprop_dma"      0 = never use the direct-to-LDS 3x3 pipeline (fprop_dma.hip), 1 = use it where it applies
  *   "fprop_dma_cfg"  -1 = automatic tile configuration, n >= 0 = force configuration n
+ *   "fprop_rw"       0 = never use the resident-weights pipeline of the thin layers (fprop_rw.hip)
+ *   "fprop_dma_dbg"  timing builds (parts of the pipeline removed; results are WRONG when non-zero)
  * Defaults come from the environment variables SEGNB_FPROP_DMA / SEGNB_FPROP_DMA_CFG.  Not thread-safe. */
 int segnb_tune(const char* key, int value);
 

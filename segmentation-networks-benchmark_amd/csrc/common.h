@@ -40,6 +40,7 @@ int segnb_num_cus();
 int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();
 int segnb_knob_fprop_dma_dbg();
+int segnb_knob_fprop_rw();
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);
@@ -47,6 +48,10 @@ int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpa
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                         hipStream_t stream);
+// resident-weights pipeline for the thin layers, Ci <= 96 and Co <= 96 (fprop_rw.hip)
+int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
+                       unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
+                       hipStream_t stream);
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
                        hipStream_t stream);
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);

@@ -1,0 +1,94 @@
+// Shared pieces of the direct-to-LDS convolution pipelines (fprop_dma.hip, fprop_rw.hip): LDS-DMA issue, raw barriers
+// with counted waits, order-pinned fragment reads / MFMAs.  See fprop_dma.hip for the scheme.
+#pragma once
+#include "common.h"
+
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+struct FdArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    unsigned x_bytes, w_bytes, out_bytes;
+    const float* bias;
+    int bias_n;
+    bf16_t* out;
+    double* stats;
+    int N, H, W;          // output grid
+    int Hi, Wi;           // input tensor
+    int Ci, Co, ld_x, ld_out, Ktot;
+    int dhmin, dwmin;
+    int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
+    int HB, WB, IT, NTL, GM, NCH;
+    int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA, 8 no epilogue
+};
+
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ int xcd_remap_fd(int b, int G) {
+    const int q = G >> 3, r = G & 7, x = b & 7, j = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+__device__ __forceinline__ i32x4_t make_rsrc4(const void* base, unsigned bytes) {
+    const unsigned long long pa = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// one LDS-DMA piece: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte lds_dst + 16*l.
+// hipcc does not count these (no s_waitcnt of its own for them): completion is the counted vmcnt of step_sync.
+__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const i32x4_t& rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+// LDS-only barrier: __syncthreads() would also wait for the global stores of the epilogue and for every DMA in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define FD_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define FD_MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int N>
+__device__ __forceinline__ void step_sync() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// counted LDS wait naming a fragment set of NF registers
+template <int N, int NF>
+__device__ __forceinline__ void ws_wait(bf16x8_t (&f)[NF]) {
+    if constexpr (NF == 6)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
+    else if constexpr (NF == 5)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N));
+    else if constexpr (NF == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+    else if constexpr (NF == 3)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
+    else {
+        static_assert(NF == 2, "fragment set");
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
+    }
+}
+
+
+}  // namespace

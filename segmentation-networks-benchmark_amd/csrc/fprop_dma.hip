@@ -34,75 +34,9 @@
 // tap before it, across the barrier), tap addresses precomputed per lane, while the partner's fetches issue in the gaps.
 #include "common.h"
 
-#include <utility>
+#include "fprop_dma.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-struct FdArgs {
-    const bf16_t* x;
-    const bf16_t* w;
-    unsigned x_bytes, w_bytes;
-    const float* bias;
-    int bias_n;
-    bf16_t* out;
-    double* stats;
-    int N, H, W;          // output grid
-    int Hi, Wi;           // input tensor
-    int Ci, Co, ld_x, ld_out, Ktot;
-    int dhmin, dwmin;
-    int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
-    int HB, WB, IT, NTL, GM, NCH;
-    int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA, 8 no epilogue
-};
-
-constexpr unsigned OOB = 0x80000000u;
-
-__device__ __forceinline__ int xcd_remap_fd(int b, int G) {
-    const int q = G >> 3, r = G & 7, x = b & 7, j = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
-
-__device__ __forceinline__ i32x4_t make_rsrc4(const void* base, unsigned bytes) {
-    const unsigned long long pa = (unsigned long long)base;
-    i32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = 0x00020000;
-    return r;
-}
-
-// one LDS-DMA piece: lane l's 16 bytes at (descriptor base + voff + soff) land at LDS byte lds_dst + 16*l.
-// hipcc does not count these (no s_waitcnt of its own for them): completion is the counted vmcnt of step_sync.
-__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const i32x4_t& rsrc, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
-}
-
-// LDS-only barrier: __syncthreads() would also wait for the global stores of the epilogue and for every DMA in flight
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#define FD_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
-#define FD_MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
-template <int N>
-__device__ __forceinline__ void step_sync() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <int BN_, int R_, int WT_, int CW_M_>
 struct WsCfg {
@@ -140,23 +74,6 @@ struct WsCfg {
     static_assert(SMEM <= 160 * 1024, "LDS");
     static_assert(TM + TN <= 6, "fragment wait statement");
 };
-
-// counted LDS wait naming a fragment set of NF registers
-template <int N, int NF>
-__device__ __forceinline__ void ws_wait(bf16x8_t (&f)[NF]) {
-    if constexpr (NF == 6)
-        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N));
-    else if constexpr (NF == 5)
-        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N));
-    else if constexpr (NF == 4)
-        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
-    else if constexpr (NF == 3)
-        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
-    else {
-        static_assert(NF == 2, "fragment set");
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
-    }
-}
 
 template <class C>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
@@ -296,7 +213,10 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     if constexpr (t < C::A_STEPS)
                         if (!(a.dbg & 2)) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
                     // the operands of tap t+2 (fetched during tap t-1) have landed: only this tap's fetches stay in flight
-                    constexpr int NA_T = t < C::A_STEPS ? APS : 0;
+                    // EXACTLY the halo pieces issued in this tap (the last slices of a chunk are short or empty: counting
+                    // APS for them left a weight piece of the tap before in flight -- wrong channels on a cold first launch)
+                    constexpr int NA_REST = APW - t * APS;
+                    constexpr int NA_T = t >= C::A_STEPS || NA_REST <= 0 ? 0 : (NA_REST < APS ? NA_REST : APS);
                     step_sync<BPW + NA_T>();
                 });
             }
@@ -520,6 +440,11 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
     a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Hi = g->Hi; a.Wi = g->Wi;
     a.Ci = g->Ci; a.Co = g->Co; a.ld_x = g->ld_in; a.ld_out = g->ld_out;
     a.Ktot = 9 * g->Ci;
+    {
+        const long long ob = (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2;
+        if (ob >= (1ll << 31)) return 0;
+        a.out_bytes = (unsigned)ob;
+    }
     a.dhmin = dhmin; a.dwmin = dwmin;
     for (int t = 0; t < 9; ++t) {
         a.dh[t] = g->dh[t] - dhmin;

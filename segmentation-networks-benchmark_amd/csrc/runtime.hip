@@ -52,6 +52,8 @@ int segnb_knob_fprop_dma_cfg() {
     }
     return g_fprop_dma_cfg;
 }
+static int g_fprop_rw = 1;
+int segnb_knob_fprop_rw() { return g_fprop_rw && segnb_knob_fprop_dma_cfg() < 0; }
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
@@ -62,6 +64,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_dma_cfg") == 0) {
         g_fprop_dma_cfg = value < 0 ? -1 : value;
+        return 0;
+    }
+    if (strcmp(key, "fprop_rw") == 0) {
+        g_fprop_rw = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero

@@ -675,7 +675,8 @@ def test_conv_fprop_dma_configs(case, cfg):
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')
 
 
-@pytest.mark.parametrize('shape', [(32, 56, 128, 128), (32, 14, 1536, 512), (32, 28, 256, 768), (16, 112, 192, 64)],
+@pytest.mark.parametrize('shape', [(32, 56, 128, 128), (32, 14, 1536, 512), (32, 28, 256, 768), (16, 112, 192, 64),
+                                   (32, 224, 32, 32), (32, 224, 96, 32), (32, 112, 32, 64), (32, 112, 64, 32)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_fprop_dma_full_size_reproducible(shape):
     """bs=32 layer shapes of BASELINE.json configs[1]: many tiles per persistent block, tile seams, look-ahead reads in
@@ -693,9 +694,15 @@ def test_conv_fprop_dma_full_size_reproducible(shape):
     for dma, reps in ((1, 4), (0, 1)):
         nv.call('segnb_tune', b'fprop_dma', dma)
         try:
-            for _ in range(reps):
+            for rep in range(reps):
                 yv = View.alloc(rt, N, S, S, op.Cop)
                 stats = rt.zeros((16, 2, op.Cop), torch.float64)
+                if rep % 2 == 0:
+                    # cold caches (weights and input from HBM): the timing in which a fetch that a counted wait does
+                    # not cover is still in flight when its LDS rows are read
+                    flush = torch.empty(160 << 20, dtype=torch.float32, device='cuda').fill_(1.0)
+                    del flush
+                    torch.cuda.synchronize()
                 op.fprop(xv, yv, stats)
                 torch.cuda.synchronize()
                 outs.append(yv.dense().clone())
@@ -707,3 +714,54 @@ def test_conv_fprop_dma_full_size_reproducible(shape):
         np.testing.assert_allclose(sts[k].numpy(), sts[0].numpy(), rtol=1e-12)
     check('dma vs register-staged y', outs[0], outs[4], 'bf16')
     np.testing.assert_allclose(sts[0].numpy(), sts[4].numpy(), rtol=1e-3, atol=1e-3 * float(sts[4].abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------------
+# resident-weights pipeline of the thin layers (fprop_rw.hip): Ci in {32, 64, 96}, Co <= 96
+# ------------------------------------------------------------------------------------------------------
+RW_CASES = [
+    # name,             N, H,  W,  segs,                    Co
+    ('rw 32->32',       2, 21, 37, [(32, 32)],              32),     # ragged tiles
+    ('rw 96->32',       3, 33, 17, [(64, 64), (32, 32)],    32),     # 3 chunks; data gradient 32 -> 96 (12 chunks / row)
+    ('rw 32->64',       1, 30, 30, [(32, 32)],              64),
+    ('rw 64->24',       2, 16, 56, [(64, 64)],              24),     # 2 chunks, padded output channels
+    ('rw 32->40',       5, 40, 24, [(32, 32)],              40),     # more tiles than blocks' first round
+    ('rw cat 62->32',   1, 19, 23, [(30, 32), (32, 32)],    32),     # padded concat segment
+]
+
+
+@pytest.mark.parametrize('case', RW_CASES, ids=[c[0] for c in RW_CASES])
+def test_conv_fprop_rw(case):
+    name, N, H, W, segs, Co = case
+    full = (name, N, H, W, segs, Co, 3, 1, 1, False)
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(11)
+    w = (torch.randn((Co, Ci, 3, 3), generator=gen) * (2.0 / (Ci * 9)) ** 0.5).bfloat16().float()
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, H, W, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=gen).bfloat16().float()
+    y_g, st_g, dx_g, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    y_g2, _, dx_g2, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    nv.call('segnb_tune', b'fprop_rw', 0)
+    try:
+        y_o, st_o, dx_o, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    finally:
+        nv.call('segnb_tune', b'fprop_rw', 1)
+    with on_emulator():
+        y_e, st_e, dx_e, _, _, _ = _run_conv('cpu', 'bf16', full, w, b, x, dy)
+    check(name + ' y', y_g, y_e, 'bf16')
+    check(name + ' dx', dx_g, dx_e, 'bf16')
+    check(name + ' y vs other kernels', y_g, y_o, 'bf16')
+    check(name + ' dx vs other kernels', dx_g, dx_o, 'bf16')
+    np.testing.assert_allclose(st_g.numpy(), st_e.numpy(), rtol=2e-3, atol=2e-2 * float(st_e.abs().max()))
+    assert float(y_g[..., Co:].abs().max()) == 0.0 if y_g.shape[-1] > Co else True
+    assert torch.equal(y_g, y_g2) and torch.equal(dx_g, dx_g2)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b, padding=1)
+    yr.backward(dy)
+    check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    parts, off = [], 0
+    for real, padded in segs:
+        parts.append(dx_g[..., off:off + real])
+        off += padded
+    check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')

@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--dma', type=int, default=None, help='segnb_tune fprop_dma (0/1)')
     ap.add_argument('--cfg', type=int, default=None, help='segnb_tune fprop_dma_cfg')
     ap.add_argument('--dbg', type=int, default=None, help='segnb_tune fprop_dma_dbg (timing builds)')
+    ap.add_argument('--rw', type=int, default=None, help='segnb_tune fprop_rw (0/1)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     args = ap.parse_args()
     rt = Runtime('cuda', args.dtype)
@@ -37,6 +38,8 @@ def main():
         nv.call('segnb_tune', b'fprop_dma', args.dma)
     if args.dbg is not None:
         nv.call('segnb_tune', b'fprop_dma_dbg', args.dbg)
+    if args.rw is not None:
+        nv.call('segnb_tune', b'fprop_rw', args.rw)
     if args.cfg is not None:
         nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
     f, N, S = 32, args.batch, args.size
