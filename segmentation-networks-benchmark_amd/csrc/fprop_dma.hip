@@ -275,15 +275,26 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         }
     } else {
         // ================= matrix stream =================
-        // K slice 0 of every tap is requested during the LAST slice of the tap before it (the fetch waves guarantee a
-        // tap's operands one barrier early), so no tap starts with an exposed LDS round trip; the slice stays in
-        // flight across the barrier and across the epilogue.
-        bf16x8_t fr[2][NF];
+        // Fragment reads run TWO K slices ahead of the MFMAs through three register sets (under load an LDS read takes
+        // longer than the four MFMAs of one slice: with one slice of look-ahead every slice stalled ~70 cycles, 65 %
+        // pipe utilisation with the fetch stream switched off).  The first two slices of a tap are requested during the
+        // last two slices of the tap before it (the fetch waves guarantee a tap's operands one barrier early) and
+        // stay in flight across the barrier.  36 slices per chunk = 0 mod 3: the set of slice (t, kk) is static.
+        bf16x8_t fr[3][NF];
         if (!(a.dbg & 4)) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) FD_READ(fr[0][j], b_rd[j]);
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) FD_READ(fr[0][TN + i], a_rd[0][i]);
+                for (int j = 0; j < TN; ++j) {
+                    const int ad = b_rd[j] ^ (kk << 5);
+                    FD_READ(fr[kk][j], ad);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int ad = a_rd[0][i] ^ (kk << 5);
+                    FD_READ(fr[kk][TN + i], ad);
+                }
+            }
         }
         for (; it < a.IT; it += a.GM) {
             f32x16_t acc[TM][TN];
@@ -299,43 +310,44 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     constexpr int t = decltype(t_c)::value;
                     constexpr int tn = t == 8 ? 0 : t + 1;
                     const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
-                    int ad[NF];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) ad[j] = b_rd[j] + bstage;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) ad[TN + i] = a_rd[t][i] + a_base;
+                    const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
+                    const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
                     if (!(a.dbg & 4)) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
-                            if (kk < 3) {
+                            const int set_cur = (4 * t + kk) % 3, set_new = (4 * t + kk + 2) % 3;
+                            int ad[NF];
+                            if (kk < 2) {                   // slice kk + 2 of this tap
 #pragma unroll
-                                for (int q = 0; q < NF; ++q) ad[q] ^= (kk ^ (kk + 1)) << 5;      // slice kk -> kk + 1
-                            } else {
-                                const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
-                                const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+                                for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bstage) ^ ((kk + 2) << 5);
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) ad[j] = b_rd[j] + bnext;
+                                for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[t][i] + a_base) ^ ((kk + 2) << 5);
+                            } else {                        // slice kk - 2 of the next tap
 #pragma unroll
-                                for (int i = 0; i < TM; ++i) ad[TN + i] = a_rd[tn][i] + anext;
+                                for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bnext) ^ ((kk - 2) << 5);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[tn][i] + anext) ^ ((kk - 2) << 5);
                             }
 #pragma unroll
-                            for (int q = 0; q < NF; ++q) FD_READ(fr[(kk + 1) & 1][q], ad[q]);
-                            ws_wait<NF>(fr[kk & 1]);
+                            for (int q = 0; q < NF; ++q) FD_READ(fr[set_new][q], ad[q]);
+                            ws_wait<2 * NF>(fr[set_cur]);
 #pragma unroll
                             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) FD_MFMA(acc[i][j], fr[kk & 1][j], fr[kk & 1][TN + i]);
+                                for (int j = 0; j < TN; ++j) FD_MFMA(acc[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
                         }
                         __builtin_amdgcn_s_setprio(0);
                     }
                     raw_barrier();
                 });
             }
-            // The slice requested for the next tile's first tap must have LANDED before the epilogue: its destination
+            // The slices requested for the next tile's first tap must have LANDED before the epilogue: their destination
             // registers count as written for the compiler, which is free to move them around in the code below -- a
             // copy taken before the data arrives is a stale register (seen as run-to-run differences at bs=32).
             ws_wait<0>(fr[0]);
+            ws_wait<0>(fr[1]);
+            ws_wait<0>(fr[2]);
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before the epilogue reads them
             unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
 #pragma unroll
@@ -396,17 +408,16 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
     int cfg = segnb_knob_fprop_dma_cfg();
     if (cfg < 0) {
         // measured per ZF_UNET layer at bs=32 (tools/layer_bench.py --cfg): 64-channel output tiles win on every level
-        // from 14x14 to 112x112 -- twice the tiles of the 128-channel form on layers that have only 200-800 of them;
+        // from 14x14 to 112x112 -- twice the tiles of a 128-channel form (measured, since removed) on layers that have
+        // only 200-800 of them;
         // 16 x 16 pixel tiles tie or beat 8 x 32 except for the widest data gradients.  Outputs of <= 32 channels
         // (half of every tile padding) and 7x7 images stay with fprop_s1 / the general kernel.
         if (a.Co <= 32 || a.W <= 8) return NOT_HANDLED;
-        cfg = (a.W >= 48 && a.Co >= 3 * a.Ci) ? 2 : 3;
+        cfg = (a.W >= 48 && a.Co >= 3 * a.Ci) ? 0 : 1;
     }
     switch (cfg) {
-        case 0: return launch_ws<WsCfg<128, 8, 32, 2>>(a, stream);
-        case 1: return launch_ws<WsCfg<128, 16, 16, 2>>(a, stream);
-        case 2: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
-        case 3: return launch_ws<WsCfg<64, 16, 16, 4>>(a, stream);
+        case 0: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
+        case 1: return launch_ws<WsCfg<64, 16, 16, 4>>(a, stream);
         default: return NOT_HANDLED;
     }
 }
