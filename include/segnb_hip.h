@@ -51,6 +51,10 @@ int segnb_device_cus(void);
  *   "fprop_dma_dbg"  timing builds (parts of the pipeline removed; results are WRONG when non-zero)
  * Defaults come from the environment variables SEGNB_FPROP_DMA / SEGNB_FPROP_DMA_CFG.  Not thread-safe. */
 int segnb_tune(const char* key, int value);
+/* Timing builds: in-kernel shader-clock stamps of block 0 of the last direct-to-LDS convolution launched with
+ * "fprop_dma_dbg" = 32.  host_dst: HOST buffer of 3 x 256 x 4 unsigned 64-bit values ([wave role][tap][event]);
+ * synchronises the device (tools/stamps.py). */
+int segnb_debug_stamps(unsigned long long* host_dst);
 
 /* ---------------------------------------------------------------------------------------------
  * Generalised gather-convolution geometry.  One launch computes, for every image n and every

@@ -526,6 +526,9 @@ class AbiEmulator(object):
         """kernel-selection knobs have no meaning on the CPU restatement"""
         return 0
 
+    def segnb_debug_stamps(self, host_dst):
+        return 0
+
     def segnb_sgd_step(self, p, g, n, lr, stream):
         _mem(p, n, torch.float32).sub_(lr * _mem(g, n, torch.float32))
         return 0

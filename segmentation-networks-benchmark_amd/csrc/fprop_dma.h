@@ -66,6 +66,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 #define FD_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 #define FD_MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+// first MFMA of an accumulator: C = 0 (no 16 v_mov per accumulator tile)
+#define FD_MFMA0(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 template <int N>

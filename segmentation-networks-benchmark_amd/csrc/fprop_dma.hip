@@ -38,6 +38,14 @@
 
 namespace {
 
+// in-kernel time stamps of block 0 (timing builds, segnb_tune("fprop_dma_dbg", 32)): [role][step][4] shader clocks
+__device__ unsigned long long g_stamps[3 * 256 * 4];
+#define FD_STAMP(role, step, k)                                                                      \
+    do {                                                                                            \
+        if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0 && (step) < 256)                           \
+            g_stamps[((role) * 256 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime();             \
+    } while (0)
+
 template <int BN_, int R_, int WT_, int CW_M_>
 struct WsCfg {
     static constexpr int BN = BN_, R = R_, WT = WT_;
@@ -50,27 +58,31 @@ struct WsCfg {
     static constexpr int XR = R + 2, XC = WT + 2, NPIX = XR * XC;
     static constexpr int APIECES = (NPIX + 7) / 8;
     static constexpr int A_BYTES = APIECES * 1024;
-    static constexpr int APW = (APIECES + NLW - 1) / NLW;
-    static constexpr int A_STEPS = 5;
+    // fetch waves: NBW stream the weight ring, NAW the halo tiles -- separate vmcnt queues (a counted wait is in issue
+    // order: behind a halo piece coming from HBM the weight ring's wait stalled every tap)
+    static constexpr int NBW = 2, NAW = 2;
+    static constexpr int APW = (APIECES + NAW - 1) / NAW;
+    static constexpr int A_STEPS = 7;                    // halo pieces go out during taps 0..6, all waited for in tap 7
     static constexpr int APS = (APW + A_STEPS - 1) / A_STEPS;
     static constexpr int BPIECES = BN / 8;
     static constexpr int B_STAGE = BN * 128;
-    static constexpr int BPW = BPIECES / NLW;
+    static constexpr int BPW = BPIECES / NBW;
     static constexpr int OUT_ROW = BN * 2 + 16;
-    static constexpr int NPASS = (BM * OUT_ROW + A_BYTES - 1) / A_BYTES;
-    static constexpr int EPR = ((BM / 32 + NPASS - 1) / NPASS) * 32;
     static constexpr int OC = BN / 8;
+    static constexpr int MT = NCW * 64;                  // matrix threads: they also store (one channel chunk each)
+    static constexpr int RPT = BM / (MT / OC);           // staged rows per thread = taps that carry one row's store
+    // LDS: [halo x2][weight ring][output staging: whole tile][dummy piece][pixel tables x2][bias]
     static constexpr int OFF_B = 2 * A_BYTES;
-    static constexpr int OFF_DUMMY = OFF_B + NB * B_STAGE;
+    static constexpr int OFF_STG = OFF_B + NB * B_STAGE;
+    static constexpr int OFF_DUMMY = OFF_STG + BM * OUT_ROW;
     static constexpr int OFF_PIX = OFF_DUMMY + 1024;
-    static constexpr int OFF_BIAS = OFF_PIX + BM * 4;
+    static constexpr int OFF_BIAS = OFF_PIX + 4 * BM * 4;      // pixel tables of tiles k-1 (being stored), k, k+1, k+2 (set up)
     static constexpr int SMEM = OFF_BIAS + BN * 4;
-    static constexpr int RED_BYTES = NLW * 64 * 16 * 8;
+    static constexpr int RED_BYTES = MT * 16 * 8;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == NCW, "wave tiling");
-    static_assert(BPIECES % NLW == 0, "weight pieces per loader wave");
-    static_assert(EPR * OUT_ROW <= A_BYTES, "epilogue staging fits one halo buffer");
-    static_assert((NLW * 64) % OC == 0 && NLW * 64 >= 2 * BN, "store pass / statistics threads");
-    static_assert(RED_BYTES <= OFF_DUMMY, "statistics reduction scratch");
+    static_assert(BPIECES % NBW == 0 && NBW + NAW == NLW, "fetch wave roles");
+    static_assert(MT % OC == 0 && MT >= 2 * BN && RPT <= 8 && BM == MT, "store pass / statistics threads");
+    static_assert(RED_BYTES <= OFF_STG, "statistics reduction scratch");
     static_assert(SMEM <= 160 * 1024, "LDS");
     static_assert(TM + TN <= 6, "fragment wait statement");
 };
@@ -104,182 +116,205 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         sBias[c] = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
     }
 
-    // ---- loader-side per-lane constants --------------------------------------------------------------------
-    unsigned b_voff[BPW];
-#pragma unroll
-    for (int pb = 0; pb < BPW; ++pb) {
-        const int row = ((lw & 3) * BPW + pb) * 8 + (lane >> 3);
-        const int q = lane & 7;
-        const int co = n_base + row;
-        b_voff[pb] = co < a.Co ? (unsigned)co * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
-    }
-    unsigned a_voff[APW];
-    auto set_fetch_tile = [&](int it) {
-        const bool live = it < a.IT;
-        const int n = it / (a.HB * a.WB);
-        const int rem = it - n * (a.HB * a.WB);
-        const int hb = rem / a.WB, wb = rem - hb * a.WB;
-        const int h0 = hb * R + a.dhmin, w0 = wb * WT + a.dwmin;
-#pragma unroll
-        for (int pa = 0; pa < APW; ++pa) {
-            const int pix = ((lw & 3) + NLW * pa) * 8 + (lane >> 3);
-            const int q = lane & 7;
-            const int xr = pix / XC, xc = pix - xr * XC;
-            const int hi = h0 + xr, wi = w0 + xc;
-            const bool ok = live && pix < C::NPIX && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-            a_voff[pa] = ok ? (unsigned)((n * a.Hi + hi) * a.Wi + wi) * (unsigned)a.ld_x * 2u +
-                                  (unsigned)((q ^ ((pix >> 1) & 7)) * 16)
-                            : OOB;
-        }
-    };
-    auto fetch_a = [&](int p0, int p1, int c, int buf) {
-#pragma unroll
-        for (int pa = 0; pa < APW; ++pa) {
-            if (pa >= p0 && pa < p1) {
-                const int piece = (lw & 3) + NLW * pa;
-                const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
-                dma16(dst, a_voff[pa], rs_x, (unsigned)c * 128u);
-            }
-        }
-    };
-    auto fetch_b = [&](int c, int t, int stage) {
-        const unsigned soff = (unsigned)(t * a.Ci + c * 64) * 2u;
-#pragma unroll
-        for (int pb = 0; pb < BPW; ++pb)
-            dma16(lds0 + C::OFF_B + stage * C::B_STAGE + ((lw & 3) * BPW + pb) * 1024, b_voff[pb], rs_w, soff);
-    };
-
-    // ---- compute-side per-lane constants: fragment offsets (see the uniform kernel for the swizzle) -----------
-    int b_rd[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn * C::WN + 32 * j + r;
-        b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
-    }
-    int a_rd[9][TM];                    // per tap and row tile, buffer 0 (kept for the whole kernel)
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = wm * C::WM + 32 * i + r;
-            const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
-            int v = (p << 7) + ((p & 12) << 3) + (((h ^ (p >> 1)) & 1) << 4);
-            asm volatile("" : "+v"(v));
-            a_rd[t][i] = v;
-        }
-
-    // ---- pipeline prologue ----------------------------------------------------------------------------------
+    // ---- three programs (weight waves / halo waves / matrix waves) with the same barrier sequence: one after the
+    // pipeline prologue, one per tap, three after the last tile.  Per-role constants are computed inside the role's
+    // branch so that they do not occupy registers of the others.
     int it = gq;
-    if (loader) {
-        set_fetch_tile(it);
-        fetch_a(0, APW, 0, 0);
-        fetch_b(0, 0, 0);
-        fetch_b(0, 1, 1);
-        fetch_b(0, 2, 2);
-    }
+    const bool wfetch = loader && lw < C::NBW;          // weight-ring wave (else: halo wave)
     int cg = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // Two programs with the same barrier sequence.  (One tile loop with role branches inside keeps the accumulators AND
-    // the store-pass statistics live everywhere: 256 registers + scratch spills.)
+    // Two programs with the same barrier sequence (one barrier per tap, three after the last tile).
     if (loader) {
-        // ================= fetch stream + store pass =================
-        const int ltid = tid - C::NCW * 64;            // 0..255
-        constexpr int LT = NLW * 64;
-        float s1[8], s2[8];                            // statistics of the stored values: one 8-channel chunk per thread
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-        for (; it < a.IT; it += a.GM) {
-            {
+        // ================= fetch streams =================
+        // Nothing but fetches (a wave that also stored would sit behind its own stores' acknowledgements at the next
+        // counted wait), and ONE kind of fetch per wave: the weight waves wait tap by tap for L2 hits, the halo waves
+        // once per chunk for HBM.
+        if (wfetch) {
+            // ---- loader-side per-lane constants --------------------------------------------------------------------
+            unsigned b_voff[BPW];
+        #pragma unroll
+            for (int pb = 0; pb < BPW; ++pb) {
+                const int row = ((lw & 1) * BPW + pb) * 8 + (lane >> 3);
+                const int q = lane & 7;
+                const int co = n_base + row;
+                b_voff[pb] = co < a.Co ? (unsigned)co * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
+            }
+            auto fetch_b = [&](int c, int t, int stage) {
+                const unsigned soff = (unsigned)(t * a.Ci + c * 64) * 2u;
+        #pragma unroll
+                for (int pb = 0; pb < BPW; ++pb)
+                    dma16(lds0 + C::OFF_B + stage * C::B_STAGE + ((lw & 1) * BPW + pb) * 1024, b_voff[pb], rs_w, soff);
+            };
+
+            fetch_b(0, 0, 0);
+            fetch_b(0, 1, 1);
+            fetch_b(0, 2, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            for (; it < a.IT; it += a.GM) {
+                for (int c = 0; c < a.NCH; ++c, ++cg) {
+                    const int cn = c + 1 == a.NCH ? 0 : c + 1;
+                    static_for<9>([&](auto t_c) {
+                        constexpr int t = decltype(t_c)::value;
+                        constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
+                        const int cf = t + 3 < 9 ? c : cn;
+                        if (lw == 0) FD_STAMP(1, cg * 9 + t, 0);
+                        if (!(a.dbg & 1)) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
+                        if (lw == 0) FD_STAMP(1, cg * 9 + t, 1);
+                        // the weights of tap t+2 (fetched during tap t-1) have landed: only this tap's fetch stays in flight
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
+                        if (lw == 0) FD_STAMP(1, cg * 9 + t, 2);
+                        raw_barrier();
+                        if (lw == 0) FD_STAMP(1, cg * 9 + t, 3);
+                    });
+                }
+            }
+        } else {
+            // Per lane the pixel of a halo piece is fixed: its offset relative to the tile origin and its halo coordinates are
+            // computed ONCE; per tile only the origin (scalar) and the border compares remain (recomputing pix / XC etc. per
+            // tile stalled every wave of the block ~1800 cycles at the tile's last chunk: in-kernel stamps, tools/stamps.py).
+            // The same call writes the tile's output pixel table (read by the store rows one tile later).
+            unsigned a_rel[APW], a_xy[APW], a_voff[APW];
+        #pragma unroll
+            for (int pa = 0; pa < APW; ++pa) {
+                const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
+                const int q = lane & 7;
+                const int xr = pix / XC, xc = pix - xr * XC;
+                a_rel[pa] = (unsigned)(xr * a.Wi + xc) * (unsigned)a.ld_x * 2u + (unsigned)((q ^ ((pix >> 1) & 7)) * 16);
+                a_xy[pa] = pix < C::NPIX ? (unsigned)xr | ((unsigned)xc << 16) : 0x7fff7fffu;      // never inside the image
+            }
+            auto set_fetch_tile = [&](int it, int table) {
+                const bool live = it < a.IT;
                 const int n = it / (a.HB * a.WB);
                 const int rem = it - n * (a.HB * a.WB);
                 const int hb = rem / a.WB, wb = rem - hb * a.WB;
-                for (int rr = ltid; rr < BM; rr += LT) {
-                    const int ho = hb * R + rr / WT, wo = wb * WT + rr % WT;
-                    sPix[rr] = (ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
+                const int h0 = hb * R + a.dhmin, w0 = wb * WT + a.dwmin;
+                const unsigned base = (unsigned)(((n * a.Hi + h0) * a.Wi + w0) * a.ld_x * 2);
+                const unsigned hlim = live ? (unsigned)a.Hi : 0u;
+        #pragma unroll
+                for (int pa = 0; pa < APW; ++pa) {
+                    const int hi = h0 + (int)(a_xy[pa] & 0xffffu), wi = w0 + (int)(a_xy[pa] >> 16);
+                    const bool ok = (unsigned)hi < hlim && (unsigned)wi < (unsigned)a.Wi;
+                    a_voff[pa] = ok ? base + a_rel[pa] : OOB;
                 }
-            }
-            for (int c = 0; c < a.NCH; ++c, ++cg) {
-                const bool last = c + 1 == a.NCH;
-                const int cn = last ? 0 : c + 1;
-                if (last) set_fetch_tile(it + a.GM);
-                const int abuf = cg & 1;
-                static_for<9>([&](auto t_c) {
-                    constexpr int t = decltype(t_c)::value;
-                    constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
-                    const int cf = t + 3 < 9 ? c : cn;
-                    if (!(a.dbg & 1)) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
-                    if constexpr (t < C::A_STEPS)
-                        if (!(a.dbg & 2)) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
-                    // the operands of tap t+2 (fetched during tap t-1) have landed: only this tap's fetches stay in flight
-                    // EXACTLY the halo pieces issued in this tap (the last slices of a chunk are short or empty: counting
-                    // APS for them left a weight piece of the tap before in flight -- wrong channels on a cold first launch)
-                    constexpr int NA_REST = APW - t * APS;
-                    constexpr int NA_T = t >= C::A_STEPS || NA_REST <= 0 ? 0 : (NA_REST < APS ? NA_REST : APS);
-                    step_sync<BPW + NA_T>();
-                });
-            }
-            const unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
-#pragma unroll
-            for (int pass = 0; pass < C::NPASS; ++pass) {
-                lds_barrier();                          // the matrix waves staged this pass
-                const int cc = ltid % OC;
-                const int co = n_base + cc * 8;
-                if (!(a.dbg & 8))
-                for (int rl = ltid / OC; rl < C::EPR; rl += LT / OC) {
-                    const int row = pass * C::EPR + rl;
-                    if (row < BM) {
-                        const int opix = sPix[row];
-                        if (opix >= 0 && co < a.Co) {
-                            const uint4 v = *reinterpret_cast<const uint4*>(sOut + rl * OUT_ROW + cc * 16);
-                            *reinterpret_cast<uint4*>(a.out + (long long)opix * a.ld_out + co) = v;
-                            if (a.stats != nullptr) {
-                                float f[8];
-                                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-                                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-                                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-                                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    s1[e] += f[e];
-                                    s2[e] += f[e] * f[e];
-                                }
-                            }
-                        }
+                // output pixel of tile rows (-1 = outside the image): 128 halo-wave threads, BM / 128 rows each
+                const int t128 = (lw & 1) * 64 + lane;
+        #pragma unroll
+                for (int rr = t128; rr < BM; rr += C::NAW * 64) {
+                    const int ho = hb * R + rr / WT, wo = wb * WT + rr % WT;
+                    sPix[table * BM + rr] = (live && ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
+                }
+            };
+            auto fetch_a = [&](int p0, int p1, int c, int buf) {
+        #pragma unroll
+                for (int pa = 0; pa < APW; ++pa) {
+                    if (pa >= p0 && pa < p1) {
+                        const int piece = (lw & 1) + C::NAW * pa;
+                        const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
+                        dma16(dst, a_voff[pa], rs_x, (unsigned)c * 128u);
                     }
                 }
-                lds_barrier();                          // staging area free again
+            };
+            set_fetch_tile(it, 0);
+            fetch_a(0, APW, 0, 0);
+            // During a tile's LAST chunk the first chunk of the next tile is fetched, so the per-lane offsets must
+            // describe that tile by then: they are switched during tap 7 of the chunk before (taps 7 and 8 issue nothing
+            // and leave ~1.5 k cycles of slack; done at the last chunk's start it held every wave at a barrier).
+            if (a.NCH == 1) set_fetch_tile(it + a.GM, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            int tile_no = 0;                                   // tiles of this block; pixel table = tile_no & 3
+            for (; it < a.IT; it += a.GM, ++tile_no) {
+                for (int c = 0; c < a.NCH; ++c, ++cg) {
+                    const bool last = c + 1 == a.NCH;
+                    const int cn = last ? 0 : c + 1;
+                    // the chunk after this one: is it the last of its tile?  then set up the tile after that one
+                    const bool next_last = last ? a.NCH == 1 : c + 2 == a.NCH;
+                    const int setup_it = last ? it + 2 * a.GM : it + a.GM;
+                    const int setup_tab = (tile_no + (last ? 2 : 1)) & 3;
+                    const int abuf = cg & 1;
+                    static_for<9>([&](auto t_c) {
+                        constexpr int t = decltype(t_c)::value;
+                        if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
+                        if constexpr (t < C::A_STEPS)
+                            if (!(a.dbg & 2)) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
+                        if constexpr (t == 7)
+                            if (next_last) set_fetch_tile(setup_it, setup_tab);
+                        if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
+                        // the next chunk's halo tile is first read during tap 8 (look-ahead slices of its tap 0)
+                        if constexpr (t == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 2);
+                        raw_barrier();
+                        if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 3);
+                    });
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // look-ahead fetches of the (absent) next tile
-        lds_barrier();
-        if (a.stats != nullptr) {
-            double* red = reinterpret_cast<double*>(smem);    // [LT][16]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[ltid * 16 + e] = (double)s1[e];
-                red[ltid * 16 + 8 + e] = (double)s2[e];
-            }
-        }
-        lds_barrier();
-        if (a.stats != nullptr && ltid < 2 * BN) {
-            const double* red = reinterpret_cast<const double*>(smem);
-            const int which = ltid / BN, col = ltid - which * BN;
-            const int cc = col >> 3, e = col & 7;
-            double s = 0.0;
-            for (int k = 0; k < LT / OC; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
-            const int co = n_base + col;
-            if (co < a.Co)
-                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], s);
-        }
+        raw_barrier();
+        raw_barrier();
+        raw_barrier();
     } else {
-        // ================= matrix stream =================
+        // ================= matrix stream (+ the previous tile's stores in its shadow) =================
         // Fragment reads run TWO K slices ahead of the MFMAs through three register sets (under load an LDS read takes
-        // longer than the four MFMAs of one slice: with one slice of look-ahead every slice stalled ~70 cycles, 65 %
-        // pipe utilisation with the fetch stream switched off).  The first two slices of a tap are requested during the
-        // last two slices of the tap before it (the fetch waves guarantee a tap's operands one barrier early) and
-        // stay in flight across the barrier.  36 slices per chunk = 0 mod 3: the set of slice (t, kk) is static.
+        // longer than the four MFMAs of one slice).  The first two slices of a tap are requested during the last two
+        // slices of the tap before it (the fetch waves guarantee a tap's operands one barrier early) and stay in flight
+        // across the barrier.  36 slices per chunk = 0 mod 3: the set of slice (t, kk) is static.
+        //
+        // EPILOGUE IN THE MFMA SHADOW.  At the end of a tile the accumulators are staged (bias, bf16) into a buffer of
+        // their own -- no barrier: the first tap barrier of the next tile publishes it -- and the tile's coalesced
+        // stores + BatchNorm statistics are issued one staged row per thread and tap during taps 1..RPT of the NEXT
+        // tile, between its MFMAs (a matrix wave needs 8 of every 32 issue cycles).  Serialised, the epilogue was
+        // 2-2.5 k cycles per tile: 30 % of a 64 -> 64 tile, 7 % of a 256 -> 256 one.
+        // ---- compute-side per-lane constants: fragment offsets (see the uniform kernel for the swizzle) -----------
+        int b_rd[TN];
+    #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * C::WN + 32 * j + r;
+            b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
+        }
+        int a_rd[9][TM];                    // per tap and row tile, buffer 0 (kept for the whole kernel)
+    #pragma unroll
+        for (int t = 0; t < 9; ++t)
+    #pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = wm * C::WM + 32 * i + r;
+                const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
+                int v = (p << 7) + ((p & 12) << 3) + (((h ^ (p >> 1)) & 1) << 4);
+                asm volatile("" : "+v"(v));
+                a_rd[t][i] = v;
+            }
+
+        lds_barrier();                                         // pipeline prologue: first operands have landed
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        unsigned char* const sOut = smem + C::OFF_STG;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+        const int cc = tid % OC, row0 = tid / OC;              // store pass: channel chunk, first staged row
+        const bool cok = n_base + cc * 8 < a.Co;
+        float s1[8], s2[8];                                    // statistics of the stored values of chunk cc
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+        auto store_row = [&](int k, const int* tab) {          // staged row row0 + k * (MT / OC) of the previous tile
+            const int row = row0 + k * (C::MT / OC);
+            const int opix = tab[row];
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(sOut + row * OUT_ROW + cc * 16);
+            const bool ok = cok && opix >= 0;
+            const unsigned voff = ok ? (unsigned)opix * (unsigned)a.ld_out * 2u + (unsigned)(n_base + cc * 8) * 2u : OOB;
+            if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
+            if (a.stats != nullptr) {
+                const float m = ok ? 1.f : 0.f;
+                float f[8];
+                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float fm = f[e] * m;
+                    s1[e] += fm;
+                    s2[e] += fm * fm;
+                }
+            }
+        };
         bf16x8_t fr[3][NF];
         if (!(a.dbg & 4)) {
 #pragma unroll
@@ -296,22 +331,21 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 }
             }
         }
-        for (; it < a.IT; it += a.GM) {
-            f32x16_t acc[TM][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        int tile_no = 0;                                       // pixel table of tile k = k & 3 (written by the halo waves)
+        bool pending = false;
+        for (; it < a.IT; it += a.GM, ++tile_no) {
+            f32x16_t acc[TM][TN];                              // (zeroed by the first MFMAs of the tile: C operand 0)
             for (int c = 0; c < a.NCH; ++c, ++cg) {
                 const int a_base = (cg & 1) * C::A_BYTES;
+                const bool drain = pending && c == 0;          // this chunk carries the previous tile's stores
                 static_for<9>([&](auto t_c) {
                     constexpr int t = decltype(t_c)::value;
                     constexpr int tn = t == 8 ? 0 : t + 1;
+                    auto& accr = acc;
                     const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
                     const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
                     const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
                     if (!(a.dbg & 4)) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -332,50 +366,85 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
                             for (int q = 0; q < NF; ++q) FD_READ(fr[set_new][q], ad[q]);
                             ws_wait<2 * NF>(fr[set_cur]);
+                            if (t == 0 && kk == 0 && c == 0) {
 #pragma unroll
-                            for (int i = 0; i < TM; ++i)
+                                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) FD_MFMA(acc[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                    for (int j = 0; j < TN; ++j) FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < TN; ++j) FD_MFMA(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                            }
                         }
                         __builtin_amdgcn_s_setprio(0);
                     }
+                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
+                    if constexpr (t >= 1 && t <= C::RPT)
+                        if (drain) store_row(t - 1, sPix + ((tile_no + 3) & 3) * BM);
+                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
                     raw_barrier();
+                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
                 });
             }
-            // The slices requested for the next tile's first tap must have LANDED before the epilogue: their destination
-            // registers count as written for the compiler, which is free to move them around in the code below -- a
-            // copy taken before the data arrives is a stale register (seen as run-to-run differences at bs=32).
+            // The slices requested for the next tile's first tap must have LANDED before compiler-scheduled code runs:
+            // their destination registers count as written, and a copy taken before the data arrives is a stale
+            // register (seen as run-to-run differences at bs=32).
             ws_wait<0>(fr[0]);
             ws_wait<0>(fr[1]);
             ws_wait<0>(fr[2]);
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before the epilogue reads them
-            unsigned char* sOut = smem + ((cg - 1) & 1) * C::A_BYTES;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before they are read
+            float4 bv[TN][4];                                  // (one batch of LDS reads, not one round trip per quad)
 #pragma unroll
-            for (int pass = 0; pass < C::NPASS; ++pass) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wm * C::WM + 32 * i + r;
-                    if ((wm * C::WM + 32 * i) / C::EPR == pass) {
+                for (int g = 0; g < 4; ++g)
+                    bv[j][g] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 32 * j + 8 * g + 4 * h);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) {
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * C::WM + 32 * i + r;
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
-                                const float4 bv4 = *reinterpret_cast<const float4*>(sBias + col);
-                                uint2 pk;
-                                pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
-                                pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
-                                *reinterpret_cast<uint2*>(sOut + (row - pass * C::EPR) * OUT_ROW + col * 2) = pk;
-                            }
-                        }
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
+                        const float4 bv4 = bv[j][g];
+                        uint2 pk;
+                        pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
+                        pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
+                        *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
-                lds_barrier();
-                lds_barrier();
+            }
+            pending = true;
+        }
+        lds_barrier();                                         // the last tile is staged
+        if (pending) {
+#pragma unroll
+            for (int k = 0; k < C::RPT; ++k) store_row(k, sPix + ((tile_no + 3) & 3) * BM);
+        }
+        // ---- statistics: fixed-order block reduction, one fp64 atomic per channel and block ----------------------
+        lds_barrier();                                         // (fetch waves: everything has landed; staging consumed)
+        if (a.stats != nullptr) {
+            double* red = reinterpret_cast<double*>(smem);     // [MT][16]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[tid * 16 + e] = (double)s1[e];
+                red[tid * 16 + 8 + e] = (double)s2[e];
             }
         }
-        raw_barrier();
-        raw_barrier();
+        lds_barrier();
+        if (a.stats != nullptr && tid < 2 * BN) {
+            const double* red = reinterpret_cast<const double*>(smem);
+            const int which = tid / BN, col = tid - which * BN;
+            const int c8 = col >> 3, e = col & 7;
+            double sum = 0.0;
+            for (int k = 0; k < C::MT / OC; ++k) sum += red[(k * OC + c8) * 16 + which * 8 + e];
+            const int co = n_base + col;
+            if (co < a.Co)
+                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], sum);
+        }
     }
 }
 
@@ -423,6 +492,11 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// timing builds: copy the stamps of the last stamped launch to the host (3 roles x 256 steps x 4 clocks)
+int segnb_fprop_dma_read_stamps(unsigned long long* host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 3 * 256 * 4);
+}
 
 // 1 = handled, 0 = not applicable (caller falls through to fprop_s1 / the general gather kernel), else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,

@@ -77,3 +77,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     segnb_set_error("segnb_tune: unknown key '%s'", key);
     return SEGNB_E_BADARG;
 }
+
+// timing builds: in-kernel time stamps of block 0 of the last conv_fprop_ws_kernel launch made with
+// segnb_tune("fprop_dma_dbg", 32).  host_dst: 3 x 256 x 4 unsigned 64-bit shader clocks (matrix / weight / halo wave).
+extern "C" int segnb_debug_stamps(unsigned long long* host_dst) {
+    SEGNB_CHECK_ARG(host_dst != nullptr, "NULL destination");
+    return segnb_fprop_dma_read_stamps(host_dst);
+}

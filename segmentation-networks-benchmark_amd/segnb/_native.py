@@ -75,6 +75,7 @@ SIGNATURES = {
     'segnb_seg_loss_finalize': [_P, ctypes.POINTER(LossSpec), _P, _P],
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_tune': [ctypes.c_char_p, c_int],
+    'segnb_debug_stamps': [_P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
