@@ -76,26 +76,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) gw[k][e] = 0.f;
     }
-    if (active)
-        for (int pix = blockIdx.x * PY + ty; pix < (int)npix; pix += gridDim.x * PY) {     // npix < 2^31 (checked)
-            const int n = pix / (int)hw, r = pix - n * (int)hw;
-            float av[8], d[8];
-            load8(a + (long long)pix * ld_a + c0, av);
+    if (active) {
+        // four pixels per trip: all their loads go out before the first use (one pixel per trip left one dependent
+        // load chain per wave in flight: 2 TB/s on a pure streaming pass); K == 1 needs no pixel -> (n, r) division
+        const int stride = gridDim.x * PY;
+        for (int pix0 = blockIdx.x * PY + ty; pix0 < (int)npix; pix0 += 4 * stride) {     // npix < 2^31 (checked)
+            float av[4][8], g[4][MAXK];
+            bool ok[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d[e] = 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int pix = pix0 + u * stride;
+                ok[u] = pix < (int)npix;
+                const int pc = ok[u] ? pix : pix0;
+                load8(a + (long long)pc * ld_a + c0, av[u]);
+                if (K == 1) {
+                    g[u][0] = dl[pc];
+                } else {
+                    const int n = pc / (int)hw, r = pc - n * (int)hw;
 #pragma unroll
-            for (int k = 0; k < MAXK; ++k)
-                if (k < K) {
-                    const float g = dl[((long long)n * K + k) * hw + r];
-                    gb[k] += g;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        d[e] = fmaf(g, wv[k][e], d[e]);
-                        gw[k][e] = fmaf(g, av[e], gw[k][e]);
-                    }
+                    for (int k = 0; k < MAXK; ++k) g[u][k] = k < K ? dl[((long long)n * K + k) * hw + r] : 0.f;
                 }
-            if (da != nullptr) store8(da + (long long)pix * ld_da + c0, d);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+                        const float gk = g[u][k];
+                        gb[k] += gk;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            d[e] = fmaf(gk, wv[k][e], d[e]);
+                            gw[k][e] = fmaf(gk, av[u][e], gw[k][e]);
+                        }
+                    }
+                if (da != nullptr) store8(da + (long long)(pix0 + u * stride) * ld_da + c0, d);
+            }
         }
+    }
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
         if (k < K) {
