@@ -13,6 +13,8 @@ libsegnb_hip.so launches (segnb.engine) -- implicit-GEMM MFMA convolutions with 
 the epilogue, one fused BN+ReLU+Dropout2d+MaxPool/Upsample pass per conv writing straight into the
 decoder's concat buffers (no torch.cat), hand-written backward.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -313,13 +315,19 @@ class _ZFUnetPlan(object):
         nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
                 nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
                 nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
+        # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
+        # they would run beside) are held back until the dependent chain has reached the deep levels.
+        npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '2'))       # measured: 0 -> 6.20, 1-2 -> 6.14, 5 -> 6.28 ms/step
+        post = []
         for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
             s1, s2 = self.stages[name]
+            hold = post if lvl < npost else None
             if lvl == 0:
-                s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'])
+                s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold)
             else:
-                s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl])
-            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl])
+                s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl], postponed=hold)
+            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold)
+        rt.flush_postponed(post)
         self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
         for i in (5, 4, 3, 2, 1, 0):
             if i == 3:

@@ -97,6 +97,15 @@ class Runtime(object):
             self._side_busy = True
         return s
 
+    def flush_postponed(self, closures):
+        """run postponed side-stream launches now (the side stream first waits for everything issued so far)"""
+        if closures:
+            side = self.fork_side()
+            with torch.cuda.stream(side):
+                for fn in closures:
+                    fn()
+            del closures[:]
+
     def join_side(self):
         if getattr(self, '_side_busy', False):
             torch.cuda.current_stream(self.device).wait_stream(self._side)
@@ -462,7 +471,7 @@ class Stage(object):
         self._saved = (xv, yv, dropmul, coef is not None)
         return yv
 
-    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None):
+    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None):
         """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
         input gradient, or None (first layer)."""
         rt = self.rt
@@ -493,8 +502,11 @@ class Stage(object):
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),
                     nv.ptr(self.bcoef), None, nv.ptr(gbias), 1, rt.stream)
-        side = rt.fork_side() if (self.defer_unpack and dx is not None) else None
-        if side is not None:
+        side = rt.fork_side() if (self.defer_unpack and dx is not None and postponed is None) else None
+        if postponed is not None and self.defer_unpack and dx is not None and rt.side_stream() is not None:
+            # launched later by the plan (flush_postponed): x and dy of this layer stay untouched until then
+            postponed.append(lambda: self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False))
+        elif side is not None:
             with torch.cuda.stream(side):
                 self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False)
         else:
