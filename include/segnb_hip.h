@@ -183,7 +183,9 @@ int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, in
                             const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
                             const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
                             const void* res, int ld_res, segnb_stream_t stream);
-/* (with a residual input, dz is also the gradient of the residual branch) */
+/* (with a residual input, dz is also the gradient of the residual branch)
+ * dz may be NULL when the only source is g_direct and there is no dropout table and no residual: a sums-only pass
+ * (one tensor write less); the layer's dy then comes from segnb_bn_bwd_apply_direct. */
 
 /* segnb_bn_finalize + segnb_bn_act_fwd in ONE launch (training mode): every block derives the coefficients of its
  * channels from `stats`; the first block column also writes `coef` (for the backward pass), updates the running
@@ -216,6 +218,13 @@ int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float
 int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                        const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
                        int ld_dy, float* dbias, int C, segnb_stream_t stream);
+
+/* The same with dz recomputed on the fly from the layer's incoming gradient g (dz = act'(z) * g, rounded to the storage
+ * type exactly as segnb_bn_act_bwd_reduce would have stored it): for layers whose gradient has a single direct source
+ * (the first convolution of every ZF_UNET block, zf_unet.py:22-23) dz never goes to memory.  dy may alias g. */
+int segnb_bn_bwd_apply_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                              const float* coef, const float* bcoef, int act, float slope, const void* g, int ld_g,
+                              void* dy, int ld_dy, float* dbias, int C, segnb_stream_t stream);
 
 /* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a */
 int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,

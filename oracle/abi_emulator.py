@@ -295,7 +295,8 @@ class AbiEmulator(object):
         if dm is not None:
             d = g * dm * self._actgrad(z, act, slope)
         d = d.to(dt)
-        _nhwc(dz, N, H, W, Cp, ld_dz, dt).copy_(d)
+        if dz is not None:
+            _nhwc(dz, N, H, W, Cp, ld_dz, dt).copy_(d)
         if sums is not None:
             S = _mem(sums, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)[0]
             dd = d.double().reshape(-1, Cp)
@@ -332,6 +333,22 @@ class AbiEmulator(object):
         co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
         bc = _mem(bcoef, 3 * Cp, torch.float32).view(3, Cp)
         yh = (Y - co[2]) * co[3]
+        out = (bc[0] * (D - bc[1] - yh * bc[2])).to(dt)
+        _nhwc(dy, N, H, W, Cp, ld_dy, dt).copy_(out)
+        if dbias is not None:
+            _mem(dbias, C, torch.float32).add_(out.float().reshape(-1, Cp).sum(0)[:C])
+        return 0
+
+    def segnb_bn_bwd_apply_direct(self, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy, ld_dy,
+                                  dbias, C, stream):
+        """segnb_bn_act_bwd_reduce's dz (never stored) recomputed from g, then segnb_bn_bwd_apply"""
+        dt = _tdt(dtype)
+        Y = _nhwc(y, N, H, W, Cp, ld_y, dt)
+        z, _, _ = self._activated(Y, Cp, coef, act, slope, None, N, dt, None)
+        D = (_nhwc(g, N, H, W, Cp, ld_g, dt).float() * self._actgrad(z, act, slope)).to(dt).float()
+        co = _mem(coef, 4 * Cp, torch.float32).view(4, Cp)
+        bc = _mem(bcoef, 3 * Cp, torch.float32).view(3, Cp)
+        yh = (Y.float() - co[2]) * co[3]
         out = (bc[0] * (D - bc[1] - yh * bc[2])).to(dt)
         _nhwc(dy, N, H, W, Cp, ld_dy, dt).copy_(out)
         if dbias is not None:

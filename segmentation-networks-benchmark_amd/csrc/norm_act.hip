@@ -378,7 +378,7 @@ __device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc
         s1[e] += dv;
         s2[e] += dv * yc;
     }
-    store8(dz + pix * ld_dz + c0, d);
+    if (dz != nullptr) store8(dz + pix * ld_dz + c0, d);      // NULL: sums only (segnb_bn_bwd_apply_direct recomputes dz)
 }
 
 template <typename T, bool HAS_D, bool HAS_P, bool HAS_U>
@@ -573,7 +573,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ bcoef,
                                                             const T* __restrict__ dz, int ld_dz, T* __restrict__ dy,
                                                             int ld_dy, float* __restrict__ dbias, int C,
-                                                            const BnBwdParams bp) {
+                                                            const BnBwdParams bp, const T* __restrict__ g, int ld_g,
+                                                            int act, float slope) {
     __shared__ float sred[32 * 8];
     __shared__ float sb3[3][32 * 8];
     for (int i = threadIdx.x; i < 32 * 8; i += NTHR) sred[i] = 0.f;
@@ -610,9 +611,11 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    float mu[8], is[8], a[8], c1[8], c2[8], sb[8];
+    float mu[8], is[8], a[8], c1[8], c2[8], sb[8], sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        sc[e] = coef[c0 + e];
+        sh[e] = coef[s.Cp + c0 + e];
         mu[e] = coef[2 * s.Cp + c0 + e];
         is[e] = coef[3 * s.Cp + c0 + e];
         a[e] = bp.bcoef != nullptr ? sb3[0][tx * 8 + e] : bcoef[c0 + e];
@@ -625,7 +628,16 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
         for (long long pix = (long long)blockIdx.x * s.PY + ty; pix < npix; pix += (long long)gridDim.x * s.PY) {
             float yv[8], d[8];
             load8(y + pix * ld_y + c0, yv);
-            load8(dz + pix * ld_dz + c0, d);
+            if (g != nullptr) {
+                // dz was never written: recompute it from the incoming gradient exactly as the reduce pass did
+                // (same expression, same rounding to the storage type)
+                load8(g + pix * ld_g + c0, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    d[e] = round_as(d[e] * 1.f * act_grad((yv[e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope), dy);
+            } else {
+                load8(dz + pix * ld_dz + c0, d);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float yh = (yv[e] - mu[e]) * is[e];
@@ -884,8 +896,10 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
                                        const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
                                        const void* res, int ld_res, segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y != nullptr && dz != nullptr, "NULL tensor");
+    SEGNB_CHECK_ARG(y != nullptr, "NULL tensor");
     SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
+    SEGNB_CHECK_ARG(dz != nullptr || (g_direct && !g_pool && !g_up && !dropmul && !res && sums),
+                    "dz may be NULL only for a direct gradient without dropout / residual (sums-only pass)");
     SEGNB_CHECK_ARG(!(res && g_pool), "residual input and pooled gradient cannot be combined");
     const EwShape s = make_shape(N, H, W, Cp);
     const bool hd = g_direct != nullptr, hp = g_pool != nullptr, hu = g_up != nullptr;
@@ -932,17 +946,20 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
 
 static int launch_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                                const float* bcoef, const void* dz, int ld_dz, void* dy, int ld_dy, float* dbias, int C,
-                               const BnBwdParams& bp, const char* who, segnb_stream_t stream) {
+                               const BnBwdParams& bp, const char* who, segnb_stream_t stream, const void* g = nullptr,
+                               int ld_g = 0, int act = 0, float slope = 0.f) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y && coef && (bcoef || bp.bcoef) && dz && dy, "NULL tensor");
+    SEGNB_CHECK_ARG(y && coef && (bcoef || bp.bcoef) && (dz || g) && dy, "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
     const dim3 grid = make_grid(s, (long long)N * H * W, 1536);
     if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
-                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp);
+                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp,
+                           (const bf16_t*)g, ld_g, act, slope);
     else if (dtype == SEGNB_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
-                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp);
+                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp,
+                           (const float*)g, ld_g, act, slope);
     else {
         segnb_set_error("%s: unknown dtype %d", who, dtype);
         return SEGNB_E_BADARG;
@@ -957,6 +974,15 @@ extern "C" int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int
     BnBwdParams bp = {};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, bp,
                                "segnb_bn_bwd_apply", stream);
+}
+
+extern "C" int segnb_bn_bwd_apply_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
+                                         const float* coef, const float* bcoef, int act, float slope, const void* g,
+                                         int ld_g, void* dy, int ld_dy, float* dbias, int C, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(g != nullptr, "NULL gradient");
+    BnBwdParams bp = {};
+    return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, nullptr, 0, dy, ld_dy, dbias, C, bp,
+                               "segnb_bn_bwd_apply_direct", stream, g, ld_g, act, slope);
 }
 
 extern "C" int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,

@@ -406,6 +406,8 @@ class Stage(object):
     nearest-x2 outputs.  (_Conv3BN of lib/models/zf_unet.py:5-17 plus the Dropout2d/pool/unpool that
     follow it at :31,:41,:42.)"""
 
+    direct_apply = os.environ.get('SEGNB_BN_DIRECT_APPLY', '1') != '0'
+
     def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
         self.defer_unpack = False     # True: the model plan runs one batched unpack at the end of backward
@@ -478,9 +480,13 @@ class Stage(object):
         xv, yv, dropmul, has_bn = self._saved
         dz = self.buffers(yv.N, yv.H, yv.W)['dz']
         coef = self.coef if has_bn else None
+        # A single direct gradient source, no dropout: dz never goes to memory -- the reduce pass only sums, the apply
+        # pass recomputes dz from g (segnb_bn_bwd_apply_direct): one tensor write less per such layer.
+        direct = (self.direct_apply and has_bn and not self._fused_fwd and g_direct is not None and g_pool is None
+                  and g_up is None and dropmul is None)
         nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                 self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
-                vptr(g_up), vld(g_up), dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
+                vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
         if has_bn and self._fused_fwd:
@@ -496,8 +502,13 @@ class Stage(object):
             # d(loss)/d(conv bias) under training-mode BatchNorm is identically zero (BN subtracts the batch mean):
             # sum(dy) = A*(sum dz - n*mean(dz) - mean(dz*yhat)*sum(yhat)) = 0.  The reference's fp32 value is pure
             # summation noise (~1e-7 of the weight-gradient scale); the flat gradient buffer already holds 0.
-            nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(self.coef),
-                    nv.ptr(self.bcoef), dz.ptr, dz.ld, dz.ptr, dz.ld, None, self.C, rt.stream)
+            if direct:
+                nv.call('segnb_bn_bwd_apply_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp,
+                        nv.ptr(self.coef), nv.ptr(self.bcoef), self.act, self.slope, g_direct.ptr, g_direct.ld,
+                        dz.ptr, dz.ld, None, self.C, rt.stream)
+            else:
+                nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(self.coef),
+                        nv.ptr(self.bcoef), dz.ptr, dz.ld, dz.ptr, dz.ld, None, self.C, rt.stream)
         else:
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),

@@ -765,3 +765,63 @@ def test_conv_fprop_rw(case):
         parts.append(dx_g[..., off:off + real])
         off += padded
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 9, 11, 32, nv.ACT_RELU), (3, 8, 8, 72, nv.ACT_LEAKY)], ids=['relu', 'leaky'])
+def test_bn_bwd_apply_direct_equals_two_pass(shape, dtype):
+    """sums-only reduce (dz == NULL) + segnb_bn_bwd_apply_direct == reduce (dz stored) + segnb_bn_bwd_apply, bit for
+    bit on the GPU and on the emulator, and GPU == emulator within the elementwise tolerance."""
+    N, H, W, C, act = shape
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(5)
+    y0 = torch.randn(N, H, W, C, generator=gen)
+    g0 = torch.randn(N, H, W, C, generator=gen)
+    gamma = torch.rand(C, generator=gen) + 0.5
+    beta = torch.randn(C, generator=gen) * 0.2
+
+    def run(device, direct):
+        rt = Runtime(device, dtype)
+        dev = rt.device
+        yv = View.alloc(rt, N, H, W, Cp)
+        yv.dense()[..., :C] = y0.to(dev, rt.tdtype)
+        gv = View.alloc(rt, N, H, W, Cp)
+        gv.dense()[..., :C] = g0.to(dev, rt.tdtype)
+        stats = torch.zeros(16, 2, Cp, dtype=torch.float64, device=dev)
+        yy = yv.dense().double()
+        stats[0, 0] = yy.sum((0, 1, 2))
+        stats[0, 1] = (yy * yy).sum((0, 1, 2))
+        coef = rt.zeros((4, Cp), torch.float32)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        g_, b_ = gamma.to(dev), beta.to(dev)
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(b_), 1e-5, 0.1,
+                nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1, nv.ptr(coef), rt.stream)
+        dz = View.alloc(rt, N, H, W, Cp)
+        sums = rt.zeros((16, 2, Cp), torch.float64)
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, None,
+                gv.ptr, gv.ld, None, 0, None, 0, None if direct else dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+        sums_copy = sums.sum(0)
+        bcoef = rt.zeros((3, Cp), torch.float32)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(coef), nv.ptr(bcoef),
+                nv.ptr(dgam), nv.ptr(dbet), 0, rt.stream)
+        dyv = View.alloc(rt, N, H, W, Cp)
+        if direct:
+            nv.call('segnb_bn_bwd_apply_direct', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), act,
+                    0.01, gv.ptr, gv.ld, dyv.ptr, dyv.ld, None, C, rt.stream)
+        else:
+            nv.call('segnb_bn_bwd_apply', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,
+                    dyv.ptr, dyv.ld, None, C, rt.stream)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return dyv.dense().float().cpu(), sums_copy.cpu(), dgam.cpu()
+
+    dy_a, s_a, dg_a = run('cuda', False)
+    dy_b, s_b, dg_b = run('cuda', True)
+    assert torch.equal(dy_a, dy_b) and torch.equal(s_a, s_b) and torch.equal(dg_a, dg_b)
+    with on_emulator():
+        dy_e, s_e, _ = run('cpu', False)
+        dy_f, s_f, _ = run('cpu', True)
+    assert torch.equal(dy_e, dy_f) and torch.equal(s_e, s_f)
+    check('apply_direct dy', dy_b, dy_f, dtype)
