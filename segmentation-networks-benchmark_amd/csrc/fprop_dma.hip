@@ -482,7 +482,15 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         // 16 x 16 pixel tiles tie or beat 8 x 32 except for the widest data gradients.  Outputs of <= 32 channels
         // (half of every tile padding) and 7x7 images stay with fprop_s1 / the general kernel.
         if (a.Co <= 32 || a.W <= 8) return NOT_HANDLED;
-        cfg = (a.W >= 48 && a.Co >= 3 * a.Ci) ? 0 : 1;
+        // 8 x 32 or 16 x 16 pixel tiles: whichever needs fewer rounds of (equal) tiles on the persistent blocks --
+        // re-measured with the final kernel, the round count decides every case (e.g. 128 -> 384 @56x56: 11 vs 12
+        // rounds, 104 vs 122 us; 64 -> 192 @112x112: 21 vs 19 rounds, 133 vs 116 us); ties go to 16 x 16
+        const int ntl = (a.Co + 63) / 64;
+        int gm = segnb_num_cus() / ntl;
+        if (gm < 1) gm = 1;
+        const long long it0 = (long long)a.N * ((a.H + 7) / 8) * ((a.W + 31) / 32);
+        const long long it1 = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
+        cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
     }
     switch (cfg) {
         case 0: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
