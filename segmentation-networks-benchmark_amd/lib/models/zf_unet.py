@@ -317,7 +317,9 @@ class _ZFUnetPlan(object):
                 nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
         # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
         # they would run beside) are held back until the dependent chain has reached the deep levels.
-        npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '2'))       # measured: 0 -> 6.20, 1-2 -> 6.14, 5 -> 6.28 ms/step
+        # (measured on one box: 0 -> 6.34 ms/step, 2 -> 6.31 ms/step, but the convolutions of the dependent chain then run
+        # beside more weight-gradient work and their own launches stretch by 6 %: off by default)
+        npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '0'))
         post = []
         for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
             s1, s2 = self.stages[name]
