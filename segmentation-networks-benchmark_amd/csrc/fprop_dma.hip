@@ -46,12 +46,18 @@ __device__ unsigned long long g_stamps[3 * 256 * 4];
             g_stamps[((role) * 256 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime();             \
     } while (0)
 
-template <int BN_, int R_, int WT_, int CW_M_>
+// TALL_: the batch is tiled as ONE image of N * (H + 1) rows -- every image followed by one virtual zero row that is
+// the bottom padding of the image above it and the top padding of the one below -- and WT = W columns: tiles of R x W
+// virtual pixels instead of one 16 x 16 tile per image.  For 7 x 7 images: 8 row tiles of 252 pixels instead of 32 tiles
+// of 49 (81 % padding); the rows m >= R * WT of a tile are dummies.
+template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false>
 struct WsCfg {
     static constexpr int BN = BN_, R = R_, WT = WT_;
+    static constexpr bool TALL = TALL_;
     static constexpr int NB = 4;
     static constexpr int NT = 512, NCW = 4, NLW = 4;
-    static constexpr int BM = R * WT;
+    static constexpr int BM = TALL_ ? 256 : R * WT;
+    static_assert(R * WT <= BM, "tile pixels");
     static constexpr int WAVES_M = CW_M_, WAVES_N = NCW / CW_M_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
@@ -184,6 +190,34 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             }
             auto set_fetch_tile = [&](int it, int table) {
                 const bool live = it < a.IT;
+                if constexpr (C::TALL) {
+                    // virtual row v of the tall image -> (image v / (H+1), row v % (H+1)); row H of an image is the shared
+                    // zero row.  (float reciprocal: exact for v < 2^20)
+                    const int HV = a.H + 1, VT = a.N * HV;
+                    const float inv = 1.0f / (float)HV;
+                    const int v0 = it * R + a.dhmin;
+        #pragma unroll
+                    for (int pa = 0; pa < APW; ++pa) {
+                        const int v = v0 + (int)(a_xy[pa] & 0xffffu), wi = a.dwmin + (int)(a_xy[pa] >> 16);
+                        const int n = (int)(((float)v + 0.5f) * inv);
+                        const int hh = v - n * HV;
+                        const bool ok = live && (unsigned)v < (unsigned)VT && hh < a.H && (unsigned)wi < (unsigned)a.Wi;
+                        const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
+                        a_voff[pa] = ok ? (unsigned)((n * a.Hi + hh) * a.Wi + wi) * (unsigned)a.ld_x * 2u +
+                                              (unsigned)(((lane & 7) ^ ((pix >> 1) & 7)) * 16)
+                                        : OOB;
+                    }
+                    const int t128 = (lw & 1) * 64 + lane;
+        #pragma unroll
+                    for (int rr = t128; rr < BM; rr += C::NAW * 64) {
+                        const int v = it * R + rr / WT, wo = rr % WT;
+                        const int n = (int)(((float)v + 0.5f) * inv);
+                        const int hh = v - n * HV;
+                        sPix[table * BM + rr] =
+                            (live && rr < R * WT && v < VT && hh < a.H && wo < a.W) ? (n * a.H + hh) * a.W + wo : -1;
+                    }
+                    return;
+                }
                 const int n = it / (a.HB * a.WB);
                 const int rem = it - n * (a.HB * a.WB);
                 const int hb = rem / a.WB, wb = rem - hb * a.WB;
@@ -363,20 +397,21 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
                                 for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[tn][i] + anext) ^ ((kk - 2) << 5);
                             }
+                            // one fragment read of slice +2 in each MFMA gap (issued as a block of four before the MFMAs, the
+                            // reads and their address VALU did not fit the shadow of the previous slice's last MFMA)
+                            ws_wait<NF>(fr[set_cur]);
+                            static_assert(TM * TN == NF, "one read per MFMA gap");
 #pragma unroll
-                            for (int q = 0; q < NF; ++q) FD_READ(fr[set_new][q], ad[q]);
-                            ws_wait<2 * NF>(fr[set_cur]);
-                            if (t == 0 && kk == 0 && c == 0) {
+                            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                    for (int j = 0; j < TN; ++j) FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                    for (int j = 0; j < TN; ++j) FD_MFMA(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
-                            }
+                                for (int j = 0; j < TN; ++j) {
+                                    const int q = i * TN + j;
+                                    FD_READ(fr[set_new][q], ad[q]);
+                                    if (t == 0 && kk == 0 && c == 0)
+                                        FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                    else
+                                        FD_MFMA(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                }
                         }
                         __builtin_amdgcn_s_setprio(0);
                     }
@@ -460,6 +495,10 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     a.HB = (a.H + C::R - 1) / C::R;
     a.WB = (a.W + C::WT - 1) / C::WT;
     a.IT = a.N * a.HB * a.WB;
+    if (C::TALL) {
+        if (a.W > C::WT || a.Hi != a.H || a.Wi != a.W) return -12345;
+        a.IT = (a.N * (a.H + 1) + C::R - 1) / C::R;
+    }
     a.NTL = (a.Co + C::BN - 1) / C::BN;
     a.NCH = a.Ci / 64;
     int gm = segnb_num_cus() / a.NTL;
@@ -481,7 +520,10 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         // only 200-800 of them;
         // 16 x 16 pixel tiles tie or beat 8 x 32 except for the widest data gradients.  Outputs of <= 32 channels
         // (half of every tile padding) and 7x7 images stay with fprop_s1 / the general kernel.
-        if (a.Co <= 32 || a.W <= 8) return NOT_HANDLED;
+        if (a.Co <= 32) return NOT_HANDLED;
+        // 7 x 7 images (the deepest ZF_UNET level): tall-image tiles of 36 x 7 virtual pixels -- 8 row tiles x 16 channel
+        // tiles = 128 blocks of 144 taps each beat the general kernel's 400 tiles of 64 x 64 (76 -> ~45 us for 1024 -> 1024)
+        if (a.W <= 8) return a.W == 7 && a.H == 7 ? launch_ws<WsCfg<64, 36, 7, 4, true>>(a, stream) : NOT_HANDLED;
         // 8 x 32 or 16 x 16 pixel tiles: whichever needs fewer rounds of (equal) tiles on the persistent blocks --
         // re-measured with the final kernel, the round count decides every case (e.g. 128 -> 384 @56x56: 11 vs 12
         // rounds, 104 vs 122 us; 64 -> 192 @112x112: 21 vs 19 rounds, 133 vs 116 us); ties go to 16 x 16
@@ -495,6 +537,7 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
     switch (cfg) {
         case 0: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
         case 1: return launch_ws<WsCfg<64, 16, 16, 4>>(a, stream);
+        case 2: return launch_ws<WsCfg<64, 36, 7, 4, true>>(a, stream);
         default: return NOT_HANDLED;
     }
 }

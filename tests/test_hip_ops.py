@@ -676,7 +676,8 @@ def test_conv_fprop_dma_configs(case, cfg):
 
 
 @pytest.mark.parametrize('shape', [(32, 56, 128, 128), (32, 14, 1536, 512), (32, 28, 256, 768), (16, 112, 192, 64),
-                                   (32, 224, 32, 32), (32, 224, 96, 32), (32, 112, 32, 64), (32, 112, 64, 32)],
+                                   (32, 224, 32, 32), (32, 224, 96, 32), (32, 112, 32, 64), (32, 112, 64, 32),
+                                   (32, 7, 1024, 1024), (32, 7, 512, 1024)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_fprop_dma_full_size_reproducible(shape):
     """bs=32 layer shapes of BASELINE.json configs[1]: many tiles per persistent block, tile seams, look-ahead reads in
@@ -825,3 +826,30 @@ def test_bn_bwd_apply_direct_equals_two_pass(shape, dtype):
         dy_f, s_f, _ = run('cpu', True)
     assert torch.equal(dy_e, dy_f) and torch.equal(s_e, s_f)
     check('apply_direct dy', dy_b, dy_f, dtype)
+
+
+@pytest.mark.parametrize('case', [('tall 7x7 a', 5, 7, 7, [(128, 128)], 72), ('tall 7x7 b', 9, 7, 7, [(64, 64)], 200),
+                                  ('tall 7x7 cat', 3, 7, 7, [(64, 64), (64, 64)], 64)], ids=lambda c: c[0])
+def test_conv_fprop_dma_tall_7x7(case):
+    """tall-image tiles of the 7x7 level (fprop_dma.hip, WsCfg<..., TALL>): images chained with one shared zero row;
+    ragged last tile, several channel tiles, two chunks."""
+    name, N, H, W, segs, Co = case
+    full = (name, N, H, W, segs, Co, 3, 1, 1, False)
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(13)
+    w = (torch.randn((Co, Ci, 3, 3), generator=gen) * (2.0 / (Ci * 9)) ** 0.5).bfloat16().float()
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, H, W, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=gen).bfloat16().float()
+    y_g, st_g, dx_g, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    y_g2, _, _, _, _, _ = _run_conv('cuda', 'bf16', full, w, b, x, dy)
+    with on_emulator():
+        y_e, st_e, dx_e, _, _, _ = _run_conv('cpu', 'bf16', full, w, b, x, dy)
+    check(name + ' y', y_g, y_e, 'bf16')
+    check(name + ' dx', dx_g, dx_e, 'bf16')
+    np.testing.assert_allclose(st_g.numpy(), st_e.numpy(), rtol=2e-3, atol=2e-2 * float(st_e.abs().max()))
+    assert torch.equal(y_g, y_g2)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b, padding=1)
+    yr.backward(dy)
+    check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
