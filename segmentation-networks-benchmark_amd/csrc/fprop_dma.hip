@@ -38,11 +38,13 @@
 
 namespace {
 
-// in-kernel time stamps of block 0 (timing builds, segnb_tune("fprop_dma_dbg", 32)): [role][step][4] shader clocks
+// in-kernel time stamps of block 0 (timing builds, segnb_tune("fprop_dma_dbg", 32)): [role][step][4] shader clocks.
+// The instrumented kernels are SEPARATE instantiations (template flag DBG): as run-time checks the stamp / timing-build
+// tests cost every tap of the production kernel ~100 cycles (an empty tap measured 330 cycles).
 __device__ unsigned long long g_stamps[3 * 256 * 4];
 #define FD_STAMP(role, step, k)                                                                      \
     do {                                                                                            \
-        if ((a.dbg & 32) && blockIdx.x == 0 && lane == 0 && (step) < 256)                           \
+        if (DBG && (a.dbg & 32) && blockIdx.x == 0 && lane == 0 && (step) < 256)                    \
             g_stamps[((role) * 256 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime();             \
     } while (0)
 
@@ -93,7 +95,7 @@ struct WsCfg {
     static_assert(TM + TN <= 6, "fragment wait statement");
 };
 
-template <class C>
+template <class C, bool DBG>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
     constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
                         const int cf = t + 3 < 9 ? c : cn;
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 0);
-                        if (!(a.dbg & 1)) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
+                        if (!(DBG && (a.dbg & 1))) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 1);
                         // the weights of tap t+2 (fetched during tap t-1) have landed: only this tap's fetch stays in flight
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         constexpr int t = decltype(t_c)::value;
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
                         if constexpr (t < C::A_STEPS)
-                            if (!(a.dbg & 2)) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
+                            if (!(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
                         if constexpr (t == 7)
                             if (next_last) set_fetch_tile(setup_it, setup_tab);
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(sOut + row * OUT_ROW + cc * 16);
             const bool ok = cok && opix >= 0;
             const unsigned voff = ok ? (unsigned)opix * (unsigned)a.ld_out * 2u + (unsigned)(n_base + cc * 8) * 2u : OOB;
-            if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
+            if (!(DBG && (a.dbg & 8))) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
             if (a.stats != nullptr) {
                 const float m = ok ? 1.f : 0.f;
                 float f[8];
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             }
         };
         bf16x8_t fr[3][NF];
-        if (!(a.dbg & 4)) {
+        if (!(DBG && (a.dbg & 4))) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
                     const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
-                    if (!(a.dbg & 4)) {
+                    if (!(DBG && (a.dbg & 4))) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
@@ -486,8 +488,11 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 template <class C>
 int launch_ws(FdArgs& a, hipStream_t stream) {
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }();
@@ -505,7 +510,10 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    hipLaunchKernelGGL((conv_fprop_ws_kernel<C>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    if (a.dbg)
+        hipLaunchKernelGGL((conv_fprop_ws_kernel<C, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     return 0;
 }
 

@@ -42,7 +42,7 @@ struct RwCfg {
     static_assert(W_MAX >= 9 * BN * 64, "at least one 32-channel chunk of weights");
 };
 
-template <class C>
+template <class C, bool DBG>
 __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
     constexpr int BN = C::BN, NS = C::NS, BM = C::BM, TM = C::TM, TN = C::TN, NF = C::NF, XC = C::XC, R = C::R, WT = C::WT;
     constexpr int APW = C::APW, OC = C::OC, NLW = C::NLW, LT = C::LT, OUT_ROW = C::OUT_ROW;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
             for (int pa = 0; pa < APW; ++pa) {
                 const int piece = lw + NLW * pa;
                 const unsigned dst = piece < C::APIECES ? lds0 + stage * C::A_STAGE + piece * 1024 : lds0 + C::OFF_DUMMY;
-                if (!(a.dbg & 2)) dma16(dst, a_voff[pa], rs_x, (unsigned)c * 64u);
+                if (!(DBG && (a.dbg & 2))) dma16(dst, a_voff[pa], rs_x, (unsigned)c * 64u);
             }
         };
         // fetch cursor: (tile, chunk) of the step whose halo tile is requested next
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         // descriptor's range check (a per-row `if` serialised two LDS round trips per row: ~2100 cycles per tile).
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
         auto store_pass = [&](const int* tab) {
-            if (a.dbg & 8) return;
+            if (DBG && (a.dbg & 8)) return;
             constexpr int RPT = BM / (LT / OC);
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
             const int cc = ltid % OC, row0 = ltid / OC;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
             for (int c = 0; c < a.NCH; ++c, ++g) {
                 const int sbase = (g % NS) * C::A_STAGE;
                 const int wbase = c * (9 * BN * 64);
-                if (!(a.dbg & 4)) {
+                if (!(DBG && (a.dbg & 4))) {
                     bf16x8_t fr[2][NF];
                     int bk[TN];
 #pragma unroll
@@ -340,8 +340,11 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
 template <class C>
 int launch_rw(FdArgs& a, hipStream_t stream) {
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_rw_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_rw_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_rw_kernel<C, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) segnb_set_error("fprop_rw hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }();
@@ -354,7 +357,10 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
     int gm = segnb_num_cus();
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    hipLaunchKernelGGL((conv_fprop_rw_kernel<C>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
+    if (a.dbg)       // timing builds: separately instantiated, the production kernel carries no run-time checks
+        hipLaunchKernelGGL((conv_fprop_rw_kernel<C, true>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fprop_rw_kernel<C, false>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
     return 0;
 }
 
