@@ -329,10 +329,21 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         float s1[8], s2[8];                                    // statistics of the stored values of chunk cc
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-        auto store_row = [&](int k, const int* tab) {          // staged row row0 + k * (MT / OC) of the previous tile
+        // A store row in two halves: its two LDS reads (pixel table entry, staged 16 bytes) are asm reads issued at the
+        // START of the tap, older than the tap's first fragment wait, so they cost no wait of their own (as compiler
+        // loads after the MFMAs they stalled on the look-ahead fragment reads in flight); the store and the statistics
+        // run on registers after the MFMAs.
+        int row_pix = -1;
+        u32x4_t row_v = {0, 0, 0, 0};
+        auto row_load = [&](int k, const int* tab) {           // staged row row0 + k * (MT / OC) of the previous tile
             const int row = row0 + k * (C::MT / OC);
-            const int opix = tab[row];
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(sOut + row * OUT_ROW + cc * 16);
+            const unsigned a_pix = (unsigned)(size_t)(tab + row), a_v = (unsigned)(size_t)(sOut + row * OUT_ROW + cc * 16);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(row_pix) : "v"(a_pix));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(row_v) : "v"(a_v));
+        };
+        auto row_store = [&]() {
+            const int opix = row_pix;
+            const u32x4_t v = row_v;
             const bool ok = cok && opix >= 0;
             const unsigned voff = ok ? (unsigned)opix * (unsigned)a.ld_out * 2u + (unsigned)(n_base + cc * 8) * 2u : OOB;
             if (!(DBG && (a.dbg & 8))) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
@@ -382,6 +393,9 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
                     const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
+                    constexpr bool row_tap = t >= 1 && t <= C::RPT;
+                    if constexpr (row_tap)
+                        if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
                     if (!(DBG && (a.dbg & 4))) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -418,8 +432,12 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         __builtin_amdgcn_s_setprio(0);
                     }
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
-                    if constexpr (t >= 1 && t <= C::RPT)
-                        if (drain) store_row(t - 1, sPix + ((tile_no + 3) & 3) * BM);
+                    if constexpr (row_tap)
+                        if (drain) {
+                            if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            asm volatile("" : "+v"(row_pix), "+v"(row_v));      // landed: older than the tap's fragment waits
+                            row_store();
+                        }
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
                     raw_barrier();
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
@@ -459,7 +477,11 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         lds_barrier();                                         // the last tile is staged
         if (pending) {
 #pragma unroll
-            for (int k = 0; k < C::RPT; ++k) store_row(k, sPix + ((tile_no + 3) & 3) * BM);
+            for (int k = 0; k < C::RPT; ++k) {
+                row_load(k, sPix + ((tile_no + 3) & 3) * BM);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(row_pix), "+v"(row_v));
+                row_store();
+            }
         }
         // ---- statistics: fixed-order block reduction, one fp64 atomic per channel and block ----------------------
         lds_barrier();                                         // (fetch waves: everything has landed; staging consumed)
