@@ -32,7 +32,8 @@ struct FdArgs {
     int dhmin, dwmin;
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
-    int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA, 8 no epilogue
+    int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA +
+                          // fragment reads, 8 no stores, 16 no fragment reads, 32 in-kernel stamps, 64 one stamp per tap
 };
 
 constexpr unsigned OOB = 0x80000000u;

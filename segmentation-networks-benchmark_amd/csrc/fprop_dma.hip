@@ -44,7 +44,8 @@ namespace {
 __device__ unsigned long long g_stamps[3 * 256 * 4];
 #define FD_STAMP(role, step, k)                                                                      \
     do {                                                                                            \
-        if (DBG && (a.dbg & 32) && blockIdx.x == 0 && lane == 0 && (step) < 256)                    \
+        if (DBG && ((a.dbg & 32) || ((a.dbg & 64) && (role) == 0 && (k) == 0)) && blockIdx.x == 0 && lane == 0 &&  \
+            (step) < 256)                                                                            \
             g_stamps[((role) * 256 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime();             \
     } while (0)
 
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
                                 for (int j = 0; j < TN; ++j) {
                                     const int q = i * TN + j;
-                                    FD_READ(fr[set_new][q], ad[q]);
+                                    if (!(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
                                     if (t == 0 && kk == 0 && c == 0)
                                         FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
                                     else

@@ -17,6 +17,8 @@ ap.add_argument('--ci', type=int, default=256)
 ap.add_argument('--co', type=int, default=256)
 ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--steps', type=int, default=45)
+ap.add_argument('--extra', type=int, default=0, help='extra fprop_dma_dbg bits (1 no weights, 2 no halo, 16 no fragment reads)')
+ap.add_argument('--light', action='store_true', help='one stamp per tap (matrix wave, tap start) only: 64 instead of 32')
 args = ap.parse_args()
 rt = Runtime('cuda', 'bf16')
 wt = torch.randn(args.co, args.ci, 3, 3, device='cuda') * 0.05
@@ -28,7 +30,7 @@ stats = rt.zeros((16, 2, op.Cop), torch.float64)
 for _ in range(3):
     op.fprop(xv, yv, stats)
 torch.cuda.synchronize()
-nv.call('segnb_tune', b'fprop_dma_dbg', 32)
+nv.call('segnb_tune', b'fprop_dma_dbg', (64 if args.light else 32) | args.extra)
 op.fprop(xv, yv, stats)
 torch.cuda.synchronize()
 nv.call('segnb_tune', b'fprop_dma_dbg', 0)
@@ -37,6 +39,11 @@ nv.call('segnb_debug_stamps', ctypes.cast(buf, ctypes.c_void_p))
 import numpy as np
 st = np.array(buf[:], dtype=np.uint64).reshape(3, 256, 4).astype(np.int64)
 t0 = st[0, 0, 0]
+if args.light:
+    d = np.diff(st[0, :args.steps + 1, 0])
+    print('tap lengths (cycles, matrix wave 0, one stamp per tap):', d.tolist())
+    print('median %d  mean %.0f' % (np.median(d), d.mean()))
+    sys.exit(0)
 print('tap | matrix: start  +mfma_issued +stores +barrier | weight: start +issued +landed +barrier | halo: start +issued +landed +barrier | tap length')
 for sidx in range(args.steps):
     m, w, h = st[0, sidx], st[1, sidx], st[2, sidx]
