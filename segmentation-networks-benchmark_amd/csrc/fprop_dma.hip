@@ -36,6 +36,10 @@
 
 #include "fprop_dma.h"
 
+#ifndef SEGNB_EXP
+#define SEGNB_EXP 0      // experiments on the production kernel (whole-file compile-time switches; never set in the build)
+#endif
+
 namespace {
 
 // in-kernel time stamps of block 0 (timing builds, segnb_tune("fprop_dma_dbg", 32)): [role][step][4] shader clocks.
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
                         const int cf = t + 3 < 9 ? c : cn;
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 0);
-                        if (!(DBG && (a.dbg & 1))) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
+                        if (!(SEGNB_EXP & 1) && !(DBG && (a.dbg & 1))) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 1);
                         // the weights of tap t+2 (fetched during tap t-1) have landed: only this tap's fetch stays in flight
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         constexpr int t = decltype(t_c)::value;
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
                         if constexpr (t < C::A_STEPS)
-                            if (!(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
+                            if (!(SEGNB_EXP & 2) && !(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
                         if constexpr (t == 7)
                             if (next_last) set_fetch_tile(setup_it, setup_tab);
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     constexpr bool row_tap = t >= 1 && t <= C::RPT;
                     if constexpr (row_tap)
                         if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
-                    if (!(DBG && (a.dbg & 4))) {
+                    if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
                                 for (int j = 0; j < TN; ++j) {
                                     const int q = i * TN + j;
-                                    if (!(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
+                                    if (!(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
                                     if (t == 0 && kk == 0 && c == 0)
                                         FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
                                     else

@@ -15,7 +15,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libsegnb_hip.so')
+LIB_PATH = os.environ.get('SEGNB_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libsegnb_hip.so')
 
 c_int, c_float, c_double, c_void_p, c_ll = (ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p,
                                             ctypes.c_longlong)
