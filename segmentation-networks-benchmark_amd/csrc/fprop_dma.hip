@@ -192,7 +192,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
                 const int q = lane & 7;
                 const int xr = pix / XC, xc = pix - xr * XC;
-                a_rel[pa] = (unsigned)(xr * a.Wi + xc) * (unsigned)a.ld_x * 2u + (unsigned)((q ^ ((pix >> 1) & 7)) * 16);
+                const int key = C::XC % 2 == 0 ? xc : pix;        // swizzle key (see a_rd below)
+                a_rel[pa] = (unsigned)(xr * a.Wi + xc) * (unsigned)a.ld_x * 2u + (unsigned)((q ^ ((key >> 1) & 7)) * 16);
                 a_xy[pa] = pix < C::NPIX ? (unsigned)xr | ((unsigned)xc << 16) : 0x7fff7fffu;      // never inside the image
             }
             auto set_fetch_tile = [&](int it, int table) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         const bool ok = live && (unsigned)v < (unsigned)VT && hh < a.H && (unsigned)wi < (unsigned)a.Wi;
                         const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
                         a_voff[pa] = ok ? (unsigned)((n * a.Hi + hh) * a.Wi + wi) * (unsigned)a.ld_x * 2u +
-                                              (unsigned)(((lane & 7) ^ ((pix >> 1) & 7)) * 16)
+                                              (unsigned)(((lane & 7) ^ ((pix >> 1) & 7)) * 16)      // (XC odd: key = pix)
                                         : OOB;
                     }
                     const int t128 = (lw & 1) * 64 + lane;
@@ -320,7 +321,12 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             for (int i = 0; i < TM; ++i) {
                 const int m = wm * C::WM + 32 * i + r;
                 const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
-                int v = (p << 7) + ((p & 12) << 3) + (((h ^ (p >> 1)) & 1) << 4);
+                // swizzle key: the halo COLUMN when the row pitch XC is even -- the sixteen lanes of a ds_read_b128 group then
+            // cover sixteen consecutive columns mod 16 whether they lie in one tile row (32-wide tiles) or in two (16-wide
+            // tiles: keyed by the row index p, two of sixteen lanes collide; measured neutral on the same box, kept for the
+            // cleaner bank picture)
+            const int key = XC % 2 == 0 ? p % XC : p;
+            int v = (p << 7) + ((key & 12) << 3) + (((h ^ (key >> 1)) & 1) << 4);
                 asm volatile("" : "+v"(v));
                 a_rd[t][i] = v;
             }
