@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         // the weights of tap t+2 (fetched during tap t-1) have landed: only this tap's fetch stays in flight
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 2);
-                        raw_barrier();
+                        if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 3);
                     });
                 }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         // the next chunk's halo tile is first read during tap 8 (look-ahead slices of its tap 0)
                         if constexpr (t == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 2);
-                        raw_barrier();
+                        if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 3);
                     });
                 }
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                                 for (int j = 0; j < TN; ++j) {
                                     const int q = i * TN + j;
                                     if (!(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
+                                    if ((SEGNB_EXP & 128) && i > 0) continue;      // (experiment 128: half the MFMAs -- timing only)
                                     if (t == 0 && kk == 0 && c == 0)
                                         FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
                                     else
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                             row_store();
                         }
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
-                    raw_barrier();
+                    if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
                     if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
                 });
             }
