@@ -53,6 +53,9 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                        hipStream_t stream);
+// first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
+int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
+                       void* out, double* stats, hipStream_t stream);
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
                        hipStream_t stream);
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);

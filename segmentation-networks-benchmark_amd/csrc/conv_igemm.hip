@@ -862,9 +862,10 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
         static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
-        rc = general_only ? 0
-                          : segnb_fprop_rw_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
-                                               (hipStream_t)stream);
+        rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
+        if (rc == 0 && !general_only)
+            rc = segnb_fprop_rw_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
+                                    (hipStream_t)stream);
         if (rc == 0 && !general_only)
             rc = segnb_fprop_dma_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
                                      (hipStream_t)stream);

@@ -1,0 +1,223 @@
+// Stride-1 3x3 convolution forward (bf16) for an 8-channel input -- the FIRST layer of every model here: 3 image
+// channels padded to 8 (lib/models/zf_unet.py:37 conv_224.l1, 3 -> 32).  The general gather kernel ran it at 35 TFLOP/s
+// (80 us at bs=32, 224x224) because K = 72 is less than two of its 64-deep K steps; the layer is HBM-bound (26 MB in,
+// 103 MB out), so this kernel is about bytes:
+//   * a pixel is ONE 16-byte vector (8 bf16 channels): the 18 x 18 halo tile of a 16 x 16 pixel tile is 324 coalesced
+//     16-byte loads, staged in LDS pixel-major (consecutive pixels = consecutive 16-byte slots: conflict-free reads);
+//   * K is ordered (tap, channel): one MFMA K step = two taps, and the A fragment of lane (r, h) for step s is exactly the
+//     16 bytes of pixel (row r shifted by tap 2s + h) -- one ds_read_b128, no gather; five steps cover the nine taps, the
+//     tenth half-step meets zero weights;
+//   * the 32 x 80 weight matrix lives in registers (five B fragments per lane) for the whole kernel;
+//   * persistent blocks, one tile per iteration, next tile's halo loads issued before the current tile's MFMAs;
+//     transposed accumulators, LDS-staged 16-byte stores, BatchNorm statistics by the store threads (as fprop_dma.hip).
+#include "fprop_dma.h"
+
+namespace {
+
+struct C8Args {
+    const bf16_t* x;
+    const bf16_t* w;       // [Co][9][8]
+    const float* bias;
+    int bias_n;
+    bf16_t* out;
+    double* stats;
+    int N, H, W, Hi, Wi, Co, ld_x, ld_out;
+    int dhmin, dwmin;
+    int dh[9], dw[9];
+    int HB, WB, IT;
+};
+
+constexpr int C8_R = 16, C8_WT = 16, C8_XC = 18, C8_NPIX = 18 * 18, C8_BM = 256, C8_BN = 32;
+constexpr int C8_OUT_ROW = C8_BN * 2 + 16;
+constexpr int C8_OFF_STG = ((C8_NPIX * 16 + 1023) / 1024) * 1024;          // halo tile: 5184 B
+constexpr int C8_OFF_PIX = C8_OFF_STG + C8_BM * C8_OUT_ROW;
+constexpr int C8_SMEM_TILE = C8_OFF_PIX + C8_BM * 4;                        // 27 KiB
+constexpr int C8_SMEM = C8_SMEM_TILE > 256 * 16 * 8 ? C8_SMEM_TILE : 256 * 16 * 8;   // >= the statistics reduction scratch
+
+__global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C8_SMEM];
+    int* sPix = reinterpret_cast<int*>(smem + C8_OFF_PIX);
+    unsigned char* sOut = smem + C8_OFF_STG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // weights: B fragment of K step s for lane (r, h) = channel r, tap 2s + h, 8 input channels (zeros past tap 8 / Co)
+    bf16x8_t wf[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + h;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tap < 9 && r < a.Co) v = *reinterpret_cast<const uint4*>(a.w + ((long long)r * 9 + tap) * 8);
+        wf[s] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    float4 bias4[4];                    // transposed accumulators: lane holds channels 8g + 4h .. +3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 8 * g + 4 * h + e;
+            b[e] = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
+        }
+        bias4[g] = make_float4(b[0], b[1], b[2], b[3]);
+    }
+    // A fragment LDS offsets: wave w owns tile rows 64w .. 64w+63 (two MFMA row tiles)
+    int a_off[5][2];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + h < 9 ? 2 * s + h : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = wave * 64 + 32 * i + r;
+            a_off[s][i] = ((m / C8_WT + a.dh[tap]) * C8_XC + (m % C8_WT) + a.dw[tap]) * 16;
+        }
+    }
+    // store pass: thread = (row group, 8-channel chunk); 4 chunks per pixel
+    const int cc = tid & 3, row0 = tid >> 2;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+
+    auto halo_load = [&](int it, uint4 (&hv)[2]) {
+        const int n = it / (a.HB * a.WB);
+        const int rem = it - n * (a.HB * a.WB);
+        const int hb = rem / a.WB, wb = rem - hb * a.WB;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = tid + u * 256;
+            const int xr = pix / C8_XC, xc = pix - xr * C8_XC;
+            const int hi = hb * C8_R + a.dhmin + xr, wi = wb * C8_WT + a.dwmin + xc;
+            hv[u] = make_uint4(0, 0, 0, 0);
+            if (pix < C8_NPIX && it < a.IT && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+                hv[u] = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x);
+        }
+    };
+
+    uint4 hv[2];
+    halo_load(blockIdx.x, hv);
+    for (int it = blockIdx.x; it < a.IT; it += gridDim.x) {
+        __syncthreads();                                  // previous tile's halo / staging consumed
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + u * 256 < C8_NPIX) *reinterpret_cast<uint4*>(smem + (tid + u * 256) * 16) = hv[u];
+        {
+            const int n = it / (a.HB * a.WB);
+            const int rem = it - n * (a.HB * a.WB);
+            const int hb = rem / a.WB, wb = rem - hb * a.WB;
+            const int ho = hb * C8_R + tid / C8_WT, wo = wb * C8_WT + tid % C8_WT;
+            sPix[tid] = (ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
+        }
+        halo_load(it + gridDim.x, hv);                    // next tile: in flight under this tile's work
+        __syncthreads();
+        f32x16_t acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(smem + a_off[s][i]);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], af, acc[i], 0, 0, 0);
+            }
+        // stage: lane holds pixel (64w + 32i + r), channels 8g + 4h .. +3
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 64 + 32 * i + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack2bf(acc[i][4 * g + 0] + bias4[g].x, acc[i][4 * g + 1] + bias4[g].y);
+                pk.y = pack2bf(acc[i][4 * g + 2] + bias4[g].z, acc[i][4 * g + 3] + bias4[g].w);
+                *reinterpret_cast<uint2*>(sOut + row * C8_OUT_ROW + (8 * g + 4 * h) * 2) = pk;
+            }
+        }
+        __syncthreads();
+        // coalesced stores: 4 threads per pixel, 64 pixels per pass
+        int opix[4];
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) opix[k] = sPix[row0 + 64 * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(sOut + (row0 + 64 * k) * C8_OUT_ROW + cc * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = opix[k] >= 0 && cc * 8 < a.Co;
+            if (ok) *reinterpret_cast<uint4*>(a.out + (long long)opix[k] * a.ld_out + cc * 8) = v[k];
+            if (a.stats != nullptr) {
+                const float m = ok ? 1.f : 0.f;
+                float f[8];
+                f[0] = __uint_as_float(v[k].x << 16); f[1] = __uint_as_float(v[k].x & 0xffff0000u);
+                f[2] = __uint_as_float(v[k].y << 16); f[3] = __uint_as_float(v[k].y & 0xffff0000u);
+                f[4] = __uint_as_float(v[k].z << 16); f[5] = __uint_as_float(v[k].z & 0xffff0000u);
+                f[6] = __uint_as_float(v[k].w << 16); f[7] = __uint_as_float(v[k].w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float fm = f[e] * m;
+                    s1[e] += fm;
+                    s2[e] += fm * fm;
+                }
+            }
+        }
+    }
+    // statistics: fixed-order block reduction, one fp64 atomic per channel and block
+    if (a.stats != nullptr) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);        // [256][16] = 32 KiB
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid * 16 + e] = (double)s1[e];
+            red[tid * 16 + 8 + e] = (double)s2[e];
+        }
+        __syncthreads();
+        if (tid < 2 * C8_BN) {
+            const int which = tid / C8_BN, col = tid - which * C8_BN;
+            const int c8 = col >> 3, e = col & 7;
+            double sum = 0.0;
+            for (int k = 0; k < 64; ++k) sum += red[(k * 4 + c8) * 16 + which * 8 + e];
+            if (col < a.Co)
+                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + col], sum);
+        }
+    }
+}
+static_assert(256 * 16 * 8 <= C8_SMEM, "statistics reduction scratch");
+
+}  // namespace
+
+// 1 = handled, 0 = not applicable, else error
+int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
+                       void* out, double* stats, hipStream_t stream) {
+    if (!segnb_knob_fprop_dma()) return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 8 || g->Co > 32 || g->Wo < 12) return 0;
+    int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
+    for (int t = 1; t < 9; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dhmax = g->dh[t] > dhmax ? g->dh[t] : dhmax;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+        dwmax = g->dw[t] > dwmax ? g->dw[t] : dwmax;
+    }
+    if (dhmax - dhmin != 2 || dwmax - dwmin != 2) return 0;
+    C8Args a;
+    a.x = (const bf16_t*)in;
+    a.w = (const bf16_t*)wpacked;
+    a.bias = bias;
+    a.bias_n = bias_n;
+    a.out = (bf16_t*)out;
+    a.stats = stats;
+    a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Hi = g->Hi; a.Wi = g->Wi;
+    a.Co = g->Co; a.ld_x = g->ld_in; a.ld_out = g->ld_out;
+    a.dhmin = dhmin; a.dwmin = dwmin;
+    for (int t = 0; t < 9; ++t) {
+        a.dh[t] = g->dh[t] - dhmin;
+        a.dw[t] = g->dw[t] - dwmin;
+    }
+    a.HB = (a.H + C8_R - 1) / C8_R;
+    a.WB = (a.W + C8_WT - 1) / C8_WT;
+    a.IT = a.N * a.HB * a.WB;
+    int grid = segnb_num_cus() * 4;          // 32 KiB of LDS per block: four blocks per CU hide each other's latencies
+    if (grid > a.IT) grid = a.IT;
+    hipLaunchKernelGGL(conv_fprop_c8_kernel, dim3(grid), dim3(256), 0, stream, a);
+    return 1;
+}

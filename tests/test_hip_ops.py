@@ -677,7 +677,7 @@ def test_conv_fprop_dma_configs(case, cfg):
 
 @pytest.mark.parametrize('shape', [(32, 56, 128, 128), (32, 14, 1536, 512), (32, 28, 256, 768), (16, 112, 192, 64),
                                    (32, 224, 32, 32), (32, 224, 96, 32), (32, 112, 32, 64), (32, 112, 64, 32),
-                                   (32, 7, 1024, 1024), (32, 7, 512, 1024)],
+                                   (32, 7, 1024, 1024), (32, 7, 512, 1024), (32, 224, 8, 32), (5, 37, 8, 24)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_fprop_dma_full_size_reproducible(shape):
     """bs=32 layer shapes of BASELINE.json configs[1]: many tiles per persistent block, tile seams, look-ahead reads in
