@@ -204,7 +204,7 @@ def main():
         n, tot_ms, tot_fl = summ[dom]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         fams = {'conv_fprop': 'segnb_conv_fprop launches: conv_fprop_ws_kernel / conv_fprop_rw_kernel / '
-                              'conv_fprop_s1x9_kernel / conv_fprop_kernel (forward + data gradient)',
+                              'conv_fprop_c8_kernel / conv_fprop_s1x9_kernel / conv_fprop_kernel (forward + data gradient)',
                 'conv_wgrad': 'segnb_conv_wgrad launches: conv_wgrad_s1x9_kernel / conv_wgrad_kernel'}
         out['roofline'] = {'kernel': fams.get(dom, dom), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
