@@ -200,7 +200,10 @@ def main():
     }
     if timer is not None:
         summ = timer.summary()
-        dom = max(summ, key=lambda k: summ[k][1])
+        # dominant family = the one that carries most of the step's algorithmic FLOPs (forward + data gradient: 2/3).
+        # By stretched in-situ time the two families tie and the choice would flip from run to run: the weight
+        # gradients run on a second stream BESIDE the dependent chain, so their launch durations include the overlap.
+        dom = max(summ, key=lambda k: summ[k][2])
         n, tot_ms, tot_fl = summ[dom]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         fams = {'conv_fprop': 'segnb_conv_fprop launches: conv_fprop_ws_kernel / conv_fprop_rw_kernel / '
