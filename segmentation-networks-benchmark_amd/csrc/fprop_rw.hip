@@ -27,7 +27,9 @@ struct RwCfg {
     static constexpr int APW = (APIECES + NLW - 1) / NLW;
     static constexpr int OUT_ROW = BN * 2 + 16;
     static constexpr int OC = BN / 8;
-    static_assert(LT % OC == 0 && LT >= 2 * BN, "store-pass thread keeps one channel chunk (statistics)");
+    static constexpr int RG = LT / OC;                   // store threads: OC chunks x RG row groups (RG * OC <= LT active)
+    static constexpr int RPT = (BM + RG - 1) / RG;       // staged rows per store thread
+    static constexpr bool STATS_OK = LT >= 2 * BN;       // the final statistics reduction needs 2 * BN threads
     // LDS: [halo ring NS stages][output staging: whole tile][pixel tables x2][bias][dummy piece][weights ...]
     static constexpr int OFF_STG = NS * A_STAGE;
     static constexpr int STG_BYTES = BM * OUT_ROW;
@@ -162,34 +164,41 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
         auto store_pass = [&](const int* tab) {
             if (DBG && (a.dbg & 8)) return;
-            constexpr int RPT = BM / (LT / OC);
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
             const int cc = ltid % OC, row0 = ltid / OC;
-            const bool cok = cc * 8 < a.Co;
-            int opix[RPT];
-            u32x4_t v[RPT];
+            const bool cok = cc * 8 < a.Co && row0 < C::RG;      // (12 chunks per row: 120 of the 128 threads)
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) opix[k] = tab[row0 + k * (LT / OC)];
+            for (int base = 0; base < C::RPT; base += 8) {
+                int opix[8];
+                u32x4_t v[8];
 #pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                v[k] = *reinterpret_cast<const u32x4_t*>(sOut + (row0 + k * (LT / OC)) * OUT_ROW + cc * 16);
+                for (int k = 0; k < 8; ++k) {
+                    const int row = row0 + (base + k) * C::RG;
+                    opix[k] = (base + k < C::RPT && row < BM) ? tab[row] : -1;
+                }
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const bool ok = cok && opix[k] >= 0;
-                const unsigned voff = ok ? (unsigned)opix[k] * (unsigned)a.ld_out * 2u + (unsigned)cc * 16u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(v[k], rs_out, (int)voff, 0, 0);
-                if (a.stats != nullptr) {
-                    const float m = ok ? 1.f : 0.f;
-                    float f[8];
-                    f[0] = __uint_as_float(v[k].x << 16); f[1] = __uint_as_float(v[k].x & 0xffff0000u);
-                    f[2] = __uint_as_float(v[k].y << 16); f[3] = __uint_as_float(v[k].y & 0xffff0000u);
-                    f[4] = __uint_as_float(v[k].z << 16); f[5] = __uint_as_float(v[k].z & 0xffff0000u);
-                    f[6] = __uint_as_float(v[k].w << 16); f[7] = __uint_as_float(v[k].w & 0xffff0000u);
+                for (int k = 0; k < 8; ++k) {
+                    const int row = row0 + (base + k) * C::RG;
+                    v[k] = *reinterpret_cast<const u32x4_t*>(sOut + (row < BM ? row : 0) * OUT_ROW + cc * 16);
+                }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float fm = f[e] * m;
-                        s1[e] += fm;
-                        s2[e] += fm * fm;
+                for (int k = 0; k < 8; ++k) {
+                    const bool ok = cok && opix[k] >= 0;
+                    const unsigned voff = ok ? (unsigned)opix[k] * (unsigned)a.ld_out * 2u + (unsigned)cc * 16u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v[k], rs_out, (int)voff, 0, 0);
+                    if (C::STATS_OK && a.stats != nullptr) {
+                        const float m = ok ? 1.f : 0.f;
+                        float f[8];
+                        f[0] = __uint_as_float(v[k].x << 16); f[1] = __uint_as_float(v[k].x & 0xffff0000u);
+                        f[2] = __uint_as_float(v[k].y << 16); f[3] = __uint_as_float(v[k].y & 0xffff0000u);
+                        f[4] = __uint_as_float(v[k].z << 16); f[5] = __uint_as_float(v[k].z & 0xffff0000u);
+                        f[6] = __uint_as_float(v[k].w << 16); f[7] = __uint_as_float(v[k].w & 0xffff0000u);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float fm = f[e] * m;
+                            s1[e] += fm;
+                            s2[e] += fm * fm;
+                        }
                     }
                 }
             }
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         }
         if (pending) store_pass(sPix + (par ^ 1) * BM);
         lds_barrier();
-        if (a.stats != nullptr) {
+        if (C::STATS_OK && a.stats != nullptr) {
             double* red = reinterpret_cast<double*>(smem);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -227,12 +236,12 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         }
         lds_barrier();
         {
-            if (a.stats != nullptr && ltid < 2 * BN) {
+            if (C::STATS_OK && a.stats != nullptr && ltid < 2 * BN) {
                 const double* red = reinterpret_cast<const double*>(smem);
                 const int which = ltid / BN, col = ltid - which * BN;
                 const int cc = col >> 3, e = col & 7;
                 double s = 0.0;
-                for (int k = 0; k < LT / OC; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
+                for (int k = 0; k < C::RG; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
                 if (col < a.Co)
                     atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + col], s);
             }
@@ -406,13 +415,16 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     int rc;
-    // ring depth by what the resident weights leave of the 160 KiB; 96-channel outputs (the data gradient of the
-    // 96 -> 32 concat layer) do not fit beside their staging buffer and stay with fprop_s1
+    // ring depth by what the resident weights leave of the 160 KiB.  96-channel outputs (the data gradient of the
+    // 96 -> 32 concat layer: 53 KiB of staging beside 55 KiB of weights) run on a two-stage ring and without the
+    // BatchNorm statistics (twelve chunks per row do not divide the store threads; a data gradient has none)
     if (g->Co <= 32)
         rc = a.NCH == 1 ? launch_rw<RwCfg<32, 5>>(a, stream)
              : a.NCH == 2 ? launch_rw<RwCfg<32, 4>>(a, stream) : launch_rw<RwCfg<32, 3>>(a, stream);
     else if (g->Co <= 64)
         rc = launch_rw<RwCfg<64, 3>>(a, stream);
+    else if (stats == nullptr)
+        rc = launch_rw<RwCfg<96, 2>>(a, stream);
     else
         return 0;
     if (rc == -12345) return 0;
