@@ -624,28 +624,44 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
         sb[e] = 0.f;
     }
     const long long npix = (long long)s.N * s.H * s.W;
-    if (active)
-        for (long long pix = (long long)blockIdx.x * s.PY + ty; pix < npix; pix += (long long)gridDim.x * s.PY) {
-            float yv[8], d[8];
-            load8(y + pix * ld_y + c0, yv);
-            if (g != nullptr) {
-                // dz was never written: recompute it from the incoming gradient exactly as the reduce pass did
-                // (same expression, same rounding to the storage type)
-                load8(g + pix * ld_g + c0, d);
+    if (active) {
+        // four pixels per trip, all eight loads issued before the first use (one pixel per trip = one dependent
+        // round trip per wave in flight: beside the weight-gradient stream the pass ran at a third of its stand-alone rate)
+        const long long stride = (long long)gridDim.x * s.PY;
+        for (long long pix0 = (long long)blockIdx.x * s.PY + ty; pix0 < npix; pix0 += 4 * stride) {
+            float yv[4][8], d[4][8];
+            bool ok[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    d[e] = round_as(d[e] * 1.f * act_grad((yv[e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope), dy);
-            } else {
-                load8(dz + pix * ld_dz + c0, d);
+            for (int u = 0; u < 4; ++u) {
+                const long long pix = pix0 + u * stride;
+                ok[u] = pix < npix;
+                const long long pc = ok[u] ? pix : pix0;
+                load8(y + pc * ld_y + c0, yv[u]);
+                if (g != nullptr)
+                    load8(g + pc * ld_g + c0, d[u]);
+                else
+                    load8(dz + pc * ld_dz + c0, d[u]);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float yh = (yv[e] - mu[e]) * is[e];
-                d[e] = round_as(a[e] * (d[e] - c1[e] - yh * c2[e]), dy);
-                sb[e] += d[e];
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                if (g != nullptr) {
+                    // dz was never written: recompute it from the incoming gradient exactly as the reduce pass did
+                    // (same expression, same rounding to the storage type)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        d[u][e] = round_as(d[u][e] * 1.f * act_grad((yv[u][e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope), dy);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float yh = (yv[u][e] - mu[e]) * is[e];
+                    d[u][e] = round_as(a[e] * (d[u][e] - c1[e] - yh * c2[e]), dy);
+                    sb[e] += d[u][e];
+                }
+                store8(dy + (pix0 + u * stride) * ld_dy + c0, d[u]);
             }
-            store8(dy + pix * ld_dy + c0, d);
         }
+    }
     if (dbias != nullptr) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(&sred[tx * 8 + e], sb[e]);
