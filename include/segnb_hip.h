@@ -226,6 +226,13 @@ int segnb_bn_bwd_apply_direct(int dtype, const void* y, int ld_y, int N, int H, 
                               const float* coef, const float* bcoef, int act, float slope, const void* g, int ld_g,
                               void* dy, int ld_dy, float* dbias, int C, segnb_stream_t stream);
 
+/* segnb_bn_bwd_apply_fused with dz recomputed from g as in segnb_bn_bwd_apply_direct (finalize + apply in one launch, dz
+ * never in memory). */
+int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                    const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                    float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
+                                    float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
+
 /* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a */
 int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,
               int H, int W, int Cp, segnb_stream_t stream);

@@ -380,6 +380,17 @@ class AbiEmulator(object):
         return rc or self.segnb_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, None, C,
                                              stream)
 
+    def segnb_bn_bwd_apply_fused_direct(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                        accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream):
+        keep = _mem(sums, REPL * 2 * Cp, torch.float64).clone()
+        rc = self.segnb_bn_bwd_finalize(sums, C, Cp, float(N * H * W), gamma, coef, bcoef, dgamma, dbeta, accumulate,
+                                        stream)
+        _mem(sums, REPL * 2 * Cp, torch.float64).copy_(keep)
+        if clear_stats is not None:
+            _mem(clear_stats, REPL * 2 * Cp, torch.float64).zero_()
+        return rc or self.segnb_bn_bwd_apply_direct(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy,
+                                                    ld_dy, None, C, stream)
+
     # ------------------------------------------------------------------------------------------ tiles
     @staticmethod
     def _d4(k, t):

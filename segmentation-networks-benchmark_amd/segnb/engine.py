@@ -414,7 +414,9 @@ class Stage(object):
         # BatchNorm finalize folded into the activation / apply passes (segnb_bn_fwd_fused / _bwd_apply_fused): saves
         # two 5 us launches per layer, but every block of the big kernel then starts with the same dependent
         # statistics loads -- measured neutral on MI355X (7.47 vs 7.39 ms/step), so off by default
-        self.fuse_finalize = False
+        # finalize folded into the activation / apply passes: 44 launches of ~5 us less on the dependent chain
+        # (re-measured after the convolutions got faster: 5.71 -> 5.58 ms/step; neutral when first tried)
+        self.fuse_finalize = os.environ.get('SEGNB_FUSE_FINALIZE', '1') != '0'
         self._stats_stale = False
         self._fused_fwd = False
         Cp = conv.Cop
@@ -482,14 +484,20 @@ class Stage(object):
         coef = self.coef if has_bn else None
         # A single direct gradient source, no dropout: dz never goes to memory -- the reduce pass only sums, the apply
         # pass recomputes dz from g (segnb_bn_bwd_apply_direct): one tensor write less per such layer.
-        direct = (self.direct_apply and has_bn and not self._fused_fwd and g_direct is not None and g_pool is None
-                  and g_up is None and dropmul is None)
+        direct = (self.direct_apply and has_bn and g_direct is not None and g_pool is None and g_up is None
+                  and dropmul is None)
         nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                 self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
                 vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
-        if has_bn and self._fused_fwd:
+        if has_bn and self._fused_fwd and direct:
+            nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
+                    nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
+                    nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,
+                    nv.ptr(self.stats), self.act, self.slope, g_direct.ptr, g_direct.ld, dz.ptr, dz.ld, rt.stream)
+            self._stats_stale = False
+        elif has_bn and self._fused_fwd:
             nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,

@@ -104,7 +104,7 @@ def run_step(model, x, y, loss_fn, device, dtype):
 def replay(make_model, x, y, loss_fn, dtype, device='cuda',
            flip_ops=('segnb_bn_act_fwd', 'segnb_bn_act_bwd_reduce', 'segnb_bn_bwd_apply', 'segnb_bn_bwd_apply_direct',
                      'segnb_bn_bwd_finalize',
-                     'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused')):
+                     'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused', 'segnb_bn_bwd_apply_fused_direct')):
     """Returns (number of calls, list of failure strings).  device='cpu' replays the emulator against itself (a
     self-test of this harness that runs without a GPU)."""
     rec = _Recorder()
