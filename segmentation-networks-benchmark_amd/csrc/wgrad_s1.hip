@@ -49,7 +49,22 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
                  : "v"(addr), "n"(off0), "n"(off1))
 #define SEGNB_MFMA(acc, af, bf) \
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(bf))
+// specialised blocks run two waves per SIMD = 256 registers per wave: accumulators in ordinary VGPRs there (with "a" the
+// allocator's VGPR/AGPR split of the halved budget shuttled them through v_accvgpr moves and scratch)
+#define SEGNB_MFMA_V(acc, af, bf) \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "v"(bf))
 #define SEGNB_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n))
+
+#ifndef SEGNB_WG_TS
+#define SEGNB_WG_TS 1
+#endif
+#ifndef SEGNB_WG_WS_DB
+#define SEGNB_WG_WS_DB 0     // specialised blocks: 1 = two tile buffers (one barrier per iteration; same speed alone, but the
+                            // 128 KB block keeps other kernels off the CU: +0.8 % step time beside the main stream)
+#endif
+#ifndef SEGNB_WG_EXP
+#define SEGNB_WG_EXP 0       // timing experiments (wrong results): 1 = no global loads after the first tile, 2 = no MFMA loop
+#endif
 
 struct WgS1Args {
     const bf16_t* x;
@@ -81,10 +96,11 @@ __device__ __forceinline__ void wg_tap(f32x16_t (&acc)[9], const bf16x4_t (&fa)[
 // slab S0 of SPW: request A of slab S0+1, then the nine taps.  Reads still allowed in flight when B_t of the
 // current slab is needed = everything issued after it = 2*(8-t) [rest of this slab] + 2 [next A] + 2*t [next
 // B_0..t-1] = 18 -> the 4-bit counter clamps it to 15; on the last slab 2*(8-t).
-template <int S0, int SPW, int KSPLIT, int SEGS, int WT, int XC, int SX, int SY>
+template <int S0, int SPW, int KSPLIT, int SEGS, int WT, int XC, int SX, int SY, int MID, typename F>
 __device__ __forceinline__ void wg_slabs(f32x16_t (&acc)[9], bf16x4_t (&fa)[2][2], bf16x4_t (&fb)[2][9][2],
-                                         unsigned va, const unsigned (&vb)[9]) {
+                                         unsigned va, const unsigned (&vb)[9], F& mid) {
     if constexpr (S0 < SPW) {
+        if constexpr (S0 == MID) mid();          // double-buffered tiles: the next iteration's LDS stores go here
         constexpr int cur = S0 & 1, nxt = cur ^ 1;
         constexpr bool more = S0 + 1 < SPW;
         constexpr int sn = (S0 + 1) * KSPLIT;
@@ -100,8 +116,93 @@ __device__ __forceinline__ void wg_slabs(f32x16_t (&acc)[9], bf16x4_t (&fa)[2][2
         wg_tap<6, more ? 15 : 4, more, ob, SX>(acc, fa[cur], fb[cur], fb[nxt], vb);
         wg_tap<7, more ? 15 : 2, more, ob, SX>(acc, fa[cur], fb[cur], fb[nxt], vb);
         wg_tap<8, more ? 15 : 0, more, ob, SX>(acc, fa[cur], fb[cur], fb[nxt], vb);
-        wg_slabs<S0 + 1, SPW, KSPLIT, SEGS, WT, XC, SX, SY>(acc, fa, fb, va, vb);
+        wg_slabs<S0 + 1, SPW, KSPLIT, SEGS, WT, XC, SX, SY, MID>(acc, fa, fb, va, vb, mid);
     }
+}
+
+// ---- tap-split wave tiles (64x64 block tiles) ------------------------------------------------------------------
+// With wave (i, j) owning sub-tile (32 co, 32 ci) for all nine taps, a 16-pixel slab costs 1 A + 9 B fragments per
+// 9 MFMAs: 4 waves x 20 ds_read_b64_tr_b16 x 512 B = 40 KB of LDS reads per 288 matrix-pipe cycles -- the loop ran
+// at the LDS's ~100 B/clk, not at the MFMA rate (measured 30 ns per MFMA against 21 ns in the forward kernel).
+// Here wave (G, j) owns ALL 64 co x 32 ci for half of the taps instead: nine (co half c, tap) units
+//     G = 0: (0,t0) (1,t0) (0,t1) (1,t1) (0,t2) (1,t2) (0,t3) (1,t3) (0,t4)
+//     G = 1: (1,t4) (0,t5) (1,t5) (0,t6) (1,t6) (0,t7) (1,t7) (0,t8) (1,t8)
+// = 2 A + 5 B fragments per 9 MFMAs (28 KB per slab round), still 9 x 16 accumulators and 9 MFMAs per wave.
+// unit u -> co half (u+G)&1, local tap b = (u+G)>>1 (tap 4G + b).  Fragments are requested in first-use order
+// F0..F6 = A_G, B0, A_(1-G), B1, B2, B3, B4: fragment Fj of the NEXT slab right after MFMA j of the current one.
+constexpr int ts_c(int G, int u) { return (u + G) & 1; }
+constexpr int ts_b(int G, int u) { return (u + G) >> 1; }
+constexpr int ts_fa(int G, int c) { return c == G ? 0 : 2; }
+constexpr int ts_fb(int b) { return b == 0 ? 1 : b + 2; }
+constexpr int ts_k(int G, int u) {
+    const int ka = ts_fa(G, ts_c(G, u)), kb = ts_fb(ts_b(G, u));
+    return ka > kb ? ka : kb;
+}
+// reads still allowed in flight when unit u issues: the fragments requested after the last one it needs (rest of the
+// previous slab's requests) plus the next slab's requests made so far in this slab (LDS returns in order)
+constexpr int ts_wait(int G, int u, bool more) {
+    const int w = (6 - ts_k(G, u)) * 2 + (more ? 2 * (u < 7 ? u : 7) : 0);
+    return w > 15 ? 15 : w;
+}
+
+template <int G, int J, int OA, int OB, int SX, int SY>
+__device__ __forceinline__ void ts_request(bf16x4_t (&fan)[2][2], bf16x4_t (&fbn)[5][2], unsigned va,
+                                           const unsigned (&vb)[5]) {
+    if constexpr (J == 0) {
+        SEGNB_TR_READ2(fan[G][0], fan[G][1], va, OA + 64 * G, OA + 64 * G + 4 * SY);
+    } else if constexpr (J == 2) {
+        SEGNB_TR_READ2(fan[1 - G][0], fan[1 - G][1], va, OA + 64 * (1 - G), OA + 64 * (1 - G) + 4 * SY);
+    } else {
+        constexpr int B = J == 1 ? 0 : J - 2;
+        SEGNB_TR_READ2(fbn[B][0], fbn[B][1], vb[B], OB, OB + 4 * SX);
+    }
+}
+
+template <int G, int U, bool MORE, int OA, int OB, int SX, int SY>
+__device__ __forceinline__ void ts_units(f32x16_t (&acc)[9], bf16x4_t (&fac)[2][2], bf16x4_t (&fbc)[5][2],
+                                         bf16x4_t (&fan)[2][2], bf16x4_t (&fbn)[5][2], unsigned va,
+                                         const unsigned (&vb)[5]) {
+    if constexpr (U < 9) {
+        constexpr int C = ts_c(G, U), B = ts_b(G, U);
+        SEGNB_WAIT_LGKM(ts_wait(G, U, MORE));
+        const bf16x8_t af = __builtin_shufflevector(fac[C][0], fac[C][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8_t bf = __builtin_shufflevector(fbc[B][0], fbc[B][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        SEGNB_MFMA_V(acc[U], af, bf);
+        if constexpr (MORE && U < 7) ts_request<G, U, OA, OB, SX, SY>(fan, fbn, va, vb);
+        ts_units<G, U + 1, MORE, OA, OB, SX, SY>(acc, fac, fbc, fan, fbn, va, vb);
+    }
+}
+
+template <int G, int J, int SX, int SY>
+__device__ __forceinline__ void ts_first(bf16x4_t (&fa0)[2][2], bf16x4_t (&fb0)[5][2], unsigned va,
+                                         const unsigned (&vb)[5]) {
+    if constexpr (J < 7) {
+        ts_request<G, J, 0, 0, SX, SY>(fa0, fb0, va, vb);
+        ts_first<G, J + 1, SX, SY>(fa0, fb0, va, vb);
+    }
+}
+
+template <int G, int S0, int SPW, int SEGS, int WT, int XC, int SX, int SY, int MID, typename F>
+__device__ __forceinline__ void ts_slabs(f32x16_t (&acc)[9], bf16x4_t (&fa)[2][2][2], bf16x4_t (&fb)[2][5][2],
+                                         unsigned va, const unsigned (&vb)[5], F& mid) {
+    if constexpr (S0 < SPW) {
+        if constexpr (S0 == MID) mid();
+        constexpr int cur = S0 & 1, nxt = cur ^ 1;
+        constexpr bool more = S0 + 1 < SPW;
+        constexpr int sn = S0 + 1;
+        constexpr int oa = ((sn / SEGS) * WT + (sn % SEGS) * 16) * SY;
+        constexpr int ob = ((sn / SEGS) * XC + (sn % SEGS) * 16) * SX;
+        ts_units<G, 0, more, oa, ob, SX, SY>(acc, fa[cur], fb[cur], fa[nxt], fb[nxt], va, vb);
+        ts_slabs<G, S0 + 1, SPW, SEGS, WT, XC, SX, SY, MID>(acc, fa, fb, va, vb, mid);
+    }
+}
+
+// one iteration's slab loop of a tap-split wave (prologue requests + SPW slabs)
+template <int G, int SPW, int SEGS, int WT, int XC, int SX, int SY, int MID, typename F>
+__device__ __forceinline__ void ts_iteration(f32x16_t (&acc)[9], unsigned va, const unsigned (&vb)[5], F& mid) {
+    bf16x4_t fa[2][2][2], fb[2][5][2];
+    ts_first<G, 0, SX, SY>(fa[0], fb[0], va, vb);
+    ts_slabs<G, 0, SPW, SEGS, WT, XC, SX, SY, MID>(acc, fa, fb, va, vb, mid);
 }
 
 template <int T, int SXB>
@@ -111,6 +212,8 @@ __device__ __forceinline__ void wg_first(bf16x4_t (&fb0)[9][2], const unsigned (
         wg_first<T + 1, SXB>(fb0, vb);
     }
 }
+
+constexpr bool wg_double_buffered(int tile_bytes) { return 2 * tile_bytes <= 160 * 1024; }
 
 constexpr int lds_stride(int channels) {
     // bytes; multiple of 16, >= 2*channels, == 64 or 192 (mod 256)
@@ -135,8 +238,20 @@ struct WgTile {
     static constexpr int YSTEP = FLAT ? PD : WT, XSTEP = FLAT ? XT : WT + 2;    // positions between those rows
 };
 
+// 64x64 tiles whose two buffers fit run WAVE-SPECIALISED: 4 matrix waves (tap-split units) + 4 fetch waves that stage the
+// next tile (global -> registers -> other LDS buffer).  With one wave per SIMD doing both, every staging instruction
+// (~300 VALU/VMEM/DS per iteration, mostly address arithmetic) sat between two MFMAs of an in-order wave: measured
+// 2.1 us per iteration = 1.5 us of MFMAs + 0.6 us of staging, whatever the prefetch distance or LDS read count.
+template <int BCO, int BCI, int R, int WT, bool FLAT>
+constexpr bool wg_specialised() {
+    using TL = WgTile<R, WT, FLAT>;
+    return SEGNB_WG_TS && BCO == 64 && BCI == 64 && !FLAT &&
+           wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO));
+}
+
 template <int BCO, int BCI, int R, int WT, bool FLAT = false>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args a) {
+__global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), 1) void conv_wgrad_s1x9_kernel(
+    const WgS1Args a) {
     using TL = WgTile<R, WT, FLAT>;
     constexpr int TCO = BCO / 32, TCI = BCI / 32;
     constexpr int NSUB = TCO * TCI;
@@ -150,11 +265,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
     constexpr int YCH = TL::YROWS * (BCO / 8);
     constexpr int XPT = (XCH + 255) / 256, YPT = (YCH + 255) / 256;
 
+    // two tile buffers when they fit (every non-FLAT shape): the LDS stores of iteration it+1 are issued in the middle
+    // of iteration it's slab loop, under its MFMAs, and one barrier per iteration separates the buffers' roles
+    // (single buffer: MFMA drain -> barrier -> stores -> barrier -> first fragment reads, all exposed, every iteration)
+    constexpr int BUF = TL::XROWS * SX + TL::YROWS * SY;
+    constexpr bool DB = wg_double_buffered(BUF) && wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB;
+
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sY = smem + TL::XROWS * SX;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr bool TS = wg_specialised<BCO, BCI, R, WT, FLAT>();
+    constexpr int NT = TS ? 512 : 256;
+    const bool fetcher = TS && threadIdx.x >= 256;                 // waves 4..7 of a specialised block
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     // blocks b, b+8, ... share an XCD (round-robin dispatch) and so an L2: give each XCD a contiguous range of
     // logical blocks, so that all (co, ci) tiles of one pixel range fetch their x / dy tiles through ONE L2
     // (without it every tile pair re-read both tensors from HBM: 249 MB per launch measured)
@@ -175,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
     // measured as the floor of the atomic version), no zeroing; segnb_unpack_wgrad sums the slabs.
     float* __restrict__ slab = a.dwp + (long long)split * a.slab_stride;
     if (it_begin >= it_end) {                       // more slabs than pixel ranges (tiny inputs): zero piece
-        for (int i = tid; i < BCO * 9 * BCI; i += 256) {
+        for (int i = threadIdx.x; i < BCO * 9 * BCI; i += NT) {
             const int ci = ci0 + i % BCI, t = (i / BCI) % 9, co = co0 + i / (9 * BCI);
             if (co < a.Co && ci < a.Ci) slab[(long long)co * a.Ktot + t * a.Ci + ci] = 0.f;
         }
@@ -242,13 +366,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
             ry[u] = v;
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int bo) {
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int c = tid + u * 256;
             if (c < XCH) {
                 const int pix = c / (BCI / 8), cc = c - pix * (BCI / 8);
-                *reinterpret_cast<uint4*>(sX + pix * SX + cc * 16) = rx[u];
+                *reinterpret_cast<uint4*>(sX + bo + pix * SX + cc * 16) = rx[u];
             }
         }
 #pragma unroll
@@ -256,15 +380,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
             const int c = tid + u * 256;
             if (c < YCH) {
                 const int pix = c / (BCO / 8), cc = c - pix * (BCO / 8);
-                *reinterpret_cast<uint4*>(sY + pix * SY + cc * 16) = ry[u];
+                *reinterpret_cast<uint4*>(sY + bo + pix * SY + cc * 16) = ry[u];
             }
         }
     };
 
     // fragment addressing: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies the address of
     // pixel row q, channels 4p..4p+3 and receives channel (l&15) of the 4 rows (probe: tools/probe_tr.hip)
-    const int sub = wave / KSPLIT, kpart = wave - sub * KSPLIT;
-    const int sco = sub / TCI, sci = sub - sco * TCI;
+    // TS (64x64 tiles): wave -> (tap group tg, ci half); otherwise wave -> (32x32 sub-tile, K part)
+    const int tg = TS ? __builtin_amdgcn_readfirstlane(wave >> 1) : 0;
+    const int sub = TS ? 0 : wave / KSPLIT, kpart = TS ? 0 : wave - sub * KSPLIT;
+    const int sco = TS ? 0 : sub / TCI, sci = TS ? (wave & 1) : sub - sco * TCI;
     const int q = (lane & 15) >> 2, p = lane & 3, h = lane >> 5, cbase = 16 * ((lane >> 4) & 1);
     const int a_off = (8 * h + q) * SY + (sco * 32 + cbase + 4 * p) * 2;
     const int b_off = (8 * h + q) * SX + (sci * 32 + cbase + 4 * p) * 2;
@@ -272,19 +398,56 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
 #pragma unroll
     for (int t = 0; t < 9; ++t) tap_off[t] = (a.dh[t] * XC + a.dw[t]) * SX;
 
+    if constexpr (TS) {
+        if (fetcher) {
+            // fetch waves: tile it+1 -> registers -> the buffer the matrix waves are not reading; same barrier sequence
+            gload(it_begin);
+            lstore(0);
+            __syncthreads();
+            int cur = 0;
+            for (int it = it_begin; it < it_end; ++it) {
+                if constexpr (DB) {
+                    if (it + 1 < it_end) {
+#if !(SEGNB_WG_EXP & 1)
+                        gload(it + 1);
+#endif
+                        lstore((cur ^ 1) * BUF);
+                    }
+                    __syncthreads();
+                    cur ^= 1;
+                } else {
+                    if (it + 1 < it_end) gload(it + 1);
+                    __syncthreads();                    // the matrix waves are done with this tile
+                    if (it + 1 < it_end) {
+                        lstore(0);
+                        __syncthreads();
+                    }
+                }
+            }
+            return;
+        }
+    }
+
     // accumulators are defined and updated only by "a"-constrained asm, so they live in AGPRs across the whole
     // pixel loop (a VALU zero-init makes the allocator keep them in VGPRs and copy 144 registers into and out of
     // AGPRs around every iteration)
     f32x16_t acc[9];
-    {
+    if constexpr (TS) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    } else {
         const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < 9; ++t)      // s_nop: the hazard recognizer does not see into asm (VALU write of z -> MFMA read)
             asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[t]) : "v"(z));
     }
 
-    gload(it_begin);
-    lstore();
+    if constexpr (!TS) {
+        gload(it_begin);
+        lstore(0);
+    }
     __syncthreads();
     constexpr int SPW = NSLAB / KSPLIT;        // slabs per wave and iteration
     // slab s0 of this wave: s = s0*KSPLIT + kpart -> row s / SEGS, column segment (s % SEGS)*16.  KSPLIT is 1 or
@@ -295,19 +458,78 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
     unsigned vb[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) vb[t] = lds_addr(sX + b_off + tap_off[t]) + (unsigned)((krow * TL::XSTEP + kseg * 16) * SX);
-    for (int it = it_begin; it < it_end; ++it) {
-        if (it + 1 < it_end) gload(it + 1);
-        bf16x4_t fa[2][2], fb[2][9][2];
-        SEGNB_TR_READ2(fa[0][0], fa[0][1], va, 0, 4 * SY);          // prologue: slab 0 -> fragment set 0
-        wg_first<0, SX>(fb[0], vb);
-        wg_slabs<0, SPW, KSPLIT, SEGS, TL::YSTEP, TL::XSTEP, SX, SY>(acc, fa, fb, va, vb);
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before anyone reads the accumulators
-        __syncthreads();                    // everyone done reading this iteration's tiles
-        if (it + 1 < it_end) {
-            lstore();
-            __syncthreads();
+    // the whole pixel loop is instantiated per tap group (the MFMA / request order differs) and branched ONCE, so the
+    // accumulators stay in their AGPRs across it
+    auto pixel_loop = [&](auto Gc) {
+        constexpr int G = decltype(Gc)::value;
+        if constexpr (DB) {
+            int cur = 0;
+            for (int it = it_begin; it < it_end; ++it) {
+                const bool more = it + 1 < it_end;
+                if constexpr (!TS) {
+                    if (more) gload(it + 1);
+                }
+                const unsigned bo = (unsigned)(cur * BUF);
+                const unsigned vac = va + bo;
+                auto mid = [&]() {
+                    if constexpr (!TS) {
+                        if (more) lstore((cur ^ 1) * BUF);
+                    }
+                };
+#if SEGNB_WG_EXP & 2
+                mid();
+                if (false) {
+#else
+                if constexpr (TS) {
+#endif
+                    unsigned vtc[5];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) vtc[b] = vb[4 * G + b] + bo;
+                    ts_iteration<G, SPW, SEGS, TL::YSTEP, TL::XSTEP, SX, SY, (SPW + 1) / 2>(acc, vac, vtc, mid);
+                } else if constexpr (!(SEGNB_WG_EXP & 2)) {
+                    unsigned vbc[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) vbc[t] = vb[t] + bo;
+                    bf16x4_t fa[2][2], fb[2][9][2];
+                    SEGNB_TR_READ2(fa[0][0], fa[0][1], vac, 0, 4 * SY);          // prologue: slab 0 -> fragment set 0
+                    wg_first<0, SX>(fb[0], vbc);
+                    wg_slabs<0, SPW, KSPLIT, SEGS, TL::YSTEP, TL::XSTEP, SX, SY, (SPW + 1) / 2>(acc, fa, fb, vac, vbc,
+                                                                                                mid);
+                }
+                __syncthreads();                // this buffer read by everyone, the other one written by everyone
+                cur ^= 1;
+            }
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before anyone reads the accumulators
+        } else {
+            auto mid = [] {};
+            for (int it = it_begin; it < it_end; ++it) {
+                if constexpr (!TS) {
+                    if (it + 1 < it_end) gload(it + 1);
+                }
+                if constexpr (TS) {
+                    unsigned vtc[5];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) vtc[b] = vb[4 * G + b];
+                    ts_iteration<G, SPW, SEGS, TL::YSTEP, TL::XSTEP, SX, SY, -1>(acc, va, vtc, mid);
+                } else {
+                    bf16x4_t fa[2][2], fb[2][9][2];
+                    SEGNB_TR_READ2(fa[0][0], fa[0][1], va, 0, 4 * SY);          // prologue: slab 0 -> fragment set 0
+                    wg_first<0, SX>(fb[0], vb);
+                    wg_slabs<0, SPW, KSPLIT, SEGS, TL::YSTEP, TL::XSTEP, SX, SY, -1>(acc, fa, fb, va, vb, mid);
+                }
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before anyone reads the accumulators
+                __syncthreads();                    // everyone done reading this iteration's tiles
+                if (it + 1 < it_end) {
+                    if constexpr (!TS) lstore(0);
+                    __syncthreads();
+                }
+            }
         }
-    }
+    };
+    if (TS && tg != 0)
+        pixel_loop(std::integral_constant<int, 1>{});
+    else
+        pixel_loop(std::integral_constant<int, 0>{});
 
     // D[i = co][j = ci]: lane holds column ci = lane&31, rows co = (e&3) + 8*(e>>2) + 4*h
     if (KSPLIT > 1) {
@@ -334,12 +556,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_s1x9_kernel(const WgS1Args 
     }
     const int ci = ci0 + sci * 32 + (lane & 31);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int u = 0; u < 9; ++u) {
+        // accumulator u: tap u of sub-tile sco, or (tap-split) unit u = (co half (u+tg)&1, tap 4*tg + ((u+tg)>>1))
+        const int t = TS ? 4 * tg + ((u + tg) >> 1) : u;
+        const int cob = co0 + (TS ? ((u + tg) & 1) : sco) * 32;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int co = co0 + sco * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (co < a.Co && ci < a.Ci) slab[(long long)co * a.Ktot + t * a.Ci + ci] = acc[t][e];
+            const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (co < a.Co && ci < a.Ci) slab[(long long)co * a.Ktot + t * a.Ci + ci] = acc[u][e];
         }
+    }
 }
 
 // slab 0 += slabs 1..nslab-1 (fixed order: bitwise reproducible).  256 threads = 64 consecutive elements x 4
@@ -375,7 +601,8 @@ int s1_slabs(int tiles) {
 template <int BCO, int BCI, int R, int WT, bool FLAT = false>
 int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     using TL = WgTile<R, WT, FLAT>;
-    constexpr int smem = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
+    constexpr int tile_bytes = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
+    constexpr int smem = (wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB) ? 2 * tile_bytes : tile_bytes;
     static_assert(smem <= 160 * 1024, "tiles fit the LDS");
     static int attr_rc = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>),
@@ -398,7 +625,8 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     }
     a.its_per_split = (a.IT + S - 1) / S;
     a.slab_stride = (long long)a.Co * a.Ktot;
-    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>), dim3(tiles * S), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>), dim3(tiles * S),
+                       dim3(wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), smem, stream, a);
     if (S > 1) {
         const long long total = a.slab_stride;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp, total,
