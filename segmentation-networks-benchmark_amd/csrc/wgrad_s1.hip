@@ -63,7 +63,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
                             // 128 KB block keeps other kernels off the CU: +0.8 % step time beside the main stream)
 #endif
 #ifndef SEGNB_WG_EXP
-#define SEGNB_WG_EXP 0       // timing experiments (wrong results): 1 = no global loads after the first tile, 2 = no MFMA loop
+#define SEGNB_WG_EXP 0       // timing experiments (wrong results): 1 = no global loads after the first tile, 2 = no MFMA loop,
+                              // 4 = no slab stores
 #endif
 
 struct WgS1Args {
@@ -245,8 +246,8 @@ struct WgTile {
 template <int BCO, int BCI, int R, int WT, bool FLAT>
 constexpr bool wg_specialised() {
     using TL = WgTile<R, WT, FLAT>;
-    return SEGNB_WG_TS && BCO == 64 && BCI == 64 && !FLAT &&
-           wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO));
+    return SEGNB_WG_TS && BCO == 64 && BCI == 64 &&
+           (!SEGNB_WG_WS_DB || wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO)));
 }
 
 template <int BCO, int BCI, int R, int WT, bool FLAT = false>
@@ -416,7 +417,9 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                     __syncthreads();
                     cur ^= 1;
                 } else {
+#if !(SEGNB_WG_EXP & 1)
                     if (it + 1 < it_end) gload(it + 1);
+#endif
                     __syncthreads();                    // the matrix waves are done with this tile
                     if (it + 1 < it_end) {
                         lstore(0);
@@ -507,10 +510,12 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                     if (it + 1 < it_end) gload(it + 1);
                 }
                 if constexpr (TS) {
+#if !(SEGNB_WG_EXP & 2)
                     unsigned vtc[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) vtc[b] = vb[4 * G + b];
                     ts_iteration<G, SPW, SEGS, TL::YSTEP, TL::XSTEP, SX, SY, -1>(acc, va, vtc, mid);
+#endif
                 } else {
                     bf16x4_t fa[2][2], fb[2][9][2];
                     SEGNB_TR_READ2(fa[0][0], fa[0][1], va, 0, 4 * SY);          // prologue: slab 0 -> fragment set 0
@@ -555,6 +560,17 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
             for (int e = 0; e < 16; ++e) acc[t][e] += sAcc[(t * 16 + e) * 64 + lane];
     }
     const int ci = ci0 + sci * 32 + (lane & 31);
+#if SEGNB_WG_EXP & 4
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[u][e];
+        if (sum == 12345.f) slab[0] = sum;
+        return;
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
         // accumulator u: tap u of sub-tile sco, or (tap-split) unit u = (co half (u+tg)&1, tap 4*tg + ((u+tg)>>1))

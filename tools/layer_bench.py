@@ -31,6 +31,9 @@ def main():
     ap.add_argument('--dbg', type=int, default=None, help='segnb_tune fprop_dma_dbg (timing builds)')
     ap.add_argument('--rw', type=int, default=None, help='segnb_tune fprop_rw (0/1)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
+    ap.add_argument('--wgrad-unpack', type=int, default=0,
+                    help='1: time the per-layer unpack (packed fp32 workspace -> parameter-layout gradient) with the '
+                         'weight gradient; the training step unpacks all layers in three batched launches instead')
     args = ap.parse_args()
     rt = Runtime('cuda', args.dtype)
     from segnb import _native as nv
@@ -74,7 +77,7 @@ def main():
         line = '%-9s %4dx%-4d %4d->%-4d' % (name, hw, hw, ci, co)
         for what in args.what.split(','):
             fn = {'fprop': lambda: op.fprop(xv, yv, stats), 'dgrad': lambda: op.dgrad(dyv, dxv),
-                  'wgrad': lambda: op.wgrad(xv, dyv, gw)}[what]
+                  'wgrad': lambda: op.wgrad(xv, dyv, gw, unpack=bool(args.wgrad_unpack))}[what]
             fn()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
