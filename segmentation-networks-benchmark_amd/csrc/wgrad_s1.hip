@@ -606,6 +606,28 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ dw
     if (grp == 0 && i < total) dwp[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// few slabs (<= 16: the layers with many tiles): one lane per FOUR consecutive elements, slabs summed in order.  The
+// 64-element blocks above are launch-rate bound there (4.7 M elements x 2 slabs = 74 k blocks: 23 us for 57 MB).
+__global__ __launch_bounds__(256) void slab_reduce_few_kernel(float4* __restrict__ dwp, long long total4, int nslab) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 a = dwp[i];
+    int s = 1;
+    for (; s + 3 < nslab; s += 4) {
+        const float4 b0 = dwp[(long long)s * total4 + i], b1 = dwp[(long long)(s + 1) * total4 + i];
+        const float4 b2 = dwp[(long long)(s + 2) * total4 + i], b3 = dwp[(long long)(s + 3) * total4 + i];
+        a.x = (((a.x + b0.x) + b1.x) + b2.x) + b3.x;
+        a.y = (((a.y + b0.y) + b1.y) + b2.y) + b3.y;
+        a.z = (((a.z + b0.z) + b1.z) + b2.z) + b3.z;
+        a.w = (((a.w + b0.w) + b1.w) + b2.w) + b3.w;
+    }
+    for (; s < nslab; ++s) {
+        const float4 b = dwp[(long long)s * total4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    dwp[i] = a;
+}
+
 // number of pixel splits (= partial slabs) for a tile count: one resident block per CU (the kernel holds 144
 // accumulator AGPRs + 160 VGPRs per lane), independent of the batch / image size so that the host can size the
 // workspace per convolution
@@ -645,8 +667,12 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
                        dim3(wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), smem, stream, a);
     if (S > 1) {
         const long long total = a.slab_stride;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp, total,
-                           S);
+        if (S <= 16 && total % 4 == 0)
+            hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<float4*>(a.dwp), total / 4, S);
+        else
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp,
+                               total, S);
     }
     return 0;
 }
