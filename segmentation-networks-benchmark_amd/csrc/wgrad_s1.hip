@@ -62,6 +62,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 #define SEGNB_WG_WS_DB 0     // specialised blocks: 1 = two tile buffers (one barrier per iteration; same speed alone, but the
                             // 128 KB block keeps other kernels off the CU: +0.8 % step time beside the main stream)
 #endif
+#ifndef SEGNB_WG_TALL
+#define SEGNB_WG_TALL 1
+#endif
 #ifndef SEGNB_WG_EXP
 #define SEGNB_WG_EXP 0       // timing experiments (wrong results): 1 = no global loads after the first tile, 2 = no MFMA loop,
                               // 4 = no slab stores
@@ -679,7 +682,8 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
 
 // tile configuration of the fast path for a geometry: 0 = not handled here (general kernel, one slab)
 struct S1Choice {
-    int cfg;        // 1: 32x32 R8 WT32, 2: 64x64 R4 WT32, 3: 64x64 R8 WT16, 4: flat 7x7 x4 images, 5: flat 14x14
+    int cfg;        // 1: 32x32 R8 WT32, 2: 64x64 R4 WT32, 3: 64x64 R8 WT16, 4: flat 7x7 x4 images, 5: flat 14x14,
+                    // 6: 32x32 R16 WT32 (halo rows 18/16 instead of 10/8 of the HBM-bound thin layers)
     int bco, bci;
 };
 S1Choice s1_choose(const segnb_conv_geom* g) {
@@ -697,7 +701,7 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
     const bool thin = g->Co <= 32 || g->Ci <= 32;
     if (thin) {
         if (g->Wo < 24) return c;
-        c = {1, 32, 32};
+        c = {(g->Ho % 16 == 0 && g->Ho >= 64 && SEGNB_WG_TALL) ? 6 : 1, 32, 32};
     } else if (g->Wo > 16) {
         c = {2, 64, 64};
     } else if (g->Wo == 14 && g->Ho == 14) {
@@ -744,6 +748,7 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     a.Ktot = 9 * g->Ci;
     int rc;
     if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream);
+    else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream);
     else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream);
     else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream);
     else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream);
