@@ -80,13 +80,17 @@ class Runtime(object):
     # unpack.  Neither kernel family fills a CU alone (one wgrad block = 4 waves / 64 KB LDS, two dgrad blocks =
     # 8 waves / 148 KB), so the hardware co-schedules them.  Captured into the step's HIP graph as a parallel branch.
     overlap_wgrad = os.environ.get('SEGNB_OVERLAP_WGRAD', '1') != '0'
+    if not overlap_wgrad:
+        # one stream: nothing runs beside the weight gradients, so they take every CU (wgrad_s1.hip: s1_slabs reads
+        # this once, at the first plan)
+        os.environ.setdefault('SEGNB_WG_CU_FRACTION', '1')
 
     def side_stream(self):
         if self.device.type != 'cuda' or not self.overlap_wgrad:
             return None
         s = getattr(self, '_side', None)
         if s is None:
-            s = self._side = torch.cuda.Stream(device=self.device)
+            s = self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('SEGNB_SIDE_PRIORITY', '0')))
         return s
 
     def fork_side(self):
