@@ -49,7 +49,10 @@ int segnb_device_cus(void);
  *   "fprop_dma_cfg"  -1 = automatic tile configuration, n >= 0 = force configuration n
  *   "fprop_rw"       0 = never use the resident-weights pipeline of the thin layers (fprop_rw.hip)
  *   "fprop_dma_dbg"  timing builds (parts of the pipeline removed; results are WRONG when non-zero)
- * Defaults come from the environment variables SEGNB_FPROP_DMA / SEGNB_FPROP_DMA_CFG.  Not thread-safe. */
+ *   "conv_cu_pct"    percentage (10..100) of the CUs the persistent convolution kernels size their grids for
+ * Defaults come from the environment variables SEGNB_FPROP_DMA / SEGNB_FPROP_DMA_CFG.  Not thread-safe.
+ * (The weight-gradient launches read SEGNB_WG_CU_FRACTION / SEGNB_WG_CU_FRACTION_THIN once: share of the CUs their
+ * pixel split is sized for, default 0.5 / 1.0; segnb_conv_wgrad_slabs reports the resulting slab count.) */
 int segnb_tune(const char* key, int value);
 /* Timing builds: in-kernel shader-clock stamps of block 0 of the last direct-to-LDS convolution launched with
  * "fprop_dma_dbg" = 32.  host_dst: HOST buffer of 3 x 256 x 4 unsigned 64-bit values ([wave role][tap][event]);

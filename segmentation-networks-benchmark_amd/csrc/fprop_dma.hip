@@ -540,7 +540,7 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     }
     a.NTL = (a.Co + C::BN - 1) / C::BN;
     a.NCH = a.Ci / 64;
-    int gm = segnb_num_cus() / a.NTL;
+    int gm = segnb_knob_conv_cus() / a.NTL;
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
@@ -570,7 +570,7 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         // re-measured with the final kernel, the round count decides every case (e.g. 128 -> 384 @56x56: 11 vs 12
         // rounds, 104 vs 122 us; 64 -> 192 @112x112: 21 vs 19 rounds, 133 vs 116 us); ties go to 16 x 16
         const int ntl = (a.Co + 63) / 64;
-        int gm = segnb_num_cus() / ntl;
+        int gm = segnb_knob_conv_cus() / ntl;
         if (gm < 1) gm = 1;
         const long long it0 = (long long)a.N * ((a.H + 7) / 8) * ((a.W + 31) / 32);
         const long long it1 = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);

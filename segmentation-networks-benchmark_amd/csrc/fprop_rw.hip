@@ -363,7 +363,7 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
     a.WB = (a.W + C::WT - 1) / C::WT;
     a.IT = a.N * a.HB * a.WB;
     a.NTL = 1;
-    int gm = segnb_num_cus();
+    int gm = segnb_knob_conv_cus();
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
     if (a.dbg)       // timing builds: separately instantiated, the production kernel carries no run-time checks

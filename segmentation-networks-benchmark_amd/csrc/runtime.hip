@@ -54,6 +54,11 @@ int segnb_knob_fprop_dma_cfg() {
 }
 static int g_fprop_rw = 1;
 int segnb_knob_fprop_rw() { return g_fprop_rw && segnb_knob_fprop_dma_cfg() < 0; }
+static int g_conv_cu_pct = 100;
+int segnb_knob_conv_cus() {
+    const int n = segnb_num_cus() * g_conv_cu_pct / 100;
+    return n < 1 ? 1 : n;
+}
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
@@ -68,6 +73,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_rw") == 0) {
         g_fprop_rw = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "conv_cu_pct") == 0) {        // CUs the persistent convolution kernels size their grids for (%)
+        g_conv_cu_pct = value < 10 ? 10 : (value > 100 ? 100 : value);
         return 0;
     }
     if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero

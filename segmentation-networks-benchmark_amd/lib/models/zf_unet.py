@@ -197,6 +197,9 @@ class _ZFUnetPlan(object):
     # (+ head), the two deepest encoder blocks (71 MB of the 126 MB of gradients), the rest.  Each group is unpacked
     # as soon as its weight gradients exist (on the side stream, beside the remaining backward) and handed to the
     # data-parallel hook, so its all-reduce overlaps the rest of backward.
+    # CUs (%) the persistent data-gradient kernels size their grids for while the weight gradients hold half of the chip
+    # (measured on one box: 100 -> 5.33 ms/step, 75 -> 5.43, 50 -> 5.45: smaller grids do not pay, left at 100)
+    BWD_CONV_CU_PCT = int(os.environ.get('SEGNB_BWD_CONV_CU_PCT', '100'))
     UNPACK_GROUPS = ((2 * len(ENCODER), None), (8, 2 * len(ENCODER)), (0, 8))       # conv index ranges
 
     def _tables(self, H, W):
@@ -311,6 +314,8 @@ class _ZFUnetPlan(object):
         N, H, W = self._last
         b = self.buffers(N, H, W)
         accumulate_in_place = flat.begin_backward()
+        if self.BWD_CONV_CU_PCT != 100:
+            nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
         head = self.module.conv_final
         nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
                 nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
@@ -341,6 +346,8 @@ class _ZFUnetPlan(object):
                 s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
                             dx=b['da1_%d' % i])
             s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
+        if self.BWD_CONV_CU_PCT != 100:
+            nv.call('segnb_tune', b'conv_cu_pct', 100)
         rt.join_side()                        # the weight gradients ran on the side stream
         self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
         self._after_backward()
