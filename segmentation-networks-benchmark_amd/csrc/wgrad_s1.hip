@@ -639,8 +639,9 @@ __global__ __launch_bounds__(256) void slab_reduce_few_kernel(float4* __restrict
 // half to the dependent chain (measured in situ: fraction 1 -> 5.69 ms/step, 0.75 -> 5.60, 0.5 -> 5.59, 0.4 -> 5.75,
 // 0.25 -> 6.3; two blocks per CU 5.91).  Half the blocks is also half the slab traffic.  The thin 32x32-tile launches
 // (224x224 / 112x112, HBM-bound) keep all CUs (1 -> 5.56, 0.5 -> 5.60, 0.25 -> 5.72 with the wide ones at 0.5).
-// SEGNB_WG_CU_FRACTION / SEGNB_WG_CU_FRACTION_THIN override (read once).
-int s1_slabs(int tiles, bool thin) {
+// SEGNB_WG_CU_FRACTION / SEGNB_WG_CU_FRACTION_THIN / SEGNB_WG_CU_FRACTION_FLAT (7x7 and 14x14 tiles; default = the
+// wide share: 0.25 .. 1 measured within +-0.5 %) override (read once).
+int s1_slabs(int tiles, bool thin, bool flat = false) {
     static const double frac_wide = [] {
         const char* e = getenv("SEGNB_WG_CU_FRACTION");
         const double r = e ? atof(e) : 0.5;
@@ -651,7 +652,13 @@ int s1_slabs(int tiles, bool thin) {
         const double r = e ? atof(e) : 1.0;
         return r <= 0.0 ? 1.0 : r;
     }();
-    int S = (int)(segnb_num_cus() * (thin ? frac_thin : frac_wide)) / tiles;
+    static const double frac_flat = [] {
+        const char* e = getenv("SEGNB_WG_CU_FRACTION_FLAT");
+        const double r = e ? atof(e) : -1.0;
+        return r;
+    }();
+    const double frac = thin ? frac_thin : ((flat && frac_flat > 0.0) ? frac_flat : frac_wide);
+    int S = (int)(segnb_num_cus() * frac) / tiles;
     return S < 1 ? 1 : S;
 }
 
@@ -674,7 +681,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     const int ncot = (a.Co + BCO - 1) / BCO;
     a.TCI_TILES = (a.Ci + BCI - 1) / BCI;
     const int tiles = ncot * a.TCI_TILES;
-    const int S = s1_slabs(tiles, BCO == 32);
+    const int S = s1_slabs(tiles, BCO == 32, FLAT);
     if (S != nslab) {
         segnb_set_error("segnb_conv_wgrad: workspace has %d slabs, this geometry needs %d (segnb_conv_wgrad_slabs)",
                         nslab, S);
@@ -736,7 +743,7 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
     const S1Choice c = s1_choose(g);
     if (!c.cfg) return 0;
-    return s1_slabs(((g->Co + c.bco - 1) / c.bco) * ((g->Ci + c.bci - 1) / c.bci), c.bco == 32);
+    return s1_slabs(((g->Co + c.bco - 1) / c.bco) * ((g->Ci + c.bci - 1) / c.bci), c.bco == 32, c.cfg == 4 || c.cfg == 5);
 }
 
 // returns 1 when the launch was handled here, 0 when the geometry is not a stride-1 3x3 bf16 case
