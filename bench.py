@@ -166,6 +166,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # host time to ENQUEUE one step (no synchronisation inside; the GPU is still busy with the first step when the last
+    # one has been issued unless the host is the slower side) -- reported beside the step time, outside the timed region
+    host_ms = None
+    if graph is None:
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(5):
+            loss_h = step()
+        host_ms = (time.perf_counter() - th) / 5 * 1e3
+        torch.cuda.synchronize()
+
     # ---- live per-kernel timing (HIP events on the launch stream).  Event records cannot sit inside a replayed
     # graph, so when the timed region ran from the graph the same step is run eagerly right after it, with the
     # events around every convolution launch; without a graph the events are recorded in the timed region itself.
@@ -196,6 +207,7 @@ def main():
                                'torch_train.py:180-190 (configs[1])' % (S, S, args.dtype, B, args.loss),
                    'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
         'final_loss': round(final_loss, 6), 'hip_graph': bool(graph is not None),
+        'host_enqueue_ms_per_step': None if host_ms is None else round(host_ms, 3),
         'step_mfma_frac': round(value / ws * gflop_img / 1e3 / peak, 4),
     }
     if timer is not None:
