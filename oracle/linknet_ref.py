@@ -1,7 +1,11 @@
 """CPU restatement of LinkNet34 (lib/models/linknet.py:5-90).  TEST INFRASTRUCTURE.
 
-PARITY UNPINNED: the reference module needs torchvision (ResNet34 encoder) and the un-vendored ``inplace_abn``
-extension; neither is available, so no golden vector can be produced from it.  Restated from the source text:
+PARITY: WIRING PINNED, THIRD-PARTY TOPOLOGY RESTATED.  tests/golden/linknet_small.npz was produced by running the
+reference's own lib/models/linknet.py:5-90 (make_golden.py gen_linknet) with the reference's importable
+lib/models/dilated_resnet.py (BasicBlock x [3,4,6,3], dilated=False) standing in for torchvision's resnet34 and a
+BatchNorm2d + LeakyReLU(0.01) module standing in for the un-vendored ``inplace_abn`` backend (bn.py:47-103,
+functions.py:62-122; gamma-vs-|gamma| of that backend stays undeterminable from the reference);
+tests/test_models_cpu.py checks this file against it (logits 1e-4, loss 1e-6, gradients 1e-3).  Restated here:
   stem  conv7x7 s2 p3 (no bias) -> BN -> ReLU -> MaxPool 3x3 s2 p1                          linknet.py:41-44,67-70
   encoder  torchvision BasicBlock x [3,4,6,3] (conv3x3-BN-ReLU-conv3x3-BN (+1x1 s2 downsample-BN) add ReLU) :45-48
   decoder  conv1x1 -> ABN -> ConvTranspose 4x4 s2 p1 -> ABN -> conv1x1 -> ABN, ABN = BN + LeakyReLU(0.01)   :12-30

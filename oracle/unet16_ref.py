@@ -1,7 +1,10 @@
 """CPU restatement of UNet16 / TernausNet-16 (lib/models/unet16.py:52-131).  TEST INFRASTRUCTURE.
 
-PARITY UNPINNED: the reference module imports torchvision (absent in the build container and on the GPU box),
-so no golden vector can be produced from it.  This restates the topology from the source text:
+PARITY: WIRING PINNED, THIRD-PARTY TOPOLOGY RESTATED.  tests/golden/unet16_small.npz was produced by running the
+reference's own lib/models/unet16.py:52-131 (make_golden.py gen_unet16) with a torch.nn stand-in for the one symbol
+it takes from the absent torchvision, ``models.vgg16(...).features`` (the cfg-"D" conv stack, restated from its
+published definition); tests/test_models_cpu.py checks this file against it (logits 1e-4, loss 1e-6, gradients
+1e-3).  The topology restated here:
 VGG16 "D" convs at features indices 0,2 | 5,7 | 10,12,14 | 17,19,21 | 24,26,28, each followed by ReLU
 (unet16.py:73-102), MaxPool2d(2,2) between groups (:64,:113-118), DecoderBlock = conv3x3+ReLU ->
 ConvTranspose2d(4, stride 2, pad 1) -> ReLU (:35-40), concatenations [decoder, encoder] (:122-127), dec1 =

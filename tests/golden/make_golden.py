@@ -20,6 +20,13 @@ Fixtures
   zf_unet_224.npz     G2+G3  ZF_UNET() default (filters=32, Dropout2d 0.2 replay tables captured from the
                           reference's own RNG draw) B=4 224x224: loss / IoU / accuracy scalars, per-tensor
                           gradient L2 norms, probed logits and gradient entries
+  unet16_small.npz    the reference's lib/models/unet16.py (UNet16 wiring :52-131) run with a torch.nn stand-in for
+                          ``torchvision.models.vgg16`` (cfg "D" features stack): logits, loss, gradient norms + probes
+  linknet_small.npz   the reference's lib/models/linknet.py (LinkNet34 wiring :5-90) run with the reference's own
+                          ``lib/models/dilated_resnet.py`` (dilated=False) standing in for torchvision's resnet34 and
+                          a BatchNorm2d + LeakyReLU stand-in for the un-vendored ``inplace_abn`` backend
+  ("wiring pinned, third-party topology restated": what those fixtures pin is the reference's own forward code;
+  the torchvision / inplace_abn pieces are restated from their published definitions.)
 """
 import os
 import sys
@@ -312,8 +319,130 @@ def gen_tiles():
     print('tiles.npz', len(out), 'arrays')
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# UNet16 / LinkNet34: the reference's wiring code run on torch.nn stand-ins for its absent third-party imports
+# ---------------------------------------------------------------------------------------------------------------------
+def _install_third_party_standins():
+    """``torchvision.models.{vgg16, resnet34}`` and ``lib.modules.abn.InPlaceABN`` as torch.nn-only stand-ins.
+
+    * vgg16(...).features: the cfg-"D" stack of torchvision's VGG16 (13 conv3x3 p1 + ReLU, MaxPool2d(2,2) after
+      convs 2, 4, 7, 10, 13) -- unet16.py:73-102 addresses it by the indices 0,2,5,7,...,28 this produces.
+    * resnet34(...): the reference's OWN restatement of the torchvision ResNet (lib/models/dilated_resnet.py:23-56,
+      136-191, imported from /root/reference) with BasicBlock x [3,4,6,3], dilated=False: conv1/bn1/relu/maxpool/
+      layer1..4, the attributes linknet.py:41-48 reads.
+    * InPlaceABN: BatchNorm2d semantics + LeakyReLU(slope) as bn.py:47-103 / functions.py:62-122 describe them
+      (batch mean / biased variance in training, running_var updated with the unbiased variance, standard affine
+      gamma -- SURVEY 8c; no num_batches_tracked buffer).
+    """
+    import types
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from lib.models import dilated_resnet as ref_resnet        # reference
+
+    def vgg16(pretrained=False, **kw):
+        cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+        layers, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        return m
+
+    def resnet34(pretrained=False, **kw):
+        return ref_resnet.DilatedResNet(ref_resnet.BasicBlock, [3, 4, 6, 3], dilated=False)
+
+    tv = types.ModuleType('torchvision')
+    tv.models = types.ModuleType('torchvision.models')
+    tv.models.vgg16, tv.models.resnet34 = vgg16, resnet34
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.models'] = tv.models
+
+    class InPlaceABN(nn.Module):
+        def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation='leaky_relu', slope=0.01):
+            super().__init__()
+            self.eps, self.momentum, self.activation, self.slope = eps, momentum, activation, slope
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+            self.register_buffer('running_mean', torch.zeros(num_features))
+            self.register_buffer('running_var', torch.ones(num_features))
+
+        def forward(self, x):
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                             self.momentum, self.eps)
+            return F.leaky_relu(y, self.slope) if self.activation == 'leaky_relu' else y
+
+    abn = types.ModuleType('lib.modules.abn')
+    abn.InPlaceABN = InPlaceABN
+    sys.modules['lib.modules.abn'] = abn
+
+
+def _run_and_record(m, x, y, fname, seed):
+    """Load the seeded fill, run train forward + (B*bce_jaccard).backward() + eval forward, store small arrays."""
+    from oracle import fill
+    sd = fill.seeded_state(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    B = x.shape[0]
+    out = {'x': x.numpy(), 'y': y.numpy(), 'seed': np.asarray(seed),
+           'sd_keys': np.array(list(sd.keys())), 'sd_numel': np.array([v.numel() for v in sd.values()])}
+    m.eval()
+    with torch.no_grad():
+        out['eval_logits'] = m(x).numpy()
+    m.train()
+    logits = m(x)
+    out['train_logits'] = logits.detach().numpy()
+    l = ref_loss('bce_jaccard')(logits, y)
+    out['loss_bce_jaccard'] = l.detach().numpy()
+    out['iou'] = ref_metrics.JaccardScore()(logits.detach(), y).numpy()
+    out['acc'] = ref_metrics.PixelAccuracy()(logits.detach(), y).numpy()
+    m.zero_grad()
+    (B * l).backward()
+    rng = np.random.RandomState(9)
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        g = p.grad.numpy().reshape(-1)
+        names.append(n)
+        norms.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        gi = rng.choice(g.size, min(64, g.size), replace=False)
+        out['gidx/' + n], out['gval/' + n] = gi, g[gi]
+    out['grad_names'], out['grad_norms'] = np.array(names), np.array(norms)
+    for n, b in m.named_buffers():
+        if b.numel() <= 1024:
+            out['buf/' + n] = b.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, 'loss', float(l), 'iou', float(out['iou']), 'params', sum(p.numel() for p in m.parameters()))
+
+
+def gen_unet16():
+    _install_third_party_standins()
+    from lib.models.unet16 import UNet16                        # reference wiring, unet16.py:52-131
+    m = UNet16(num_classes=1, num_filters=8, pretrained=False)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    y = (torch.rand(2, 1, 64, 96, generator=g) > 0.7).long()
+    _run_and_record(m, x, y, 'unet16_small.npz', seed=16)
+
+
+def gen_linknet():
+    _install_third_party_standins()
+    from lib.models.linknet import LinkNet34                    # reference wiring, linknet.py:5-90
+    m = LinkNet34(num_classes=1, num_channels=3, pretrained=False)
+    m.finaldrop1.p = 0.0
+    g = torch.Generator().manual_seed(34)
+    x = torch.randn(2, 3, 128, 160, generator=g)
+    y = (torch.rand(2, 1, 128, 160, generator=g) > 0.7).long()
+    _run_and_record(m, x, y, 'linknet_small.npz', seed=34)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles', 'unet16', 'linknet']
+    if 'unet16' in which:
+        gen_unet16()
+    if 'linknet' in which:
+        gen_linknet()
     if 'tiles' in which:
         gen_tiles()
     if 'losses' in which:

@@ -125,3 +125,114 @@ def check_tiramisu_golden(model, golden, device, dtype='f32'):
     with torch.no_grad():
         ev = model(x.to(device))
     np.testing.assert_allclose(ev.cpu().numpy(), golden['eval_logits'], rtol=1e-3, atol=1e-4)
+
+
+# ---- UNet16 / LinkNet34 vs the fixtures produced by the REFERENCE's own wiring code (make_golden.py gen_unet16 /
+# gen_linknet: lib/models/unet16.py:52-131, lib/models/linknet.py:5-90 run on torch.nn stand-ins for torchvision /
+# inplace_abn).  Weights: oracle.fill.seeded_state, loaded into the product module here exactly as the generator
+# loaded them into the reference module.
+def make_unet16_golden(golden):
+    from lib.models.unet16 import UNet16
+    m = UNet16(num_filters=8)
+    return _load_seeded(m, golden), unet16_ref.forward
+
+
+def make_linknet_golden(golden):
+    from lib.models.linknet import LinkNet34
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = LinkNet34()
+    m.finaldrop1.p = 0.0
+    return _load_seeded(m, golden), None
+
+
+def _load_seeded(m, golden):
+    from oracle import fill
+    sd = fill.seeded_state(m.state_dict(), int(golden['seed']))
+    assert list(sd.keys()) == [str(k) for k in golden['sd_keys']], 'state_dict layout differs from the reference'
+    assert [v.numel() for v in sd.values()] == [int(n) for n in golden['sd_numel']]
+    m.load_state_dict(sd)
+    return m
+
+
+def check_oracle_golden(forward_train, forward_eval, model, golden):
+    """The oracle restatement (functional, on the module's state_dict) vs the reference fixture: this is the PIN."""
+    x, y = torch.from_numpy(golden['x']), torch.from_numpy(golden['y'])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pnames = [n for n, _ in model.named_parameters()]
+    with torch.no_grad():
+        ev = forward_eval({k: v.clone() for k, v in sd.items()}, x)
+    np.testing.assert_allclose(ev.numpy(), golden['eval_logits'], rtol=1e-4, atol=2e-5)
+    leaves = {k: (v.clone().requires_grad_(True) if k in pnames else v.clone()) for k, v in sd.items()}
+    # aliased keys (UNet16: encoder.N.* == convK.M.*) must be ONE leaf, or the gradient splits between the aliases
+    seen = {}
+    for n, p in model.state_dict(keep_vars=True).items():
+        if id(p) in seen:
+            leaves[n] = leaves[seen[id(p)]]
+        else:
+            seen[id(p)] = n
+    logits = forward_train(leaves, x)
+    np.testing.assert_allclose(logits.detach().numpy(), golden['train_logits'], rtol=1e-4, atol=2e-5)
+    loss = losses_ref.bce_jaccard(logits, y)
+    assert abs(loss.item() - float(golden['loss_bce_jaccard'])) < 1e-6
+    (x.shape[0] * loss).backward()
+    _check_grads_golden({n: leaves[n].grad for n in pnames}, golden, 1e-3, 2e-3)
+    for k in golden.files:
+        if k.startswith('buf/') and 'num_batches' not in k:
+            np.testing.assert_allclose(leaves[k[4:]].detach().numpy(), golden[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def _check_grads_golden(grads, golden, norm_rtol, probe_rtol):
+    names = [str(n) for n in golden['grad_names']]
+    norms = dict(zip(names, golden['grad_norms']))
+    gmax = max(norms.values())
+    for n in names:
+        g = grads[n].detach().cpu().double().reshape(-1)
+        if norms[n] < 1e-6 * gmax:
+            continue                                          # analytically zero (conv bias in front of BatchNorm)
+        assert abs(float(g.norm()) - norms[n]) <= norm_rtol * norms[n], (n, float(g.norm()), norms[n])
+        ref = golden['gval/' + n].astype(np.float64)
+        got = g.numpy()[golden['gidx/' + n]]
+        assert np.abs(got - ref).max() <= probe_rtol * max(np.abs(ref).max(), norms[n] / np.sqrt(g.numel())), n
+
+
+def check_product_golden(model, golden, device, dtype='f32'):
+    """The product module (through the C ABI on `device`) vs the reference fixture."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore
+    x, y = torch.from_numpy(golden['x']), torch.from_numpy(golden['y'])
+    B = x.shape[0]
+    model.set_compute_dtype(dtype)
+    model.to(device)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x.to(device))
+    scale = float(np.abs(golden['eval_logits']).max())
+    tol = 2e-4 if dtype == 'f32' else 6e-2
+    assert float(np.abs(ev.cpu().numpy() - golden['eval_logits']).max()) <= tol * scale
+    model.train()
+    out = model(x.to(device))
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y.to(device))
+    iou = JaccardScore()(out, y.to(device))
+    (B * loss).backward()
+    scale = float(np.abs(golden['train_logits']).max())
+    assert float(np.abs(out.detach().cpu().numpy() - golden['train_logits']).max()) <= tol * scale
+    dl, di = abs(loss.item() - float(golden['loss_bce_jaccard'])), abs(iou.item() - float(golden['iou']))
+    if dtype == 'f32':
+        assert dl < 1e-5 and di < 1e-4, (dl, di)              # north_star tolerances
+        # per-tensor gradient norms within 1e-2, probed entries within 5e-2 of the tensor's scale: a ReLU whose
+        # pre-activation is within an fp32 ulp of zero flips between two correct implementations (abi_replay.py)
+        _check_grads_golden({n: p.grad for n, p in model.named_parameters()}, golden, 1e-2, 5e-2)
+        for k in golden.files:
+            if k.startswith('buf/') and 'num_batches' not in k:
+                b = dict(model.named_buffers())[k[4:]]
+                np.testing.assert_allclose(b.cpu().numpy(), golden[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    else:
+        assert dl < 5e-3 and di < 5e-3, (dl, di)
+        names = [str(n) for n in golden['grad_names']]
+        gmax = float(golden['grad_norms'].max())
+        for n, p in model.named_parameters():
+            ref = float(golden['grad_norms'][names.index(n)])
+            if ref > 1e-3 * gmax:
+                assert abs(float(p.grad.norm()) - ref) < 0.25 * ref, (n, float(p.grad.norm()), ref)
+    return dl, di

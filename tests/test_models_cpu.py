@@ -58,6 +58,25 @@ def test_unet16_vs_oracle():
     mc.check_against_oracle(m, fwd, x, y, 'cpu')
 
 
+def test_unet16_oracle_and_product_vs_reference_golden(golden_dir):
+    """PIN of oracle/unet16_ref.py: the fixture was produced by the reference's unet16.py:52-131."""
+    from oracle import unet16_ref
+    g = np.load(os.path.join(golden_dir, 'unet16_small.npz'))
+    m, fwd = mc.make_unet16_golden(g)
+    mc.check_oracle_golden(fwd, fwd, m, g)
+    mc.check_product_golden(m, g, 'cpu')
+
+
+def test_linknet34_oracle_and_product_vs_reference_golden(golden_dir):
+    """PIN of oracle/linknet_ref.py: the fixture was produced by the reference's linknet.py:5-90."""
+    from oracle import linknet_ref
+    g = np.load(os.path.join(golden_dir, 'linknet_small.npz'))
+    m, _ = mc.make_linknet_golden(g)
+    mc.check_oracle_golden(lambda sd, x: linknet_ref.forward(sd, x, True), lambda sd, x: linknet_ref.forward(sd, x, False),
+                           m, g)
+    mc.check_product_golden(m, g, 'cpu')
+
+
 def test_unet16_default_parameter_count():
     from lib.models.unet16 import UNet16
     assert sum(p.numel() for p in UNet16().parameters()) == 32202337     # SURVEY 8a a5

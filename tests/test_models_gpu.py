@@ -36,6 +36,20 @@ def test_tiramisu_vs_oracle(golden_dir, dtype):
     print('tiramisu %s cosine %.6f' % (dtype, mc.check_against_oracle(m, fwd, x, y, 'cuda', dtype)))
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_unet16_vs_reference_golden(golden_dir, dtype):
+    g = np.load(os.path.join(golden_dir, 'unet16_small.npz'))
+    m, _ = mc.make_unet16_golden(g)
+    print('unet16 %s dloss %.2e diou %.2e' % ((dtype,) + mc.check_product_golden(m, g, 'cuda', dtype)))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_linknet34_vs_reference_golden(golden_dir, dtype):
+    g = np.load(os.path.join(golden_dir, 'linknet_small.npz'))
+    m, _ = mc.make_linknet_golden(g)
+    print('linknet34 %s dloss %.2e diou %.2e' % ((dtype,) + mc.check_product_golden(m, g, 'cuda', dtype)))
+
+
 def test_training_steps_reduce_loss_all_models():
     """torch_train.py:180-190 loop on each model family, bf16, a few SGD steps on a fixed batch."""
     import warnings
