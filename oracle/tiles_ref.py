@@ -135,3 +135,39 @@ def predict_tiled(image, logits_fn, patch_size, batch_size):
         y = 1.0 / (1.0 + np.exp(-logits_fn(x).astype(np.float64)))
         preds.extend(np.moveaxis(y, 1, -1).astype(np.float32))
     return slicer.merge(tta_d4_deaug(preds), dtype=np.float32)
+
+
+def pad(image, pad_size):
+    """augmentations.py:513-532 with cv2.BORDER_REPLICATE == numpy 'edge' (inria_submit.py:218).  Quirk kept: when
+    only one side is not a multiple of pad_size, the other side is still padded by a full pad_size."""
+    rows, cols = image.shape[:2]
+    pad_rows, pad_cols = rows % pad_size, cols % pad_size
+    if pad_rows == 0 and pad_cols == 0:
+        return image, (0, 0, 0, 0)
+    pad_rows, pad_cols = pad_size - pad_rows, pad_size - pad_cols
+    pad_top = pad_rows // 2
+    pad_btm = pad_rows - pad_top
+    pad_left = pad_cols // 2
+    pad_right = pad_cols - pad_left
+    widths = [(pad_top, pad_btm), (pad_left, pad_right)] + [(0, 0)] * (image.ndim - 2)
+    return np.pad(image, widths, mode='edge'), (pad_top, pad_btm, pad_left, pad_right)
+
+
+def unpad(image, pads):
+    """augmentations.py:535-538"""
+    pad_top, pad_btm, pad_left, pad_right = pads
+    rows, cols = image.shape[:2]
+    return image[pad_top:rows - pad_btm, pad_left:cols - pad_right]
+
+
+def predict_full(image, logits_fn):
+    """inria_submit.py:217-234 with `logits_fn(batch NCHW float32 ndarray) -> logits [1,K,h,w]` in place of the model
+    call and an identity test_transform.  The reference's last statement, ``next(aug.tta_d4_deaug(predicts))``, raises
+    TypeError on a list; the evident intent -- the one de-augmented mask -- is what is returned here."""
+    image, pads = pad(image, 32)
+    predicts = []
+    for view in tta_d4_aug([image]):
+        x = np.ascontiguousarray(np.moveaxis(view, -1, 0))[None].astype(np.float32)
+        y = 1.0 / (1.0 + np.exp(-logits_fn(x).astype(np.float64)))
+        predicts.append(np.squeeze(np.moveaxis(y.astype(np.float32), 1, -1)))
+    return unpad(tta_d4_deaug(predicts)[0], pads)

@@ -1,24 +1,36 @@
 """The test-time-augmentation pair of the reference's ``lib.augmentations`` (/root/reference/lib/augmentations.py:
 476-511): the 8 elements of D4 per image and their inverse + average.  (The training-time augmenters of that module
-are data plumbing: out of scope)  The device path (segnb.tiled) folds both into index maps."""
+are data plumbing: out of scope)  The device path (segnb.tiled) folds both into index maps built from the
+same table."""
 import numpy as np
+
+# the dihedral group of the square in the order the reference emits it: (quarter turns, mirrored afterwards)
+D4 = tuple((k, f) for f in (False, True) for k in range(4))
+
+
+def d4_apply(image, k, mirrored):
+    out = np.rot90(image, k)
+    return np.fliplr(out) if mirrored else out
+
+
+def d4_undo(image, k, mirrored):
+    return np.rot90(np.fliplr(image) if mirrored else image, -k)
 
 
 def tta_d4_aug(images):
-    res = []
-    for image in images:
-        res.extend([image, np.rot90(image, 1), np.rot90(image, 2), np.rot90(image, 3), np.fliplr(image),
-                    np.fliplr(np.rot90(image, 1)), np.fliplr(np.rot90(image, 2)), np.fliplr(np.rot90(image, 3))])
-    return res
+    """[img, ...] -> [the 8 D4 views of img0, the 8 views of img1, ...] (augmentations.py:476-491)"""
+    return [d4_apply(image, k, f) for image in images for k, f in D4]
 
 
 def tta_d4_deaug(image_list):
-    assert len(image_list) % 8 == 0
+    """Inverse of tta_d4_aug followed by the mean over each group of 8 (augmentations.py:494-511); the partial sums
+    run in table order, as there."""
+    assert len(image_list) % len(D4) == 0
     res = []
-    one_over_8 = float(1. / 8.)
-    for i in range(0, len(image_list), 8):
-        g = image_list[i:i + 8]
-        res.append((g[0] + np.rot90(g[1], -1) + np.rot90(g[2], -2) + np.rot90(g[3], -3) + np.fliplr(g[4]) +
-                    np.rot90(np.fliplr(g[5]), -1) + np.rot90(np.fliplr(g[6]), -2) +
-                    np.rot90(np.fliplr(g[7]), -3)) * one_over_8)
+    for first in range(0, len(image_list), len(D4)):
+        acc = None
+        for view, (k, f) in zip(image_list[first:first + len(D4)], D4):
+            back = d4_undo(view, k, f)
+            acc = back if acc is None else acc + back
+        res.append(acc * float(1. / 8.))
     return res

@@ -26,44 +26,52 @@ def compute_patch_weight_loss(width, height):
     return alpha * ratio, Dc, De
 
 
+def _axis_layout(length, tile_size, tile_step, image_margin):
+    """One image axis -> (margin before, margin after, tile origins in the padded axis).
+
+    Tiles of `tile_size` every `tile_step` must cover the padded axis exactly.  With image_margin == 0 the padding is
+    whatever makes that true (the smaller half in front, tiles.py:66-77); a given image_margin must already make it
+    true (tiles.py:79-89: ValueError otherwise)."""
+    overlap = tile_size - tile_step
+    if image_margin:
+        if (length - overlap + 2 * image_margin) % tile_step:
+            raise ValueError()
+        before = after = image_margin
+    else:
+        count = max(1, math.ceil((length - overlap) / tile_step))
+        extra = count * tile_step - (length - overlap)
+        before = extra // 2
+        after = extra - before
+    origins = list(range(0, before + length + after - tile_size + 1, tile_step))
+    return before, after, origins
+
+
 class ImageSlicer:
-    """Helper class to slice image into tiles and merge them back with fusion (tiles.py:30-168)."""
+    """Slices an image into overlapping square tiles and fuses per-tile predictions back (tiles.py:30-168): same
+    constructor, attributes (``crops`` as (x, y, w, h), ``margin_left/right/top/bottom``, ``tile_size``,
+    ``tile_step``, ``image_height/width``, ``compute_weight``) and results as the reference class."""
 
     def __init__(self, image_shape, tile_size, tile_step=0, image_margin=0, weight='mean'):
-        self.image_height = image_shape[0]
-        self.image_width = image_shape[1]
-        self.tile_size = tile_size
-        self.tile_step = tile_step
-        weights = {'mean': self._mean, 'pyramid': self._pyramid}
-        self.compute_weight = weights[weight]
-        if tile_step < 1 or tile_step > tile_size:
+        self.image_height, self.image_width = image_shape[0], image_shape[1]
+        self.tile_size, self.tile_step = tile_size, tile_step
+        self.compute_weight = {'mean': self._mean, 'pyramid': self._pyramid}[weight]       # KeyError as the reference
+        if not 1 <= tile_step <= tile_size:
             raise ValueError()
-        overlap = tile_size - tile_step
-        self.margin_left = self.margin_right = self.margin_top = self.margin_bottom = 0
-        if image_margin == 0:
-            nw = max(1, math.ceil((self.image_width - overlap) / tile_step))
-            nh = max(1, math.ceil((self.image_height - overlap) / tile_step))
-            extra_w = self.tile_step * nw - (self.image_width - overlap)
-            extra_h = self.tile_step * nh - (self.image_height - overlap)
-            self.margin_left = extra_w // 2
-            self.margin_right = extra_w - self.margin_left
-            self.margin_top = extra_h // 2
-            self.margin_bottom = extra_h - self.margin_top
-        else:
-            if (self.image_width - overlap + 2 * image_margin) % tile_step != 0:
-                raise ValueError()
-            if (self.image_height - overlap + 2 * image_margin) % tile_step != 0:
-                raise ValueError()
-            self.margin_left = self.margin_right = self.margin_top = self.margin_bottom = image_margin
-        self.crops = []
-        for y in range(0, self.image_height + self.margin_top + self.margin_bottom - tile_size + 1, tile_step):
-            for x in range(0, self.image_width + self.margin_left + self.margin_right - tile_size + 1, tile_step):
-                self.crops.append((x, y, tile_size, tile_size))
+        self.margin_left, self.margin_right, xs = _axis_layout(self.image_width, tile_size, tile_step, image_margin)
+        self.margin_top, self.margin_bottom, ys = _axis_layout(self.image_height, tile_size, tile_step, image_margin)
+        self._grid = (len(xs), len(ys))
+        self.crops = [(x, y, tile_size, tile_size) for y in ys for x in xs]                 # row-major, like :93-97
+        self._coverage = None
 
     # ---- host (numpy) API of the reference ---------------------------------------------------------------
+    def _canvas_shape(self, channels):
+        return (self.margin_top + self.image_height + self.margin_bottom,
+                self.margin_left + self.image_width + self.margin_right, channels)
+
     def _padded(self, image, borderType):
-        assert image.shape[0] == self.image_height
-        assert image.shape[1] == self.image_width
+        if image.shape[:2] != (self.image_height, self.image_width):
+            raise AssertionError('image is %s, slicer was built for %dx%d' % (image.shape[:2], self.image_height,
+                                                                           self.image_width))
         if borderType != BORDER_REFLECT101:
             raise ValueError('only BORDER_REFLECT101 is supported')
         pad = [(self.margin_top, self.margin_bottom), (self.margin_left, self.margin_right)] + \
@@ -78,35 +86,40 @@ class ImageSlicer:
         x, y, tw, th = self.crops[slice_index]
         return self._padded(image, borderType)[y:y + th, x:x + tw].copy()
 
+    def _overlap_add(self, canvas, pieces):
+        """canvas[tile window k] += pieces[k], k in crop order (float64: the order fixes the rounding)."""
+        for (x, y, tw, th), piece in zip(self.crops, pieces):
+            canvas[y:y + th, x:x + tw] += piece
+        return canvas
+
+    def coverage(self):
+        """Sum of the fusion weights of every tile covering a padded-image pixel, [Hp, Wp] float64, floored at the
+        float64 epsilon (the divisor of merge, tiles.py:151-157); depends on the geometry only, so computed once."""
+        if self._coverage is None:
+            w = np.asarray(self.compute_weight(self.tile_size))[..., None]
+            cov = self._overlap_add(np.zeros(self._canvas_shape(1), dtype=np.float64), [w] * len(self.crops))
+            self._coverage = np.maximum(cov, np.finfo(np.float64).eps)
+        return self._coverage
+
     def merge(self, tiles, dtype=np.float32):
         if len(tiles) != len(self.crops):
             raise ValueError
-        channels = 1 if len(tiles[0].shape) == 2 else tiles[0].shape[2]
-        target_shape = (self.image_height + self.margin_bottom + self.margin_top,
-                        self.image_width + self.margin_right + self.margin_left, channels)
-        image = np.zeros(target_shape, dtype=np.float64)
-        norm_mask = np.zeros(target_shape, dtype=np.float64)
-        w = np.dstack([self.compute_weight(self.tile_size)] * channels)
-        for tile, (x, y, tw, th) in zip(tiles, self.crops):
-            image[y:y + th, x:x + tw] += tile.reshape(th, tw, channels) * w
-            norm_mask[y:y + th, x:x + tw] += w
-        norm_mask = np.clip(norm_mask, a_min=np.finfo(norm_mask.dtype).eps, a_max=None)
-        normalized = np.divide(image, norm_mask).astype(dtype)
-        crop = normalized[self.margin_top:self.image_height + self.margin_top,
-                          self.margin_left:self.image_width + self.margin_left]
-        assert crop.shape[0] == self.image_height
-        assert crop.shape[1] == self.image_width
-        return crop
+        channels = 1 if tiles[0].ndim == 2 else tiles[0].shape[2]
+        w = np.asarray(self.compute_weight(self.tile_size))[..., None]
+        ts = self.tile_size
+        fused = self._overlap_add(np.zeros(self._canvas_shape(channels), dtype=np.float64),
+                                  (np.reshape(t, (ts, ts, channels)) * w for t in tiles))
+        fused = (fused / self.coverage()).astype(dtype)
+        return fused[self.margin_top:self.margin_top + self.image_height,
+                     self.margin_left:self.margin_left + self.image_width]
 
     def _mean(self, tile_size):
         return np.ones((tile_size, tile_size), dtype=np.float32)
 
     def _pyramid(self, tile_size):
-        w, _, _ = compute_patch_weight_loss(tile_size, tile_size)
-        return w
+        return compute_patch_weight_loss(tile_size, tile_size)[0]
 
     # ---- geometry for the device path -------------------------------------------------------------------------
     def grid(self):
         """(tiles per row, tiles per column) of the regular crop grid."""
-        nx = len(set(c[0] for c in self.crops))
-        return nx, len(self.crops) // nx
+        return self._grid

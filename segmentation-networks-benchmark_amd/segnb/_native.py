@@ -117,8 +117,13 @@ def load():
 
 
 def set_backend_for_testing(backend):
-    """tests only: route ABI calls to an emulator object exposing the same function names."""
+    """tests only: route ABI calls to an emulator object exposing the same function names.  Refused unless the
+    process was started by the test harness (tests/conftest.py exports SEGNB_TEST_HARNESS=1): nothing in the product
+    can switch the HIP library off, by accident or otherwise."""
     global _test_backend
+    if backend is not None and os.environ.get('SEGNB_TEST_HARNESS') != '1':
+        raise RuntimeError('set_backend_for_testing is test infrastructure (SEGNB_TEST_HARNESS=1 not set); the product '
+                           'path runs on libsegnb_hip.so only')
     _test_backend = backend
 
 

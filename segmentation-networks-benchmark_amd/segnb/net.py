@@ -35,7 +35,7 @@ class Tape(object):
         self.flat = FlatParams(module)
         self.flat.ensure(self.rt.device)
         self._cache = {}
-        self._packed_key = None
+        self.pack_key = None
         self.back = []
 
     # ---- per-step bookkeeping ------------------------------------------------------------------------------
@@ -43,9 +43,10 @@ class Tape(object):
         self.flat.ensure(self.rt.device)
         self.train, self.need_grad = train, need_grad
         self.back, self._seq = [], 0
-        key = (sum(p._version for p in self.module.parameters()), self.flat.version, self.flat.flat_p.data_ptr())
-        self.repack = key != self._packed_key
-        self._packed_key = key
+        # weight-packing generation: every ConvOp plan (one per input size) remembers the generation it was packed at,
+        # so a plan first used -- or last used -- under other parameter values is (re)packed on its next use
+        self.pack_key = (sum(p._version for p in self.module.parameters()), self.flat.version,
+                         self.flat.flat_p.data_ptr())
 
     def site(self, tag):
         """Call-site identity = position in the (static) build order."""
@@ -112,8 +113,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     conv = tape.cached(site + '/op', lambda: ConvOp(rt, weight, bias, in_segments, stride, pad, transposed,
                                                     need_dgrad=x.needs_grad, out_hw=out_hw))
     xv = x.v
-    if tape.repack:
+    plan = conv.plan(xv.H, xv.W)
+    if plan.get('packed_key') != tape.pack_key:
         conv.pack(xv.H, xv.W)
+        plan['packed_key'] = tape.pack_key
     Ho, Wo = conv.out_hw(xv.H, xv.W)
     N, Cp, C = xv.N, conv.Cop, conv.Co
     y = tape.view(site + '/y', N, Ho, Wo, Cp)

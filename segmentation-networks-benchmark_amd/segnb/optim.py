@@ -69,15 +69,41 @@ def _stream(flat):
 
 
 class _FlatStateMixin(object):
-    """flat state buffers live on the optimizer (keyed by the FlatParams object); parameters torch would handle
-    itself fall through to the parent class"""
+    """The moments live in flat buffers parallel to FlatParams.flat_p (one launch per step), and are PUBLISHED through
+    ``optimizer.state`` as per-parameter views of those buffers plus torch's ``step`` entry, so ``state_dict()`` /
+    ``load_state_dict()`` round-trip exactly like torch.optim's (the reference's save_snapshot / restore_snapshot,
+    torch_train.py:308-330, checkpoint ``optimizer.state_dict()``).  State loaded from a checkpoint -- or produced by
+    the parent class before the flat path became eligible -- is adopted: copied into the flat buffers on the next step.
+    Parameters torch has to handle itself fall through to the parent class."""
 
     def _flat_state(self, flat, names):
         st = self.__dict__.setdefault('_segnb_state', {})
         key = id(flat)
-        if key not in st or st[key]['p'].data_ptr() != flat.flat_p.data_ptr():
-            st[key] = dict(p=flat.flat_p, step=0, **{n: torch.zeros_like(flat.flat_p) for n in names})
-        return st[key]
+        ent = st.get(key)
+        if ent is None or ent['p'].data_ptr() != flat.flat_p.data_ptr():
+            ent = dict(p=flat.flat_p, step=torch.zeros((), dtype=torch.float32),
+                       **{n: torch.zeros_like(flat.flat_p) for n in names})
+            st[key] = ent
+        params = list(flat.module.parameters())
+        first = self.state.get(params[0])
+        n0 = names[0]
+        synced = (first is not None and first.get('step') is ent['step'] and n0 in first and
+                  first[n0].data_ptr() == ent[n0].data_ptr() + 4 * flat._off[id(params[0])][0])
+        if not synced:
+            for p in params:
+                ps = self.state[p]
+                off, n = flat._off[id(p)]
+                for name in names:
+                    view = ent[name][off:off + n].view(p.shape)
+                    cur = ps.get(name)
+                    if cur is not None and cur.data_ptr() != view.data_ptr():
+                        view.copy_(cur)                      # adopt loaded / foreign state
+                    ps[name] = view
+                cur = ps.get('step')
+                if cur is not None and cur is not ent['step']:
+                    ent['step'].fill_(float(cur))
+                ps['step'] = ent['step']                     # ONE shared counter tensor (state_dict copies it per param)
+        return ent
 
     def _step_groups(self, closure, handler):
         loss = None
@@ -104,6 +130,7 @@ class RMSprop(_FlatStateMixin, torch.optim.RMSprop):
             if flat is None:
                 return False
             st = self._flat_state(flat, ('square_avg',))
+            st['step'] += 1
             nv.call('segnb_rmsprop_step', nv.ptr(flat.flat_p), nv.ptr(flat.flat_g), nv.ptr(st['square_avg']), flat.total,
                     float(g['lr']), float(g['alpha']), float(g['eps']), _stream(flat))
             flat.version += 1
@@ -123,7 +150,7 @@ class Adam(_FlatStateMixin, torch.optim.Adam):
             b1, b2 = g['betas']
             nv.call('segnb_adam_step', nv.ptr(flat.flat_p), nv.ptr(flat.flat_g), nv.ptr(st['exp_avg']),
                     nv.ptr(st['exp_avg_sq']), flat.total, float(g['lr']), float(b1), float(b2), float(g['eps']),
-                    st['step'], _stream(flat))
+                    int(st['step']), _stream(flat))
             flat.version += 1
             return True
         return self._step_groups(closure, handle)

@@ -15,6 +15,7 @@ for p in (PKG, ROOT):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+os.environ['SEGNB_TEST_HARNESS'] = '1'      # lets tests install the ABI emulator (segnb._native.set_backend_for_testing)
 
 
 def pytest_configure(config):

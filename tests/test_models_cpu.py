@@ -77,6 +77,32 @@ def test_linknet34_oracle_and_product_vs_reference_golden(golden_dir):
     mc.check_product_golden(m, g, 'cpu')
 
 
+def test_two_input_sizes_without_a_parameter_update():
+    """Packed weights are per input size (ConvOp.plan): a second size with NO optimizer step in between must pack its
+    own plan, and going back to the first size after a step must see the new weights (net.py Tape.begin)."""
+    from lib.models.unet16 import UNet16
+    torch.manual_seed(0)
+    m = UNet16(num_filters=4).set_compute_dtype('f32').eval()
+    g = torch.Generator().manual_seed(1)
+    xa, xb = torch.randn(1, 3, 32, 32, generator=g), torch.randn(1, 3, 64, 32, generator=g)
+    with torch.no_grad():
+        ya1 = m(xa)
+        yb1 = m(xb)
+    fresh = UNet16(num_filters=4).set_compute_dtype('f32').eval()
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        torch.testing.assert_close(yb1, fresh(xb), rtol=0, atol=0)
+        torch.testing.assert_close(ya1, fresh(xa), rtol=0, atol=0)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)
+    fresh2 = UNet16(num_filters=4).set_compute_dtype('f32').eval()
+    fresh2.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        torch.testing.assert_close(m(xb), fresh2(xb), rtol=0, atol=0)
+        torch.testing.assert_close(m(xa), fresh2(xa), rtol=0, atol=0)     # A's plan was packed before the update
+
+
 def test_unet16_default_parameter_count():
     from lib.models.unet16 import UNet16
     assert sum(p.numel() for p in UNet16().parameters()) == 32202337     # SURVEY 8a a5

@@ -105,8 +105,87 @@ def test_predict_tiled_device_flow_on_emulator(shape):
     img = rng.randn(*shape).astype(np.float32)
     S = 16
     model = _Lin(S)
-    got = predict_tiled(img, model, S, batch_size=5)
+    got = predict_tiled(img, model, None, S, 5)
     with torch.no_grad():
         ref = tiles_ref.predict_tiled(img, lambda x: model(torch.from_numpy(x)).numpy(), S, 5)
     assert got.shape == (shape[0], shape[1], 1)
     np.testing.assert_allclose(got, ref.reshape(got.shape), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize('shape', [(50, 71, 3), (64, 70, 3), (64, 96, 3)])
+def test_predict_full_flow(shape):
+    """segnb.tiled.predict_full == the oracle's restatement of inria_submit.predict_full (:217-234), incl. the
+    replicate padding to a multiple of 32 and its full-extra-block quirk when only one side needs padding."""
+    from segnb.tiled import predict_full, pad_to_multiple
+    rng = np.random.RandomState(5)
+    img = rng.randn(*shape).astype(np.float32)
+    torch.manual_seed(1)
+    model = torch.nn.Conv2d(3, 1, 3, padding=1)
+    got = predict_full(img, model, None)
+    with torch.no_grad():
+        ref = tiles_ref.predict_full(img, lambda x: model(torch.from_numpy(x)).numpy())
+    assert got.shape == shape[:2]
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-7)
+    padded, pads = pad_to_multiple(img, 32)
+    ref_padded, ref_pads = tiles_ref.pad(img, 32)
+    assert pads == ref_pads and np.array_equal(padded, ref_padded)
+
+
+def test_predict_tiled_reference_positional_order():
+    """inria_submit.py:237: predict_tiled(image, model, test_transform, patch_size, batch_size) -- the reference's own
+    call site (:303) binds positionally."""
+    import inspect
+    from segnb.tiled import predict_tiled
+    assert list(inspect.signature(predict_tiled).parameters)[:5] == ['image', 'model', 'test_transform', 'patch_size',
+                                                                     'batch_size']
+    rng = np.random.RandomState(2)
+    img = (rng.rand(40, 40, 3) * 255).astype(np.uint8)
+    model = _Lin(16)
+    norm = lambda im: ((im.astype(np.float32) / 255.0 - 0.5) / 0.25, None)       # (image, mask) like the reference's
+    got = predict_tiled(img, model, norm, 16, 4)
+    ref = predict_tiled(norm(img)[0], model, None, 16, 4)
+    assert np.array_equal(got, ref)
+
+
+def _tiled_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, 'segmentation-networks-benchmark_amd'), root):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from oracle import abi_emulator
+    from segnb import _native as nv
+    from segnb import dist as sdist
+    from segnb.tiled import predict_tiled
+    nv.set_backend_for_testing(abi_emulator.AbiEmulator())
+    sdist.init_from_env(backend='gloo')
+    rng = np.random.RandomState(2)
+    img = rng.randn(50, 71, 3).astype(np.float32)
+    got = predict_tiled(img, _Lin(16), None, 16, 5)
+    np.save(os.path.join(out_dir, 'rank%d.npy' % rank), got)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_predict_tiled_sharded_over_two_ranks(tmp_path):
+    """cfg5 partitioning: the (tile, transform) list split over 2 ranks (gloo) + all-gather of the logits
+    == the single-process mask, bit for bit, on every rank."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    from segnb.tiled import item_range, predict_tiled
+    assert item_range(10, 4, 3) == (9, 10, 3) and item_range(10, 4, 0) == (0, 3, 3) and item_range(2, 4, 3) == (2, 2, 1)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_tiled_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.RandomState(2)
+    img = rng.randn(50, 71, 3).astype(np.float32)
+    single = predict_tiled(img, _Lin(16), None, 16, 5)
+    for r in range(2):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), 'rank%d.npy' % r)), single)

@@ -30,7 +30,7 @@ def test_gather_merge_kernels_vs_oracle(shape, S):
     rng = np.random.RandomState(3)
     img = rng.randn(*shape).astype(np.float32)
     model = _Lin(S, shape[2]).cuda()
-    got = predict_tiled(img, model, S, batch_size=7)
+    got = predict_tiled(img, model, None, S, 7)
     cpu = _Lin(S, shape[2])
     with torch.no_grad():
         ref = tiles_ref.predict_tiled(img, lambda x: cpu(torch.from_numpy(x)).numpy(), S, 7)
@@ -47,7 +47,7 @@ def test_predict_tiled_zf_unet_eval_and_throughput():
     model = ZF_UNET(filters=8).cuda().eval()
     rng = np.random.RandomState(4)
     img = rng.randn(200, 300, 3).astype(np.float32)
-    got = predict_tiled(img, model, 64, batch_size=16)
+    got = predict_tiled(img, model, None, 64, 16)
 
     def logits_fn(x):
         with torch.no_grad():
@@ -56,10 +56,10 @@ def test_predict_tiled_zf_unet_eval_and_throughput():
     np.testing.assert_allclose(got[..., 0], ref[..., 0] if ref.ndim == 3 else ref, rtol=1e-5, atol=1e-5)
     big = rng.randn(1024, 1024, 3).astype(np.float32)
     full = ZF_UNET().cuda().eval()
-    predict_tiled(big, full, 256, batch_size=32)
+    predict_tiled(big, full, None, 256, 32)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mask = predict_tiled(big, full, 256, batch_size=32)
+    mask = predict_tiled(big, full, None, 256, 32)
     dt = time.perf_counter() - t0
     assert mask.shape == (1024, 1024, 1) and np.isfinite(mask).all() and 0.0 <= mask.min() and mask.max() <= 1.0
     print('predict_tiled 1024x1024, 256-px tiles, D4 TTA, ZF_UNET bf16: %.1f ms (%.0f tile-forwards/s)'

@@ -121,3 +121,45 @@ def test_flat_optimizers_match_torch(name):
         for rp, p in zip(ref_params, model.parameters()):
             assert torch.allclose(p.detach(), rp.detach(), rtol=1e-5, atol=1e-6), (name, it)
     assert getattr(opt, '_segnb_state', None) is not None or name == 'sgd'
+
+
+@pytest.mark.parametrize('name', ['rms', 'adam'])
+def test_flat_optimizer_state_dict_round_trip(name):
+    """optimizer.state_dict() of the one-launch optimizers carries the moments and the step count (views of the flat
+    buffers), equals torch.optim's after the same steps, and a run resumed from it continues bit-identically
+    (restore_snapshot, torch_train.py:319-330).  ADVICE r1: the state used to live outside optimizer.state."""
+    import torch_train as TT
+    from lib.models.zf_unet import ZF_UNET
+    from lib.losses import BCEWithSigmoidLoss
+    x, y = torch.randn(2, 3, 32, 32), (torch.rand(2, 1, 32, 32) > 0.7).long()
+
+    def run(model, opt, steps):
+        for _ in range(steps):
+            opt.zero_grad()
+            (2 * BCEWithSigmoidLoss()(model(x), y)).backward()
+            opt.step()
+
+    torch.manual_seed(0)
+    a = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    oa = TT.get_optimizer(name, a.parameters(), 1e-2)
+    run(a, oa, 2)
+    sd = oa.state_dict()
+    nparams = len(list(a.parameters()))
+    assert len(sd['state']) == nparams
+    keys = {'rms': {'step', 'square_avg'}, 'adam': {'step', 'exp_avg', 'exp_avg_sq'}}[name]
+    assert set(sd['state'][0].keys()) == keys and float(sd['state'][0]['step']) == 2.0
+    # resume in a fresh model + optimizer from (model.state_dict, optimizer.state_dict)
+    import copy
+    msd, osd = copy.deepcopy(a.state_dict()), copy.deepcopy(sd)
+    b = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    b.load_state_dict(msd)
+    ob = TT.get_optimizer(name, b.parameters(), 1e-2)
+    ob.load_state_dict(osd)
+    run(a, oa, 2)
+    run(b, ob, 2)
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(pa, pb), n
+    assert float(ob.state_dict()['state'][0]['step']) == 4.0
+    mom = 'square_avg' if name == 'rms' else 'exp_avg_sq'
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(oa.state[pa][mom], ob.state[pb][mom])

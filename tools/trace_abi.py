@@ -1,3 +1,4 @@
+import os
 """debug tool: run one training step of a model on the ABI emulator (CPU) and on the GPU, checksumming every
 tensor argument after every ABI call; report the first calls whose results differ."""
 import sys, os
@@ -87,6 +88,7 @@ def run(device):
     return log
 
 
+os.environ['SEGNB_TEST_HARNESS'] = '1'       # a tool, not the product: allowed to install the emulator
 nv.set_backend_for_testing(abi_emulator.AbiEmulator())
 ref = run('cpu')
 nv.set_backend_for_testing(None)
