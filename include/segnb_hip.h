@@ -276,12 +276,14 @@ typedef struct {
     float eps;         /* 1e-7 of JaccardLoss / DiceLoss */
     float norm;        /* divisor of the weighted sum */
     int focal_mean;    /* FocalLossBinary size_average */
+    int bce_sum;       /* BCEWithSigmoidLoss(size_average=False): sum instead of mean (losses.py:47,53) */
+    float focal_gamma; /* FocalLossBinary gamma (losses.py:84; 2 = the reference default) */
 } segnb_loss_spec;
 
 /* sums fp64 [8]: sum bce2, sum focal, sum p*t, sum p, sum t, #correct@0.5, #pixels, (unused);
  * accumulated atomically, caller zeroes.  A data-parallel job all-reduces these 8 doubles. */
-int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, double* sums,
-                          segnb_stream_t stream);
+int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, float focal_gamma,
+                          double* sums, segnb_stream_t stream);
 /* out fp32 [8]: loss, soft IoU (metrics.py:14-20), pixel accuracy, GI, GU, bce mean, -, - */
 int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, float* out,
                             segnb_stream_t stream);
@@ -290,6 +292,24 @@ int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, flo
 int segnb_seg_loss_bwd(const float* logits, const long long* target, long long n,
                        const double* sums, const float* fin, const segnb_loss_spec* spec,
                        const float* grad_out, float* dlogits, segnb_stream_t stream);
+
+/* reduce=False forms (BCEWithSigmoidLoss(reduce=False), losses.py:47-53): per-pixel loss map, kind 0 = double-sigmoid
+ * BCE element, 1 = focal element, and its backward dlogits = grad_out[i] * d(map[i])/d(logits[i]) */
+int segnb_seg_loss_map(const float* logits, const long long* target, long long n, int kind, float gamma,
+                       float* out, segnb_stream_t stream);
+int segnb_seg_loss_map_bwd(const float* logits, const long long* target, long long n, int kind, float gamma,
+                           const float* grad_out, float* dlogits, segnb_stream_t stream);
+
+/* *out = max |x[i]| over a flat, 16-byte aligned fp32 buffer: the gradient-explosion monitor of
+ * torch_train.py:199-205 (there: one reduction and one host sync per parameter tensor) as ONE launch over the flat
+ * gradient buffer. */
+int segnb_absmax_f32(const float* x, long long n, float* out, segnb_stream_t stream);
+
+/* PRCurveMeter.update (lib/train_utils.py:109-125): hist[c][b] += #pixels of target class c (0 / non-zero) whose
+ * sigmoid(logit) exceeds exactly b of the `nthr` ascending thresholds; hist: unsigned 64-bit [2][nthr + 1],
+ * accumulated (caller zeroes).  tp/fp at threshold i = suffix sums over b > i. */
+int segnb_pr_histogram(const float* logits, const long long* target, long long n, const float* thresholds,
+                       int nthr, unsigned long long* hist, segnb_stream_t stream);
 
 /* plain SGD p -= lr * g over a flat buffer (torch.optim.SGD of torch_train.py:71) */
 int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream);

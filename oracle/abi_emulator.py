@@ -497,21 +497,27 @@ class AbiEmulator(object):
 
     # ------------------------------------------------------------------------------------------ loss
     @staticmethod
-    def _terms(x, t):
+    def _terms(x, t, gamma=2.0):
         ls = torch.nn.functional.logsigmoid(x)
         p = torch.exp(ls)
         e = -t * ls + torch.log1p(p)
         de = (1 - p) * (p / (1 + p) - t)
         pt = torch.exp(-e)
         om = 1 - pt
-        f = om * om * e
-        df = (2 * om * pt * e + om * om) * de
+        if gamma == 2.0:
+            f = om * om * e
+            df = (2 * om * pt * e + om * om) * de
+        else:
+            pg1 = om.clamp_min(1e-38).pow(gamma - 1.0)
+            pg = pg1 * om
+            f = pg * e
+            df = (gamma * pg1 * pt * e + pg) * de
         return p, e, de, f, df
 
-    def segnb_seg_loss_reduce(self, logits, target, n, sums, stream):
+    def segnb_seg_loss_reduce(self, logits, target, n, focal_gamma, sums, stream):
         x = _mem(logits, n, torch.float32)
         t = _mem(target, n, torch.int64).float()
-        p, e, _, f, _ = self._terms(x, t)
+        p, e, _, f, _ = self._terms(x, t, float(focal_gamma))
         S = _mem(sums, 8, torch.float64)
         S[0] += e.double().sum()
         S[1] += f.double().sum()
@@ -526,7 +532,7 @@ class AbiEmulator(object):
         sp = _geom(spec)
         S = _mem(sums, 8, torch.float64).tolist()
         n, I, U = S[6], S[2], S[3] + S[4]
-        bce = S[0] / n
+        bce = S[0] if sp.bce_sum else S[0] / n
         focal = S[1] / n if sp.focal_mean else S[1]
         eps, sm = float(sp.eps), float(sp.smooth)
         Dj, Ds, Dd = U - I + eps, U - I + sm, U + eps
@@ -543,11 +549,36 @@ class AbiEmulator(object):
         t = _mem(target, n, torch.int64).float()
         F = _mem(fin, 8, torch.float32)
         go = (float(_mem(grad_out, 1, torch.float32)[0]) if grad_out is not None else 1.0) / sp.norm
-        p, _, de, _, df = self._terms(x, t)
+        p, _, de, _, df = self._terms(x, t, float(sp.focal_gamma))
         inv_n = 1.0 / float(F[6])
         wf = sp.w_focal * inv_n if sp.focal_mean else sp.w_focal
-        dx = go * (sp.w_bce * inv_n * de + wf * df + p * (1 - p) * (t * float(F[3]) + float(F[4])))
+        wb = sp.w_bce if sp.bce_sum else sp.w_bce * inv_n
+        dx = go * (wb * de + wf * df + p * (1 - p) * (t * float(F[3]) + float(F[4])))
         _mem(dlogits, n, torch.float32).copy_(dx)
+        return 0
+
+    def segnb_seg_loss_map(self, logits, target, n, kind, gamma, out, stream):
+        _, e, _, f, _ = self._terms(_mem(logits, n, torch.float32), _mem(target, n, torch.int64).float(), float(gamma))
+        _mem(out, n, torch.float32).copy_(e if kind == 0 else f)
+        return 0
+
+    def segnb_seg_loss_map_bwd(self, logits, target, n, kind, gamma, grad_out, dlogits, stream):
+        _, _, de, _, df = self._terms(_mem(logits, n, torch.float32), _mem(target, n, torch.int64).float(), float(gamma))
+        _mem(dlogits, n, torch.float32).copy_(_mem(grad_out, n, torch.float32) * (de if kind == 0 else df))
+        return 0
+
+    def segnb_absmax_f32(self, x, n, out, stream):
+        _mem(out, 1, torch.float32)[0] = _mem(x, n, torch.float32).abs().max()
+        return 0
+
+    def segnb_pr_histogram(self, logits, target, n, thresholds, nthr, hist, stream):
+        """train_utils.py:109-125 restated as a histogram: bucket = #thresholds strictly below sigmoid(x)"""
+        p = torch.exp(torch.nn.functional.logsigmoid(_mem(logits, n, torch.float32)))
+        t = _mem(target, n, torch.int64) != 0
+        b = torch.bucketize(p, _mem(thresholds, nthr, torch.float32), right=False)
+        H = _mem(hist, 2 * (nthr + 1), torch.int64).view(2, nthr + 1)
+        H[0] += torch.bincount(b[~t], minlength=nthr + 1)
+        H[1] += torch.bincount(b[t], minlength=nthr + 1)
         return 0
 
     def segnb_tune(self, key, value):

@@ -147,7 +147,7 @@ struct PixTerms {
     float df;   // d f / d x
 };
 
-__device__ __forceinline__ PixTerms pix_terms(float x, float t) {
+__device__ __forceinline__ PixTerms pix_terms(float x, float t, float gamma = 2.f) {
     PixTerms o;
     // logsigmoid(x) = min(x,0) - log1p(exp(-|x|)), as ATen computes it
     const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
@@ -157,20 +157,29 @@ __device__ __forceinline__ PixTerms pix_terms(float x, float t) {
     o.de = (1.f - p) * (p / (1.f + p) - t);
     const float pt = expf(-o.e);
     const float om = 1.f - pt;
-    o.f = om * om * o.e;
-    o.df = (2.f * om * pt * o.e + om * om) * o.de;
+    if (gamma == 2.f) {                        // the reference default (losses.py:84): exact products, no powf
+        o.f = om * om * o.e;
+        o.df = (2.f * om * pt * o.e + om * om) * o.de;
+    } else if (om > 0.f) {                     // (1-pt)^gamma * e;  d/dx = (gamma (1-pt)^(gamma-1) pt e + (1-pt)^gamma) de
+        const float pg1 = powf(om, gamma - 1.f), pg = pg1 * om;
+        o.f = pg * o.e;
+        o.df = (gamma * pg1 * pt * o.e + pg) * o.de;
+    } else {
+        o.f = gamma == 0.f ? o.e : 0.f;
+        o.df = gamma == 0.f ? o.de : 0.f;
+    }
     return o;
 }
 
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ x,
                                                           const long long* __restrict__ tg, long long n,
-                                                          double* __restrict__ sums, int vec) {
+                                                          double* __restrict__ sums, int vec, float gamma) {
     double s[6] = {0, 0, 0, 0, 0, 0};
     auto term = [&](float xv, long long tgv) {
         const float t = tgv != 0 ? 1.f : 0.f;
         // the reference multiplies by target.float(): any integer label value; binary masks are 0/1
         const float tf = (float)tgv;
-        const PixTerms q = pix_terms(xv, tf);
+        const PixTerms q = pix_terms(xv, tf, gamma);
         s[0] += q.e;
         s[1] += q.f;
         s[2] += q.p * tf;
@@ -213,7 +222,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ sums, segnb_loss
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double n = sums[6];
     const double I = sums[2], U = sums[3] + sums[4];
-    const double bce = sums[0] / n;
+    const double bce = sp.bce_sum ? sums[0] : sums[0] / n;
     const double focal = sp.focal_mean ? sums[1] / n : sums[1];
     const double eps = (double)sp.eps, sm = (double)sp.smooth;
     const double Dj = U - I + eps, Ds = U - I + sm, Dd = U + eps;
@@ -244,11 +253,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     const float go = (grad_out != nullptr ? grad_out[0] : 1.f) / sp.norm;
     const float GI = fin[3], GU = fin[4];
     const float inv_n = 1.f / fin[6];   // GLOBAL pixel count (== n on one GPU; all-reduced sums in a DP job)
-    const float wb = sp.w_bce * inv_n;
+    const float wb = sp.bce_sum ? sp.w_bce : sp.w_bce * inv_n;
     const float wf = sp.focal_mean ? sp.w_focal * inv_n : sp.w_focal;
     auto grad = [&](float xv, long long tgv) {
         const float tf = (float)tgv;
-        const PixTerms q = pix_terms(xv, tf);
+        const PixTerms q = pix_terms(xv, tf, sp.focal_gamma);
         const float dp = q.p * (1.f - q.p);
         return go * (wb * q.de + wf * q.df + dp * (tf * GI + GU));
     };
@@ -267,6 +276,68 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     for (long long i = 4 * n4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
         dx[i] = grad(x[i], tg[i]);
+}
+
+
+// reduce=False forms (losses.py:53 with reduce=False): the per-pixel loss map and its backward
+__global__ __launch_bounds__(256) void loss_map_kernel(const float* __restrict__ x, const long long* __restrict__ tg,
+                                                       long long n, int kind, float gamma, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const PixTerms q = pix_terms(x[i], (float)tg[i], gamma);
+        out[i] = kind == 0 ? q.e : q.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_map_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ tg,
+                                                           long long n, int kind, float gamma,
+                                                           const float* __restrict__ gout, float* __restrict__ dx) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const PixTerms q = pix_terms(x[i], (float)tg[i], gamma);
+        dx[i] = gout[i] * (kind == 0 ? q.de : q.df);
+    }
+}
+
+// max |x| over a flat fp32 buffer (the gradient-explosion monitor of torch_train.py:199-205: one launch over the
+// flat gradient buffer instead of one reduction + one host sync per parameter tensor).  |x| as uint bits is monotone.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    const long long n4 = n / 4;                      // flat buffers are 16-byte aligned (FlatParams)
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n4; j += (long long)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(x)[j];
+        m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+    }
+    for (long long i = 4 * n4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(out, m);
+}
+
+// PRCurveMeter.update (lib/train_utils.py:109-125): per pixel, bucket = number of thresholds strictly below
+// sigmoid(x); one histogram per class of the target.  hist: [2][nthr + 1] unsigned 64-bit, accumulated.
+__global__ __launch_bounds__(256) void pr_hist_kernel(const float* __restrict__ x, const long long* __restrict__ tg,
+                                                      long long n, const float* __restrict__ thr, int nthr,
+                                                      unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned sm[];                 // [2][nthr + 1] counters, then the thresholds
+    unsigned* cnt = sm;
+    float* th = reinterpret_cast<float*>(sm + 2 * (nthr + 1));
+    for (int i = threadIdx.x; i < 2 * (nthr + 1); i += blockDim.x) cnt[i] = 0;
+    for (int i = threadIdx.x; i < nthr; i += blockDim.x) th[i] = thr[i];
+    __syncthreads();
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[i];
+        const float p = expf(fminf(xv, 0.f) - log1pf(expf(-fabsf(xv))));       // the loss kernels' sigmoid
+        int lo = 0, hi = nthr;                       // first index with th[idx] >= p  ==  #thresholds < p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (th[mid] < p) lo = mid + 1; else hi = mid;
+        }
+        atomicAdd(&cnt[(tg[i] != 0 ? nthr + 1 : 0) + lo], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * (nthr + 1); i += blockDim.x)
+        if (cnt[i]) atomicAdd(&hist[i], (unsigned long long)cnt[i]);
 }
 
 }  // namespace
@@ -326,15 +397,15 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
     return 0;
 }
 
-extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, double* sums,
-                                     segnb_stream_t stream) {
+extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, float focal_gamma,
+                                     double* sums, segnb_stream_t stream) {
     SEGNB_CHECK_ARG(logits && target && sums && n > 0, "bad arguments");
     // few blocks: every block ends in six double atomics on the SAME six addresses (1568 blocks = 9.4 k serialised
     // atomics were most of the 27 us)
     int grid = ceil_div(n, 256 * 4);
     if (grid > 512) grid = 512;
     const int vec = (((uintptr_t)logits | (uintptr_t)target) & 15) == 0;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, sums, vec);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, sums, vec, focal_gamma);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
@@ -358,6 +429,53 @@ extern "C" int segnb_seg_loss_bwd(const float* logits, const long long* target, 
     const int vec = (((uintptr_t)logits | (uintptr_t)target | (uintptr_t)dlogits) & 15) == 0;
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, fin, *spec,
                        grad_out, dlogits, vec);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_map(const float* logits, const long long* target, long long n, int kind, float gamma,
+                                  float* out, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(logits && target && out && n > 0 && (kind == 0 || kind == 1), "bad arguments");
+    int grid = ceil_div(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(loss_map_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, kind, gamma, out);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_map_bwd(const float* logits, const long long* target, long long n, int kind, float gamma,
+                                      const float* grad_out, float* dlogits, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(logits && target && grad_out && dlogits && n > 0 && (kind == 0 || kind == 1), "bad arguments");
+    int grid = ceil_div(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(loss_map_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, kind,
+                       gamma, grad_out, dlogits);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_absmax_f32(const float* x, long long n, float* out, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0, "bad arguments");
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        segnb_set_error("segnb_absmax_f32: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int grid = ceil_div(n, 256 * 16);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, reinterpret_cast<unsigned*>(out));
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_pr_histogram(const float* logits, const long long* target, long long n, const float* thresholds,
+                                  int nthr, unsigned long long* hist, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(logits && target && thresholds && hist && n > 0 && nthr > 0 && nthr <= 4096, "bad arguments");
+    int grid = ceil_div(n, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    const int smem = (2 * (nthr + 1) + nthr) * 4;
+    hipLaunchKernelGGL(pr_hist_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, logits, target, n, thresholds,
+                       nthr, hist);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

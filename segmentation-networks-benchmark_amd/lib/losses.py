@@ -10,7 +10,7 @@ Each forward is two kernel launches (global sums + finalize), backward one; noth
 """
 from torch.nn.modules.loss import _Loss
 
-from segnb.seglosses import make_spec, seg_loss
+from segnb.seglosses import make_spec, seg_loss, seg_loss_map
 
 
 class DiceLoss(_Loss):
@@ -43,13 +43,14 @@ class SmoothJaccardLoss(_Loss):
 class BCEWithSigmoidLoss(_Loss):
     def __init__(self, size_average=True, reduce=True):
         super(BCEWithSigmoidLoss, self).__init__()
-        if not (size_average and reduce):
-            raise ValueError('only the mean-reduced form is used by the reference (torch_train.py:95-96)')
         self.size_average, self.reduce = size_average, reduce
-        self._spec = make_spec(w_bce=1.0)
 
     def forward(self, outputs, targets):
-        return seg_loss(outputs, targets, self._spec)
+        # the legacy (size_average, reduce) pair of F.binary_cross_entropy_with_logits (losses.py:53):
+        # reduce=False -> per-pixel map; else mean (size_average) or sum
+        if not self.reduce:
+            return seg_loss_map(outputs, targets, 0)
+        return seg_loss(outputs, targets, make_spec(w_bce=1.0, bce_sum=0 if self.size_average else 1))
 
 
 class BCEWithLogitsLossAndSmoothJaccard(_Loss):
@@ -84,10 +85,10 @@ class BCEAndDiceLoss(_Loss):
 class FocalLossBinary(_Loss):
     def __init__(self, gamma=2, size_average=True, reduce=True):
         super(FocalLossBinary, self).__init__()
-        if gamma != 2:
-            raise ValueError('the fused kernel implements gamma = 2 (the reference default, losses.py:84)')
         self.gamma = gamma
         self.size_average, self.reduce = size_average, reduce
 
     def forward(self, outputs, targets):
-        return seg_loss(outputs, targets, make_spec(w_focal=1.0, focal_mean=1 if self.size_average else 0))
+        # `reduce` is accepted and ignored, as in the reference (losses.py:97-101 always reduces)
+        return seg_loss(outputs, targets, make_spec(w_focal=1.0, focal_mean=1 if self.size_average else 0,
+                                                    focal_gamma=self.gamma))

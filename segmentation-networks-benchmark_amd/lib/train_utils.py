@@ -1,6 +1,6 @@
 """Training helpers -- drop-in for the reference's ``lib.train_utils`` (/root/reference/lib/train_utils.py:14-125):
 ``AverageMeter``, ``find_optimal_lr``, ``auto_file``, ``PRCurveMeter`` with the same names, signatures and
-results.  ``PRCurveMeter.update`` is one device histogram instead of 127 host passes over the prediction map."""
+results.  ``PRCurveMeter.update`` is one device histogram kernel instead of 127 host passes over the prediction map."""
 import glob
 import os
 
@@ -81,21 +81,29 @@ class PRCurveMeter(object):
             a.fill(0)
 
     def update(self, y_pred, y_true):
-        p = torch.sigmoid(y_pred.detach().float()).reshape(-1)
-        t = (y_true.reshape(-1) != 0)
-        thr = torch.from_numpy(self.thresholds).to(p.device)
-        # number of thresholds strictly below p  ==  number of thresholds the pixel is predicted positive at
-        b = torch.bucketize(p, thr, right=False)
+        """One device histogram launch (segnb_pr_histogram): bucket b of a pixel = number of thresholds strictly below
+        sigmoid(logit) = number of thresholds it is predicted positive at; the 127 confusion matrices of the
+        reference's threshold loop (train_utils.py:113-125) are suffix sums of the two class histograms."""
+        from segnb import _native as nv
+        x = y_pred.detach().contiguous().float().reshape(-1)
+        t = y_true.detach().reshape(-1)
+        if t.dtype != torch.int64:
+            t = t.to(torch.int64)
+        t = t.contiguous()
         n = self.n_thresholds
-        hp = torch.bincount(b[t], minlength=n + 1).double()       # positives per bucket
-        hn = torch.bincount(b[~t], minlength=n + 1).double()
+        thr = torch.from_numpy(self.thresholds).to(x.device)
+        hist = torch.zeros((2, n + 1), dtype=torch.int64, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
+        nv.call('segnb_pr_histogram', nv.ptr(x), nv.ptr(t), x.numel(), nv.ptr(thr), n, nv.ptr(hist), st)
+        h = hist.cpu().numpy().astype(np.uint64)
+        hn, hp = h[0], h[1]
         # predicted positive at threshold i  <=>  bucket > i
-        tp = hp.flip(0).cumsum(0).flip(0)[1:]
-        fp = hn.flip(0).cumsum(0).flip(0)[1:]
-        self.tp += tp.cpu().numpy().astype(np.uint64)
-        self.fp += fp.cpu().numpy().astype(np.uint64)
-        self.fn += (hp.sum() - tp).cpu().numpy().astype(np.uint64)
-        self.tn += (hn.sum() - fp).cpu().numpy().astype(np.uint64)
+        tp = hp[::-1].cumsum()[::-1][1:]
+        fp = hn[::-1].cumsum()[::-1][1:]
+        self.tp += tp
+        self.fp += fp
+        self.fn += hp.sum() - tp
+        self.tn += hn.sum() - fp
 
     def precision(self):
         return np.divide(self.tp, self.tp + self.fp)

@@ -37,7 +37,7 @@ class LossSpec(ctypes.Structure):
     """segnb_loss_spec"""
     _fields_ = [('w_bce', c_float), ('w_focal', c_float), ('w_jaccard', c_float), ('w_sjaccard', c_float),
                 ('w_dice', c_float), ('smooth', c_float), ('eps', c_float), ('norm', c_float),
-                ('focal_mean', c_int)]
+                ('focal_mean', c_int), ('bce_sum', c_int), ('focal_gamma', c_float)]
 
 
 _P = c_void_p
@@ -75,7 +75,11 @@ SIGNATURES = {
                            _P],
     'segnb_head_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     'segnb_head_bwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P],
-    'segnb_seg_loss_reduce': [_P, _P, c_ll, _P, _P],
+    'segnb_seg_loss_reduce': [_P, _P, c_ll, c_float, _P, _P],
+    'segnb_seg_loss_map': [_P, _P, c_ll, c_int, c_float, _P, _P],
+    'segnb_seg_loss_map_bwd': [_P, _P, c_ll, c_int, c_float, _P, _P, _P],
+    'segnb_absmax_f32': [_P, c_ll, _P, _P],
+    'segnb_pr_histogram': [_P, _P, c_ll, _P, c_int, _P, _P],
     'segnb_seg_loss_finalize': [_P, ctypes.POINTER(LossSpec), _P, _P],
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_tune': [ctypes.c_char_p, c_int],

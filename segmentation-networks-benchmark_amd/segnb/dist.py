@@ -60,8 +60,18 @@ class DataParallel(object):
         self._pending = []
         self._done_upto = None
         if self.active:
-            seglosses.sums_allreduce_hook = self._allreduce_sums
-            seglosses.grad_scale = float(self.ws)
+            seglosses.DataParallelHooks.sums_allreduce = self._allreduce_sums
+            seglosses.DataParallelHooks.grad_scale = float(self.ws)
+
+    def detach(self):
+        """Undo __init__: remove the model's hooks and the loss-path hooks (a process that goes on to run the same
+        model outside the job -- validation on rank 0, a second DataParallel -- must not keep all-reducing)."""
+        for name in ('_grad_sync_hook', '_grad_ready_hook'):
+            if getattr(self.model, name, None) is not None:
+                delattr(self.model, name)
+        if self.active:
+            seglosses.DataParallelHooks.reset()
+        self.active = False
 
     def __call__(self, *a, **k):
         return self.model(*a, **k)

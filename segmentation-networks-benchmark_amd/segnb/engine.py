@@ -590,6 +590,14 @@ class FlatParams(object):
         off, n = self._off[id(p)]
         return self.flat_g[off:off + n].view(p.shape)
 
+    def grad_absmax(self):
+        """max |g| over every parameter gradient, as a 0-dim device tensor: ONE launch over the flat gradient buffer
+        (the reference loops over named_parameters with a reduction and a host sync per tensor, torch_train.py:199-203)."""
+        out = torch.zeros((), dtype=torch.float32, device=self.flat_g.device)
+        st = torch.cuda.current_stream(self.flat_g.device).cuda_stream if self.flat_g.is_cuda else 0
+        nv.call('segnb_absmax_f32', nv.ptr(self.flat_g), self.total, nv.ptr(out), st)
+        return out
+
     def grads_alias(self):
         """True when every parameter's .grad is already a view of flat_g (accumulate in place)."""
         base = self.flat_g.data_ptr()

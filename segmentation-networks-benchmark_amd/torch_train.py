@@ -5,6 +5,8 @@
     optimizer.zero_grad(); outputs = model(x); batch_loss = loss(outputs, y)
     (batch_size * batch_loss).backward(); optimizer.step()                         torch_train.py:180-190
 """
+import sys
+
 import torch
 
 from lib.losses import (BCEAndDiceLoss, BCEWithLogitsLossAndSmoothJaccard, BCEWithSigmoidLoss, FocalLossBinary,
@@ -58,8 +60,24 @@ def default_metrics():
     return {'iou': JaccardScore(), 'accuracy': PixelAccuracy()}
 
 
-def train(model, loss, optimizer, dataloader, epoch=0, metrics=None):
-    """One epoch of the training step; returns (AverageMeter of the loss, {metric: AverageMeter})."""
+def grad_global_abs_max(model):
+    """'train/grad/global_abs_max' of torch_train.py:199-205.  One fused reduction over the flat gradient buffer and
+    one host sync when the model's gradients live in segnb's FlatParams; the reference's per-tensor loop otherwise."""
+    from segnb.engine import FlatParams
+    params = [p for p in model.parameters() if p.grad is not None]
+    flat = FlatParams.registry.get(id(params[0])) if params else None
+    if flat is not None and len(params) == len(flat._off) and flat.grads_alias():
+        return flat.grad_absmax().cpu().item()
+    grad_max = 0
+    for p in params:
+        grad_max = max(grad_max, p.grad.abs().max().cpu().item())
+    return grad_max
+
+
+def train(model, loss, optimizer, dataloader, epoch=0, metrics=None, grad_monitor=None):
+    """One epoch of the training step; returns (AverageMeter of the loss, {metric: AverageMeter}).
+    grad_monitor: optional callable(step, value) receiving the global gradient abs-max of every step (the
+    summary_writer.add_scalar('train/grad/global_abs_max', ...) of torch_train.py:205)."""
     metrics = metrics or {}
     losses, scores = AverageMeter(), {k: AverageMeter() for k in metrics}
     device = next(model.parameters()).device
@@ -73,8 +91,10 @@ def train(model, loss, optimizer, dataloader, epoch=0, metrics=None):
             (x.size(0) * batch_loss).backward()
             optimizer.step()
             losses.update(batch_loss.cpu().item())
+            if grad_monitor is not None:
+                grad_monitor(losses.count - 1, grad_global_abs_max(model))
             for k, m in metrics.items():
-                scores[k].update(m(outputs, y).cpu().item())
+                scores[k].update(m(outputs, y).cpu().item())      # answered from the loss launch's sums
     return losses, scores
 
 
@@ -91,3 +111,30 @@ def validate(model, loss, dataloader, epoch=0, metrics=None):
             for k, m in metrics.items():
                 scores[k].update(m(outputs, y).cpu().item())
     return losses, scores
+
+
+def save_snapshot(model, optimizer, loss, epoch, train_history, snapshot_file):
+    """torch_train.py:308-316: the reference's checkpoint dict, key for key.  train_history: a pandas DataFrame (as
+    there) or anything with ``to_dict``; a plain dict is stored as is."""
+    torch.save({
+        'model': model.state_dict(),
+        'optimizer': optimizer.state_dict(),
+        'epoch': epoch,
+        'loss': loss,
+        'train_history': train_history.to_dict() if hasattr(train_history, 'to_dict') else train_history,
+        'args': ' '.join(sys.argv[1:]),
+    }, snapshot_file)
+
+
+def restore_snapshot(model, optimizer, snapshot_file):
+    """torch_train.py:319-330 -> (start_epoch, train_history DataFrame, best_loss).  Checkpoints written by the
+    reference load here and vice versa (same keys, same state_dict names)."""
+    import pandas as pd
+    checkpoint = torch.load(snapshot_file, map_location='cpu', weights_only=False)
+    start_epoch = checkpoint['epoch'] + 1
+    best_loss = checkpoint['loss']
+    model.load_state_dict(checkpoint['model'])
+    if optimizer is not None:
+        optimizer.load_state_dict(checkpoint['optimizer'])
+    train_history = pd.DataFrame.from_dict(checkpoint['train_history'])
+    return start_epoch, train_history, best_loss

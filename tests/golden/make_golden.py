@@ -76,6 +76,12 @@ def ref_loss(name):
     return c
 
 
+def _legacy(crit, size_average, reduce):
+    """the API-rot fix of SURVEY 8c: torch >= 1.x no longer stores the two legacy attributes the reference reads"""
+    crit.size_average, crit.reduce = size_average, reduce
+    return crit
+
+
 LOSS_NAMES = ['bce', 'jaccard', 'smooth_jaccard', 'dice', 'bce_jaccard', 'bce_dice', 'focal']
 
 
@@ -92,6 +98,23 @@ def gen_losses():
         out['dx_' + name] = xx.grad.numpy()
     out['iou'] = ref_metrics.JaccardScore()(x, t).numpy()
     out['acc'] = ref_metrics.PixelAccuracy()(x, t).numpy()
+    # the rest of the constructor surface (losses.py:47,84): sum / unreduced BCE, focal with other gammas / mean
+    r = torch.randn(x.shape, generator=g)                   # upstream gradient of the unreduced map
+    for tag, make, seed_grad in (
+            ('bce_sum', lambda: _legacy(ref_losses.BCEWithSigmoidLoss(size_average=False), False, True), None),
+            ('bce_none', lambda: _legacy(ref_losses.BCEWithSigmoidLoss(reduce=False), True, False), r),
+            ('focal_g15_mean', lambda: _legacy(ref_losses.FocalLossBinary(gamma=1.5), True, True), None),
+            ('focal_g3_sum', lambda: _legacy(ref_losses.FocalLossBinary(gamma=3, size_average=False), False, True), None),
+            ('focal_g0_sum', lambda: _legacy(ref_losses.FocalLossBinary(gamma=0, size_average=False), False, True), None)):
+        xx = x.clone().requires_grad_(True)
+        l = make()(xx, t)
+        if seed_grad is None:
+            (x.shape[0] * l).backward()
+        else:
+            l.backward(seed_grad)
+        out['loss_' + tag] = l.detach().numpy()
+        out['dx_' + tag] = xx.grad.numpy()
+    out['map_seed'] = r.numpy()
     # known answers: x = 0 everywhere, t = 1 -> bce = log(1.5) + log(2)
     x0 = torch.zeros(1, 1, 4, 4)
     t1 = torch.ones(1, 1, 4, 4).long()
@@ -104,7 +127,7 @@ def gen_losses():
     xe = torch.full((1, 1, 2, 2), 3.0)
     out['acc_nomatch'] = np.asarray(float(ref_metrics.PixelAccuracy()(xe, t0[:, :, :2, :2])))
     np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
-    print('losses.npz', {k: float(v) for k, v in out.items() if k.startswith('loss_')})
+    print('losses.npz', {k: float(v) for k, v in out.items() if k.startswith('loss_') and np.ndim(v) == 0})
 
 
 def make_reference_model(seed, **kw):

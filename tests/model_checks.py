@@ -236,3 +236,27 @@ def check_product_golden(model, golden, device, dtype='f32'):
             if ref > 1e-3 * gmax:
                 assert abs(float(p.grad.norm()) - ref) < 0.25 * ref, (n, float(p.grad.norm()), ref)
     return dl, di
+
+
+# ---- the rest of the loss constructor surface (lib/losses.py:47,84) vs values the REFERENCE produced (losses.npz)
+EXTRA_LOSS_CASES = ['bce_sum', 'bce_none', 'focal_g15_mean', 'focal_g3_sum', 'focal_g0_sum']
+
+
+def check_extra_loss_case(golden, tag, device):
+    from lib import losses as L
+    crit = {'bce_sum': lambda: L.BCEWithSigmoidLoss(size_average=False),
+            'bce_none': lambda: L.BCEWithSigmoidLoss(reduce=False),
+            'focal_g15_mean': lambda: L.FocalLossBinary(gamma=1.5),
+            'focal_g3_sum': lambda: L.FocalLossBinary(gamma=3, size_average=False),
+            'focal_g0_sum': lambda: L.FocalLossBinary(gamma=0, size_average=False)}[tag]()
+    x = torch.from_numpy(golden['x']).to(device).requires_grad_(True)
+    t = torch.from_numpy(golden['t']).to(device)
+    l = crit(x, t)
+    if tag == 'bce_none':
+        l.backward(torch.from_numpy(golden['map_seed']).to(device))
+    else:
+        (x.shape[0] * l).backward()
+    ref = golden['loss_' + tag]
+    np.testing.assert_allclose(l.detach().cpu().numpy(), ref, rtol=2e-5, atol=1e-6)
+    dref = golden['dx_' + tag]
+    np.testing.assert_allclose(x.grad.cpu().numpy(), dref, rtol=2e-4, atol=3e-6 * np.abs(dref).max())

@@ -428,6 +428,96 @@ def test_metrics_vs_reference_golden(golden_dir):
     assert PixelAccuracy()(xe, torch.zeros(1, 1, 2, 2).long().cuda()).item() == 0.0
 
 
+@pytest.mark.parametrize('tag', __import__('model_checks').EXTRA_LOSS_CASES)
+def test_loss_constructor_surface_vs_reference_golden(golden_dir, tag):
+    """BCEWithSigmoidLoss(size_average=False | reduce=False), FocalLossBinary(gamma != 2) on the HIP kernels vs values
+    and gradients produced by the REFERENCE's lib/losses.py:47-53,84-101."""
+    import os
+    import model_checks as mc
+    mc.check_extra_loss_case(np.load(os.path.join(golden_dir, 'losses.npz')), tag, 'cuda')
+
+
+def test_metrics_come_from_the_loss_sums(golden_dir):
+    """JaccardScore / PixelAccuracy right after the loss on the same tensors (torch_train.py:185,209-210): answered
+    from the loss launch's sums -- same values as the stand-alone pass and as the reference."""
+    import os
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore, PixelAccuracy
+    from segnb import seglosses
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    x, t = torch.from_numpy(g['x']).cuda().requires_grad_(True), torch.from_numpy(g['t']).cuda()
+    BCEWithLogitsLossAndSmoothJaccard()(x, t)
+    assert seglosses._recall(x, t) is not None
+    iou, acc = JaccardScore()(x, t).item(), PixelAccuracy()(x, t).item()
+    assert abs(iou - float(g['iou'])) < 1e-6 and abs(acc - float(g['acc'])) < 1e-7
+    x2 = x.detach().clone()
+    assert seglosses._recall(x2, t) is None
+    assert JaccardScore()(x2, t).item() == iou
+
+
+def test_grad_absmax_kernel():
+    gen = torch.Generator().manual_seed(5)
+    for n in (4, 1003, 31454724):
+        v = torch.randn(n, generator=gen)
+        v[n // 3] = -7.25 if n > 4 else 0.5
+        d = v.cuda()
+        out = torch.zeros((), device='cuda')
+        nv.call('segnb_absmax_f32', nv.ptr(d), n, nv.ptr(out), torch.cuda.current_stream().cuda_stream)
+        assert out.item() == v.abs().max().item()
+    z = torch.zeros(64, device='cuda')
+    out = torch.ones((), device='cuda')
+    nv.call('segnb_absmax_f32', nv.ptr(z), 64, nv.ptr(out), torch.cuda.current_stream().cuda_stream)
+    assert out.item() == 0.0
+
+
+def test_pr_curve_histogram_kernel_vs_threshold_loop():
+    """PRCurveMeter.update on the GPU (segnb_pr_histogram) vs the reference's 127-threshold loop
+    (lib/train_utils.py:109-125) restated in numpy.  A pixel whose probability sits within 2e-7 of a threshold may
+    fall on either side (sigmoid implementations differ by an ulp): counts must agree up to those pixels."""
+    from lib.train_utils import PRCurveMeter
+    gen = torch.Generator().manual_seed(0)
+    logits = 3 * torch.randn(4, 1, 224, 224, generator=gen)
+    y = (torch.rand(4, 1, 224, 224, generator=gen) > 0.6).long()
+    m = PRCurveMeter()
+    m.update(logits.cuda(), y.cuda())
+    p = torch.sigmoid(logits.double()).numpy().reshape(-1)
+    t = y.numpy().reshape(-1).astype(np.int64)
+    for i, v in enumerate(np.arange(0., 1., 1. / 127, dtype=np.float32)):
+        pred = (p > float(v)).astype(np.int64)
+        conf = np.bincount(pred + 2 * t, minlength=4).reshape(2, 2)
+        slack = int((np.abs(p - float(v)) < 2e-7).sum())
+        for got, ref in ((m.tp[i], conf[1, 1]), (m.tn[i], conf[0, 0]), (m.fp[i], conf[0, 1]), (m.fn[i], conf[1, 0])):
+            assert abs(int(got) - int(ref)) <= slack, (i, got, ref, slack)
+    assert int(m.tp[0] + m.fn[0]) == int(t.sum()) and int(m.tp[5] + m.tn[5] + m.fp[5] + m.fn[5]) == t.size
+
+
+def test_snapshot_round_trip_gpu(tmp_path):
+    """save_snapshot / restore_snapshot (torch_train.py:308-330) with the bf16 HIP path and the one-launch Adam:
+    the resumed run continues bit-identically."""
+    import torch_train as TT
+    from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(0)
+    model = ZF_UNET(filters=8, dropout_val=0.0).cuda()
+    opt = TT.get_optimizer('adam', model.parameters(), 1e-3)
+    gen = torch.Generator().manual_seed(1)
+    data = [(torch.randn(4, 3, 64, 64, generator=gen), (torch.rand(4, 1, 64, 64, generator=gen) > 0.7).long())
+            for _ in range(2)]
+    seen = []
+    TT.train(model, TT.get_loss('bce_jaccard'), opt, data, metrics=TT.default_metrics(),
+             grad_monitor=lambda step, v: seen.append(v))
+    assert seen[-1] == max(p.grad.abs().max().item() for p in model.parameters())
+    f = str(tmp_path / 'snap.pth')
+    TT.save_snapshot(model, opt, 0.25, 0, {'epoch': {0: 0}}, f)
+    m2 = ZF_UNET(filters=8, dropout_val=0.0).cuda()
+    o2 = TT.get_optimizer('adam', m2.parameters(), 1e-3)
+    start, _, best = TT.restore_snapshot(m2, o2, f)
+    assert start == 1 and best == 0.25
+    TT.train(model, TT.get_loss('bce_jaccard'), opt, data)
+    TT.train(m2, TT.get_loss('bce_jaccard'), o2, data)
+    for (k, a), b in zip(model.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
 def test_sgd_and_input_pack():
     gen = torch.Generator().manual_seed(0)
     p = torch.randn(1000003 // 4 * 4 + 3, generator=gen)

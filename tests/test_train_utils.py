@@ -163,3 +163,85 @@ def test_flat_optimizer_state_dict_round_trip(name):
     mom = 'square_avg' if name == 'rms' else 'exp_avg_sq'
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(oa.state[pa][mom], ob.state[pb][mom])
+
+
+@pytest.mark.parametrize('tag', __import__('model_checks').EXTRA_LOSS_CASES)
+def test_loss_constructor_surface_vs_reference_golden(golden_dir, tag):
+    """BCEWithSigmoidLoss(size_average=False | reduce=False), FocalLossBinary(gamma != 2): host logic + emulator vs the
+    reference's values (VERDICT r1 missing #6)."""
+    import os
+    import model_checks as mc
+    mc.check_extra_loss_case(np.load(os.path.join(golden_dir, 'losses.npz')), tag, 'cpu')
+
+
+class _CountingBackend(abi_emulator.AbiEmulator):
+    def __init__(self):
+        self.calls = {}
+
+    def __getattribute__(self, name):
+        attr = object.__getattribute__(self, name)
+        if name.startswith('segnb_') and callable(attr):
+            calls = object.__getattribute__(self, 'calls')
+            calls[name] = calls.get(name, 0) + 1
+        return attr
+
+
+def test_metrics_reuse_the_loss_launch():
+    """torch_train.py:185,209-210 calls loss, then JaccardScore and PixelAccuracy on the same (outputs, y): ONE
+    reduction pass serves all three; different tensors, or a tensor changed in place, reduce again."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore, PixelAccuracy
+    from oracle import losses_ref
+    be = _CountingBackend()
+    nv.set_backend_for_testing(be)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 1, 16, 16, generator=g).requires_grad_(True)
+    y = (torch.rand(2, 1, 16, 16, generator=g) > 0.6).long()
+    loss = BCEWithLogitsLossAndSmoothJaccard()(x, y)
+    iou, acc = JaccardScore()(x, y), PixelAccuracy()(x, y)
+    assert be.calls.get('segnb_seg_loss_reduce') == 1
+    assert abs(iou.item() - losses_ref.jaccard_score(x.detach(), y).item()) < 1e-6
+    assert abs(acc.item() - losses_ref.pixel_accuracy(x.detach(), y).item()) < 1e-7
+    loss.backward()
+    x2 = x.detach().clone()
+    JaccardScore()(x2, y)
+    assert be.calls['segnb_seg_loss_reduce'] == 2          # another tensor: its own pass
+    PixelAccuracy()(x2, y)
+    assert be.calls['segnb_seg_loss_reduce'] == 2          # ... shared by the second metric
+    x2.mul_(2.0)
+    i2 = JaccardScore()(x2, y)
+    assert be.calls['segnb_seg_loss_reduce'] == 3          # changed in place: recomputed
+    assert abs(i2.item() - losses_ref.jaccard_score(x2, y).item()) < 1e-6
+
+
+def test_grad_abs_max_and_snapshot_round_trip(tmp_path):
+    """torch_train.py:199-205 (one fused reduction instead of a sync per tensor) and :308-330 (checkpoint dict)."""
+    import pandas as pd
+    import torch_train as TT
+    from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(0)
+    model = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    opt = TT.get_optimizer('adam', model.parameters(), 1e-3)
+    data = [(torch.randn(2, 3, 32, 32), (torch.rand(2, 1, 32, 32) > 0.7).long()) for _ in range(2)]
+    seen = []
+    TT.train(model, TT.get_loss('bce_jaccard'), opt, data, metrics=TT.default_metrics(),
+             grad_monitor=lambda step, v: seen.append(v))
+    loop = max(p.grad.abs().max().item() for p in model.parameters())
+    assert len(seen) == 2 and seen[-1] == loop and TT.grad_global_abs_max(model) == loop
+    hist = pd.DataFrame({'epoch': [0], 'train_loss': [0.5]})
+    f = str(tmp_path / 'snap.pth')
+    TT.save_snapshot(model, opt, 0.5, 3, hist, f)
+    ck = torch.load(f, weights_only=False)
+    assert sorted(ck.keys()) == ['args', 'epoch', 'loss', 'model', 'optimizer', 'train_history']
+    assert len(ck['optimizer']['state']) == len(list(model.parameters()))
+    m2 = ZF_UNET(filters=4, dropout_val=0.0).set_compute_dtype('f32')
+    o2 = TT.get_optimizer('adam', m2.parameters(), 1e-3)
+    start, h2, best = TT.restore_snapshot(m2, o2, f)
+    assert start == 4 and best == 0.5 and list(h2.columns) == ['epoch', 'train_loss']
+    for (k, a), b in zip(model.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+    # the resumed run continues exactly like the uninterrupted one
+    TT.train(model, TT.get_loss('bce_jaccard'), opt, data)
+    TT.train(m2, TT.get_loss('bce_jaccard'), o2, data)
+    for (k, a), b in zip(model.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
