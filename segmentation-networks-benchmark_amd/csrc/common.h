@@ -41,6 +41,7 @@ int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();
 int segnb_knob_fprop_dma_dbg();
 int segnb_knob_fprop_rw();
+int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients
 int segnb_knob_conv_cus();        // CUs the persistent fprop / dgrad kernels size their grids for (segnb_tune "conv_cu_pct")
 int segnb_fprop_dma_read_stamps(unsigned long long* host_dst);
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error

@@ -59,6 +59,8 @@ int segnb_knob_conv_cus() {
     const int n = segnb_num_cus() * g_conv_cu_pct / 100;
     return n < 1 ? 1 : n;
 }
+static int g_wg_cu_pct = 0;        // 0 = SEGNB_WG_CU_FRACTION / built-in default; else % of the CUs for the wide weight gradients
+int segnb_knob_wg_cu_pct() { return g_wg_cu_pct; }
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
@@ -77,6 +79,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "conv_cu_pct") == 0) {        // CUs the persistent convolution kernels size their grids for (%)
         g_conv_cu_pct = value < 10 ? 10 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
+        g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
         return 0;
     }
     if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero

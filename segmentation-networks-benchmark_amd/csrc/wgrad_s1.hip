@@ -657,7 +657,9 @@ int s1_slabs(int tiles, bool thin, bool flat = false) {
         const double r = e ? atof(e) : -1.0;
         return r;
     }();
-    const double frac = thin ? frac_thin : ((flat && frac_flat > 0.0) ? frac_flat : frac_wide);
+    const int pct = segnb_knob_wg_cu_pct();
+    const double wide = pct > 0 ? pct / 100.0 : frac_wide;
+    const double frac = thin ? frac_thin : ((flat && frac_flat > 0.0) ? frac_flat : wide);
     int S = (int)(segnb_num_cus() * frac) / tiles;
     return S < 1 ? 1 : S;
 }

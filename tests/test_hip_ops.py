@@ -807,6 +807,71 @@ def test_conv_fprop_dma_full_size_reproducible(shape):
     np.testing.assert_allclose(sts[0].numpy(), sts[4].numpy(), rtol=1e-3, atol=1e-3 * float(sts[4].abs().max()))
 
 
+FULL_SIZE_LAYERS = [(32, 224, 3, 32), (32, 224, 32, 32), (32, 112, 32, 64), (32, 112, 64, 64), (32, 56, 64, 128),
+                    (32, 28, 256, 256), (32, 14, 512, 512), (32, 7, 1024, 1024), (32, 14, 1536, 512),
+                    (32, 28, 768, 256), (32, 56, 384, 128), (32, 112, 192, 64), (32, 224, 96, 32)]
+
+
+@pytest.mark.parametrize('wg_cu_pct', [0, 100], ids=['wg-default-cus', 'wg-all-cus'])
+@pytest.mark.parametrize('shape', FULL_SIZE_LAYERS, ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_full_size_vs_torch(shape, wg_cu_pct):
+    """The layer shapes of the TIMED configuration (BASELINE.json configs[1]: ZF_UNET 224x224 bs=32, bf16) through
+    ConvOp exactly as the training step launches them -- forward, data gradient AND weight gradient, the latter with the
+    default share of the CUs (multi-slab split, what the two-stream step runs) and with all CUs -- against
+    F.conv2d autograd on the CPU (fp32 math on the same bf16-rounded operands): the oracle, not another HIP kernel.
+    (VERDICT r1 weak #3.)"""
+    N, S, Ci, Co = shape
+    first = Ci == 3
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(S * 1000 + Ci + Co)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) * (2.0 / (Ci * 9)) ** 0.5).bfloat16().float()
+    b = (torch.randn(Co, generator=gen) * 0.1)
+    x = torch.randn(N, Ci, S, S, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, S, S, generator=gen).bfloat16().float()
+    Cip = cp.pad8(Ci)
+    nv.call('segnb_tune', b'wg_cu_pct', wg_cu_pct)
+    try:
+        op = ConvOp(rt, w.cuda(), b.cuda(), [(Ci, Cip)], 1, 1, False, need_dgrad=not first)
+        op.pack(S, S)
+        xv = View.alloc(rt, N, S, S, op.Cip)
+        xv.dense()[..., :Ci] = x.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+        yv = View.alloc(rt, N, S, S, op.Cop)
+        stats = rt.zeros((16, 2, op.Cop), torch.float64)
+        op.fprop(xv, yv, stats)
+        dyv = View.alloc(rt, N, S, S, op.Cop)
+        dyv.dense()[..., :Co] = dy.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+        gw = torch.zeros_like(op.weight)
+        op.wgrad(xv, dyv, gw)
+        gw2 = torch.zeros_like(op.weight)
+        op.wgrad(xv, dyv, gw2)
+        dxv = None
+        if not first:
+            dxv = View.alloc(rt, N, S, S, op.Cip)
+            op.dgrad(dyv, dxv)
+        torch.cuda.synchronize()
+    finally:
+        nv.call('segnb_tune', b'wg_cu_pct', 0)
+    xr = x.clone().requires_grad_(not first)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    yr.backward(dy)
+    name = 'x'.join(map(str, shape))
+    y_g = yv.dense().float().cpu()
+    check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    assert op.Cop == Co or float(y_g[..., Co:].abs().max()) == 0.0
+    # BatchNorm statistics of the epilogue = sums of the STORED (bf16) outputs
+    st = stats.sum(0).cpu()
+    ys = yr.detach().bfloat16().double()
+    np.testing.assert_allclose(st[0, :Co].numpy(), ys.sum((0, 2, 3)).numpy(), rtol=1e-3,
+                               atol=2e-2 * float(ys.abs().max()) * (N * S * S) ** 0.5)
+    np.testing.assert_allclose(st[1, :Co].numpy(), (ys * ys).sum((0, 2, 3)).numpy(), rtol=2e-3)
+    # weight gradient: fp32 accumulation over N*S*S pixels on both sides
+    check(name + ' dw vs torch', gw.cpu(), wr.grad, 'f32')
+    assert torch.equal(gw, gw2), 'weight gradient differs between two launches (slab reduction order)'
+    if not first:
+        check(name + ' dx vs torch', dxv.dense().float().cpu()[..., :Ci].permute(0, 3, 1, 2), xr.grad, 'bf16')
+
+
 # ------------------------------------------------------------------------------------------------------
 # resident-weights pipeline of the thin layers (fprop_rw.hip): Ci in {32, 64, 96}, Co <= 96
 # ------------------------------------------------------------------------------------------------------

@@ -77,3 +77,191 @@ def test_training_steps_reduce_loss_all_models():
             losses.append(loss.item())
         assert all(np.isfinite(losses)), (type(m).__name__, losses)
         assert losses[-1] < losses[0], (type(m).__name__, losses)
+
+
+# ---- the remaining BASELINE.json configurations at their own sizes (configs_untested) ------------------
+def _full_size_bf16_vs_fp32(make, B, S, tag):
+    """One training step (torch_train.py:180-190 body, bce_jaccard) of `make()` at the configuration's size on the
+    bf16 throughput path vs the exact-fp32 HIP path (the one pinned to the reference fixtures at small sizes), same
+    weights / batch, Dropout2d off; plus size-independent properties: finite, run-to-run reproducible eval forward,
+    loss goes down under SGD."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.metrics import JaccardScore
+    from segnb import optim
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, S, S, generator=gen).cuda()
+    y = (torch.rand(B, 1, S, S, generator=gen) > 0.7).long().cuda()
+    res = {}
+    for dtype in ('f32', 'bf16'):
+        torch.manual_seed(0)
+        m = make().set_compute_dtype(dtype).cuda().train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        out = m(x)
+        loss = BCEWithLogitsLossAndSmoothJaccard()(out, y)
+        iou = JaccardScore()(out, y).item()
+        (B * loss).backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        g = torch.cat([p.grad.detach().double().reshape(-1).cpu() for p in m.parameters() if p.dim() == 4])
+        res[dtype] = (loss.item(), iou, g, out.detach().cpu())
+        if dtype == 'bf16':
+            m.eval()
+            with torch.no_grad():
+                a, b = m(x).clone(), m(x).clone()
+            assert torch.equal(a, b), 'eval forward is not run-to-run reproducible'
+            m.train()
+            opt = optim.SGD(m.parameters(), lr=1e-3)
+            losses = []
+            for _ in range(4):
+                opt.zero_grad()
+                l = BCEWithLogitsLossAndSmoothJaccard()(m(x), y)
+                (B * l).backward()
+                opt.step()
+                losses.append(l.item())
+            assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        del m
+        torch.cuda.empty_cache()
+    (l32, i32, g32, o32), (l16, i16, g16, o16) = res['f32'], res['bf16']
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print('%s bs=%d %dx%d bf16 - fp32: dloss %.3e dIoU %.3e, conv-weight gradient cosine %.4f, norm ratio %.4f'
+          % (tag, B, S, S, l16 - l32, i16 - i32, cos, float(g16.norm() / g32.norm())))
+    assert abs(l16 - l32) < 5e-3 and abs(i16 - i32) < 5e-3
+    assert cos > 0.7 and abs(float(g16.norm() / g32.norm()) - 1.0) < 0.15, cos
+
+
+def test_fcdensenet103_256_bs8_config():
+    """BASELINE.json configs[3]: FCDenseNet-103 256x256 bs=8 (per-GPU shard of the data-parallel job)."""
+    from lib.models.tiramisu import FCDenseNet103
+    _full_size_bf16_vs_fp32(lambda: FCDenseNet103(n_classes=1), 8, 256, 'FCDenseNet103')
+
+
+def test_linknet34_512_bs16_config():
+    """BASELINE.json configs[2]: LinkNet-34 512x512 bf16 bs=16."""
+    import warnings
+    from lib.models.linknet import LinkNet34
+
+    def make():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return LinkNet34()
+    _full_size_bf16_vs_fp32(make, 16, 512, 'LinkNet34')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_replay_fcdensenet103_structure(dtype):
+    """Teacher-forced replay (tests/abi_replay.py) of the REAL FCDenseNet103 (all 103 layers, growth 16, 1072-channel
+    dense inputs) at a small spatial size: every launch of the plan vs the emulator at per-op tolerance."""
+    import abi_replay
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.models.tiramisu import FCDenseNet103
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 3, 64, 64, generator=gen)
+    y = (torch.rand(2, 1, 64, 64, generator=gen) > 0.7).long()
+
+    def make():
+        torch.manual_seed(3)
+        m = FCDenseNet103(n_classes=1)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        return m
+    n, rep = abi_replay.replay(make, x, y, BCEWithLogitsLossAndSmoothJaccard(), dtype)
+    assert n > 1000 and not rep, '%d of %d calls differ:\n%s' % (len(rep), n, '\n'.join(rep[:20]))
+
+
+def test_unet16_1024_tiled_config():
+    """BASELINE.json configs[4]: default UNet16 (TernausNet VGG16-UNet, 32.2 M parameters) on 1024x1024 tiles, bs=4,
+    through lib/tiles.py sliding-window inference with D4 TTA (segnb.tiled.predict_tiled).
+    (1) the eval forward of one 1024x1024 tile, fp32 HIP path and bf16 path, vs the oracle restatement
+        (oracle/unet16_ref.py, pinned to the reference's unet16.py by unet16_small.npz) on the CPU;
+    (2) predict_tiled over a 1100x1300 image (4 tiles x 8 transforms, last batch short) == the oracle's restatement
+        of inria_submit.predict_tiled fed by the same model."""
+    from lib.models.unet16 import UNet16
+    from oracle import tiles_ref, unet16_ref
+    from segnb.tiled import predict_tiled
+    torch.manual_seed(0)
+    m = UNet16().cuda().eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(2)
+    x1 = torch.randn(1, 3, 1024, 1024, generator=gen)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = unet16_ref.forward(sd, x1)
+    scale = float(ref.abs().max())
+    for dtype, tol in (('f32', 5e-4), ('bf16', 6e-2)):
+        m.set_compute_dtype(dtype)
+        with torch.no_grad():
+            got = m(x1.cuda()).cpu()
+        err = float((got - ref).abs().max())
+        print('UNet16 1024x1024 eval forward %s vs oracle: max|d| %.3e of scale %.3e' % (dtype, err, scale))
+        assert err <= tol * scale, (dtype, err, scale)
+    rng = np.random.RandomState(4)
+    img = rng.randn(1100, 1300, 3).astype(np.float32)
+    got = predict_tiled(img, m, None, 1024, 4)
+
+    def logits_fn(xb):
+        with torch.no_grad():
+            return m(torch.from_numpy(xb).cuda()).float().cpu().numpy()
+    ref = tiles_ref.predict_tiled(img, logits_fn, 1024, 4)
+    assert got.shape == (1100, 1300, 1) and np.isfinite(got).all()
+    np.testing.assert_allclose(got[..., 0], ref[..., 0] if ref.ndim == 3 else ref, rtol=1e-5, atol=1e-5)
+
+
+def test_inplace_abn_standalone_gpu():
+    """lib.modules.abn.InPlaceABN called on its own (bn.py:47-103) on the HIP kernels == BatchNorm2d + LeakyReLU(0.01)
+    on the CPU, forward / backward / running statistics; eval mode too."""
+    from lib.modules.abn import InPlaceABN
+    torch.manual_seed(3)
+    x = torch.randn(3, 12, 9, 7)
+    abn = InPlaceABN(12).cuda()
+    bn = torch.nn.BatchNorm2d(12)
+    with torch.no_grad():
+        abn.weight.copy_(1 + 0.2 * torch.randn(12))
+        abn.bias.copy_(0.1 * torch.randn(12))
+        bn.weight.copy_(abn.weight.cpu())
+        bn.bias.copy_(abn.bias.cpu())
+    xa, xb = x.clone().cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = abn(xa)
+    yb = torch.nn.functional.leaky_relu(bn(xb), 0.01)
+    r = torch.randn_like(yb)
+    (ya * r.cuda()).sum().backward()
+    (yb * r).sum().backward()
+    torch.testing.assert_close(ya.cpu(), yb, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xa.grad.cpu(), xb.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.weight.grad.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.bias.grad.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(abn.running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(abn.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    abn.eval()
+    bn.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(abn(x.cuda()).cpu(), torch.nn.functional.leaky_relu(bn(x), 0.01), rtol=1e-5, atol=1e-5)
+
+
+def test_find_optimal_lr_gpu():
+    """lib.train_utils.find_optimal_lr (train_utils.py:36-69) on the HIP path: 30 steps, lr doubling from 1e-8,
+    gradients accumulate (never zeroed) exactly as the same loop on the oracle."""
+    from lib.losses import BCEWithSigmoidLoss
+    from lib.models.zf_unet import ZF_UNET
+    from lib.train_utils import find_optimal_lr
+    from oracle import train_step_ref, zf_unet_ref
+    B, S, F = 2, 64, 8
+    x, y = train_step_ref.synthetic_batch(B, S, seed=13)
+    torch.manual_seed(5)
+    m = ZF_UNET(dropout_val=0.0, filters=F).set_compute_dtype('f32').cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    lrs, loss = find_optimal_lr(m, BCEWithSigmoidLoss(), opt, [(x, y)] * 30)
+    assert lrs.shape == (30,) and abs(lrs[0] - 1e-8) < 1e-12 and np.all(np.isfinite(loss))
+    # the same 30-step loop on the oracle (accumulating gradients, lr table through the base lr 1.0)
+    sd = zf_unet_ref.default_init_state(filters=F, seed=5)
+    acc = None
+    ref = []
+    for i in range(30):
+        l, _, grads = train_step_ref.loss_and_grads(sd, x, y, 'bce')
+        acc = grads if acc is None else {k: acc[k] + grads[k] for k in grads}
+        for k in acc:
+            sd[k] = sd[k] - float(lrs[i]) * acc[k]
+        ref.append(l.item())
+    np.testing.assert_allclose(loss, np.array(ref, dtype=np.float32), rtol=0, atol=2e-5)

@@ -242,6 +242,60 @@ def test_full_size_bs32_bf16_properties():
         assert torch.isfinite(p.grad).all()
 
 
+def test_timed_config_bs32_bf16_vs_fp32_hip_path():
+    """The TIMED configuration (BASELINE.json configs[1]: ZF_UNET 224x224 bs=32 bf16, BCE+Dice, Dropout2d 0.2) against
+    the exact-fp32 HIP path on the same weights, batch and Dropout2d draw.  The fp32 path is the one pinned to the
+    reference goldens (test_config1_224_f32_vs_reference_golden, |dloss| < 1e-5, |dIoU| < 1e-4), so this ties the
+    numbers bench.py times to the reference at the timed size.  Reported and bounded: dloss, dIoU, daccuracy,
+    per-tensor weight-gradient cosine and norm ratio.  (VERDICT r1 weak #2.)"""
+    from lib.losses import BCEAndDiceLoss
+    from lib.metrics import JaccardScore, PixelAccuracy
+    from lib.models.zf_unet import ZF_UNET
+    B, S = 32, 224
+    x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
+    x, y = x.cuda(), y.cuda()
+    drop = zf_unet_ref.make_dropout_tables(32, B, 0.2, torch.Generator().manual_seed(7))
+    res = {}
+    for dtype in ('f32', 'bf16'):
+        torch.manual_seed(0)
+        m = ZF_UNET().set_compute_dtype(dtype).cuda().train()
+        m.dropout_override = drop
+        out = m(x)
+        loss = BCEAndDiceLoss()(out, y)
+        iou, acc = JaccardScore()(out, y).item(), PixelAccuracy()(out, y).item()
+        (B * loss).backward()
+        torch.cuda.synchronize()
+        res[dtype] = (loss.item(), iou, acc, {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()},
+                      out.detach().cpu())
+        del m
+    (l32, i32, a32, g32, o32), (l16, i16, a16, g16, o16) = res['f32'], res['bf16']
+    print('bs=32 bf16 - fp32: dloss %.3e  dIoU %.3e  dacc %.3e  logits max|d| %.3e (scale %.2f)'
+          % (l16 - l32, i16 - i32, a16 - a32, float((o16 - o32).abs().max()), float(o32.abs().max())))
+    assert abs(l16 - l32) < 5e-4 and abs(i16 - i32) < 5e-4 and abs(a16 - a32) < 2e-3
+    worst_cos, worst_ratio = ('', 1.0), ('', 0.0)
+    ga, gb = [], []
+    for n in g32:
+        if not (n.endswith('conv.weight') or n == 'conv_final.weight'):
+            continue
+        a, b = g16[n].reshape(-1), g32[n].reshape(-1)
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        ratio = abs(float(a.norm() / b.norm()) - 1.0)
+        if cos < worst_cos[1]:
+            worst_cos = (n, cos)
+        if ratio > worst_ratio[1]:
+            worst_ratio = (n, ratio)
+        ga.append(a)
+        gb.append(b)
+    ga, gb = torch.cat(ga), torch.cat(gb)
+    cos_all = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    print('bs=32 weight gradients bf16 vs fp32: global cosine %.5f, worst tensor %s %.5f, worst norm ratio %s %.3e'
+          % (cos_all, worst_cos[0], worst_cos[1], worst_ratio[0], worst_ratio[1]))
+    # bf16 storage noise grows ~x1.1-1.6 per BatchNorm stage on the way down the net (the reference
+    # under bf16 autocast behaves the same); at bs=32 each BatchNorm averages over 8x more samples than at B=4
+    assert cos_all > 0.8 and worst_cos[1] > 0.5, (cos_all, worst_cos)
+    assert worst_ratio[1] < 0.1, worst_ratio
+
+
 def test_eval_matches_train_statistics_path():
     """validate() path (torch_train.py:248-265): no-grad eval forward uses running statistics."""
     m = _model(8, 0.0, 4.0, 'f32')
