@@ -132,6 +132,21 @@ int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segn
 int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out, int dtype, int Cp,
                           int ld_out, segnb_stream_t stream);
 
+/* The network input as the dataset holds it: uint8 HWC [N][H][W][C] (cv2.imread, lib/common.py:44), 1 <= C <= 8.
+ * NormalizeImage (lib/augmentations.py:452-460: x * scale - mean) / std), the HWC -> CHW move (lib/common.py:70) and the
+ * float conversion happen in registers: v = (u8 * scale - mean[c]) * (1 / std[c]) in fp32, stored as `dtype`.
+ * mean / std: HOST arrays of C floats (copied into the launch).   */
+int segnb_pack_input_u8(const unsigned char* img, int N, int H, int W, int C, float scale, const float* mean,
+                        const float* stdv, void* out, int dtype, int Cp, int ld_out, segnb_stream_t stream);
+/* The FIRST convolution (3x3, stride 1, <= 32 output channels, bf16) reading the uint8 image directly: no packed copy
+ * is read at all.  x_packed (optional, [N][H][W][ld_packed] bf16, 8 channels written): the normalised pixels, written
+ * once by the tile that owns them -- the x operand of this layer's weight gradient; NULL for inference.  The result
+ * is bit-identical to segnb_pack_input_u8 + segnb_conv_fprop.  segnb_conv_fprop_u8_ok: 1 if the geometry is served. */
+int segnb_conv_fprop_u8_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_fprop_u8(const segnb_conv_geom* g, const unsigned char* img, int C, float scale, const float* mean,
+                        const float* stdv, const void* wpacked, const float* bias, int bias_n, void* out,
+                        double* stats, void* x_packed, int ld_packed, segnb_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tiled inference: ImageSlicer.split / merge of lib/tiles.py:99-161, the D4 test-time
  * augmentation of lib/augmentations.py:476-511 and the sigmoid of inria_submit.py:249.

@@ -91,6 +91,37 @@ class AbiEmulator(object):
             S[1] += (v * v).sum(0)
         return 0
 
+    # ---- uint8 HWC input (NormalizeImage, lib/augmentations.py:452-460, on the way in)
+    @staticmethod
+    def _norm_u8(img, N, H, W, C, scale, mean, std):
+        u = _mem(img, N * H * W * C, torch.uint8).view(N, H, W, C).float()
+        m = torch.tensor([float(mean[i]) for i in range(C)])
+        inv = 1.0 / torch.tensor([float(std[i]) for i in range(C)], dtype=torch.float32)
+        return (u * torch.tensor(scale, dtype=torch.float32) - m) * inv
+
+    def segnb_pack_input_u8(self, img, N, H, W, C, scale, mean, std, out, dtype, Cp, ld, stream):
+        O = _nhwc(out, N, H, W, Cp, ld, _tdt(dtype))
+        O.zero_()
+        O[..., :C] = self._norm_u8(img, N, H, W, C, scale, mean, std).to(_tdt(dtype))
+        return 0
+
+    def segnb_conv_fprop_u8_ok(self, g, dtype):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.Ci == 8 and g.Co <= 32
+                   and g.Wo >= 12 and g.Hi == g.Ho and g.Wi == g.Wo and g.QH == g.Ho and g.QW == g.Wo)
+
+    def segnb_conv_fprop_u8(self, g, img, C, scale, mean, std, wp, bias, bias_n, out_p, stats, x_packed, ld_packed, stream):
+        gg = _geom(g)
+        x = torch.zeros(gg.N, gg.Hi, gg.Wi, 8, dtype=torch.bfloat16)
+        x[..., :C] = self._norm_u8(img, gg.N, gg.Hi, gg.Wi, C, scale, mean, std).to(torch.bfloat16)
+        if x_packed is not None:
+            _nhwc(x_packed, gg.N, gg.Hi, gg.Wi, 8, ld_packed, torch.bfloat16).copy_(x)
+        keep = x.contiguous()
+        g2 = type(gg)()
+        ctypes.memmove(ctypes.addressof(g2), ctypes.addressof(gg), ctypes.sizeof(gg))
+        g2.ld_in = 8
+        return self.segnb_conv_fprop(g2, BF16, keep.data_ptr(), wp, bias, bias_n, out_p, stats, stream)
+
     # slab count of the emulated device: stride-1 3x3 bf16 launches write EMU_SLABS partial slabs (the HIP library
     # derives its count from the CU count); everything else accumulates into one zeroed slab
     EMU_SLABS = 3

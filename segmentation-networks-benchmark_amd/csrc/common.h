@@ -40,6 +40,7 @@ int segnb_num_cus();
 int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();
 int segnb_knob_fprop_dma_dbg();
+int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients
 int segnb_knob_conv_cus();        // CUs the persistent fprop / dgrad kernels size their grids for (segnb_tune "conv_cu_pct")

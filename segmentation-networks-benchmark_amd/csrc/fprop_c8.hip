@@ -14,7 +14,18 @@
 
 namespace {
 
+// U8 input: the network input as the dataset holds it -- uint8 HWC (lib/common.py:44 cv2.imread) -- normalised in
+// registers on the way in: v = (u8 * scale - mean[c]) / std[c]  (NormalizeImage, lib/augmentations.py:452-460), rounded to
+// bf16 exactly as segnb_pack_input_u8 does.  3 bytes per pixel from HBM instead of 12 (fp32 CHW) + 16 + 16 (pack, re-read).
+struct C8Norm {
+    const unsigned char* img;     // [N][Hi][Wi][C] uint8
+    bf16_t* packed_out;           // optional: the normalised 8-channel bf16 pixels, [N][Hi][Wi][ld_p] (the weight gradient's x)
+    int C, ld_p;
+    float scale, mean[8], inv_std[8];
+};
+
 struct C8Args {
+    C8Norm u8;
     const bf16_t* x;
     const bf16_t* w;       // [Co][9][8]
     const float* bias;
@@ -34,6 +45,20 @@ constexpr int C8_OFF_PIX = C8_OFF_STG + C8_BM * C8_OUT_ROW;
 constexpr int C8_SMEM_TILE = C8_OFF_PIX + C8_BM * 4;                        // 27 KiB
 constexpr int C8_SMEM = C8_SMEM_TILE > 256 * 16 * 8 ? C8_SMEM_TILE : 256 * 16 * 8;   // >= the statistics reduction scratch
 
+__device__ __forceinline__ uint4 c8_norm_pixel(const C8Norm& u, long long pix) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    const unsigned char* p = u.img + pix * u.C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < u.C) v[e] = ((float)p[e] * u.scale - u.mean[e]) * u.inv_std[e];
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    return o;
+}
+
+template <bool U8>
 __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[C8_SMEM];
     int* sPix = reinterpret_cast<int*>(smem + C8_OFF_PIX);
@@ -88,8 +113,18 @@ __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
             const int xr = pix / C8_XC, xc = pix - xr * C8_XC;
             const int hi = hb * C8_R + a.dhmin + xr, wi = wb * C8_WT + a.dwmin + xc;
             hv[u] = make_uint4(0, 0, 0, 0);
-            if (pix < C8_NPIX && it < a.IT && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-                hv[u] = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x);
+            if (pix < C8_NPIX && it < a.IT && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
+                const long long ipix = (long long)(n * a.Hi + hi) * a.Wi + wi;
+                if constexpr (U8) {
+                    hv[u] = c8_norm_pixel(a.u8, ipix);
+                    // the tile that OWNS the pixel (not a halo copy of it) also publishes the packed form
+                    if (a.u8.packed_out != nullptr && (unsigned)(xr + a.dhmin) < (unsigned)C8_R &&
+                        (unsigned)(xc + a.dwmin) < (unsigned)C8_WT)
+                        *reinterpret_cast<uint4*>(a.u8.packed_out + ipix * a.u8.ld_p) = hv[u];
+                } else {
+                    hv[u] = *reinterpret_cast<const uint4*>(a.x + ipix * a.ld_x);
+                }
+            }
         }
     };
 
@@ -185,10 +220,18 @@ static_assert(256 * 16 * 8 <= C8_SMEM, "statistics reduction scratch");
 
 }  // namespace
 
+static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8, const void* wpacked, const float* bias,
+                     int bias_n, void* out, double* stats, hipStream_t stream);
+
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream) {
     if (!segnb_knob_fprop_dma()) return 0;
+    return c8_launch(g, in, nullptr, wpacked, bias, bias_n, out, stats, stream);
+}
+
+static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8, const void* wpacked, const float* bias,
+                     int bias_n, void* out, double* stats, hipStream_t stream) {
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 8 || g->Co > 32 || g->Wo < 12) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
@@ -200,6 +243,7 @@ int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpa
     }
     if (dhmax - dhmin != 2 || dwmax - dwmin != 2) return 0;
     C8Args a;
+    if (u8 != nullptr) a.u8 = *u8;
     a.x = (const bf16_t*)in;
     a.w = (const bf16_t*)wpacked;
     a.bias = bias;
@@ -218,6 +262,95 @@ int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpa
     a.IT = a.N * a.HB * a.WB;
     int grid = segnb_num_cus() * 4;          // 32 KiB of LDS per block: four blocks per CU hide each other's latencies
     if (grid > a.IT) grid = a.IT;
-    hipLaunchKernelGGL(conv_fprop_c8_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (u8 != nullptr)
+        hipLaunchKernelGGL(conv_fprop_c8_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(conv_fprop_c8_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
     return 1;
+}
+
+// ---- uint8 HWC network input ----------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ void pack_input_u8_kernel(const C8Norm u, long long npix, T* __restrict__ out, int Cp, int ld) {
+    const int CPP = Cp / 8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix * CPP;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / CPP;
+        const int cc = (int)(i - pix * CPP);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = cc * 8 + e;
+            v[e] = 0.f;
+            if (ch < u.C) v[e] = ((float)u.img[pix * u.C + ch] * u.scale - u.mean[ch]) * u.inv_std[ch];
+        }
+        store8(out + pix * ld + cc * 8, v);
+    }
+}
+
+int fill_norm(C8Norm& u, const unsigned char* img, int C, float scale, const float* mean, const float* stdv) {
+    if (img == nullptr || mean == nullptr || stdv == nullptr || C < 1 || C > 8) return 1;
+    u.img = img;
+    u.packed_out = nullptr;
+    u.C = C;
+    u.ld_p = 0;
+    u.scale = scale;
+    for (int e = 0; e < 8; ++e) {
+        u.mean[e] = e < C ? mean[e] : 0.f;
+        u.inv_std[e] = e < C ? 1.0f / stdv[e] : 0.f;
+        if (e < C && !(stdv[e] != 0.f)) return 1;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int segnb_pack_input_u8(const unsigned char* img, int N, int H, int W, int C, float scale, const float* mean,
+                                   const float* stdv, void* out, int dtype, int Cp, int ld_out, segnb_stream_t stream) {
+    C8Norm u;
+    SEGNB_CHECK_ARG(fill_norm(u, img, C, scale, mean, stdv) == 0, "bad normalisation (1 <= C <= 8, std != 0)");
+    SEGNB_CHECK_ARG(out && N > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C && ld_out >= Cp && ld_out % 8 == 0, "bad shape");
+    const long long npix = (long long)N * H * W;
+    int grid = ceil_div(npix * (Cp / 8), 256);
+    if (grid > 8192) grid = 8192;
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(pack_input_u8_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, npix,
+                           (bf16_t*)out, Cp, ld_out);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(pack_input_u8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, u, npix, (float*)out,
+                           Cp, ld_out);
+    else {
+        segnb_set_error("segnb_pack_input_u8: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_conv_fprop_u8_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || !segnb_knob_fprop_dma()) return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 8 || g->Co > 32 || g->Wo < 12 || g->Hi != g->Ho || g->Wi != g->Wo) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
+    return 1;
+}
+
+extern "C" int segnb_conv_fprop_u8(const segnb_conv_geom* g, const unsigned char* img, int C, float scale, const float* mean,
+                                   const float* stdv, const void* wpacked, const float* bias, int bias_n, void* out,
+                                   double* stats, void* x_packed, int ld_packed, segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(g && wpacked && out, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_u8_ok(g, SEGNB_BF16), "geometry not served by the uint8 first-layer kernel (segnb_conv_fprop_u8_ok)");
+    C8Norm u;
+    SEGNB_CHECK_ARG(fill_norm(u, img, C, scale, mean, stdv) == 0, "bad normalisation (1 <= C <= 8, std != 0)");
+    SEGNB_CHECK_ARG(x_packed == nullptr || (ld_packed >= 8 && ld_packed % 8 == 0), "bad packed-input stride");
+    u.packed_out = (bf16_t*)x_packed;
+    u.ld_p = ld_packed;
+    const int rc = c8_launch(g, nullptr, &u, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
+    if (rc != 1) {
+        segnb_set_error("segnb_conv_fprop_u8: launch refused (%d)", rc);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
 }

@@ -57,10 +57,12 @@ __device__ unsigned long long g_stamps[3 * 256 * 4];
 // the bottom padding of the image above it and the top padding of the one below -- and WT = W columns: tiles of R x W
 // virtual pixels instead of one 16 x 16 tile per image.  For 7 x 7 images: 8 row tiles of 252 pixels instead of 32 tiles
 // of 49 (81 % padding); the rows m >= R * WT of a tile are dummies.
-template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false>
+template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false, bool MF16_ = true>
 struct WsCfg {
     static constexpr int BN = BN_, R = R_, WT = WT_;
     static constexpr bool TALL = TALL_;
+    static constexpr bool MF16 = MF16_;                  // v_mfma_f32_16x16x32_bf16 (else 32x32x16)
+    static constexpr int TM16 = (TALL_ ? 256 : R_ * WT_) / CW_M_ / 16, TN16 = BN_ / (4 / CW_M_) / 16;
     static constexpr int NB = 4;
     static constexpr int NT = 512, NCW = 4, NLW = 4;
     static constexpr int BM = TALL_ ? 256 : R * WT;
@@ -308,29 +310,57 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         // tile, between its MFMAs (a matrix wave needs 8 of every 32 issue cycles).  Serialised, the epilogue was
         // 2-2.5 k cycles per tile: 30 % of a 64 -> 64 tile, 7 % of a 256 -> 256 one.
         // ---- compute-side per-lane constants: fragment offsets (see the uniform kernel for the swizzle) -----------
-        int b_rd[TN];
+        constexpr bool MF16 = C::MF16;
+        int tile_no_out = 0;
+        bool pending_out = false;
+        constexpr int TM16 = C::TM16, TN16 = C::TN16;
+        int b_rd[MF16 ? 1 : TN];
+        int a_rd[MF16 ? 1 : 9][MF16 ? 1 : TM];
+        // 16x16x32 form: lane = (row r16 of the 16-row fragment, 8-channel group g4 of the 32-channel K slice); the 16-byte
+        // slot of (row, slice kk, group g4) is (kk * 4 + g4) ^ ((key >> 1) & 7) -- the same source swizzle, read 32 channels deep
+        int b_rd16[MF16 ? TN16 : 1];
+        int a_rd16[MF16 ? 9 : 1][MF16 ? TM16 : 1];
+        if constexpr (MF16) {
+            const int r16 = lane & 15, g4 = lane >> 4;
     #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * C::WN + 32 * j + r;
-            b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
-        }
-        int a_rd[9][TM];                    // per tap and row tile, buffer 0 (kept for the whole kernel)
-    #pragma unroll
-        for (int t = 0; t < 9; ++t)
-    #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = wm * C::WM + 32 * i + r;
-                const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
-                // swizzle key: the halo COLUMN when the row pitch XC is even -- the sixteen lanes of a ds_read_b128 group then
-            // cover sixteen consecutive columns mod 16 whether they lie in one tile row (32-wide tiles) or in two (16-wide
-            // tiles: keyed by the row index p, two of sixteen lanes collide; measured neutral on the same box, kept for the
-            // cleaner bank picture)
-            const int key = XC % 2 == 0 ? p % XC : p;
-            int v = (p << 7) + ((key & 12) << 3) + (((h ^ (key >> 1)) & 1) << 4);
-                asm volatile("" : "+v"(v));
-                a_rd[t][i] = v;
+            for (int j = 0; j < TN16; ++j) {
+                const int row = wn * C::WN + 16 * j + r16;
+                b_rd16[j] = C::OFF_B + row * 128 + ((g4 ^ ((row >> 1) & 7)) << 4);
             }
+    #pragma unroll
+            for (int t = 0; t < 9; ++t)
+    #pragma unroll
+                for (int i = 0; i < TM16; ++i) {
+                    const int m = wm * C::WM + 16 * i + r16;
+                    const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
+                    const int key = XC % 2 == 0 ? p % XC : p;
+                    int v = (p << 7) + ((g4 ^ ((key >> 1) & 7)) << 4);
+                    asm volatile("" : "+v"(v));
+                    a_rd16[t][i] = v;
+                }
+        } else {
+        #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * C::WN + 32 * j + r;
+                b_rd[j] = C::OFF_B + row * 128 + ((row & 12) << 3) + (((h ^ (row >> 1)) & 1) << 4);
+            }
+        #pragma unroll
+            for (int t = 0; t < 9; ++t)
+        #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = wm * C::WM + 32 * i + r;
+                    const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
+                    // swizzle key: the halo COLUMN when the row pitch XC is even -- the sixteen lanes of a ds_read_b128 group then
+                // cover sixteen consecutive columns mod 16 whether they lie in one tile row (32-wide tiles) or in two (16-wide
+                // tiles: keyed by the row index p, two of sixteen lanes collide; measured neutral on the same box, kept for the
+                // cleaner bank picture)
+                const int key = XC % 2 == 0 ? p % XC : p;
+                int v = (p << 7) + ((key & 12) << 3) + (((h ^ (key >> 1)) & 1) << 4);
+                    asm volatile("" : "+v"(v));
+                    a_rd[t][i] = v;
+                }
 
+        }
         lds_barrier();                                         // pipeline prologue: first operands have landed
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         unsigned char* const sOut = smem + C::OFF_STG;
@@ -373,124 +403,239 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 }
             }
         };
-        bf16x8_t fr[3][NF];
-        if (!(DBG && (a.dbg & 4))) {
+        if constexpr (MF16) {
+            // ---- 16x16x32 matrix stream: 2 K slices of 32 channels per tap; wave tile = TM16 x TN16 tiles of 16 pixels x
+            // 16 channels (4 x 4: 16 MFMAs of 16 cycles per slice).  Two fragment sets (set = slice parity): the 8 reads of
+            // the NEXT slice go out in the first 8 MFMA gaps of the current one, in consumption order (x0 w0 w1 w2 w3 x1 x2
+            // x3), and every use waits only for what it consumes (counted lgkmcnt).
+            static_assert(TM16 == 4 && TN16 == 4, "16x16x32 wave tile is 64 pixels x 64 channels");
+            bf16x8_t fw[2][TN16], fx[2][TM16];
+            auto issue = [&](int q, int set, int wbase, int xbase, int xr_t, int kbit) {
+                // q-th read of a slice's fragment set, in consumption order
+                if (q == 0) { const int ad = (a_rd16[xr_t][0] + xbase) ^ kbit; FD_READ(fx[set][0], ad); }
+                else if (q <= 4) { const int ad = (b_rd16[q - 1] + wbase) ^ kbit; FD_READ(fw[set][q - 1], ad); }
+                else { const int ad = (a_rd16[xr_t][q - 4] + xbase) ^ kbit; FD_READ(fx[set][q - 4], ad); }
+            };
+            if (!(DBG && (a.dbg & 4))) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int ad = b_rd[j] ^ (kk << 5);
-                    FD_READ(fr[kk][j], ad);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int ad = a_rd[0][i] ^ (kk << 5);
-                    FD_READ(fr[kk][TN + i], ad);
-                }
+                for (int q = 0; q < 8; ++q) issue(q, 0, 0, 0, 0, 0);
             }
-        }
-        int tile_no = 0;                                       // pixel table of tile k = k & 3 (written by the halo waves)
-        bool pending = false;
-        for (; it < a.IT; it += a.GM, ++tile_no) {
-            f32x16_t acc[TM][TN];                              // (zeroed by the first MFMAs of the tile: C operand 0)
-            for (int c = 0; c < a.NCH; ++c, ++cg) {
-                const int a_base = (cg & 1) * C::A_BYTES;
-                const bool drain = pending && c == 0;          // this chunk carries the previous tile's stores
-                static_for<9>([&](auto t_c) {
-                    constexpr int t = decltype(t_c)::value;
-                    constexpr int tn = t == 8 ? 0 : t + 1;
-                    auto& accr = acc;
-                    const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
-                    const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
-                    const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
-                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
-                    constexpr bool row_tap = t >= 1 && t <= C::RPT;
-                    if constexpr (row_tap)
-                        if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
-                    if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
-                        __builtin_amdgcn_s_setprio(1);
+            int tile_no = 0;
+            bool pending = false;
+            for (; it < a.IT; it += a.GM, ++tile_no) {
+                f32x4_t acc[TM16][TN16];
+                for (int c = 0; c < a.NCH; ++c, ++cg) {
+                    const int a_base = (cg & 1) * C::A_BYTES;
+                    const bool drain = pending && c == 0;
+                    static_for<9>([&](auto t_c) {
+                        constexpr int t = decltype(t_c)::value;
+                        constexpr int tn = t == 8 ? 0 : t + 1;
+                        auto& accr = acc;
+                        const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
+                        const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
+                        const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
+                        constexpr bool row_tap = t >= 1 && t <= C::RPT;
+                        if constexpr (row_tap)
+                            if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
+                        if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
+                            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int set_cur = (4 * t + kk) % 3, set_new = (4 * t + kk + 2) % 3;
-                            int ad[NF];
-                            if (kk < 2) {                   // slice kk + 2 of this tap
+                            for (int kk = 0; kk < 2; ++kk) {
+                                const int cur = kk, nxt = kk ^ 1;
+                                // next slice: (t, 1) in this tap's stage, or (t + 1, 0) in the next tap's
+                                const int wbase = kk == 0 ? bstage : bnext;
+                                const int xbase = kk == 0 ? a_base : anext;
+                                const int kbit = kk == 0 ? 64 : 0;
+                                constexpr int xr_t = 0;       // placeholder (static table index chosen below)
+                                (void)xr_t;
+                                // the current slice's x0, w0..w3 have landed (its x1..x3 may still be in flight; the
+                                // two row-store reads of a row tap are younger: the count is then conservative)
+                                ws_wait5<3>(fx[cur][0], fw[cur][0], fw[cur][1], fw[cur][2], fw[cur][3]);
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bstage) ^ ((kk + 2) << 5);
+                                for (int i = 0; i < TM16; ++i) {
+                                    if (i == 1) ws_wait1<6>(fx[cur][1]);      // 2 older (x2, x3) + 4 new reads outstanding
+                                    if (i == 2) ws_wait1<9>(fx[cur][2]);      // 1 older (x3) + 8 new
+                                    if (i == 3) ws_wait1<8>(fx[cur][3]);      // the 8 new ones only
 #pragma unroll
-                                for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[t][i] + a_base) ^ ((kk + 2) << 5);
-                            } else {                        // slice kk - 2 of the next tap
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bnext) ^ ((kk - 2) << 5);
-#pragma unroll
-                                for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[tn][i] + anext) ^ ((kk - 2) << 5);
-                            }
-                            // one fragment read of slice +2 in each MFMA gap (issued as a block of four before the MFMAs, the
-                            // reads and their address VALU did not fit the shadow of the previous slice's last MFMA)
-                            ws_wait<NF>(fr[set_cur]);
-                            static_assert(TM * TN == NF, "one read per MFMA gap");
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) {
-                                    const int q = i * TN + j;
-                                    if (!(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
-                                    if ((SEGNB_EXP & 128) && i > 0) continue;      // (experiment 128: half the MFMAs -- timing only)
-                                    if (t == 0 && kk == 0 && c == 0)
-                                        FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
-                                    else
-                                        FD_MFMA(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                    for (int j = 0; j < TN16; ++j) {
+                                        const int q = i * TN16 + j;
+                                        if (q < 8 && !(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) {
+                                            if (kk == 0) issue(q, nxt, wbase, xbase, t, kbit);
+                                            else issue(q, nxt, wbase, xbase, tn, kbit);
+                                        }
+                                        if (t == 0 && kk == 0 && c == 0)
+                                            FD_MFMA16_0(accr[i][j], fw[cur][j], fx[cur][i]);
+                                        else
+                                            FD_MFMA16(accr[i][j], fw[cur][j], fx[cur][i]);
+                                    }
                                 }
+                            }
+                            __builtin_amdgcn_s_setprio(0);
                         }
-                        __builtin_amdgcn_s_setprio(0);
-                    }
-                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
-                    if constexpr (row_tap)
-                        if (drain) {
-                            if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            asm volatile("" : "+v"(row_pix), "+v"(row_v));      // landed: older than the tap's fragment waits
-                            row_store();
-                        }
-                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
-                    if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
-                    if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
-                });
-            }
-            // The slices requested for the next tile's first tap must have LANDED before compiler-scheduled code runs:
-            // their destination registers count as written, and a copy taken before the data arrives is a stale
-            // register (seen as run-to-run differences at bs=32).
-            ws_wait<0>(fr[0]);
-            ws_wait<0>(fr[1]);
-            ws_wait<0>(fr[2]);
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before they are read
-            float4 bv[TN][4];                                  // (one batch of LDS reads, not one round trip per quad)
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
+                        if constexpr (row_tap)
+                            if (drain) {
+                                if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(row_pix), "+v"(row_v));     // older than the 8 look-ahead reads
+                                row_store();
+                            }
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
+                        raw_barrier();
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
+                    });
+                }
+                // look-ahead reads of the next tile's first slice must have LANDED before compiler-scheduled code runs
+                ws_wait5<0>(fx[0][0], fw[0][0], fw[0][1], fw[0][2], fw[0][3]);
+                ws_wait1<0>(fx[0][1]);
+                ws_wait1<0>(fx[0][2]);
+                ws_wait1<0>(fx[0][3]);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);
+                // accumulator tile (i, j): this lane holds channels 16 j + 4 g4 + {0..3} of pixel 16 i + r16
+                const int r16 = lane & 15, g4 = lane >> 4;
+                float4 bv[TN16];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN16; ++j)
+                    bv[j] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 16 * j + 4 * g4);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    bv[j][g] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 32 * j + 8 * g + 4 * h);
+                for (int i = 0; i < TM16; ++i) {
+                    const int row = wm * C::WM + 16 * i + r16;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * C::WM + 32 * i + r;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
-                        const float4 bv4 = bv[j][g];
+                    for (int j = 0; j < TN16; ++j) {
+                        const int col = wn * C::WN + 16 * j + 4 * g4;
                         uint2 pk;
-                        pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
-                        pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
+                        pk.x = pack2bf(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y);
+                        pk.y = pack2bf(acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
                         *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
+                pending = true;
             }
-            pending = true;
+            tile_no_out = tile_no;
+            pending_out = pending;
+        } else {
+
+            bf16x8_t fr[3][NF];
+            if (!(DBG && (a.dbg & 4))) {
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int ad = b_rd[j] ^ (kk << 5);
+                        FD_READ(fr[kk][j], ad);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int ad = a_rd[0][i] ^ (kk << 5);
+                        FD_READ(fr[kk][TN + i], ad);
+                    }
+                }
+            }
+            int tile_no = 0;                                       // pixel table of tile k = k & 3 (written by the halo waves)
+            bool pending = false;
+            for (; it < a.IT; it += a.GM, ++tile_no) {
+                f32x16_t acc[TM][TN];                              // (zeroed by the first MFMAs of the tile: C operand 0)
+                for (int c = 0; c < a.NCH; ++c, ++cg) {
+                    const int a_base = (cg & 1) * C::A_BYTES;
+                    const bool drain = pending && c == 0;          // this chunk carries the previous tile's stores
+                    static_for<9>([&](auto t_c) {
+                        constexpr int t = decltype(t_c)::value;
+                        constexpr int tn = t == 8 ? 0 : t + 1;
+                        auto& accr = acc;
+                        const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
+                        const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
+                        const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
+                        constexpr bool row_tap = t >= 1 && t <= C::RPT;
+                        if constexpr (row_tap)
+                            if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
+                        if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
+                            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const int set_cur = (4 * t + kk) % 3, set_new = (4 * t + kk + 2) % 3;
+                                int ad[NF];
+                                if (kk < 2) {                   // slice kk + 2 of this tap
+    #pragma unroll
+                                    for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bstage) ^ ((kk + 2) << 5);
+    #pragma unroll
+                                    for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[t][i] + a_base) ^ ((kk + 2) << 5);
+                                } else {                        // slice kk - 2 of the next tap
+    #pragma unroll
+                                    for (int j = 0; j < TN; ++j) ad[j] = (b_rd[j] + bnext) ^ ((kk - 2) << 5);
+    #pragma unroll
+                                    for (int i = 0; i < TM; ++i) ad[TN + i] = (a_rd[tn][i] + anext) ^ ((kk - 2) << 5);
+                                }
+                                // one fragment read of slice +2 in each MFMA gap (issued as a block of four before the MFMAs, the
+                                // reads and their address VALU did not fit the shadow of the previous slice's last MFMA)
+                                ws_wait<NF>(fr[set_cur]);
+                                static_assert(TM * TN == NF, "one read per MFMA gap");
+    #pragma unroll
+                                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                                    for (int j = 0; j < TN; ++j) {
+                                        const int q = i * TN + j;
+                                        if (!(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) FD_READ(fr[set_new][q], ad[q]);
+                                        if ((SEGNB_EXP & 128) && i > 0) continue;      // (experiment 128: half the MFMAs -- timing only)
+                                        if (t == 0 && kk == 0 && c == 0)
+                                            FD_MFMA0(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                        else
+                                            FD_MFMA(accr[i][j], fr[set_cur][j], fr[set_cur][TN + i]);
+                                    }
+                            }
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
+                        if constexpr (row_tap)
+                            if (drain) {
+                                if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                asm volatile("" : "+v"(row_pix), "+v"(row_v));      // landed: older than the tap's fragment waits
+                                row_store();
+                            }
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
+                        if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
+                        if (wave == 0) FD_STAMP(0, cg * 9 + t, 3);
+                    });
+                }
+                // The slices requested for the next tile's first tap must have LANDED before compiler-scheduled code runs:
+                // their destination registers count as written, and a copy taken before the data arrives is a stale
+                // register (seen as run-to-run differences at bs=32).
+                ws_wait<0>(fr[0]);
+                ws_wait<0>(fr[1]);
+                ws_wait<0>(fr[2]);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before they are read
+                float4 bv[TN][4];                                  // (one batch of LDS reads, not one round trip per quad)
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bv[j][g] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 32 * j + 8 * g + 4 * h);
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * C::WM + 32 * i + r;
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+    #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = wn * C::WN + 32 * j + 8 * g + 4 * h;
+                            const float4 bv4 = bv[j][g];
+                            uint2 pk;
+                            pk.x = pack2bf(acc[i][j][4 * g + 0] + bv4.x, acc[i][j][4 * g + 1] + bv4.y);
+                            pk.y = pack2bf(acc[i][j][4 * g + 2] + bv4.z, acc[i][j][4 * g + 3] + bv4.w);
+                            *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
+                        }
+                    }
+                }
+                pending = true;
+            }
+            tile_no_out = tile_no;
+            pending_out = pending;
         }
         lds_barrier();                                         // the last tile is staged
-        if (pending) {
+        if (pending_out) {
 #pragma unroll
             for (int k = 0; k < C::RPT; ++k) {
-                row_load(k, sPix + ((tile_no + 3) & 3) * BM);
+                row_load(k, sPix + ((tile_no_out + 3) & 3) * BM);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(row_pix), "+v"(row_v));
                 row_store();
             }
@@ -565,7 +710,11 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         if (a.Co <= 32) return NOT_HANDLED;
         // 7 x 7 images (the deepest ZF_UNET level): tall-image tiles of 36 x 7 virtual pixels -- 8 row tiles x 16 channel
         // tiles = 128 blocks of 144 taps each beat the general kernel's 400 tiles of 64 x 64 (76 -> ~45 us for 1024 -> 1024)
-        if (a.W <= 8) return a.W == 7 && a.H == 7 ? launch_ws<WsCfg<64, 36, 7, 4, true>>(a, stream) : NOT_HANDLED;
+        if (a.W <= 8) {
+            if (a.W != 7 || a.H != 7) return NOT_HANDLED;
+            return segnb_knob_fprop_mf16() ? launch_ws<WsCfg<64, 36, 7, 4, true, true>>(a, stream)
+                                           : launch_ws<WsCfg<64, 36, 7, 4, true, false>>(a, stream);
+        }
         // 8 x 32 or 16 x 16 pixel tiles: whichever needs fewer rounds of (equal) tiles on the persistent blocks --
         // re-measured with the final kernel, the round count decides every case (e.g. 128 -> 384 @56x56: 11 vs 12
         // rounds, 104 vs 122 us; 64 -> 192 @112x112: 21 vs 19 rounds, 133 vs 116 us); ties go to 16 x 16
@@ -576,10 +725,18 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         const long long it1 = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
         cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
     }
+    if (segnb_knob_fprop_mf16()) {
+        switch (cfg) {
+            case 0: return launch_ws<WsCfg<64, 8, 32, 4, false, true>>(a, stream);
+            case 1: return launch_ws<WsCfg<64, 16, 16, 4, false, true>>(a, stream);
+            case 2: return launch_ws<WsCfg<64, 36, 7, 4, true, true>>(a, stream);
+            default: return NOT_HANDLED;
+        }
+    }
     switch (cfg) {
-        case 0: return launch_ws<WsCfg<64, 8, 32, 4>>(a, stream);
-        case 1: return launch_ws<WsCfg<64, 16, 16, 4>>(a, stream);
-        case 2: return launch_ws<WsCfg<64, 36, 7, 4, true>>(a, stream);
+        case 0: return launch_ws<WsCfg<64, 8, 32, 4, false, false>>(a, stream);
+        case 1: return launch_ws<WsCfg<64, 16, 16, 4, false, false>>(a, stream);
+        case 2: return launch_ws<WsCfg<64, 36, 7, 4, true, false>>(a, stream);
         default: return NOT_HANDLED;
     }
 }

@@ -61,6 +61,14 @@ int segnb_knob_conv_cus() {
 }
 static int g_wg_cu_pct = 0;        // 0 = SEGNB_WG_CU_FRACTION / built-in default; else % of the CUs for the wide weight gradients
 int segnb_knob_wg_cu_pct() { return g_wg_cu_pct; }
+static int g_fprop_mf16 = -2;      // conv_fprop_ws_kernel on v_mfma_f32_16x16x32_bf16 (1, default) or 32x32x16 (0)
+int segnb_knob_fprop_mf16() {
+    if (g_fprop_mf16 == -2) {
+        const char* e = getenv("SEGNB_FPROP_MF16");
+        g_fprop_mf16 = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_mf16;
+}
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
@@ -83,6 +91,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
         g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "fprop_mf16") == 0) {
+        g_fprop_mf16 = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero

@@ -20,7 +20,7 @@ from torch import nn
 
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.engine import ConvOp, FlatParams, PackTable, Runtime, Stage, View
+from segnb.engine import ConvOp, FlatParams, InputNorm, PackTable, Runtime, Stage, View, pack_input
 
 ENCODER = ('conv_224', 'conv_112', 'conv_56', 'conv_28', 'conv_14', 'conv_7')
 DECODER = ('up_conv_14', 'up_conv_28', 'up_conv_56', 'up_conv_112', 'up_conv_224')
@@ -72,6 +72,7 @@ class ZF_UNET(nn.Module):
         self.compute_dtype = 'bf16'     # 'bf16' = throughput path, 'f32' = exact-fp32 MFMA parity path
         self._engine = None
         self.dropout_override = None    # {block name: fp32 [N, C] multiplier table} -- Dropout2d replay
+        self.input_norm = InputNorm()   # applied on the device when forward() is given a uint8 NHWC batch
 
     def set_compute_dtype(self, dtype):
         if dtype not in ('bf16', 'f32'):
@@ -89,13 +90,19 @@ class ZF_UNET(nn.Module):
         return e
 
     def forward(self, x):
-        if x.dim() != 4 or x.shape[1] != self._cfg['cin']:
-            raise ValueError('expected input [N, %d, H, W], got %s' % (self._cfg['cin'], tuple(x.shape)))
-        if x.shape[2] % 32 or x.shape[3] % 32:
+        """x: float32 [N, C, H, W] (already normalised: what torch_train.py:177 hands the model), or the batch as the
+        dataset holds it -- uint8 [N, H, W, C] -- which is normalised with ``self.input_norm`` inside the first
+        convolution (lib/augmentations.py:452-460 + lib/common.py:70 fused into the kernel)."""
+        u8 = x.dtype == torch.uint8
+        cdim, hdim, wdim = (3, 1, 2) if u8 else (1, 2, 3)
+        if x.dim() != 4 or x.shape[cdim] != self._cfg['cin']:
+            raise ValueError('expected input [N, %d, H, W] (float) or [N, H, W, %d] (uint8), got %s %s'
+                             % (self._cfg['cin'], self._cfg['cin'], x.dtype, tuple(x.shape)))
+        if x.shape[hdim] % 32 or x.shape[wdim] % 32:
             raise ValueError('ZF_UNET needs H and W divisible by 32 (five 2x poolings), got %dx%d'
-                             % (x.shape[2], x.shape[3]))
+                             % (x.shape[hdim], x.shape[wdim]))
         eng = self._get_engine(x.device)
-        x = x.detach().contiguous().float()
+        x = x.detach().contiguous() if u8 else x.detach().contiguous().float()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _ZFUnetFn.apply(eng, x, *list(self.parameters()))
         return eng.forward(x, self.training, False)
@@ -275,17 +282,24 @@ class _ZFUnetPlan(object):
     def forward(self, x, train, need_grad):
         rt = self.rt
         self.flat.ensure(rt.device)
-        N, C, H, W = x.shape
+        u8 = x.dtype == torch.uint8
+        if u8:
+            N, H, W, C = x.shape
+        else:
+            N, C, H, W = x.shape
         b = self.buffers(N, H, W)
         self._pack_if_needed(H, W)
         drop = self._dropout_tables(b, N, train)
-        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, b['x'].ptr, rt.code, self.cin_p, b['x'].ld,
-                rt.stream)
+        first = None
+        if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
+            first = (x, self.module.input_norm)          # the first convolution reads the image itself
+        else:
+            pack_input(rt, x, b['x'], self.module.input_norm)
         wp = self.wp
         cur = b['x']
         for i, name in enumerate(ENCODER):
             s1, s2 = self.stages[name]
-            s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad)
+            s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None)
             if i < 5:
                 skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
                 s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)

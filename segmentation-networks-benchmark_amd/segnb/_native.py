@@ -50,6 +50,10 @@ SIGNATURES = {
     'segnb_pack_weight_multi': [_P, c_int, c_int, _P],
     'segnb_unpack_wgrad_multi': [_P, c_int, c_int, _P],
     'segnb_pack_input_nchw': [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P],
+    'segnb_pack_input_u8': [_P, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P,
+                            c_int, c_int, c_int, _P],
+    'segnb_conv_fprop_u8': [ctypes.POINTER(ConvGeom), _P, c_int, c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                            _P, _P, c_int, _P, _P, _P, c_int, _P],
     'segnb_bn_finalize': [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P],
     'segnb_bn_act_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P,
                          c_int, _P, c_int, _P, c_int, _P],
@@ -88,7 +92,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None
@@ -158,6 +162,10 @@ def ptr(t, offset_elems=0):
     if t is None:
         return None
     return t.data_ptr() + offset_elems * t.element_size()
+
+
+def float_array(values):
+    return (c_float * len(values))(*[float(v) for v in values])
 
 
 def int_array(values):

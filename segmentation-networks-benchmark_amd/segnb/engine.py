@@ -119,6 +119,34 @@ class Runtime(object):
         return torch.tensor(list(values), dtype=torch.int32, device=self.device)
 
 
+class InputNorm(object):
+    """NormalizeImage of the reference's input pipeline (lib/augmentations.py:452-460): x * scale - mean) / std per
+    channel, applied on the device to a uint8 HWC batch.  Defaults = the reference's."""
+
+    def __init__(self, scale=1. / 255., mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        self.scale, self.mean, self.std = float(scale), tuple(float(m) for m in mean), tuple(float(v) for v in std)
+        if len(self.mean) != len(self.std) or not all(v != 0.0 for v in self.std):
+            raise ValueError('mean / std must have one non-zero std per channel')
+
+    def arrays(self, C):
+        if len(self.mean) != C:
+            raise ValueError('input has %d channels, normalisation has %d' % (C, len(self.mean)))
+        return nv.float_array(self.mean), nv.float_array(self.std)
+
+
+def pack_input(rt, x, xv, norm=None):
+    """The network input -> the NHWC `rt.tdtype` view xv (channels zero-padded): float32 NCHW (what torch_train.py:177
+    hands the model) or uint8 NHWC (what the dataset holds, normalised on the device with `norm`)."""
+    if x.dtype == torch.uint8:
+        N, H, W, C = x.shape
+        mean, std = (norm or InputNorm()).arrays(C)
+        nv.call('segnb_pack_input_u8', nv.ptr(x), N, H, W, C, (norm or InputNorm()).scale, mean, std, xv.ptr, rt.code,
+                xv.Cp, xv.ld, rt.stream)
+    else:
+        N, C, H, W = x.shape
+        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, xv.ptr, rt.code, xv.Cp, xv.ld, rt.stream)
+
+
 class View(object):
     """[N, H, W, Cp] NHWC activation = channel slice [off, off+Cp) of a buffer with pixel stride ld."""
     __slots__ = ('t', 'off', 'ld', 'N', 'H', 'W', 'Cp')
@@ -319,6 +347,28 @@ class ConvOp(object):
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
                                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream))
 
+    def u8_direct_ok(self, N, H, W, ld_out):
+        """True when segnb_conv_fprop_u8 serves this convolution as the network's first layer."""
+        p = self.plan(H, W)
+        if len(p['fwd']) != 1 or self.Cip != 8 or p['out_hw'] != (H, W):
+            return False
+        g = self._geom(p, 'f', 0, p['fwd'][0], N, H, W, self.Cip, self.Cip, H, W, self.Cop, ld_out)
+        return bool(nv.query('segnb_conv_fprop_u8_ok', g, self.rt.code))
+
+    def fprop_u8(self, img, norm, yv, stats=None, packed=None):
+        """First layer straight from the uint8 HWC batch `img` [N,H,W,C]; packed: optional View that receives the
+        normalised bf16 pixels (the x operand of this layer's weight gradient)."""
+        N, H, W, C = img.shape
+        p, rt = self.plan(H, W), self.rt
+        l = p['fwd'][0]
+        g = self._geom(p, 'f', 0, l, N, H, W, self.Cip, self.Cip, yv.H, yv.W, self.Cop, yv.ld)
+        mean, std = norm.arrays(C)
+        b = self.bias.detach() if self.bias is not None else None
+        _timed('conv_fprop', 2.0 * N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_u8', g, nv.ptr(img), C, norm.scale, mean, std, nv.ptr(p['wp_fwd'][0]),
+                               nv.ptr(b), self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), vptr(packed),
+                               vld(packed), rt.stream))
+
     def dgrad(self, dyv, dxv):
         p, rt = self.plan(dxv.H, dxv.W), self.rt
         assert self.need_dgrad and dyv.Cp == self.Cop and dxv.Cp == self.Cip
@@ -439,7 +489,9 @@ class Stage(object):
             self._bufs[key] = b
         return b
 
-    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True):
+    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True, u8=None):
+        """u8: (uint8 NHWC batch, InputNorm) -- this stage is the network's first convolution and reads the image
+        itself (segnb_conv_fprop_u8); xv then only RECEIVES the normalised pixels (for the weight gradient)."""
         rt = self.rt
         Ho, Wo = self.conv.out_hw(xv.H, xv.W)
         b = self.buffers(xv.N, Ho, Wo)
@@ -449,7 +501,10 @@ class Stage(object):
             # the previous training-mode forward was fused (statistics left unconsumed) and no backward cleared them
             self.stats.zero_()
             self._stats_stale = False
-        self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
+        if u8 is not None:
+            self.conv.fprop_u8(u8[0], u8[1], yv, self.stats if use_batch_stats else None, xv if need_grad else None)
+        else:
+            self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
         coef = None
         fused = use_batch_stats and self.fuse_finalize and need_grad
         if fused:

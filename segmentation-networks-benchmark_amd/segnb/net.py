@@ -17,7 +17,7 @@ from torch import nn
 
 from . import _native as nv
 from . import convplan as cp
-from .engine import BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, Runtime, View, vld, vptr
+from .engine import BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, InputNorm, Runtime, View, pack_input, vld, vptr
 
 
 class Act(object):
@@ -336,6 +336,7 @@ class HipNet(nn.Module):
         self.compute_dtype = 'bf16'
         self._tape = None
         self._in_channels = in_channels
+        self.input_norm = InputNorm()           # for uint8 NHWC batches (lib/augmentations.py:452-460 on the device)
 
     def set_compute_dtype(self, dtype):
         if dtype not in ('bf16', 'f32'):
@@ -346,12 +347,19 @@ class HipNet(nn.Module):
         return self
 
     def _check_input(self, x):
-        if x.dim() != 4 or x.shape[1] != self._in_channels:
-            raise ValueError('expected input [N, %d, H, W], got %s' % (self._in_channels, tuple(x.shape)))
+        cdim = 3 if x.dtype == torch.uint8 else 1
+        if x.dim() != 4 or x.shape[cdim] != self._in_channels:
+            raise ValueError('expected input [N, %d, H, W] (float) or [N, H, W, %d] (uint8), got %s %s'
+                             % (self._in_channels, self._in_channels, x.dtype, tuple(x.shape)))
 
     def forward(self, x):
-        self._check_input(x)
-        x = x.detach().contiguous().float()
+        """x: float32 [N, C, H, W], or uint8 [N, H, W, C] normalised on the device with ``self.input_norm``."""
+        if x.dtype == torch.uint8:              # the shape checks of the subclasses speak NCHW
+            self._check_input(torch.empty((x.shape[0], x.shape[3], x.shape[1], x.shape[2]), device='meta'))
+            x = x.detach().contiguous()
+        else:
+            self._check_input(x)
+            x = x.detach().contiguous().float()
         if self._tape is None or self._tape.rt.device != x.device:
             self._tape = Tape(self, x.device, self.compute_dtype)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -361,10 +369,13 @@ class HipNet(nn.Module):
     def _run(self, x, need_grad):
         tape = self._tape
         tape.begin(self.training, need_grad)
-        N, C, H, W = x.shape
+        if x.dtype == torch.uint8:
+            N, H, W, C = x.shape
+        else:
+            N, C, H, W = x.shape
         cin_p = cp.pad8(C)
         xin = tape.view('input', N, H, W, cin_p)
-        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, xin.ptr, tape.rt.code, cin_p, xin.ld, tape.rt.stream)
+        pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         self._dlogits = [None]
         logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
         return logits.clone()

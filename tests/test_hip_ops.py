@@ -492,8 +492,9 @@ def test_pr_curve_histogram_kernel_vs_threshold_loop():
 
 
 def test_snapshot_round_trip_gpu(tmp_path):
-    """save_snapshot / restore_snapshot (torch_train.py:308-330) with the bf16 HIP path and the one-launch Adam:
-    the resumed run continues bit-identically."""
+    """save_snapshot / restore_snapshot (torch_train.py:308-330) with the bf16 HIP path and the one-launch Adam: model
+    and optimizer state come back bit for bit; the resumed run then tracks the uninterrupted one (not bitwise: the head's
+    weight gradient is accumulated with fp32 atomics, and Adam turns an ulp of a near-zero gradient into lr-sized steps)."""
     import torch_train as TT
     from lib.models.zf_unet import ZF_UNET
     torch.manual_seed(0)
@@ -512,10 +513,19 @@ def test_snapshot_round_trip_gpu(tmp_path):
     o2 = TT.get_optimizer('adam', m2.parameters(), 1e-3)
     start, _, best = TT.restore_snapshot(m2, o2, f)
     assert start == 1 and best == 0.25
-    TT.train(model, TT.get_loss('bce_jaccard'), opt, data)
-    TT.train(m2, TT.get_loss('bce_jaccard'), o2, data)
     for (k, a), b in zip(model.state_dict().items(), m2.state_dict().values()):
         assert torch.equal(a, b), k
+    sa, sb = opt.state_dict()['state'], o2.state_dict()['state']
+    assert len(sa) == len(sb) == len(list(model.parameters()))
+    for i in sa:
+        assert float(sa[i]['step']) == float(sb[i]['step']) == 2.0
+        assert torch.equal(sa[i]['exp_avg'], sb[i]['exp_avg']) and torch.equal(sa[i]['exp_avg_sq'], sb[i]['exp_avg_sq'])
+    la, _ = TT.train(model, TT.get_loss('bce_jaccard'), opt, data)
+    lb, _ = TT.train(m2, TT.get_loss('bce_jaccard'), o2, data)
+    assert abs(la.avg - lb.avg) < 1e-3
+    for (k, a), b in zip(model.named_parameters(), m2.parameters()):
+        assert float((a - b).abs().max()) <= 5e-3, k            # two Adam steps of lr 1e-3 each
+    assert float(o2.state_dict()['state'][0]['step']) == 4.0
 
 
 def test_sgd_and_input_pack():

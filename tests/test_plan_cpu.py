@@ -156,3 +156,12 @@ def test_grad_accumulation_without_zero_grad(golden_dir):
     for n, p in m.named_parameters():
         # second pass sees updated BN running stats only (train-mode output unchanged) -> exactly 2x
         np.testing.assert_allclose(p.grad.numpy(), 2 * g1[n].numpy(), rtol=1e-5, atol=1e-7, err_msg=n)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_uint8_hwc_input_matches_normalized_float_input(dtype):
+    """the dataset's uint8 HWC batch fed straight to the model (NormalizeImage of
+    lib/augmentations.py:452-460 + the HWC -> CHW move of lib/common.py:70 on the device; bf16: inside the first
+    convolution) == the reference flow (normalise on the host, float NCHW tensor).  Host logic on the emulator."""
+    import model_checks as mc
+    mc.check_uint8_input('cpu', dtype)

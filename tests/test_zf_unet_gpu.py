@@ -296,6 +296,50 @@ def test_timed_config_bs32_bf16_vs_fp32_hip_path():
     assert worst_ratio[1] < 0.1, worst_ratio
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_uint8_hwc_input_matches_normalized_float_input(dtype):
+    """SURVEY 8f rank 2 on the HIP kernels: uint8 HWC batch -> segnb_conv_fprop_u8 (bf16: the first convolution reads the
+    image itself and publishes the packed pixels for its weight gradient) / segnb_pack_input_u8 (f32) vs the float NCHW
+    batch normalised by the reference's formula."""
+    import model_checks as mc
+    mc.check_uint8_input('cuda', dtype)
+
+
+def test_uint8_first_layer_kernel_bitwise_vs_packed_path():
+    """segnb_conv_fprop_u8 == segnb_pack_input_u8 + segnb_conv_fprop bit for bit (same arithmetic, no packed copy read),
+    at the timed size (bs=32 224x224), including the packed pixels it publishes and the BatchNorm statistics."""
+    from segnb import _native as nv
+    from segnb import convplan as cp
+    from segnb.engine import ConvOp, InputNorm, Runtime, View, pack_input
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (32, 224, 224, 3), generator=gen, dtype=torch.uint8).cuda()
+    w = (torch.randn(32, 3, 3, 3, generator=gen) * 0.2).cuda()
+    b = (torch.randn(32, generator=gen) * 0.1).cuda()
+    op = ConvOp(rt, w, b, [(3, 8)], 1, 1, False, need_dgrad=False)
+    op.pack(224, 224)
+    norm = InputNorm()
+    xv = View.alloc(rt, 32, 224, 224, 8)
+    pack_input(rt, img, xv, norm)
+    y0, st0 = View.alloc(rt, 32, 224, 224, 32), rt.zeros((16, 2, 32), torch.float64)
+    op.fprop(xv, y0, st0)
+    assert op.u8_direct_ok(32, 224, 224, 32)
+    xp = View.alloc(rt, 32, 224, 224, 8)
+    y1, st1 = View.alloc(rt, 32, 224, 224, 32), rt.zeros((16, 2, 32), torch.float64)
+    op.fprop_u8(img, norm, y1, st1, xp)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.t, y1.t) and torch.equal(xv.t, xp.t)
+    np.testing.assert_allclose(st1.sum(0).cpu().numpy(), st0.sum(0).cpu().numpy(), rtol=1e-12)
+    # and the packed pixels are the reference's NormalizeImage rounded to bf16 (fp32 vs float64 arithmetic: a rounding
+    # boundary is crossed at most once in ~1e4 values)
+    import model_checks as mc
+    ref = torch.from_numpy(mc.normalize_image_ref(img.cpu().numpy()).astype(np.float32)).bfloat16().float()
+    got = xv.dense()[..., :3].float().cpu()
+    diff = (got - ref).abs()
+    assert float(diff.max()) <= 2 ** -7 * float(ref.abs().max()) and float((diff > 0).float().mean()) < 1e-3
+    assert float(xv.dense()[..., 3:].abs().max()) == 0.0
+
+
 def test_eval_matches_train_statistics_path():
     """validate() path (torch_train.py:248-265): no-grad eval forward uses running statistics."""
     m = _model(8, 0.0, 4.0, 'f32')
