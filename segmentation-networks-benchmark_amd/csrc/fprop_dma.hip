@@ -318,25 +318,33 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         int a_rd[MF16 ? 1 : 9][MF16 ? 1 : TM];
         // 16x16x32 form: lane = (row r16 of the 16-row fragment, 8-channel group g4 of the 32-channel K slice); the 16-byte
         // slot of (row, slice kk, group g4) is (kk * 4 + g4) ^ ((key >> 1) & 7) -- the same source swizzle, read 32 channels deep
-        int b_rd16[MF16 ? TN16 : 1];
-        int a_rd16[MF16 ? 9 : 1][MF16 ? TM16 : 1];
+        // per fragment BOTH K-slice variants (kk = 0 / 1: the slot index differs in bit 2, i.e. address bit 6 XOR-ed) are kept,
+        // and the tap enters only through its column shift dw (the swizzle key of a pixel is its halo column) plus a
+        // wave-uniform row term: a read address is ONE vector add of a scalar (matrix waves have 8 free issue cycles per
+        // 16-cycle MFMA).  Requires XC even and taps ordered t = 3 * (row) + (column) (checked on the host).
+        static_assert(!MF16 || XC % 2 == 0, "16x16x32 form: the swizzle key must be the halo column");
+        int b_rd16[MF16 ? 2 : 1][MF16 ? TN16 : 1];
+        int a_rd16[MF16 ? 3 : 1][MF16 ? TM16 : 1][MF16 ? 2 : 1];
         if constexpr (MF16) {
             const int r16 = lane & 15, g4 = lane >> 4;
     #pragma unroll
             for (int j = 0; j < TN16; ++j) {
                 const int row = wn * C::WN + 16 * j + r16;
-                b_rd16[j] = C::OFF_B + row * 128 + ((g4 ^ ((row >> 1) & 7)) << 4);
+                const int v = C::OFF_B + row * 128 + ((g4 ^ ((row >> 1) & 7)) << 4);
+                b_rd16[0][j] = v;
+                b_rd16[1][j] = v ^ 64;
             }
     #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int dwi = 0; dwi < 3; ++dwi)
     #pragma unroll
                 for (int i = 0; i < TM16; ++i) {
                     const int m = wm * C::WM + 16 * i + r16;
-                    const int p = (m / WT) * XC + (m % WT) + a.dh[t] * XC + a.dw[t];
-                    const int key = XC % 2 == 0 ? p % XC : p;
+                    const int p = (m / WT) * XC + (m % WT) + a.dw[dwi];          // column-shifted pixel, tap row 0
+                    const int key = p % XC;
                     int v = (p << 7) + ((g4 ^ ((key >> 1) & 7)) << 4);
                     asm volatile("" : "+v"(v));
-                    a_rd16[t][i] = v;
+                    a_rd16[dwi][i][0] = v;
+                    a_rd16[dwi][i][1] = v ^ 64;
                 }
         } else {
         #pragma unroll
@@ -410,15 +418,19 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             // x3), and every use waits only for what it consumes (counted lgkmcnt).
             static_assert(TM16 == 4 && TN16 == 4, "16x16x32 wave tile is 64 pixels x 64 channels");
             bf16x8_t fw[2][TN16], fx[2][TM16];
-            auto issue = [&](int q, int set, int wbase, int xbase, int xr_t, int kbit) {
-                // q-th read of a slice's fragment set, in consumption order
-                if (q == 0) { const int ad = (a_rd16[xr_t][0] + xbase) ^ kbit; FD_READ(fx[set][0], ad); }
-                else if (q <= 4) { const int ad = (b_rd16[q - 1] + wbase) ^ kbit; FD_READ(fw[set][q - 1], ad); }
-                else { const int ad = (a_rd16[xr_t][q - 4] + xbase) ^ kbit; FD_READ(fx[set][q - 4], ad); }
+            // q-th read of a fragment set, in consumption order; t = tap of the slice being fetched, k = its K slice,
+            // wbase / xbase = wave-uniform LDS bases of its weight stage / halo buffer (+ the tap's row term)
+            auto issue = [&](int q, int set, int wbase, int xbase, int t, int k) {
+                if (q == 0) { const int ad = a_rd16[t % 3][0][k] + xbase; FD_READ(fx[set][0], ad); }
+                else if (q <= 4) { const int ad = b_rd16[k][q - 1] + wbase; FD_READ(fw[set][q - 1], ad); }
+                else { const int ad = a_rd16[t % 3][q - 4][k] + xbase; FD_READ(fx[set][q - 4], ad); }
             };
+            int arow[3];                                           // row term of tap rows 0..2 (bytes)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) arow[k] = __builtin_amdgcn_readfirstlane(a.dh[3 * k] * XC * 128);
             if (!(DBG && (a.dbg & 4))) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) issue(q, 0, 0, 0, 0, 0);
+                for (int q = 0; q < 8; ++q) issue(q, 0, 0, arow[0], 0, 0);
             }
             int tile_no = 0;
             bool pending = false;
@@ -443,26 +455,26 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
                             for (int kk = 0; kk < 2; ++kk) {
                                 const int cur = kk, nxt = kk ^ 1;
-                                // next slice: (t, 1) in this tap's stage, or (t + 1, 0) in the next tap's
+                                // the slice fetched during this one: (t, 1) in this tap's stage, or (t + 1, 0) in the next tap's
+                                constexpr int ft = 0;
+                                (void)ft;
                                 const int wbase = kk == 0 ? bstage : bnext;
-                                const int xbase = kk == 0 ? a_base : anext;
-                                const int kbit = kk == 0 ? 64 : 0;
-                                constexpr int xr_t = 0;       // placeholder (static table index chosen below)
-                                (void)xr_t;
+                                const int xbase = kk == 0 ? a_base + arow[t / 3] : anext + arow[tn / 3];
                                 // the current slice's x0, w0..w3 have landed (its x1..x3 may still be in flight; the
                                 // two row-store reads of a row tap are younger: the count is then conservative)
                                 ws_wait5<3>(fx[cur][0], fw[cur][0], fw[cur][1], fw[cur][2], fw[cur][3]);
 #pragma unroll
                                 for (int i = 0; i < TM16; ++i) {
-                                    if (i == 1) ws_wait1<6>(fx[cur][1]);      // 2 older (x2, x3) + 4 new reads outstanding
-                                    if (i == 2) ws_wait1<9>(fx[cur][2]);      // 1 older (x3) + 8 new
-                                    if (i == 3) ws_wait1<8>(fx[cur][3]);      // the 8 new ones only
+                                    // one read of the next slice every second MFMA gap: at the waits below 2 i of the 8 are out
+                                    if (i == 1) ws_wait1<4>(fx[cur][1]);      // older x2, x3 + 2 new reads may be outstanding
+                                    if (i == 2) ws_wait1<5>(fx[cur][2]);      // older x3 + 4 new
+                                    if (i == 3) ws_wait1<6>(fx[cur][3]);      // 6 new
 #pragma unroll
                                     for (int j = 0; j < TN16; ++j) {
                                         const int q = i * TN16 + j;
-                                        if (q < 8 && !(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) {
-                                            if (kk == 0) issue(q, nxt, wbase, xbase, t, kbit);
-                                            else issue(q, nxt, wbase, xbase, tn, kbit);
+                                        if (q % 2 == 0 && !(SEGNB_EXP & 16) && !(DBG && (a.dbg & 16))) {
+                                            if (kk == 0) issue(q / 2, nxt, wbase, xbase, t, 1);
+                                            else issue(q / 2, nxt, wbase, xbase, tn, 0);
                                         }
                                         if (t == 0 && kk == 0 && c == 0)
                                             FD_MFMA16_0(accr[i][j], fw[cur][j], fx[cur][i]);
@@ -712,8 +724,7 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         // tiles = 128 blocks of 144 taps each beat the general kernel's 400 tiles of 64 x 64 (76 -> ~45 us for 1024 -> 1024)
         if (a.W <= 8) {
             if (a.W != 7 || a.H != 7) return NOT_HANDLED;
-            return segnb_knob_fprop_mf16() ? launch_ws<WsCfg<64, 36, 7, 4, true, true>>(a, stream)
-                                           : launch_ws<WsCfg<64, 36, 7, 4, true, false>>(a, stream);
+            return launch_ws<WsCfg<64, 36, 7, 4, true, false>>(a, stream);      // odd halo pitch: 32x32x16 form
         }
         // 8 x 32 or 16 x 16 pixel tiles: whichever needs fewer rounds of (equal) tiles on the persistent blocks --
         // re-measured with the final kernel, the round count decides every case (e.g. 128 -> 384 @56x56: 11 vs 12
@@ -725,11 +736,13 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         const long long it1 = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
         cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
     }
-    if (segnb_knob_fprop_mf16()) {
+    bool row_major_taps = true;          // the 16x16x32 form indexes its address tables by (t / 3, t % 3)
+    for (int t = 0; t < 9; ++t) row_major_taps = row_major_taps && a.dw[t] == a.dw[t % 3] && a.dh[t] == a.dh[3 * (t / 3)];
+    if (segnb_knob_fprop_mf16() && row_major_taps) {
         switch (cfg) {
             case 0: return launch_ws<WsCfg<64, 8, 32, 4, false, true>>(a, stream);
             case 1: return launch_ws<WsCfg<64, 16, 16, 4, false, true>>(a, stream);
-            case 2: return launch_ws<WsCfg<64, 36, 7, 4, true, true>>(a, stream);
+            case 2: return launch_ws<WsCfg<64, 36, 7, 4, true, false>>(a, stream);
             default: return NOT_HANDLED;
         }
     }
