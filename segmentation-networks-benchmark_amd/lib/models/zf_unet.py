@@ -112,10 +112,17 @@ class _ZFUnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, x, *params):
         ctx.eng = eng
-        return eng.forward(x, eng.module.training, True)
+        out = eng.forward(x, eng.module.training, True)
+        ctx.generation = eng.generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        if ctx.generation != ctx.eng.generation:
+            # one set of activation / dropout / statistics buffers per input geometry: a later forward has overwritten
+            # what this graph's backward needs -- refuse instead of using the wrong activations
+            raise RuntimeError('ZF_UNET: another forward ran on this model since the forward being differentiated; '
+                               'run backward before the next forward (the plan keeps ONE set of activation buffers)')
         grads = ctx.eng.backward(dlogits.contiguous().float())
         return (None, None) + tuple(grads)
 
@@ -146,6 +153,7 @@ class _ZFUnetPlan(object):
         self._bufs = {}
         self._pack_tables = {}
         self._packed_key = None
+        self.generation = 0
         self.K = module.num_classes
 
     def _add(self, name, blk, seg1, need_dgrad_l1):
@@ -318,6 +326,8 @@ class _ZFUnetPlan(object):
         nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
                 nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
         self._last = (N, H, W) if need_grad else None
+        self.generation += 1                       # every forward overwrites the activation buffers
+        self._last_train = bool(train)
         return logits.clone()
 
     # ---- backward --------------------------------------------------------------------------------------
@@ -325,6 +335,11 @@ class _ZFUnetPlan(object):
         rt, flat, wp = self.rt, self.flat, self.wp
         if self._last is None:
             raise RuntimeError('backward without a grad-enabled forward')
+        if not self._last_train and self.module._cfg['bn']:
+            # the backward plan implements the TRAINING-mode BatchNorm gradient (batch statistics); through an eval-mode
+            # forward (running statistics) BatchNorm is a plain affine map and that formula is wrong
+            raise RuntimeError('backward through an eval-mode forward is not supported: BatchNorm gradients are '
+                               'implemented for training mode (call model.train(), or run the forward under no_grad)')
         N, H, W = self._last
         b = self.buffers(N, H, W)
         accumulate_in_place = flat.begin_backward()

@@ -40,20 +40,23 @@ class _ABNFn(torch.autograd.Function):
         coef = torch.zeros((4, Cp), dtype=torch.float32, device=dev)
         if training:
             nv.call('segnb_bn_stats', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(stats), st)
-        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(weight.detach()),
-                nv.ptr(bias.detach()), eps, momentum, nv.ptr(running_mean), nv.ptr(running_var), None,
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W),
+                nv.ptr(weight.detach() if weight is not None else None),
+                nv.ptr(bias.detach() if bias is not None else None), eps, momentum, nv.ptr(running_mean),
+                nv.ptr(running_var), None,
                 1 if training else 0, nv.ptr(coef), st)
         out = torch.empty_like(y)
         nv.call('segnb_bn_act_fwd', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(out), Cp,
                 None, 0, None, 0, None, 0, st)
-        ctx.save_for_backward(y, coef, weight)
-        ctx.cfg = (N, C, H, W, Cp, act, slope)
+        ctx.training = bool(training)
+        ctx.save_for_backward(y, coef, weight if weight is not None else coef.new_empty(0))
+        ctx.cfg = (N, C, H, W, Cp, act, slope, weight is not None)
         return out[..., :C].permute(0, 3, 1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, gout):
         y, coef, weight = ctx.saved_tensors
-        N, C, H, W, Cp, act, slope = ctx.cfg
+        N, C, H, W, Cp, act, slope, affine = ctx.cfg
         dev, st = y.device, (torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0)
         g = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=dev)
         g[..., :C] = gout.detach().permute(0, 2, 3, 1)
@@ -64,11 +67,24 @@ class _ABNFn(torch.autograd.Function):
         dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
         nv.call('segnb_bn_act_bwd_reduce', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(g),
                 Cp, None, 0, None, 0, nv.ptr(dz), Cp, nv.ptr(sums), None, 0, st)
-        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(weight.detach()), nv.ptr(coef),
-                nv.ptr(bcoef), nv.ptr(dgamma), nv.ptr(dbeta), 0, st)
+        if not ctx.training:
+            # inference-mode backward of the reference (functions.py:113-116: edz = eydz = 0): a plain affine map,
+            # dx = dz * gamma * rstd; dgamma / dbeta are still the sums (the training formula is wrong here)
+            sums_keep = sums.clone()
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums_keep), C, Cp, float(N * H * W),
+                    nv.ptr(weight.detach() if affine else None), nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dgamma),
+                    nv.ptr(dbeta), 0, st)
+            scale = coef[0, :C]                                   # gamma * rstd of the running statistics
+            dx = dz[..., :C] * scale
+            return (dx.permute(0, 3, 1, 2).contiguous(), dgamma if affine else None, dbeta if affine else None, None,
+                    None, None, None, None, None, None)
+        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W),
+                nv.ptr(weight.detach() if affine else None), nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dgamma), nv.ptr(dbeta),
+                0, st)
         nv.call('segnb_bn_bwd_apply', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dz), Cp,
                 nv.ptr(dz), Cp, None, C, st)
-        return dz[..., :C].permute(0, 3, 1, 2).contiguous(), dgamma, dbeta, None, None, None, None, None, None, None
+        return (dz[..., :C].permute(0, 3, 1, 2).contiguous(), dgamma if affine else None, dbeta if affine else None, None,
+                None, None, None, None, None, None)
 
 
 class InPlaceABN(nn.Module):
@@ -76,27 +92,32 @@ class InPlaceABN(nn.Module):
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation='leaky_relu', slope=0.01):
         super(InPlaceABN, self).__init__()
-        if not affine:
-            raise NotImplementedError('affine=False is used by no model in the reference')
-        if activation not in (ACT_LEAKY_RELU, ACT_NONE):
-            raise NotImplementedError("activation %r: the reference's models use only 'leaky_relu'" % (activation,))
+        if activation not in (ACT_LEAKY_RELU, ACT_ELU, ACT_NONE):
+            raise ValueError('activation must be one of leaky_relu, elu, none (bn.py:59), got %r' % (activation,))
         self.num_features, self.affine, self.eps, self.momentum = num_features, affine, eps, momentum
         self.activation, self.slope = activation, slope
-        self.weight = nn.Parameter(torch.ones(num_features))
-        self.bias = nn.Parameter(torch.zeros(num_features))
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
 
     def reset_parameters(self):
         nn.init.constant_(self.running_mean, 0)
         nn.init.constant_(self.running_var, 1)
-        nn.init.constant_(self.weight, 1)
-        nn.init.constant_(self.bias, 0)
+        if self.affine:
+            nn.init.constant_(self.weight, 1)
+            nn.init.constant_(self.bias, 0)
 
     def forward(self, x):
         act = nv.ACT_LEAKY if self.activation == ACT_LEAKY_RELU else nv.ACT_NONE
-        return _ABNFn.apply(x.float(), self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                            self.momentum, self.eps, act, self.slope)
+        y = _ABNFn.apply(x.float(), self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                         self.momentum, self.eps, act, self.slope)
+        # 'elu' is used by no model of the reference: BatchNorm on the HIP kernels, the ELU as a torch op on top
+        return torch.nn.functional.elu(y) if self.activation == ACT_ELU else y
 
     def __repr__(self):
         return '%s(%d, eps=%g, momentum=%g, affine=%s, activation=%s slope=%g)' % (

@@ -78,6 +78,7 @@ class DataParallel(object):
 
     # ---- parameters ------------------------------------------------------------------------------------
     def broadcast_parameters(self, flat):
+        flat.track_accumulation = self.active       # (one abs-max of the flat gradient buffer per backward, DP jobs only)
         if self.active and not self._synced:
             td.broadcast(flat.flat_p, src=0)
             for b in self.model.buffers():
@@ -130,6 +131,11 @@ class DataParallel(object):
         """End of backward: reduce whatever is left, then make the compute stream wait for the collectives."""
         if not self.active:
             return
+        if getattr(flat, 'accumulating', False):
+            # .grad already aliased the flat buffer and was not zeroed: it holds REDUCED gradients of earlier steps plus
+            # this step's local ones -- a second all-reduce would multiply the earlier part by the world size (ADVICE r1)
+            raise RuntimeError('data parallel: gradients were accumulated across steps (no zero_grad between them); '
+                               'zero the gradients every step, or all-reduce once after the last accumulation step')
         self.grads_ready(flat, 0)          # (the plan joined its side stream before calling: no other producers)
         self._done_upto = None
         for w in self._pending:

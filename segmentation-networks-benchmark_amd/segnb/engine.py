@@ -671,7 +671,10 @@ class FlatParams(object):
         lib/train_utils.py:54-65; zero_grad(set_to_none=False) zeroes them in place); otherwise flat_g is
         cleared first."""
         if self.grads_alias():
+            # accumulating on top of non-zero gradients?  (a data-parallel sync must not reduce them twice)
+            self.accumulating = bool(self.flat_g.abs().max() > 0) if getattr(self, 'track_accumulation', False) else False
             return True
+        self.accumulating = False
         self.flat_g.zero_()
         return False
 

@@ -43,6 +43,7 @@ class Tape(object):
         self.flat.ensure(self.rt.device)
         self.train, self.need_grad = train, need_grad
         self.back, self._seq = [], 0
+        self.generation = getattr(self, 'generation', 0) + 1
         # weight-packing generation: every ConvOp plan (one per input size) remembers the generation it was packed at,
         # so a plan first used -- or last used -- under other parameter values is (re)packed on its next use
         self.pack_key = (sum(p._version for p in self.module.parameters()), self.flat.version,
@@ -321,10 +322,16 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         ctx.net = net
-        return net._run(x, True)
+        out = net._run(x, True)
+        ctx.generation = net._tape.generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        if ctx.generation != ctx.net._tape.generation:
+            raise RuntimeError('%s: another forward ran on this model since the forward being differentiated; run '
+                               'backward before the next forward (the tape keeps ONE set of activation buffers)'
+                               % type(ctx.net).__name__)
         ctx.net._run_backward(dlogits.contiguous().float())
         return (None, None) + tuple(None for _ in ctx.net.parameters())
 
@@ -382,6 +389,10 @@ class HipNet(nn.Module):
 
     def _run_backward(self, dlogits):
         tape = self._tape
+        if not tape.train and any(isinstance(m, nn.modules.batchnorm._BatchNorm) or type(m).__name__ == 'InPlaceABN'
+                                  for m in self.modules()):
+            raise RuntimeError('backward through an eval-mode forward is not supported: BatchNorm gradients are '
+                               'implemented for training mode (call model.train(), or run the forward under no_grad)')
         self._dlogits[0] = dlogits
         acc = tape.flat.begin_backward()
         tape.backward()

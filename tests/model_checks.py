@@ -309,3 +309,38 @@ def check_uint8_input(device, dtype):
     # the bound is on the relative L2 error per tensor, not per element
     for a, b in ((g1_u, g1_f), (g2_u, g2_f)):
         assert float((a - b).norm() / b.norm()) <= (5e-2 if dtype == 'f32' else 0.2), float((a - b).norm() / b.norm())
+
+
+def check_inplace_abn_surface(device):
+    """InPlaceABN constructor surface (bn.py:50): activation in {leaky_relu, elu, none}, affine False, and the
+    inference-mode backward (functions.py:113-116) vs torch BatchNorm2d + activation on the CPU."""
+    from lib.modules.abn import InPlaceABN
+    import torch.nn.functional as F
+    torch.manual_seed(7)
+    x = torch.randn(3, 12, 9, 7)
+    r = torch.randn(3, 12, 9, 7)
+    for activation, affine, train in (('elu', True, True), ('none', False, True), ('leaky_relu', False, True),
+                                      ('leaky_relu', True, False)):
+        abn = InPlaceABN(12, activation=activation, affine=affine).to(device)
+        bn = torch.nn.BatchNorm2d(12, affine=affine)
+        with torch.no_grad():
+            abn.running_mean.copy_(0.1 * torch.randn(12)); abn.running_var.copy_(0.5 + torch.rand(12))
+            bn.running_mean.copy_(abn.running_mean.cpu()); bn.running_var.copy_(abn.running_var.cpu())
+            if affine:
+                abn.weight.copy_(1 + 0.2 * torch.randn(12)); abn.bias.copy_(0.1 * torch.randn(12))
+                bn.weight.copy_(abn.weight.cpu()); bn.bias.copy_(abn.bias.cpu())
+        abn.train(train); bn.train(train)
+        act = {'elu': F.elu, 'none': lambda t: t, 'leaky_relu': lambda t: F.leaky_relu(t, 0.01)}[activation]
+        xa, xb = x.clone().to(device).requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = abn(xa), act(bn(xb))
+        (ya * r.to(device)).sum().backward()
+        (yb * r).sum().backward()
+        tag = (activation, affine, train)
+        torch.testing.assert_close(ya.detach().cpu(), yb.detach(), rtol=1e-5, atol=1e-5, msg=str(tag))
+        torch.testing.assert_close(xa.grad.cpu(), xb.grad, rtol=1e-4, atol=1e-5, msg=str(tag))
+        if affine:
+            torch.testing.assert_close(abn.weight.grad.cpu(), bn.weight.grad, rtol=1e-4, atol=1e-5, msg=str(tag))
+            torch.testing.assert_close(abn.bias.grad.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-5, msg=str(tag))
+        else:
+            assert abn.weight is None and abn.bias is None and 'weight' not in abn.state_dict()
+        torch.testing.assert_close(abn.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6, msg=str(tag))

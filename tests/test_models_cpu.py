@@ -143,6 +143,10 @@ def test_inplace_abn_module_standalone():
     torch.testing.assert_close(abn.running_var, bn.running_var, rtol=1e-5, atol=1e-6)
 
 
+def test_inplace_abn_constructor_surface():
+    mc.check_inplace_abn_surface('cpu')
+
+
 def test_replay_harness_self_consistent(golden_dir):
     """tests/abi_replay.py (the teacher-forced GPU parity harness) replaying the emulator against itself."""
     import abi_replay

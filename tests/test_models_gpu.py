@@ -240,6 +240,10 @@ def test_inplace_abn_standalone_gpu():
         torch.testing.assert_close(abn(x.cuda()).cpu(), torch.nn.functional.leaky_relu(bn(x), 0.01), rtol=1e-5, atol=1e-5)
 
 
+def test_inplace_abn_constructor_surface_gpu():
+    mc.check_inplace_abn_surface('cuda')
+
+
 def test_find_optimal_lr_gpu():
     """lib.train_utils.find_optimal_lr (train_utils.py:36-69) on the HIP path: 30 steps, lr doubling from 1e-8,
     gradients accumulate (never zeroed) exactly as the same loop on the oracle."""

@@ -165,3 +165,26 @@ def test_uint8_hwc_input_matches_normalized_float_input(dtype):
     convolution) == the reference flow (normalise on the host, float NCHW tensor).  Host logic on the emulator."""
     import model_checks as mc
     mc.check_uint8_input('cpu', dtype)
+
+
+def test_backward_through_eval_forward_is_refused():
+    """the backward plan implements the training-mode BatchNorm gradient; after an eval-mode forward it
+    would be silently wrong -> explicit error."""
+    from lib.losses import BCEWithSigmoidLoss
+    m = _model(4, 0.0, 1).eval()
+    x, y = train_step_ref.synthetic_batch(1, 32, seed=2)
+    loss = BCEWithSigmoidLoss()(m(x), y)
+    with pytest.raises(RuntimeError, match='eval-mode forward'):
+        loss.backward()
+
+
+def test_backward_after_a_later_forward_is_refused():
+    """one set of activation buffers per geometry -- a second forward invalidates the first graph."""
+    from lib.losses import BCEWithSigmoidLoss
+    m = _model(4, 0.0, 1).train()
+    x, y = train_step_ref.synthetic_batch(1, 32, seed=2)
+    l1 = BCEWithSigmoidLoss()(m(x), y)
+    l2 = BCEWithSigmoidLoss()(m(x), y)
+    with pytest.raises(RuntimeError, match='another forward'):
+        l1.backward()
+    l2.backward()                      # the latest graph is fine
