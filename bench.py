@@ -54,17 +54,34 @@ def cpu_baseline(seconds_budget=20.0):
                       '1 warm-up, torch %s CPU' % (n, torch.__version__)}
 
 
+def kernel_sources_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/*.h): what a committed PMC profile is stamped with."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'segmentation-networks-benchmark_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'segmentation-networks-benchmark_amd', 'csrc', '*.h')) +
+                    glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate runs of this same command, summarised by tools/pmc_traffic.py with the gfx950 corrections of
-    MI355X_MICROARCH.md); None when no such profile is committed.  Counters cannot be read from inside the run."""
+    MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so the figure is only reported when the
+    profile is stamped with the digest of the kernel sources THIS run was built from; otherwise None (a profile of
+    other kernels says nothing about this build)."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                          'r*_pmc_traffic.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None
     with open(files[-1]) as fh:
-        k = json.load(fh).get('kernels', {}).get(kernel)
+        prof = json.load(fh)
+    if prof.get('kernel_sources_digest') != kernel_sources_digest():
+        return None
+    k = prof.get('kernels', {}).get(kernel)
     return None if k is None else k['traffic_bytes_per_launch']
 
 
@@ -73,10 +90,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
-    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the model\'s configuration)')
+    ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--loss', default='bce_dice', choices=['bce_dice', 'bce_jaccard', 'bce'])
+    ap.add_argument('--model', default='zf_unet', choices=['zf_unet', 'linknet34', 'fcdensenet103', 'fcdensenet67', 'unet16'],
+                    help='zf_unet = the headline metric (BASELINE.json); the others time the remaining SURVEY 8d rows at '
+                         'their own sizes: linknet34 512x512 bs=16, fcdensenet103 256x256 bs=8, unet16 1024x1024 bs=4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -97,8 +117,22 @@ def main():
     torch.cuda.set_device(dev)
     nv.load()
 
+    # (model constructor, images per GPU, size, algorithmic GFLOP per image fwd+bwd at that size -- SURVEY 8d)
+    import warnings
+    models = {'zf_unet': (ZF_UNET, 32, 224, GFLOP_PER_IMAGE_224),
+              'linknet34': (lambda: __import__('lib.models.linknet', fromlist=['x']).LinkNet34(), 16, 512, 138.5),
+              'fcdensenet103': (lambda: __import__('lib.models.tiramisu', fromlist=['x']).FCDenseNet103(n_classes=1), 8, 256, 156.1),
+              'fcdensenet67': (lambda: __import__('lib.models.tiramisu', fromlist=['x']).FCDenseNet67(n_classes=1), 8, 256, 6 * 27.11),
+              'unet16': (lambda: __import__('lib.models.unet16', fromlist=['x']).UNet16(), 4, 1024, 3 * 1278.8)}
+    ctor, dB, dS, gflop_at = models[args.model]
+    args.batch = args.batch or dB
+    args.size = args.size or dS
     torch.manual_seed(0)
-    model = ZF_UNET().set_compute_dtype(args.dtype).to(dev).train()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ctor().set_compute_dtype(args.dtype).to(dev).train()
+    if args.model != 'zf_unet':
+        args.no_cpu_baseline = True          # the CPU baseline is the headline step (oracle ZF_UNET)
     crit = {'bce_dice': L.BCEAndDiceLoss, 'bce_jaccard': L.BCEWithLogitsLossAndSmoothJaccard,
             'bce': L.BCEWithSigmoidLoss}[args.loss]()
     opt = optim.SGD(model.parameters(), lr=1e-3)
@@ -108,10 +142,13 @@ def main():
     x = torch.randn(B, 3, S, S, generator=g).to(dev)
     y = (torch.rand(B, 1, S, S, generator=g) > 0.7).long().to(dev)
 
+    def flat_of():
+        return model._engine.flat if args.model == 'zf_unet' else model._tape.flat
+
     def step_keep_grads():
         # zero_grad(set_to_none=False) semantics without touching .grad objects: the backward plan clears the
         # flat gradient buffer itself when every .grad already aliases it
-        model._engine.flat.flat_g.zero_()
+        flat_of().flat_g.zero_()
         out = model(x)
         loss = crit(out, y)
         (x.size(0) * loss).backward()
@@ -127,7 +164,7 @@ def main():
         return loss
 
     loss = step()                          # builds the plan, flat buffers
-    dp.broadcast_parameters(model._engine.flat)
+    dp.broadcast_parameters(flat_of())
     for _ in range(max(0, args.warmup - 1)):
         loss = step()
     torch.cuda.synchronize()
@@ -195,16 +232,20 @@ def main():
         return
     ms = dt / args.steps * 1e3
     value = ws * B * args.steps / dt
-    gflop_img = GFLOP_PER_IMAGE_224 * (S / 224.0) ** 2
+    gflop_img = gflop_at * (S / float(dS)) ** 2
     peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
     out = {
-        'metric': 'images/sec/GPU (fwd+bwd) ZF_UNET 224x224 bs=32; 1/2/4/8-GPU scaling',
+        'metric': ('images/sec/GPU (fwd+bwd) ZF_UNET 224x224 bs=32; 1/2/4/8-GPU scaling' if args.model == 'zf_unet' else
+                   'images/sec/GPU (fwd+bwd) %s %dx%d bs=%d (SURVEY 8d row, not the headline metric)' % (args.model, S, S, B)),
         'value': round(value, 2), 'unit': 'images/s', 'per_gpu': round(value / ws, 2),
         'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': 'ZF_UNET %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, Dropout2d 0.2, train step '
-                               'torch_train.py:180-190 (configs[1])' % (S, S, args.dtype, B, args.loss),
+        'config': {'workload': ('ZF_UNET %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, Dropout2d 0.2, train step '
+                                'torch_train.py:180-190 (configs[1])' % (S, S, args.dtype, B, args.loss))
+                               if args.model == 'zf_unet' else
+                               '%s %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, train step torch_train.py:180-190'
+                               % (args.model, S, S, args.dtype, B, args.loss),
                    'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
         'final_loss': round(final_loss, 6), 'hip_graph': bool(graph is not None),
         'host_enqueue_ms_per_step': None if host_ms is None else round(host_ms, 3),
@@ -221,6 +262,7 @@ def main():
         fams = {'conv_fprop': 'segnb_conv_fprop launches: conv_fprop_ws_kernel / conv_fprop_rw_kernel / '
                               'conv_fprop_c8_kernel / conv_fprop_s1x9_kernel / conv_fprop_kernel (forward + data gradient)',
                 'conv_wgrad': 'segnb_conv_wgrad launches: conv_wgrad_s1x9_kernel / conv_wgrad_kernel'}
+        out['kernel_sources_digest'] = kernel_sources_digest()
         out['roofline'] = {'kernel': fams.get(dom, dom), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            'traffic': pmc_traffic(dom),

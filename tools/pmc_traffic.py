@@ -69,7 +69,10 @@ def main():
                           'FETCH_SIZE_KiB_per_launch_raw': round(f_launch, 2),
                           'WRITE_SIZE_KiB_per_launch': round(w_launch, 2),
                           'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
-    doc = {'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    doc = {'kernel_sources_digest': bench.kernel_sources_digest(),      # bench.py reports `traffic` only for this build
+           'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
                    'separate --pmc passes; average over all launches of the kernel family in the profiled command',
            'kernels': res}
     with open(out, 'w') as fh:
