@@ -268,6 +268,25 @@ int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int
 int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
                            segnb_stream_t stream);
 
+/* A DATA-GRADIENT launch whose epilogue also does the BatchNorm-backward reduction of the layer that produced its
+ * output's forward counterpart: out = g (the gradient of that layer's activation, exactly what segnb_conv_fprop
+ * writes), and sums[r][0][c] += sum dz, sums[r][1][c] += sum dz * yhat with dz = round(g * act'((y - mean) * scale +
+ * shift)) -- segnb_bn_act_bwd_reduce(g_direct = out, dz = NULL, no dropout) without its own pass over y and g (the
+ * edz_eydz phase of lib/modules/abn/functions.py:112 folded into the producer of dz).  y: [N][Ho][Wo][ld_y] `dtype`,
+ * coef: [4][Co] of segnb_bn_finalize, sums: [16][2][Co] fp64.  _ok: 1 when a fused kernel serves the geometry (thin
+ * stride-1 3x3 layers on conv_fprop_rw_kernel); otherwise call the two entry points separately. */
+typedef struct {
+    const void* y;
+    int ld_y;
+    const float* coef;
+    double* sums;
+    int act;
+    float slope;
+} segnb_bn_reduce_epilogue;
+int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,
+                              const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 1x1 classifier head with a handful of classes (zf_unet.py:58,93; tiramisu.py:162; unet16.py:111):
  * fp32 NCHW logits out, fp32 NCHW dlogits in.

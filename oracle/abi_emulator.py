@@ -122,6 +122,22 @@ class AbiEmulator(object):
         g2.ld_in = 8
         return self.segnb_conv_fprop(g2, BF16, keep.data_ptr(), wp, bias, bias_n, out_p, stats, stream)
 
+    # ---- data gradient + the BatchNorm-backward reduction of its output's producer (segnb_conv_fprop_bnreduce) = the two
+    # separate entry points, composed
+    def segnb_conv_fprop_bnreduce_ok(self, g, dtype):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and
+                   g.QW == g.Wo and g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and g.Wo >= 12 and
+                   not (g.Co > 32 and g.Ci > 32))
+
+    def segnb_conv_fprop_bnreduce(self, g, dtype, in_p, wp, out_p, ep, stream):
+        gg, e = _geom(g), _geom(ep)
+        rc = self.segnb_conv_fprop(g, dtype, in_p, wp, None, 0, out_p, None, stream)
+        if rc:
+            return rc
+        return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, e.coef, e.act, e.slope, None,
+                                            out_p, gg.ld_out, None, 0, None, 0, None, 0, e.sums, None, 0, stream)
+
     # slab count of the emulated device: stride-1 3x3 bf16 launches write EMU_SLABS partial slabs (the HIP library
     # derives its count from the CU count); everything else accumulates into one zeroed slab
     EMU_SLABS = 3

@@ -40,6 +40,7 @@ int segnb_num_cus();
 int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();
 int segnb_knob_fprop_dma_dbg();
+int segnb_knob_bnreduce_fused();  // 1: segnb_conv_fprop_bnreduce_ok may say yes
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients
@@ -55,7 +56,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
 // resident-weights pipeline for the thin layers, Ci <= 96 and Co <= 96 (fprop_rw.hip)
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                       hipStream_t stream);
+                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);

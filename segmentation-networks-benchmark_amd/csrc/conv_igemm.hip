@@ -917,6 +917,36 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     return 0;
 }
 
+extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g)) return 0;
+    if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || !segnb_knob_bnreduce_fused()) return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 64 || g->Co % 8 != 0 || g->Wo < 12) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
+    if (g->Co > 32 && g->Ci > 32) return 0;      // (the 64-wide tile keeps one 32-channel chunk of weights resident)
+    return 1;
+}
+
+extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                                         void* out, const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream) {
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && wpacked && out && ep && ep->y && ep->coef && ep->sums, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_bnreduce_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_bnreduce_ok)");
+    SEGNB_CHECK_ARG(ep->ld_y >= g->Co && ep->ld_y % 8 == 0, "bad y stride");
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
+    const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    const int rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr,
+                                      (hipStream_t)stream, ep);
+    if (rc != 1) {
+        segnb_set_error("segnb_conv_fprop_bnreduce: the fused kernel refused the launch (%d)", rc);
+        return rc > 1 ? rc : SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool wgrad_general_only() {
     static const bool v = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
     return v;

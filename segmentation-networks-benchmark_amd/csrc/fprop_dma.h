@@ -32,6 +32,16 @@ struct FdArgs {
     int dhmin, dwmin;
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
+    // fused BatchNorm-backward reduction in the epilogue of a DATA-GRADIENT launch (segnb_conv_fprop_bnreduce): the output
+    // tile is the gradient g of the producing layer's activation; with that layer's pre-BatchNorm output y the store
+    // threads accumulate sum dz and sum dz * yhat (dz = g * act'(z)) -- segnb_bn_act_bwd_reduce without its own pass
+    const bf16_t* bn_y;   // NULL: off
+    unsigned bn_y_bytes;
+    int bn_ld;
+    const float* bn_coef; // [4][Co]: scale, shift, mean, invstd
+    double* bn_sums;      // [REPL][2][Co]
+    int bn_act;
+    float bn_slope;
     int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA +
                           // fragment reads, 8 no stores, 16 no fragment reads, 32 in-kernel stamps, 64 one stamp per tap
 };

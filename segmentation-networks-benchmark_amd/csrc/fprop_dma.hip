@@ -799,6 +799,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.bn_y = nullptr;
     const int rc = dispatch_fd(a, stream);
     if (rc == NOT_HANDLED) return 0;
     return rc ? rc : 1;

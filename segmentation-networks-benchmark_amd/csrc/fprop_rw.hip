@@ -162,6 +162,23 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         // all table and staging reads of a thread go out first, pixels outside the image are dropped by the output
         // descriptor's range check (a per-row `if` serialised two LDS round trips per row: ~2100 cycles per tile).
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+        // fused BatchNorm-backward reduction (a.bn_y != NULL): per-thread constants of its channel chunk
+        const bool bnred = C::STATS_OK && a.bn_y != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_y =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bnred ? a.bn_y : a.out), 0, bnred ? (int)a.bn_y_bytes : 0, 0x00020000);
+        float bsc[8], bsh[8], bmu[8];
+        float bneg = 0.f;
+        if (bnred) {
+            const int c0 = (ltid % OC) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = c0 + e < a.Co;
+                bsc[e] = in ? a.bn_coef[c0 + e] : 0.f;
+                bsh[e] = in ? a.bn_coef[a.Co + c0 + e] : 0.f;
+                bmu[e] = in ? a.bn_coef[2 * a.Co + c0 + e] : 0.f;
+            }
+            bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
+        }
         auto store_pass = [&](const int* tab) {
             if (DBG && (a.dbg & 8)) return;
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -175,6 +192,16 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
                 for (int k = 0; k < 8; ++k) {
                     const int row = row0 + (base + k) * C::RG;
                     opix[k] = (base + k < C::RPT && row < BM) ? tab[row] : -1;
+                }
+                u32x4_t yv[8];
+                if (bnred) {
+                    // the y rows of these pixels: requested before anything else of the batch (HBM latency)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool ok = cok && opix[k] >= 0;
+                        const unsigned yoff = ok ? (unsigned)opix[k] * (unsigned)a.bn_ld * 2u + (unsigned)cc * 16u : OOB;
+                        yv[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)yoff, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -198,6 +225,26 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
                             const float fm = f[e] * m;
                             s1[e] += fm;
                             s2[e] += fm * fm;
+                        }
+                    } else if (bnred) {
+                        // dz = round(g * act'(z)), z = (y - mean) * scale + shift: the arithmetic of bn_act_bwd_reduce_kernel
+                        const float m = ok ? 1.f : 0.f;
+                        float gq[8], yq[8];
+                        gq[0] = __uint_as_float(v[k].x << 16); gq[1] = __uint_as_float(v[k].x & 0xffff0000u);
+                        gq[2] = __uint_as_float(v[k].y << 16); gq[3] = __uint_as_float(v[k].y & 0xffff0000u);
+                        gq[4] = __uint_as_float(v[k].z << 16); gq[5] = __uint_as_float(v[k].z & 0xffff0000u);
+                        gq[6] = __uint_as_float(v[k].w << 16); gq[7] = __uint_as_float(v[k].w & 0xffff0000u);
+                        yq[0] = __uint_as_float(yv[k].x << 16); yq[1] = __uint_as_float(yv[k].x & 0xffff0000u);
+                        yq[2] = __uint_as_float(yv[k].y << 16); yq[3] = __uint_as_float(yv[k].y & 0xffff0000u);
+                        yq[4] = __uint_as_float(yv[k].z << 16); yq[5] = __uint_as_float(yv[k].z & 0xffff0000u);
+                        yq[6] = __uint_as_float(yv[k].w << 16); yq[7] = __uint_as_float(yv[k].w & 0xffff0000u);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float yc = yq[e] - bmu[e];
+                            const float z = yc * bsc[e] + bsh[e];
+                            const float dv = bf16_bits_to_f32(f32_to_bf16_bits(gq[e] * (z > 0.f ? 1.f : bneg))) * m;
+                            s1[e] += dv;
+                            s2[e] += dv * yc;
                         }
                     }
                 }
@@ -226,7 +273,13 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         }
         if (pending) store_pass(sPix + (par ^ 1) * BM);
         lds_barrier();
-        if (C::STATS_OK && a.stats != nullptr) {
+        if (bnred) {
+            const int c0 = (ltid % OC) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s2[e] *= c0 + e < a.Co ? a.bn_coef[3 * a.Co + c0 + e] : 0.f;    // * invstd: sum dz * yhat
+        }
+        double* const acc_out = bnred ? a.bn_sums : a.stats;
+        if (C::STATS_OK && acc_out != nullptr) {
             double* red = reinterpret_cast<double*>(smem);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -236,14 +289,14 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
         }
         lds_barrier();
         {
-            if (C::STATS_OK && a.stats != nullptr && ltid < 2 * BN) {
+            if (C::STATS_OK && acc_out != nullptr && ltid < 2 * BN) {
                 const double* red = reinterpret_cast<const double*>(smem);
                 const int which = ltid / BN, col = ltid - which * BN;
                 const int cc = col >> 3, e = col & 7;
                 double s = 0.0;
                 for (int k = 0; k < C::RG; ++k) s += red[(k * OC + cc) * 16 + which * 8 + e];
                 if (col < a.Co)
-                    atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + col], s);
+                    atomicAdd(&acc_out[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + col], s);
             }
         }
     } else {
@@ -378,7 +431,7 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                       hipStream_t stream) {
+                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_rw()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 96 || g->Wo < 12) return 0;
@@ -414,6 +467,19 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.bn_y = nullptr;
+    if (bn != nullptr) {
+        if (stats != nullptr || g->Co > 64) return 0;                 // one accumulator set per launch; 96-wide: no statistics threads
+        const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;
+        if (yb >= (1ll << 31)) return 0;
+        a.bn_y = (const bf16_t*)bn->y;
+        a.bn_y_bytes = (unsigned)yb;
+        a.bn_ld = bn->ld_y;
+        a.bn_coef = bn->coef;
+        a.bn_sums = bn->sums;
+        a.bn_act = bn->act;
+        a.bn_slope = bn->slope;
+    }
     int rc;
     // ring depth by what the resident weights leave of the 160 KiB.  96-channel outputs (the data gradient of the
     // 96 -> 32 concat layer: 53 KiB of staging beside 55 KiB of weights) run on a two-stage ring and without the

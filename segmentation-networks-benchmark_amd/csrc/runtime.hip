@@ -69,6 +69,14 @@ int segnb_knob_fprop_mf16() {
     }
     return g_fprop_mf16;
 }
+static int g_bnreduce_fused = -2;  // data-gradient launches that also do the next BatchNorm-backward reduction (A/B: SEGNB_BNREDUCE_FUSED=0)
+int segnb_knob_bnreduce_fused() {
+    if (g_bnreduce_fused == -2) {
+        const char* e = getenv("SEGNB_BNREDUCE_FUSED");
+        g_bnreduce_fused = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_bnreduce_fused;
+}
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
@@ -91,6 +99,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
         g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "bnreduce_fused") == 0) {
+        g_bnreduce_fused = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_mf16") == 0) {

@@ -358,11 +358,14 @@ class _ZFUnetPlan(object):
         for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
             s1, s2 = self.stages[name]
             hold = post if lvl < npost else None
+            # the first convolution of a block has ONE direct gradient source -- the data gradient of the second one: that
+            # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
             if lvl == 0:
-                s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold)
+                red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
             else:
-                s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl], postponed=hold)
-            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold)
+                red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
+                                  postponed=hold, fuse_reduce_of=s1)
+            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
         rt.flush_postponed(post)
         self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
         for i in (5, 4, 3, 2, 1, 0):
@@ -370,11 +373,11 @@ class _ZFUnetPlan(object):
                 self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
             s1, s2 = self.stages[ENCODER[i]]
             if i == 5:
-                s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'])
+                red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
             else:
-                s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
-                            dx=b['da1_%d' % i])
-            s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None))
+                red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
+                                  dx=b['da1_%d' % i], fuse_reduce_of=s1)
+            s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red)
         if self.BWD_CONV_CU_PCT != 100:
             nv.call('segnb_tune', b'conv_cu_pct', 100)
         rt.join_side()                        # the weight gradients ran on the side stream

@@ -33,6 +33,12 @@ class ConvGeom(ctypes.Structure):
                 ('dh', c_int * MAX_TAPS), ('dw', c_int * MAX_TAPS)]
 
 
+class BnReduceEpilogue(ctypes.Structure):
+    """segnb_bn_reduce_epilogue"""
+    _fields_ = [('y', c_void_p), ('ld_y', c_int), ('coef', c_void_p), ('sums', c_void_p), ('act', c_int),
+                ('slope', c_float)]
+
+
 class LossSpec(ctypes.Structure):
     """segnb_loss_spec"""
     _fields_ = [('w_bce', c_float), ('w_focal', c_float), ('w_jaccard', c_float), ('w_sjaccard', c_float),
@@ -44,6 +50,7 @@ _P = c_void_p
 # name -> argtypes (all return int status)
 SIGNATURES = {
     'segnb_conv_fprop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, _P],
+    'segnb_conv_fprop_bnreduce': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_pack_weight': [_P, _P, c_int, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, _P],
     'segnb_unpack_wgrad': [_P, _P, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, c_int, _P],
@@ -92,7 +99,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

@@ -369,13 +369,31 @@ class ConvOp(object):
                                nv.ptr(b), self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), vptr(packed),
                                vld(packed), rt.stream))
 
-    def dgrad(self, dyv, dxv):
+    def dgrad_bnreduce_ok(self, dyv, dxv):
+        """True when this data gradient can also do the BatchNorm-backward reduction of the layer that produced its
+        input (segnb_conv_fprop_bnreduce): one launch geometry, served by a fused kernel."""
+        p = self.plan(dxv.H, dxv.W)
+        if not self.need_dgrad or len(p['dg']) != 1 or not p['dg_full']:
+            return False
+        g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+        return bool(nv.query('segnb_conv_fprop_bnreduce_ok', g, self.rt.code))
+
+    def dgrad(self, dyv, dxv, bn_reduce=None):
+        """bn_reduce: (y View, coef, sums, act, slope) of the layer whose activation gradient dxv is -- its reduction
+        pass is then done by this launch's epilogue (check dgrad_bnreduce_ok first)."""
         p, rt = self.plan(dxv.H, dxv.W), self.rt
         assert self.need_dgrad and dyv.Cp == self.Cop and dxv.Cp == self.Cip
         if not p['dg_full']:
             dxv.dense().zero_()
         for li, l in enumerate(p['dg']):
             g = self._geom(p, 'd', li, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+            if bn_reduce is not None:
+                yv, coef, sums, act, slope = bn_reduce
+                ep = nv.BnReduceEpilogue(yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(sums), act, slope)
+                _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                       lambda: nv.call('segnb_conv_fprop_bnreduce', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), dxv.ptr,
+                                       ep, rt.stream))
+                continue
             _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
                                    dxv.ptr, None, rt.stream))
@@ -534,9 +552,21 @@ class Stage(object):
         self._saved = (xv, yv, dropmul, coef is not None)
         return yv
 
-    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None):
+    def reduce_in_producer(self):
+        """-> the (y, coef, sums, act, slope) a data-gradient launch needs to do THIS layer's BatchNorm-backward
+        reduction in its epilogue, or None when the layer does not qualify (it must be a 'direct' layer: BatchNorm,
+        one direct gradient source, no dropout; the caller guarantees the single direct source)."""
+        xv, yv, dropmul, has_bn = self._saved
+        if not (self.direct_apply and has_bn and dropmul is None and self._fused_fwd):
+            return None
+        return (yv, self.coef, self.sums, self.act, self.slope)
+
+    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None, reduced=False,
+                 fuse_reduce_of=None):
         """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
-        input gradient, or None (first layer)."""
+        input gradient, or None (first layer).  reduced: the reduction pass of this layer was already done by the
+        data-gradient launch that produced g_direct.  fuse_reduce_of: the Stage whose activation gradient dx is -- if
+        it qualifies, this layer's data gradient does that stage's reduction too; returns True when it did."""
         rt = self.rt
         xv, yv, dropmul, has_bn = self._saved
         dz = self.buffers(yv.N, yv.H, yv.W)['dz']
@@ -545,9 +575,11 @@ class Stage(object):
         # pass recomputes dz from g (segnb_bn_bwd_apply_direct): one tensor write less per such layer.
         direct = (self.direct_apply and has_bn and g_direct is not None and g_pool is None and g_up is None
                   and dropmul is None)
-        nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
-                self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
-                vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
+        assert not reduced or direct, 'only a direct layer can be reduced by its producer'
+        if not reduced:
+            nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
+                    self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
+                    vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
         if has_bn and self._fused_fwd and direct:
@@ -589,9 +621,15 @@ class Stage(object):
                 self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False)
         else:
             self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=not self.defer_unpack)
+        fused = False
         if dx is not None:
-            self.conv.dgrad(dz, dx)
-        return dx
+            ep = fuse_reduce_of.reduce_in_producer() if fuse_reduce_of is not None else None
+            if ep is not None and self.conv.dgrad_bnreduce_ok(dz, dx):
+                self.conv.dgrad(dz, dx, bn_reduce=ep)
+                fused = True
+            else:
+                self.conv.dgrad(dz, dx)
+        return fused
 
 
 class FlatParams(object):

@@ -882,6 +882,55 @@ def test_conv_full_size_vs_torch(shape, wg_cu_pct):
         check(name + ' dx vs torch', dxv.dense().float().cpu()[..., :Ci].permute(0, 3, 1, 2), xr.grad, 'bf16')
 
 
+@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_dgrad_with_fused_bn_reduce(shape):
+    """segnb_conv_fprop_bnreduce: the data-gradient launch whose epilogue does the BatchNorm-backward reduction of the
+    layer that produced its input (the edz_eydz phase of lib/modules/abn/functions.py:112 folded into
+    the producer of dz).  dx is bit-identical to the plain data gradient; the sums equal segnb_bn_act_bwd_reduce on that
+    dx (same per-element arithmetic, another summation order) and the emulator's."""
+    N, H, W, C1, C2, act = shape           # layer 1: ? -> C1 (BatchNorm, act);  layer 2: C1 -> C2
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 7 + C2)
+    w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    op = ConvOp(rt, w2, None, [(C1, C1)], 1, 1, False, True)
+    op.pack(H, W)
+    dyv = View.alloc(rt, N, H, W, op.Cop)
+    dyv.t.normal_(generator=None)
+    y1 = View.alloc(rt, N, H, W, C1)
+    y1.t.normal_()
+    coef = torch.stack([0.5 + torch.rand(C1, generator=gen), 0.3 * torch.randn(C1, generator=gen),
+                        0.2 * torch.randn(C1, generator=gen), 0.5 + torch.rand(C1, generator=gen)]).cuda().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    dx_plain = View.alloc(rt, N, H, W, C1)
+    op.dgrad(dyv, dx_plain)
+    sums_ref = rt.zeros((16, 2, C1), torch.float64)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, y1.ptr, y1.ld, N, H, W, C1, nv.ptr(coef), act, 0.01, None, dx_plain.ptr,
+            dx_plain.ld, None, 0, None, 0, None, 0, nv.ptr(sums_ref), None, 0, st)
+    assert op.dgrad_bnreduce_ok(dyv, dx_plain)
+    dx_f = View.alloc(rt, N, H, W, C1)
+    sums_f = rt.zeros((16, 2, C1), torch.float64)
+    op.dgrad(dyv, dx_f, bn_reduce=(y1, coef, sums_f, act, 0.01))
+    sums_f2 = rt.zeros((16, 2, C1), torch.float64)
+    op.dgrad(dyv, dx_f, bn_reduce=(y1, coef, sums_f2, act, 0.01))
+    torch.cuda.synchronize()
+    assert torch.equal(dx_f.t, dx_plain.t)
+    a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
+    scale = np.abs(b).max(axis=1, keepdims=True) + 1e-30
+    assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
+    np.testing.assert_allclose(a / scale, b / scale, atol=1e-4)
+    # fixed summation order inside a block, fp64 across blocks: run-to-run equal to fp64 rounding
+    np.testing.assert_allclose(sums_f2.sum(0).cpu().numpy(), a, rtol=1e-12, atol=1e-9)
+    if N * H * W <= 20000:
+        with on_emulator():
+            sums_e = torch.zeros((16, 2, C1), dtype=torch.float64)
+            ye, ce, de = y1.t.cpu(), coef.cpu(), dx_plain.t.cpu()
+            EMU.segnb_bn_act_bwd_reduce(nv.BF16, ye.data_ptr(), C1, N, H, W, C1, ce.data_ptr(), act, 0.01, None,
+                                        de.data_ptr(), C1, None, 0, None, 0, None, 0, sums_e.data_ptr(), None, 0, 0)
+        e = sums_e.sum(0).numpy()
+        np.testing.assert_allclose(a / scale, e / scale, atol=2e-4)
+
+
 # ------------------------------------------------------------------------------------------------------
 # resident-weights pipeline of the thin layers (fprop_rw.hip): Ci in {32, 64, 96}, Co <= 96
 # ------------------------------------------------------------------------------------------------------

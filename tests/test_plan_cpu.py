@@ -188,3 +188,34 @@ def test_backward_after_a_later_forward_is_refused():
     with pytest.raises(RuntimeError, match='another forward'):
         l1.backward()
     l2.backward()                      # the latest graph is fine
+
+
+def test_fused_bn_reduce_in_data_gradient_host_logic():
+    """segnb_conv_fprop_bnreduce: the data gradient of a block's second convolution also does
+    the BatchNorm-backward reduction of the first one.  Host logic on the emulator (where the fused entry is the
+    composition of the two separate ones): the same step with the fusion refused gives bit-identical gradients, and the
+    fused entry is actually used for the default-width net (32-channel level)."""
+    from lib.losses import BCEWithSigmoidLoss
+    x, y = train_step_ref.synthetic_batch(1, 32, seed=3)
+    grads, calls = [], []
+    for allow in (True, False):
+        be = abi_emulator.AbiEmulator()
+        n = {'fused': 0}
+        if allow:
+            orig = be.segnb_conv_fprop_bnreduce
+            def counted(*a, _o=orig, _n=n):
+                _n['fused'] += 1
+                return _o(*a)
+            be.segnb_conv_fprop_bnreduce = counted
+        else:
+            be.segnb_conv_fprop_bnreduce_ok = lambda g, dtype: 0
+        nv.set_backend_for_testing(be)
+        m = _model(32, 0.2, 7, 'bf16').train()
+        m.dropout_override = {}
+        loss = BCEWithSigmoidLoss()(m(x), y)
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        calls.append(n['fused'])
+    assert calls[0] >= 2 and calls[1] == 0, calls
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
