@@ -85,6 +85,7 @@ class Tape(object):
         for fn in reversed(self.back):
             fn()
         self.back = []
+        self.rt.join_side()               # the weight gradients ran on the side stream
 
     def dropout_table(self, site, N, Cp, p):
         """fp32 [N, Cp] Dropout2d multipliers (0 or 1/(1-p)) drawn on the device; None when inactive."""
@@ -168,7 +169,15 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                     None, nv.ptr(gb), 1, rt.stream)
         if res is not None:
             tape.contribute(res, dz)
-        conv.wgrad(xv, dy, flat.grad_of(weight))
+        # the weight gradient (and its unpack) only READ x and dy, and nothing reads dW before the end of backward: side
+        # stream, beside the dependent chain reduce -> apply -> data gradient (engine.Runtime.fork_side; dy is a buffer
+        # of this call site that nothing writes again during this backward)
+        side = rt.fork_side()
+        if side is not None:
+            with torch.cuda.stream(side):
+                conv.wgrad(xv, dy, flat.grad_of(weight))
+        else:
+            conv.wgrad(xv, dy, flat.grad_of(weight))
         if x.needs_grad:
             dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
             conv.dgrad(dy, dx)
