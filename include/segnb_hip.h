@@ -102,6 +102,11 @@ int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const 
 int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype);
 int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                      float* dwp, int nslab, segnb_stream_t stream);
+/* The same, but the nslab partial slabs [nslab][Co][ntaps][Ci] are left UNREDUCED: the caller sums them where it consumes
+ * them -- segnb_unpack_wgrad_multi with the job's nslab field -- instead of paying a reduction launch per layer that
+ * writes the sum back only for the unpack to read it again. */
+int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout, float* dwp,
+                             int nslab, segnb_stream_t stream);
 
 /* Parameter-layout <-> packed-GEMM-layout.  Packed matrix is [Mp][ntaps][Cp]; element (mp,t,cp)
  * maps to w[mmap[mp]*s_m + cmap[cp]*s_c + tap_off[t]] (maps are device int32 arrays, -1 = padding).
@@ -117,7 +122,8 @@ int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long lo
 /* Batched forms: one launch for every weight matrix of a model (one for every gradient).  `jobs` is a DEVICE
  * array of njobs records, each segnb_pack_job_bytes() long:
  *   { const float* param_or_grad; void* packed; const int* mmap; const int* cmap; int64 s_m, s_c;
- *     int32 Mp, Cp, ntaps, dtype, block_start, pad; int32 tap_off[SEGNB_MAX_TAPS]; }
+ *     int32 Mp, Cp, ntaps, dtype, block_start, nslab; int32 tap_off[SEGNB_MAX_TAPS]; }
+ *     (nslab: unpack jobs only -- partial slabs to sum, see segnb_conv_wgrad_partial; 0 or 1 = a single slab)
  * sorted by block_start; job k owns blocks [block_start_k, block_start_k + segnb_pack_job_blocks(...)) (LDS-tiled
  * transposes: both the parameter side and the packed side are accessed in contiguous runs).
  * segnb_pack_job_blocks returns -1 for kernels wider than 3x3 (use the single-job calls for those).

@@ -166,6 +166,27 @@ class AbiEmulator(object):
             G[0, :, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
         return 0
 
+    def segnb_conv_wgrad_partial(self, g, dtype, in_p, dout_p, dwp, nslab, stream):
+        """partial slabs left unreduced: the emulated device splits the pixel range over the images (slab s = images
+        s, s + nslab, ...); segnb_unpack_wgrad_multi sums them (job field nslab)"""
+        if nslab != self.segnb_conv_wgrad_slabs(g, dtype):
+            return 1
+        if nslab == 1:
+            return self.segnb_conv_wgrad(g, dtype, in_p, dout_p, dwp, nslab, stream)
+        g = _geom(g)
+        dt = _tdt(dtype)
+        X = _nhwc(in_p, g.N, g.Hi, g.Wi, g.Ci, g.ld_in, dt)
+        D = _nhwc(dout_p, g.N, g.Ho, g.Wo, g.Co, g.ld_out, dt)
+        oh = torch.arange(g.QH) * g.out_step + g.oh0
+        ow = torch.arange(g.QW) * g.out_step + g.ow0
+        G = _mem(dwp, nslab * g.Co * g.ntaps * g.Ci, torch.float32).view(nslab, g.Co, g.ntaps, g.Ci)
+        G.zero_()
+        for n in range(g.N):
+            d = D[n:n + 1][:, oh[:, None], ow[None, :], :].float().reshape(-1, g.Co)
+            for t in range(g.ntaps):
+                G[n % nslab, :, t, :] += d.t() @ _gather(X[n:n + 1], g, t).reshape(-1, g.Ci)
+        return 0
+
     def _maps(self, Mp, Cp, ntaps, tap_off, mmap, cmap):
         mm = _mem(mmap, Mp, torch.int32).long()
         cm = _mem(cmap, Cp, torch.int32).long()
@@ -214,7 +235,7 @@ class AbiEmulator(object):
         raw = bytes((ctypes.c_char * (njobs * self.JOB_BYTES)).from_address(int(jobs)))
         dt = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
                        ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
-                       ('block_start', '<i4'), ('pad', '<i4'), ('tap_off', '<i4', (64,))])
+                       ('block_start', '<i4'), ('nslab', '<i4'), ('tap_off', '<i4', (64,))])
         return np.frombuffer(raw, dtype=dt)
 
     def segnb_pack_weight_multi(self, jobs, njobs, total_blocks, stream):
@@ -226,6 +247,12 @@ class AbiEmulator(object):
 
     def segnb_unpack_wgrad_multi(self, jobs, njobs, total_blocks, stream):
         for j in self._jobs(jobs, njobs):
+            ns = int(j['nslab'])
+            if ns > 1:                      # partial slabs of segnb_conv_wgrad_partial: slab 0 += slabs 1.., in order
+                n1 = int(j['Mp']) * int(j['ntaps']) * int(j['Cp'])
+                G = _mem(int(j['packed']), ns * n1, torch.float32).view(ns, n1)
+                for sl in range(1, ns):
+                    G[0] += G[sl]
             self.segnb_unpack_wgrad(int(j['packed']), int(j['w']), int(j['Mp']), int(j['Cp']), int(j['ntaps']),
                                     int(j['s_m']), int(j['s_c']), [int(v) for v in j['tap_off'][:int(j['ntaps'])]],
                                     int(j['mmap']), int(j['cmap']), 1, stream)

@@ -61,7 +61,7 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream);
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream);
+                       hipStream_t stream, bool partial = false);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 
 // ------------------------------------------------------------------------------------------------

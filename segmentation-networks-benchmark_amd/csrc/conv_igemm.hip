@@ -565,7 +565,7 @@ struct __attribute__((aligned(8))) PackJob {
     long long s_m, s_c;
     int Mp, Cp, ntaps, dtype;
     int block_start;         // first block of this job; jobs sorted by it
-    int pad_;
+    int nslab;               // unpack jobs: partial slabs to sum ([nslab][Mp][ntaps][Cp], segnb_conv_wgrad_partial); 0/1 = one
     int tap_off[SEGNB_MAX_TAPS];
 };
 
@@ -710,6 +710,15 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
                 const long long di = ((long long)mp * nt + t) * Cp + cp;
                 float v[8];
                 load8(dwp + di, v);
+                // partial slabs of the pixel splits (segnb_conv_wgrad_partial): summed here, in slab order, instead of by
+                // a reduction launch per layer that wrote the sum back for this kernel to read again
+                const long long sstride = (long long)Mp * nt * Cp;
+                for (int sl = 1; sl < j.nslab; ++sl) {
+                    float u[8];
+                    load8(dwp + sl * sstride + di, u);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += u[k];
+                }
                 const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 store8(dwp + di, z);                                  // workspace consumed
                 const int base = tile_idx(mpl, t, cpl);
@@ -947,6 +956,8 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     return 0;
 }
 
+static thread_local bool g_wgrad_partial = false;      // set by segnb_conv_wgrad_partial around its call
+
 static bool wgrad_general_only() {
     static const bool v = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
     return v;
@@ -976,7 +987,7 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream);
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;
@@ -992,6 +1003,14 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     if (rc) return rc;
     SEGNB_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
+                                        float* dwp, int nslab, segnb_stream_t stream) {
+    g_wgrad_partial = true;
+    const int rc = segnb_conv_wgrad(g, dtype, in, dout, dwp, nslab, stream);
+    g_wgrad_partial = false;
+    return rc;
 }
 
 static int fill_pack_args(PackArgs& p, int Mp, int Cp, int ntaps, long long s_m, long long s_c,

@@ -665,7 +665,7 @@ int s1_slabs(int tiles, bool thin, bool flat = false) {
 }
 
 template <int BCO, int BCI, int R, int WT, bool FLAT = false>
-int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
+int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
     using TL = WgTile<R, WT, FLAT>;
     constexpr int tile_bytes = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
     constexpr int smem = (wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB) ? 2 * tile_bytes : tile_bytes;
@@ -693,7 +693,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream) {
     a.slab_stride = (long long)a.Co * a.Ktot;
     hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>), dim3(tiles * S),
                        dim3(wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), smem, stream, a);
-    if (S > 1) {
+    if (S > 1 && !partial) {
         const long long total = a.slab_stride;
         if (S <= 16 && total % 4 == 0)
             hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
@@ -751,7 +751,7 @@ int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
 // returns 1 when the launch was handled here, 0 when the geometry is not a stride-1 3x3 bf16 case
 // (caller falls through to the general kernel), <0 / hipError on failure
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool partial) {
     const S1Choice c = s1_choose(g);
     if (!c.cfg) return 0;
     int dhmin = g->dh[0], dwmin = g->dw[0];
@@ -772,11 +772,11 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     }
     a.Ktot = 9 * g->Ci;
     int rc;
-    if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream);
-    else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream);
-    else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream);
-    else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream);
-    else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream);
-    else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream);
+    if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream, partial);
+    else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream, partial);
+    else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream, partial);
     return rc ? rc : 1;
 }

@@ -52,6 +52,7 @@ SIGNATURES = {
     'segnb_conv_fprop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, _P],
     'segnb_conv_fprop_bnreduce': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
+    'segnb_conv_wgrad_partial': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_pack_weight': [_P, _P, c_int, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, _P],
     'segnb_unpack_wgrad': [_P, _P, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, c_int, _P],
     'segnb_pack_weight_multi': [_P, c_int, c_int, _P],

@@ -325,12 +325,12 @@ class ConvOp(object):
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
                                  s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32,
-                                 tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=p['nslab'][li], tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         else:
             for li, l in enumerate(p['fwd']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
                                  s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=nv.F32,
-                                 tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=p['nslab'][li], tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         return jobs
 
     # ---- kernels ------------------------------------------------------------------------------------
@@ -400,15 +400,16 @@ class ConvOp(object):
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
-        workspace for a later batched segnb_unpack_wgrad_multi (unpack_jobs)."""
+        workspace -- as UNREDUCED partial slabs (segnb_conv_wgrad_partial) -- for a later batched
+        segnb_unpack_wgrad_multi (unpack_jobs), which sums the slabs while it unpacks."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         gw = grad_w
+        entry = 'segnb_conv_wgrad' if unpack else 'segnb_conv_wgrad_partial'
         if self.transposed:
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
                 g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
-                nv.call('segnb_conv_wgrad', g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li],
-                        rt.stream)
+                nv.call(entry, g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li], rt.stream)
                 if unpack:
                     nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
                             self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
@@ -417,8 +418,8 @@ class ConvOp(object):
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-                   lambda: nv.call('segnb_conv_wgrad', g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]),
-                                   p['nslab'][li], rt.stream))
+                   lambda: nv.call(entry, g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li],
+                                   rt.stream))
             if unpack:
                 nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
                         self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,
@@ -427,7 +428,7 @@ class ConvOp(object):
 
 PACK_JOB_DTYPE = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
                            ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
-                           ('block_start', '<i4'), ('pad', '<i4'), ('tap_off', '<i4', (nv.MAX_TAPS,))])
+                           ('block_start', '<i4'), ('nslab', '<i4'), ('tap_off', '<i4', (nv.MAX_TAPS,))])
 
 
 class PackTable(object):
@@ -450,6 +451,7 @@ class PackTable(object):
                 self._keep.append(j[f])
             for f in ('s_m', 's_c', 'Mp', 'Cp', 'ntaps', 'dtype'):
                 row[f] = j[f]
+            row['nslab'] = j.get('nslab', 1)
             row['tap_off'][:len(j['tap_off'])] = j['tap_off']
             row['block_start'] = blocks
             blocks += nb
