@@ -188,6 +188,8 @@ class ConvOp(object):
     reference's weight tensor.
     """
 
+X
+
     def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True,
                  out_hw=None):
         self.rt = rt
@@ -325,12 +327,12 @@ class ConvOp(object):
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
                                  s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32,
-                                 nslab=p['nslab'][li], tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=p['nslab'][li] if self.partial_slabs else 1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         else:
             for li, l in enumerate(p['fwd']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
                                  s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=nv.F32,
-                                 nslab=p['nslab'][li], tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=p['nslab'][li] if self.partial_slabs else 1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         return jobs
 
     # ---- kernels ------------------------------------------------------------------------------------
@@ -404,7 +406,7 @@ class ConvOp(object):
         segnb_unpack_wgrad_multi (unpack_jobs), which sums the slabs while it unpacks."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         gw = grad_w
-        entry = 'segnb_conv_wgrad' if unpack else 'segnb_conv_wgrad_partial'
+        entry = 'segnb_conv_wgrad' if (unpack or not self.partial_slabs) else 'segnb_conv_wgrad_partial'
         if self.transposed:
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
