@@ -188,7 +188,11 @@ class ConvOp(object):
     reference's weight tensor.
     """
 
-X
+    # deferred unpack: leave the weight-gradient slabs unreduced and let the batched unpack sum them (SEGNB_WGRAD_PARTIAL=1).
+    # Measured on MI355X, same box: 5.63 ms/step with it against 5.39 without -- a layer with one channel tile has up to
+    # 128 slabs, which one unpack thread then walks serially on the critical path, where the reduction kernel spreads them
+    # over the chip beside the dependent chain: OFF by default.
+    partial_slabs = os.environ.get('SEGNB_WGRAD_PARTIAL', '0') != '0'
 
     def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True,
                  out_hw=None):
