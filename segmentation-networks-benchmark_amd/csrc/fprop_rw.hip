@@ -15,11 +15,16 @@
 
 namespace {
 
-template <int BN_, int NS_>
+// NSW_ store waves: the store pass (table + staging reads, 16-byte stores, BatchNorm statistics) of a tile must finish
+// within the next tile's matrix time -- 0.5 us of MFMAs on the 32-channel layers -- or it paces the block: with two store
+// waves the forward launch (statistics in the pass) took 62 us against 52 us for the data gradient (none).
+template <int BN_, int NS_, int NSW_ = 2, int R_ = 16, int WT_ = 16>
 struct RwCfg {
     static constexpr int BN = BN_, NS = NS_;
-    static constexpr int R = 16, WT = 16, BM = 256;
-    static constexpr int NT = 512, NCW = 4, NLW = 2, NSW = 2, LT = NSW * 64;     // matrix / fetch / store waves
+    static constexpr int R = R_, WT = WT_, BM = 256;
+    static_assert(R_ * WT_ == 256, "tile pixels");
+    static constexpr int NCW = 4, NLW = 2, NSW = NSW_, LT = NSW * 64;     // matrix / fetch / store waves
+    static constexpr int NT = (NCW + NLW + NSW) * 64;
     static constexpr int TM = 2, TN = BN / 32, NF = TM + TN;
     static constexpr int XR = R + 2, XC = WT + 2, NPIX = XR * XC;
     static constexpr int APIECES = (NPIX + 15) / 16;      // 1-KiB pieces of 16 halo pixels x 64 B
@@ -45,7 +50,7 @@ struct RwCfg {
 };
 
 template <class C, bool DBG>
-__global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
+__global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
     constexpr int BN = C::BN, NS = C::NS, BM = C::BM, TM = C::TM, TN = C::TN, NF = C::NF, XC = C::XC, R = C::R, WT = C::WT;
     constexpr int APW = C::APW, OC = C::OC, NLW = C::NLW, LT = C::LT, OUT_ROW = C::OUT_ROW;
     constexpr int LA = NS - 1;                      // fetch look-ahead in steps
@@ -334,40 +339,42 @@ __global__ __launch_bounds__(512) void conv_fprop_rw_kernel(const FdArgs a) {
                 const int sbase = (g % NS) * C::A_STAGE;
                 const int wbase = c * (9 * BN * 64);
                 if (!(DBG && (a.dbg & 4))) {
-                    bf16x8_t fr[2][NF];
+                    // Fragment reads run AHEAD slices in front of the MFMAs through AHEAD + 1 register sets: one slice carries
+                    // only TM * TN MFMAs (64 cycles on the 32-channel layers) -- less than an LDS read takes under load, so with
+                    // one slice of look-ahead every slice stalled on its fragments (~1 us of the 2.1 us a tile took).
+                    constexpr int AHEAD = NF <= 3 ? 4 : 2, SETS = AHEAD + 1;      // (64-channel tiles: 168 registers at 10 waves)
+                    static_assert(AHEAD * NF <= 15, "lgkmcnt range");
+                    bf16x8_t fr[SETS][NF];
                     int bk[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bk[j] = b_rd[j] + wbase;
-                    // slice sl = 2*t + kk; fragment set sl & 1
+                    // slice sl = 2*t + kk; fragment set sl % SETS
                     auto read_slice = [&](auto sl_c) {
                         constexpr int sl = decltype(sl_c)::value;
                         constexpr int t = sl >> 1, kk = sl & 1;
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             const int ad = bk[j] ^ (kk << 5);
-                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[sl & 1][j]) : "v"(ad), "n"(t * BN * 64));
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[sl % SETS][j]) : "v"(ad), "n"(t * BN * 64));
                         }
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             const int ad = (a_rd[t][i] + sbase) ^ (kk << 5);
-                            FD_READ(fr[sl & 1][TN + i], ad);
+                            FD_READ(fr[sl % SETS][TN + i], ad);
                         }
                     };
-                    read_slice(std::integral_constant<int, 0>{});
+                    static_for<AHEAD>([&](auto k_c) { read_slice(k_c); });
                     __builtin_amdgcn_s_setprio(1);
                     static_for<18>([&](auto sl_c) {
                         constexpr int sl = decltype(sl_c)::value;
                         auto& accr = acc;               // (asm operands alone do not make a generic lambda capture it)
-                        if constexpr (sl < 17) {
-                            read_slice(std::integral_constant<int, sl + 1>{});
-                            ws_wait<NF>(fr[sl & 1]);
-                        } else {
-                            ws_wait<0>(fr[sl & 1]);
-                        }
+                        if constexpr (sl + AHEAD < 18) read_slice(std::integral_constant<int, sl + AHEAD>{});
+                        constexpr int younger = (sl + AHEAD < 18 ? AHEAD : 17 - sl) * NF;      // reads issued after this slice's
+                        ws_wait<younger>(fr[sl % SETS]);
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int j = 0; j < TN; ++j) FD_MFMA(accr[i][j], fr[sl & 1][j], fr[sl & 1][TN + i]);
+                            for (int j = 0; j < TN; ++j) FD_MFMA(accr[i][j], fr[sl % SETS][j], fr[sl % SETS][TN + i]);
                     });
                     __builtin_amdgcn_s_setprio(0);
                 }
@@ -484,11 +491,20 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
     // ring depth by what the resident weights leave of the 160 KiB.  96-channel outputs (the data gradient of the
     // 96 -> 32 concat layer: 53 KiB of staging beside 55 KiB of weights) run on a two-stage ring and without the
     // BatchNorm statistics (twelve chunks per row do not divide the store threads; a data gradient has none)
-    if (g->Co <= 32)
+    const int nsw = segnb_knob_rw_store_waves();
+    // 8 x 32 pixel tiles on wide images: longer contiguous rows per fetch / store (224 x 224: 65 vs 69 us forward, 54 vs 58
+    // data gradient, same box); 16 x 16 stays better at 112 x 112 (40 vs 45 us)
+    if (g->Co <= 32 && (nsw == 8 || (nsw == 4 && g->Wo >= 192)))
+        rc = a.NCH == 1 ? launch_rw<RwCfg<32, 5, 4, 8, 32>>(a, stream)
+             : a.NCH == 2 ? launch_rw<RwCfg<32, 4, 4, 8, 32>>(a, stream) : launch_rw<RwCfg<32, 3, 4, 8, 32>>(a, stream);
+    else if (g->Co <= 32 && nsw == 4)
+        rc = a.NCH == 1 ? launch_rw<RwCfg<32, 5, 4>>(a, stream)
+             : a.NCH == 2 ? launch_rw<RwCfg<32, 4, 4>>(a, stream) : launch_rw<RwCfg<32, 3, 4>>(a, stream);
+    else if (g->Co <= 32)
         rc = a.NCH == 1 ? launch_rw<RwCfg<32, 5>>(a, stream)
              : a.NCH == 2 ? launch_rw<RwCfg<32, 4>>(a, stream) : launch_rw<RwCfg<32, 3>>(a, stream);
     else if (g->Co <= 64)
-        rc = launch_rw<RwCfg<64, 3>>(a, stream);
+        rc = nsw == 4 ? launch_rw<RwCfg<64, 3, 4>>(a, stream) : launch_rw<RwCfg<64, 3>>(a, stream);
     else if (stats == nullptr)
         rc = launch_rw<RwCfg<96, 2>>(a, stream);
     else

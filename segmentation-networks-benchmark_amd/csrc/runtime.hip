@@ -69,6 +69,14 @@ int segnb_knob_fprop_mf16() {
     }
     return g_fprop_mf16;
 }
+static int g_rw_store_waves = -2;   // store waves of conv_fprop_rw_kernel: 4 (default) or 2 (round 1)
+int segnb_knob_rw_store_waves() {
+    if (g_rw_store_waves == -2) {
+        const char* e = getenv("SEGNB_RW_STORE_WAVES");
+        g_rw_store_waves = (e != nullptr && e[0] == '2') ? 2 : 4;
+    }
+    return g_rw_store_waves;
+}
 static int g_bnreduce_fused = -2;  // data-gradient launches that also do the next BatchNorm-backward reduction (A/B: SEGNB_BNREDUCE_FUSED=0)
 int segnb_knob_bnreduce_fused() {
     if (g_bnreduce_fused == -2) {
@@ -99,6 +107,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
         g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "rw_store_waves") == 0) {
+        g_rw_store_waves = value == 2 ? 2 : (value == 8 ? 8 : 4);
         return 0;
     }
     if (strcmp(key, "bnreduce_fused") == 0) {
