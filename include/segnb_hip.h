@@ -266,10 +266,13 @@ int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp
                    segnb_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad), floor mode (resnet stem maxpool 3x3 s2 p1, linknet.py:44) and its backward
  * (gradient to the first maximum of each window) */
+/* idx (optional, uint8 [N][Ho][Wo][Cp]): the forward records the window position a*k+b of each maximum; handed to the
+ * backward it replaces the re-scan of every covering window (NULL on either side: the re-scanning backward). */
 int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
-                      int pad, void* out, int ld_out, segnb_stream_t stream);
+                      int pad, void* out, int ld_out, unsigned char* idx, segnb_stream_t stream);
 int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
-                      int Cp, int k, int stride, int pad, void* dx, int ld_dx, segnb_stream_t stream);
+                      int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
+                      segnb_stream_t stream);
 /* NHWC `dtype` -> fp32 NCHW (logits of a head that is not a 1x1 conv: linknet.py:62) */
 int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
                            segnb_stream_t stream);

@@ -522,14 +522,20 @@ class AbiEmulator(object):
         S[1] += (v * v).sum(0)
         return 0
 
-    def segnb_maxpool_fwd(self, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, stream):
+    def segnb_maxpool_fwd(self, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, idx, stream):
         dt = _tdt(dtype)
         X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2)
-        P = torch.nn.functional.max_pool2d(X, k, stride, pad)
+        P, I = torch.nn.functional.max_pool2d(X, k, stride, pad, return_indices=True)
         _nhwc(out, N, P.shape[2], P.shape[3], Cp, ld_out, dt).copy_(P.permute(0, 2, 3, 1).to(dt))
+        if idx is not None:               # flat input index -> window position a*k + b
+            Ho, Wo = P.shape[2], P.shape[3]
+            hi, wi = I // W, I % W
+            a = hi - (torch.arange(Ho)[:, None] * stride - pad)
+            b = wi - (torch.arange(Wo)[None, :] * stride - pad)
+            _mem(idx, N * Ho * Wo * Cp, torch.uint8).view(N, Ho, Wo, Cp).copy_((a * k + b).permute(0, 2, 3, 1).to(torch.uint8))
         return 0
 
-    def segnb_maxpool_bwd(self, dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, stream):
+    def segnb_maxpool_bwd(self, dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream):
         dt = _tdt(dtype)
         with torch.enable_grad():      # called from inside autograd.Function.backward (grad mode off there)
             X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2).clone().requires_grad_(True)

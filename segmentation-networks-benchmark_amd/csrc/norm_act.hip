@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NTHR) void bn_stats_kernel(const T* __restrict__ x,
 template <typename T>
 __global__ __launch_bounds__(NTHR) void maxpool_fwd_kernel(const T* __restrict__ x, int ld_x, int N, int H, int W, int CPP,
                                                            int k, int st, int pd, int Ho, int Wo, T* __restrict__ out,
-                                                           int ld_out) {
+                                                           int ld_out, unsigned char* __restrict__ idx) {
     const long long total = (long long)N * Ho * Wo * CPP;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -751,8 +751,12 @@ __global__ __launch_bounds__(NTHR) void maxpool_fwd_kernel(const T* __restrict__
         const int ho = (int)(q % Ho);
         const int n = (int)(q / Ho);
         float m[8];
+        unsigned am[8];                    // window position a * k + b of the FIRST maximum in scan order (torch's tie rule)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+        for (int e = 0; e < 8; ++e) {
+            m[e] = -INFINITY;
+            am[e] = 255u;
+        }
         for (int a = 0; a < k; ++a)
             for (int b = 0; b < k; ++b) {
                 const int hi = ho * st - pd + a, wi = wo * st - pd + b;
@@ -760,10 +764,20 @@ __global__ __launch_bounds__(NTHR) void maxpool_fwd_kernel(const T* __restrict__
                     float v[8];
                     load8(x + (((long long)n * H + hi) * W + wi) * ld_x + c0, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+                    for (int e = 0; e < 8; ++e)
+                        if (v[e] > m[e] || am[e] == 255u) {
+                            m[e] = v[e];
+                            am[e] = (unsigned)(a * k + b);
+                        }
                 }
             }
         store8(out + (((long long)n * Ho + ho) * Wo + wo) * ld_out + c0, m);
+        if (idx != nullptr) {
+            uint2 pk;
+            pk.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+            pk.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+            *reinterpret_cast<uint2*>(idx + (i / CPP) * (long long)(CPP * 8) + c0) = pk;
+        }
     }
 }
 
@@ -813,6 +827,47 @@ __global__ __launch_bounds__(NTHR) void maxpool_bwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (win[e]) g[e] += gv[e];
+            }
+        store8(dx + (((long long)n * H + h) * W + w) * ld_dx + c0, g);
+    }
+}
+
+// The same from the argmax positions the forward pass recorded (segnb_maxpool_fwd idx): a pixel reads one index vector and
+// one gradient vector per covering window (<= ceil(k / stride)^2 of them) instead of re-scanning every window --
+// 3x3 stride 2 at 256x256x64 (the ResNet stem of LinkNet34 at 512x512): 2.4 ms -> the price of a streaming pass.
+template <typename T>
+__global__ __launch_bounds__(NTHR) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ go,
+                                                               int ld_go, int N, int H, int W, int CPP, int k, int st,
+                                                               int pd, int Ho, int Wo, T* __restrict__ dx, int ld_dx) {
+    const long long total = (long long)N * H * W * CPP;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % CPP) * 8;
+        long long q = i / CPP;
+        const int w = (int)(q % W);
+        q /= W;
+        const int h = (int)(q % H);
+        const int n = (int)(q / H);
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        int ho_lo = (h + pd - k + st) / st;
+        if (h + pd - k + 1 < 0) ho_lo = 0;
+        int wo_lo = (w + pd - k + st) / st;
+        if (w + pd - k + 1 < 0) wo_lo = 0;
+        const int ho_hi = min((h + pd) / st, Ho - 1), wo_hi = min((w + pd) / st, Wo - 1);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const unsigned mine = (unsigned)((h - (ho * st - pd)) * k + (w - (wo * st - pd)));
+                const long long wpix = ((long long)n * Ho + ho) * Wo + wo;
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + wpix * (long long)(CPP * 8) + c0);
+                float gv[8];
+                load8(go + wpix * ld_go + c0, gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                    if (a == mine) g[e] += gv[e];
+                }
             }
         store8(dx + (((long long)n * H + h) * W + w) * ld_dx + c0, g);
     }
@@ -1124,7 +1179,7 @@ extern "C" int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, in
 }
 
 extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
-                                 int pad, void* out, int ld_out, segnb_stream_t stream) {
+                                 int pad, void* out, int ld_out, unsigned char* idx, segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(x && out && k >= 1 && stride >= 1 && pad >= 0 && pad < k, "bad pooling arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -1133,21 +1188,32 @@ extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int 
     if (grid > 8192) grid = 8192;
     SEGNB_DISPATCH_T(
         hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)out, ld_out),
+                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)out, ld_out, idx),
         hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)x,
-                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)out, ld_out),
+                           ld_x, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)out, ld_out, idx),
         "segnb_maxpool_fwd")
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
-                                 int Cp, int k, int stride, int pad, void* dx, int ld_dx, segnb_stream_t stream) {
+                                 int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
+                                 segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(x && g_out && dx && k >= 1 && stride >= 1 && pad >= 0 && pad < k, "bad pooling arguments");
+    SEGNB_CHECK_ARG(x && g_out && dx && k >= 1 && stride >= 1 && pad >= 0 && pad < k && k * k < 255, "bad pooling arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     int grid = ceil_div((long long)N * H * W * (Cp / 8), NTHR);
     if (grid > 8192) grid = 8192;
+    if (idx != nullptr) {
+        SEGNB_DISPATCH_T(
+            hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                               (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx),
+            hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                               (const float*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)dx, ld_dx),
+            "segnb_maxpool_bwd")
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
     SEGNB_DISPATCH_T(
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x,
                            ld_x, (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx),

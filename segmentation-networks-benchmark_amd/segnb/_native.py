@@ -77,8 +77,8 @@ SIGNATURES = {
     'segnb_tiles_merge': [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'segnb_bn_stats': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
-    'segnb_maxpool_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
-    'segnb_maxpool_bwd': [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    'segnb_maxpool_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
+    'segnb_maxpool_bwd': [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     'segnb_nhwc_to_nchw_f32': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_bn_bwd_finalize': [_P, c_int, c_int, c_double, _P, _P, _P, _P, _P, c_int, _P],
     'segnb_bn_bwd_apply_direct': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_float, _P, c_int, _P, c_int,

@@ -229,8 +229,10 @@ def maxpool(tape, x, k, stride, pad, tag='pool'):
     site = tape.site(tag)
     Ho, Wo = (xv.H + 2 * pad - k) // stride + 1, (xv.W + 2 * pad - k) // stride + 1
     ov = tape.view(site + '/o', xv.N, Ho, Wo, xv.Cp)
+    # argmax positions recorded by the forward for the backward (a re-scanning backward costs 36 loads per pixel)
+    idx = tape.small(site + '/idx', (xv.N, Ho, Wo, xv.Cp), torch.uint8) if tape.need_grad and x.needs_grad else None
     nv.call('segnb_maxpool_fwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride, pad, ov.ptr, ov.ld,
-            rt.stream)
+            nv.ptr(idx), rt.stream)
     oa = Act(ov)
 
     def backward():
@@ -238,7 +240,7 @@ def maxpool(tape, x, k, stride, pad, tag='pool'):
             return
         dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
         nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, oa.g.ptr, oa.g.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride,
-                pad, dx.ptr, dx.ld, rt.stream)
+                pad, dx.ptr, dx.ld, nv.ptr(idx), rt.stream)
         tape.contribute(x, dx)
 
     tape.record(backward)

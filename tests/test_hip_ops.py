@@ -656,13 +656,22 @@ def test_maxpool_general_fwd_bwd(case, dtype):
     g = torch.randn(N, Ho, Wo, C, generator=gen).to(rt.tdtype).float()
     pr.backward(g.permute(0, 3, 1, 2))
     xv, gv = _view_from(rt, x, C, slack=8), _view_from(rt, g, C)
-    ov, dxv = View.alloc(rt, N, Ho, Wo, C), View.alloc(rt, N, H, W, C)
-    nv.call('segnb_maxpool_fwd', rt.code, xv.ptr, xv.ld, N, H, W, C, k, s, p, ov.ptr, ov.ld, rt.stream)
-    nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, gv.ptr, gv.ld, N, H, W, C, k, s, p, dxv.ptr, dxv.ld,
+    ov, dxv, dxi = View.alloc(rt, N, Ho, Wo, C), View.alloc(rt, N, H, W, C), View.alloc(rt, N, H, W, C)
+    idx = torch.zeros((N, Ho, Wo, C), dtype=torch.uint8, device='cuda')
+    nv.call('segnb_maxpool_fwd', rt.code, xv.ptr, xv.ld, N, H, W, C, k, s, p, ov.ptr, ov.ld, nv.ptr(idx), rt.stream)
+    nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, gv.ptr, gv.ld, N, H, W, C, k, s, p, dxv.ptr, dxv.ld, None,
             rt.stream)
+    nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, gv.ptr, gv.ld, N, H, W, C, k, s, p, dxi.ptr, dxi.ld,
+            nv.ptr(idx), rt.stream)
     assert torch.equal(ov.dense().float().cpu().permute(0, 3, 1, 2), pr.detach())
     # overlapping windows sum several gradients into one input: one rounding (bf16) / summation order (f32)
     check('maxpool dx', dxv.dense().permute(0, 3, 1, 2), xr.grad, dtype)
+    # the backward from the argmax positions the forward recorded == the re-scanning one, bit for bit
+    assert torch.equal(dxi.t, dxv.t)
+    _, ir = F.max_pool2d(x.permute(0, 3, 1, 2), k, s, p, return_indices=True)
+    a = ir // W - (torch.arange(Ho)[:, None] * s - p)
+    b = ir % W - (torch.arange(Wo)[None, :] * s - p)
+    assert torch.equal(idx.cpu().long(), (a * k + b).permute(0, 2, 3, 1))
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
