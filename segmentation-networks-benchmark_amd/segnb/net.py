@@ -17,7 +17,8 @@ from torch import nn
 
 from . import _native as nv
 from . import convplan as cp
-from .engine import BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, InputNorm, Runtime, View, pack_input, vld, vptr
+from .engine import (BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, InputNorm, PackTable, Runtime, View,
+                     pack_input, vld, vptr)
 
 
 class Act(object):
@@ -37,6 +38,13 @@ class Tape(object):
         self._cache = {}
         self.pack_key = None
         self.back = []
+        # every (convolution, input size) the model has run, in first-use order: ONE batched weight-pack launch per
+        # parameter update and ONE batched gradient-unpack launch per backward (PackTable), instead of two / one per layer
+        self.convs = []
+        self._conv_seen = set()
+        self._pack_table = None
+        self._unpack_table = None
+        self._unpack_pending = []
 
     # ---- per-step bookkeeping ------------------------------------------------------------------------------
     def begin(self, train, need_grad):
@@ -46,8 +54,21 @@ class Tape(object):
         self.generation = getattr(self, 'generation', 0) + 1
         # weight-packing generation: every ConvOp plan (one per input size) remembers the generation it was packed at,
         # so a plan first used -- or last used -- under other parameter values is (re)packed on its next use
-        self.pack_key = (sum(p._version for p in self.module.parameters()), self.flat.version,
-                         self.flat.flat_p.data_ptr())
+        key = (sum(p._version for p in self.module.parameters()), self.flat.version, self.flat.flat_p.data_ptr())
+        if key != self.pack_key and self.convs:
+            # parameters changed since the last pack: all known plans in one launch (plans first met later in this
+            # forward pack themselves in conv_unit and join the table for the next step)
+            t = self._pack_table
+            if t is None or t[0] != (len(self.convs), self.flat.flat_p.data_ptr()):
+                jobs = []
+                for conv, h, w in self.convs:
+                    jobs += conv.pack_jobs(h, w)
+                t = self._pack_table = ((len(self.convs), self.flat.flat_p.data_ptr()),
+                                        PackTable(self.rt, jobs, 'segnb_pack_weight_multi', 'segnb_pack_weight'))
+            t[1].run()
+            for conv, h, w in self.convs:
+                conv.plan(h, w)['packed_key'] = key
+        self.pack_key = key
 
     def site(self, tag):
         """Call-site identity = position in the (static) build order."""
@@ -81,11 +102,31 @@ class Tape(object):
             nv.call('segnb_add', self.rt.code, v.ptr, v.ld, gview.ptr, gview.ld, v.ptr, v.ld, v.N, v.H, v.W, v.Cp,
                     self.rt.stream)
 
+    def register_conv(self, conv, H, W):
+        k = (id(conv), H, W)
+        if k not in self._conv_seen:
+            self._conv_seen.add(k)
+            self.convs.append((conv, H, W))
+
+    def defer_unpack(self, conv, H, W, grad_w):
+        """conv.wgrad(..., unpack=False) was launched: its packed result joins this backward's batched unpack."""
+        self._unpack_pending.append((conv, H, W, grad_w))
+
     def backward(self):
         for fn in reversed(self.back):
             fn()
         self.back = []
         self.rt.join_side()               # the weight gradients ran on the side stream
+        if self._unpack_pending:
+            key = (tuple((id(c), h, w) for c, h, w, _ in self._unpack_pending), self.flat.flat_g.data_ptr())
+            t = self._unpack_table
+            if t is None or t[0] != key:
+                jobs = []
+                for conv, h, w, gw in self._unpack_pending:
+                    jobs += conv.unpack_jobs(h, w, gw)
+                t = self._unpack_table = (key, PackTable(self.rt, jobs, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
+            t[1].run()
+            self._unpack_pending = []
 
     def dropout_table(self, site, N, Cp, p):
         """fp32 [N, Cp] Dropout2d multipliers (0 or 1/(1-p)) drawn on the device; None when inactive."""
@@ -116,7 +157,8 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                                                     need_dgrad=x.needs_grad, out_hw=out_hw))
     xv = x.v
     plan = conv.plan(xv.H, xv.W)
-    if plan.get('packed_key') != tape.pack_key:
+    tape.register_conv(conv, xv.H, xv.W)
+    if plan.get('packed_key') != tape.pack_key:          # (first use of this plan: Tape.begin packs the known ones in one launch)
         conv.pack(xv.H, xv.W)
         plan['packed_key'] = tape.pack_key
     Ho, Wo = conv.out_hw(xv.H, xv.W)
@@ -175,9 +217,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         side = rt.fork_side()
         if side is not None:
             with torch.cuda.stream(side):
-                conv.wgrad(xv, dy, flat.grad_of(weight))
+                conv.wgrad(xv, dy, flat.grad_of(weight), unpack=False)
         else:
-            conv.wgrad(xv, dy, flat.grad_of(weight))
+            conv.wgrad(xv, dy, flat.grad_of(weight), unpack=False)
+        tape.defer_unpack(conv, xv.H, xv.W, flat.grad_of(weight))
         if x.needs_grad:
             dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
             conv.dgrad(dy, dx)
