@@ -277,6 +277,20 @@ int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int
 int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
                            segnb_stream_t stream);
 
+/* Convolution with an affine + activation epilogue: out = act(v),
+ *   coef == NULL : v = conv + bias                          (nn.Conv2d -> nn.ReLU with no BatchNorm between them: unet16.py:12-21,
+ *                                                            35-40; linknet.py:57-62) -- no separate activation pass
+ *   coef != NULL : v = (conv + bias - mean) * scale + shift  (eval-mode BatchNorm folded in; coef = [4][Co] of segnb_bn_finalize
+ *                                                            with training = 0: validate(), torch_train.py:248-265, and inference)
+ * act: SEGNB_ACT_NONE / RELU / LEAKY(slope).  No statistics (a training-mode BatchNorm needs the raw output first). */
+typedef struct {
+    const float* coef;
+    int act;
+    float slope;
+} segnb_act_epilogue;
+int segnb_conv_fprop_act(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
+                         int bias_n, void* out, const segnb_act_epilogue* ep, segnb_stream_t stream);
+
 /* A DATA-GRADIENT launch whose epilogue also does the BatchNorm-backward reduction of the layer that produced its
  * output's forward counterpart: out = g (the gradient of that layer's activation, exactly what segnb_conv_fprop
  * writes), and sums[r][0][c] += sum dz, sums[r][1][c] += sum dz * yhat with dz = round(g * act'((y - mean) * scale +

@@ -122,6 +122,31 @@ class AbiEmulator(object):
         g2.ld_in = 8
         return self.segnb_conv_fprop(g2, BF16, keep.data_ptr(), wp, bias, bias_n, out_p, stats, stream)
 
+    # ---- convolution with the affine + activation epilogue (segnb_conv_fprop_act)
+    def segnb_conv_fprop_act(self, g, dtype, in_p, wp, bias, bias_n, out_p, ep, stream):
+        gg, e = _geom(g), _geom(ep)
+        dt = _tdt(dtype)
+        X = _nhwc(in_p, gg.N, gg.Hi, gg.Wi, gg.Ci, gg.ld_in, dt)
+        O = _nhwc(out_p, gg.N, gg.Ho, gg.Wo, gg.Co, gg.ld_out, dt)
+        Wm = _mem(wp, gg.Co * gg.ntaps * gg.Ci, dt).view(gg.Co, gg.ntaps, gg.Ci).float()
+        acc = torch.zeros(gg.N, gg.QH, gg.QW, gg.Co)
+        for t in range(gg.ntaps):
+            acc += _gather(X, gg, t) @ Wm[:, t, :].t()
+        b = torch.zeros(gg.Co)
+        if bias is not None and bias_n > 0:
+            b[:bias_n] = _mem(bias, bias_n, torch.float32)
+        if e.coef:
+            co = _mem(e.coef, 4 * gg.Co, torch.float32).view(4, gg.Co)
+            v = acc * co[0] + ((b - co[2]) * co[0] + co[1])
+        else:
+            v = acc + b
+        neg = 0.0 if e.act == 1 else (float(e.slope) if e.act == 2 else 1.0)
+        v = torch.where(v < 0, v * neg, v) + 0.0
+        oh = torch.arange(gg.QH) * gg.out_step + gg.oh0
+        ow = torch.arange(gg.QW) * gg.out_step + gg.ow0
+        O[:, oh[:, None], ow[None, :], :] = v.to(dt)
+        return 0
+
     # ---- data gradient + the BatchNorm-backward reduction of its output's producer (segnb_conv_fprop_bnreduce) = the two
     # separate entry points, composed
     def segnb_conv_fprop_bnreduce_ok(self, g, dtype):

@@ -53,14 +53,14 @@ int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpa
 // direct-to-LDS pipeline for Ci % 64 == 0 (fprop_dma.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                        hipStream_t stream);
+                        hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
 // resident-weights pipeline for the thin layers, Ci <= 96 and Co <= 96 (fprop_rw.hip)
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                        hipStream_t stream, const segnb_bn_reduce_epilogue* bn = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
-                       void* out, double* stats, hipStream_t stream);
+                       void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
                        hipStream_t stream, bool partial = false);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);

@@ -28,6 +28,9 @@ struct FpropArgs {
     const void* w;
     const float* bias;
     int bias_n;
+    const float* ep_coef;      // affine + activation epilogue (segnb_conv_fprop_act); ep_act < 0: off
+    int ep_act;
+    float ep_slope;
     void* out;
     double* stats;
     int M, Ktot, ksteps, MT, NTL, GM;
@@ -267,14 +270,22 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
         for (int j = 0; j < TN; ++j) {
             const int col = wc * WN + 32 * j + r;
             const int co = n_base + col;
-            const float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+            float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+            float sv = 1.f;
+            if (a.ep_act >= 0 && a.ep_coef != nullptr && co < a.g.Co) {       // (acc + bias - mean) * scale + shift
+                sv = a.ep_coef[co];
+                bv = (bv - a.ep_coef[2 * a.g.Co + co]) * sv + a.ep_coef[a.g.Co + co];
+            }
+            const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = wr * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const T tv = Elem<T>::from_f32(acc[i][j][e] + bv);
+                    float ev = a.ep_act >= 0 ? acc[i][j][e] * sv + bv : acc[i][j][e] + bv;
+                    if (a.ep_act >= 0 && ev < 0.f) ev = ev * ep_neg + 0.f;
+                    const T tv = Elem<T>::from_f32(ev);
                     *reinterpret_cast<T*>(sOut + row * OUT_ROW + col * (int)sizeof(T)) = tv;
                     if (m_base + row < a.M) {
                         const float vr = Elem<T>::to_f32(tv);
@@ -871,12 +882,30 @@ int check_geom(const segnb_conv_geom* g) {
 
 }  // namespace
 
+static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
+                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep);
+
 extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                 const float* bias, int bias_n, void* out, double* stats,
                                 segnb_stream_t stream) {
+    return conv_fprop_impl(g, dtype, in, wpacked, bias, bias_n, out, stats, stream, nullptr);
+}
+
+extern "C" int segnb_conv_fprop_act(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                                    const float* bias, int bias_n, void* out, const segnb_act_epilogue* ep,
+                                    segnb_stream_t stream) {
+    SEGNB_CHECK_ARG(ep != nullptr && ep->act >= SEGNB_ACT_NONE && ep->act <= SEGNB_ACT_LEAKY, "bad epilogue");
+    return conv_fprop_impl(g, dtype, in, wpacked, bias, bias_n, out, nullptr, stream, ep);
+}
+
+static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
+                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep) {
     if (int rc = check_geom(g)) return rc;
     SEGNB_CHECK_ARG(in && wpacked && out, "NULL tensor");
     FpropArgs a;
+    a.ep_act = ep != nullptr ? ep->act : -1;
+    a.ep_coef = ep != nullptr ? ep->coef : nullptr;
+    a.ep_slope = ep != nullptr ? ep->slope : 0.f;
     a.g = *g;
     a.in = in;
     a.w = wpacked;
@@ -898,14 +927,15 @@ extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void*
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
         static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
-        rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
-        if (rc == 0 && !general_only)
+        // (the affine + activation epilogue lives in the c8, ws and general kernels: rw / s1 are skipped for it)
+        rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
+        if (rc == 0 && !general_only && ep == nullptr)
             rc = segnb_fprop_rw_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
                                     (hipStream_t)stream);
         if (rc == 0 && !general_only)
             rc = segnb_fprop_dma_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
-                                     (hipStream_t)stream);
-        if (rc == 0 && !general_only)
+                                     (hipStream_t)stream, ep);
+        if (rc == 0 && !general_only && ep == nullptr)
             rc = segnb_fprop_s1_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();

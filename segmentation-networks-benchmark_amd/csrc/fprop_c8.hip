@@ -26,6 +26,9 @@ struct C8Norm {
 
 struct C8Args {
     C8Norm u8;
+    const float* ep_coef;      // affine + activation epilogue (segnb_conv_fprop_act), as FdArgs
+    int ep_act;
+    float ep_slope;
     const bf16_t* x;
     const bf16_t* w;       // [Co][9][8]
     const float* bias;
@@ -75,17 +78,29 @@ __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
         if (tap < 9 && r < a.Co) v = *reinterpret_cast<const uint4*>(a.w + ((long long)r * 9 + tap) * 8);
         wf[s] = __builtin_bit_cast(bf16x8_t, v);
     }
-    float4 bias4[4];                    // transposed accumulators: lane holds channels 8g + 4h .. +3
+    float4 bias4[4], scale4[4];         // transposed accumulators: lane holds channels 8g + 4h .. +3
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float b[4];
+        float b[4], sc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 8 * g + 4 * h + e;
             b[e] = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
+            sc[e] = 1.f;
+            if (a.ep_act >= 0 && a.ep_coef != nullptr && c < a.Co) {
+                sc[e] = a.ep_coef[c];
+                b[e] = (b[e] - a.ep_coef[2 * a.Co + c]) * sc[e] + a.ep_coef[a.Co + c];
+            }
         }
         bias4[g] = make_float4(b[0], b[1], b[2], b[3]);
+        scale4[g] = make_float4(sc[0], sc[1], sc[2], sc[3]);
     }
+    const bool ep_on = a.ep_act >= 0;
+    const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
+    auto ep = [&](float acc, float sc, float sh) {
+        const float v = ep_on ? acc * sc + sh : acc + sh;
+        return (ep_on && v < 0.f) ? v * ep_neg + 0.f : v;
+    };
     // A fragment LDS offsets: wave w owns tile rows 64w .. 64w+63 (two MFMA row tiles)
     int a_off[5][2];
 #pragma unroll
@@ -163,8 +178,8 @@ __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
-                pk.x = pack2bf(acc[i][4 * g + 0] + bias4[g].x, acc[i][4 * g + 1] + bias4[g].y);
-                pk.y = pack2bf(acc[i][4 * g + 2] + bias4[g].z, acc[i][4 * g + 3] + bias4[g].w);
+                pk.x = pack2bf(ep(acc[i][4 * g + 0], scale4[g].x, bias4[g].x), ep(acc[i][4 * g + 1], scale4[g].y, bias4[g].y));
+                pk.y = pack2bf(ep(acc[i][4 * g + 2], scale4[g].z, bias4[g].z), ep(acc[i][4 * g + 3], scale4[g].w, bias4[g].w));
                 *reinterpret_cast<uint2*>(sOut + row * C8_OUT_ROW + (8 * g + 4 * h) * 2) = pk;
             }
         }
@@ -221,17 +236,17 @@ static_assert(256 * 16 * 8 <= C8_SMEM, "statistics reduction scratch");
 }  // namespace
 
 static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8, const void* wpacked, const float* bias,
-                     int bias_n, void* out, double* stats, hipStream_t stream);
+                     int bias_n, void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
 
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
-                       void* out, double* stats, hipStream_t stream) {
+                       void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep) {
     if (!segnb_knob_fprop_dma()) return 0;
-    return c8_launch(g, in, nullptr, wpacked, bias, bias_n, out, stats, stream);
+    return c8_launch(g, in, nullptr, wpacked, bias, bias_n, out, stats, stream, ep);
 }
 
 static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8, const void* wpacked, const float* bias,
-                     int bias_n, void* out, double* stats, hipStream_t stream) {
+                     int bias_n, void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep) {
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 8 || g->Co > 32 || g->Wo < 12) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
@@ -243,6 +258,9 @@ static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8,
     }
     if (dhmax - dhmin != 2 || dwmax - dwmin != 2) return 0;
     C8Args a;
+    a.ep_act = ep != nullptr ? ep->act : -1;
+    a.ep_coef = ep != nullptr ? ep->coef : nullptr;
+    a.ep_slope = ep != nullptr ? ep->slope : 0.f;
     if (u8 != nullptr) a.u8 = *u8;
     a.x = (const bf16_t*)in;
     a.w = (const bf16_t*)wpacked;

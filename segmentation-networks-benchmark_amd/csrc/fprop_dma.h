@@ -42,6 +42,11 @@ struct FdArgs {
     double* bn_sums;      // [REPL][2][Co]
     int bn_act;
     float bn_slope;
+    // affine + activation epilogue (segnb_conv_fprop_act): out = act((acc + bias) affine-mapped); ep_act < 0: off.
+    // ep_coef NULL: v = acc + bias;  else [4][Co] of segnb_bn_finalize: v = (acc + bias - mean) * scale + shift
+    const float* ep_coef;
+    int ep_act;
+    float ep_slope;
     int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA +
                           // fragment reads, 8 no stores, 16 no fragment reads, 32 in-kernel stamps, 64 one stamp per tap
 };

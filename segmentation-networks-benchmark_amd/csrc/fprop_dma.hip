@@ -92,7 +92,8 @@ struct WsCfg {
     static constexpr int OFF_DUMMY = OFF_STG + BM * OUT_ROW;
     static constexpr int OFF_PIX = OFF_DUMMY + 1024;
     static constexpr int OFF_BIAS = OFF_PIX + 4 * BM * 4;      // pixel tables of tiles k-1 (being stored), k, k+1, k+2 (set up)
-    static constexpr int SMEM = OFF_BIAS + BN * 4;
+    static constexpr int OFF_SCALE = OFF_BIAS + BN * 4;       // per-channel factor of the affine epilogue (1 when off)
+    static constexpr int SMEM = OFF_SCALE + BN * 4;
     static constexpr int RED_BYTES = MT * 16 * 8;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == NCW, "wave tiling");
     static_assert(BPIECES % NBW == 0 && NBW + NAW == NLW, "fetch wave roles");
@@ -126,10 +127,24 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     const i32x4_t rs_x = make_rsrc4(a.x, a.x_bytes);
     const i32x4_t rs_w = make_rsrc4(a.w, a.w_bytes);
 
+    float* sScale = reinterpret_cast<float*>(smem + C::OFF_SCALE);
     for (int c = tid; c < BN; c += NT) {
         const int co = n_base + c;
-        sBias[c] = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+        const float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+        float sc = 1.f, sh = bv;
+        if (a.ep_act >= 0 && a.ep_coef != nullptr && co < a.Co) {      // (acc + bias - mean) * scale + shift
+            sc = a.ep_coef[co];
+            sh = (bv - a.ep_coef[2 * a.Co + co]) * sc + a.ep_coef[a.Co + co];
+        }
+        sBias[c] = sh;
+        sScale[c] = sc;
     }
+    const bool ep_on = a.ep_act >= 0;
+    const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
+    auto ep = [&](float acc, float sc, float sh) {
+        const float v = ep_on ? acc * sc + sh : acc + sh;
+        return (ep_on && v < 0.f) ? v * ep_neg + 0.f : v;
+    };
 
     // ---- three programs (weight waves / halo waves / matrix waves) with the same barrier sequence: one after the
     // pipeline prologue, one per tap, three after the last tile.  Per-role constants are computed inside the role's
@@ -505,10 +520,12 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);
                 // accumulator tile (i, j): this lane holds channels 16 j + 4 g4 + {0..3} of pixel 16 i + r16
                 const int r16 = lane & 15, g4 = lane >> 4;
-                float4 bv[TN16];
+                float4 bv[TN16], sv[TN16];
 #pragma unroll
-                for (int j = 0; j < TN16; ++j)
+                for (int j = 0; j < TN16; ++j) {
                     bv[j] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 16 * j + 4 * g4);
+                    sv[j] = *reinterpret_cast<const float4*>(sScale + wn * C::WN + 16 * j + 4 * g4);
+                }
 #pragma unroll
                 for (int i = 0; i < TM16; ++i) {
                     const int row = wm * C::WM + 16 * i + r16;
@@ -516,8 +533,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     for (int j = 0; j < TN16; ++j) {
                         const int col = wn * C::WN + 16 * j + 4 * g4;
                         uint2 pk;
-                        pk.x = pack2bf(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y);
-                        pk.y = pack2bf(acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+                        pk.x = pack2bf(ep(acc[i][j][0], sv[j].x, bv[j].x), ep(acc[i][j][1], sv[j].y, bv[j].y));
+                        pk.y = pack2bf(ep(acc[i][j][2], sv[j].z, bv[j].z), ep(acc[i][j][3], sv[j].w, bv[j].w));
                         *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
@@ -764,7 +781,7 @@ int segnb_fprop_dma_read_stamps(unsigned long long* host_dst) {
 // 1 = handled, 0 = not applicable (caller falls through to fprop_s1 / the general gather kernel), else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                        hipStream_t stream) {
+                        hipStream_t stream, const segnb_act_epilogue* ep) {
     if (!segnb_knob_fprop_dma()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 64 != 0) return 0;
@@ -800,6 +817,9 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     a.bn_y = nullptr;
+    a.ep_act = ep != nullptr ? ep->act : -1;
+    a.ep_coef = ep != nullptr ? ep->coef : nullptr;
+    a.ep_slope = ep != nullptr ? ep->slope : 0.f;
     const int rc = dispatch_fd(a, stream);
     if (rc == NOT_HANDLED) return 0;
     return rc ? rc : 1;

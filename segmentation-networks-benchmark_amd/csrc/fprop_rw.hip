@@ -475,6 +475,9 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     a.bn_y = nullptr;
+    a.ep_act = -1;
+    a.ep_coef = nullptr;
+    a.ep_slope = 0.f;
     if (bn != nullptr) {
         if (stats != nullptr || g->Co > 64) return 0;                 // one accumulator set per launch; 96-wide: no statistics threads
         const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;

@@ -39,6 +39,11 @@ class BnReduceEpilogue(ctypes.Structure):
                 ('slope', c_float)]
 
 
+class ActEpilogue(ctypes.Structure):
+    """segnb_act_epilogue"""
+    _fields_ = [('coef', c_void_p), ('act', c_int), ('slope', c_float)]
+
+
 class LossSpec(ctypes.Structure):
     """segnb_loss_spec"""
     _fields_ = [('w_bce', c_float), ('w_focal', c_float), ('w_jaccard', c_float), ('w_sjaccard', c_float),
@@ -50,6 +55,7 @@ _P = c_void_p
 # name -> argtypes (all return int status)
 SIGNATURES = {
     'segnb_conv_fprop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, _P],
+    'segnb_conv_fprop_act': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, ctypes.POINTER(ActEpilogue), _P],
     'segnb_conv_fprop_bnreduce': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_conv_wgrad_partial': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],

@@ -340,18 +340,37 @@ class ConvOp(object):
         return jobs
 
     # ---- kernels ------------------------------------------------------------------------------------
-    def fprop(self, xv, yv, stats=None):
+    # activation (and eval-mode BatchNorm) in the convolution's epilogue instead of a pass of its own (A/B: SEGNB_FPROP_ACT=0)
+    fuse_act = os.environ.get('SEGNB_FPROP_ACT', '1') != '0'
+
+    def fprop(self, xv, yv, stats=None, epilogue=None):
+        """epilogue: (coef or None, act, slope) -- segnb_conv_fprop_act: yv receives act(conv + bias) (coef None) or
+        act of the eval-mode BatchNorm of it (coef = [4][Cop] of segnb_bn_finalize); no statistics then."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         assert xv.Cp == self.Cip and yv.Cp == self.Cop, (xv.Cp, self.Cip, yv.Cp, self.Cop)
         assert (yv.H, yv.W) == p['out_hw']
         if not p['fwd_full']:
             yv.dense().zero_()
         b = self.bias.detach() if self.bias is not None else None
+        if epilogue is not None:
+            assert stats is None and p['fwd_full'] and len(p['fwd']) == 1, 'one full-coverage launch, no statistics'
+            l = p['fwd'][0]
+            g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+            ep = nv.ActEpilogue(nv.ptr(epilogue[0]), epilogue[1], epilogue[2])
+            _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_fprop_act', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
+                                   self.Co if b is not None else 0, yv.ptr, ep, rt.stream))
+            return
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
             _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
                                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream))
+
+    def act_epilogue_ok(self, H, W):
+        """segnb_conv_fprop_act needs ONE launch that covers the whole output (not a phase-split transposed convolution)."""
+        p = self.plan(H, W)
+        return self.fuse_act and p['fwd_full'] and len(p['fwd']) == 1
 
     def u8_direct_ok(self, N, H, W, ld_out):
         """True when segnb_conv_fprop_u8 serves this convolution as the network's first layer."""
@@ -527,6 +546,21 @@ class Stage(object):
             # the previous training-mode forward was fused (statistics left unconsumed) and no backward cleared them
             self.stats.zero_()
             self._stats_stale = False
+        if (not need_grad and not use_batch_stats and u8 is None and out is not None and pool_out is None and up_out is None
+                and dropmul is None and self.conv.act_epilogue_ok(xv.H, xv.W)):
+            # inference (validate(), tiled prediction): eval-mode BatchNorm and the activation in the convolution's epilogue --
+            # the activated output goes straight to `out`, no BatchNorm pass at all
+            coef = None
+            if self.bn is not None:
+                bn = self.bn
+                nv.call('segnb_bn_finalize', nv.ptr(self.stats), self.C, self.Cp, float(xv.N * Ho * Wo),
+                        nv.ptr(bn.weight.detach()), nv.ptr(bn.bias.detach()), BN_EPS, BN_MOMENTUM,
+                        nv.ptr(bn.running_mean), nv.ptr(bn.running_var), nv.ptr(bn.num_batches_tracked), 0,
+                        nv.ptr(self.coef), rt.stream)
+                coef = self.coef
+            self.conv.fprop(xv, out, None, epilogue=(coef, self.act, self.slope))
+            self._saved = None
+            return out
         if u8 is not None:
             self.conv.fprop_u8(u8[0], u8[1], yv, self.stats if use_batch_stats else None, xv if need_grad else None)
         else:

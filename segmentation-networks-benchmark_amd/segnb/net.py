@@ -168,6 +168,51 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     coef_buf = tape.small(site + '/coef', (4, Cp), torch.float32)
     has_bn = bn is not None
     use_batch_stats = has_bn and tape.train
+    # activation in the convolution's epilogue (segnb_conv_fprop_act): no BatchNorm (unet16.py:12-21, the linknet head), or
+    # BatchNorm in inference -- with no residual, dropout or fused pooling in the way.  The backward of the no-BatchNorm
+    # form reads the ACTIVATED tensor where it read the raw one: act'(z) has the sign of act(z).
+    ov_direct = out if out is not None else None
+    fuse = ((not has_bn or (not tape.train and not tape.need_grad)) and res is None and dropmul is None and not pool
+            and act in (nv.ACT_NONE, nv.ACT_RELU, nv.ACT_LEAKY) and conv.act_epilogue_ok(xv.H, xv.W))
+    if fuse:
+        coef = None
+        if has_bn:
+            gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
+                    nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 0, nv.ptr(coef_buf), rt.stream)
+            coef = coef_buf
+        ov = ov_direct if ov_direct is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
+        conv.fprop(xv, ov, None, epilogue=(coef, act, slope))
+        oa = Act(ov)
+
+        def backward_fused():
+            if oa.g is None:
+                return
+            flat = tape.flat
+            dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
+            sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+            bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
+            # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one
+            nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
+                    oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+            gb = flat.grad_of(bias) if bias is not None else None
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * Ho * Wo), None, nv.ptr(coef_buf), nv.ptr(bcoef),
+                    None, nv.ptr(gb), 1, rt.stream)
+            side = rt.fork_side()
+            if side is not None:
+                with torch.cuda.stream(side):
+                    conv.wgrad(xv, dz, flat.grad_of(weight), unpack=False)
+            else:
+                conv.wgrad(xv, dz, flat.grad_of(weight), unpack=False)
+            tape.defer_unpack(conv, xv.H, xv.W, flat.grad_of(weight))
+            if x.needs_grad:
+                dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
+                conv.dgrad(dz, dx)
+                tape.contribute(x, dx)
+
+        if not has_bn:
+            tape.record(backward_fused)
+        return oa
     conv.fprop(xv, y, stats if use_batch_stats else None)
     coef = None
     if has_bn:

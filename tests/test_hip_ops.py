@@ -940,6 +940,82 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
         np.testing.assert_allclose(a / scale, e / scale, atol=2e-4)
 
 
+ACT_EP_CASES = [
+    # name,                 N, H,  W,  segs,               Co, k, s, p, transposed
+    ('ws 64->64 relu',      2, 24, 40, [(64, 64)],         64, 3, 1, 1, False),
+    ('ws 128->72 leaky',    1, 33, 17, [(128, 128)],       72, 3, 1, 1, False),
+    ('c8 3->32',            2, 32, 48, [(3, 8)],           32, 3, 1, 1, False),
+    ('general 1x1 40->24',  2, 19, 23, [(40, 40)],         24, 1, 1, 0, False),
+    ('general 3x3 s2',      2, 21, 30, [(16, 16)],         48, 3, 2, 1, False),
+    ('general 2x2 p1',      1, 15, 15, [(32, 32)],         8,  2, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('with_bn', [False, True], ids=['act', 'evalbn+act'])
+@pytest.mark.parametrize('case', ACT_EP_CASES, ids=[c[0] for c in ACT_EP_CASES])
+def test_conv_fprop_act_epilogue(case, with_bn, dtype):
+    """segnb_conv_fprop_act: activation (and eval-mode BatchNorm) in the convolution's epilogue == conv -> [BatchNorm2d in
+    eval mode] -> ReLU / LeakyReLU as torch computes them (unet16.py:12-21, linknet.py:57-62; validate() of
+    torch_train.py:248-265), and == the emulator.  The output is written into a channel slice of a wider buffer."""
+    name, N, H, W, segs, Co, k, s, p, transposed = case
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(len(name) * 7 + Co)
+    rt = Runtime('cuda', dtype)
+    q = (lambda t: t.bfloat16().float()) if dtype == 'bf16' else (lambda t: t)
+    w = q(torch.randn(Co, Ci, k, k, generator=gen) * (2.0 / (Ci * k * k)) ** 0.5)
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = q(torch.randn(N, Ci, H, W, generator=gen))
+    act, slope = (nv.ACT_LEAKY, 0.01) if 'leaky' in name or k == 2 else (nv.ACT_RELU, 0.0)
+    bn = torch.nn.BatchNorm2d(Co).eval()
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(Co, generator=gen)); bn.bias.copy_(0.2 * torch.randn(Co, generator=gen))
+        bn.running_mean.copy_(0.1 * torch.randn(Co, generator=gen)); bn.running_var.copy_(0.5 + torch.rand(Co, generator=gen))
+    with torch.no_grad():
+        ref = F.conv2d(x, w, b, stride=s, padding=p)
+        if with_bn:
+            ref = bn(ref)
+        ref = F.leaky_relu(ref, slope) if act == nv.ACT_LEAKY else torch.relu(ref)
+
+    def run(device):
+        r = Runtime(device, dtype)
+        op = ConvOp(r, w.to(device), b.to(device), segs, s, p, transposed, need_dgrad=False)
+        op.pack(H, W)
+        Ho, Wo = op.out_hw(H, W)
+        xv = View.alloc(r, N, H, W, op.Cip)
+        off = 0
+        for real, padded in segs:
+            xv.dense()[..., off:off + real] = x[:, :real].permute(0, 2, 3, 1).to(device, r.tdtype)
+            off += padded
+        buf = r.zeros((N, Ho, Wo, op.Cop + 16))
+        yv = View(buf, N, Ho, Wo, op.Cop, op.Cop + 16, 8)
+        coef = None
+        if with_bn:
+            coef = r.zeros((4, op.Cop), torch.float32)
+            stats = r.zeros((16, 2, op.Cop), torch.float64)
+            dv = lambda t: t.detach().to(device)
+            rm, rv, gam, bet = dv(bn.running_mean), dv(bn.running_var), dv(bn.weight), dv(bn.bias)     # (kept alive)
+            nv.call('segnb_bn_finalize', nv.ptr(stats), Co, op.Cop, float(N * Ho * Wo), nv.ptr(gam), nv.ptr(bet), 1e-5,
+                    0.1, nv.ptr(rm), nv.ptr(rv), None, 0, nv.ptr(coef), r.stream)
+            if device != 'cpu':
+                torch.cuda.synchronize()
+        assert op.act_epilogue_ok(H, W)
+        op.fprop(xv, yv, None, epilogue=(coef, act, slope))
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return yv.dense().float().cpu(), buf.float().cpu()
+
+    y_g, buf_g = run('cuda')
+    with on_emulator():
+        y_e, _ = run('cpu')
+    check(name + ' vs emulator', y_g, y_e, dtype)
+    check(name + ' vs torch', y_g[..., :Co].permute(0, 3, 1, 2), ref, dtype)
+    assert float(buf_g[..., :8].abs().max()) == 0.0 and float(buf_g[..., 8 + y_g.shape[-1]:].abs().max()) == 0.0
+    if y_g.shape[-1] > Co:
+        pad = y_g[..., Co:]
+        assert float(pad.abs().max()) == 0.0, 'padding channels must stay zero'
+
+
 # ------------------------------------------------------------------------------------------------------
 # resident-weights pipeline of the thin layers (fprop_rw.hip): Ci in {32, 64, 96}, Co <= 96
 # ------------------------------------------------------------------------------------------------------
