@@ -927,11 +927,11 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
         static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
-        // (the affine + activation epilogue lives in the c8, ws and general kernels: rw / s1 are skipped for it)
+        // (the affine + activation epilogue lives in the c8, rw, ws and general kernels: s1 is skipped for it)
         rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
-        if (rc == 0 && !general_only && ep == nullptr)
+        if (rc == 0 && !general_only)
             rc = segnb_fprop_rw_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, nullptr, ep);
         if (rc == 0 && !general_only)
             rc = segnb_fprop_dma_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
                                      (hipStream_t)stream, ep);

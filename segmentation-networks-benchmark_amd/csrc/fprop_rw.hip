@@ -40,7 +40,8 @@ struct RwCfg {
     static constexpr int STG_BYTES = BM * OUT_ROW;
     static constexpr int OFF_PIX = OFF_STG + STG_BYTES;
     static constexpr int OFF_BIAS = OFF_PIX + 2 * BM * 4;
-    static constexpr int OFF_DUMMY = ((OFF_BIAS + BN * 4 + 1023) / 1024) * 1024;
+    static constexpr int OFF_SCALE = OFF_BIAS + BN * 4;      // per-channel factor of the affine epilogue (segnb_conv_fprop_act)
+    static constexpr int OFF_DUMMY = ((OFF_SCALE + BN * 4 + 1023) / 1024) * 1024;
     static constexpr int OFF_W = OFF_DUMMY + 1024;
     static constexpr int W_MAX = 160 * 1024 - OFF_W;      // bytes left for the resident weights
     static constexpr int SMEM = 160 * 1024;
@@ -71,7 +72,23 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
     const i32x4_t rs_x = make_rsrc4(a.x, a.x_bytes);
     const i32x4_t rs_w = make_rsrc4(a.w, a.w_bytes);
 
-    for (int c = tid; c < BN; c += C::NT) sBias[c] = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
+    float* sScale = reinterpret_cast<float*>(smem + C::OFF_SCALE);
+    for (int c = tid; c < BN; c += C::NT) {
+        const float bv = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
+        float sc = 1.f, sh = bv;
+        if (a.ep_act >= 0 && a.ep_coef != nullptr && c < a.Co) {      // (acc + bias - mean) * scale + shift
+            sc = a.ep_coef[c];
+            sh = (bv - a.ep_coef[2 * a.Co + c]) * sc + a.ep_coef[a.Co + c];
+        }
+        sBias[c] = sh;
+        sScale[c] = sc;
+    }
+    const bool ep_on = a.ep_act >= 0;
+    const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
+    auto ep = [&](float acc, float sc, float sh) {
+        const float v = ep_on ? acc * sc + sh : acc + sh;
+        return (ep_on && v < 0.f) ? v * ep_neg + 0.f : v;
+    };
 
     if (fetcher) {
         // ================= fetch stream =================
@@ -392,9 +409,10 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const int col = 32 * j + 8 * q + 4 * h;
                         const float4 bv4 = *reinterpret_cast<const float4*>(sBias + col);
+                        const float4 sv4 = *reinterpret_cast<const float4*>(sScale + col);
                         uint2 pk;
-                        pk.x = pack2bf(acc[i][j][4 * q + 0] + bv4.x, acc[i][j][4 * q + 1] + bv4.y);
-                        pk.y = pack2bf(acc[i][j][4 * q + 2] + bv4.z, acc[i][j][4 * q + 3] + bv4.w);
+                        pk.x = pack2bf(ep(acc[i][j][4 * q + 0], sv4.x, bv4.x), ep(acc[i][j][4 * q + 1], sv4.y, bv4.y));
+                        pk.y = pack2bf(ep(acc[i][j][4 * q + 2], sv4.z, bv4.z), ep(acc[i][j][4 * q + 3], sv4.w, bv4.w));
                         *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
@@ -438,7 +456,7 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn) {
+                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn, const segnb_act_epilogue* ep) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_rw()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 96 || g->Wo < 12) return 0;
@@ -475,9 +493,9 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     a.bn_y = nullptr;
-    a.ep_act = -1;
-    a.ep_coef = nullptr;
-    a.ep_slope = 0.f;
+    a.ep_act = ep != nullptr ? ep->act : -1;
+    a.ep_coef = ep != nullptr ? ep->coef : nullptr;
+    a.ep_slope = ep != nullptr ? ep->slope : 0.f;
     if (bn != nullptr) {
         if (stats != nullptr || g->Co > 64) return 0;                 // one accumulator set per launch; 96-wide: no statistics threads
         const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;

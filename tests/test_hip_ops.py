@@ -945,6 +945,8 @@ ACT_EP_CASES = [
     ('ws 64->64 relu',      2, 24, 40, [(64, 64)],         64, 3, 1, 1, False),
     ('ws 128->72 leaky',    1, 33, 17, [(128, 128)],       72, 3, 1, 1, False),
     ('c8 3->32',            2, 32, 48, [(3, 8)],           32, 3, 1, 1, False),
+    ('rw 32->64 relu',      2, 24, 40, [(32, 32)],         64, 3, 1, 1, False),
+    ('rw cat 96->32 leaky', 1, 30, 36, [(64, 64), (32, 32)], 32, 3, 1, 1, False),
     ('general 1x1 40->24',  2, 19, 23, [(40, 40)],         24, 1, 1, 0, False),
     ('general 3x3 s2',      2, 21, 30, [(16, 16)],         48, 3, 2, 1, False),
     ('general 2x2 p1',      1, 15, 15, [(32, 32)],         8,  2, 1, 1, False),
@@ -983,10 +985,11 @@ def test_conv_fprop_act_epilogue(case, with_bn, dtype):
         op.pack(H, W)
         Ho, Wo = op.out_hw(H, W)
         xv = View.alloc(r, N, H, W, op.Cip)
-        off = 0
+        off, roff = 0, 0
         for real, padded in segs:
-            xv.dense()[..., off:off + real] = x[:, :real].permute(0, 2, 3, 1).to(device, r.tdtype)
+            xv.dense()[..., off:off + real] = x[:, roff:roff + real].permute(0, 2, 3, 1).to(device, r.tdtype)
             off += padded
+            roff += real
         buf = r.zeros((N, Ho, Wo, op.Cop + 16))
         yv = View(buf, N, Ho, Wo, op.Cop, op.Cop + 16, 8)
         coef = None
