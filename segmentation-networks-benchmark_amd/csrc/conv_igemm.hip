@@ -117,7 +117,7 @@ constexpr int fprop_smem_bytes() {
 // ================================================================================================
 // forward / data-gradient
 // ================================================================================================
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool EP = false>      // EP: affine + activation epilogue (separate instantiation)
 __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
@@ -271,20 +271,25 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
             const int col = wc * WN + 32 * j + r;
             const int co = n_base + col;
             float bv = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
-            float sv = 1.f;
-            if (a.ep_act >= 0 && a.ep_coef != nullptr && co < a.g.Co) {       // (acc + bias - mean) * scale + shift
-                sv = a.ep_coef[co];
-                bv = (bv - a.ep_coef[2 * a.g.Co + co]) * sv + a.ep_coef[a.g.Co + co];
+            float sv = 1.f, ep_neg = 1.f;
+            if constexpr (EP) {
+                if (a.ep_coef != nullptr && co < a.g.Co) {       // (acc + bias - mean) * scale + shift
+                    sv = a.ep_coef[co];
+                    bv = (bv - a.ep_coef[2 * a.g.Co + co]) * sv + a.ep_coef[a.g.Co + co];
+                }
+                ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
             }
-            const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = wr * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    float ev = a.ep_act >= 0 ? acc[i][j][e] * sv + bv : acc[i][j][e] + bv;
-                    if (a.ep_act >= 0 && ev < 0.f) ev = ev * ep_neg + 0.f;
+                    float ev = acc[i][j][e] + bv;
+                    if constexpr (EP) {
+                        ev = acc[i][j][e] * sv + bv;
+                        if (ev < 0.f) ev = ev * ep_neg + 0.f;
+                    }
                     const T tv = Elem<T>::from_f32(ev);
                     *reinterpret_cast<T*>(sOut + row * OUT_ROW + col * (int)sizeof(T)) = tv;
                     if (m_base + row < a.M) {
@@ -798,7 +803,10 @@ int set_smem(K kernel, int bytes) {
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_fprop(FpropArgs& a, hipStream_t stream) {
     constexpr int smem = fprop_smem_bytes<BM, BN, T>();
-    static int attr_rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
+    static int attr_rc = [] {
+        const int rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
+        return rc ? rc : set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, true>, smem);
+    }();
     if (attr_rc) return attr_rc;
     a.MT = ceil_div(a.M, BM);
     a.NTL = ceil_div(a.g.Co, BN);
@@ -811,7 +819,10 @@ int launch_fprop(FpropArgs& a, hipStream_t stream) {
     if (gm > a.MT) gm = a.MT;
     a.GM = gm;
     const int grid = a.GM * a.NTL;
-    hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), smem, stream, a);
+    if (a.ep_act >= 0)
+        hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, true>), dim3(grid), dim3(NT), smem, stream, a);
+    else
+        hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), smem, stream, a);
     return 0;
 }
 

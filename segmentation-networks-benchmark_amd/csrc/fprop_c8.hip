@@ -61,7 +61,7 @@ __device__ __forceinline__ uint4 c8_norm_pixel(const C8Norm& u, long long pix) {
     return o;
 }
 
-template <bool U8>
+template <bool U8, bool EP = false>      // EP: affine + activation epilogue, a separate instantiation (see conv_fprop_ws_kernel)
 __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[C8_SMEM];
     int* sPix = reinterpret_cast<int*>(smem + C8_OFF_PIX);
@@ -87,19 +87,24 @@ __global__ __launch_bounds__(256) void conv_fprop_c8_kernel(const C8Args a) {
             const int c = 8 * g + 4 * h + e;
             b[e] = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
             sc[e] = 1.f;
-            if (a.ep_act >= 0 && a.ep_coef != nullptr && c < a.Co) {
-                sc[e] = a.ep_coef[c];
-                b[e] = (b[e] - a.ep_coef[2 * a.Co + c]) * sc[e] + a.ep_coef[a.Co + c];
+            if constexpr (EP) {
+                if (a.ep_coef != nullptr && c < a.Co) {
+                    sc[e] = a.ep_coef[c];
+                    b[e] = (b[e] - a.ep_coef[2 * a.Co + c]) * sc[e] + a.ep_coef[a.Co + c];
+                }
             }
         }
         bias4[g] = make_float4(b[0], b[1], b[2], b[3]);
         scale4[g] = make_float4(sc[0], sc[1], sc[2], sc[3]);
     }
-    const bool ep_on = a.ep_act >= 0;
     const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
     auto ep = [&](float acc, float sc, float sh) {
-        const float v = ep_on ? acc * sc + sh : acc + sh;
-        return (ep_on && v < 0.f) ? v * ep_neg + 0.f : v;
+        if constexpr (EP) {
+            const float v = acc * sc + sh;
+            return v < 0.f ? v * ep_neg + 0.f : v;
+        } else {
+            return acc + sh;
+        }
     };
     // A fragment LDS offsets: wave w owns tile rows 64w .. 64w+63 (two MFMA row tiles)
     int a_off[5][2];
@@ -280,10 +285,14 @@ static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8,
     a.IT = a.N * a.HB * a.WB;
     int grid = segnb_num_cus() * 4;          // 32 KiB of LDS per block: four blocks per CU hide each other's latencies
     if (grid > a.IT) grid = a.IT;
-    if (u8 != nullptr)
-        hipLaunchKernelGGL(conv_fprop_c8_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    if (u8 != nullptr && a.ep_act >= 0)
+        hipLaunchKernelGGL((conv_fprop_c8_kernel<true, true>), dim3(grid), dim3(256), 0, stream, a);
+    else if (u8 != nullptr)
+        hipLaunchKernelGGL((conv_fprop_c8_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a);
+    else if (a.ep_act >= 0)
+        hipLaunchKernelGGL((conv_fprop_c8_kernel<false, true>), dim3(grid), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(conv_fprop_c8_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_fprop_c8_kernel<false, false>), dim3(grid), dim3(256), 0, stream, a);
     return 1;
 }
 

@@ -50,7 +50,7 @@ struct RwCfg {
     static_assert(W_MAX >= 9 * BN * 64, "at least one 32-channel chunk of weights");
 };
 
-template <class C, bool DBG>
+template <class C, bool DBG, bool EP = false>      // EP: see conv_fprop_ws_kernel
 __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
     constexpr int BN = C::BN, NS = C::NS, BM = C::BM, TM = C::TM, TN = C::TN, NF = C::NF, XC = C::XC, R = C::R, WT = C::WT;
     constexpr int APW = C::APW, OC = C::OC, NLW = C::NLW, LT = C::LT, OUT_ROW = C::OUT_ROW;
@@ -76,18 +76,23 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
     for (int c = tid; c < BN; c += C::NT) {
         const float bv = (a.bias != nullptr && c < a.bias_n) ? a.bias[c] : 0.f;
         float sc = 1.f, sh = bv;
-        if (a.ep_act >= 0 && a.ep_coef != nullptr && c < a.Co) {      // (acc + bias - mean) * scale + shift
-            sc = a.ep_coef[c];
-            sh = (bv - a.ep_coef[2 * a.Co + c]) * sc + a.ep_coef[a.Co + c];
+        if constexpr (EP) {
+            if (a.ep_coef != nullptr && c < a.Co) {      // (acc + bias - mean) * scale + shift
+                sc = a.ep_coef[c];
+                sh = (bv - a.ep_coef[2 * a.Co + c]) * sc + a.ep_coef[a.Co + c];
+            }
+            sScale[c] = sc;
         }
         sBias[c] = sh;
-        sScale[c] = sc;
     }
-    const bool ep_on = a.ep_act >= 0;
     const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
     auto ep = [&](float acc, float sc, float sh) {
-        const float v = ep_on ? acc * sc + sh : acc + sh;
-        return (ep_on && v < 0.f) ? v * ep_neg + 0.f : v;
+        if constexpr (EP) {
+            const float v = acc * sc + sh;
+            return v < 0.f ? v * ep_neg + 0.f : v;
+        } else {
+            return acc + sh;
+        }
     };
 
     if (fetcher) {
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const int col = 32 * j + 8 * q + 4 * h;
                         const float4 bv4 = *reinterpret_cast<const float4*>(sBias + col);
-                        const float4 sv4 = *reinterpret_cast<const float4*>(sScale + col);
+                        float4 sv4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if constexpr (EP) sv4 = *reinterpret_cast<const float4*>(sScale + col);
                         uint2 pk;
                         pk.x = pack2bf(ep(acc[i][j][4 * q + 0], sv4.x, bv4.x), ep(acc[i][j][4 * q + 1], sv4.y, bv4.y));
                         pk.y = pack2bf(ep(acc[i][j][4 * q + 2], sv4.z, bv4.z), ep(acc[i][j][4 * q + 3], sv4.w, bv4.w));
@@ -432,6 +438,9 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_rw_kernel<C, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_rw_kernel<C, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) segnb_set_error("fprop_rw hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }();
@@ -444,7 +453,9 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
     int gm = segnb_knob_conv_cus();
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    if (a.dbg)       // timing builds: separately instantiated, the production kernel carries no run-time checks
+    if (a.ep_act >= 0)
+        hipLaunchKernelGGL((conv_fprop_rw_kernel<C, false, true>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
+    else if (a.dbg)       // timing builds: separately instantiated, the production kernel carries no run-time checks
         hipLaunchKernelGGL((conv_fprop_rw_kernel<C, true>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
     else
         hipLaunchKernelGGL((conv_fprop_rw_kernel<C, false>), dim3(a.GM), dim3(C::NT), C::SMEM, stream, a);
