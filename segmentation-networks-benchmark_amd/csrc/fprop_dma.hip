@@ -105,7 +105,9 @@ struct WsCfg {
 
 // EP: the affine + activation epilogue (segnb_conv_fprop_act) is a SEPARATE instantiation: as run-time checks in the staging
 // code of the training kernels it cost 0.22 ms per step (5.62 vs 5.40 ms, same box)
-template <class C, bool DBG, bool EP = false>
+// STATS: BatchNorm statistics in the store rows (forward launches) -- data gradients take none and run the instantiation
+// without the 16 accumulator registers and ~32 VALU per stored row
+template <class C, bool DBG, bool EP = false, bool STATS = true>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
     constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             const bool ok = cok && opix >= 0;
             const unsigned voff = ok ? (unsigned)opix * (unsigned)a.ld_out * 2u + (unsigned)(n_base + cc * 8) * 2u : OOB;
             if (!(DBG && (a.dbg & 8))) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
-            if (a.stats != nullptr) {
+            if constexpr (STATS) {
                 const float m = ok ? 1.f : 0.f;
                 float f[8];
                 f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         }
         // ---- statistics: fixed-order block reduction, one fp64 atomic per channel and block ----------------------
         lds_barrier();                                         // (fetch waves: everything has landed; staging consumed)
-        if (a.stats != nullptr) {
+        if constexpr (STATS) {
             double* red = reinterpret_cast<double*>(smem);     // [MT][16]
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             }
         }
         lds_barrier();
-        if (a.stats != nullptr && tid < 2 * BN) {
+        if (STATS && a.stats != nullptr && tid < 2 * BN) {
             const double* red = reinterpret_cast<const double*>(smem);
             const int which = tid / BN, col = tid - which * BN;
             const int c8 = col >> 3, e = col & 7;
@@ -710,7 +712,10 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -729,8 +734,10 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    if (a.ep_act >= 0)
-        hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    if (a.ep_act >= 0)            // (never with statistics: segnb_conv_fprop_act takes none)
+        hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, true, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    else if (a.stats == nullptr && !a.dbg && segnb_knob_fprop_nostats())
+        hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     else if (a.dbg)
         hipLaunchKernelGGL((conv_fprop_ws_kernel<C, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     else

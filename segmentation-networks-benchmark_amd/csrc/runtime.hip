@@ -69,6 +69,14 @@ int segnb_knob_fprop_mf16() {
     }
     return g_fprop_mf16;
 }
+static int g_fprop_nostats = -2;    // conv_fprop_ws_kernel: statistics-free instantiation for launches without statistics (A/B)
+int segnb_knob_fprop_nostats() {
+    if (g_fprop_nostats == -2) {
+        const char* e = getenv("SEGNB_FPROP_NOSTATS");
+        g_fprop_nostats = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_nostats;
+}
 static int g_rw_store_waves = -2;   // store waves of conv_fprop_rw_kernel: 4 (default) or 2 (round 1)
 int segnb_knob_rw_store_waves() {
     if (g_rw_store_waves == -2) {
@@ -107,6 +115,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
         g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "fprop_nostats") == 0) {
+        g_fprop_nostats = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "rw_store_waves") == 0) {

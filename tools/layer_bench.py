@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--rw', type=int, default=None, help='segnb_tune fprop_rw (0/1)')
     ap.add_argument('--mf16', type=int, default=None, help='segnb_tune fprop_mf16 (0/1)')
     ap.add_argument('--rwsw', type=int, default=None, help='segnb_tune rw_store_waves (2/4)')
+    ap.add_argument('--nostats', type=int, default=None, help='segnb_tune fprop_nostats (0/1)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     ap.add_argument('--wgrad-unpack', type=int, default=0,
                     help='1: time the per-layer unpack (packed fp32 workspace -> parameter-layout gradient) with the '
@@ -43,6 +44,8 @@ def main():
         nv.call('segnb_tune', b'fprop_dma', args.dma)
     if args.dbg is not None:
         nv.call('segnb_tune', b'fprop_dma_dbg', args.dbg)
+    if args.nostats is not None:
+        nv.call('segnb_tune', b'fprop_nostats', args.nostats)
     if args.rwsw is not None:
         nv.call('segnb_tune', b'rw_store_waves', args.rwsw)
     if args.mf16 is not None:
