@@ -379,6 +379,23 @@ int segnb_rmsprop_step(float* p, const float* g, float* square_avg, long long n,
 int segnb_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                     float beta1, float beta2, float eps, int step, segnb_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch plans: the launch list of a model's forward (or backward) replayed from C.  The reference drives its step from
+ * Python one torch operator at a time (torch_train.py:183-190); this path's ~300 launches per step cost the Python
+ * launcher 10-14 us each, which bounds small-batch steps.  Between segnb_plan_begin and segnb_plan_end every top-level
+ * entry point called on this thread records itself (pointer arguments by value, host structs copied) and executes
+ * normally; segnb_plan_run replays the list with the same pointers -- the caller keeps the buffers alive and unchanged in
+ * place.  Entry points that read HOST arrays (segnb_pack_weight, segnb_unpack_wgrad, the uint8 input functions) and
+ * segnb_tune make the plan unusable: segnb_plan_end then returns *plan_out = NULL.
+ * segnb_stream_fork / _join: `side` waits for what has been issued on `main` / `main` waits for `side` (events).
+ * ------------------------------------------------------------------------------------------- */
+int segnb_plan_begin(void);
+int segnb_plan_end(void** plan_out, int* nops);
+int segnb_plan_run(void* plan);
+int segnb_plan_destroy(void* plan);
+int segnb_stream_fork(segnb_stream_t main_stream, segnb_stream_t side_stream);
+int segnb_stream_join(segnb_stream_t main_stream, segnb_stream_t side_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -686,6 +686,12 @@ class AbiEmulator(object):
         H[1] += torch.bincount(b[t], minlength=nthr + 1)
         return 0
 
+    def segnb_stream_fork(self, main, side):
+        return 0
+
+    def segnb_stream_join(self, main, side):
+        return 0
+
     def segnb_tune(self, key, value):
         """kernel-selection knobs have no meaning on the CPU restatement"""
         return 0

@@ -36,6 +36,51 @@ void segnb_set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// launch plans (runtime.hip: segnb_plan_begin / _end / _run): while a plan is being recorded on this thread every
+// top-level C-ABI call appends itself -- function pointer + its arguments, host structs copied into the plan -- and then
+// executes as usual; segnb_plan_run replays the list from C (the Python launcher needs 10-14 us per launch).
+// ------------------------------------------------------------------------------------------------
+#include <functional>
+#include <tuple>
+bool segnb_plan_recording();
+void segnb_plan_push(std::function<int()> op, const char* name);
+const void* segnb_plan_dup(const void* p, size_t bytes);
+struct SegnbPlanScope {          // nested entry points (conv_wgrad_partial -> conv_wgrad) record once, at the top
+    bool top;
+    SegnbPlanScope();
+    ~SegnbPlanScope();
+};
+template <class T>
+inline T segnb_plan_keep(T v) { return v; }
+inline const segnb_conv_geom* segnb_plan_keep(const segnb_conv_geom* g) {
+    return g ? (const segnb_conv_geom*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
+inline const segnb_loss_spec* segnb_plan_keep(const segnb_loss_spec* g) {
+    return g ? (const segnb_loss_spec*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
+inline const segnb_bn_reduce_epilogue* segnb_plan_keep(const segnb_bn_reduce_epilogue* g) {
+    return g ? (const segnb_bn_reduce_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
+inline const segnb_act_epilogue* segnb_plan_keep(const segnb_act_epilogue* g) {
+    return g ? (const segnb_act_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
+template <class... P, class... A>
+inline void segnb_plan_record_call(const char* name, int (*fn)(P...), A... args) {
+    static_assert(sizeof...(P) == sizeof...(A), "argument count");
+    std::tuple<P...> kept(segnb_plan_keep((P)args)...);
+    segnb_plan_push([fn, kept]() { return std::apply(fn, kept); }, name);
+}
+// first statement of a recordable extern "C" entry point (entry points that take HOST arrays -- tap offsets, mean / std --
+// are not recordable: SEGNB_PLAN_REFUSE marks the plan being recorded as unusable)
+#define SEGNB_PLAN_RECORD(fn, ...)                                                           \
+    SegnbPlanScope plan_scope__;                                                             \
+    if (plan_scope__.top && segnb_plan_recording()) segnb_plan_record_call(#fn, fn, __VA_ARGS__)
+void segnb_plan_refuse(const char* why);
+#define SEGNB_PLAN_REFUSE(why)                                         \
+    SegnbPlanScope plan_scope__;                                       \
+    if (plan_scope__.top && segnb_plan_recording()) segnb_plan_refuse(why)
+
 int segnb_num_cus();
 int segnb_knob_fprop_dma();       // runtime.hip: segnb_tune() knobs
 int segnb_knob_fprop_dma_cfg();

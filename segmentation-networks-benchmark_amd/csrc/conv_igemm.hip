@@ -899,12 +899,14 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
 extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                 const float* bias, int bias_n, void* out, double* stats,
                                 segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop, g, dtype, in, wpacked, bias, bias_n, out, stats, stream);
     return conv_fprop_impl(g, dtype, in, wpacked, bias, bias_n, out, stats, stream, nullptr);
 }
 
 extern "C" int segnb_conv_fprop_act(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                     const float* bias, int bias_n, void* out, const segnb_act_epilogue* ep,
                                     segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_act, g, dtype, in, wpacked, bias, bias_n, out, ep, stream);
     SEGNB_CHECK_ARG(ep != nullptr && ep->act >= SEGNB_ACT_NONE && ep->act <= SEGNB_ACT_LEAKY, "bad epilogue");
     return conv_fprop_impl(g, dtype, in, wpacked, bias, bias_n, out, nullptr, stream, ep);
 }
@@ -980,6 +982,7 @@ extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype)
 
 extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                          void* out, const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_bnreduce, g, dtype, in, wpacked, out, ep, stream);
     if (int rc = check_geom(g)) return rc;
     SEGNB_CHECK_ARG(in && wpacked && out && ep && ep->y && ep->coef && ep->sums, "NULL argument");
     SEGNB_CHECK_ARG(segnb_conv_fprop_bnreduce_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_bnreduce_ok)");
@@ -1015,6 +1018,7 @@ extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
 
 extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                                 float* dwp, int nslab, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_wgrad, g, dtype, in, dout, dwp, nslab, stream);
     if (int rc = check_geom(g)) return rc;
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
@@ -1048,6 +1052,7 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
 
 extern "C" int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                                         float* dwp, int nslab, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_wgrad_partial, g, dtype, in, dout, dwp, nslab, stream);
     g_wgrad_partial = true;
     const int rc = segnb_conv_wgrad(g, dtype, in, dout, dwp, nslab, stream);
     g_wgrad_partial = false;
@@ -1072,6 +1077,7 @@ static int fill_pack_args(PackArgs& p, int Mp, int Cp, int ntaps, long long s_m,
 extern "C" int segnb_pack_weight(const float* w, void* wpacked, int dtype, int Mp, int Cp, int ntaps,
                                  long long s_m, long long s_c, const int* tap_off_host, const int* mmap,
                                  const int* cmap, segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_pack_weight takes a host tap table");
     SEGNB_CHECK_ARG(w && wpacked, "NULL tensor");
     PackArgs p;
     if (int rc = fill_pack_args(p, Mp, Cp, ntaps, s_m, s_c, tap_off_host, mmap, cmap)) return rc;
@@ -1095,6 +1101,7 @@ extern "C" int segnb_pack_weight(const float* w, void* wpacked, int dtype, int M
 extern "C" int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long long s_m,
                                   long long s_c, const int* tap_off_host, const int* mmap, const int* cmap,
                                   int accumulate, segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_unpack_wgrad takes a host tap table");
     SEGNB_CHECK_ARG(dwp && gw, "NULL tensor");
     PackArgs p;
     if (int rc = fill_pack_args(p, Mp, Cp, ntaps, s_m, s_c, tap_off_host, mmap, cmap)) return rc;
@@ -1120,6 +1127,7 @@ extern "C" int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, l
 }
 
 extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_pack_weight_multi, jobs, njobs, total_blocks, stream);
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
     hipLaunchKernelGGL(pack_tiled_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs);
@@ -1128,6 +1136,7 @@ extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_bl
 }
 
 extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_unpack_wgrad_multi, jobs, njobs, total_blocks, stream);
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
     hipLaunchKernelGGL(pack_tiled_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs);
@@ -1137,6 +1146,7 @@ extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_b
 
 extern "C" int segnb_pack_input_nchw(const float* x, int N, int C, int H, int W, void* out, int dtype, int Cp,
                                      int ld_out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_pack_input_nchw, x, N, C, H, W, out, dtype, Cp, ld_out, stream);
     SEGNB_CHECK_ARG(x && out, "NULL tensor");
     SEGNB_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C && ld_out >= Cp && ld_out % 8 == 0,
                     "bad shape");

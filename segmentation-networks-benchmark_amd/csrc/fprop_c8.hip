@@ -334,6 +334,7 @@ int fill_norm(C8Norm& u, const unsigned char* img, int C, float scale, const flo
 
 extern "C" int segnb_pack_input_u8(const unsigned char* img, int N, int H, int W, int C, float scale, const float* mean,
                                    const float* stdv, void* out, int dtype, int Cp, int ld_out, segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_pack_input_u8 takes host mean / std arrays");
     C8Norm u;
     SEGNB_CHECK_ARG(fill_norm(u, img, C, scale, mean, stdv) == 0, "bad normalisation (1 <= C <= 8, std != 0)");
     SEGNB_CHECK_ARG(out && N > 0 && H > 0 && W > 0 && Cp % 8 == 0 && Cp >= C && ld_out >= Cp && ld_out % 8 == 0, "bad shape");
@@ -366,6 +367,7 @@ extern "C" int segnb_conv_fprop_u8_ok(const segnb_conv_geom* g, int dtype) {
 extern "C" int segnb_conv_fprop_u8(const segnb_conv_geom* g, const unsigned char* img, int C, float scale, const float* mean,
                                    const float* stdv, const void* wpacked, const float* bias, int bias_n, void* out,
                                    double* stats, void* x_packed, int ld_packed, segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_conv_fprop_u8 takes host mean / std arrays");
     SEGNB_CHECK_ARG(g && wpacked && out, "NULL argument");
     SEGNB_CHECK_ARG(segnb_conv_fprop_u8_ok(g, SEGNB_BF16), "geometry not served by the uint8 first-layer kernel (segnb_conv_fprop_u8_ok)");
     C8Norm u;

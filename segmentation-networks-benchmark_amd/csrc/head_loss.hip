@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void pr_hist_kernel(const float* __restrict__ 
 
 extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, const float* w,
                               const float* bias, int K, float* logits, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_fwd, dtype, a, ld_a, N, H, W, C, w, bias, K, logits, stream);
     SEGNB_CHECK_ARG(a && w && logits, "NULL tensor");
     SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
     SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ld_a % 8 == 0 && ld_a >= ((C + 7) & ~7), "bad shape");
@@ -369,6 +370,7 @@ extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, 
 extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
                               const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                               float* db, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_bwd, dtype, a, ld_a, N, H, W, C, Cp, w, K, dlogits, da, ld_da, dw, db, stream);
     SEGNB_CHECK_ARG(a && w && dlogits, "NULL tensor");
     SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
     SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Cp % 8 == 0 && Cp >= C, "bad shape");
@@ -399,6 +401,7 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
 
 extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* target, long long n, float focal_gamma,
                                      double* sums, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_reduce, logits, target, n, focal_gamma, sums, stream);
     SEGNB_CHECK_ARG(logits && target && sums && n > 0, "bad arguments");
     // few blocks: every block ends in six double atomics on the SAME six addresses (1568 blocks = 9.4 k serialised
     // atomics were most of the 27 us)
@@ -412,6 +415,7 @@ extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* targe
 
 extern "C" int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, float* out,
                                        segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_finalize, sums, spec, out, stream);
     SEGNB_CHECK_ARG(sums && spec && out, "bad arguments");
     SEGNB_CHECK_ARG(spec->norm != 0.f, "loss norm must be non-zero");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, *spec, out);
@@ -422,6 +426,7 @@ extern "C" int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec
 extern "C" int segnb_seg_loss_bwd(const float* logits, const long long* target, long long n,
                                   const double* sums, const float* fin, const segnb_loss_spec* spec,
                                   const float* grad_out, float* dlogits, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_bwd, logits, target, n, sums, fin, spec, grad_out, dlogits, stream);
     (void)sums;
     SEGNB_CHECK_ARG(logits && target && fin && spec && dlogits && n > 0, "bad arguments");
     int grid = ceil_div(n, 256 * 4);
@@ -435,6 +440,7 @@ extern "C" int segnb_seg_loss_bwd(const float* logits, const long long* target, 
 
 extern "C" int segnb_seg_loss_map(const float* logits, const long long* target, long long n, int kind, float gamma,
                                   float* out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_map, logits, target, n, kind, gamma, out, stream);
     SEGNB_CHECK_ARG(logits && target && out && n > 0 && (kind == 0 || kind == 1), "bad arguments");
     int grid = ceil_div(n, 256);
     if (grid > 4096) grid = 4096;
@@ -445,6 +451,7 @@ extern "C" int segnb_seg_loss_map(const float* logits, const long long* target, 
 
 extern "C" int segnb_seg_loss_map_bwd(const float* logits, const long long* target, long long n, int kind, float gamma,
                                       const float* grad_out, float* dlogits, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_map_bwd, logits, target, n, kind, gamma, grad_out, dlogits, stream);
     SEGNB_CHECK_ARG(logits && target && grad_out && dlogits && n > 0 && (kind == 0 || kind == 1), "bad arguments");
     int grid = ceil_div(n, 256);
     if (grid > 4096) grid = 4096;
@@ -455,6 +462,7 @@ extern "C" int segnb_seg_loss_map_bwd(const float* logits, const long long* targ
 }
 
 extern "C" int segnb_absmax_f32(const float* x, long long n, float* out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_absmax_f32, x, n, out, stream);
     SEGNB_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0, "bad arguments");
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) {
@@ -470,6 +478,7 @@ extern "C" int segnb_absmax_f32(const float* x, long long n, float* out, segnb_s
 
 extern "C" int segnb_pr_histogram(const float* logits, const long long* target, long long n, const float* thresholds,
                                   int nthr, unsigned long long* hist, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_pr_histogram, logits, target, n, thresholds, nthr, hist, stream);
     SEGNB_CHECK_ARG(logits && target && thresholds && hist && n > 0 && nthr > 0 && nthr <= 4096, "bad arguments");
     int grid = ceil_div(n, 256 * 8);
     if (grid > 1024) grid = 1024;

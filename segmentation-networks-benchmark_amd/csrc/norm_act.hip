@@ -899,6 +899,7 @@ extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, con
                                  const float* beta, float eps, float momentum, float* running_mean,
                                  float* running_var, long long* nbt, int training, float* coef,
                                  segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_finalize, stats, C, Cp, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, training, coef, stream);
     SEGNB_CHECK_ARG(coef != nullptr && C > 0 && Cp >= C && Cp % 8 == 0, "bad channel counts");
     SEGNB_CHECK_ARG(training ? stats != nullptr : (running_mean != nullptr && running_var != nullptr),
                     "missing statistics source");
@@ -917,6 +918,7 @@ extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H
                                 const float* coef, int act, float slope, const float* dropmul, void* out,
                                 int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up, const void* res,
                                 int ld_res, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_act_fwd, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, pool_out, ld_pool, up_out, ld_up, res, ld_res, stream);
     BnFwdParams fp = {};
     return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, pool_out, ld_pool,
                              up_out, ld_up, res, ld_res, fp, "segnb_bn_act_fwd", stream);
@@ -928,6 +930,7 @@ extern "C" int segnb_bn_fwd_fused(int dtype, const void* y, int ld_y, int N, int
                                   float* coef, double* bwd_sums_to_clear, int act, float slope, const float* dropmul,
                                   void* out, int ld_out, void* pool_out, int ld_pool, void* up_out, int ld_up,
                                   const void* res, int ld_res, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_fwd_fused, dtype, y, ld_y, N, H, W, C, Cp, stats, gamma, beta, eps, momentum, running_mean, running_var, nbt, coef, bwd_sums_to_clear, act, slope, dropmul, out, ld_out, pool_out, ld_pool, up_out, ld_up, res, ld_res, stream);
     SEGNB_CHECK_ARG(stats != nullptr && coef != nullptr && C > 0 && Cp >= C, "missing statistics / coefficient buffer");
     BnFwdParams fp = {stats, (double)N * H * W, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, 1, coef,
                       bwd_sums_to_clear};
@@ -966,6 +969,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
                                        const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
                                        const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
                                        const void* res, int ld_res, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_act_bwd_reduce, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd, g_pool, ld_gp, g_up, ld_gu, dz, ld_dz, sums, res, ld_res, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr, "NULL tensor");
     SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
@@ -1008,6 +1012,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
 extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,
                                      const float* coef, float* bcoef, float* dgamma, float* dbeta,
                                      int accumulate, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_finalize, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream);
     SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
     BnBwdParams bp = {sums, count, gamma, dgamma, dbeta, C, accumulate, bcoef, nullptr};
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, bp, coef, Cp);
@@ -1042,6 +1047,7 @@ static int launch_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H,
 extern "C" int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                   const float* coef, const float* bcoef, const void* dz, int ld_dz, void* dy,
                                   int ld_dy, float* dbias, int C, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, stream);
     BnBwdParams bp = {};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, bp,
                                "segnb_bn_bwd_apply", stream);
@@ -1050,6 +1056,7 @@ extern "C" int segnb_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int
 extern "C" int segnb_bn_bwd_apply_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                          const float* coef, const float* bcoef, int act, float slope, const void* g,
                                          int ld_g, void* dy, int ld_dy, float* dbias, int C, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_direct, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy, ld_dy, dbias, C, stream);
     SEGNB_CHECK_ARG(g != nullptr, "NULL gradient");
     BnBwdParams bp = {};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, nullptr, 0, dy, ld_dy, dbias, C, bp,
@@ -1060,6 +1067,7 @@ extern "C" int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int 
                                         const float* coef, const double* sums, const float* gamma, float* bcoef,
                                         float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
                                         const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_fused, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, dz, ld_dz, dy, ld_dy, stream);
     SEGNB_CHECK_ARG(sums != nullptr && bcoef != nullptr && C > 0 && Cp >= C, "missing sums / coefficient buffer");
     BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, dz, ld_dz, dy, ld_dy, nullptr, C, bp,
@@ -1071,6 +1079,7 @@ extern "C" int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_
                                                float* bcoef, float* dgamma, float* dbeta, int accumulate,
                                                double* fwd_stats_to_clear, int act, float slope, const void* g,
                                                int ld_g, void* dy, int ld_dy, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_fused_direct, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, act, slope, g, ld_g, dy, ld_dy, stream);
     SEGNB_CHECK_ARG(sums != nullptr && bcoef != nullptr && C > 0 && Cp >= C, "missing sums / coefficient buffer");
     SEGNB_CHECK_ARG(g != nullptr, "NULL gradient");
     BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
@@ -1107,6 +1116,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" int segnb_rmsprop_step(float* p, const float* g, float* square_avg, long long n, float lr, float alpha,
                                   float eps, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_rmsprop_step, p, g, square_avg, n, lr, alpha, eps, stream);
     SEGNB_CHECK_ARG(p && g && square_avg && n > 0, "bad arguments");
     int grid = ceil_div(n, 256);
     if (grid > 4096) grid = 4096;
@@ -1117,6 +1127,7 @@ extern "C" int segnb_rmsprop_step(float* p, const float* g, float* square_avg, l
 
 extern "C" int segnb_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                                float beta1, float beta2, float eps, int step, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_adam_step, p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, stream);
     SEGNB_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     int grid = ceil_div(n, 256);
@@ -1128,6 +1139,7 @@ extern "C" int segnb_adam_step(float* p, const float* g, float* exp_avg, float* 
 }
 
 extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_sgd_step, p, g, n, lr, stream);
     SEGNB_CHECK_ARG(p && g && n > 0, "bad arguments");
     SEGNB_CHECK_ARG((((uintptr_t)p | (uintptr_t)g) & 15) == 0, "buffers must be 16-byte aligned");
     int grid = ceil_div(n / 4 + 1, 256);
@@ -1149,6 +1161,7 @@ extern "C" int segnb_sgd_step(float* p, const float* g, long long n, float lr, s
 
 extern "C" int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,
                          int H, int W, int Cp, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_add, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(a && b && out, "NULL tensor");
     const long long npix = (long long)N * H * W;
@@ -1166,6 +1179,7 @@ extern "C" int segnb_add(int dtype, const void* a, int ld_a, const void* b, int 
 
 extern "C" int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats,
                               segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_stats, dtype, x, ld, N, H, W, Cp, stats, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(x && stats, "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
@@ -1180,6 +1194,7 @@ extern "C" int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, in
 
 extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
                                  int pad, void* out, int ld_out, unsigned char* idx, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_maxpool_fwd, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, idx, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(x && out && k >= 1 && stride >= 1 && pad >= 0 && pad < k, "bad pooling arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -1199,6 +1214,7 @@ extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int 
 extern "C" int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
                                  int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
                                  segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_maxpool_bwd, dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(x && g_out && dx && k >= 1 && stride >= 1 && pad >= 0 && pad < k && k * k < 255, "bad pooling arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -1226,6 +1242,7 @@ extern "C" int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void*
 
 extern "C" int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
                                       segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_nhwc_to_nchw_f32, dtype, a, ld, N, H, W, C, out, stream);
     SEGNB_CHECK_ARG(a && out && N > 0 && H > 0 && W > 0 && C > 0 && ld >= C, "bad arguments");
     int grid = ceil_div((long long)N * C * H * W, 256);
     if (grid > 8192) grid = 8192;

@@ -34,6 +34,145 @@ extern "C" int segnb_device_cus(void) {
     return segnb_num_cus();
 }
 
+// ---- launch plans ---------------------------------------------------------------------------------------------------
+#include <memory>
+#include <vector>
+namespace {
+struct Plan {
+    std::vector<std::function<int()>> ops;
+    std::vector<const char*> names;
+    std::vector<std::unique_ptr<unsigned char[]>> arena;
+    bool refused = false;
+    char why[128] = "";
+};
+thread_local Plan* g_rec = nullptr;
+thread_local int g_depth = 0;
+}  // namespace
+
+bool segnb_plan_recording() { return g_rec != nullptr; }
+void segnb_plan_push(std::function<int()> op, const char* name) {
+    g_rec->ops.push_back(std::move(op));
+    g_rec->names.push_back(name);
+}
+const void* segnb_plan_dup(const void* p, size_t bytes) {
+    g_rec->arena.emplace_back(new unsigned char[bytes]);
+    memcpy(g_rec->arena.back().get(), p, bytes);
+    return g_rec->arena.back().get();
+}
+void segnb_plan_refuse(const char* why) {
+    g_rec->refused = true;
+    snprintf(g_rec->why, sizeof(g_rec->why), "%s", why);
+}
+SegnbPlanScope::SegnbPlanScope() : top(g_depth == 0) { ++g_depth; }
+SegnbPlanScope::~SegnbPlanScope() { --g_depth; }
+
+// segnb_tune("plan_profile", 1): segnb_plan_run times every replayed call on the host (per entry point); ("plan_profile", 2)
+// prints the table to stderr and clears it; 0 = off
+#include <chrono>
+#include <map>
+#include <string>
+namespace {
+int g_plan_profile = 0;
+std::map<std::string, std::pair<long, double>> g_plan_prof;
+int plan_run_profiled(Plan* p) {
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = p->ops[i]();
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        auto& e = g_plan_prof[p->names[i]];
+        e.first += 1;
+        e.second += us;
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+void plan_profile_dump() {
+    double tot = 0;
+    long n = 0;
+    for (auto& kv : g_plan_prof) {
+        fprintf(stderr, "plan_profile %-34s %7ld calls %9.1f us  %6.2f us/call\n", kv.first.c_str(), kv.second.first,
+                kv.second.second, kv.second.second / kv.second.first);
+        tot += kv.second.second;
+        n += kv.second.first;
+    }
+    fprintf(stderr, "plan_profile %-34s %7ld calls %9.1f us  %6.2f us/call\n", "total", n, tot, n ? tot / n : 0.0);
+    g_plan_prof.clear();
+}
+}  // namespace
+
+extern "C" int segnb_plan_begin(void) {
+    delete g_rec;            // (a recording abandoned by an exception on the host side)
+    g_rec = new Plan();
+    return 0;
+}
+
+// *plan_out = the recorded plan, or NULL when a call that cannot be replayed was made while recording (segnb_last_error says
+// which); *nops = number of recorded launches
+extern "C" int segnb_plan_end(void** plan_out, int* nops) {
+    SEGNB_CHECK_ARG(g_rec != nullptr && plan_out != nullptr, "no plan is being recorded");
+    Plan* p = g_rec;
+    g_rec = nullptr;
+    if (nops != nullptr) *nops = (int)p->ops.size();
+    if (p->refused) {
+        segnb_set_error("segnb_plan_end: not replayable: %s", p->why);
+        delete p;
+        *plan_out = nullptr;
+        return 0;
+    }
+    *plan_out = p;
+    return 0;
+}
+
+extern "C" int segnb_plan_run(void* plan) {
+    SEGNB_CHECK_ARG(plan != nullptr && g_rec == nullptr, "NULL plan, or a plan is being recorded");
+    Plan* p = (Plan*)plan;
+    if (g_plan_profile) return plan_run_profiled(p);
+    for (auto& op : p->ops) {
+        const int rc = op();
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+extern "C" int segnb_plan_destroy(void* plan) {
+    delete (Plan*)plan;
+    return 0;
+}
+
+// `side` waits for everything issued so far on `main` (fork) / `main` waits for `side` (join): what the two-stream backward
+// needs, as recordable entry points (events from a small ring: an event may be re-recorded once its wait has been issued)
+namespace {
+hipEvent_t next_event() {
+    static thread_local hipEvent_t ring[64];
+    static thread_local int n = 0, made = 0;
+    if (made < 64) {
+        if (hipEventCreateWithFlags(&ring[made], hipEventDisableTiming) != hipSuccess) return nullptr;
+        ++made;
+        return ring[made - 1];
+    }
+    n = (n + 1) & 63;
+    return ring[n];
+}
+int wait_on(hipStream_t waiter, hipStream_t signaller, const char* who) {
+    hipEvent_t ev = next_event();
+    hipError_t e = ev == nullptr ? hipErrorOutOfMemory : hipEventRecord(ev, signaller);
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+    if (e != hipSuccess) {
+        segnb_set_error("%s: %s", who, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+}  // namespace
+extern "C" int segnb_stream_fork(segnb_stream_t main_stream, segnb_stream_t side_stream) {
+    SEGNB_PLAN_RECORD(segnb_stream_fork, main_stream, side_stream);
+    return wait_on((hipStream_t)side_stream, (hipStream_t)main_stream, "segnb_stream_fork");
+}
+extern "C" int segnb_stream_join(segnb_stream_t main_stream, segnb_stream_t side_stream) {
+    SEGNB_PLAN_RECORD(segnb_stream_join, main_stream, side_stream);
+    return wait_on((hipStream_t)main_stream, (hipStream_t)side_stream, "segnb_stream_join");
+}
+
 // ---- tuning knobs (A/B measurements and tests; defaults come from the environment once) ------------------------
 static int g_fprop_dma = -2;       // -2 = not initialised, 0 = off, 1 = on
 static int g_fprop_dma_cfg = -2;   // -1 = automatic, >= 0 forced configuration
@@ -96,6 +235,7 @@ int segnb_knob_bnreduce_fused() {
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 extern "C" int segnb_tune(const char* key, int value) {
+    SEGNB_PLAN_REFUSE("segnb_tune inside a recorded plan");
     SEGNB_CHECK_ARG(key != nullptr, "NULL key");
     if (strcmp(key, "fprop_dma") == 0) {
         g_fprop_dma = value ? 1 : 0;
@@ -111,6 +251,11 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "conv_cu_pct") == 0) {        // CUs the persistent convolution kernels size their grids for (%)
         g_conv_cu_pct = value < 10 ? 10 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "plan_profile") == 0) {
+        if (value == 2) plan_profile_dump();
+        else g_plan_profile = value;
         return 0;
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)

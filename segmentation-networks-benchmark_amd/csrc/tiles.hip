@@ -104,6 +104,7 @@ __global__ void tiles_merge_kernel(const float* __restrict__ logits, int K, int 
 extern "C" int segnb_tiles_gather(const float* image, int H, int W, int C, int margin_top, int margin_left,
                                   const int* crops_xy, int first_item, int count, int S, float* out,
                                   segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_tiles_gather, image, H, W, C, margin_top, margin_left, crops_xy, first_item, count, S, out, stream);
     SEGNB_CHECK_ARG(image && crops_xy && out && H > 1 && W > 1 && C > 0 && S > 0 && count > 0 && first_item >= 0,
                     "bad arguments");
     const long long total = (long long)count * C * S * S;
@@ -118,6 +119,7 @@ extern "C" int segnb_tiles_gather(const float* image, int H, int W, int C, int m
 extern "C" int segnb_tiles_merge(const float* logits, int K, int S, const int* crops_xy, int ntiles, int step, int nx,
                                  int ny, const double* weight, int H, int W, int margin_top, int margin_left,
                                  float* out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_tiles_merge, logits, K, S, crops_xy, ntiles, step, nx, ny, weight, H, W, margin_top, margin_left, out, stream);
     SEGNB_CHECK_ARG(logits && crops_xy && weight && out && K > 0 && S > 0 && step > 0 && step <= S && nx * ny == ntiles,
                     "bad arguments");
     const long long total = (long long)H * W * K;

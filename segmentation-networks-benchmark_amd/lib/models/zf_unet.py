@@ -103,14 +103,18 @@ class ZF_UNET(nn.Module):
                              % (x.shape[hdim], x.shape[wdim]))
         eng = self._get_engine(x.device)
         x = x.detach().contiguous() if u8 else x.detach().contiguous().float()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _ZFUnetFn.apply(eng, x, *list(self.parameters()))
+        if torch.is_grad_enabled():
+            # ONE parameter ties the output to the autograd graph (the backward plan writes every .grad itself, as views
+            # of the flat gradient buffer, and returns no gradients): 70 fewer edges for autograd to set up and check
+            anchor = next((p for p in eng.flat.param_list() if p.requires_grad), None)
+            if anchor is not None:
+                return _ZFUnetFn.apply(eng, x, anchor)
         return eng.forward(x, self.training, False)
 
 
 class _ZFUnetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, x, *params):
+    def forward(ctx, eng, x, anchor):
         ctx.eng = eng
         out = eng.forward(x, eng.module.training, True)
         ctx.generation = eng.generation
@@ -123,8 +127,8 @@ class _ZFUnetFn(torch.autograd.Function):
             # what this graph's backward needs -- refuse instead of using the wrong activations
             raise RuntimeError('ZF_UNET: another forward ran on this model since the forward being differentiated; '
                                'run backward before the next forward (the plan keeps ONE set of activation buffers)')
-        grads = ctx.eng.backward(dlogits.contiguous().float())
-        return (None, None) + tuple(grads)
+        ctx.eng.backward(dlogits.contiguous().float())
+        return None, None, None
 
 
 class _ZFUnetPlan(object):
@@ -153,6 +157,7 @@ class _ZFUnetPlan(object):
         self._bufs = {}
         self._pack_tables = {}
         self._packed_key = None
+        self._cplans = {}
         self.generation = 0
         self.K = module.num_classes
 
@@ -252,10 +257,11 @@ class _ZFUnetPlan(object):
             unpacks[gi].run()
         hook = getattr(self.module, '_grad_ready_hook', None)
         if hook is not None and gi < 2:
+            self._plan_cut(('ready', gi, side is not None))      # a recorded launch list is cut where the hook runs
             hook(self.flat, los[gi], (side,) if side is not None else ())
 
     def _pack_if_needed(self, H, W):
-        key = (sum(p._version for p in self.module.parameters()), self.flat.version, H, W,
+        key = (sum(p._version for p in self.flat.param_list()), self.flat.version, H, W,
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return
@@ -286,6 +292,70 @@ class _ZFUnetPlan(object):
             out[n] = t
         return out
 
+    # ---- launch plans (segnb_plan_*): the forward / backward launch lists replayed from C ----------------------------
+    # The first step of a configuration runs eagerly WHILE the library records the ABI calls; later steps replay the list
+    # with one call (the Python launcher needs 10-14 us per launch: 3.6-4.4 ms for the ~300 launches of a step).  Valid
+    # only while every pointer in the list is: same buffers (geometry, flat parameter / gradient storage), same streams,
+    # same mode.  Anything a replay cannot express -- the data-parallel hooks between gradient groups, the bench's
+    # per-launch timer, a uint8 input (host normalisation constants), CPU -- runs the eager path.
+    use_cplan = os.environ.get('SEGNB_CPLAN', '1') != '0'
+
+    def _cplan_key(self, kind, N, H, W, train, need_grad, drop):
+        from segnb import engine
+        rt = self.rt
+        if (not self.use_cplan or rt.device.type != 'cuda' or engine.TIMER is not None or self.BWD_CONV_CU_PCT != 100):
+            return None
+        side = rt.side_stream()
+        return (kind, N, H, W, bool(train), bool(need_grad), tuple(n for n in ENCODER + DECODER if drop[n] is not None),
+                getattr(self.module, '_grad_ready_hook', None) is not None,
+                rt.stream, side.cuda_stream if side is not None else 0, self.flat.flat_p.data_ptr(),
+                self.flat.flat_g.data_ptr(), tuple(p.data_ptr() for p in self.flat.buffer_list()))
+
+    # ---- recorded launch lists (segnb_plan_*) ---------------------------------------------------------------------
+    # A list is a sequence of segments [(handle, launches, mark)]: the data-parallel "gradients ready" hook is host code that
+    # must run BETWEEN launches (it starts an all-reduce behind what has been issued so far), so the recording is cut there
+    # and the replay calls the hook after the segment that ends at the cut.
+    _rec = None
+
+    def _plan_begin(self):
+        self._rec = []
+        nv.plan_record_begin()
+
+    def _plan_cut(self, mark):
+        if self._rec is not None:
+            handle, nops = nv.plan_record_end()
+            self._rec.append((handle, nops, mark))
+            nv.plan_record_begin()
+
+    def _plan_end(self, ckey):
+        handle, nops = nv.plan_record_end()
+        segs, self._rec = self._rec + [(handle, nops, None)], None
+        if any(h is None for h, _, _ in segs):           # a call that cannot be replayed: remembered, never recorded again
+            for h, _, _ in segs:
+                if h is not None:
+                    nv.call('segnb_plan_destroy', h)
+            segs = None
+        self._cplans[ckey] = (segs, self._stage_state(), sum(n for _, n, _ in segs) if segs else 0)
+
+    def _plan_replay(self, plan, H=None, W=None):
+        for handle, _, mark in plan[0]:
+            nv.call('segnb_plan_run', handle)
+            if mark is not None:
+                hook = getattr(self.module, '_grad_ready_hook', None)
+                if hook is not None:
+                    los = self._tables(H, W)[3]
+                    hook(self.flat, los[mark[1]], (self.rt.side_stream(),) if mark[2] else ())
+        self._restore_stage_state(plan[1])
+
+    def _stage_state(self):
+        return [(st, st._stats_stale, st._fused_fwd, getattr(st, '_saved', None))
+                for n in ENCODER + DECODER for st in self.stages[n]]
+
+    @staticmethod
+    def _restore_stage_state(state):
+        for st, stale, fused, saved in state:
+            st._stats_stale, st._fused_fwd, st._saved = stale, fused, saved
+
     # ---- forward ---------------------------------------------------------------------------------------
     def forward(self, x, train, need_grad):
         rt = self.rt
@@ -298,6 +368,30 @@ class _ZFUnetPlan(object):
         b = self.buffers(N, H, W)
         self._pack_if_needed(H, W)
         drop = self._dropout_tables(b, N, train)
+        ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)
+        if ckey is not None:
+            # statistics a fused training forward left unconsumed are cleared here, outside the recorded list
+            for n in ENCODER + DECODER:
+                for st in self.stages[n]:
+                    if st.bn is not None and train and st._stats_stale:
+                        st.stats.zero_()
+                        st._stats_stale = False
+            xin = b.get('x_in')
+            if xin is None:
+                xin = b['x_in'] = torch.empty_like(x)
+            xin.copy_(x)                                  # the list reads the batch from ONE persistent tensor
+            x = xin
+            plan = self._cplans.get(ckey)
+            if plan is not None and plan[0] is not None:
+                self._plan_replay(plan)
+                self._last = (N, H, W) if need_grad else None
+                self._last_train = bool(train)
+                self.generation += 1
+                return b['logits'].clone()
+            if plan is None:
+                self._plan_begin()
+            else:
+                ckey = None                               # recorded before and found not replayable: eager
         first = None
         if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
             first = (x, self.module.input_norm)          # the first convolution reads the image itself
@@ -325,6 +419,8 @@ class _ZFUnetPlan(object):
         logits = b['logits']
         nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
                 nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+        if ckey is not None:
+            self._plan_end(ckey)
         self._last = (N, H, W) if need_grad else None
         self.generation += 1                       # every forward overwrites the activation buffers
         self._last_train = bool(train)
@@ -343,6 +439,25 @@ class _ZFUnetPlan(object):
         N, H, W = self._last
         b = self.buffers(N, H, W)
         accumulate_in_place = flat.begin_backward()
+        drop_now = {n: self.stages[n][1]._saved[2] if self.stages[n][1]._saved is not None else None for n in ENCODER + DECODER}
+        ckey = self._cplan_key('bwd', N, H, W, True, True, drop_now)
+        if ckey is not None:
+            din = b.get('dlogits_in')
+            if din is None:
+                din = b['dlogits_in'] = torch.empty_like(dlogits)
+            din.copy_(dlogits)                            # (autograd hands over a different tensor every step)
+            dlogits = din
+            plan = self._cplans.get(ckey)
+            if plan is not None and plan[0] is not None:
+                self._plan_replay(plan, H, W)
+                rt._side_busy = False
+                self._after_backward()
+                flat.publish_grads(accumulate_in_place)
+                return [None] * len(flat._off)
+            if plan is None:
+                self._plan_begin()
+            else:
+                ckey = None
         if self.BWD_CONV_CU_PCT != 100:
             nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
         head = self.module.conv_final
@@ -382,11 +497,13 @@ class _ZFUnetPlan(object):
             nv.call('segnb_tune', b'conv_cu_pct', 100)
         rt.join_side()                        # the weight gradients ran on the side stream
         self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
+        if ckey is not None:
+            self._plan_end(ckey)
         self._after_backward()
         # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not
         # returned through autograd, so they never get cloned and a flat optimizer / all-reduce can run)
         flat.publish_grads(accumulate_in_place)
-        return [None for _ in self.module.parameters()]
+        return [None] * len(flat._off)
 
     def _after_backward(self):
         hook = getattr(self.module, '_grad_sync_hook', None)

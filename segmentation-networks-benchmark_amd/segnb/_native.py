@@ -101,6 +101,12 @@ SIGNATURES = {
     'segnb_seg_loss_finalize': [_P, ctypes.POINTER(LossSpec), _P, _P],
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_tune': [ctypes.c_char_p, c_int],
+    'segnb_plan_begin': [],
+    'segnb_plan_end': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)],
+    'segnb_plan_run': [_P],
+    'segnb_plan_destroy': [_P],
+    'segnb_stream_fork': [_P, _P],
+    'segnb_stream_join': [_P, _P],
     'segnb_debug_stamps': [_P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
@@ -162,6 +168,17 @@ def call(name, *args):
         msg = lib.segnb_last_error()
         raise RuntimeError('HIP error encountered in %s (status %d): %s'
                            % (name, rc, msg.decode() if msg else ''))
+
+
+def plan_record_begin():
+    call('segnb_plan_begin')
+
+
+def plan_record_end():
+    """-> (opaque plan handle or None when the recorded sequence is not replayable, number of recorded launches)"""
+    h, n = c_void_p(), c_int()
+    call('segnb_plan_end', ctypes.byref(h), ctypes.byref(n))
+    return (h.value or None), n.value
 
 
 def query(name, *args):

@@ -97,7 +97,7 @@ class Runtime(object):
         """-> side stream (made to wait for everything issued so far on the current stream) or None"""
         s = self.side_stream()
         if s is not None:
-            s.wait_stream(torch.cuda.current_stream(self.device))
+            nv.call('segnb_stream_fork', self.stream, s.cuda_stream)       # (an ABI call: recordable in a launch plan)
             self._side_busy = True
         return s
 
@@ -112,7 +112,7 @@ class Runtime(object):
 
     def join_side(self):
         if getattr(self, '_side_busy', False):
-            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            nv.call('segnb_stream_join', self.stream, self._side.cuda_stream)
             self._side_busy = False
 
     def int32(self, values):
@@ -686,10 +686,47 @@ class FlatParams(object):
         self.flat_p = None
         self.flat_g = None
         self._off = {}
+        self._gviews = {}
+        self._slots = None
         self.version = 0   # bumped by in-place updates that bypass torch's version counters (fused SGD)
 
+    # module.parameters() / .buffers() walk the whole module tree (0.1-0.2 ms for a 60-module net, several times per step):
+    # the walk is done once and remembered as (owning module, attribute name) slots, which still see a replaced Parameter
+    # or buffer object; a net whose sub-modules are added or removed afterwards calls forget_structure()
+    def _structure(self):
+        if self._slots is None:
+            ps, bs, seen = [], [], set()
+            for m in self.module.modules():
+                for n, p in m._parameters.items():
+                    if p is not None and id(p) not in seen:
+                        seen.add(id(p))
+                        ps.append((m, n))
+                for n, b in m._buffers.items():
+                    if b is not None and id(b) not in seen:
+                        seen.add(id(b))
+                        bs.append((m, n))
+            self._slots = (ps, bs)
+        return self._slots
+
+    def forget_structure(self):
+        self._slots = None
+
+    def param_list(self):
+        out = [m._parameters[n] for m, n in self._structure()[0]]
+        if any(p is None for p in out):
+            self._slots = None
+            out = [m._parameters[n] for m, n in self._structure()[0]]
+        return out
+
+    def buffer_list(self):
+        out = [m._buffers[n] for m, n in self._structure()[1]]
+        if any(b is None for b in out):
+            self._slots = None
+            out = [m._buffers[n] for m, n in self._structure()[1]]
+        return out
+
     def ensure(self, device):
-        params = [p for p in self.module.parameters()]
+        params = self.param_list()
         ok = self.flat_p is not None and self.flat_p.device == device
         if ok:
             base = self.flat_p.data_ptr()
@@ -716,14 +753,14 @@ class FlatParams(object):
                 view.copy_(p.data.to(device))
                 p.data = view
         self.flat_p, self.flat_g, self._off = flat_p, flat_g, offs
+        self._gviews = {id(p): flat_g[offs[id(p)][0]:offs[id(p)][0] + offs[id(p)][1]].view(p.shape) for p in params}
         self.total = total
         self.version += 1
         for p in params:
             FlatParams.registry[id(p)] = self
 
     def grad_of(self, p):
-        off, n = self._off[id(p)]
-        return self.flat_g[off:off + n].view(p.shape)
+        return self._gviews[id(p)]
 
     def grad_absmax(self):
         """max |g| over every parameter gradient, as a 0-dim device tensor: ONE launch over the flat gradient buffer
@@ -736,7 +773,7 @@ class FlatParams(object):
     def grads_alias(self):
         """True when every parameter's .grad is already a view of flat_g (accumulate in place)."""
         base = self.flat_g.data_ptr()
-        for p in self.module.parameters():
+        for p in self.param_list():
             g = p.grad
             if g is None:
                 return False
@@ -763,8 +800,9 @@ class FlatParams(object):
         if accumulated_in_place:
             return
         base = self.flat_g.data_ptr()
-        for p in self.module.parameters():
-            view = self.grad_of(p)
+        views = self._gviews
+        for p in self.param_list():
+            view = views[id(p)]
             if p.grad is None:
                 p.grad = view
             elif p.grad.data_ptr() != base + 4 * self._off[id(p)][0]:

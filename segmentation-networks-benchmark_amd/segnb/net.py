@@ -54,7 +54,7 @@ class Tape(object):
         self.generation = getattr(self, 'generation', 0) + 1
         # weight-packing generation: every ConvOp plan (one per input size) remembers the generation it was packed at,
         # so a plan first used -- or last used -- under other parameter values is (re)packed on its next use
-        key = (sum(p._version for p in self.module.parameters()), self.flat.version, self.flat.flat_p.data_ptr())
+        key = (sum(p._version for p in self.flat.param_list()), self.flat.version, self.flat.flat_p.data_ptr())
         if key != self.pack_key and self.convs:
             # parameters changed since the last pack: all known plans in one launch (plans first met later in this
             # forward pack themselves in conv_unit and join the table for the next step)
@@ -421,6 +421,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         ctx.net = net
+        ctx.nparams = len(params)
         out = net._run(x, True)
         ctx.generation = net._tape.generation
         return out
@@ -432,7 +433,7 @@ class _NetFn(torch.autograd.Function):
                                'backward before the next forward (the tape keeps ONE set of activation buffers)'
                                % type(ctx.net).__name__)
         ctx.net._run_backward(dlogits.contiguous().float())
-        return (None, None) + tuple(None for _ in ctx.net.parameters())
+        return (None, None) + (None,) * ctx.nparams
 
 
 class HipNet(nn.Module):
@@ -468,8 +469,11 @@ class HipNet(nn.Module):
             x = x.detach().contiguous().float()
         if self._tape is None or self._tape.rt.device != x.device:
             self._tape = Tape(self, x.device, self.compute_dtype)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _NetFn.apply(self, x, *list(self.parameters()))
+        if torch.is_grad_enabled():
+            flat = getattr(getattr(self, '_tape', None), 'flat', None)
+            params = flat.param_list() if flat is not None else list(self.parameters())
+            if any(p.requires_grad for p in params):
+                return _NetFn.apply(self, x, *params)
         return self._run(x, False)
 
     def _run(self, x, need_grad):

@@ -84,7 +84,7 @@ class _FlatStateMixin(object):
             ent = dict(p=flat.flat_p, step=torch.zeros((), dtype=torch.float32),
                        **{n: torch.zeros_like(flat.flat_p) for n in names})
             st[key] = ent
-        params = list(flat.module.parameters())
+        params = flat.param_list()
         first = self.state.get(params[0])
         n0 = names[0]
         synced = (first is not None and first.get('step') is ent['step'] and n0 in first and

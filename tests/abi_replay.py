@@ -166,6 +166,9 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
 
     overlap = E.Runtime.overlap_wgrad
     E.Runtime.overlap_wgrad = False          # the harness reads results right after each call: one stream
+    from lib.models import zf_unet as _zf
+    cplan = _zf._ZFUnetPlan.use_cplan
+    _zf._ZFUnetPlan.use_cplan = False        # every call must pass through the patched nv.call (no C-side replay)
     nv.ptr = ptr
     nv.call = call
     E.View.ptr = property(lambda self: (rec.reg(self.t), orig_vptr.fget(self))[1])
@@ -190,4 +193,5 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
         nv.set_backend_for_testing(None)
         nv.ptr, nv.call, E.View.ptr = orig_ptr, orig_call, orig_vptr
         E.Runtime.overlap_wgrad = overlap
+        _zf._ZFUnetPlan.use_cplan = cplan
     return len(rec.calls), rec.report

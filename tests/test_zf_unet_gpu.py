@@ -340,6 +340,68 @@ def test_uint8_first_layer_kernel_bitwise_vs_packed_path():
     assert float(xv.dense()[..., 3:].abs().max()) == 0.0
 
 
+def test_launch_plan_replay_matches_eager_and_cuts_host_time():
+    """segnb_plan_*: the forward / backward launch lists replayed from C.  Same steps with the
+    replay on and off: losses, BatchNorm buffers and parameters (after two steps, to 1e-5) agree -- not bitwise: the head's
+    weight gradient is summed with fp32 atomics, dropout and changing inputs flow through the recorded lists, and the host enqueues a step in
+    under a third of the eager launcher's time."""
+    import time
+    from lib.losses import BCEAndDiceLoss
+    from lib.models import zf_unet as zf
+    from segnb import optim
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(8, 3, 64, 64, generator=gen).cuda() for _ in range(4)]
+    ys = [(torch.rand(8, 1, 64, 64, generator=gen) > 0.7).long().cuda() for _ in range(4)]
+    drop = zf_unet_ref.make_dropout_tables(32, 8, 0.2, torch.Generator().manual_seed(5))
+    res, host = {}, {}
+    for mode in (True, False):
+        zf._ZFUnetPlan.use_cplan = mode
+        try:
+            torch.manual_seed(0)
+            m = zf.ZF_UNET().cuda().train()
+            m.dropout_override = drop
+            opt = optim.SGD(m.parameters(), lr=1e-2)
+            losses = []
+            for it in range(6):
+                opt.zero_grad()
+                loss = BCEAndDiceLoss()(m(xs[it % 4]), ys[it % 4])
+                (8 * loss).backward()
+                opt.step()
+                losses.append(loss.item())
+                if it == 1:    # (later steps: the fp32-atomic summation order of the head's gradients, amplified through bf16
+                    #            roundings, makes two EAGER runs differ by 1e-3 .. 1e-1 of a small parameter as well)
+                    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            m.eval()
+            with torch.no_grad():
+                ev = m(xs[0]).clone()
+                ev2 = m(xs[1]).clone()
+            m.train()
+            if mode:
+                eng = m._engine
+                assert len(eng._cplans) >= 3 and all(p[0] is not None and p[2] > 20 for p in eng._cplans.values())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(10):
+                opt.zero_grad()
+                loss = BCEAndDiceLoss()(m(xs[it % 4]), ys[it % 4])
+                (8 * loss).backward()
+                opt.step()
+            host[mode] = (time.perf_counter() - t0) / 10 * 1e3          # enqueue time: nothing synchronises in the loop
+            torch.cuda.synchronize()
+            res[mode] = (losses, ev.cpu(), ev2.cpu(), state)
+        finally:
+            zf._ZFUnetPlan.use_cplan = True
+    (l1, e1, f1, s1), (l0, e0, f0, s0) = res[True], res[False]
+    np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-4)
+    assert float((e1 - e0).abs().max()) <= 2e-2 * float(e0.abs().max()) and float((f1 - f0).abs().max()) <= 2e-2 * float(f0.abs().max())
+    assert float((e1 - f1).abs().max()) > 0          # the second eval input really went through the replayed list
+    for k in s0:
+        if s0[k].is_floating_point():
+            assert float((s1[k] - s0[k]).abs().max()) <= 1e-5 * float(s0[k].abs().max()) + 1e-7, k
+    print('host enqueue per step: replayed %.2f ms, eager %.2f ms' % (host[True], host[False]))
+    assert host[True] < 0.5 * host[False]
+
+
 def test_eval_matches_train_statistics_path():
     """validate() path (torch_train.py:248-265): no-grad eval forward uses running statistics."""
     m = _model(8, 0.0, 4.0, 'f32')
@@ -364,8 +426,13 @@ def test_bench_runs_over_rccl_single_rank():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
            '127.0.0.1', '--master-port', '29731', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3',
            '--warmup', '2', '--batch', '4', '--no-cpu-baseline']
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
-    res = json.loads(line)
-    assert res['n_gpus'] == 1 and res['value'] > 0 and np.isfinite(res['final_loss'])
+    losses = {}
+    for cplan in ('1', '0'):       # the launch lists replayed from C (cut at the gradient-ready hooks) / the eager launcher
+        out = subprocess.run(cmd, env=dict(env, SEGNB_CPLAN=cplan), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+        res = json.loads(line)
+        assert res['n_gpus'] == 1 and res['value'] > 0 and np.isfinite(res['final_loss'])
+        assert res['launch_plan'] == (cplan == '1')
+        losses[cplan] = res['final_loss']
+    assert abs(losses['1'] - losses['0']) <= 2e-4
