@@ -254,7 +254,8 @@ def main():
                    'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
         'final_loss': round(final_loss, 6), 'hip_graph': bool(graph is not None),
         # forward / backward launch lists recorded once and replayed from C (segnb_plan_run) in the timed region
-        'launch_plan': bool(args.model == 'zf_unet' and any(p[0] for p in model._engine._cplans.values())),
+        'launch_plan': bool(any(p[0] for p in model._engine._cplans.values()) if args.model == 'zf_unet' else
+                            any(e.get('state') == 'ready' for e in model._tape.plans.values())),
         'host_enqueue_ms_per_step': None if host_ms is None else round(host_ms, 3),
         'step_mfma_frac': round(value / ws * gflop_img / 1e3 / peak, 4),
     }

@@ -257,7 +257,9 @@ int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, i
                                     float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
                                     float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
 
-/* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a */
+/* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a.
+ * A NULL operand counts as zeros: (NULL, b) copies b, (NULL, NULL) clears out -- the strided copies / clears of the
+ * executor as recordable launches (segnb_plan_*) */
 int segnb_add(int dtype, const void* a, int ld_a, const void* b, int ld_b, void* out, int ld_out, int N,
               int H, int W, int Cp, segnb_stream_t stream);
 /* stats[r][0][c] += sum x, stats[r][1][c] += sum x^2 of an arbitrary NHWC tensor: batch statistics for a

@@ -536,8 +536,12 @@ class AbiEmulator(object):
 
     def segnb_add(self, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream):
         dt = _tdt(dtype)
-        r = (_nhwc(a, N, H, W, Cp, ld_a, dt).float() + _nhwc(b, N, H, W, Cp, ld_b, dt).float()).to(dt)
-        _nhwc(out, N, H, W, Cp, ld_out, dt).copy_(r)
+        o = _nhwc(out, N, H, W, Cp, ld_out, dt)
+        r = torch.zeros(o.shape, dtype=torch.float32)
+        for src, ld in ((a, ld_a), (b, ld_b)):          # a NULL operand counts as zeros
+            if src:
+                r = r + _nhwc(src, N, H, W, Cp, ld, dt).float()
+        o.copy_(r.to(dt))
         return 0
 
     def segnb_bn_stats(self, dtype, x, ld, N, H, W, Cp, stats, stream):

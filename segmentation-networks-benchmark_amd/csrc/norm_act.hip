@@ -698,8 +698,10 @@ __global__ __launch_bounds__(NTHR) void add_kernel(const T* __restrict__ a, int 
         const long long pix = i / CPP;
         const int c0 = (int)(i - pix * CPP) * 8;
         float x[8], yv[8];
-        load8(a + pix * ld_a + c0, x);
-        load8(b + pix * ld_b + c0, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = yv[e] = 0.f;
+        if (a != nullptr) load8(a + pix * ld_a + c0, x);          // (a missing operand counts as zeros: copy / clear)
+        if (b != nullptr) load8(b + pix * ld_b + c0, yv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] += yv[e];
         store8(out + pix * ld_out + c0, x);
@@ -1163,7 +1165,7 @@ extern "C" int segnb_add(int dtype, const void* a, int ld_a, const void* b, int 
                          int H, int W, int Cp, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_add, dtype, a, ld_a, b, ld_b, out, ld_out, N, H, W, Cp, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(a && b && out, "NULL tensor");
+    SEGNB_CHECK_ARG(out, "NULL tensor");
     const long long npix = (long long)N * H * W;
     int grid = ceil_div(npix * (Cp / 8), NTHR);
     if (grid > 4096) grid = 4096;

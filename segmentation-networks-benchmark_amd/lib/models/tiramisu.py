@@ -146,7 +146,7 @@ class FCDenseNet(HipNet):
             ubufs.append(tape.view('U%d' % i, N, sizes[d][0], sizes[d][1], ch))
             gb = tape.view('GU%d' % i, N, sizes[d][0], sizes[d][1], ch) if need else None
             if gb is not None:
-                gb.t.zero_()
+                tape.rt.clear_view(gb)
             gbufs.append(gb)
         # ---- encoder: block d lives in the skip slice of its decoder stage buffer
         cur = self._first
@@ -180,7 +180,7 @@ class FCDenseNet(HipNet):
         B = tape.view('B', N, sizes[nd][0], sizes[nd][1], cur + g * nb)
         GB = tape.view('GB', N, sizes[nd][0], sizes[nd][1], cur + g * nb) if need else None
         if GB is not None:
-            GB.t.zero_()
+            tape.rt.clear_view(GB)
         o = pooled_writer(B.slice(0, cur))
         o.g = GB.slice(0, cur) if GB is not None else None
         self._dense_layers(tape, self.bottleneck.bottleneck.layers, B, GB, 0, cur, 'bottleneck')

@@ -118,6 +118,13 @@ class Runtime(object):
     def int32(self, values):
         return torch.tensor(list(values), dtype=torch.int32, device=self.device)
 
+    # clears / copies of (strided) activation views as ABI launches, so that a recorded launch list contains them
+    def clear_view(self, v):
+        nv.call('segnb_add', self.code, None, 0, None, 0, v.ptr, v.ld, v.N, v.H, v.W, v.Cp, self.stream)
+
+    def copy_view(self, src, dst):
+        nv.call('segnb_add', self.code, None, 0, src.ptr, src.ld, dst.ptr, dst.ld, dst.N, dst.H, dst.W, dst.Cp, self.stream)
+
 
 class InputNorm(object):
     """NormalizeImage of the reference's input pipeline (lib/augmentations.py:452-460): x * scale - mean) / std per
@@ -350,7 +357,7 @@ class ConvOp(object):
         assert xv.Cp == self.Cip and yv.Cp == self.Cop, (xv.Cp, self.Cip, yv.Cp, self.Cop)
         assert (yv.H, yv.W) == p['out_hw']
         if not p['fwd_full']:
-            yv.dense().zero_()
+            rt.clear_view(yv)
         b = self.bias.detach() if self.bias is not None else None
         if epilogue is not None:
             assert stats is None and p['fwd_full'] and len(p['fwd']) == 1, 'one full-coverage launch, no statistics'
@@ -409,7 +416,7 @@ class ConvOp(object):
         p, rt = self.plan(dxv.H, dxv.W), self.rt
         assert self.need_dgrad and dyv.Cp == self.Cop and dxv.Cp == self.Cip
         if not p['dg_full']:
-            dxv.dense().zero_()
+            rt.clear_view(dxv)
         for li, l in enumerate(p['dg']):
             g = self._geom(p, 'd', li, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
             if bn_reduce is not None:
@@ -710,6 +717,14 @@ class FlatParams(object):
 
     def forget_structure(self):
         self._slots = None
+        self._modules = None
+
+    _modules = None
+
+    def module_list(self):
+        if self._modules is None:
+            self._modules = list(self.module.modules())
+        return self._modules
 
     def param_list(self):
         out = [m._parameters[n] for m, n in self._structure()[0]]

@@ -12,6 +12,8 @@ Gradients of multi-consumer tensors (ResNet identity branches, dense concatenati
 Used by lib.models.{unet16, linknet, tiramisu}; ZF_UNET keeps its hand-scheduled plan (fused pool/upsample
 routing, batched pack/unpack).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -45,12 +47,18 @@ class Tape(object):
         self._pack_table = None
         self._unpack_table = None
         self._unpack_pending = []
+        self._drop_sites, self._drop_pools = {}, {}
+        self.plans = {}            # recorded launch lists (HipNet._run / _run_backward)
 
     # ---- per-step bookkeeping ------------------------------------------------------------------------------
     def begin(self, train, need_grad):
         self.flat.ensure(self.rt.device)
         self.train, self.need_grad = train, need_grad
         self.back, self._seq = [], 0
+        for p, pool in self._drop_pools.items():
+            pool['drawn'] = pool['used'] if train else 0
+            if train and pool['used']:
+                pool['buf'][:pool['used']].bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         self.generation = getattr(self, 'generation', 0) + 1
         # weight-packing generation: every ConvOp plan (one per input size) remembers the generation it was packed at,
         # so a plan first used -- or last used -- under other parameter values is (re)packed on its next use
@@ -113,10 +121,16 @@ class Tape(object):
         self._unpack_pending.append((conv, H, W, grad_w))
 
     def backward(self):
+        self.run_closures()
+        self.run_unpack()
+
+    def run_closures(self):
         for fn in reversed(self.back):
             fn()
         self.back = []
         self.rt.join_side()               # the weight gradients ran on the side stream
+
+    def run_unpack(self):
         if self._unpack_pending:
             key = (tuple((id(c), h, w) for c, h, w, _ in self._unpack_pending), self.flat.flat_g.data_ptr())
             t = self._unpack_table
@@ -128,12 +142,30 @@ class Tape(object):
             t[1].run()
             self._unpack_pending = []
 
+    DROP_POOL_FLOATS = 1 << 20
+
     def dropout_table(self, site, N, Cp, p):
-        """fp32 [N, Cp] Dropout2d multipliers (0 or 1/(1-p)) drawn on the device; None when inactive."""
+        """fp32 [N, Cp] Dropout2d multipliers (0 or 1/(1-p)) drawn on the device; None when inactive.  The tables of
+        all call sites with the same p are slices of ONE pool, redrawn by one bernoulli launch per step in begin()
+        (FCDenseNet103 has 100+ Dropout2d sites); a site first met in this step draws its own slice."""
         if not self.train or p <= 0.0:
             return None
-        t = self.small(site + '/drop', (N, Cp), torch.float32)
-        t.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+        key = (site + '/drop', N, Cp)
+        ent = self._drop_sites.get(key)
+        if ent is None:
+            pool = self._drop_pools.get(p)
+            if pool is None:
+                pool = self._drop_pools[p] = {'buf': self.rt.zeros((self.DROP_POOL_FLOATS,), torch.float32), 'used': 0,
+                                              'drawn': 0}
+            n = N * Cp
+            if pool['used'] + n > pool['buf'].numel():
+                raise RuntimeError('dropout pool exhausted (%d floats): raise Tape.DROP_POOL_FLOATS' % pool['buf'].numel())
+            t = pool['buf'][pool['used']:pool['used'] + n].view(N, Cp)
+            pool['used'] += n
+            ent = self._drop_sites[key] = (t, pool['used'])
+        t, end = ent
+        if end > self._drop_pools[p]['drawn']:
+            t.bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
         return t
 
 
@@ -350,7 +382,7 @@ def add(tape, a, b, tag='add'):
         tape.contribute(a, oa.g)
         if b.g is None and b.needs_grad:
             gb = tape.view(site + '/gb', av.N, av.H, av.W, av.Cp)
-            gb.dense().copy_(oa.g.dense())
+            rt.copy_view(oa.g, gb)
             b.g = gb
         else:
             tape.contribute(b, oa.g)
@@ -476,6 +508,34 @@ class HipNet(nn.Module):
                 return _NetFn.apply(self, x, *params)
         return self._run(x, False)
 
+    # ---- recorded launch lists (segnb_plan_*: include/segnb_hip.h) --------------------------------------------------------
+    # The graphs are static: the SECOND step of a (geometry, mode) runs the Python build once more while the library records
+    # every ABI call it makes (the first one allocated buffers and packed weights with calls that are not replayable); from
+    # the third step on the forward and the backward are one segnb_plan_run each -- 3-4 us of host time per launch instead
+    # of the 10-14 us of a ctypes call, which is what bounds FCDenseNet103's ~2250 launches of ~10 us.  Whatever varies
+    # between steps enters through persistent buffers: the input batch and the logits gradient are copied into them, the
+    # dropout pools are redrawn in Tape.begin, BatchNorm statistics are cleared by the kernels that consume them.
+    use_cplan = os.environ.get('SEGNB_CPLAN', '1') != '0'
+
+    def _plan_key(self, x, need_grad):
+        from . import engine
+        tape = self._tape
+        rt = tape.rt
+        if not self.use_cplan or rt.device.type != 'cuda' or engine.TIMER is not None or x.dtype == torch.uint8:
+            return None
+        side = rt.side_stream()
+        return (tuple(x.shape), bool(self.training), bool(need_grad), rt.stream, side.cuda_stream if side is not None else 0,
+                tape.flat.flat_p.data_ptr(), tape.flat.flat_g.data_ptr(), tuple(b.data_ptr() for b in tape.flat.buffer_list()),
+                tuple(sorted((p, pool['used']) for p, pool in tape._drop_pools.items())) if self.training else ())
+
+    @staticmethod
+    def _plan_drop(ent):
+        for k in ('fwd', 'bwd'):
+            h = ent.get(k)
+            if h:
+                nv.call('segnb_plan_destroy', h)
+            ent[k] = None
+
     def _run(self, x, need_grad):
         tape = self._tape
         tape.begin(self.training, need_grad)
@@ -483,22 +543,79 @@ class HipNet(nn.Module):
             N, H, W, C = x.shape
         else:
             N, C, H, W = x.shape
+        key = self._plan_key(x, need_grad)
+        ent, recording = None, False
+        self._plan_live = None
+        if key is not None:
+            ent = tape.plans.get(key)
+            if ent is None:
+                ent = tape.plans[key] = {'state': 'seen'}                  # first step of this key: eager
+            else:
+                xin_t = ent.get('x_in')
+                if xin_t is None:
+                    xin_t = ent['x_in'] = torch.empty_like(x)
+                xin_t.copy_(x)                                              # the list reads the batch from ONE tensor
+                x = xin_t
+                if ent['state'] == 'ready':
+                    nv.call('segnb_plan_run', ent['fwd'])
+                    tape.back = []
+                    self._plan_live = ent if need_grad else None
+                    return ent['logits'].clone()
+                if ent['state'] == 'seen' or (ent['state'] == 'fwd' and need_grad):
+                    self._plan_drop(ent)                                    # (a recorded forward whose backward never ran)
+                    nv.plan_record_begin()
+                    recording = True
         cin_p = cp.pad8(C)
         xin = tape.view('input', N, H, W, cin_p)
         pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         self._dlogits = [None]
         logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
+        if recording:
+            handle, nops = nv.plan_record_end()
+            if handle is None:
+                ent['state'] = 'eager'                                     # not replayable: remembered
+            else:
+                ent.update(fwd=handle, logits=logits, nfwd=nops, state='fwd' if need_grad else 'ready')
+                self._plan_live = ent if need_grad else None
         return logits.clone()
 
     def _run_backward(self, dlogits):
         tape = self._tape
         if not tape.train and any(isinstance(m, nn.modules.batchnorm._BatchNorm) or type(m).__name__ == 'InPlaceABN'
-                                  for m in self.modules()):
+                                  for m in tape.flat.module_list()):
             raise RuntimeError('backward through an eval-mode forward is not supported: BatchNorm gradients are '
                                'implemented for training mode (call model.train(), or run the forward under no_grad)')
-        self._dlogits[0] = dlogits
+        ent = getattr(self, '_plan_live', None)
+        self._plan_live = None
         acc = tape.flat.begin_backward()
-        tape.backward()
+        if ent is not None:
+            din = ent.get('dlogits_in')
+            if din is None:
+                din = ent['dlogits_in'] = torch.empty_like(dlogits)
+            din.copy_(dlogits)                                              # (autograd hands over a new tensor every step)
+            dlogits = din
+        if ent is not None and ent['state'] == 'ready':
+            nv.call('segnb_plan_run', ent['bwd'])
+            tape.rt._side_busy = False
+            if ent['unpack'] is not None:
+                ent['unpack'].run()
+        else:
+            self._dlogits[0] = dlogits
+            recording = ent is not None and ent['state'] == 'fwd'
+            if recording:
+                nv.plan_record_begin()
+            tape.run_closures()
+            if recording:
+                handle, nops = nv.plan_record_end()
+                if handle is None:
+                    self._plan_drop(ent)
+                    ent['state'] = 'eager'
+                else:
+                    ent.update(bwd=handle, nbwd=nops, state='ready')
+            had = bool(tape._unpack_pending)
+            tape.run_unpack()                                               # (7x7 / strided jobs take host tap arrays: eager)
+            if recording and ent['state'] == 'ready':
+                ent['unpack'] = tape._unpack_table[1] if had else None
         hook = getattr(self, '_grad_sync_hook', None)
         if hook is not None:
             hook(tape.flat)

@@ -169,6 +169,9 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
     from lib.models import zf_unet as _zf
     cplan = _zf._ZFUnetPlan.use_cplan
     _zf._ZFUnetPlan.use_cplan = False        # every call must pass through the patched nv.call (no C-side replay)
+    from segnb import net as _net
+    cplan_net = _net.HipNet.use_cplan
+    _net.HipNet.use_cplan = False
     nv.ptr = ptr
     nv.call = call
     E.View.ptr = property(lambda self: (rec.reg(self.t), orig_vptr.fget(self))[1])
@@ -194,4 +197,5 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
         nv.ptr, nv.call, E.View.ptr = orig_ptr, orig_call, orig_vptr
         E.Runtime.overlap_wgrad = overlap
         _zf._ZFUnetPlan.use_cplan = cplan
+        _net.HipNet.use_cplan = cplan_net
     return len(rec.calls), rec.report
