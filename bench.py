@@ -98,6 +98,8 @@ def main():
                     help='zf_unet = the headline metric (BASELINE.json); the others time the remaining SURVEY 8d rows at '
                          'their own sizes: linknet34 512x512 bs=16, fcdensenet103 256x256 bs=8, unet16 1024x1024 bs=4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fuse-optimizer', action='store_true',
+                    help='N > 1: SGD update of each gradient bucket behind its all-reduce (segnb.dist.DataParallel.fuse_optimizer)')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the whole training step from one captured HIP graph (auto = off: eager launches overlap the weight-gradient stream better)')
@@ -137,6 +139,8 @@ def main():
             'bce': L.BCEWithSigmoidLoss}[args.loss]()
     opt = optim.SGD(model.parameters(), lr=1e-3)
     dp = sdist.DataParallel(model)
+    if args.fuse_optimizer:
+        dp.fuse_optimizer(opt)
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(B, 3, S, S, generator=g).to(dev)
@@ -253,6 +257,7 @@ def main():
                                % (args.model, S, S, args.dtype, B, args.loss),
                    'global_batch': B * ws, 'parallelism': 'dp%d' % ws},
         'final_loss': round(final_loss, 6), 'hip_graph': bool(graph is not None),
+        'optimizer_in_allreduce_epilogue': bool(args.fuse_optimizer and dp.active),
         # forward / backward launch lists recorded once and replayed from C (segnb_plan_run) in the timed region
         'launch_plan': bool(any(p[0] for p in model._engine._cplans.values()) if args.model == 'zf_unet' else
                             any(e.get('state') == 'ready' for e in model._tape.plans.values())),

@@ -59,9 +59,33 @@ class DataParallel(object):
         model._grad_ready_hook = self.grads_ready
         self._pending = []
         self._done_upto = None
+        self._fused_opt = None
         if self.active:
             seglosses.DataParallelHooks.sums_allreduce = self._allreduce_sums
             seglosses.DataParallelHooks.grad_scale = float(self.ws)
+
+    def fuse_optimizer(self, optimizer):
+        """Fold the optimizer step into the all-reduce epilogue: each bucket's slice of the flat
+        parameter buffer is updated on the communication stream right behind that bucket's all-reduce, beside the rest of
+        backward, and ``optimizer.step()`` (torch_train.py:190) finds the work done.  For the segnb.optim classes on their
+        one-launch path (one param group holding every parameter of the model, no momentum / weight decay); anything
+        else -- and a backward that meets foreign .grad tensors or accumulates -- keeps the ordinary step.  The learning
+        rate is read when the bucket is launched, i.e. during backward (the reference changes it between epochs only)."""
+        if not hasattr(optimizer, 'fusable_group') or not hasattr(optimizer, 'step_range'):
+            raise TypeError('fuse_optimizer needs a segnb.optim optimizer (SGD, RMSprop, Adam)')
+        self._fused_opt = optimizer
+        return self
+
+    def _fused_group(self, flat):
+        opt = self._fused_opt
+        if opt is None or not self.active:
+            return None
+        if not getattr(flat, 'track_accumulation', False):
+            flat.track_accumulation = True      # (from the next backward on, accumulation across steps is detected)
+            return None
+        if not getattr(flat, 'fresh_backward', False):
+            return None
+        return opt.fusable_group(flat)
 
     def detach(self):
         """Undo __init__: remove the model's hooks and the loss-path hooks (a process that goes on to run the same
@@ -118,14 +142,27 @@ class DataParallel(object):
     def _launch(self, flat, start, end):
         chunk = flat.flat_g[start:end]
         cs = self._stream(flat)
+        group = self._fused_group(flat)
+        first = end == flat.total
+        if first:
+            self._fused_cover = 0
         if cs is None:
-            self._pending.append(td.all_reduce(chunk, op=td.ReduceOp.SUM, async_op=True))
+            work = td.all_reduce(chunk, op=td.ReduceOp.SUM, async_op=True)
+            if group is None:
+                self._pending.append(work)
+                return
+            work.wait()
+            self._fused_opt.step_range(flat, group, start, end, first)
+            self._fused_cover += end - start
             return
         cs.wait_stream(torch.cuda.current_stream(flat.flat_g.device))
         for ps in getattr(self, '_producers', ()):
             cs.wait_stream(ps)
         with torch.cuda.stream(cs):
             td.all_reduce(chunk, op=td.ReduceOp.SUM)
+            if group is not None:
+                self._fused_opt.step_range(flat, group, start, end, first)
+                self._fused_cover += end - start
 
     def sync_grads(self, flat):
         """End of backward: reduce whatever is left, then make the compute stream wait for the collectives."""
@@ -138,6 +175,9 @@ class DataParallel(object):
                                'zero the gradients every step, or all-reduce once after the last accumulation step')
         self.grads_ready(flat, 0)          # (the plan joined its side stream before calling: no other producers)
         self._done_upto = None
+        if self._fused_opt is not None and getattr(self, '_fused_cover', 0) == flat.total:
+            flat.stepped_in_backward = True         # optimizer.step() finds the update done
+        self._fused_cover = 0
         for w in self._pending:
             w.wait()
         self._pending = []

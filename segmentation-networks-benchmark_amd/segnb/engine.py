@@ -802,11 +802,16 @@ class FlatParams(object):
         accumulate on top of flat_g (every .grad already aliases it: find_optimal_lr never zeroes grads,
         lib/train_utils.py:54-65; zero_grad(set_to_none=False) zeroes them in place); otherwise flat_g is
         cleared first."""
+        self.stepped_in_backward = False
         if self.grads_alias():
             # accumulating on top of non-zero gradients?  (a data-parallel sync must not reduce them twice)
             self.accumulating = bool(self.flat_g.abs().max() > 0) if getattr(self, 'track_accumulation', False) else False
+            self.fresh_backward = not self.accumulating
             return True
         self.accumulating = False
+        # every .grad None (zero_grad's default): this backward's flat_g IS the step's gradient -- what a data-parallel
+        # optimizer fold needs to know (a foreign .grad tensor gets the result added to it afterwards instead)
+        self.fresh_backward = all(p.grad is None for p in self.param_list())
         self.flat_g.zero_()
         return False
 

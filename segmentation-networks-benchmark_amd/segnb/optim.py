@@ -8,7 +8,29 @@ from . import _native as nv
 from .engine import FlatParams
 
 
+def _take_fused_token(flat):
+    """True when segnb.dist.DataParallel already applied this step's update bucket by bucket behind the all-reduces
+    (DataParallel.fuse_optimizer): step() then only has to leave the parameters' version bumped."""
+    if getattr(flat, 'stepped_in_backward', False):
+        flat.stepped_in_backward = False
+        return True
+    return False
+
+
 class SGD(torch.optim.SGD):
+    # ---- update of one contiguous range of the flat buffers (DataParallel.fuse_optimizer) -------------------------------
+    def fusable_group(self, flat):
+        """The param group this optimizer would update with its one-launch step over `flat`, else None (grad aliasing is
+        checked by the caller: during backward .grad may still be None)."""
+        return _sole_group(self, flat, lambda g: not (g['momentum'] != 0 or g['weight_decay'] != 0 or g['nesterov'] or
+                                                      g.get('maximize')))
+
+    @torch.no_grad()
+    def step_range(self, flat, group, start, end, first):
+        st = torch.cuda.current_stream(flat.flat_p.device).cuda_stream if flat.flat_p.is_cuda else 0
+        nv.call('segnb_sgd_step', nv.ptr(flat.flat_p[start:end]), nv.ptr(flat.flat_g[start:end]), end - start,
+                float(group['lr']), st)
+
     def _flat_of_group(self, group):
         if group['momentum'] != 0 or group['weight_decay'] != 0 or group['nesterov'] or group.get('maximize'):
             return None
@@ -35,6 +57,9 @@ class SGD(torch.optim.SGD):
             flat = self._flat_of_group(group)
             if flat is None:
                 plain.append(group)
+                continue
+            if _take_fused_token(flat):
+                flat.version += 1
                 continue
             st = torch.cuda.current_stream(flat.flat_p.device).cuda_stream if flat.flat_p.is_cuda else 0
             nv.call('segnb_sgd_step', nv.ptr(flat.flat_p), nv.ptr(flat.flat_g), flat.total, float(group['lr']), st)
@@ -121,14 +146,43 @@ class _FlatStateMixin(object):
         return loss
 
 
+def _sole_group(opt, flat, simple):
+    if len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if not simple(g) or len(g['params']) != len(flat._off):
+        return None
+    if any(FlatParams.registry.get(id(p)) is not flat for p in g['params']):
+        return None
+    return g
+
+
 class RMSprop(_FlatStateMixin, torch.optim.RMSprop):
+    @staticmethod
+    def _simple(g):
+        return g['momentum'] == 0 and g['weight_decay'] == 0 and not g['centered'] and not g.get('maximize')
+
+    def fusable_group(self, flat):
+        return _sole_group(self, flat, self._simple)
+
+    @torch.no_grad()
+    def step_range(self, flat, g, start, end, first):
+        st = self._flat_state(flat, ('square_avg',))
+        if first:
+            st['step'] += 1
+        nv.call('segnb_rmsprop_step', nv.ptr(flat.flat_p[start:end]), nv.ptr(flat.flat_g[start:end]),
+                nv.ptr(st['square_avg'][start:end]), end - start, float(g['lr']), float(g['alpha']), float(g['eps']),
+                _stream(flat))
+
     @torch.no_grad()
     def step(self, closure=None):
         def handle(g):
-            flat = _flat_of(g, g['momentum'] == 0 and g['weight_decay'] == 0 and not g['centered'] and
-                            not g.get('maximize'))
+            flat = _flat_of(g, self._simple(g))
             if flat is None:
                 return False
+            if _take_fused_token(flat):
+                flat.version += 1
+                return True
             st = self._flat_state(flat, ('square_avg',))
             st['step'] += 1
             nv.call('segnb_rmsprop_step', nv.ptr(flat.flat_p), nv.ptr(flat.flat_g), nv.ptr(st['square_avg']), flat.total,
@@ -139,12 +193,32 @@ class RMSprop(_FlatStateMixin, torch.optim.RMSprop):
 
 
 class Adam(_FlatStateMixin, torch.optim.Adam):
+    @staticmethod
+    def _simple(g):
+        return g['weight_decay'] == 0 and not g['amsgrad'] and not g.get('maximize')
+
+    def fusable_group(self, flat):
+        return _sole_group(self, flat, self._simple)
+
+    @torch.no_grad()
+    def step_range(self, flat, g, start, end, first):
+        st = self._flat_state(flat, ('exp_avg', 'exp_avg_sq'))
+        if first:
+            st['step'] += 1
+        b1, b2 = g['betas']
+        nv.call('segnb_adam_step', nv.ptr(flat.flat_p[start:end]), nv.ptr(flat.flat_g[start:end]),
+                nv.ptr(st['exp_avg'][start:end]), nv.ptr(st['exp_avg_sq'][start:end]), end - start, float(g['lr']),
+                float(b1), float(b2), float(g['eps']), int(st['step']), _stream(flat))
+
     @torch.no_grad()
     def step(self, closure=None):
         def handle(g):
-            flat = _flat_of(g, g['weight_decay'] == 0 and not g['amsgrad'] and not g.get('maximize'))
+            flat = _flat_of(g, self._simple(g))
             if flat is None:
                 return False
+            if _take_fused_token(flat):
+                flat.version += 1
+                return True
             st = self._flat_state(flat, ('exp_avg', 'exp_avg_sq'))
             st['step'] += 1
             b1, b2 = g['betas']
