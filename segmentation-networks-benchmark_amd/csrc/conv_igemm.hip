@@ -338,6 +338,102 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
 }
 
 // ================================================================================================
+// forward of FEW pixels x FEW output channels x VERY deep K (tiramisu.py:14 at the bottleneck: 8 x 16 x 16 pixels,
+// Ci ~ 1000, Co = 16 -- the block tiles above leave 16 blocks walking 140 K steps each: 175 us for 0.6 GFLOP).
+// Both MFMA operands are K-contiguous in HBM as they are (NHWC pixels, packed weights), and a 32 x 32 tile per wave
+// shares nothing with its neighbours, so there is no LDS staging: each of the 16 waves of a block owns every 16th
+// 16-element K unit of ONE 32-pixel x 32-channel tile, loads its fragments straight into registers (8 units in flight)
+// and the 16 partial tiles are summed through LDS in a fixed order.  No statistics / epilogue forms (callers that need
+// them take the general kernel).
+// ================================================================================================
+constexpr int DK_WAVES = 16, DK_DEPTH = 8;
+__global__ __launch_bounds__(DK_WAVES * 64) void conv_fprop_deepk_kernel(const FpropArgs a) {
+    __shared__ float sAcc[DK_WAVES][16][64];
+    const segnb_conv_geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m_base = blockIdx.x * 32, n_base = blockIdx.y * 32;
+    const __amdgpu_buffer_rsrc_t rsrc_in = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.w, a.w_bytes);
+    const int QHW = g.QH * g.QW;
+    // A row of this lane = pixel m_base + r; B row = output channel n_base + r
+    const int m = m_base + r;
+    const bool m_ok = m < a.M;
+    const int n = m_ok ? m / QHW : 0;
+    const int rem = m - n * QHW;
+    const int qh = rem / g.QW, qw = rem - qh * g.QW;
+    const int ph = qh * g.in_step, pw = qw * g.in_step;
+    const int co = n_base + r;
+    const unsigned b_row = co < g.Co ? (unsigned)(co * a.Ktot + h * 8) * 2u : OOB_OFFSET;
+    const int cpt = g.Ci >> 4;                       // 16-element units per tap
+    const int units = g.ntaps * cpt;
+    int tap = 0, c16 = wave;                         // this wave's next unit
+    while (c16 >= cpt) { c16 -= cpt; ++tap; }
+    unsigned a_row = OOB_OFFSET;
+    auto set_tap = [&]() {
+        a_row = OOB_OFFSET;
+        if (tap < g.ntaps && m_ok) {
+            const int hi = ph + g.dh[tap], wi = pw + g.dw[tap];
+            if ((unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi)
+                a_row = (unsigned)(((n * g.Hi + hi) * g.Wi + wi) * g.ld_in + h * 8) * 2u;
+        }
+    };
+    set_tap();
+    uint4 fa[DK_DEPTH], fb[DK_DEPTH];
+    auto issue = [&](int slot) {
+        const bool live = tap < g.ntaps;
+        fa[slot] = buf_load16(rsrc_in, live && a_row != OOB_OFFSET ? a_row + (unsigned)(c16 * 32) : OOB_OFFSET, 0);
+        fb[slot] = buf_load16(rsrc_w, live && b_row != OOB_OFFSET ? b_row + (unsigned)((tap * g.Ci + c16 * 16) * 2) : OOB_OFFSET, 0);
+        c16 += DK_WAVES;
+        if (c16 >= cpt) {
+            do { c16 -= cpt; ++tap; } while (c16 >= cpt);
+            set_tap();
+        }
+    };
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DK_DEPTH; ++i) issue(i);
+    const int rounds = (units + DK_WAVES * DK_DEPTH - 1) / (DK_WAVES * DK_DEPTH);
+    for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int i = 0; i < DK_DEPTH; ++i) {
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&fa[i]);
+            const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(&fb[i]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            issue(i);                                 // (past the last unit: out-of-range offsets, zeros)
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sAcc[wave][e][lane] = acc[e];
+    __syncthreads();
+    // thread -> accumulator element (e, lane) of the tile: 16 * 64 = the block's 1024 threads
+    const int e = tid >> 6;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DK_WAVES; ++w) v += sAcc[w][e][lane];
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int mo = m_base + row;
+    if (mo < a.M && co < g.Co) {
+        if (a.bias != nullptr && co < a.bias_n) v += a.bias[co];
+        const int no = mo / QHW;
+        const int ro = mo - no * QHW;
+        const int qho = ro / g.QW, qwo = ro - qho * g.QW;
+        const long long opix = (long long)(no * g.Ho + qho * g.out_step + g.oh0) * g.Wo + qwo * g.out_step + g.ow0;
+        reinterpret_cast<bf16_t*>(a.out)[opix * g.ld_out + co] = Elem<bf16_t>::from_f32(v);
+    }
+}
+
+static bool fprop_deepk_applies(const FpropArgs& a) {
+    if (!segnb_knob_fprop_deepk() || a.stats != nullptr || a.ep_act >= 0 || (a.g.Ci & 15) != 0 || a.Ktot < 2048) return false;
+    // the block tiles of the general kernel would leave more than half of the CUs without a block
+    const long long general_blocks = (long long)ceil_div(a.M, 128) * ceil_div(a.g.Co, a.g.Co <= 32 ? 32 : 64);
+    return general_blocks * 2 <= segnb_num_cus();
+}
+
+// ================================================================================================
 // weight gradient:  dW[co][k'] += sum_pixels dy[pix][co] * im2col(x)[pix][k']
 // GEMM view: M = Co, N = K' = ntaps*Ci, reduction over pixels (split across blocks, fp32 atomics).
 // Both operands are pixel-major in HBM but MFMA wants the reduction index contiguous per lane, so
@@ -948,6 +1044,12 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         if (rc == 0 && !general_only)
             rc = segnb_fprop_dma_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
                                      (hipStream_t)stream, ep);
+        if (rc == 0 && !general_only && fprop_deepk_applies(a)) {
+            // few pixels x few channels x deep K (before the halo-tile kernel below, whose blocks also walk K serially)
+            hipLaunchKernelGGL(conv_fprop_deepk_kernel, dim3(ceil_div(a.M, 32), ceil_div(g->Co, 32)), dim3(DK_WAVES * 64), 0,
+                               (hipStream_t)stream, a);
+            rc = 1;
+        }
         if (rc == 0 && !general_only && ep == nullptr)
             rc = segnb_fprop_s1_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
         if (rc == 1) {

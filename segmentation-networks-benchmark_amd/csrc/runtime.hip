@@ -200,6 +200,14 @@ int segnb_knob_conv_cus() {
 }
 static int g_wg_cu_pct = 0;        // 0 = SEGNB_WG_CU_FRACTION / built-in default; else % of the CUs for the wide weight gradients
 int segnb_knob_wg_cu_pct() { return g_wg_cu_pct; }
+static int g_fprop_deepk = -2;     // few pixels x few channels x deep K forwards on conv_fprop_deepk_kernel (1, default)
+int segnb_knob_fprop_deepk() {
+    if (g_fprop_deepk == -2) {
+        const char* e = getenv("SEGNB_FPROP_DEEPK");
+        g_fprop_deepk = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_deepk;
+}
 static int g_fprop_mf16 = -2;      // conv_fprop_ws_kernel on v_mfma_f32_16x16x32_bf16 (1, default) or 32x32x16 (0)
 int segnb_knob_fprop_mf16() {
     if (g_fprop_mf16 == -2) {
@@ -272,6 +280,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "bnreduce_fused") == 0) {
         g_bnreduce_fused = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "fprop_deepk") == 0) {
+        g_fprop_deepk = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_mf16") == 0) {

@@ -89,6 +89,10 @@ CONV_CASES = [
     ('3x3 s1x9 flat7',   6, 7, 7,   [(96, 96)],            72, 3, 1, 1, False),      # 4 images / iteration, ragged N
     ('3x3 s1x9 flat7 cat', 5, 7, 7, [(64, 64), (40, 40)],  136, 3, 1, 1, False),
     ('3x3 s1x9 flat14',  2, 14, 14, [(64, 64)],            64, 3, 1, 1, False),
+    # few pixels x few output channels x deep K: the register-direct split-K forward (conv_fprop_deepk_kernel)
+    ('3x3 deep K',       8, 16, 16, [(1040, 1040)],        16, 3, 1, 1, False),
+    ('3x3 deep K cat',   3, 9,  12, [(512, 512), (520, 528)], 16, 3, 1, 1, False),
+    ('1x1 deep K',       2, 8,  8,  [(2304, 2304)],        24, 1, 1, 0, False),
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
 ]
@@ -169,6 +173,61 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
         off += padded
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, dtype)
     check(name + ' dW vs torch', gw_g, wr.grad, 'f32' if dtype == 'f32' else 'bf16', scale=float(wr.grad.abs().max()))
+
+
+DEEPK_CASES = [c for c in CONV_CASES if 'deep K' in c[0]]
+
+
+@pytest.mark.parametrize('case', DEEPK_CASES, ids=[c[0] for c in DEEPK_CASES])
+def test_conv_fprop_deepk(case):
+    """conv_fprop_deepk_kernel (forward without statistics of few pixels x few channels x deep K: the FCDenseNet bottleneck
+    layers, tiramisu.py:14) against the general kernel it replaces, the emulator and F.conv2d; reproducible run to run."""
+    name, N, H, W, segs, Co, k, s, p, transposed = case
+    Ci = sum(r for r, _ in segs)
+    gen = torch.Generator().manual_seed(hash(name) % 1000)
+    w = (torch.randn((Co, Ci, k, k), generator=gen) * (2.0 / (Ci * k * k)) ** 0.5).bfloat16().float()
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, H, W, generator=gen).bfloat16().float()
+
+    def run(device):
+        rt = Runtime(device, 'bf16')
+        op = ConvOp(rt, w.to(device), b.to(device), segs, s, p, transposed, need_dgrad=False)
+        op.pack(H, W)
+        Ho, Wo = op.out_hw(H, W)
+        ld_in = op.Cip + 8
+        xbuf = rt.zeros((N, H, W, ld_in))
+        xv = View(xbuf, N, H, W, op.Cip, ld_in, 8)
+        off, roff = 0, 0
+        for real, padded in segs:
+            xv.dense()[..., off:off + real] = x[:, roff:roff + real].permute(0, 2, 3, 1).to(device, rt.tdtype)
+            off += padded
+            roff += real
+        ybuf = rt.zeros((N, Ho, Wo, op.Cop + 16))
+        ybuf.fill_(7.0)
+        yv = View(ybuf, N, Ho, Wo, op.Cop, op.Cop + 16, 8)       # a channel slice of a wider buffer
+        op.fprop(xv, yv, None)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return yv.dense().float().cpu(), ybuf.float().cpu()
+
+    outs = {}
+    for knob in (1, 0, 1):
+        nv.call('segnb_tune', b'fprop_deepk', knob)
+        try:
+            outs.setdefault(knob, []).append(run('cuda'))
+        finally:
+            nv.call('segnb_tune', b'fprop_deepk', 1)
+    (y1, buf1), (y1b, _) = outs[1]
+    y0, _ = outs[0][0]
+    assert torch.equal(y1, y1b)                                      # fixed summation order
+    assert float(buf1[..., :8].min()) == 7.0 and float(buf1[..., 8 + y1.shape[-1]:].min()) == 7.0     # nothing outside the slice
+    with on_emulator():
+        ye, _ = run('cpu')
+    check(name + ' deepk vs general', y1, y0, 'bf16')
+    check(name + ' deepk vs emulator', y1, ye, 'bf16')
+    yr = F.conv2d(x, w, b, stride=s, padding=p)
+    check(name + ' deepk vs torch', y1[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    assert float(y1[..., Co:].abs().max()) == 0.0 if y1.shape[-1] > Co else True
 
 
 # ------------------------------------------------------------------------------------------------------
