@@ -231,6 +231,14 @@ int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int N, int H, i
                              float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
                              const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream);
 
+/* The same with dy += result instead of dy = result: the input of a PRE-activation BatchNorm (tiramisu.py:12-13) has
+ * other consumers, whose gradients are already in dy -- the separate segnb_add pass of the accumulation folded in (the
+ * result, rounded to the storage type, is added to the stored value as segnb_add would).  dz must not alias dy. */
+int segnb_bn_bwd_apply_fused_acc(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                 const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                 float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
+                                 const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream);
+
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */
 int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,

@@ -479,6 +479,16 @@ class AbiEmulator(object):
         return rc or self.segnb_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, None, C,
                                              stream)
 
+    def segnb_bn_bwd_apply_fused_acc(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                     accumulate, clear_stats, dz, ld_dz, dy, ld_dy, stream):
+        dt = _tdt(dtype)
+        old = _nhwc(dy, N, H, W, Cp, ld_dy, dt).clone()
+        rc = self.segnb_bn_bwd_apply_fused(dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                           accumulate, clear_stats, dz, ld_dz, dy, ld_dy, stream)
+        o = _nhwc(dy, N, H, W, Cp, ld_dy, dt)
+        o.copy_((old.float() + o.float()).to(dt))
+        return rc
+
     def segnb_bn_bwd_apply_fused_direct(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
                                         accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream):
         keep = _mem(sums, REPL * 2 * Cp, torch.float64).clone()

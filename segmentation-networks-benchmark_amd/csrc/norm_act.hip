@@ -567,7 +567,7 @@ __global__ void bn_bwd_finalize_kernel(const BnBwdParams p, const float* __restr
     p.bcoef[2 * Cp + c] = c2;
 }
 
-template <typename T>
+template <typename T, bool ACC = false>       // ACC: dy += result (gradient of a multi-consumer tensor: no separate segnb_add pass)
 __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict__ y, int ld_y, EwShape s,
                                                             const float* __restrict__ coef,
                                                             const float* __restrict__ bcoef,
@@ -657,6 +657,12 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
                     const float yh = (yv[u][e] - mu[e]) * is[e];
                     d[u][e] = round_as(a[e] * (d[u][e] - c1[e] - yh * c2[e]), dy);
                     sb[e] += d[u][e];
+                }
+                if constexpr (ACC) {          // (the rounded result added to the stored gradient, as segnb_add would)
+                    float old[8];
+                    load8(dy + (pix0 + u * stride) * ld_dy + c0, old);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[u][e] = __fadd_rn(old[e], d[u][e]);      // (no contraction with the product above)
                 }
                 store8(dy + (pix0 + u * stride) * ld_dy + c0, d[u]);
             }
@@ -1025,12 +1031,20 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
 static int launch_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                                const float* bcoef, const void* dz, int ld_dz, void* dy, int ld_dy, float* dbias, int C,
                                const BnBwdParams& bp, const char* who, segnb_stream_t stream, const void* g = nullptr,
-                               int ld_g = 0, int act = 0, float slope = 0.f) {
+                               int ld_g = 0, int act = 0, float slope = 0.f, bool acc = false) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y && coef && (bcoef || bp.bcoef) && (dz || g) && dy, "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
     const dim3 grid = make_grid(s, (long long)N * H * W, 1536);
-    if (dtype == SEGNB_BF16)
+    if (acc && dtype == SEGNB_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+                           ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp,
+                           (const bf16_t*)g, ld_g, act, slope);
+    else if (acc && dtype == SEGNB_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
+                           ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp,
+                           (const float*)g, ld_g, act, slope);
+    else if (dtype == SEGNB_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp,
                            (const bf16_t*)g, ld_g, act, slope);
@@ -1074,6 +1088,18 @@ extern "C" int segnb_bn_bwd_apply_fused(int dtype, const void* y, int ld_y, int 
     BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, dz, ld_dz, dy, ld_dy, nullptr, C, bp,
                                "segnb_bn_bwd_apply_fused", stream);
+}
+
+extern "C" int segnb_bn_bwd_apply_fused_acc(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                            const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                            float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
+                                            const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_fused_acc, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, dz, ld_dz, dy, ld_dy, stream);
+    SEGNB_CHECK_ARG(sums != nullptr && bcoef != nullptr && C > 0 && Cp >= C, "missing sums / coefficient buffer");
+    SEGNB_CHECK_ARG(dz != nullptr && dz != dy, "the accumulating form needs dz in a buffer of its own");
+    BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
+    return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, dz, ld_dz, dy, ld_dy, nullptr, C, bp,
+                               "segnb_bn_bwd_apply_fused_acc", stream, nullptr, 0, 0, 0.f, true);
 }
 
 extern "C" int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,

@@ -49,12 +49,30 @@ class Tape(object):
         self._unpack_pending = []
         self._drop_sites, self._drop_pools = {}, {}
         self.plans = {}            # recorded launch lists (HipNet._run / _run_backward)
+        # forward statistics that segnb_bn_fwd_fused left for this step's backward to clear (segnb_bn_bwd_apply_fused*):
+        # if that backward never runs, begin() clears them before the next forward accumulates on top
+        self.fused_stats, self.stats_pending = [], False
+
+    # BatchNorm finalize folded into the activation / apply launches of a differentiated training forward (one launch less
+    # per layer and direction; A/B: SEGNB_FUSE_FINALIZE=0)
+    fuse_finalize = os.environ.get('SEGNB_FUSE_FINALIZE', '1') != '0'
+
+    def fuses_finalize(self):
+        return self.fuse_finalize and self.train and self.need_grad
+
+    def note_fused_stats(self, stats):
+        self.fused_stats.append(stats)
 
     # ---- per-step bookkeeping ------------------------------------------------------------------------------
     def begin(self, train, need_grad):
         self.flat.ensure(self.rt.device)
+        if self.stats_pending:                      # the differentiated forward before this one had no backward
+            for t in self.fused_stats:
+                t.zero_()
+            self.stats_pending = False
         self.train, self.need_grad = train, need_grad
         self.back, self._seq = [], 0
+        self.fused_stats = []
         for p, pool in self._drop_pools.items():
             pool['drawn'] = pool['used'] if train else 0
             if train and pool['used']:
@@ -128,6 +146,7 @@ class Tape(object):
         for fn in reversed(self.back):
             fn()
         self.back = []
+        self.stats_pending = False
         self.rt.join_side()               # the weight gradients ran on the side stream
 
     def run_unpack(self):
@@ -247,22 +266,38 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         return oa
     conv.fprop(xv, y, stats if use_batch_stats else None)
     coef = None
-    if has_bn:
-        gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
-        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
-                nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
-                nv.ptr(coef_buf), rt.stream)
-        coef = coef_buf
     ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
     pv = (pool_out if pool_out is not None else tape.view(site + '/p', N, Ho // 2, Wo // 2, Cp)) if pool else None
-    nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
-            ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
-            0 if res is None else res.v.ld, rt.stream)
+    fused_bn = has_bn and tape.fuses_finalize()
+    if fused_bn:
+        # finalize + activation pass in one launch; the statistics stay for this layer's backward to clear, the
+        # backward sums are cleared here (segnb_bn_fwd_fused / segnb_bn_bwd_apply_fused, include/segnb_hip.h)
+        gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+        sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+        nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(stats), nv.ptr(gamma.detach()),
+                nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef_buf), nv.ptr(sums_f),
+                act, slope, nv.ptr(dropmul), ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0,
+                None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
+        tape.note_fused_stats(stats)
+        coef = coef_buf
+    else:
+        if has_bn:
+            gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
+                    nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
+                    nv.ptr(coef_buf), rt.stream)
+            coef = coef_buf
+        nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+                ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
+                0 if res is None else res.v.ld, rt.stream)
     oa = Act(ov)
     pa = Act(pv) if pool else None
 
     def backward():
         if oa.g is None and (pa is None or pa.g is None):
+            if fused_bn:                     # nothing will clear the forward statistics: not a replayable backward
+                stats.zero_()
+                tape.unplannable = True
             return
         flat = tape.flat
         dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
@@ -276,12 +311,17 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         dy = dz
         if has_bn:
             gamma = bn.weight
-            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, nv.ptr(gamma.detach()), nv.ptr(coef_buf),
-                    nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
             if res is not None:             # dz is also the residual branch's gradient: keep it intact
                 dy = tape.view(site + '/dy', N, Ho, Wo, Cp)
-            nv.call('segnb_bn_bwd_apply', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef_buf), nv.ptr(bcoef),
-                    dz.ptr, dz.ld, dy.ptr, dy.ld, None, C, rt.stream)
+            if fused_bn:
+                nv.call('segnb_bn_bwd_apply_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf), nv.ptr(sums),
+                        nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)),
+                        nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats), dz.ptr, dz.ld, dy.ptr, dy.ld, rt.stream)
+            else:
+                nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, nv.ptr(gamma.detach()), nv.ptr(coef_buf),
+                        nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
+                nv.call('segnb_bn_bwd_apply', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef_buf), nv.ptr(bcoef),
+                        dz.ptr, dz.ld, dy.ptr, dy.ld, None, C, rt.stream)
         else:
             gb = flat.grad_of(bias) if bias is not None else None
             nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, None, nv.ptr(coef_buf), nv.ptr(bcoef),
@@ -318,15 +358,26 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
     coef = tape.small(site + '/coef', (4, Cp), torch.float32)
     if tape.train:
         nv.call('segnb_bn_stats', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
-    nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(beta.detach()),
-            eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0, nv.ptr(coef), rt.stream)
     ov = tape.view(site + '/a', N, H, W, Cp)
-    nv.call('segnb_bn_act_fwd', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None, ov.ptr, ov.ld,
-            None, 0, None, 0, None, 0, rt.stream)
+    fused = tape.fuses_finalize()
+    if fused:
+        sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+        nv.call('segnb_bn_fwd_fused', rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(stats), nv.ptr(gamma.detach()),
+                nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums_f), act,
+                slope, None, ov.ptr, ov.ld, None, 0, None, 0, None, 0, rt.stream)
+        tape.note_fused_stats(stats)
+    else:
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(beta.detach()),
+                eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0, nv.ptr(coef), rt.stream)
+        nv.call('segnb_bn_act_fwd', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None, ov.ptr, ov.ld,
+                None, 0, None, 0, None, 0, rt.stream)
     oa = Act(ov)
 
     def backward():
         if oa.g is None:
+            if fused:
+                stats.zero_()
+                tape.unplannable = True
             return
         flat = tape.flat
         dz = tape.view(site + '/dz', N, H, W, Cp)
@@ -334,6 +385,17 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
         nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
                 oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+        if fused:
+            fargs = (rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()),
+                     nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats),
+                     dz.ptr, dz.ld)
+            if x.needs_grad and x.g is not None:
+                # the input has other consumers whose gradients are already in x.g: accumulate there (no segnb_add pass)
+                nv.call('segnb_bn_bwd_apply_fused_acc', *(fargs + (x.g.ptr, x.g.ld, rt.stream)))
+            else:
+                nv.call('segnb_bn_bwd_apply_fused', *(fargs + (dz.ptr, dz.ld, rt.stream)))
+                tape.contribute(x, dz)
+            return
         nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(coef),
                 nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
         nv.call('segnb_bn_bwd_apply', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,
@@ -559,6 +621,8 @@ class HipNet(nn.Module):
                 if ent['state'] == 'ready':
                     nv.call('segnb_plan_run', ent['fwd'])
                     tape.back = []
+                    tape.fused_stats = ent['fused_stats']
+                    tape.stats_pending = bool(tape.fused_stats)
                     self._plan_live = ent if need_grad else None
                     return ent['logits'].clone()
                 if ent['state'] == 'seen' or (ent['state'] == 'fwd' and need_grad):
@@ -569,13 +633,16 @@ class HipNet(nn.Module):
         xin = tape.view('input', N, H, W, cin_p)
         pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         self._dlogits = [None]
+        tape.unplannable = False
         logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
+        tape.stats_pending = bool(tape.fused_stats)
         if recording:
             handle, nops = nv.plan_record_end()
             if handle is None:
                 ent['state'] = 'eager'                                     # not replayable: remembered
             else:
-                ent.update(fwd=handle, logits=logits, nfwd=nops, state='fwd' if need_grad else 'ready')
+                ent.update(fwd=handle, logits=logits, nfwd=nops, state='fwd' if need_grad else 'ready',
+                           fused_stats=list(tape.fused_stats))
                 self._plan_live = ent if need_grad else None
         return logits.clone()
 
@@ -597,6 +664,7 @@ class HipNet(nn.Module):
         if ent is not None and ent['state'] == 'ready':
             nv.call('segnb_plan_run', ent['bwd'])
             tape.rt._side_busy = False
+            tape.stats_pending = False
             if ent['unpack'] is not None:
                 ent['unpack'].run()
         else:
@@ -607,7 +675,9 @@ class HipNet(nn.Module):
             tape.run_closures()
             if recording:
                 handle, nops = nv.plan_record_end()
-                if handle is None:
+                if handle is None or getattr(tape, 'unplannable', False):
+                    if handle is not None:
+                        nv.call('segnb_plan_destroy', handle)
                     self._plan_drop(ent)
                     ent['state'] = 'eager'
                 else:

@@ -394,6 +394,19 @@ def test_bn_fused_finalize_equals_separate_launches(case, dtype):
                     nv.ptr(gamma), nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), dz.ptr, dz.ld, dy.ptr,
                     dy.ld, rt.stream)
             assert float(stats.abs().max()) == 0.0
+            # the accumulating form (gradient of a multi-consumer input): old + result == segnb_add of the two
+            prior = _view_from(rt, torch.randn(N, H, W, C, generator=gen), Cp)
+            want = View.alloc(rt, N, H, W, Cp)
+            nv.call('segnb_add', rt.code, prior.ptr, prior.ld, dy.ptr, dy.ld, want.ptr, want.ld, N, H, W, Cp, rt.stream)
+            dg2, db2, bc2 = torch.ones(C, device='cuda'), torch.ones(C, device='cuda'), rt.zeros((3, Cp), torch.float32)
+            nv.call('segnb_bn_bwd_apply_fused_acc', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums),
+                    nv.ptr(gamma), nv.ptr(bc2), nv.ptr(dg2), nv.ptr(db2), 1, None, dz.ptr, dz.ld, prior.ptr, prior.ld,
+                    rt.stream)
+            torch.cuda.synchronize()
+            assert torch.equal(dg2, dgam) and torch.equal(bc2, bcoef)
+            # (bf16: bit for bit; fp32: the two instantiations may contract the BatchNorm expression differently -- one ulp)
+            err = float((prior.dense().float() - want.dense().float()).abs().max())
+            assert err == 0.0 if dtype == 'bf16' else err <= 2.5e-7 * float(want.dense().abs().max()), err
         else:
             nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma), nv.ptr(coef),
                     nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, rt.stream)

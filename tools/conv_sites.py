@@ -86,6 +86,15 @@ def main():
         a[1] += us
         a[2] += fl
     print('%s B=%d %dx%d: per-kind totals (us): %s' % (args.model, B, S, S, '  '.join('%s %.0f' % kv for kv in tot.items())))
+    buckets = {}
+    for kind, geom, us, fl in rows:
+        size = geom.split(' in ')[1].split(' ')[0]
+        b = buckets.setdefault((kind, geom.split(' ')[0] + ' ' + geom.split(' ')[1], size), [0, 0.0])
+        b[0] += 1
+        b[1] += us
+    print('buckets (kind, kernel, input size): launches, total us')
+    for k, (n, us) in sorted(buckets.items(), key=lambda kv: -kv[1][1])[:30]:
+        print('  %-6s %-10s %-9s x%-3d %8.1f us' % (k[0], k[1], k[2], n, us))
     for (kind, geom), (n, us, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
         print('%-6s %-46s x%-3d %8.1f us total %8.1f us each %7.1f TF/s' % (kind, geom, n, us, us / n, fl / us / 1e6))
 
