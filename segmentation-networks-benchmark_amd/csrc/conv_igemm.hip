@@ -951,7 +951,10 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     a.total_steps = ceil_div(a.M, BKP);
     const int tiles = a.MT * a.NTL;
     const int cus = segnb_num_cus();
-    int S = (cus * 2 + tiles - 1) / tiles;
+    // blocks per CU the pixel range is split for (measured on LinkNet34's 7x7 / transposed / 2x2 layers: 2 -> 5.53 ms of
+    // weight gradients per step, 4 -> 5.19 ms, 8 -> 5.10 ms; step 10.7 -> 10.3 ms at 4)
+    static const int per_cu = getenv("SEGNB_WG_GENERAL_PER_CU") ? atoi(getenv("SEGNB_WG_GENERAL_PER_CU")) : 4;
+    int S = (cus * per_cu + tiles - 1) / tiles;
     if (S < 1) S = 1;
     // keep at least 4 K steps per split so the pipeline prologue amortises
     const int maxS = a.total_steps / 4 > 0 ? a.total_steps / 4 : 1;
