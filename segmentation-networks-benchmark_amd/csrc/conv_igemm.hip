@@ -623,6 +623,89 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // ================================================================================================
+// weight gradient of a convolution with AT MOST 8 output channels (one 16-byte group of dy): the heads that are a general
+// convolution (linknet.py:62: 2x2, 32 -> 1 at 512 x 512).  The MFMA tiles above are built for wide dW matrices; here dW is
+// 8 x (taps * Ci) numbers and the work is one pass over x and dy -- HBM-bound.  Plain FMAs: thread = (tap, 8-channel group
+// of x) x pixel lane, 8 x 8 accumulators; a block walks whole output rows (no per-pixel division), x is fetched as
+// contiguous 64-byte pixel rows by neighbouring threads, dy as one broadcast 16-byte load.  Partial sums meet in LDS, then
+// in the workspace, with fp32 atomics (as in the general kernel).
+// ================================================================================================
+__global__ __launch_bounds__(NT) void conv_wgrad_co8_kernel(const WgradArgs a, int nslot, int PL) {
+    __shared__ float sAcc[NT * 64 / 4];      // [nslot][64] <= 64 slots x 64 when PL >= 4; larger slot counts loop below
+    const segnb_conv_geom& g = a.g;
+    const int tid = threadIdx.x;
+    const int slot = tid % nslot, pl = tid / nslot;
+    const bool live = pl < PL;
+    const int cpt = g.Ci >> 3;
+    const int tap = slot / cpt, chunk = slot - tap * cpt;
+    const int dh = g.dh[tap], dw = g.dw[tap];
+    const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.in);
+    const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dout);
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    const int rows = g.N * g.QH;
+    for (int row = blockIdx.x; row < rows && live; row += gridDim.x) {
+        const int n = row / g.QH, qh = row - n * g.QH;
+        const int hi = qh * g.in_step + dh;
+        if ((unsigned)hi >= (unsigned)g.Hi) continue;
+        const bf16_t* xr = x + (long long)(n * g.Hi + hi) * g.Wi * g.ld_in + chunk * 8;
+        const bf16_t* dr = dy + ((long long)(n * g.Ho + qh * g.out_step + g.oh0) * g.Wo + g.ow0) * g.ld_out;
+        // four pixels per trip, all eight loads issued before the first FMA
+        for (int qw0 = pl; qw0 < g.QW; qw0 += 4 * PL) {
+            float xv[4][8], dv[4][8];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qw = qw0 + u * PL;
+                const int wi = qw * g.in_step + dw;
+                ok[u] = qw < g.QW && (unsigned)wi < (unsigned)g.Wi;
+                const int qs = ok[u] ? qw : 0, ws = ok[u] ? wi : 0;
+                load8(xr + (long long)ws * g.ld_in, xv[u]);
+                load8(dr + (long long)qs * g.out_step * g.ld_out, dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(dv[u][i], xv[u][j], acc[i][j]);
+            }
+        }
+    }
+    // slots in groups that fit the LDS array
+    const int per_pass = (NT * 64 / 4) / 64;          // 64 slots per pass
+    for (int s0 = 0; s0 < nslot; s0 += per_pass) {
+        for (int i = tid; i < per_pass * 64; i += NT) sAcc[i] = 0.f;
+        __syncthreads();
+        if (live && slot >= s0 && slot < s0 + per_pass) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(&sAcc[(slot - s0) * 64 + i * 8 + j], acc[i][j]);
+        }
+        __syncthreads();
+        const int n_here = nslot - s0 < per_pass ? nslot - s0 : per_pass;
+        for (int i = tid; i < n_here * 64; i += NT) {
+            const int sl = s0 + i / 64, co = (i >> 3) & 7, ci = i & 7;
+            const int t = sl / cpt, ch = sl - t * cpt;
+            const float v = sAcc[i];
+            if (v != 0.f) atomicAdd(&a.dwp[(long long)co * a.Ktot + t * g.Ci + ch * 8 + ci], v);
+        }
+        __syncthreads();
+    }
+}
+
+static bool wgrad_co8_applies(const segnb_conv_geom* g) {
+    static const bool off = getenv("SEGNB_WGRAD_CO8") != nullptr && getenv("SEGNB_WGRAD_CO8")[0] == '0';
+    const int nslot = g->ntaps * (g->Ci / 8);
+    return !off && g->Co == 8 && nslot <= NT && (long long)g->N * g->QH * g->QW >= 1024;
+}
+
+// ================================================================================================
 // weight pack / gradient unpack
 // ================================================================================================
 struct PackArgs {
@@ -1143,7 +1226,13 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
             return 0;
         }
         if (rc != 0) return rc;
-        rc = dispatch_wgrad<bf16_t>(a, (hipStream_t)stream);
+        if (wgrad_co8_applies(g)) {
+            const int nslot = g->ntaps * (g->Ci / 8), PL = NT / nslot;
+            int grid = segnb_num_cus() * 8;
+            if (grid > g->N * g->QH) grid = g->N * g->QH;
+            hipLaunchKernelGGL(conv_wgrad_co8_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a, nslot, PL);
+        } else
+            rc = dispatch_wgrad<bf16_t>(a, (hipStream_t)stream);
     } else if (dtype == SEGNB_F32)
         rc = dispatch_wgrad<float>(a, (hipStream_t)stream);
     else {

@@ -93,6 +93,10 @@ CONV_CASES = [
     ('3x3 deep K',       8, 16, 16, [(1040, 1040)],        16, 3, 1, 1, False),
     ('3x3 deep K cat',   3, 9,  12, [(512, 512), (520, 528)], 16, 3, 1, 1, False),
     ('1x1 deep K',       2, 8,  8,  [(2304, 2304)],        24, 1, 1, 0, False),
+    # at most 8 output channels, >= 1024 output pixels: the FMA weight-gradient kernel (conv_wgrad_co8_kernel)
+    ('2x2 head co1',     2, 40, 48, [(32, 32)],            1,  2, 1, 1, False),
+    ('3x3 co6 cat',      1, 36, 40, [(12, 16), (6, 8)],    6,  3, 1, 1, False),
+    ('3x3 s2 co8',       2, 48, 40, [(16, 16)],            8,  3, 2, 1, False),
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
 ]
