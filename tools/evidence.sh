@@ -1,0 +1,31 @@
+#!/bin/bash
+# The measurement set behind profiles/rNN_*: run on the GPU box from the repository root as
+#     bash tools/evidence.sh r02
+# Writes under gpurun_out/<tag>_*; the summaries that are judged are then copied into profiles/ (tools/evidence_collect.py).
+# rocprofv3: the python program directly after "--" (no env / bash -c hop), counters in passes of their own.
+set -u
+TAG=${1:-r02}
+R=$(pwd)
+O=$R/gpurun_out
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+python3 $R/bench.py --size 512 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_512.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/${TAG}_prof_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq2.log 2>&1
+cd $R
+python3 tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
+python3 tools/pmc_summary.py $O/${TAG}_pmc_sq1 conv_ > $O/${TAG}_pmc_conv_issue_wait.txt 2>&1
+python3 tools/pmc_summary.py $O/${TAG}_pmc_sq2 conv_ > $O/${TAG}_pmc_conv_lds.txt 2>&1
+find $O/${TAG}_prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_bench_bs32_kernel_stats.csv
+python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
+python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
+python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
+python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
+python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
+for m in linknet34 fcdensenet103 unet16; do python3 bench.py --model $m --no-cpu-baseline >> $O/${TAG}_bench_models.json 2>/dev/null; done
+rm -rf $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq1 $O/${TAG}_pmc_sq2 $O/${TAG}_prof_stats
+echo evidence done

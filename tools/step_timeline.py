@@ -6,6 +6,8 @@ import argparse
 import os
 import sys
 
+os.environ['SEGNB_CPLAN'] = '0'      # the marks hook the Python launcher (join_side); the replayed lists issue the same launches
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'segmentation-networks-benchmark_amd'))
 sys.path.insert(0, ROOT)
