@@ -16,6 +16,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq2.log 2>&1
+for m in linknet34 fcdensenet103; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_$m -- python3 $R/bench.py --model $m --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_prof_$m.log 2>&1
+  find $O/${TAG}_prof_$m -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_${m}_kernel_stats.csv
+  rm -rf $O/${TAG}_prof_$m
+done
 cd $R
 python3 tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
 python3 tools/pmc_summary.py $O/${TAG}_pmc_sq1 conv_ > $O/${TAG}_pmc_conv_issue_wait.txt 2>&1
@@ -26,6 +31,8 @@ python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
 python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
 python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
+python3 tools/conv_sites.py --model linknet34 --top 30 > $O/${TAG}_conv_sites_linknet34.txt 2>&1
+python3 tools/conv_sites.py --model fcdensenet103 --top 30 > $O/${TAG}_conv_sites_fcdensenet103.txt 2>&1
 for m in linknet34 fcdensenet103 unet16; do python3 bench.py --model $m --no-cpu-baseline >> $O/${TAG}_bench_models.json 2>/dev/null; done
 rm -rf $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq1 $O/${TAG}_pmc_sq2 $O/${TAG}_prof_stats
 echo evidence done
