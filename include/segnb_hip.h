@@ -405,6 +405,8 @@ int segnb_plan_run(void* plan);
 int segnb_plan_destroy(void* plan);
 int segnb_stream_fork(segnb_stream_t main_stream, segnb_stream_t side_stream);
 int segnb_stream_join(segnb_stream_t main_stream, segnb_stream_t side_stream);
+/* hipEventRecord(event, stream) as a recordable call: timing events inside a replayed launch list (bench.py) */
+int segnb_event_record(void* event, segnb_stream_t stream);
 
 #ifdef __cplusplus
 }

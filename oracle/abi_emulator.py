@@ -703,6 +703,9 @@ class AbiEmulator(object):
     def segnb_stream_fork(self, main, side):
         return 0
 
+    def segnb_event_record(self, event, stream):
+        return 0
+
     def segnb_stream_join(self, main, side):
         return 0
 

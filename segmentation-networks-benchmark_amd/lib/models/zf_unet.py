@@ -303,11 +303,12 @@ class _ZFUnetPlan(object):
     def _cplan_key(self, kind, N, H, W, train, need_grad, drop):
         from segnb import engine
         rt = self.rt
-        if (not self.use_cplan or rt.device.type != 'cuda' or engine.TIMER is not None or self.BWD_CONV_CU_PCT != 100):
+        if not self.use_cplan or rt.device.type != 'cuda' or self.BWD_CONV_CU_PCT != 100:
             return None
         side = rt.side_stream()
         return (kind, N, H, W, bool(train), bool(need_grad), tuple(n for n in ENCODER + DECODER if drop[n] is not None),
                 getattr(self.module, '_grad_ready_hook', None) is not None,
+                id(engine.TIMER),                     # (its event records are part of the list recorded under it)
                 rt.stream, side.cuda_stream if side is not None else 0, self.flat.flat_p.data_ptr(),
                 self.flat.flat_g.data_ptr(), tuple(p.data_ptr() for p in self.flat.buffer_list()))
 
@@ -318,6 +319,9 @@ class _ZFUnetPlan(object):
     _rec = None
 
     def _plan_begin(self):
+        from segnb import engine
+        if engine.TIMER is not None:
+            engine.TIMER.persistent = True
         self._rec = []
         nv.plan_record_begin()
 

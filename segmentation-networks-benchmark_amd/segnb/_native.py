@@ -108,6 +108,7 @@ SIGNATURES = {
     'segnb_plan_run': [_P],
     'segnb_plan_destroy': [_P],
     'segnb_stream_fork': [_P, _P],
+    'segnb_event_record': [_P, _P],
     'segnb_stream_join': [_P, _P],
     'segnb_debug_stamps': [_P],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],

@@ -25,22 +25,34 @@ class KernelTimer(object):
 
     def __init__(self):
         self.records = []      # (label, algorithmic_flops, start_event, end_event)
+        self.acc = {}
+        self.persistent = False    # the events are part of a recorded launch list: re-recorded by every replay
 
     def launch(self, label, flops, fn):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
+        a.record()             # (creates the HIP event; recorded again below through the ABI)
         b.record()
+        st = torch.cuda.current_stream().cuda_stream
+        # through the ABI, so that a launch list being recorded contains the two records around the launch
+        nv.call('segnb_event_record', a.cuda_event, st)
+        fn()
+        nv.call('segnb_event_record', b.cuda_event, st)
         self.records.append((label, flops, a, b))
+
+    def collect(self):
+        """After a device synchronize at the end of a step: add the step's launch durations to the totals."""
+        for label, flops, a, b in self.records:
+            n, ms, fl = self.acc.get(label, (0, 0.0, 0.0))
+            self.acc[label] = (n + 1, ms + a.elapsed_time(b), fl + flops)
+        if not self.persistent:
+            self.records = []
 
     def summary(self):
         """{label: (launches, total_ms, total_flops)} -- call after a device synchronize."""
-        out = {}
-        for label, flops, a, b in self.records:
-            n, ms, fl = out.get(label, (0, 0.0, 0.0))
-            out[label] = (n + 1, ms + a.elapsed_time(b), fl + flops)
-        return out
+        if self.records and not self.persistent:
+            self.collect()
+        return dict(self.acc)
 
 
 TIMER = None
