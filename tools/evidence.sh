@@ -29,6 +29,7 @@ find $O/${TAG}_prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {}
 python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
 python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
+python3 tools/insitu.py > $O/${TAG}_insitu.txt 2>&1
 python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
 python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
 python3 tools/conv_sites.py --model linknet34 --top 30 > $O/${TAG}_conv_sites_linknet34.txt 2>&1
