@@ -342,7 +342,7 @@ def test_uint8_first_layer_kernel_bitwise_vs_packed_path():
 
 def test_launch_plan_replay_matches_eager_and_cuts_host_time():
     """segnb_plan_*: the forward / backward launch lists replayed from C.  Same steps with the
-    replay on and off: losses, BatchNorm buffers and parameters (after two steps, to 1e-5) agree -- not bitwise: the head's
+    replay on and off: losses, BatchNorm buffers and parameters (after two steps, to 5e-4) agree -- not bitwise: the head's
     weight gradient is summed with fp32 atomics, dropout and changing inputs flow through the recorded lists, and the host enqueues a step in
     under a third of the eager launcher's time."""
     import time
@@ -401,7 +401,8 @@ def test_launch_plan_replay_matches_eager_and_cuts_host_time():
     assert float((e1 - f1).abs().max()) > 0          # the second eval input really went through the replayed list
     for k in s0:
         if s0[k].is_floating_point():
-            assert float((s1[k] - s0[k]).abs().max()) <= 1e-5 * float(s0[k].abs().max()) + 1e-7, k
+            # (two eager runs differ by up to ~5e-5 of a first-layer weight here: atomics order amplified down the backward chain)
+            assert float((s1[k] - s0[k]).abs().max()) <= 5e-4 * float(s0[k].abs().max()) + 1e-6, k
     print('host enqueue per step: replayed %.2f ms, eager %.2f ms' % (host[True], host[False]))
     assert host[True] < 0.85 * host[False]          # (0.55-0.6 measured; a wide margin: the box may be busy)
 
