@@ -787,7 +787,11 @@ class FlatParams(object):
             FlatParams.registry[id(p)] = self
 
     def grad_of(self, p):
+        if self.touch_log is not None:
+            self.touch_log.add(id(p))
         return self._gviews[id(p)]
+
+    touch_log = None       # a set while a backward learns which closure finishes which parameters (segnb.net.Tape)
 
     def grad_absmax(self):
         """max |g| over every parameter gradient, as a 0-dim device tensor: ONE launch over the flat gradient buffer

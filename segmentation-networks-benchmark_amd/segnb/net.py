@@ -45,8 +45,9 @@ class Tape(object):
         self.convs = []
         self._conv_seen = set()
         self._pack_table = None
-        self._unpack_table = None
+        self._unpack_tables = {}
         self._unpack_pending = []
+        self._cuts = {}
         self._drop_sites, self._drop_pools = {}, {}
         self.plans = {}            # recorded launch lists (HipNet._run / _run_backward)
         # forward statistics that segnb_bn_fwd_fused left for this step's backward to clear (segnb_bn_bwd_apply_fused*):
@@ -142,24 +143,88 @@ class Tape(object):
         self.run_closures()
         self.run_unpack()
 
-    def run_closures(self):
-        for fn in reversed(self.back):
+    # ---- gradients handed to the data-parallel hook while backward is still running -----------------------------------
+    # Parameters sit in the flat buffer in registration (= forward) order and the closures run in reverse, so the END of
+    # the flat gradient buffer is final first.  The first backward under an active data-parallel hook learns, per closure,
+    # the frontier "every gradient at flat offset >= lo is final after this closure" (FlatParams.touch_log: which
+    # parameters a closure writes); later backwards stop at the closures where the frontier passes 2/3 and 1/3 of the
+    # buffer, unpack the weight gradients launched so far (behind them, on the weight-gradient stream) and call
+    # model._grad_ready_hook(flat, lo, producers) -- segnb.dist.DataParallel.grads_ready starts the all-reduce of the
+    # finished buckets beside the rest of backward (ZF_UNET does the same with its fixed groups).
+    CUT_FRACTIONS = (2.0 / 3.0, 1.0 / 3.0)
+
+    def _ready_hook(self):
+        hook = getattr(self.module, '_grad_ready_hook', None)
+        if hook is None or not getattr(getattr(hook, '__self__', None), 'active', True):
+            return None
+        return hook
+
+    def _learn_cuts(self, nback, frontiers):
+        cuts, k = {}, 0
+        for i, lo in enumerate(frontiers):
+            while k < len(self.CUT_FRACTIONS) and lo <= self.CUT_FRACTIONS[k] * self.flat.total:
+                if 0 < lo < self.flat.total:
+                    cuts[i] = lo           # (several fractions passed by one closure: the lowest offset wins)
+                k += 1
+        self._cuts[nback] = cuts
+
+    def run_closures(self, around_cut=None):
+        """around_cut(do): wraps the partial unpack + hook of a cut -- do() performs them and returns (unpack table or None,
+        flat offset, weight-gradient stream in use) -- so that HipNet can cut its recorded launch list there."""
+        hook = self._ready_hook()
+        back = list(reversed(self.back))
+        nback = len(back)
+        cuts = self._cuts.get(nback) if hook is not None else None
+        learn = hook is not None and cuts is None
+        if learn:
+            flat = self.flat
+            offs = sorted((flat._off[k][0], k) for k in flat._off)
+            pending = {k for _, k in offs}
+            frontiers, hi = [], len(offs)
+        for i, fn in enumerate(back):
+            if learn:
+                flat.touch_log = set()
             fn()
+            if learn:
+                pending -= flat.touch_log
+                flat.touch_log = None
+                while hi > 0 and offs[hi - 1][1] not in pending:
+                    hi -= 1
+                frontiers.append(offs[hi][0] if hi < len(offs) else flat.total)
+            elif cuts and i in cuts and i + 1 < nback:
+                def do(i=i):
+                    side = self.rt.side_stream() if getattr(self.rt, '_side_busy', False) else None
+                    if side is not None:
+                        with torch.cuda.stream(side):
+                            table = self.run_unpack(group=i)
+                    else:
+                        table = self.run_unpack(group=i)
+                    hook(self.flat, cuts[i], (side,) if side is not None else ())
+                    return table, cuts[i], side is not None
+                if around_cut is not None:
+                    around_cut(do)
+                else:
+                    do()
+        if learn:
+            self._learn_cuts(nback, frontiers)
         self.back = []
         self.stats_pending = False
         self.rt.join_side()               # the weight gradients ran on the side stream
 
-    def run_unpack(self):
+    def run_unpack(self, group='end'):
+        """Batched unpack of the weight gradients launched since the last one (group: which cut of the backward this is)."""
         if self._unpack_pending:
             key = (tuple((id(c), h, w) for c, h, w, _ in self._unpack_pending), self.flat.flat_g.data_ptr())
-            t = self._unpack_table
+            t = self._unpack_tables.get(group)
             if t is None or t[0] != key:
                 jobs = []
                 for conv, h, w, gw in self._unpack_pending:
                     jobs += conv.unpack_jobs(h, w, gw)
-                t = self._unpack_table = (key, PackTable(self.rt, jobs, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
+                t = self._unpack_tables[group] = (key, PackTable(self.rt, jobs, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
             t[1].run()
             self._unpack_pending = []
+            return t[1]
+        return None
 
     DROP_POOL_FLOATS = 1 << 20
 
@@ -588,15 +653,15 @@ class HipNet(nn.Module):
         side = rt.side_stream()
         return (tuple(x.shape), bool(self.training), bool(need_grad), rt.stream, side.cuda_stream if side is not None else 0,
                 tape.flat.flat_p.data_ptr(), tape.flat.flat_g.data_ptr(), tuple(b.data_ptr() for b in tape.flat.buffer_list()),
-                tuple(sorted((p, pool['used']) for p, pool in tape._drop_pools.items())) if self.training else ())
+                tuple(sorted((p, pool['used']) for p, pool in tape._drop_pools.items())) if self.training else (),
+                tape._ready_hook() is not None)
 
     @staticmethod
     def _plan_drop(ent):
-        for k in ('fwd', 'bwd'):
-            h = ent.get(k)
+        for h in [ent.get('fwd')] + [h for h, _ in (ent.get('bwd') or [])]:
             if h:
                 nv.call('segnb_plan_destroy', h)
-            ent[k] = None
+        ent['fwd'] = ent['bwd'] = None
 
     def _run(self, x, need_grad):
         tape = self._tape
@@ -662,7 +727,20 @@ class HipNet(nn.Module):
             din.copy_(dlogits)                                              # (autograd hands over a new tensor every step)
             dlogits = din
         if ent is not None and ent['state'] == 'ready':
-            nv.call('segnb_plan_run', ent['bwd'])
+            for handle, cut in ent['bwd']:
+                nv.call('segnb_plan_run', handle)
+                if cut is not None:          # host work between two segments: partial unpack + the data-parallel hook
+                    table, lo, on_side = cut
+                    side = tape.rt.side_stream() if on_side else None
+                    if table is not None:
+                        if side is not None:
+                            with torch.cuda.stream(side):
+                                table.run()
+                        else:
+                            table.run()
+                    hook = tape._ready_hook()
+                    if hook is not None:
+                        hook(tape.flat, lo, (side,) if side is not None else ())
             tape.rt._side_busy = False
             tape.stats_pending = False
             if ent['unpack'] is not None:
@@ -670,22 +748,29 @@ class HipNet(nn.Module):
         else:
             self._dlogits[0] = dlogits
             recording = ent is not None and ent['state'] == 'fwd'
+            segs, around = [], None
             if recording:
                 nv.plan_record_begin()
-            tape.run_closures()
+
+                def around(do):
+                    handle, nops = nv.plan_record_end()
+                    segs.append((handle, nops, do()))
+                    nv.plan_record_begin()
+            tape.run_closures(around)
             if recording:
                 handle, nops = nv.plan_record_end()
-                if handle is None or getattr(tape, 'unplannable', False):
-                    if handle is not None:
-                        nv.call('segnb_plan_destroy', handle)
+                segs.append((handle, nops, None))
+                if any(h is None for h, _, _ in segs) or getattr(tape, 'unplannable', False):
+                    for h, _, _ in segs:
+                        if h is not None:
+                            nv.call('segnb_plan_destroy', h)
                     self._plan_drop(ent)
                     ent['state'] = 'eager'
                 else:
-                    ent.update(bwd=handle, nbwd=nops, state='ready')
-            had = bool(tape._unpack_pending)
-            tape.run_unpack()                                               # (7x7 / strided jobs take host tap arrays: eager)
+                    ent.update(bwd=[(h, c) for h, _, c in segs], nbwd=sum(n for _, n, _ in segs), state='ready')
+            table = tape.run_unpack()                                       # (7x7 / strided jobs take host tap arrays: eager)
             if recording and ent['state'] == 'ready':
-                ent['unpack'] = tape._unpack_table[1] if had else None
+                ent['unpack'] = table
         hook = getattr(self, '_grad_sync_hook', None)
         if hook is not None:
             hook(tape.flat)

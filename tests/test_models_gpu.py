@@ -125,7 +125,7 @@ def test_launch_plans_replay_matches_eager(name):
         finally:
             net.HipNet.use_cplan = True
     (l1, e1), (l0, e0) = res[True], res[False]
-    np.testing.assert_allclose(l1, l0, rtol=0, atol=1e-3)
+    np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-3)
     for a, b in zip(e1, e0):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
     assert float((e1[3] - e1[1]).abs().max()) == 0.0 and float((e1[0] - e1[1]).abs().max()) > 0
