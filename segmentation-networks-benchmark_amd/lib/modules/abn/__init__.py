@@ -4,7 +4,8 @@
 The reference delegates to the un-vendored ``inplace_abn`` CUDA extension (functions.py:1: mean_var / forward /
 edz_eydz / backward).  Here the same four phases are segnb_bn_stats + segnb_bn_finalize / segnb_bn_act_fwd /
 segnb_bn_act_bwd_reduce / segnb_bn_bwd_apply.  Inside LinkNet34 the module is only a parameter holder (the
-executor fuses BN + LeakyReLU behind each convolution); called on its own it runs the kernels on an NHWC copy.
+executor fuses BN + LeakyReLU behind each convolution); called on its own it runs the same kernels, with the NCHW <->
+NHWC moves as launches of the library too, and writes its result into the input's storage like the reference.
 
 Parity note (SURVEY 8c): whether the backend applies gamma or |gamma|+eps cannot be determined from the reference;
 this implementation uses the standard affine gamma (identical at the gamma = 1 initialisation).
@@ -29,13 +30,18 @@ class ABN(nn.Sequential):
 
 
 class _ABNFn(torch.autograd.Function):
+    """The four phases of functions.py:62-122 on the HIP kernels.  No torch operator touches the activations: the NCHW
+    tensors of the module interface are moved to / from the kernels' NHWC layout by segnb_pack_input_nchw /
+    segnb_nhwc_to_nchw_f32, and -- as in the reference (functions.py:92 ``ctx.mark_dirty(x)``) -- the result is written
+    INTO x's storage when autograd allows it (x is not a leaf that requires grad), so the module allocates no output."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, slope):
         N, C, H, W = x.shape
         Cp = cp.pad8(C)
         dev, st = x.device, (torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
-        y = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=dev)
-        y[..., :C] = x.detach().permute(0, 2, 3, 1)
+        y = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
+        nv.call('segnb_pack_input_nchw', nv.ptr(x), N, C, H, W, nv.ptr(y), nv.F32, Cp, Cp, st)
         stats = torch.zeros((16, 2, Cp), dtype=torch.float64, device=dev)
         coef = torch.zeros((4, Cp), dtype=torch.float32, device=dev)
         if training:
@@ -51,40 +57,49 @@ class _ABNFn(torch.autograd.Function):
         ctx.training = bool(training)
         ctx.save_for_backward(y, coef, weight if weight is not None else coef.new_empty(0))
         ctx.cfg = (N, C, H, W, Cp, act, slope, weight is not None)
-        return out[..., :C].permute(0, 3, 1, 2).contiguous()
+        in_place = not (x.is_leaf and x.requires_grad)
+        res = x if in_place else torch.empty_like(x)
+        nv.call('segnb_nhwc_to_nchw_f32', nv.F32, nv.ptr(out), Cp, N, H, W, C, nv.ptr(res), st)
+        if in_place:
+            ctx.mark_dirty(x)
+        return res
 
     @staticmethod
     def backward(ctx, gout):
         y, coef, weight = ctx.saved_tensors
         N, C, H, W, Cp, act, slope, affine = ctx.cfg
         dev, st = y.device, (torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0)
-        g = torch.zeros((N, H, W, Cp), dtype=torch.float32, device=dev)
-        g[..., :C] = gout.detach().permute(0, 2, 3, 1)
+        gout = gout.detach().contiguous().float()
+        g = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
+        nv.call('segnb_pack_input_nchw', nv.ptr(gout), N, C, H, W, nv.ptr(g), nv.F32, Cp, Cp, st)
         dz = torch.empty_like(g)
         sums = torch.zeros((16, 2, Cp), dtype=torch.float64, device=dev)
         bcoef = torch.zeros((3, Cp), dtype=torch.float32, device=dev)
         dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
         dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dev)
         nv.call('segnb_bn_act_bwd_reduce', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(g),
                 Cp, None, 0, None, 0, nv.ptr(dz), Cp, nv.ptr(sums), None, 0, st)
         if not ctx.training:
             # inference-mode backward of the reference (functions.py:113-116: edz = eydz = 0): a plain affine map,
-            # dx = dz * gamma * rstd; dgamma / dbeta are still the sums (the training formula is wrong here)
-            sums_keep = sums.clone()
-            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums_keep), C, Cp, float(N * H * W),
+            # dx = dz * gamma * rstd; dgamma / dbeta are still the sums (the training formula is wrong here).
+            # As launches: sums -> dgamma / dbeta, then dz scaled per channel by coef row 0 = gamma * rstd of the running
+            # statistics (segnb_bn_act_fwd with a coefficient table whose shift row is zero, no activation)
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W),
                     nv.ptr(weight.detach() if affine else None), nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dgamma),
                     nv.ptr(dbeta), 0, st)
-            scale = coef[0, :C]                                   # gamma * rstd of the running statistics
-            dx = dz[..., :C] * scale
-            return (dx.permute(0, 3, 1, 2).contiguous(), dgamma if affine else None, dbeta if affine else None, None,
-                    None, None, None, None, None, None)
-        nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W),
-                nv.ptr(weight.detach() if affine else None), nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dgamma), nv.ptr(dbeta),
-                0, st)
-        nv.call('segnb_bn_bwd_apply', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dz), Cp,
-                nv.ptr(dz), Cp, None, C, st)
-        return (dz[..., :C].permute(0, 3, 1, 2).contiguous(), dgamma if affine else None, dbeta if affine else None, None,
-                None, None, None, None, None, None)
+            scale_only = torch.zeros_like(coef)
+            scale_only[0].copy_(coef[0])
+            nv.call('segnb_bn_act_fwd', nv.F32, nv.ptr(dz), Cp, N, H, W, Cp, nv.ptr(scale_only), nv.ACT_NONE, 0.0, None,
+                    nv.ptr(dz), Cp, None, 0, None, 0, None, 0, st)
+        else:
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W),
+                    nv.ptr(weight.detach() if affine else None), nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dgamma),
+                    nv.ptr(dbeta), 0, st)
+            nv.call('segnb_bn_bwd_apply', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dz), Cp,
+                    nv.ptr(dz), Cp, None, C, st)
+        nv.call('segnb_nhwc_to_nchw_f32', nv.F32, nv.ptr(dz), Cp, N, H, W, C, nv.ptr(dx), st)
+        return (dx, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
 
 
 class InPlaceABN(nn.Module):
@@ -114,8 +129,8 @@ class InPlaceABN(nn.Module):
 
     def forward(self, x):
         act = nv.ACT_LEAKY if self.activation == ACT_LEAKY_RELU else nv.ACT_NONE
-        y = _ABNFn.apply(x.float(), self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                         self.momentum, self.eps, act, self.slope)
+        y = _ABNFn.apply(x.contiguous().float(), self.weight, self.bias, self.running_mean, self.running_var,
+                         self.training, self.momentum, self.eps, act, self.slope)
         # 'elu' is used by no model of the reference: BatchNorm on the HIP kernels, the ELU as a torch op on top
         return torch.nn.functional.elu(y) if self.activation == ACT_ELU else y
 

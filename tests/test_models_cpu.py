@@ -141,6 +141,16 @@ def test_inplace_abn_module_standalone():
     torch.testing.assert_close(abn.weight.grad, bn.weight.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(abn.bias.grad, bn.bias.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(abn.running_var, bn.running_var, rtol=1e-5, atol=1e-6)
+    # in place, like the reference (functions.py:92 mark_dirty): a non-leaf input receives the result in its own storage
+    xc, xd = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    h = xc * 2.0
+    yc = abn(h)
+    assert yc.data_ptr() == h.data_ptr()
+    yd = torch.nn.functional.leaky_relu(bn(xd * 2.0), 0.01)
+    (yc * r).sum().backward()
+    (yd * r).sum().backward()
+    torch.testing.assert_close(yc, yd, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xc.grad, xd.grad, rtol=1e-4, atol=1e-5)
 
 
 def test_inplace_abn_constructor_surface():

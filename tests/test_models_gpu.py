@@ -286,6 +286,20 @@ def test_inplace_abn_standalone_gpu():
     torch.testing.assert_close(abn.bias.grad.cpu(), bn.bias.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(abn.running_mean.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(abn.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    # in place, like the reference (functions.py:92): a non-leaf input receives the result in its own storage
+    bn2 = torch.nn.BatchNorm2d(12)
+    bn2.load_state_dict(bn.state_dict())
+    abn2 = InPlaceABN(12).cuda()
+    abn2.load_state_dict({k: v for k, v in bn.state_dict().items() if k != 'num_batches_tracked'})
+    xc, xd = x.clone().cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    h = xc * 2.0
+    yc = abn2(h)
+    assert yc.data_ptr() == h.data_ptr()
+    yd = torch.nn.functional.leaky_relu(bn2(xd * 2.0), 0.01)
+    (yc * r.cuda()).sum().backward()
+    (yd * r).sum().backward()
+    torch.testing.assert_close(yc.cpu(), yd, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xc.grad.cpu(), xd.grad, rtol=1e-4, atol=1e-5)
     abn.eval()
     bn.eval()
     with torch.no_grad():
