@@ -351,6 +351,15 @@ class _ZFUnetPlan(object):
                     hook(self.flat, los[mark[1]], (self.rt.side_stream(),) if mark[2] else ())
         self._restore_stage_state(plan[1])
 
+    def __del__(self):
+        try:                       # recorded lists are owned by this plan: free them with it
+            for plan in self._cplans.values():
+                for handle, _, _ in (plan[0] or ()):
+                    if handle is not None:
+                        nv.call('segnb_plan_destroy', handle)
+        except Exception:          # (interpreter shutdown: the library may be gone already)
+            pass
+
     def _stage_state(self):
         return [(st, st._stats_stale, st._fused_fwd, getattr(st, '_saved', None))
                 for n in ENCODER + DECODER for st in self.stages[n]]

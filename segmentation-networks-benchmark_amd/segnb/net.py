@@ -64,6 +64,15 @@ class Tape(object):
     def note_fused_stats(self, stats):
         self.fused_stats.append(stats)
 
+    def __del__(self):
+        try:                       # recorded launch lists are owned by this tape: free them with it
+            for ent in self.plans.values():
+                for h in [ent.get('fwd')] + [h for h, _ in (ent.get('bwd') or [])]:
+                    if h:
+                        nv.call('segnb_plan_destroy', h)
+        except Exception:          # (interpreter shutdown: the library may be gone already)
+            pass
+
     # ---- per-step bookkeeping ------------------------------------------------------------------------------
     def begin(self, train, need_grad):
         self.flat.ensure(self.rt.device)
