@@ -239,6 +239,14 @@ int segnb_bn_bwd_apply_fused_acc(int dtype, const void* y, int ld_y, int N, int 
                                  float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
                                  const void* dz, int ld_dz, void* dy, int ld_dy, segnb_stream_t stream);
 
+/* ... and with dz recomputed from the incoming gradient g as in segnb_bn_bwd_apply_fused_direct: a pre-activation
+ * BatchNorm + ReLU whose activation has ONE consumer (tiramisu.py:12-14) needs no dz tensor at all -- sums-only reduce,
+ * then this launch: dy += BatchNorm-backward(act'(z) * g). */
+int segnb_bn_bwd_apply_fused_direct_acc(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                        const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                        float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
+                                        float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
+
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */
 int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,

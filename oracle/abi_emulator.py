@@ -500,6 +500,16 @@ class AbiEmulator(object):
         return rc or self.segnb_bn_bwd_apply_direct(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy,
                                                     ld_dy, None, C, stream)
 
+    def segnb_bn_bwd_apply_fused_direct_acc(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                            accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream):
+        dt = _tdt(dtype)
+        old = _nhwc(dy, N, H, W, Cp, ld_dy, dt).clone()
+        rc = self.segnb_bn_bwd_apply_fused_direct(dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                                  accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream)
+        o = _nhwc(dy, N, H, W, Cp, ld_dy, dt)
+        o.copy_((old.float() + o.float()).to(dt))
+        return rc
+
     # ------------------------------------------------------------------------------------------ tiles
     @staticmethod
     def _d4(k, t):

@@ -1115,6 +1115,19 @@ extern "C" int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_
                                "segnb_bn_bwd_apply_fused_direct", stream, g, ld_g, act, slope);
 }
 
+extern "C" int segnb_bn_bwd_apply_fused_direct_acc(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                                   const float* coef, const double* sums, const float* gamma,
+                                                   float* bcoef, float* dgamma, float* dbeta, int accumulate,
+                                                   double* fwd_stats_to_clear, int act, float slope, const void* g,
+                                                   int ld_g, void* dy, int ld_dy, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_fused_direct_acc, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, act, slope, g, ld_g, dy, ld_dy, stream);
+    SEGNB_CHECK_ARG(sums != nullptr && bcoef != nullptr && C > 0 && Cp >= C, "missing sums / coefficient buffer");
+    SEGNB_CHECK_ARG(g != nullptr && g != dy, "the accumulating form needs the incoming gradient in a buffer of its own");
+    BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
+    return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, nullptr, 0, dy, ld_dy, nullptr, C, bp,
+                               "segnb_bn_bwd_apply_fused_direct_acc", stream, g, ld_g, act, slope, true);
+}
+
 // torch.optim.RMSprop (alpha, eps; no momentum / centering / weight decay) and torch.optim.Adam (betas, eps; no
 // amsgrad / weight decay) over the flat buffers: get_optimizer('rms' | 'adam') of torch_train.py:73-77
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long long n,

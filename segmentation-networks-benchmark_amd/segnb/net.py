@@ -454,22 +454,28 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
                 tape.unplannable = True
             return
         flat = tape.flat
-        dz = tape.view(site + '/dz', N, H, W, Cp)
         sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
-        nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
-                oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
         if fused:
+            # ONE gradient source, no dropout, no residual: dz never goes to memory -- a sums-only reduction, then the apply
+            # launch recomputes dz = act'(z) * g from the incoming gradient (the *_direct forms, as ZF_UNET's first
+            # convolutions) and, when the input has other consumers whose gradients are already in x.g, adds its result
+            # there (no segnb_add pass)
+            nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
+                    oa.g.ptr, oa.g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
             fargs = (rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()),
                      nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats),
-                     dz.ptr, dz.ld)
+                     act, slope, oa.g.ptr, oa.g.ld)
             if x.needs_grad and x.g is not None:
-                # the input has other consumers whose gradients are already in x.g: accumulate there (no segnb_add pass)
-                nv.call('segnb_bn_bwd_apply_fused_acc', *(fargs + (x.g.ptr, x.g.ld, rt.stream)))
+                nv.call('segnb_bn_bwd_apply_fused_direct_acc', *(fargs + (x.g.ptr, x.g.ld, rt.stream)))
             else:
-                nv.call('segnb_bn_bwd_apply_fused', *(fargs + (dz.ptr, dz.ld, rt.stream)))
+                dz = tape.view(site + '/dz', N, H, W, Cp)
+                nv.call('segnb_bn_bwd_apply_fused_direct', *(fargs + (dz.ptr, dz.ld, rt.stream)))
                 tape.contribute(x, dz)
             return
+        dz = tape.view(site + '/dz', N, H, W, Cp)
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
+                oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
         nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(coef),
                 nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
         nv.call('segnb_bn_bwd_apply', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,

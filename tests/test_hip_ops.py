@@ -406,6 +406,19 @@ def test_bn_fused_finalize_equals_separate_launches(case, dtype):
             nv.call('segnb_bn_bwd_apply_fused_acc', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums),
                     nv.ptr(gamma), nv.ptr(bc2), nv.ptr(dg2), nv.ptr(db2), 1, None, dz.ptr, dz.ld, prior.ptr, prior.ld,
                     rt.stream)
+            if not use_drop:
+                # ... and with dz recomputed from the incoming gradient (no dz tensor): the same sums, the same result
+                prior2 = _view_from(rt, prior.dense()[..., :C].float().cpu() * 0 + 1.0, Cp)
+                want2 = View.alloc(rt, N, H, W, Cp)
+                nv.call('segnb_add', rt.code, prior2.ptr, prior2.ld, dy.ptr, dy.ld, want2.ptr, want2.ld, N, H, W, Cp, rt.stream)
+                dg3, db3, bc3 = torch.ones(C, device='cuda'), torch.ones(C, device='cuda'), rt.zeros((3, Cp), torch.float32)
+                nv.call('segnb_bn_bwd_apply_fused_direct_acc', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef),
+                        nv.ptr(sums), nv.ptr(gamma), nv.ptr(bc3), nv.ptr(dg3), nv.ptr(db3), 1, None, act, 0.01, gd.ptr, gd.ld,
+                        prior2.ptr, prior2.ld, rt.stream)
+                torch.cuda.synchronize()
+                err2 = float((prior2.dense().float() - want2.dense().float()).abs().max())
+                assert err2 == 0.0 if dtype == 'bf16' else err2 <= 2.5e-7 * float(want2.dense().abs().max()), err2
+                assert torch.equal(dg3, dgam) and torch.equal(bc3, bcoef)
             torch.cuda.synchronize()
             assert torch.equal(dg2, dgam) and torch.equal(bc2, bcoef)
             # (bf16: bit for bit; fp32: the two instantiations may contract the BatchNorm expression differently -- one ulp)
