@@ -378,16 +378,25 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
         gp = pa.g if pa is not None else None
+        # one direct gradient source and nothing else in the way: dz stays in registers (sums-only reduce, then the apply
+        # launch recomputes it from the incoming gradient -- segnb_bn_bwd_apply_fused_direct, as ZF_UNET's first convolutions)
+        direct = fused_bn and gp is None and res is None and dropmul is None and oa.g is not None
         nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
-                nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, dz.ptr, dz.ld, nv.ptr(sums),
-                None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
+                nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
+                0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
+                rt.stream)
         count = float(N * Ho * Wo)
         dy = dz
         if has_bn:
             gamma = bn.weight
             if res is not None:             # dz is also the residual branch's gradient: keep it intact
                 dy = tape.view(site + '/dy', N, Ho, Wo, Cp)
-            if fused_bn:
+            if direct:
+                nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf),
+                        nv.ptr(sums), nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)),
+                        nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats), act, slope, oa.g.ptr, oa.g.ld, dy.ptr, dy.ld,
+                        rt.stream)
+            elif fused_bn:
                 nv.call('segnb_bn_bwd_apply_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf), nv.ptr(sums),
                         nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)),
                         nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats), dz.ptr, dz.ld, dy.ptr, dy.ld, rt.stream)
