@@ -555,21 +555,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
             int qw = rem - qh * g.QW;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (it_ch[u] >= 0 && m < a.M) {
-                    if (it_isA[u]) {
-                        const long long pix = (long long)(n * g.Ho + qh * g.out_step + g.oh0) * g.Wo +
-                                              qw * g.out_step + g.ow0;
-                        v = *reinterpret_cast<const uint4*>(doT + pix * g.ld_out + it_ch[u]);
-                    } else {
-                        const int hi = qh * g.in_step + it_dh[u], wi = qw * g.in_step + it_dw[u];
-                        if ((unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi) {
-                            const long long pix = (long long)(n * g.Hi + hi) * g.Wi + wi;
-                            v = *reinterpret_cast<const uint4*>(inT + pix * g.ld_in + it_ch[u]);
-                        }
-                    }
+                // branch-free: an element outside the image / the pixel range loads the tensor's first chunk instead and
+                // is zeroed afterwards, so that the EPC loads of an item are all in flight together (under the nested
+                // conditions of the first version each load waited for the one before it)
+                const T* p = it_isA[u] ? doT : inT;
+                bool ok = it_ch[u] >= 0 && m < a.M;
+                if (it_isA[u]) {
+                    const long long pix = (long long)(n * g.Ho + qh * g.out_step + g.oh0) * g.Wo + qw * g.out_step + g.ow0;
+                    if (ok) p = doT + pix * g.ld_out + it_ch[u];
+                } else {
+                    const int hi = qh * g.in_step + it_dh[u], wi = qw * g.in_step + it_dw[u];
+                    ok = ok && (unsigned)hi < (unsigned)g.Hi && (unsigned)wi < (unsigned)g.Wi;
+                    const long long pix = (long long)(n * g.Hi + hi) * g.Wi + wi;
+                    if (ok) p = inT + pix * g.ld_in + it_ch[u];
                 }
-                regs[u][e] = v;
+                const uint4 v = *reinterpret_cast<const uint4*>(p);
+                regs[u][e] = ok ? v : make_uint4(0, 0, 0, 0);
                 ++m;
                 if (++qw == g.QW) {
                     qw = 0;
@@ -596,17 +597,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const WgradArgs a) {
     };
 
     if (nsteps > 0) {
+        // ONE LDS tile: a K step is a handful of MFMAs behind a gather of 8 scattered 16-byte loads per thread, so the loop
+        // is bound by load latency (rocprofv3: 80-84 % of the wave cycles waiting, 0.1 % MFMA) and what hides it is the
+        // number of blocks a CU holds, not a second tile (half the LDS per block: 5 blocks per CU instead of 2-3)
         gload(0);
         lstore(0);
         __syncthreads();
+        const unsigned char* sA = sTiles + (wr * WM) * LDS_ROW;
+        const unsigned char* sB = sTiles + (BM + wc * WN) * LDS_ROW;
         for (int s = 0; s < nsteps; ++s) {
-            const int buf = s & 1;
             if (s + 1 < nsteps) gload(s + 1);
-            const unsigned char* sA = sTiles + buf * TILE_BYTES + (wr * WM) * LDS_ROW;
-            const unsigned char* sB = sTiles + buf * TILE_BYTES + (BM + wc * WN) * LDS_ROW;
             mma_step<T, TM, TN>(sA, sB, r, h, acc);
-            if (s + 1 < nsteps) lstore(buf ^ 1);
-            __syncthreads();
+            __syncthreads();                          // every wave has read the tile
+            if (s + 1 < nsteps) {
+                lstore(0);
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1025,7 +1031,7 @@ int dispatch_fprop(FpropArgs& a, hipStream_t stream) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_wgrad(WgradArgs& a, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * LDS_ROW;
+    constexpr int smem = (BM + BN) * LDS_ROW;
     static int attr_rc = set_smem(conv_wgrad_kernel<T, BM, BN, WM, WN>, smem);
     if (attr_rc) return attr_rc;
     constexpr int BKP = 8 * Elem<T>::EPC;
@@ -1036,7 +1042,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     const int cus = segnb_num_cus();
     // blocks per CU the pixel range is split for (measured on LinkNet34's 7x7 / transposed / 2x2 layers: 2 -> 5.53 ms of
     // weight gradients per step, 4 -> 5.19 ms, 8 -> 5.10 ms; step 10.7 -> 10.3 ms at 4)
-    static const int per_cu = getenv("SEGNB_WG_GENERAL_PER_CU") ? atoi(getenv("SEGNB_WG_GENERAL_PER_CU")) : 4;
+    static const int per_cu = getenv("SEGNB_WG_GENERAL_PER_CU") ? atoi(getenv("SEGNB_WG_GENERAL_PER_CU")) : 8;
     int S = (cus * per_cu + tiles - 1) / tiles;
     if (S < 1) S = 1;
     // keep at least 4 K steps per split so the pipeline prologue amortises
