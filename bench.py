@@ -4,7 +4,9 @@
 ZF_UNET 224x224, bs=32 per GPU, bf16 compute, BCE+Dice, synthetic tiles resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 and no RANK in the environment: bench.py starts its own N ranks (child `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N ... bench.py ...`, before anything touches the GPU) and forwards rank 0's line and
+    the job's exit code; under a launcher that has already set RANK / WORLD_SIZE it just joins the job.
 
 Prints ONE JSON line on rank 0.  Besides the throughput it carries
   roofline     : the dominant kernel (the implicit-GEMM convolution) timed live with HIP events on its launch
@@ -85,6 +87,41 @@ def pmc_traffic(kernel):
     return None if k is None else k['traffic_bytes_per_launch']
 
 
+def self_launch(n, argv):
+    """--gpus N without a launcher: run the N ranks as CHILD processes (never exec: this process may not be replaced
+    once anything has touched the GPU, and nothing here has) and return the job's exit code.  Rank 0's JSON line goes
+    to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_check(args):
+    """--dry-run: join the job, count the ranks with an all-reduce of ones, print the line's job fields and stop -- the
+    launch / rendezvous path of `bench.py --gpus N` without a kernel (gloo on a box without GPUs: tests/test_dist_cpu.py)."""
+    import torch.distributed as td
+    from segnb import dist as sdist
+    sdist.init_from_env()
+    ws, rank = sdist.world(), sdist.rank()
+    ones = torch.ones(1)
+    if ws > 1:
+        if torch.cuda.is_available():
+            ones = ones.cuda(int(os.environ.get('LOCAL_RANK', '0')))
+        td.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': ws, 'ranks_seen': int(ones.item()), 'requested_gpus': args.gpus,
+                          'backend': td.get_backend() if ws > 1 else None}))
+    return 0 if int(ones.item()) == max(1, args.gpus) else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -103,7 +140,18 @@ def main():
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the whole training step from one captured HIP graph (auto = off: eager launches overlap the weight-gradient stream better)')
+    ap.add_argument('--wire', default='f32', choices=['f32', 'bf16'],
+                    help='N > 1: wire format of the gradient all-reduce buckets (bf16 halves the bytes on xGMI; the sum is '
+                         'taken in bf16 by RCCL -- off by default: the headline keeps the fp32 exchange)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='join the job, count the ranks (all-reduce of ones), print n_gpus / ranks_seen and stop')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # nothing above has touched the GPU (importing torch and parsing arguments do not)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        sys.exit(rendezvous_check(args))
 
     from segnb import dist as sdist
     from segnb import engine, optim
@@ -138,7 +186,7 @@ def main():
     crit = {'bce_dice': L.BCEAndDiceLoss, 'bce_jaccard': L.BCEWithLogitsLossAndSmoothJaccard,
             'bce': L.BCEWithSigmoidLoss}[args.loss]()
     opt = optim.SGD(model.parameters(), lr=1e-3)
-    dp = sdist.DataParallel(model)
+    dp = sdist.DataParallel(model, wire_dtype=args.wire)
     if args.fuse_optimizer:
         dp.fuse_optimizer(opt)
     B, S = args.batch, args.size
@@ -207,10 +255,14 @@ def main():
     if ws > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if ws > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)            # every rank that timed the region adds one
+        ranks_seen = int(ones.item())
 
     # host time to ENQUEUE one step (no synchronisation inside; the GPU is still busy with the first step when the last
     # one has been issued unless the host is the slower side) -- reported beside the step time, outside the timed region
@@ -258,7 +310,7 @@ def main():
         'metric': ('images/sec/GPU (fwd+bwd) ZF_UNET 224x224 bs=32; 1/2/4/8-GPU scaling' if args.model == 'zf_unet' else
                    'images/sec/GPU (fwd+bwd) %s %dx%d bs=%d (SURVEY 8d row, not the headline metric)' % (args.model, S, S, B)),
         'value': round(value, 2), 'unit': 'images/s', 'per_gpu': round(value / ws, 2),
-        'n_gpus': ws, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+        'n_gpus': ws, 'ranks_seen': ranks_seen, 'grad_wire': args.wire if ws > 1 else None, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': ('ZF_UNET %dx%d %s bs=%d/GPU, %s, SGD lr 1e-3, Dropout2d 0.2, train step '

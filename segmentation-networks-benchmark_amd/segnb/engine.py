@@ -818,10 +818,18 @@ class FlatParams(object):
         accumulate on top of flat_g (every .grad already aliases it: find_optimal_lr never zeroes grads,
         lib/train_utils.py:54-65; zero_grad(set_to_none=False) zeroes them in place); otherwise flat_g is
         cleared first."""
+        if getattr(self, 'stepped_in_backward', False):
+            import warnings
+            warnings.warn('the previous backward updated the parameters in the all-reduce epilogue '
+                          '(DataParallel.fuse_optimizer) and no optimizer.step() consumed it: that step was applied anyway')
         self.stepped_in_backward = False
+        # data-parallel jobs note whether this backward accumulates on top of earlier gradients (DataParallel sets the
+        # flag on the module when it attaches, i.e. before the first backward)
+        track = bool(getattr(self, 'track_accumulation', False) or getattr(self.module, '_dp_track_accumulation', False))
+        self.accumulation_tracked = track
         if self.grads_alias():
             # accumulating on top of non-zero gradients?  (a data-parallel sync must not reduce them twice)
-            self.accumulating = bool(self.flat_g.abs().max() > 0) if getattr(self, 'track_accumulation', False) else False
+            self.accumulating = bool(self.grad_absmax() > 0) if track else False
             self.fresh_backward = not self.accumulating
             return True
         self.accumulating = False
