@@ -341,6 +341,21 @@ class _ZFUnetPlan(object):
             segs = None
         self._cplans[ckey] = (segs, self._stage_state(), sum(n for _, n, _ in segs) if segs else 0)
 
+    def _plan_abort(self, ckey):
+        """An exception escaped a step that was being recorded (e.g. an allocation failure the caller catches): close the
+        recording, free its segments and remember the configuration as eager."""
+        if self._rec is None:
+            return
+        segs, self._rec = self._rec, None
+        nv.plan_record_abort()
+        for h, _, _ in segs:
+            if h is not None:
+                try:
+                    nv.call('segnb_plan_destroy', h)
+                except Exception:
+                    pass
+        self._cplans[ckey] = (None, self._stage_state(), 0)
+
     def _plan_replay(self, plan, H=None, W=None):
         for handle, _, mark in plan[0]:
             nv.call('segnb_plan_run', handle)
@@ -405,33 +420,38 @@ class _ZFUnetPlan(object):
                 self._plan_begin()
             else:
                 ckey = None                               # recorded before and found not replayable: eager
-        first = None
-        if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
-            first = (x, self.module.input_norm)          # the first convolution reads the image itself
-        else:
-            pack_input(rt, x, b['x'], self.module.input_norm)
-        wp = self.wp
-        cur = b['x']
-        for i, name in enumerate(ENCODER):
-            s1, s2 = self.stages[name]
-            s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None)
-            if i < 5:
-                skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
-                s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
-                cur = b['p_%d' % (i + 1)]
+        try:
+            first = None
+            if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
+                first = (x, self.module.input_norm)          # the first convolution reads the image itself
             else:
-                s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad)
-        for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
-            s1, s2 = self.stages[name]
-            s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
-            if lvl > 0:
-                s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad)
-            else:
-                s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
-        head = self.module.conv_final
-        logits = b['logits']
-        nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
-                nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+                pack_input(rt, x, b['x'], self.module.input_norm)
+            wp = self.wp
+            cur = b['x']
+            for i, name in enumerate(ENCODER):
+                s1, s2 = self.stages[name]
+                s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None)
+                if i < 5:
+                    skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
+                    s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
+                    cur = b['p_%d' % (i + 1)]
+                else:
+                    s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad)
+            for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
+                s1, s2 = self.stages[name]
+                s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
+                if lvl > 0:
+                    s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad)
+                else:
+                    s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
+            head = self.module.conv_final
+            logits = b['logits']
+            nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
+                    nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+        except BaseException:
+            if ckey is not None:
+                self._plan_abort(ckey)
+            raise
         if ckey is not None:
             self._plan_end(ckey)
         self._last = (N, H, W) if need_grad else None
@@ -471,45 +491,50 @@ class _ZFUnetPlan(object):
                 self._plan_begin()
             else:
                 ckey = None
-        if self.BWD_CONV_CU_PCT != 100:
-            nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
-        head = self.module.conv_final
-        nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
-                nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
-                nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
-        # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
-        # they would run beside) are held back until the dependent chain has reached the deep levels.
-        # (measured on one box: 0 -> 6.34 ms/step, 2 -> 6.31 ms/step, but the convolutions of the dependent chain then run
-        # beside more weight-gradient work and their own launches stretch by 6 %: off by default)
-        npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '0'))
-        post = []
-        for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
-            s1, s2 = self.stages[name]
-            hold = post if lvl < npost else None
-            # the first convolution of a block has ONE direct gradient source -- the data gradient of the second one: that
-            # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
-            if lvl == 0:
-                red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
-            else:
-                red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
-                                  postponed=hold, fuse_reduce_of=s1)
-            s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
-        rt.flush_postponed(post)
-        self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
-        for i in (5, 4, 3, 2, 1, 0):
-            if i == 3:
-                self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
-            s1, s2 = self.stages[ENCODER[i]]
-            if i == 5:
-                red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
-            else:
-                red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
-                                  dx=b['da1_%d' % i], fuse_reduce_of=s1)
-            s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red)
-        if self.BWD_CONV_CU_PCT != 100:
-            nv.call('segnb_tune', b'conv_cu_pct', 100)
-        rt.join_side()                        # the weight gradients ran on the side stream
-        self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
+        try:
+            if self.BWD_CONV_CU_PCT != 100:
+                nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
+            head = self.module.conv_final
+            nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
+                    nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
+                    nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
+            # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
+            # they would run beside) are held back until the dependent chain has reached the deep levels.
+            # (measured on one box: 0 -> 6.34 ms/step, 2 -> 6.31 ms/step, but the convolutions of the dependent chain then run
+            # beside more weight-gradient work and their own launches stretch by 6 %: off by default)
+            npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '0'))
+            post = []
+            for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
+                s1, s2 = self.stages[name]
+                hold = post if lvl < npost else None
+                # the first convolution of a block has ONE direct gradient source -- the data gradient of the second one: that
+                # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
+                if lvl == 0:
+                    red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
+                else:
+                    red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
+                                      postponed=hold, fuse_reduce_of=s1)
+                s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
+            rt.flush_postponed(post)
+            self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
+            for i in (5, 4, 3, 2, 1, 0):
+                if i == 3:
+                    self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
+                s1, s2 = self.stages[ENCODER[i]]
+                if i == 5:
+                    red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
+                else:
+                    red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
+                                      dx=b['da1_%d' % i], fuse_reduce_of=s1)
+                s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red)
+            if self.BWD_CONV_CU_PCT != 100:
+                nv.call('segnb_tune', b'conv_cu_pct', 100)
+            rt.join_side()                        # the weight gradients ran on the side stream
+            self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
+        except BaseException:
+            if ckey is not None:
+                self._plan_abort(ckey)
+            raise
         if ckey is not None:
             self._plan_end(ckey)
         self._after_backward()

@@ -89,13 +89,24 @@ class PRCurveMeter(object):
         t = y_true.detach().reshape(-1)
         if t.dtype != torch.int64:
             t = t.to(torch.int64)
-        t = t.contiguous()
+        t = t.to(x.device).contiguous()        # (the reference takes both through .cpu(): any device mix is accepted)
         n = self.n_thresholds
+        if not x.is_cuda and not nv.has_test_backend():
+            # host tensors (the reference's own call pattern, train_utils.py:111-112): the same histogram with torch ops --
+            # the kernel dereferences device pointers
+            thr = torch.from_numpy(self.thresholds)
+            bucket = torch.bucketize(torch.sigmoid(x), thr, right=False)       # thresholds strictly below the probability
+            hist = torch.stack([torch.bincount(bucket[t == 0], minlength=n + 1),
+                                torch.bincount(bucket[t != 0], minlength=n + 1)])
+            self._add_hist(hist.numpy().astype(np.uint64))
+            return
         thr = torch.from_numpy(self.thresholds).to(x.device)
         hist = torch.zeros((2, n + 1), dtype=torch.int64, device=x.device)
         st = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
         nv.call('segnb_pr_histogram', nv.ptr(x), nv.ptr(t), x.numel(), nv.ptr(thr), n, nv.ptr(hist), st)
-        h = hist.cpu().numpy().astype(np.uint64)
+        self._add_hist(hist.cpu().numpy().astype(np.uint64))
+
+    def _add_hist(self, h):
         hn, hp = h[0], h[1]
         # predicted positive at threshold i  <=>  bucket > i
         tp = hp[::-1].cumsum()[::-1][1:]

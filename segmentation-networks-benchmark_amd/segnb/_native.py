@@ -175,6 +175,10 @@ def call(name, *args):
                            % (name, rc, msg.decode() if msg else ''))
 
 
+def has_test_backend():
+    return _test_backend is not None
+
+
 def plan_record_begin():
     call('segnb_plan_begin')
 
@@ -184,6 +188,20 @@ def plan_record_end():
     h, n = c_void_p(), c_int()
     call('segnb_plan_end', ctypes.byref(h), ctypes.byref(n))
     return (h.value or None), n.value
+
+
+def plan_record_abort():
+    """An exception escaped a region that was being recorded: close the recording on this thread and free what it holds
+    (otherwise every later ABI call would be appended to the abandoned list and segnb_plan_run would refuse to run)."""
+    try:
+        handle, _ = plan_record_end()
+    except Exception:
+        return
+    if handle is not None:
+        try:
+            call('segnb_plan_destroy', handle)
+        except Exception:
+            pass
 
 
 def query(name, *args):

@@ -723,7 +723,13 @@ class HipNet(nn.Module):
         pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         self._dlogits = [None]
         tape.unplannable = False
-        logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
+        try:
+            logits = self._build(tape, Act(xin, needs_grad=False), self._dlogits)
+        except BaseException:
+            if recording:                      # close the abandoned recording: this key stays eager
+                nv.plan_record_abort()
+                ent['state'] = 'eager'
+            raise
         tape.stats_pending = bool(tape.fused_stats)
         if recording:
             handle, nops = nv.plan_record_end()
@@ -780,7 +786,17 @@ class HipNet(nn.Module):
                     handle, nops = nv.plan_record_end()
                     segs.append((handle, nops, do()))
                     nv.plan_record_begin()
-            tape.run_closures(around)
+            try:
+                tape.run_closures(around)
+            except BaseException:
+                if recording:
+                    nv.plan_record_abort()
+                    for h, _, _ in segs:
+                        if h is not None:
+                            nv.call('segnb_plan_destroy', h)
+                    self._plan_drop(ent)
+                    ent['state'] = 'eager'
+                raise
             if recording:
                 handle, nops = nv.plan_record_end()
                 segs.append((handle, nops, None))

@@ -48,6 +48,51 @@ def test_pr_curve_meter_matches_threshold_loop():
     assert m.precision().shape == (127,) and m.recall().shape == (127,)
 
 
+def test_pr_curve_meter_accepts_host_tensors_without_the_library():
+    """ADVICE r2: the reference calls .cpu() on both arguments (train_utils.py:111-112), so host tensors are legal input;
+    without a device the histogram is taken with torch ops instead of handing host pointers to the kernel."""
+    from lib.train_utils import PRCurveMeter
+    g = torch.Generator().manual_seed(1)
+    logits = 2 * torch.randn(3, 1, 9, 11, generator=g)
+    y = (torch.rand(3, 1, 9, 11, generator=g) > 0.5).long()
+    emu = PRCurveMeter()
+    emu.update(logits, y)                       # through the ABI (emulated here)
+    nv.set_backend_for_testing(None)
+    host = PRCurveMeter()
+    host.update(logits, y.to(torch.uint8))      # host path, other target dtype
+    for a, b in ((host.tp, emu.tp), (host.tn, emu.tn), (host.fp, emu.fp), (host.fn, emu.fn)):
+        assert np.array_equal(a, b)
+
+
+def test_recording_is_closed_when_a_recorded_step_raises():
+    """an exception inside a step that is being recorded must not leave the thread in recording mode."""
+    from lib.models.zf_unet import ZF_UNET, _ZFUnetPlan
+    be = nv._test_backend
+    state = {'rec': 0}
+    be.segnb_plan_begin = lambda: state.__setitem__('rec', state['rec'] + 1) or 0
+    def end(h, n):
+        state['rec'] -= 1
+        return 0
+    be.segnb_plan_end = end
+    torch.manual_seed(0)
+    m = ZF_UNET(dropout_val=0.0, filters=4).set_compute_dtype('f32').train()
+    x = torch.randn(1, 3, 32, 32)
+    with torch.no_grad():
+        m(x)
+    eng = m._engine
+    eng._cplan_key = lambda *a, **k: ('forced',) + tuple(str(v) for v in a[:4])     # force the recording path on CPU
+    orig = be.segnb_head_fwd
+    be.segnb_head_fwd = lambda *a: (_ for _ in ()).throw(RuntimeError('boom'))
+    with pytest.raises(RuntimeError, match='boom'):
+        with torch.no_grad():
+            m(x)
+    assert state['rec'] == 0 and eng._rec is None
+    be.segnb_head_fwd = orig
+    with torch.no_grad():
+        out = m(x)                               # the configuration is remembered as eager and still runs
+    assert out.shape == (1, 1, 32, 32) and state['rec'] == 0
+
+
 def test_auto_file(tmp_path):
     from lib.train_utils import auto_file
     (tmp_path / 'a' / 'b').mkdir(parents=True)
