@@ -31,6 +31,8 @@ import torch
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
 GFLOP_PER_IMAGE_224 = 79.26     # conv MACs only, fwd + dgrad + wgrad, no dgrad for the first conv
+PEAK_HBM_TBS = 8.0              # HBM3E spec (MI355X_MICROARCH.md; 6.3 TB/s is what a copy achieves)
+ALGO_MB_PER_IMAGE_224 = 184.4 + 15.7      # activations 3 (I + O) bf16 per conv + weights / gradients / SGD at bs=32
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -69,19 +71,29 @@ def kernel_sources_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs of this same command, summarised by tools/pmc_traffic.py with the gfx950 corrections of
-    MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so the figure is only reported when the
-    profile is stamped with the digest of the kernel sources THIS run was built from; otherwise None (a profile of
-    other kernels says nothing about this build)."""
+def pmc_profile(model='zf_unet'):
+    """The committed PMC traffic profile of this build for `model` (profiles/r*_pmc_traffic[_<model>].json), or None
+    when there is none or it was taken from other kernel sources."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    pat = 'r*_pmc_traffic.json' if model == 'zf_unet' else 'r*_pmc_traffic_%s.json' % model
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)))
     if not files:
         return None
     with open(files[-1]) as fh:
         prof = json.load(fh)
     if prof.get('kernel_sources_digest') != kernel_sources_digest():
+        return None
+    return prof
+
+
+def pmc_traffic(kernel, model='zf_unet'):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs of this same command, summarised by tools/pmc_traffic.py with the gfx950 corrections of
+    MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so the figure is only reported when the
+    profile is stamped with the digest of the kernel sources THIS run was built from; otherwise None (a profile of
+    other kernels says nothing about this build)."""
+    prof = pmc_profile(model)
+    if prof is None:
         return None
     k = prof.get('kernels', {}).get(kernel)
     return None if k is None else k['traffic_bytes_per_launch']
@@ -341,13 +353,29 @@ def main():
         out['kernel_sources_digest'] = kernel_sources_digest()
         out['roofline'] = {'kernel': fams.get(dom, dom), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           'traffic': pmc_traffic(dom),
+                           'traffic': pmc_traffic(dom, args.model),
                            'launches_per_step': n // timer_steps,
                            'avg_launch_us': round(tot_ms / n * 1e3, 2),
                            'flops_per_launch': round(tot_fl / n),
                            'share_of_step': round((tot_ms / timer_steps) / (dt * 1e3 / args.steps), 4)}
         out['kernels'] = {k: {'launches_per_step': v[0] // timer_steps, 'ms_per_step': round(v[1] / timer_steps, 3),
                               'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+    # second roofline figure: HBM.  bytes_per_step = measured HBM traffic of one step (PMC passes of this same command,
+    # stamped with the kernel digest: tools/pmc_traffic.py); achieved = those bytes / the step time of THIS run.
+    prof = pmc_profile(args.model)
+    step_bytes = prof.get('bytes_per_step') if prof else None
+    algo_bytes = ALGO_MB_PER_IMAGE_224 * 1e6 * B * (S / 224.0) ** 2 if args.model == 'zf_unet' else None
+    hbm = {'peak': PEAK_HBM_TBS, 'unit': 'TB/s', 'bytes_per_step': step_bytes,
+           'algorithmic_bytes_per_step': None if algo_bytes is None else round(algo_bytes)}
+    if step_bytes:
+        hbm['achieved'] = round(step_bytes / (ms * 1e-3) / 1e12, 3)
+        hbm['frac'] = round(hbm['achieved'] / PEAK_HBM_TBS, 4)
+        if algo_bytes:
+            hbm['traffic_over_algorithmic'] = round(step_bytes / algo_bytes, 3)
+    out['roofline_hbm'] = hbm
+    if 'roofline' in out and hbm.get('frac') is not None:
+        # the step sits under BOTH roofs at once; `bound` names the one it is closer to
+        out['roofline']['bound'] = 'hbm' if hbm['frac'] > out['step_mfma_frac'] else 'mfma'
     if ws == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

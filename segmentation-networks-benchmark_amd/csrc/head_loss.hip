@@ -55,11 +55,8 @@ template <typename T, int KM>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, int ld_a, long long npix,
                                                        long long hw, int C, int Cp, const float* __restrict__ w,
                                                        int K, const float* __restrict__ dl, T* __restrict__ da,
-                                                       int ld_da, float* __restrict__ dw, float* __restrict__ db,
-                                                       int CT) {
-    __shared__ float sred[MAXK * 32 * 8 + MAXK];
-    for (int i = threadIdx.x; i < MAXK * 32 * 8 + MAXK; i += blockDim.x) sred[i] = 0.f;
-    __syncthreads();
+                                                       int ld_da, float* __restrict__ part, int CT) {
+    __shared__ float sred[256 * 8];
     const int PY = 256 / CT;
     const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
     const int cc = blockIdx.y * CT + tx;
@@ -120,20 +117,65 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
             }
         }
     }
+    // ---- reproducible reduction (LDS and global float atomics made dw / db differ run to run) ----
+    // within the block: the PY pixel lanes of a channel chunk are summed in lane order through LDS, class by class;
+    // across blocks: every block writes its partial sums to its own row of `part`, head_bwd_finish_kernel adds them in
+    // block order.
+    float* sg = sred;                                   // [PY][CT][8] floats = 8 KB
+    float* prow = part + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * (K * (CT * 8 + 1));
 #pragma unroll
     for (int k = 0; k < KM; ++k)
         if (k < K) {
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(&sred[(k * 32 + tx) * 8 + e], gw[k][e]);
-            if (tx == 0 && blockIdx.y == 0) atomicAdd(&sred[MAXK * 32 * 8 + k], gb[k]);
+            for (int e = 0; e < 8; ++e) sg[(ty * CT + tx) * 8 + e] = gw[k][e];
+            __syncthreads();
+            if (threadIdx.x < CT * 8) {
+                float sum = 0.f;
+                for (int j = 0; j < PY; ++j) sum += sg[j * CT * 8 + threadIdx.x];
+                prow[k * (CT * 8 + 1) + threadIdx.x] = sum;
+            }
+            __syncthreads();
+            // bias: the pixel lanes of chunk column 0 hold the same pixels as every other column
+            if (tx == 0) sg[ty] = gb[k];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float sum = 0.f;
+                for (int j = 0; j < PY; ++j) sum += sg[j];
+                prow[k * (CT * 8 + 1) + CT * 8] = sum;
+            }
         }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * CT * 8; i += blockDim.x) {
-        const int k = i / (CT * 8), idx = i - k * (CT * 8);
-        const int ch = blockIdx.y * CT * 8 + idx;
-        if (ch < C && dw != nullptr) atomicAdd(&dw[k * C + ch], sred[(k * 32 + idx / 8) * 8 + (idx & 7)]);
+}
+
+// dw[k][c] += sum over the pixel blocks (fixed order) of their partial sums; db[k] likewise (channel-chunk row 0).
+// One wave per output element: lanes stride the blocks, then a fixed shuffle tree.
+__global__ __launch_bounds__(64) void head_bwd_finish_kernel(const float* __restrict__ part, int gx, int gy, int K, int C,
+                                                             int CT, float* __restrict__ dw, float* __restrict__ db) {
+    const int o = blockIdx.x;                           // 0 .. K*C-1: weights, K*C .. K*C+K-1: biases
+    const int lane = threadIdx.x;
+    const int row = K * (CT * 8 + 1);
+    int k, by, idx;
+    if (o < K * C) {
+        k = o / C;
+        const int c = o - k * C;
+        by = c / (CT * 8);
+        idx = c - by * (CT * 8);
+    } else {
+        k = o - K * C;
+        by = 0;
+        idx = CT * 8;
     }
-    if (blockIdx.y == 0 && threadIdx.x < K && db != nullptr) atomicAdd(&db[threadIdx.x], sred[MAXK * 32 * 8 + threadIdx.x]);
+    float sum = 0.f;
+    for (int bx = lane; bx < gx; bx += 64) sum += part[(long long)(by * gx + bx) * row + k * (CT * 8 + 1) + idx];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if (lane == 0) {
+        if (o < K * C) {
+            if (dw != nullptr) dw[o] += sum;
+        } else if (db != nullptr) {
+            db[k] += sum;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,6 +409,34 @@ extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, 
     return 0;
 }
 
+namespace {
+// device scratch of the head backward: one buffer per device, grown (never shrunk) on demand.  hipMalloc happens on the
+// first call of a geometry, i.e. in the eager / recording step; replayed launch lists find the same pointer.
+float* head_scratch(size_t bytes) {
+    constexpr int MAXDEV = 16;
+    static float* buf[MAXDEV] = {nullptr};
+    static size_t cap[MAXDEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+        segnb_set_error("segnb_head_bwd: hipGetDevice failed");
+        return nullptr;
+    }
+    if (bytes > cap[dev]) {
+        // (the old buffer may still be read by launches in flight: it is left allocated -- a few hundred KB, at most a
+        // handful of times per process)
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+        float* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            segnb_set_error("segnb_head_bwd: scratch allocation of %zu bytes failed", want);
+            return nullptr;
+        }
+        buf[dev] = p;
+        cap[dev] = want;
+    }
+    return buf[dev];
+}
+}  // namespace
+
 extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
                               const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                               float* db, segnb_stream_t stream) {
@@ -385,17 +455,25 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
     if (gx > 2048 / gy) gx = 2048 / gy;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)gy);
-    if (dtype == SEGNB_BF16)
-        (K == 1 ? head_bwd_kernel<bf16_t, 1> : head_bwd_kernel<bf16_t, MAXK>)<<<grid, dim3(256), 0, (hipStream_t)stream>>>(
-            (const bf16_t*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (bf16_t*)da, ld_da, dw, db, ct);
-    else if (dtype == SEGNB_F32)
-        (K == 1 ? head_bwd_kernel<float, 1> : head_bwd_kernel<float, MAXK>)<<<grid, dim3(256), 0, (hipStream_t)stream>>>(
-            (const float*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (float*)da, ld_da, dw, db, ct);
-    else {
+    if (dtype != SEGNB_BF16 && dtype != SEGNB_F32) {
         segnb_set_error("segnb_head_bwd: unknown dtype %d", dtype);
         return SEGNB_E_BADARG;
     }
+    // per-block partial sums of dw / db (summed in block order by head_bwd_finish_kernel): a library-owned scratch buffer
+    // per device, grown on demand -- launches on ONE stream per device are assumed (the training step's main stream)
+    float* part = head_scratch((size_t)gx * gy * K * (ct * 8 + 1) * sizeof(float));
+    if (part == nullptr) return SEGNB_E_BADARG;
+    if (dtype == SEGNB_BF16)
+        (K == 1 ? head_bwd_kernel<bf16_t, 1> : head_bwd_kernel<bf16_t, MAXK>)<<<grid, dim3(256), 0, (hipStream_t)stream>>>(
+            (const bf16_t*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (bf16_t*)da, ld_da, part, ct);
+    else
+        (K == 1 ? head_bwd_kernel<float, 1> : head_bwd_kernel<float, MAXK>)<<<grid, dim3(256), 0, (hipStream_t)stream>>>(
+            (const float*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (float*)da, ld_da, part, ct);
     SEGNB_LAUNCH_CHECK();
+    if (dw != nullptr || db != nullptr) {
+        head_bwd_finish_kernel<<<dim3(K * C + K), dim3(64), 0, (hipStream_t)stream>>>(part, (int)gx, gy, K, C, ct, dw, db);
+        SEGNB_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -3,7 +3,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json [step kernel]
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes for gfx950: both counters are in
 KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes for wide coalesced reads, so it is DOUBLED; WRITE_SIZE is
@@ -71,7 +71,17 @@ def main():
                           'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
+    # HBM bytes of ONE training step: everything the profiled command moved, divided by the steps it ran (the optimizer
+    # kernel runs exactly once per step; warm-up and the host-enqueue measurement are steps like the timed ones)
+    step_kernel = sys.argv[4] if len(sys.argv) > 4 else 'sgd_kernel'
+    total_f = sum(v[1] for v in fe.values())
+    total_w = sum(v[1] for v in wr.values())
+    steps_f, steps_w = fe.get(step_kernel, [0, 0.0])[0], wr.get(step_kernel, [0, 0.0])[0]
+    per_step = None
+    if steps_f and steps_w:
+        per_step = round((2.0 * total_f / steps_f + total_w / steps_w) * 1024.0)
     doc = {'kernel_sources_digest': bench.kernel_sources_digest(),      # bench.py reports `traffic` only for this build
+           'bytes_per_step': per_step, 'steps_profiled': steps_f, 'step_kernel': step_kernel,
            'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
                    'separate --pmc passes; average over all launches of the kernel family in the profiled command',
            'kernels': res}
