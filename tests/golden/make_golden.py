@@ -342,6 +342,71 @@ def gen_tiles():
     print('tiles.npz', len(out), 'arrays')
 
 
+def _install_cv2_standin():
+    """cv2 is absent from the image.  What lib.tiles / lib.augmentations need from it at IMPORT time are enum constants
+    used as default arguments; what ImageSlicer.split / cut_patch need at run time is copyMakeBorder with
+    BORDER_REFLECT101, which is numpy's 'reflect' padding.  Anything else raises."""
+    import types
+
+    class _CV2(types.ModuleType):
+        BORDER_CONSTANT, BORDER_REPLICATE, BORDER_REFLECT, BORDER_WRAP, BORDER_REFLECT_101 = 0, 1, 2, 3, 4
+        BORDER_REFLECT101 = BORDER_DEFAULT = 4
+
+        def __getattr__(self, name):
+            if name.isupper():                 # INTER_*, COLOR_*: only ever stored as default arguments here
+                return hash(name) & 0xffff
+            raise AttributeError('cv2.%s is not available in this container' % name)
+
+        @staticmethod
+        def copyMakeBorder(image, top, bottom, left, right, borderType=4, value=0):
+            assert borderType == 4, 'only BORDER_REFLECT101 (the reference default) is restated'
+            pad = [(top, bottom), (left, right)] + [(0, 0)] * (image.ndim - 2)
+            return np.pad(image, pad, mode='reflect')
+
+    sys.modules['cv2'] = _CV2('cv2')
+
+
+def gen_augment():
+    """What was still a restatement after round 2, now produced by the reference's own code:
+    NormalizeImage (lib/augmentations.py:452-460), tta_d4_aug / tta_d4_deaug (:476-511) on NON-symmetric arrays, and
+    ImageSlicer.split / cut_patch (lib/tiles.py:98-135) -- the reference's margin / crop / indexing code around a
+    copyMakeBorder that is np.pad(mode='reflect') (cv2 itself is absent: _install_cv2_standin)."""
+    _install_cv2_standin()
+    for mod in ('lib.tiles', 'lib.augmentations'):
+        sys.modules.pop(mod, None)
+    from lib import augmentations as ref_aug
+    from lib import tiles as ref_tiles
+    rng = np.random.RandomState(11)
+    out = {}
+    img = rng.randint(0, 256, size=(9, 7, 3)).astype(np.uint8)
+    out['norm/u8'] = img
+    out['norm/default'] = ref_aug.NormalizeImage()(img)
+    out['norm/custom_args'] = np.array([1. / 128., 0.1, 0.2, 0.3, 0.5, 0.25, 2.0])
+    out['norm/custom'] = ref_aug.NormalizeImage(1. / 128., [0.1, 0.2, 0.3], [0.5, 0.25, 2.0])(img)
+    out['norm/f32_in'] = ref_aug.NormalizeImage()(img.astype(np.float32))
+    sq = [rng.rand(6, 6, 2).astype(np.float32), rng.rand(5, 5).astype(np.float32)]
+    for k, a in enumerate(sq):
+        out['d4/in%d' % k] = a
+        aug = ref_aug.tta_d4_aug([a])
+        out['d4/aug%d' % k] = np.stack(aug)
+        preds = [rng.rand(*a.shape).astype(np.float32) for _ in range(8)]
+        out['d4/preds%d' % k] = np.stack(preds)
+        out['d4/deaug%d' % k] = ref_aug.tta_d4_deaug(preds)[0]
+    cases = [((37, 45, 3), 16, 8, 0), ((40, 40), 16, 8, 0), ((30, 50, 1), 20, 10, 5), ((33, 33, 2), 32, 16, 0)]
+    for k, (shape, ts, step, margin) in enumerate(cases):
+        sl = ref_tiles.ImageSlicer(shape, ts, step, margin)
+        image = rng.rand(*shape).astype(np.float32)
+        tiles = sl.split(image)
+        out['split%d/args' % k] = np.array(list(shape) + [0] * (3 - len(shape)) + [len(shape), ts, step, margin])
+        out['split%d/image' % k] = image
+        out['split%d/tiles' % k] = np.stack(tiles)
+        idx = len(tiles) // 2
+        out['split%d/patch_index' % k] = np.array(idx)
+        out['split%d/patch' % k] = sl.cut_patch(image, idx)
+    np.savez_compressed(os.path.join(HERE, 'augment.npz'), **out)
+    print('augment.npz', len(out), 'arrays')
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # UNet16 / LinkNet34: the reference's wiring code run on torch.nn stand-ins for its absent third-party imports
 # ---------------------------------------------------------------------------------------------------------------------
@@ -461,7 +526,9 @@ def gen_linknet():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles', 'unet16', 'linknet']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles', 'augment', 'unet16', 'linknet']
+    if 'augment' in which:
+        gen_augment()
     if 'unet16' in which:
         gen_unet16()
     if 'linknet' in which:

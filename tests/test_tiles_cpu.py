@@ -83,6 +83,87 @@ def test_tta_d4_roundtrip():
         np.testing.assert_allclose(a, b, rtol=1e-6)
 
 
+def _split_cases(g):
+    k = 0
+    while 'split%d/args' % k in g.files:
+        a = g['split%d/args' % k]
+        nd = int(a[3])
+        yield k, tuple(int(v) for v in a[:nd]), int(a[4]), int(a[5]), int(a[6])
+        k += 1
+
+
+@pytest.mark.parametrize('impl', ['oracle', 'product'])
+def test_split_cut_patch_d4_vs_reference_golden(golden_dir, impl):
+    """tests/golden/augment.npz (make_golden.py gen_augment: the reference's lib/tiles.py:98-135 and
+    lib/augmentations.py:476-511 run on non-symmetric arrays): split / cut_patch tiles and the D4 pair, bit for bit."""
+    if impl == 'oracle':
+        tmod, amod = tiles_ref, tiles_ref
+    else:
+        import lib.augmentations as amod
+        import lib.tiles as tmod
+    g = np.load(os.path.join(golden_dir, 'augment.npz'))
+    n = 0
+    for k, shape, ts, step, margin in _split_cases(g):
+        sl = tmod.ImageSlicer(shape, ts, step, margin)
+        image = g['split%d/image' % k]
+        tiles = sl.split(image)
+        want = g['split%d/tiles' % k]
+        assert len(tiles) == len(want)
+        for a, b in zip(tiles, want):
+            assert np.array_equal(np.asarray(a).reshape(b.shape), b)
+        patch = sl.cut_patch(image, int(g['split%d/patch_index' % k]))
+        assert np.array_equal(np.asarray(patch).reshape(g['split%d/patch' % k].shape), g['split%d/patch' % k])
+        n += 1
+    assert n == 4
+    for k in (0, 1):
+        a = g['d4/in%d' % k]
+        aug = amod.tta_d4_aug([a])
+        assert len(aug) == 8 and all(np.array_equal(x, y) for x, y in zip(aug, g['d4/aug%d' % k]))
+        de = amod.tta_d4_deaug(list(g['d4/preds%d' % k]))
+        assert len(de) == 1 and np.array_equal(de[0], g['d4/deaug%d' % k])      # same summation order: bitwise
+
+
+def test_normalize_image_vs_reference_golden(golden_dir):
+    """NormalizeImage (lib/augmentations.py:452-460) as the reference computes it (uint8 * python float -> float64):
+    the test-side restatement bitwise, the product's device normalisation (InputNorm through segnb_pack_input_u8, here on
+    the ABI emulator) to fp32 rounding."""
+    from model_checks import normalize_image_ref
+    from segnb.engine import InputNorm, Runtime, View, pack_input
+    g = np.load(os.path.join(golden_dir, 'augment.npz'))
+    img = g['norm/u8']
+    assert np.array_equal(normalize_image_ref(img), g['norm/default'])
+    a = g['norm/custom_args']
+    assert np.array_equal(normalize_image_ref(img, a[0], a[1:4], a[4:7]), g['norm/custom'])
+    np.testing.assert_allclose(normalize_image_ref(img.astype(np.float32)), g['norm/f32_in'], rtol=1e-6, atol=1e-7)
+    rt = Runtime('cpu', 'f32')
+    for norm, want in ((InputNorm(), g['norm/default']), (InputNorm(a[0], a[1:4], a[4:7]), g['norm/custom'])):
+        xv = View.alloc(rt, 1, img.shape[0], img.shape[1], 8)
+        pack_input(rt, torch.from_numpy(img[None]), xv, norm)
+        got = xv.dense()[0, :, :, :3].numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+        assert float(xv.dense()[..., 3:].abs().max()) == 0.0
+
+
+def test_device_gather_reproduces_reference_split(golden_dir):
+    """segnb_tiles_gather (emulated here; the kernel itself in tests/test_tiles_gpu.py) with transform 0 == the
+    reference's ImageSlicer.split tiles."""
+    g = np.load(os.path.join(golden_dir, 'augment.npz'))
+    from lib.tiles import ImageSlicer
+    for k, shape, ts, step, margin in _split_cases(g):
+        image = g['split%d/image' % k]
+        img3 = image if image.ndim == 3 else image[..., None]
+        H, W, C = img3.shape
+        sl = ImageSlicer(shape, ts, step, margin)
+        img = torch.from_numpy(np.ascontiguousarray(img3))
+        crops = torch.tensor([[c[0], c[1]] for c in sl.crops], dtype=torch.int32)
+        want = g['split%d/tiles' % k]
+        for t in range(len(sl.crops)):
+            x = torch.zeros((1, C, ts, ts), dtype=torch.float32)
+            nv.call('segnb_tiles_gather', nv.ptr(img), H, W, C, sl.margin_top, sl.margin_left, nv.ptr(crops), 8 * t, 1, ts,
+                    nv.ptr(x), 0)
+            assert np.array_equal(x[0].permute(1, 2, 0).numpy().reshape(want[t].shape), want[t]), (k, t)
+
+
 class _Lin(torch.nn.Module):
     """a stand-in "model" with orientation-dependent output: 1x1 mix of the channels + a position ramp"""
 

@@ -38,6 +38,34 @@ def test_gather_merge_kernels_vs_oracle(shape, S):
     np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
 
 
+def test_gather_kernel_reproduces_reference_split(golden_dir):
+    """segnb_tiles_gather, transform 0, vs the tiles the reference's ImageSlicer.split produced (tests/golden/augment.npz:
+    lib/tiles.py:98-120 run by make_golden.py) -- incl. the margin case and single-channel images; bitwise (a gather)."""
+    import os
+    from lib.tiles import ImageSlicer
+    from segnb import _native as nv
+    g = np.load(os.path.join(golden_dir, 'augment.npz'))
+    k = 0
+    while 'split%d/args' % k in g.files:
+        a = g['split%d/args' % k]
+        shape, ts, step, margin = tuple(int(v) for v in a[:int(a[3])]), int(a[4]), int(a[5]), int(a[6])
+        image = g['split%d/image' % k]
+        img3 = image if image.ndim == 3 else image[..., None]
+        H, W, C = img3.shape
+        sl = ImageSlicer(shape, ts, step, margin)
+        img = torch.from_numpy(np.ascontiguousarray(img3)).cuda()
+        crops = torch.tensor([[c[0], c[1]] for c in sl.crops], dtype=torch.int32).cuda()
+        want = g['split%d/tiles' % k]
+        n = len(sl.crops)
+        x = torch.zeros((8 * n, C, ts, ts), dtype=torch.float32).cuda()
+        nv.call('segnb_tiles_gather', nv.ptr(img), H, W, C, sl.margin_top, sl.margin_left, nv.ptr(crops), 0, 8 * n, ts,
+                nv.ptr(x), torch.cuda.current_stream().cuda_stream)
+        got = x.view(n, 8, C, ts, ts)[:, 0].permute(0, 2, 3, 1).cpu().numpy()
+        assert np.array_equal(got.reshape(want.shape), want), k
+        k += 1
+    assert k == 4
+
+
 def test_predict_tiled_zf_unet_eval_and_throughput():
     """the real model in the loop (eval mode, bf16 kernels): device flow == oracle flow fed by the same model, and a
     throughput figure for the record (1024x1024 image, 256-pixel tiles, 49 tiles x 8 transforms)."""
