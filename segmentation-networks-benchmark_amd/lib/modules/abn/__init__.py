@@ -7,10 +7,21 @@ segnb_bn_act_bwd_reduce / segnb_bn_bwd_apply.  Inside LinkNet34 the module is on
 executor fuses BN + LeakyReLU behind each convolution); called on its own it runs the same kernels, with the NCHW <->
 NHWC moves as launches of the library too, and writes its result into the input's storage like the reference.
 
-Parity note (SURVEY 8c): whether the backend applies gamma or |gamma|+eps cannot be determined from the reference;
-this implementation uses the standard affine gamma (identical at the gamma = 1 initialisation).
+Affine form.  The un-vendored backend is absent, so which scale it applies cannot be
+read off the reference.  The API generation functions.py binds -- ``forward(x, mean, var, weight, bias, affine, eps)``,
+``edz_eydz(z, dz, weight, bias, affine, eps)``, ``backward(z, dz, var, weight, bias, edz, eydz, affine, eps)`` -- is
+mapillary's first release, whose kernels scale by ``abs(weight) + eps`` (invertibility of the in-place form) and
+return ``dweight = sign(weight) * sum(dz * yhat)``.  Both forms are offered:
+  * ``affine_form='gamma'`` (default): y = yhat * weight + bias -- what torch.nn.BatchNorm2d computes, what the
+    LinkNet34 executor fuses, and what every golden of this repository was produced with (the stand-in of
+    tests/golden/make_golden.py is BatchNorm2d + LeakyReLU);
+  * ``affine_form='abs_eps'`` (or SEGNB_ABN_AFFINE=abs_eps): y = yhat * (|weight| + eps) + bias with the backend's
+    gradient.  At the weight = 1 initialisation the two differ by the factor 1 + eps (1e-5 relative per layer), for
+    negative or near-zero weights outright.  Stand-alone module only: LinkNet34's fused plan keeps 'gamma'.
 ``InPlaceABNSync`` is instantiated by no model in the reference and is not provided.
 """
+import os
+
 from collections import OrderedDict
 
 import torch
@@ -36,8 +47,12 @@ class _ABNFn(torch.autograd.Function):
     INTO x's storage when autograd allows it (x is not a leaf that requires grad), so the module allocates no output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, slope):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, slope, abs_form=False):
         N, C, H, W = x.shape
+        w_param = weight
+        if abs_form and weight is not None:
+            # the backend's effective scale (a C-element parameter op; the activations stay on the kernels)
+            weight = weight.detach().abs() + eps
         Cp = cp.pad8(C)
         dev, st = x.device, (torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
         y = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
@@ -55,8 +70,10 @@ class _ABNFn(torch.autograd.Function):
         nv.call('segnb_bn_act_fwd', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), act, slope, None, nv.ptr(out), Cp,
                 None, 0, None, 0, None, 0, st)
         ctx.training = bool(training)
-        ctx.save_for_backward(y, coef, weight if weight is not None else coef.new_empty(0))
+        ctx.save_for_backward(y, coef, weight if weight is not None else coef.new_empty(0),
+                              w_param if (abs_form and w_param is not None) else coef.new_empty(0))
         ctx.cfg = (N, C, H, W, Cp, act, slope, weight is not None)
+        ctx.abs_form = bool(abs_form and w_param is not None)
         in_place = not (x.is_leaf and x.requires_grad)
         res = x if in_place else torch.empty_like(x)
         nv.call('segnb_nhwc_to_nchw_f32', nv.F32, nv.ptr(out), Cp, N, H, W, C, nv.ptr(res), st)
@@ -66,7 +83,7 @@ class _ABNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        y, coef, weight = ctx.saved_tensors
+        y, coef, weight, w_param = ctx.saved_tensors
         N, C, H, W, Cp, act, slope, affine = ctx.cfg
         dev, st = y.device, (torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0)
         gout = gout.detach().contiguous().float()
@@ -99,16 +116,25 @@ class _ABNFn(torch.autograd.Function):
             nv.call('segnb_bn_bwd_apply', nv.F32, nv.ptr(y), Cp, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), nv.ptr(dz), Cp,
                     nv.ptr(dz), Cp, None, C, st)
         nv.call('segnb_nhwc_to_nchw_f32', nv.F32, nv.ptr(dz), Cp, N, H, W, C, nv.ptr(dx), st)
-        return (dx, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
+        if ctx.abs_form:
+            # d(|w| + eps)/dw as the backend signs it: +1 for w > 0, -1 otherwise
+            dgamma = torch.where(w_param.detach() > 0, dgamma, -dgamma)
+        return (dx, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None, None)
 
 
 class InPlaceABN(nn.Module):
     """InPlace Activated Batch Normalization (bn.py:47-103): parameters weight/bias, buffers running_mean/var."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation='leaky_relu', slope=0.01):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation='leaky_relu', slope=0.01,
+                 affine_form=None):
         super(InPlaceABN, self).__init__()
         if activation not in (ACT_LEAKY_RELU, ACT_ELU, ACT_NONE):
             raise ValueError('activation must be one of leaky_relu, elu, none (bn.py:59), got %r' % (activation,))
+        if affine_form is None:
+            affine_form = os.environ.get('SEGNB_ABN_AFFINE', 'gamma')
+        if affine_form not in ('gamma', 'abs_eps'):
+            raise ValueError("affine_form must be 'gamma' or 'abs_eps', got %r" % (affine_form,))
+        self.affine_form = affine_form
         self.num_features, self.affine, self.eps, self.momentum = num_features, affine, eps, momentum
         self.activation, self.slope = activation, slope
         if affine:
@@ -130,7 +156,7 @@ class InPlaceABN(nn.Module):
     def forward(self, x):
         act = nv.ACT_LEAKY if self.activation == ACT_LEAKY_RELU else nv.ACT_NONE
         y = _ABNFn.apply(x.contiguous().float(), self.weight, self.bias, self.running_mean, self.running_var,
-                         self.training, self.momentum, self.eps, act, self.slope)
+                         self.training, self.momentum, self.eps, act, self.slope, self.affine_form == 'abs_eps')
         # 'elu' is used by no model of the reference: BatchNorm on the HIP kernels, the ELU as a torch op on top
         return torch.nn.functional.elu(y) if self.activation == ACT_ELU else y
 

@@ -5,6 +5,7 @@ summation noise by orders of magnitude on the way back to the first layers)."""
 import warnings
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import linknet_ref, losses_ref, tiramisu_ref, unet16_ref
@@ -345,3 +346,53 @@ def check_inplace_abn_surface(device):
         else:
             assert abn.weight is None and abn.bias is None and 'weight' not in abn.state_dict()
         torch.testing.assert_close(abn.running_var.cpu(), bn.running_var, rtol=1e-5, atol=1e-6, msg=str(tag))
+
+
+def check_inplace_abn_abs_form(device):
+    """InPlaceABN(affine_form='abs_eps'): y = leaky(yhat * (|w| + eps) + b), dw = sign(w) * sum(dz * yhat) -- the affine
+    form of the inplace_abn API generation that lib/modules/abn/functions.py:81-118 binds -- against a torch restatement,
+    with negative and near-zero weights; and the default 'gamma' form against nn.BatchNorm2d on the same weights (the
+    two differ there)."""
+    import torch.nn.functional as F
+    from lib.modules.abn import InPlaceABN
+    torch.manual_seed(7)
+    C = 10
+    x = torch.randn(4, C, 6, 5)
+    w0 = torch.tensor([1.0, -0.7, 1e-7, -1e-7, 0.3, -1.5, 2.0, 1.0, -1.0, 0.05])
+    b0 = 0.1 * torch.randn(C)
+    r = torch.randn(4, C, 6, 5)
+    eps = 1e-5
+
+    def restated(xin, w, b, abs_form):
+        mean = xin.mean((0, 2, 3), keepdim=True)
+        var = xin.var((0, 2, 3), unbiased=False, keepdim=True)
+        scale = (w.abs() + eps) if abs_form else w
+        return F.leaky_relu((xin - mean) * torch.rsqrt(var + eps) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1), 0.01)
+
+    outs = {}
+    for form in ('abs_eps', 'gamma'):
+        abn = InPlaceABN(C, affine_form=form).to(device)
+        with torch.no_grad():
+            abn.weight.copy_(w0)
+            abn.bias.copy_(b0)
+        xa = x.clone().to(device).requires_grad_(True)
+        ya = abn(xa)
+        (ya * r.to(device)).sum().backward()
+        w = w0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        yb = restated(xb, w, b, form == 'abs_eps')
+        (yb * r).sum().backward()
+        torch.testing.assert_close(ya.detach().cpu(), yb.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(xa.grad.cpu(), xb.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(abn.weight.grad.cpu(), w.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(abn.bias.grad.cpu(), b.grad, rtol=1e-4, atol=2e-5)
+        outs[form] = ya.detach().cpu()
+    # the forms are different functions of the same parameters (negative weights flip the sign of the scaled term)
+    assert float((outs['abs_eps'] - outs['gamma']).abs().max()) > 0.1
+    # at the weight = 1 initialisation they differ by the factor 1 + eps on the normalised term
+    a1, a2 = InPlaceABN(C, affine_form='abs_eps').to(device), InPlaceABN(C, affine_form='gamma').to(device)
+    d = (a1(x.clone().to(device)) - a2(x.clone().to(device))).abs().max().item()
+    assert 0.0 < d < 1e-4
+    with pytest.raises(ValueError):
+        InPlaceABN(C, affine_form='other')

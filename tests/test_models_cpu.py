@@ -157,6 +157,10 @@ def test_inplace_abn_constructor_surface():
     mc.check_inplace_abn_surface('cpu')
 
 
+def test_inplace_abn_abs_eps_affine_form():
+    mc.check_inplace_abn_abs_form('cpu')
+
+
 def test_replay_harness_self_consistent(golden_dir):
     """tests/abi_replay.py (the teacher-forced GPU parity harness) replaying the emulator against itself."""
     import abi_replay

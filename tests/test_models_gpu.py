@@ -310,6 +310,10 @@ def test_inplace_abn_constructor_surface_gpu():
     mc.check_inplace_abn_surface('cuda')
 
 
+def test_inplace_abn_abs_eps_affine_form_gpu():
+    mc.check_inplace_abn_abs_form('cuda')
+
+
 def test_find_optimal_lr_gpu():
     """lib.train_utils.find_optimal_lr (train_utils.py:36-69) on the HIP path: 30 steps, lr doubling from 1e-8,
     gradients accumulate (never zeroed) exactly as the same loop on the oracle."""
