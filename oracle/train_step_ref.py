@@ -15,8 +15,11 @@ from . import losses_ref, zf_unet_ref
 
 
 def loss_and_grads(sd, x, y, loss_name='bce_jaccard', drop=None, train=True, forward=zf_unet_ref.forward,
-                   is_param=zf_unet_ref.is_param):
-    """One forward + loss + (B*loss).backward().  Returns (loss, logits, {name: grad})."""
+                   is_param=zf_unet_ref.is_param, autocast=False):
+    """One forward + loss + (B*loss).backward().  Returns (loss, logits, {name: grad}).
+    autocast: run the model under torch.autocast('cpu', bfloat16) -- what the reference's own code computes when a user
+    switches it to bf16 (fp32 parameters, bf16 convolutions, loss on the fp32-cast logits): the yardstick the HIP bf16
+    throughput path is measured against (tests/test_zf_unet_gpu.py)."""
     leaves = {}
     work = {}
     for k, v in sd.items():
@@ -25,7 +28,12 @@ def loss_and_grads(sd, x, y, loss_name='bce_jaccard', drop=None, train=True, for
             work[k] = leaves[k]
         else:
             work[k] = v            # BN buffers: updated in place, as nn.BatchNorm2d does
-    logits = forward(work, x, train=train, drop=drop)
+    if autocast:
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            logits = forward(work, x, train=train, drop=drop)
+        logits = logits.float()
+    else:
+        logits = forward(work, x, train=train, drop=drop)
     loss = losses_ref.LOSSES[loss_name](logits, y)
     (x.shape[0] * loss).backward()
     grads = {k: p.grad for k, p in leaves.items()}

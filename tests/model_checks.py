@@ -396,3 +396,48 @@ def check_inplace_abn_abs_form(device):
     assert 0.0 < d < 1e-4
     with pytest.raises(ValueError):
         InPlaceABN(C, affine_form='other')
+
+
+# ---- bf16 yardstick: the reference's own arithmetic under torch.autocast('cpu', bfloat16) -------------------------------
+def grad_cosines(ga, gb, names):
+    """(global cosine, (worst tensor name, its cosine)) over the named gradient tensors."""
+    worst = ('', 1.0)
+    num = da = db = 0.0
+    for n in names:
+        a, b = ga[n].double().reshape(-1), gb[n].double().reshape(-1)
+        ab, aa, bb = float((a * b).sum()), float((a * a).sum()), float((b * b).sum())
+        c = ab / max(np.sqrt(aa * bb), 1e-300)
+        if c < worst[1]:
+            worst = (n, c)
+        num, da, db = num + ab, da + aa, db + bb
+    return num / np.sqrt(da * db), worst
+
+
+def autocast_yardstick(sd_fn, x, y, loss_name, drop):
+    """The oracle step in fp32 and under bf16 autocast on the same weights / batch / dropout draw.
+    -> dict(dloss, diou, cos, worst, flipped) of autocast relative to fp32, plus the fp32 results for further use."""
+    from oracle import train_step_ref
+    l32, o32, g32 = train_step_ref.loss_and_grads(sd_fn(), x, y, loss_name, drop=drop)
+    l16, o16, g16 = train_step_ref.loss_and_grads(sd_fn(), x, y, loss_name, drop=drop, autocast=True)
+    names = [n for n in g32 if n.endswith('conv.weight') or n == 'conv_final.weight']
+    cos, worst = grad_cosines(g16, g32, names)
+    return dict(dloss=float(l16 - l32), diou=float(losses_ref.jaccard_score(o16, y) - losses_ref.jaccard_score(o32, y)),
+                cos=cos, worst=worst, flipped=float(((o16 > 0) != (o32 > 0)).float().mean()),
+                fp32=(float(l32), o32, g32), names=names)
+
+
+def blob_batch(B, S, seed):
+    """A learnable synthetic segmentation task: 2-5 filled rectangles / discs per image on a noisy background; the mask
+    is their union, the image shows them as brighter, differently tinted regions."""
+    rng = np.random.RandomState(seed)
+    x = 0.35 * rng.randn(B, 3, S, S).astype(np.float32)
+    y = np.zeros((B, 1, S, S), dtype=np.int64)
+    yy, xx = np.mgrid[0:S, 0:S]
+    for b in range(B):
+        for _ in range(rng.randint(2, 6)):
+            cy, cx, r = rng.randint(0, S), rng.randint(0, S), rng.randint(S // 12, S // 4)
+            m = ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r) if rng.rand() < 0.5 else \
+                ((abs(yy - cy) <= r) & (abs(xx - cx) <= r // 2 + 1))
+            y[b, 0][m] = 1
+            x[b][:, m] += (0.8 + 0.4 * rng.rand(3, 1)).astype(np.float32)
+    return torch.from_numpy(x), torch.from_numpy(y)

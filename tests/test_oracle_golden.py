@@ -126,3 +126,20 @@ def test_zf_unet_224_scalars(golden_dir):
     names = list(g['grad_names'])
     norms = np.array([np.sqrt((grads[n].numpy().astype(np.float64) ** 2).sum()) for n in names])
     np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-3, atol=2e-6 * norms.max())
+
+
+def test_bf16_autocast_yardstick_b4(golden_dir):
+    """What bf16 costs the REFERENCE's arithmetic (oracle under torch.autocast('cpu', bfloat16), B=4 224x224, the golden
+    weights and Dropout2d draw): the yardstick the HIP bf16 path is held to in tests/test_zf_unet_gpu.py (VERDICT r2
+    item 5a).  Measured here: dloss +6.3e-5, dIoU -6.6e-5, weight-gradient cosine 0.66 (worst tensor 0.62), 5 % of the
+    thresholded pixels flipped -- a random-init net; the bounds only pin the order of magnitude."""
+    import model_checks as mc
+    g = _load(golden_dir, 'zf_unet_224.npz')
+    x, y = train_step_ref.synthetic_batch(4, 224, seed=1234)
+    drop = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('drop/')}
+    ys = mc.autocast_yardstick(lambda: zf_unet_ref.default_init_state(filters=32, seed=1), x, y, 'bce_jaccard', drop)
+    print('autocast yardstick B=4: dloss %.3e dIoU %.3e cos %.4f worst %s %.4f flipped %.4f'
+          % (ys['dloss'], ys['diou'], ys['cos'], ys['worst'][0], ys['worst'][1], ys['flipped']))
+    assert abs(ys['fp32'][0] - float(g['loss_bce_jaccard'])) < 1e-5
+    assert 5e-6 < abs(ys['dloss']) < 5e-4 and abs(ys['diou']) < 5e-4
+    assert 0.4 < ys['cos'] < 0.95 and 0.005 < ys['flipped'] < 0.15
