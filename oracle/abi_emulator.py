@@ -244,13 +244,13 @@ class AbiEmulator(object):
         return 0
 
     # batched forms: decode the device job table (segnb.engine.PACK_JOB_DTYPE) and run the single-job methods
-    JOB_BYTES = 328
+    JOB_BYTES = 336
 
     def segnb_pack_job_bytes(self):
         return self.JOB_BYTES
 
     def segnb_pack_job_blocks(self, Mp, Cp, ntaps, s_m, s_c):
-        if min(s_m, s_c) > 9 or ntaps > 9:
+        if min(s_m, s_c) > 9 or ntaps > 64:
             return -1
         if s_c < s_m:
             return (Cp + 255) // 256 * Mp
@@ -260,11 +260,46 @@ class AbiEmulator(object):
         raw = bytes((ctypes.c_char * (njobs * self.JOB_BYTES)).from_address(int(jobs)))
         dt = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
                        ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
-                       ('block_start', '<i4'), ('nslab', '<i4'), ('tap_off', '<i4', (64,))])
+                       ('block_start', '<i4'), ('nslab', '<i4'), ('masked', '<i4'), ('pad_', '<i4'),
+                       ('tap_off', '<i4', (64,))])
         return np.frombuffer(raw, dtype=dt)
+
+    # masked jobs (PackJob.masked): tap_off[t] is a bit mask over the <= 9 kernel positions of the parameter --
+    # pack: packed(m, t, c) = sum_{k in mask[t]} w(m, c, k), rounded once;  unpack: gw(m, c, k) += sum_{t: k in mask[t]} dwp(m, t, c)
+    def _pack_masked(self, j):
+        Mp, Cp, nt = int(j['Mp']), int(j['Cp']), int(j['ntaps'])
+        dt = _tdt(int(j['dtype']))
+        acc = torch.zeros(Mp, nt, Cp)
+        for t in range(nt):
+            for k in range(9):
+                if int(j['tap_off'][t]) >> k & 1:
+                    one = torch.zeros(Mp * Cp, dtype=torch.float32)
+                    self.segnb_pack_weight(int(j['w']), one.data_ptr(), F32, Mp, Cp, 1, int(j['s_m']), int(j['s_c']), [k],
+                                           int(j['mmap']), int(j['cmap']), 0)
+                    acc[:, t, :] += one.view(Mp, Cp)
+        _mem(int(j['packed']), Mp * nt * Cp, dt).view(Mp, nt, Cp).copy_(acc.to(dt))
+
+    def _unpack_masked(self, j):
+        Mp, Cp, nt = int(j['Mp']), int(j['Cp']), int(j['ntaps'])
+        src = _mem(int(j['packed']), Mp * nt * Cp, torch.float32).view(Mp, nt, Cp)
+        for k in range(9):
+            part = torch.zeros(Mp, 1, Cp)
+            hit = False
+            for t in range(nt):
+                if int(j['tap_off'][t]) >> k & 1:
+                    part[:, 0, :] += src[:, t, :]
+                    hit = True
+            if hit:
+                keep = part.clone()
+                self.segnb_unpack_wgrad(keep.data_ptr(), int(j['w']), Mp, Cp, 1, int(j['s_m']), int(j['s_c']), [k],
+                                        int(j['mmap']), int(j['cmap']), 1, 0)
+        src.zero_()
 
     def segnb_pack_weight_multi(self, jobs, njobs, total_blocks, stream):
         for j in self._jobs(jobs, njobs):
+            if int(j['masked']):
+                self._pack_masked(j)
+                continue
             self.segnb_pack_weight(int(j['w']), int(j['packed']), int(j['dtype']), int(j['Mp']), int(j['Cp']),
                                    int(j['ntaps']), int(j['s_m']), int(j['s_c']),
                                    [int(v) for v in j['tap_off'][:int(j['ntaps'])]], int(j['mmap']), int(j['cmap']), stream)
@@ -278,6 +313,9 @@ class AbiEmulator(object):
                 G = _mem(int(j['packed']), ns * n1, torch.float32).view(ns, n1)
                 for sl in range(1, ns):
                     G[0] += G[sl]
+            if int(j['masked']):
+                self._unpack_masked(j)
+                continue
             self.segnb_unpack_wgrad(int(j['packed']), int(j['w']), int(j['Mp']), int(j['Cp']), int(j['ntaps']),
                                     int(j['s_m']), int(j['s_c']), [int(v) for v in j['tap_off'][:int(j['ntaps'])]],
                                     int(j['mmap']), int(j['cmap']), 1, stream)

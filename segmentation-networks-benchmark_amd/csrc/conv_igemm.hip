@@ -767,6 +767,13 @@ struct __attribute__((aligned(8))) PackJob {
     int Mp, Cp, ntaps, dtype;
     int block_start;         // first block of this job; jobs sorted by it
     int nslab;               // unpack jobs: partial slabs to sum ([nslab][Mp][ntaps][Cp], segnb_conv_wgrad_partial); 0/1 = one
+    // masked != 0: tap_off[t] is a BIT MASK over the (<= 9) kernel positions of the parameter tensor instead of one offset --
+    //   pack  : packed(m, t, c) = sum over the set positions k of w(m, c, k)      (rounded once, after the fp32 sum)
+    //   unpack: gw(m, c, k)    += sum over the taps t whose mask holds k of dwp(m, t, c)          (taps in order)
+    // = the convolution of a nearest-x2 upsampled tensor as the 4x4 / stride-2 transposed convolution it is, on the
+    // reference's own 3x3 parameter (lib/models/zf_unet.py:42,78-90: Upsample(scale_factor=2) -> cat -> conv3x3)
+    int masked;
+    int pad_;
     int tap_off[SEGNB_MAX_TAPS];
 };
 
@@ -859,6 +866,10 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         return sl * run + fa * g.Tsrc + j.tap_off[t];
     };
     const int cp_step = g.fast_is_c ? g.Tsrc : run;              // LDS stride between consecutive cp
+    auto tile_base = [&](int mpl, int cpl) {                     // LDS index of kernel position 0 of packed (mp, cp)
+        const int sl = g.fast_is_c ? mpl : cpl, fa = g.fast_is_c ? cpl : mpl;
+        return sl * run + fa * g.Tsrc;
+    };
 
     if (IS_PACK) {
         // parameter -> LDS, in parameter order (coalesced along the fast channel and the taps).  All of a lane's loads
@@ -889,9 +900,21 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
             const int mp = (g.fast_is_c ? s0 : f0) + mpl, cp = (g.fast_is_c ? f0 : s0) + cpl;
             if (mp < Mp && cp < Cp) {
                 float v[8];
-                const int base = tile_idx(mpl, t, cpl);
+                if (j.masked) {
+                    const int base0 = tile_base(mpl, cpl);
+                    const unsigned mask = (unsigned)j.tap_off[t];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = tile[base + k * cp_step];
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                    for (int pos = 0; pos < g.Tsrc; ++pos)
+                        if (mask >> pos & 1u) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] += tile[base0 + pos + k * cp_step];
+                        }
+                } else {
+                    const int base = tile_idx(mpl, t, cpl);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = tile[base + k * cp_step];
+                }
                 const long long di = ((long long)mp * nt + t) * Cp + cp;
                 if (j.dtype == SEGNB_BF16)
                     store8(reinterpret_cast<bf16_t*>(j.packed) + di, v);
@@ -903,6 +926,49 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         float* dwp = reinterpret_cast<float*>(j.packed);
         for (int i = threadIdx.x; i < n_param; i += 256) tile[i] = 0.f;
         __syncthreads();
+        if (j.masked) {
+            // one thread owns every tap of its (mp, 8 x cp) group: the taps that share a kernel position are summed in
+            // registers, in tap order (no collisions in the tile, bitwise reproducible)
+            const int pairs = nmp * (ncp / 8);
+            const long long sstride = (long long)Mp * nt * Cp;
+            for (int gi = threadIdx.x; gi < pairs; gi += 256) {
+                const int cpl = (gi % (ncp / 8)) * 8, mpl = gi / (ncp / 8);
+                const int mp = (g.fast_is_c ? s0 : f0) + mpl, cp = (g.fast_is_c ? f0 : s0) + cpl;
+                if (mp >= Mp || cp >= Cp) continue;
+                float acc[9][8];
+#pragma unroll
+                for (int pos = 0; pos < 9; ++pos)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[pos][k] = 0.f;
+                for (int t = 0; t < nt; ++t) {
+                    const long long di = ((long long)mp * nt + t) * Cp + cp;
+                    float v[8];
+                    load8(dwp + di, v);
+                    for (int sl = 1; sl < j.nslab; ++sl) {
+                        float u[8];
+                        load8(dwp + sl * sstride + di, u);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += u[k];
+                    }
+                    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    store8(dwp + di, z);
+                    const unsigned mask = (unsigned)j.tap_off[t];
+#pragma unroll
+                    for (int pos = 0; pos < 9; ++pos)
+                        if (mask >> pos & 1u) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) acc[pos][k] += v[k];
+                        }
+                }
+                const int base0 = tile_base(mpl, cpl);
+#pragma unroll
+                for (int pos = 0; pos < 9; ++pos)
+                    if (pos < g.Tsrc) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) tile[base0 + pos + k * cp_step] = acc[pos][k];
+                    }
+            }
+        } else
         for (int gi = threadIdx.x; gi < groups; gi += 256) {
             int mpl, t, cpl;
             group(gi, mpl, t, cpl);
@@ -1321,7 +1387,9 @@ extern "C" int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, l
     j.Mp = Mp; j.Cp = Cp; j.ntaps = ntaps; j.s_m = s_m; j.s_c = s_c;
     const bool fast_is_c = s_c < s_m;
     const long long tsrc = fast_is_c ? s_c : s_m;
-    if (tsrc > 9 || ntaps > 9) return -1;           // tiled kernel sized for <= 3x3
+    // tiled kernel sized for parameter tensors of <= 3x3 positions; jobs with MORE packed taps than that are the masked
+    // ones (several packed taps per kernel position, PackJob.masked)
+    if (tsrc > 9 || (ntaps > 9 && ntaps > SEGNB_MAX_TAPS)) return -1;
     if (fast_is_c) return ((Cp + 255) / 256) * Mp;
     return ((Mp + 7) / 8) * ((Cp + 63) / 64);
 }

@@ -20,7 +20,7 @@ from torch import nn
 
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.engine import ConvOp, FlatParams, InputNorm, PackTable, Runtime, Stage, View, pack_input
+from segnb.engine import ConvOp, FlatParams, InputNorm, PackTable, Runtime, Stage, UpCatConvOp, View, pack_input
 
 ENCODER = ('conv_224', 'conv_112', 'conv_56', 'conv_28', 'conv_14', 'conv_7')
 DECODER = ('up_conv_14', 'up_conv_28', 'up_conv_56', 'up_conv_112', 'up_conv_224')
@@ -150,10 +150,15 @@ class _ZFUnetPlan(object):
             blk = getattr(module, name)
             seg1 = [(cfg['cin'], self.cin_p)] if i == 0 else [(widths[i - 1], self.wp[i - 1])]
             self._add(name, blk, seg1, need_dgrad_l1=(i > 0))
+        # Decoder blocks: the backward of conv3x3(cat([Upsample x2(u), skip])) by input segment, the upsampled one on the
+        # low-resolution tensor (segnb.engine.UpCatConvOp: 4 x 4 / stride-2 transposed-convolution identity, 16 instead of 36
+        # multiply-adds per low-resolution pixel).  Throughput path only: the exact-fp32 parity mode keeps the plain plan.
+        sp = os.environ.get('SEGNB_SUBPIXEL', 'auto')
+        self.subpixel = (module.compute_dtype == 'bf16') if sp == 'auto' else sp not in ('0', 'off')
         for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
             blk = getattr(module, name)
             seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
-            self._add(name, blk, seg1, True)
+            self._add(name, blk, seg1, True, upcat=self.subpixel)
         self._bufs = {}
         self._pack_tables = {}
         self._packed_key = None
@@ -161,10 +166,13 @@ class _ZFUnetPlan(object):
         self.generation = 0
         self.K = module.num_classes
 
-    def _add(self, name, blk, seg1, need_dgrad_l1):
+    def _add(self, name, blk, seg1, need_dgrad_l1, upcat=False):
         rt = self.rt
         cout = blk.l1.conv.out_channels
-        c1 = ConvOp(rt, blk.l1.conv.weight, blk.l1.conv.bias, seg1, 1, 1, False, need_dgrad_l1)
+        if upcat:
+            c1 = UpCatConvOp(rt, blk.l1.conv.weight, blk.l1.conv.bias, seg1, need_dgrad_l1)
+        else:
+            c1 = ConvOp(rt, blk.l1.conv.weight, blk.l1.conv.bias, seg1, 1, 1, False, need_dgrad_l1)
         c2 = ConvOp(rt, blk.l2.conv.weight, blk.l2.conv.bias, [(cout, cp.pad8(cout))], 1, 1, False, True)
         self.stages[name] = (Stage(rt, c1, blk.l1.bn, nv.ACT_RELU, 0.0, name + '.l1'),
                              Stage(rt, c2, blk.l2.bn, nv.ACT_RELU, 0.0, name + '.l2'))
@@ -192,6 +200,11 @@ class _ZFUnetPlan(object):
                 b['dcat_%d' % i] = View.alloc(rt, N, h, w, wp[i + 1] + wp[i])
                 b['b1_%d' % i] = View.alloc(rt, N, h, w, wp[i])      # decoder l1 activated
                 b['db1_%d' % i] = View.alloc(rt, N, h, w, wp[i])
+                if self.subpixel:
+                    # the tensor cat_i's first segment is upsampled from, at its own (half) resolution, and its gradient
+                    h2, w2 = hs[i + 1]
+                    b['u_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
+                    b['du_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
         b['f0'] = View.alloc(rt, N, H, W, wp[0])
         b['df0'] = View.alloc(rt, N, H, W, wp[0])
         b['logits'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
@@ -436,12 +449,14 @@ class _ZFUnetPlan(object):
                     s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
                     cur = b['p_%d' % (i + 1)]
                 else:
-                    s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad)
+                    s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad,
+                               out=b['u_4'] if (self.subpixel and need_grad) else None)
             for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
                 s1, s2 = self.stages[name]
                 s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
                 if lvl > 0:
-                    s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad)
+                    s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad,
+                               out=b['u_%d' % (lvl - 1)] if (self.subpixel and need_grad) else None)
                 else:
                     s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
             head = self.module.conv_final
@@ -511,9 +526,15 @@ class _ZFUnetPlan(object):
                 # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
                 if lvl == 0:
                     red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
+                elif self.subpixel:
+                    # the level above handed the gradient of this block's output over at THIS resolution (du)
+                    red = s2.backward(flat, g_direct=b['du_%d' % (lvl - 1)], dx=b['db1_%d' % lvl], postponed=hold,
+                                      fuse_reduce_of=s1)
                 else:
                     red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
                                       postponed=hold, fuse_reduce_of=s1)
+                if self.subpixel:
+                    s1.conv.bind_up(b['u_%d' % lvl], b['du_%d' % lvl])
                 s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
             rt.flush_postponed(post)
             self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
@@ -521,7 +542,9 @@ class _ZFUnetPlan(object):
                 if i == 3:
                     self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
                 s1, s2 = self.stages[ENCODER[i]]
-                if i == 5:
+                if i == 5 and self.subpixel:
+                    red = s2.backward(flat, g_direct=b['du_4'], dx=b['da1_5'], fuse_reduce_of=s1)
+                elif i == 5:
                     red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
                 else:
                     red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],

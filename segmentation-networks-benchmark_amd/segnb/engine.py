@@ -26,9 +26,14 @@ class KernelTimer(object):
     def __init__(self):
         self.records = []      # (label, algorithmic_flops, start_event, end_event)
         self.acc = {}
+        self.executed, self.algorithmic = {}, {}      # per label, summed over the launches SEEN by launch() (recording steps)
         self.persistent = False    # the events are part of a recorded launch list: re-recorded by every replay
 
-    def launch(self, label, flops, fn):
+    def launch(self, label, flops, fn, executed=None):
+        """flops: ALGORITHMIC count of the launch (the reference's 3x3 taps); executed: what the kernel
+        really issues when that differs (sub-pixel form of Upsample -> conv: 4 taps instead of 9)."""
+        self.executed[label] = self.executed.get(label, 0.0) + (flops if executed is None else executed)
+        self.algorithmic[label] = self.algorithmic.get(label, 0.0) + flops
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()             # (creates the HIP event; recorded again below through the ABI)
@@ -58,11 +63,11 @@ class KernelTimer(object):
 TIMER = None
 
 
-def _timed(label, flops, fn):
+def _timed(label, flops, fn, executed=None):
     if TIMER is None:
         fn()
     else:
-        TIMER.launch(label, flops, fn)
+        TIMER.launch(label, flops, fn, executed)
 
 
 class Runtime(object):
@@ -213,8 +218,13 @@ class ConvOp(object):
     # over the chip beside the dependent chain: OFF by default.
     partial_slabs = os.environ.get('SEGNB_WGRAD_PARTIAL', '0') != '0'
 
+    algo_scale = 1.0        # algorithmic / executed FLOPs of a launch (UpConvOp: 9 / 4)
+    pack_fwd = True         # False: the forward matrix is never used (the owner runs the forward through another op)
+
     def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True,
-                 out_hw=None):
+                 out_hw=None, ci_offset=0):
+        """ci_offset: the op covers input channels [ci_offset, ci_offset + sum(real)) of the parameter tensor only (one
+        segment of a concatenated input handled on its own)."""
         self.rt = rt
         self.out_hw_override = out_hw      # transposed conv only: crop the output at the bottom/right
                                            # (center_crop of tiramisu.py:86-90 always has offset 0)
@@ -227,10 +237,13 @@ class ConvOp(object):
         else:
             self.Co, self.Ci, self.KH, self.KW = weight.shape
             self.s_out, self.s_in = self.Ci * self.KH * self.KW, self.KH * self.KW
+        if ci_offset or sum(r for r, _ in in_segments) != self.Ci:
+            assert not transposed and ci_offset + sum(r for r, _ in in_segments) <= self.Ci
+            self.Ci = sum(r for r, _ in in_segments)       # (strides above stay those of the whole parameter)
         assert sum(r for r, _ in in_segments) == self.Ci, (in_segments, self.Ci)
         self.Cop = cp.pad8(self.Co)
         imap = []
-        base = 0
+        base = ci_offset
         for real, padded in in_segments:
             assert padded % 8 == 0 and padded >= real
             imap += [base + i for i in range(real)] + [-1] * (padded - real)
@@ -331,7 +344,7 @@ class ConvOp(object):
         p, rt = self.plan(Hi, Wi), self.rt
         w = self.weight.detach()
         jobs = []
-        for li, l in enumerate(p['fwd']):
+        for li, l in enumerate(p['fwd'] if self.pack_fwd else ()):
             jobs.append(dict(w=w, packed=p['wp_fwd'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
                              s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code,
                              tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
@@ -382,9 +395,10 @@ class ConvOp(object):
             return
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
-            _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+            ex = 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co
+            _timed('conv_fprop', ex * self.algo_scale,
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
-                                   self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream))
+                                   self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream), ex)
 
     def act_epilogue_ok(self, H, W):
         """segnb_conv_fprop_act needs ONE launch that covers the whole output (not a phase-split transposed convolution)."""
@@ -438,9 +452,10 @@ class ConvOp(object):
                        lambda: nv.call('segnb_conv_fprop_bnreduce', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), dxv.ptr,
                                        ep, rt.stream))
                 continue
-            _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+            ex = 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co
+            _timed('conv_fprop', ex * self.algo_scale,
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
-                                   dxv.ptr, None, rt.stream))
+                                   dxv.ptr, None, rt.stream), ex)
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
@@ -453,7 +468,10 @@ class ConvOp(object):
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
                 g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
-                nv.call(entry, g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li], rt.stream)
+                ex = 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co
+                _timed('conv_wgrad', ex * self.algo_scale,
+                       lambda: nv.call(entry, g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li], rt.stream),
+                       ex)
                 if unpack:
                     nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
                             self.s_in, self.s_out, p['tapoff_dg'][li], nv.ptr(self.in_map), nv.ptr(self.out_map), 1,
@@ -470,9 +488,139 @@ class ConvOp(object):
                         rt.stream)
 
 
+class UpConvOp(ConvOp):
+    """The nearest-x2 upsampled segment of a convolution's input, computed on the LOW-resolution tensor.
+
+    conv3x3(pad 1) over Upsample(scale_factor=2)(u)  (lib/models/zf_unet.py:42,78-90) is exactly the transposed
+    convolution ConvTranspose2d(k=4, stride=2, pad=1)(u) whose 4x4 kernel is Wt[k] = sum of the 3x3 rows T[k]:
+        k = 0: {dy = +1}    k = 1: {dy = 0, +1}    k = 2: {dy = -1, 0}    k = 3: {dy = -1}     (same along the width)
+    i.e. per output parity 2 x 2 taps on u instead of 3 x 3 taps on the 4x larger upsampled tensor: 4/9 of the
+    multiply-adds, forward, data gradient and weight gradient alike, and the upsampled copy is never read.  The op reuses
+    ConvOp's transposed-convolution plan (phase launches forward, one 16-tap stride-2 gather for the data gradient, the
+    'wt' weight-gradient geometry); only the weight pack / gradient unpack differ: they work on the reference's own 3x3
+    parameter through MASKED jobs (PackJob.masked: one packed tap = the sum of several kernel positions).
+    """
+    T = ((2,), (1, 2), (0, 1), (0,))
+    algo_scale = 9.0 / 4.0
+
+    def __init__(self, rt, weight, ci_real, ci_pad, need_dgrad=True, pack_fwd=True):
+        co, ci_total, kh, kw = weight.shape
+        assert (kh, kw) == (3, 3) and ci_real <= ci_total and ci_pad % 8 == 0 and ci_pad >= ci_real
+        self.rt, self.weight, self.bias = rt, weight, None
+        self.out_hw_override = None
+        self.stride, self.pad, self.transposed = 2, 1, True
+        self.need_dgrad, self.pack_fwd = need_dgrad, pack_fwd
+        self.Ci, self.Co, self.KH, self.KW = ci_real, co, 4, 4
+        # element strides of the 3x3 parameter [Co][Ci_total][3][3], in ConvOp's transposed-convolution naming:
+        # s_out = stride of one OUTPUT channel, s_in = stride of one input channel
+        self.s_out, self.s_in = ci_total * 9, 9
+        self.Cop, self.Cip = cp.pad8(co), ci_pad
+        self.in_map = rt.int32(list(range(ci_real)) + [-1] * (ci_pad - ci_real))
+        self.out_map = rt.int32(list(range(co)) + [-1] * (self.Cop - co))
+        self._plans = {}
+
+    @classmethod
+    def mask(cls, a, b):
+        """bit mask over the nine 3x3 positions (kh * 3 + kw) summed into position (a, b) of the 4x4 kernel"""
+        return sum(1 << (kh * 3 + kw) for kh in cls.T[a] for kw in cls.T[b])
+
+    def pack(self, Hi, Wi):
+        raise NotImplementedError('UpConvOp packs through the batched job table only (masked jobs)')
+
+    def pack_jobs(self, Hi, Wi):
+        p, rt = self.plan(Hi, Wi), self.rt
+        w = self.weight.detach()
+        jobs = []
+        for li, l in enumerate(p['fwd'] if self.pack_fwd else ()):
+            # ConvOp's transposed naming: the forward matrix is [Co][taps][Ci]
+            jobs.append(dict(w=w, packed=p['wp_fwd'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
+                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code, masked=True,
+                             tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]))
+        if self.need_dgrad:
+            for li, l in enumerate(p['dg']):
+                jobs.append(dict(w=w, packed=p['wp_dg'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
+                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code, masked=True,
+                                 tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]))
+        return jobs
+
+    def unpack_jobs(self, Hi, Wi, grad_w):
+        p = self.plan(Hi, Wi)
+        return [dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in, s_c=self.s_out,
+                     Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32, masked=True,
+                     nslab=p['nslab'][li] if self.partial_slabs else 1,
+                     tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]) for li, l in enumerate(p['dg'])]
+
+
+class UpCatConvOp(object):
+    """conv3x3(cat([Upsample x2(u), skip])) -- the first convolution of every ZF_UNET decoder block
+    (lib/models/zf_unet.py:78-90) -- with its BACKWARD split by input segment:
+        skip segment : the ordinary 3x3 data / weight gradient restricted to the skip channels (same kernels, a row
+                       range of the packed matrix, a channel slice of the views);
+        up segment   : UpConvOp -- the 4x4 / stride-2 gather from dy straight to the LOW-resolution gradient of u and the
+                       matching weight gradient: 16 instead of 36 multiply-adds per low-resolution pixel, and the
+                       upsampled gradient slice (4x the size it is consumed at) is neither written nor read.
+    The forward stays the one 9-tap launch over the concat buffer.  Presents ConvOp's interface to Stage; the plan binds
+    the low-resolution views with bind_up() before backward."""
+
+    def __init__(self, rt, weight, bias, in_segments, need_dgrad=True):
+        (up_real, up_pad), (sk_real, sk_pad) = in_segments
+        self.rt, self.weight, self.bias = rt, weight, bias
+        self.full = ConvOp(rt, weight, bias, in_segments, 1, 1, False, need_dgrad=False)
+        self.skip = ConvOp(rt, weight, None, [(sk_real, sk_pad)], 1, 1, False, need_dgrad=True, ci_offset=up_real)
+        self.skip.pack_fwd = False
+        self.up = UpConvOp(rt, weight, up_real, up_pad, need_dgrad=True, pack_fwd=False)
+        self.up_pad, self.sk_pad = up_pad, sk_pad
+        self.Co, self.Cop, self.Ci, self.Cip = self.full.Co, self.full.Cop, self.full.Ci, self.full.Cip
+        self.need_dgrad = need_dgrad
+        self.stride, self.pad, self.transposed = 1, 1, False
+        self._u = self._du = None
+
+    def bind_up(self, u, du):
+        """u: the low-resolution activated tensor the up segment was upsampled from; du: receives its gradient"""
+        self._u, self._du = u, du
+
+    # ---- forward: the whole 9-tap convolution over the concat buffer
+    def plan(self, Hi, Wi):
+        return self.full.plan(Hi, Wi)
+
+    def out_hw(self, Hi, Wi):
+        return self.full.out_hw(Hi, Wi)
+
+    def fprop(self, xv, yv, stats=None, epilogue=None):
+        return self.full.fprop(xv, yv, stats, epilogue)
+
+    def act_epilogue_ok(self, H, W):
+        return self.full.act_epilogue_ok(H, W)
+
+    def u8_direct_ok(self, *a):
+        return False
+
+    def dgrad_bnreduce_ok(self, dyv, dxv):
+        return False
+
+    # ---- backward, by segment
+    def dgrad(self, dyv, dxv, bn_reduce=None):
+        assert bn_reduce is None and self._du is not None
+        self.skip.dgrad(dyv, dxv.slice(self.up_pad, self.sk_pad))
+        self.up.dgrad(dyv, self._du)
+
+    def wgrad(self, xv, dyv, grad_w, unpack=True):
+        assert not unpack and self._u is not None, 'segmented weight gradients are unpacked by the batched table'
+        self.skip.wgrad(xv.slice(self.up_pad, self.sk_pad), dyv, grad_w, unpack=False)
+        self.up.wgrad(self._u, dyv, grad_w, unpack=False)
+
+    # ---- weight pack / gradient unpack jobs of all three ops (H, W: the convolution's own, high, resolution)
+    def pack_jobs(self, H, W):
+        return self.full.pack_jobs(H, W) + self.skip.pack_jobs(H, W) + self.up.pack_jobs(H // 2, W // 2)
+
+    def unpack_jobs(self, H, W, grad_w):
+        return self.skip.unpack_jobs(H, W, grad_w) + self.up.unpack_jobs(H // 2, W // 2, grad_w)
+
+
 PACK_JOB_DTYPE = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('cmap', '<u8'), ('s_m', '<i8'),
                            ('s_c', '<i8'), ('Mp', '<i4'), ('Cp', '<i4'), ('ntaps', '<i4'), ('dtype', '<i4'),
-                           ('block_start', '<i4'), ('nslab', '<i4'), ('tap_off', '<i4', (nv.MAX_TAPS,))])
+                           ('block_start', '<i4'), ('nslab', '<i4'), ('masked', '<i4'), ('pad_', '<i4'),
+                           ('tap_off', '<i4', (nv.MAX_TAPS,))])
 
 
 class PackTable(object):
@@ -496,6 +644,7 @@ class PackTable(object):
             for f in ('s_m', 's_c', 'Mp', 'Cp', 'ntaps', 'dtype'):
                 row[f] = j[f]
             row['nslab'] = j.get('nslab', 1)
+            row['masked'] = 1 if j.get('masked') else 0
             row['tap_off'][:len(j['tap_off'])] = j['tap_off']
             row['block_start'] = blocks
             blocks += nb
@@ -510,6 +659,7 @@ class PackTable(object):
         if self.table is not None:
             nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
         for j in self.singles:
+            assert not j.get('masked'), 'masked jobs exist in the batched form only'
             tap = nv.int_array(j['tap_off'])
             if self.single_entry == 'segnb_pack_weight':
                 nv.call('segnb_pack_weight', nv.ptr(j['w']), nv.ptr(j['packed']), j['dtype'], j['Mp'], j['Cp'],

@@ -219,3 +219,51 @@ def test_fused_bn_reduce_in_data_gradient_host_logic():
     assert calls[0] >= 2 and calls[1] == 0, calls
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_subpixel_backward_plan_vs_reference_golden(golden_dir, monkeypatch):
+    """The decoder blocks' backward by input segment (segnb.engine.UpCatConvOp): the upsampled segment's data and weight
+    gradients computed on the low-resolution tensor through the ConvTranspose2d(4, 2, 1) identity, with masked weight
+    pack / gradient unpack jobs on the reference's 3x3 parameter -- every gradient of the reference golden, fp32 on the
+    ABI emulator (geometry, masks, pack / unpack index math, plan wiring; the kernels: tests/test_hip_ops.py)."""
+    monkeypatch.setenv('SEGNB_SUBPIXEL', '1')
+    g = np.load(os.path.join(golden_dir, 'zf_unet_tiny.npz'))
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    m = _model(4, 0.0, 3.0)
+    m.train()
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    out = m(x)
+    assert m._engine.subpixel
+    loss = BCEWithLogitsLossAndSmoothJaccard()(out, y)
+    assert abs(loss.item() - float(g['loss_bce_jaccard'])) < 1e-5
+    (x.shape[0] * loss).backward()
+    for n, p in m.named_parameters():
+        ref = g['grad/' + n]
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(p.grad.numpy() - ref).max()
+        assert err <= 3e-4 * scale + 3e-6, (n, err, scale)
+    # a second step reuses the (consumed, re-zeroed) weight-gradient workspaces
+    m.zero_grad()
+    loss2 = BCEWithLogitsLossAndSmoothJaccard()(m(x), y)
+    (x.shape[0] * loss2).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_upconv_masks_are_the_transposed_convolution_identity():
+    """conv3x3(pad 1)(Upsample x2 (u)) == conv_transpose2d(u, Wt, stride 2, padding 1) with Wt built from the masks."""
+    import torch.nn.functional as F
+    from segnb.engine import UpConvOp
+    torch.manual_seed(0)
+    u = torch.randn(2, 5, 6, 7)
+    w = torch.randn(4, 5, 3, 3)
+    ref = F.conv2d(F.interpolate(u, scale_factor=2, mode='nearest'), w, padding=1)
+    wt = torch.zeros(5, 4, 4, 4)                       # ConvTranspose2d weight: [Cin][Cout][4][4]
+    for a in range(4):
+        for b in range(4):
+            mk = UpConvOp.mask(a, b)
+            for k in range(9):
+                if mk >> k & 1:
+                    wt[:, :, a, b] += w[:, :, k // 3, k % 3].t()
+    got = F.conv_transpose2d(u, wt, stride=2, padding=1)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    assert sum(bin(UpConvOp.mask(a, b)).count('1') for a in range(4) for b in range(4)) == 36
