@@ -325,6 +325,13 @@ typedef struct {
     float slope;
 } segnb_bn_reduce_epilogue;
 int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
+
+/* 1 if segnb_conv_fprop serves this 4x4 / stride-2 gather (ntaps 16, in_step 2: the data gradient of an
+ * Upsample(scale_factor=2) -> conv3x3 segment on the low-resolution grid, lib/models/zf_unet.py:42,78-90; also the data gradient
+ * of ConvTranspose2d(4, 2, 1), unet16.py:38 / linknet.py:16) on the plane-gather form of the direct-to-LDS pipeline; 0: it
+ * would run on the general gather kernel.  A plan uses it to decide between the segmented and the plain data gradient of a
+ * decoder block (segnb.engine.UpCatConvOp). */
+int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype);
 int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,
                               const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream);
 

@@ -149,6 +149,10 @@ class AbiEmulator(object):
 
     # ---- data gradient + the BatchNorm-backward reduction of its output's producer (segnb_conv_fprop_bnreduce) = the two
     # separate entry points, composed
+    def segnb_conv_fprop_upd_ok(self, g, dtype):
+        g = _geom(g)
+        return int(g.ntaps == 16 and g.in_step == 2)       # (the emulator serves every geometry: the segmented plan is exercised)
+
     def segnb_conv_fprop_bnreduce_ok(self, g, dtype):
         g = _geom(g)
         return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and

@@ -89,6 +89,7 @@ int segnb_knob_fprop_nostats();   // 1: launches without statistics run the stat
 int segnb_knob_rw_store_waves();  // 2 or 4 store waves in conv_fprop_rw_kernel
 int segnb_knob_bnreduce_fused();  // 1: segnb_conv_fprop_bnreduce_ok may say yes
 int segnb_knob_fprop_deepk();     // 1: conv_fprop_deepk_kernel serves the shapes it applies to
+int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients

@@ -32,6 +32,7 @@ struct FdArgs {
     int dhmin, dwmin;
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
+    int NCHP;             // plane gather (WsCfg::UPD): 64-channel chunks per source plane (NCH = 4 * NCHP)
     // fused BatchNorm-backward reduction in the epilogue of a DATA-GRADIENT launch (segnb_conv_fprop_bnreduce): the output
     // tile is the gradient g of the producing layer's activation; with that layer's pre-BatchNorm output y the store
     // threads accumulate sum dz and sum dz * yhat (dz = g * act'(z)) -- segnb_bn_act_bwd_reduce without its own pass

@@ -57,9 +57,20 @@ __device__ unsigned long long g_stamps[3 * 256 * 4];
 // the bottom padding of the image above it and the top padding of the one below -- and WT = W columns: tiles of R x W
 // virtual pixels instead of one 16 x 16 tile per image.  For 7 x 7 images: 8 row tiles of 252 pixels instead of 32 tiles
 // of 49 (81 % padding); the rows m >= R * WT of a tile are dummies.
-template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false, bool MF16_ = true>
+// NTAP_ = 4, UPD_: the data gradient of an Upsample(x2) -> conv3x3 segment on the LOW-resolution grid, i.e. the 4x4 /
+// stride-2 gather (ntaps 16, in_step 2) of segnb.engine.UpConvOp.  Per output pixel (Y, X) the sixteen taps split by the
+// parity plane (py, px) of the high-resolution gradient dz they read: plane pixel (Y - py + ta, X - px + tb), ta, tb in
+// {0, 1}.  A K chunk = (plane, 64 channels) with a 2 x 2 tap window whose halo origin is shifted by (-py, -px): the
+// matrix waves see ONE tap geometry (window offsets {0,1}^2) for every chunk, the halo waves keep one set of per-lane source
+// offsets per plane (dz pixel (2 Yp + py, 2 Xp + px): a strided LDS-DMA gather, whole 128-byte channel rows).
+template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false, bool MF16_ = true, int NTAP_ = 9, bool UPD_ = false>
 struct WsCfg {
     static constexpr int BN = BN_, R = R_, WT = WT_;
+    static constexpr int NTAP = NTAP_, KW = NTAP_ == 9 ? 3 : 2, KH = KW;
+    static constexpr bool UPD = UPD_;
+    static constexpr int NPL = UPD_ ? 4 : 1;             // source planes (sets of per-lane halo offsets)
+    static_assert(NTAP_ == 9 || NTAP_ == 4, "3 x 3 or 2 x 2 tap window");
+    static_assert(!UPD_ || (NTAP_ == 4 && !TALL_ && MF16_), "plane gather: 2 x 2 window, 16x16x32 form");
     static constexpr bool TALL = TALL_;
     static constexpr bool MF16 = MF16_;                  // v_mfma_f32_16x16x32_bf16 (else 32x32x16)
     static constexpr int TM16 = (TALL_ ? 256 : R_ * WT_) / CW_M_ / 16, TN16 = BN_ / (4 / CW_M_) / 16;
@@ -70,14 +81,14 @@ struct WsCfg {
     static constexpr int WAVES_M = CW_M_, WAVES_N = NCW / CW_M_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
-    static constexpr int XR = R + 2, XC = WT + 2, NPIX = XR * XC;
+    static constexpr int XR = R + KH - 1, XC = WT + 2, NPIX = XR * XC;       // (even halo pitch kept for the 2 x 2 window)
     static constexpr int APIECES = (NPIX + 7) / 8;
     static constexpr int A_BYTES = APIECES * 1024;
     // fetch waves: NBW stream the weight ring, NAW the halo tiles -- separate vmcnt queues (a counted wait is in issue
     // order: behind a halo piece coming from HBM the weight ring's wait stalled every tap)
     static constexpr int NBW = 2, NAW = 2;
     static constexpr int APW = (APIECES + NAW - 1) / NAW;
-    static constexpr int A_STEPS = 7;                    // halo pieces go out during taps 0..6, all waited for in tap 7
+    static constexpr int A_STEPS = NTAP - 2;             // halo pieces go out during taps 0..NTAP-3, all waited for in tap NTAP-2
     static constexpr int APS = (APW + A_STEPS - 1) / A_STEPS;
     static constexpr int BPIECES = BN / 8;
     static constexpr int B_STAGE = BN * 128;
@@ -112,6 +123,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
     constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
     constexpr int OUT_ROW = C::OUT_ROW, NF = TM + TN;
+    constexpr int NTAP = C::NTAP, KW = C::KW;
+    constexpr int SM = NTAP & 3;                         // weight-ring stage of step (chunk cg, tap t) = (cg * SM + t) & 3
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     int* sPix = reinterpret_cast<int*>(smem + C::OFF_PIX);
@@ -178,7 +191,16 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 b_voff[pb] = co < a.Co ? (unsigned)co * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
             }
             auto fetch_b = [&](int c, int t, int stage) {
-                const unsigned soff = (unsigned)(t * a.Ci + c * 64) * 2u;
+                unsigned soff;
+                if constexpr (C::UPD) {
+                    // chunk c = (plane, 64-channel slice); tap (ta, tb) of plane (py, px) is tap (2 ta - py + 1, 2 tb - px + 1)
+                    // of the 4 x 4 kernel (row-major tap list of segnb.convplan.convt_dgrad)
+                    const int pl = c / a.NCHP, sl = c - pl * a.NCHP;
+                    const int t16 = (2 * (t >> 1) - (pl >> 1) + 1) * 4 + (2 * (t & 1) - (pl & 1) + 1);
+                    soff = (unsigned)(t16 * a.Ci + sl * 64) * 2u;
+                } else {
+                    soff = (unsigned)(t * a.Ci + c * 64) * 2u;
+                }
         #pragma unroll
                 for (int pb = 0; pb < BPW; ++pb)
                     dma16(lds0 + C::OFF_B + stage * C::B_STAGE + ((lw & 1) * BPW + pb) * 1024, b_voff[pb], rs_w, soff);
@@ -192,12 +214,12 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             for (; it < a.IT; it += a.GM) {
                 for (int c = 0; c < a.NCH; ++c, ++cg) {
                     const int cn = c + 1 == a.NCH ? 0 : c + 1;
-                    static_for<9>([&](auto t_c) {
+                    static_for<NTAP>([&](auto t_c) {
                         constexpr int t = decltype(t_c)::value;
-                        constexpr int tf = t + 3 < 9 ? t + 3 : t + 3 - 9;
-                        const int cf = t + 3 < 9 ? c : cn;
+                        constexpr int tf = t + 3 < NTAP ? t + 3 : t + 3 - NTAP;
+                        const int cf = t + 3 < NTAP ? c : cn;
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 0);
-                        if (!(SEGNB_EXP & 1) && !(DBG && (a.dbg & 1))) fetch_b(cf, tf, (cg + t + 3) & (NB - 1));
+                        if (!(SEGNB_EXP & 1) && !(DBG && (a.dbg & 1))) fetch_b(cf, tf, (cg * SM + t + 3) & (NB - 1));
                         if (lw == 0) FD_STAMP(1, cg * 9 + t, 1);
                         // the weights of tap t+2 (fetched during tap t-1) have landed: only this tap's fetch stays in flight
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
@@ -212,14 +234,15 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             // computed ONCE; per tile only the origin (scalar) and the border compares remain (recomputing pix / XC etc. per
             // tile stalled every wave of the block ~1800 cycles at the tile's last chunk: in-kernel stamps, tools/stamps.py).
             // The same call writes the tile's output pixel table (read by the store rows one tile later).
-            unsigned a_rel[APW], a_xy[APW], a_voff[APW];
+            unsigned a_rel[APW], a_xy[APW], a_voff[C::NPL][APW];
         #pragma unroll
             for (int pa = 0; pa < APW; ++pa) {
                 const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
                 const int q = lane & 7;
                 const int xr = pix / XC, xc = pix - xr * XC;
                 const int key = C::XC % 2 == 0 ? xc : pix;        // swizzle key (see a_rd below)
-                a_rel[pa] = (unsigned)(xr * a.Wi + xc) * (unsigned)a.ld_x * 2u + (unsigned)((q ^ ((key >> 1) & 7)) * 16);
+                a_rel[pa] = (unsigned)((xr * a.Wi + xc) * (C::UPD ? 2 : 1)) * (unsigned)a.ld_x * 2u +
+                            (unsigned)((q ^ ((key >> 1) & 7)) * 16);
                 a_xy[pa] = pix < C::NPIX ? (unsigned)xr | ((unsigned)xc << 16) : 0x7fff7fffu;      // never inside the image
             }
             auto set_fetch_tile = [&](int it, int table) {
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         const int hh = v - n * HV;
                         const bool ok = live && (unsigned)v < (unsigned)VT && hh < a.H && (unsigned)wi < (unsigned)a.Wi;
                         const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
-                        a_voff[pa] = ok ? (unsigned)((n * a.Hi + hh) * a.Wi + wi) * (unsigned)a.ld_x * 2u +
+                        a_voff[0][pa] = ok ? (unsigned)((n * a.Hi + hh) * a.Wi + wi) * (unsigned)a.ld_x * 2u +
                                               (unsigned)(((lane & 7) ^ ((pix >> 1) & 7)) * 16)      // (XC odd: key = pix)
                                         : OOB;
                     }
@@ -255,6 +278,23 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 const int n = it / (a.HB * a.WB);
                 const int rem = it - n * (a.HB * a.WB);
                 const int hb = rem / a.WB, wb = rem - hb * a.WB;
+                if constexpr (C::UPD) {
+                    // plane (py, px): halo position (xr, xc) = plane pixel (hb R - py + xr, wb WT - px + xc), valid inside
+                    // the H x W plane; its source is dz pixel (2 Yp + py, 2 Xp + px).  (32-bit wrap-around arithmetic: the
+                    // tile origin may lie one plane pixel outside the tensor, a VALID lane's offset never does)
+                    const unsigned hlim = live ? (unsigned)a.H : 0u;
+                    static_for<4>([&](auto pl_c) {
+                        constexpr int pl = decltype(pl_c)::value, py = pl >> 1, px = pl & 1;
+                        const int y0 = hb * R - py, x0 = wb * WT - px;
+                        const unsigned base = (unsigned)(((n * a.Hi + 2 * y0 + py) * a.Wi + 2 * x0 + px) * a.ld_x * 2);
+        #pragma unroll
+                        for (int pa = 0; pa < APW; ++pa) {
+                            const int yp = y0 + (int)(a_xy[pa] & 0xffffu), xp = x0 + (int)(a_xy[pa] >> 16);
+                            const bool ok = (unsigned)yp < hlim && (unsigned)xp < (unsigned)a.W;
+                            a_voff[pl][pa] = ok ? base + a_rel[pa] : OOB;
+                        }
+                    });
+                } else {
                 const int h0 = hb * R + a.dhmin, w0 = wb * WT + a.dwmin;
                 const unsigned base = (unsigned)(((n * a.Hi + h0) * a.Wi + w0) * a.ld_x * 2);
                 const unsigned hlim = live ? (unsigned)a.Hi : 0u;
@@ -262,7 +302,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 for (int pa = 0; pa < APW; ++pa) {
                     const int hi = h0 + (int)(a_xy[pa] & 0xffffu), wi = w0 + (int)(a_xy[pa] >> 16);
                     const bool ok = (unsigned)hi < hlim && (unsigned)wi < (unsigned)a.Wi;
-                    a_voff[pa] = ok ? base + a_rel[pa] : OOB;
+                    a_voff[0][pa] = ok ? base + a_rel[pa] : OOB;
+                }
                 }
                 // output pixel of tile rows (-1 = outside the image): 128 halo-wave threads, BM / 128 rows each
                 const int t128 = (lw & 1) * 64 + lane;
@@ -273,13 +314,30 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 }
             };
             auto fetch_a = [&](int p0, int p1, int c, int buf) {
+                int pl = 0;
+                unsigned soff = (unsigned)c * 128u;
+                if constexpr (C::UPD) {
+                    pl = c / a.NCHP;
+                    soff = (unsigned)(c - pl * a.NCHP) * 128u;
+                }
+                auto go = [&](auto pl_c) {
+                    constexpr int PL = decltype(pl_c)::value;
         #pragma unroll
-                for (int pa = 0; pa < APW; ++pa) {
-                    if (pa >= p0 && pa < p1) {
-                        const int piece = (lw & 1) + C::NAW * pa;
-                        const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
-                        dma16(dst, a_voff[pa], rs_x, (unsigned)c * 128u);
+                    for (int pa = 0; pa < APW; ++pa) {
+                        if (pa >= p0 && pa < p1) {
+                            const int piece = (lw & 1) + C::NAW * pa;
+                            const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
+                            dma16(dst, a_voff[PL][pa], rs_x, soff);
+                        }
                     }
+                };
+                if constexpr (C::UPD) {
+                    if (pl == 0) go(std::integral_constant<int, 0>{});
+                    else if (pl == 1) go(std::integral_constant<int, 1>{});
+                    else if (pl == 2) go(std::integral_constant<int, 2>{});
+                    else go(std::integral_constant<int, 3>{});
+                } else {
+                    go(std::integral_constant<int, 0>{});
                 }
             };
             set_fetch_tile(it, 0);
@@ -300,16 +358,16 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     const int setup_it = last ? it + 2 * a.GM : it + a.GM;
                     const int setup_tab = (tile_no + (last ? 2 : 1)) & 3;
                     const int abuf = cg & 1;
-                    static_for<9>([&](auto t_c) {
+                    static_for<NTAP>([&](auto t_c) {
                         constexpr int t = decltype(t_c)::value;
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
                         if constexpr (t < C::A_STEPS)
                             if (!(SEGNB_EXP & 2) && !(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
-                        if constexpr (t == 7)
+                        if constexpr (t == NTAP - 2)
                             if (next_last) set_fetch_tile(setup_it, setup_tab);
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
-                        // the next chunk's halo tile is first read during tap 8 (look-ahead slices of its tap 0)
-                        if constexpr (t == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // the next chunk's halo tile is first read during the last tap (look-ahead slices of its tap 0)
+                        if constexpr (t == NTAP - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 2);
                         if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 3);
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         // 16-cycle MFMA).  Requires XC even and taps ordered t = 3 * (row) + (column) (checked on the host).
         static_assert(!MF16 || XC % 2 == 0, "16x16x32 form: the swizzle key must be the halo column");
         int b_rd16[MF16 ? 2 : 1][MF16 ? TN16 : 1];
-        int a_rd16[MF16 ? 3 : 1][MF16 ? TM16 : 1][MF16 ? 2 : 1];
+        int a_rd16[MF16 ? KW : 1][MF16 ? TM16 : 1][MF16 ? 2 : 1];
         if constexpr (MF16) {
             const int r16 = lane & 15, g4 = lane >> 4;
     #pragma unroll
@@ -359,7 +417,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 b_rd16[1][j] = v ^ 64;
             }
     #pragma unroll
-            for (int dwi = 0; dwi < 3; ++dwi)
+            for (int dwi = 0; dwi < KW; ++dwi)
     #pragma unroll
                 for (int i = 0; i < TM16; ++i) {
                     const int m = wm * C::WM + 16 * i + r16;
@@ -445,13 +503,13 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             // q-th read of a fragment set, in consumption order; t = tap of the slice being fetched, k = its K slice,
             // wbase / xbase = wave-uniform LDS bases of its weight stage / halo buffer (+ the tap's row term)
             auto issue = [&](int q, int set, int wbase, int xbase, int t, int k) {
-                if (q == 0) { const int ad = a_rd16[t % 3][0][k] + xbase; FD_READ(fx[set][0], ad); }
+                if (q == 0) { const int ad = a_rd16[t % KW][0][k] + xbase; FD_READ(fx[set][0], ad); }
                 else if (q <= 4) { const int ad = b_rd16[k][q - 1] + wbase; FD_READ(fw[set][q - 1], ad); }
-                else { const int ad = a_rd16[t % 3][q - 4][k] + xbase; FD_READ(fx[set][q - 4], ad); }
+                else { const int ad = a_rd16[t % KW][q - 4][k] + xbase; FD_READ(fx[set][q - 4], ad); }
             };
-            int arow[3];                                           // row term of tap rows 0..2 (bytes)
+            int arow[KW];                                          // row term of the tap rows (bytes)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) arow[k] = __builtin_amdgcn_readfirstlane(a.dh[3 * k] * XC * 128);
+            for (int k = 0; k < KW; ++k) arow[k] = __builtin_amdgcn_readfirstlane(a.dh[KW * k] * XC * 128);
             if (!(DBG && (a.dbg & 4))) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) issue(q, 0, 0, arow[0], 0, 0);
@@ -463,27 +521,36 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 for (int c = 0; c < a.NCH; ++c, ++cg) {
                     const int a_base = (cg & 1) * C::A_BYTES;
                     const bool drain = pending && c == 0;
-                    static_for<9>([&](auto t_c) {
+                    static_for<NTAP>([&](auto t_c) {
                         constexpr int t = decltype(t_c)::value;
-                        constexpr int tn = t == 8 ? 0 : t + 1;
+                        constexpr int tn = t == NTAP - 1 ? 0 : t + 1;
                         auto& accr = acc;
-                        const int bstage = ((cg + t) & (NB - 1)) * C::B_STAGE;
-                        const int bnext = ((cg + t + 1) & (NB - 1)) * C::B_STAGE;
-                        const int anext = t == 8 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
+                        const int bstage = ((cg * SM + t) & (NB - 1)) * C::B_STAGE;
+                        const int bnext = ((cg * SM + t + 1) & (NB - 1)) * C::B_STAGE;
+                        const int anext = t == NTAP - 1 ? ((cg + 1) & 1) * C::A_BYTES : a_base;
                         if (wave == 0) FD_STAMP(0, cg * 9 + t, 0);
-                        constexpr bool row_tap = t >= 1 && t <= C::RPT;
-                        if constexpr (row_tap)
-                            if (drain) row_load(t - 1, sPix + ((tile_no + 3) & 3) * BM);
+                        // the previous tile's store rows: one per tap from the tile's second step on -- taps 1..RPT of the first
+                        // chunk (3 x 3 window, compile-time) or steps 1..RPT across the first chunks (2 x 2 window: 4 taps each)
+                        constexpr bool row_tap9 = NTAP == 9 && t >= 1 && t <= C::RPT;
+                        bool do_row = false;
+                        int krow = t - 1;
+                        if constexpr (NTAP == 9) {
+                            do_row = drain;
+                        } else {
+                            const int si = c * NTAP + t;
+                            krow = si - 1;
+                            do_row = pending && si >= 1 && si <= C::RPT;
+                        }
+                        if constexpr (row_tap9 || NTAP != 9)
+                            if (do_row) row_load(krow, sPix + ((tile_no + 3) & 3) * BM);
                         if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
                             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                             for (int kk = 0; kk < 2; ++kk) {
                                 const int cur = kk, nxt = kk ^ 1;
                                 // the slice fetched during this one: (t, 1) in this tap's stage, or (t + 1, 0) in the next tap's
-                                constexpr int ft = 0;
-                                (void)ft;
                                 const int wbase = kk == 0 ? bstage : bnext;
-                                const int xbase = kk == 0 ? a_base + arow[t / 3] : anext + arow[tn / 3];
+                                const int xbase = kk == 0 ? a_base + arow[t / KW] : anext + arow[tn / KW];
                                 // the current slice's x0, w0..w3 have landed (its x1..x3 may still be in flight; the
                                 // two row-store reads of a row tap are younger: the count is then conservative)
                                 ws_wait5<3>(fx[cur][0], fw[cur][0], fw[cur][1], fw[cur][2], fw[cur][3]);
@@ -510,8 +577,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                             __builtin_amdgcn_s_setprio(0);
                         }
                         if (wave == 0) FD_STAMP(0, cg * 9 + t, 1);
-                        if constexpr (row_tap)
-                            if (drain) {
+                        if constexpr (row_tap9 || NTAP != 9)
+                            if (do_row) {
                                 if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                                 asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(row_pix), "+v"(row_v));     // older than the 8 look-ahead reads
                                 row_store();
@@ -553,6 +620,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             tile_no_out = tile_no;
             pending_out = pending;
         } else {
+            static_assert(MF16 || NTAP == 9, "the 32x32x16 form serves the 3 x 3 window only (fragment sets cycle with 36 slices)");
 
             bf16x8_t fr[3][NF];
             if (!(DBG && (a.dbg & 4))) {
@@ -747,6 +815,61 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
 
 constexpr int NOT_HANDLED = -12345;
 
+// the plane gather (data gradient of an upsampled segment): one instantiation (no statistics, no epilogue)
+template <class C>
+int launch_ws_upd(FdArgs& a, hipStream_t stream) {
+    static int attr_rc = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }();
+    if (attr_rc) return attr_rc;
+    a.HB = (a.H + C::R - 1) / C::R;
+    a.WB = (a.W + C::WT - 1) / C::WT;
+    a.IT = a.N * a.HB * a.WB;
+    a.NTL = (a.Co + C::BN - 1) / C::BN;
+    a.NCHP = a.Ci / 64;
+    a.NCH = 4 * a.NCHP;
+    if (a.NCH * C::NTAP - 1 < C::RPT) return NOT_HANDLED;       // the previous tile's store rows ride on steps 1..RPT
+    int gm = segnb_knob_conv_cus() / a.NTL;
+    if (gm < 1) gm = 1;
+    if (gm > a.IT) gm = a.IT;
+    a.GM = gm;
+    hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    return 0;
+}
+
+// ntaps 16, in_step 2: out[Y, X] = sum_{a, b < 4} in[2 Y + a - 1, 2 X + b - 1] . W[a * 4 + b]  (segnb.convplan.convt_dgrad of a
+// 4 x 4 / stride-2 / pad-1 transposed convolution -- UpConvOp, unet16.py:38, linknet.py:16)
+bool upd_geometry(const segnb_conv_geom* g) {
+    if (g->ntaps != 16 || g->in_step != 2 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo) return false;
+    if (g->Ci % 64 != 0 || g->Co <= 32 || g->Wo < 12) return false;
+    for (int t = 0; t < 16; ++t)
+        if (g->dh[t] != t / 4 - 1 || g->dw[t] != t % 4 - 1) return false;
+    return true;
+}
+
+int try_upd(const segnb_conv_geom* g, FdArgs& a, hipStream_t stream) {
+    if (!upd_geometry(g)) return NOT_HANDLED;
+    a.Ktot = 16 * g->Ci;
+    a.dhmin = a.dwmin = 0;
+    for (int t = 0; t < 9; ++t) a.dh[t] = a.dw[t] = 0;
+    a.dh[2] = a.dh[3] = 1;          // 2 x 2 window, row-major: (0,0) (0,1) (1,0) (1,1)
+    a.dw[1] = a.dw[3] = 1;
+    // 8 x 32 or 16 x 16 output tiles: fewer rounds of (equal) tiles on the persistent blocks wins, ties go to 16 x 16
+    const int ntl = (g->Co + 63) / 64;
+    int gm = segnb_knob_conv_cus() / ntl;
+    if (gm < 1) gm = 1;
+    const long long it0 = (long long)g->N * ((g->Ho + 7) / 8) * ((g->Wo + 31) / 32);
+    const long long it1 = (long long)g->N * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
+    int cfg = segnb_knob_fprop_dma_cfg();
+    if (cfg < 0) cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
+    if (cfg == 0) return launch_ws_upd<WsCfg<64, 8, 32, 4, false, true, 4, true>>(a, stream);
+    return launch_ws_upd<WsCfg<64, 16, 16, 4, false, true, 4, true>>(a, stream);
+}
+
 int dispatch_fd(FdArgs& a, hipStream_t stream) {
     // A/B testing (segnb_tune / environment): "fprop_dma" = 0 disables this path, "fprop_dma_cfg" forces a configuration
     int cfg = segnb_knob_fprop_dma_cfg();
@@ -793,6 +916,13 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16) return 0;
+    if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_upd() || getenv("SEGNB_FPROP_GENERAL") != nullptr) return 0;
+    const long long ob = (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2;
+    return upd_geometry(g) && ob < (1ll << 31) ? 1 : 0;
+}
+
 // timing builds: copy the stamps of the last stamped launch to the host (3 roles x 256 steps x 4 clocks)
 int segnb_fprop_dma_read_stamps(unsigned long long* host_dst) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 3 * 256 * 4);
@@ -803,6 +933,30 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                         hipStream_t stream, const segnb_act_epilogue* ep) {
     if (!segnb_knob_fprop_dma()) return 0;
+    if (g->ntaps == 16 && ep == nullptr && stats == nullptr && bias == nullptr && segnb_knob_fprop_upd()) {
+        FdArgs a;
+        a.x = (const bf16_t*)in;
+        a.w = (const bf16_t*)wpacked;
+        a.x_bytes = in_bytes;
+        a.w_bytes = w_bytes;
+        a.bias = nullptr;
+        a.bias_n = 0;
+        a.out = (bf16_t*)out;
+        a.stats = nullptr;
+        a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Hi = g->Hi; a.Wi = g->Wi;
+        a.Ci = g->Ci; a.Co = g->Co; a.ld_x = g->ld_in; a.ld_out = g->ld_out;
+        const long long ob = (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2;
+        if (ob >= (1ll << 31)) return 0;
+        a.out_bytes = (unsigned)ob;
+        a.dbg = 0;
+        a.bn_y = nullptr;
+        a.ep_act = -1;
+        a.ep_coef = nullptr;
+        a.ep_slope = 0.f;
+        const int rc = try_upd(g, a, stream);
+        if (rc == NOT_HANDLED) return 0;
+        return rc ? rc : 1;
+    }
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 64 != 0) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];

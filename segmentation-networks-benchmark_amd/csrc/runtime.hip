@@ -228,6 +228,14 @@ int segnb_knob_fprop_mf16() {
     }
     return g_fprop_mf16;
 }
+static int g_fprop_upd = -2;       // plane-gather form of conv_fprop_ws_kernel for 4x4 / stride-2 gathers (A/B: SEGNB_FPROP_UPD=0)
+int segnb_knob_fprop_upd() {
+    if (g_fprop_upd == -2) {
+        const char* e = getenv("SEGNB_FPROP_UPD");
+        g_fprop_upd = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_upd;
+}
 static int g_fprop_nostats = -2;    // conv_fprop_ws_kernel: statistics-free instantiation for launches without statistics (A/B)
 int segnb_knob_fprop_nostats() {
     if (g_fprop_nostats == -2) {

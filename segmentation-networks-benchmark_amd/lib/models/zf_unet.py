@@ -159,6 +159,7 @@ class _ZFUnetPlan(object):
             blk = getattr(module, name)
             seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
             self._add(name, blk, seg1, True, upcat=self.subpixel)
+        self.keep_u = self.subpixel and UpCatConvOp.segment_wgrad
         self._bufs = {}
         self._pack_tables = {}
         self._packed_key = None
@@ -203,8 +204,10 @@ class _ZFUnetPlan(object):
                 if self.subpixel:
                     # the tensor cat_i's first segment is upsampled from, at its own (half) resolution, and its gradient
                     h2, w2 = hs[i + 1]
-                    b['u_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
-                    b['du_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
+                    if self.keep_u:
+                        b['u_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
+                    if self._seg(i, N, H, W):
+                        b['du_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
         b['f0'] = View.alloc(rt, N, H, W, wp[0])
         b['df0'] = View.alloc(rt, N, H, W, wp[0])
         b['logits'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
@@ -235,16 +238,23 @@ class _ZFUnetPlan(object):
     BWD_CONV_CU_PCT = int(os.environ.get('SEGNB_BWD_CONV_CU_PCT', '100'))
     UNPACK_GROUPS = ((2 * len(ENCODER), None), (8, 2 * len(ENCODER)), (0, 8))       # conv index ranges
 
-    def _tables(self, H, W):
+    def _seg(self, lvl, N, H, W):
+        """Does decoder level lvl run its first convolution's data gradient by segment at this input size?"""
+        conv = self.stages[DECODER[4 - lvl]][0].conv
+        return self.subpixel and conv.segmented(N, H >> lvl, W >> lvl)
+
+    def _tables(self, H, W, N=None):
         """One-launch weight pack table and per-group gradient unpack tables for this input size (rebuilt if the
         flat parameter buffers were re-created).  -> (key, pack, (unpack_dec, unpack_deep, unpack_rest), (lo, lo))"""
-        key = (H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr())
+        N = self._last_N if N is None else N
+        self._last_N = N
+        key = (N, H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr())
         t = self._pack_tables.get((H, W))
         if t is None or t[0] != key:
             convs = self._conv_sizes(H, W)
             pj = []
             for conv, h, w in convs:
-                pj += conv.pack_jobs(h, w)
+                pj += conv.pack_jobs(h, w, N) if isinstance(conv, UpCatConvOp) else conv.pack_jobs(h, w)
             unpacks, los = [], []
             for a, b in self.UNPACK_GROUPS:
                 uj = []
@@ -273,12 +283,14 @@ class _ZFUnetPlan(object):
             self._plan_cut(('ready', gi, side is not None))      # a recorded launch list is cut where the hook runs
             hook(self.flat, los[gi], (side,) if side is not None else ())
 
-    def _pack_if_needed(self, H, W):
-        key = (sum(p._version for p in self.flat.param_list()), self.flat.version, H, W,
+    _last_N = None
+
+    def _pack_if_needed(self, H, W, N):
+        key = (sum(p._version for p in self.flat.param_list()), self.flat.version, N, H, W,
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return
-        self._tables(H, W)[1].run()
+        self._tables(H, W, N)[1].run()
         self._packed_key = key
 
     def _dropout_tables(self, b, N, train):
@@ -407,7 +419,7 @@ class _ZFUnetPlan(object):
         else:
             N, C, H, W = x.shape
         b = self.buffers(N, H, W)
-        self._pack_if_needed(H, W)
+        self._pack_if_needed(H, W, N)
         drop = self._dropout_tables(b, N, train)
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)
         if ckey is not None:
@@ -450,13 +462,13 @@ class _ZFUnetPlan(object):
                     cur = b['p_%d' % (i + 1)]
                 else:
                     s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad,
-                               out=b['u_4'] if (self.subpixel and need_grad) else None)
+                               out=b['u_4'] if (self.keep_u and need_grad) else None)
             for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
                 s1, s2 = self.stages[name]
                 s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
                 if lvl > 0:
                     s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad,
-                               out=b['u_%d' % (lvl - 1)] if (self.subpixel and need_grad) else None)
+                               out=b['u_%d' % (lvl - 1)] if (self.keep_u and need_grad) else None)
                 else:
                     s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
             head = self.module.conv_final
@@ -526,7 +538,7 @@ class _ZFUnetPlan(object):
                 # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
                 if lvl == 0:
                     red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
-                elif self.subpixel:
+                elif self._seg(lvl - 1, N, H, W):
                     # the level above handed the gradient of this block's output over at THIS resolution (du)
                     red = s2.backward(flat, g_direct=b['du_%d' % (lvl - 1)], dx=b['db1_%d' % lvl], postponed=hold,
                                       fuse_reduce_of=s1)
@@ -534,7 +546,7 @@ class _ZFUnetPlan(object):
                     red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
                                       postponed=hold, fuse_reduce_of=s1)
                 if self.subpixel:
-                    s1.conv.bind_up(b['u_%d' % lvl], b['du_%d' % lvl])
+                    s1.conv.bind_up(b.get('u_%d' % lvl), b.get('du_%d' % lvl))
                 s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
             rt.flush_postponed(post)
             self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
@@ -542,7 +554,7 @@ class _ZFUnetPlan(object):
                 if i == 3:
                     self._unpack_group(H, W, 1)   # conv_7 / conv_14: the bulk of the encoder's parameters
                 s1, s2 = self.stages[ENCODER[i]]
-                if i == 5 and self.subpixel:
+                if i == 5 and self._seg(4, N, H, W):
                     red = s2.backward(flat, g_direct=b['du_4'], dx=b['da1_5'], fuse_reduce_of=s1)
                 elif i == 5:
                     red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)

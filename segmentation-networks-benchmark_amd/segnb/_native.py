@@ -117,7 +117,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

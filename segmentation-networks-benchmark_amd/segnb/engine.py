@@ -562,22 +562,48 @@ class UpCatConvOp(object):
     The forward stays the one 9-tap launch over the concat buffer.  Presents ConvOp's interface to Stage; the plan binds
     the low-resolution views with bind_up() before backward."""
 
+    # SEGNB_SUBPIXEL_WGRAD=1: the weight gradient by segment too (default: the one 9-tap launch over the concat buffer --
+    # measured alone at the five decoder shapes of the timed configuration, tools/upcat_bench.py: the weight-gradient kernel's
+    # fixed cost per launch (partial slabs + their reduction) eats the 4/9 of the upsampled segment's multiply-adds)
+    segment_wgrad = os.environ.get('SEGNB_SUBPIXEL_WGRAD', '0') != '0'
+
     def __init__(self, rt, weight, bias, in_segments, need_dgrad=True):
         (up_real, up_pad), (sk_real, sk_pad) = in_segments
         self.rt, self.weight, self.bias = rt, weight, bias
-        self.full = ConvOp(rt, weight, bias, in_segments, 1, 1, False, need_dgrad=False)
+        # (full: also the PLAIN data gradient, for the input sizes whose low-resolution gather has no fast kernel)
+        self.full = ConvOp(rt, weight, bias, in_segments, 1, 1, False, need_dgrad=need_dgrad)
         self.skip = ConvOp(rt, weight, None, [(sk_real, sk_pad)], 1, 1, False, need_dgrad=True, ci_offset=up_real)
         self.skip.pack_fwd = False
         self.up = UpConvOp(rt, weight, up_real, up_pad, need_dgrad=True, pack_fwd=False)
+        self.needs_u = self.segment_wgrad        # the plan keeps the low-resolution tensor only for the segmented weight gradient
         self.up_pad, self.sk_pad = up_pad, sk_pad
         self.Co, self.Cop, self.Ci, self.Cip = self.full.Co, self.full.Cop, self.full.Ci, self.full.Cip
         self.need_dgrad = need_dgrad
         self.stride, self.pad, self.transposed = 1, 1, False
         self._u = self._du = None
+        self._seg = {}
 
     def bind_up(self, u, du):
         """u: the low-resolution activated tensor the up segment was upsampled from; du: receives its gradient"""
         self._u, self._du = u, du
+
+    def segmented(self, N, H, W):
+        """Is the data gradient of this convolution at input size H x W computed by segment?  Only where the
+        low-resolution gather runs on a fast kernel (segnb_conv_fprop_upd_ok): on the general gather kernel it costs more
+        than the 5/9 of the multiply-adds it saves (measured in situ: 198 / 103 us against 118 / 124 us plain at the
+        224x224 / 14x14 decoder levels of the timed configuration)."""
+        if not self.need_dgrad:
+            return False
+        key = (N, H, W)
+        v = self._seg.get(key)
+        if v is None:
+            p = self.up.plan(H // 2, W // 2)
+            g = self.up._geom(p, 'd', 0, p['dg'][0], N, H, W, self.up.Cop, self.up.Cop, H // 2, W // 2, self.up.Cip, self.up.Cip)
+            v = self._seg[key] = self.force_segmented or bool(nv.query('segnb_conv_fprop_upd_ok', g, self.rt.code))
+        return v
+
+    _seg = None
+    force_segmented = os.environ.get('SEGNB_SUBPIXEL', 'auto') == 'force'
 
     # ---- forward: the whole 9-tap convolution over the concat buffer
     def plan(self, Hi, Wi):
@@ -600,20 +626,33 @@ class UpCatConvOp(object):
 
     # ---- backward, by segment
     def dgrad(self, dyv, dxv, bn_reduce=None):
-        assert bn_reduce is None and self._du is not None
+        assert bn_reduce is None
+        if not self.segmented(dxv.N, dxv.H, dxv.W):
+            return self.full.dgrad(dyv, dxv)
+        assert self._du is not None
         self.skip.dgrad(dyv, dxv.slice(self.up_pad, self.sk_pad))
         self.up.dgrad(dyv, self._du)
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
+        if not self.segment_wgrad:
+            return self.full.wgrad(xv, dyv, grad_w, unpack)
         assert not unpack and self._u is not None, 'segmented weight gradients are unpacked by the batched table'
         self.skip.wgrad(xv.slice(self.up_pad, self.sk_pad), dyv, grad_w, unpack=False)
         self.up.wgrad(self._u, dyv, grad_w, unpack=False)
+        self._u = None
 
     # ---- weight pack / gradient unpack jobs of all three ops (H, W: the convolution's own, high, resolution)
-    def pack_jobs(self, H, W):
-        return self.full.pack_jobs(H, W) + self.skip.pack_jobs(H, W) + self.up.pack_jobs(H // 2, W // 2)
+    def pack_jobs(self, H, W, N=None):
+        """N: the batch size the plan runs at (the fast-kernel query is per geometry); None = segmented wherever possible"""
+        seg = self.segmented(N, H, W) if N is not None else True
+        if not seg:
+            return self.full.pack_jobs(H, W)
+        fwd_only = [j for j in self.full.pack_jobs(H, W) if j['mmap'] is self.full.out_map]
+        return fwd_only + self.skip.pack_jobs(H, W) + self.up.pack_jobs(H // 2, W // 2)
 
     def unpack_jobs(self, H, W, grad_w):
+        if not self.segment_wgrad:
+            return self.full.unpack_jobs(H, W, grad_w)
         return self.skip.unpack_jobs(H, W, grad_w) + self.up.unpack_jobs(H // 2, W // 2, grad_w)
 
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from oracle import abi_emulator
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.engine import ConvOp, Runtime, View
+from segnb.engine import ConvOp, PackTable, Runtime, UpCatConvOp, View
 
 pytestmark = pytest.mark.gpu
 
@@ -978,6 +978,71 @@ def test_conv_full_size_vs_torch(shape, wg_cu_pct):
     assert torch.equal(gw, gw2), 'weight gradient differs between two launches (slab reduction order)'
     if not first:
         check(name + ' dx vs torch', dxv.dense().float().cpu()[..., :Ci].permute(0, 3, 1, 2), xr.grad, 'bf16')
+
+
+# (N, high-resolution size, channels of the upsampled tensor, skip channels, output channels): the five decoder levels of
+# the timed configuration, a ragged toy, and sizes that take the general kernels (odd, non-multiples of 64)
+UPCAT_SHAPES = [(32, 14, 1024, 512, 512), (32, 28, 512, 256, 256), (32, 56, 256, 128, 128), (32, 112, 128, 64, 64),
+                (32, 224, 64, 32, 32), (3, 12, 24, 12, 20), (2, 20, 64, 64, 64), (2, 36, 128, 64, 64)]
+
+
+@pytest.mark.parametrize('shape', UPCAT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_upcat_segmented_backward_vs_torch(shape):
+    """UpCatConvOp (the decoder blocks' first convolution, lib/models/zf_unet.py:78-90: cat([Upsample x2(u), skip]) ->
+    conv3x3): data gradient of the skip segment, LOW-resolution gradient of u and the weight gradient of both segments --
+    the upsampled one through the ConvTranspose2d(4, 2, 1) identity on the low-resolution tensor with masked pack /
+    unpack jobs -- against torch autograd of F.conv2d(cat(F.interpolate(nearest), skip)) on the CPU, at the five decoder
+    shapes of the timed configuration (bs=32) and at ragged sizes.  Weight gradients land in the reference's 3x3 layout."""
+    N, S, Cu, Cs, Co = shape
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(S * 131 + Cu + Co)
+    Ci = Cu + Cs
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) * (2.0 / (Ci * 9)) ** 0.5)
+    u = torch.randn(N, Cu, S // 2, S // 2, generator=gen).bfloat16().float()
+    sk = torch.randn(N, Cs, S, S, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, S, S, generator=gen).bfloat16().float()
+    Cup, Csp = cp.pad8(Cu), cp.pad8(Cs)
+    wd = w.cuda()
+    op = UpCatConvOp(rt, wd, None, [(Cu, Cup), (Cs, Csp)], need_dgrad=True)
+    op.segment_wgrad = True                            # (instance override: both segmented paths are exercised here)
+    PackTable(rt, op.pack_jobs(S, S), 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
+    cat = View.alloc(rt, N, S, S, Cup + Csp)
+    cat.dense()[..., :Cu] = F.interpolate(u, scale_factor=2, mode='nearest').permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+    cat.dense()[..., Cup:Cup + Cs] = sk.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+    uv = View.alloc(rt, N, S // 2, S // 2, Cup)
+    uv.dense()[..., :Cu] = u.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+    duv = View.alloc(rt, N, S // 2, S // 2, Cup)
+    duv.t.fill_(7.0)                                   # every element must be overwritten
+    dcat = View.alloc(rt, N, S, S, Cup + Csp)
+    dyv = View.alloc(rt, N, S, S, op.Cop)
+    dyv.dense()[..., :Co] = dy.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+    yv = View.alloc(rt, N, S, S, op.Cop)
+    op.fprop(cat, yv)
+    op.bind_up(uv, duv)
+    op.dgrad(dyv, dcat)
+    gw = torch.zeros_like(wd)
+    op.wgrad(cat, dyv, gw, unpack=False)
+    unp = PackTable(rt, op.unpack_jobs(S, S, gw), 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad')
+    unp.run()
+    gw1 = gw.clone()
+    gw.zero_()
+    op.wgrad(cat, dyv, gw, unpack=False)               # second round: consumed workspaces, same bits
+    unp.run()
+    torch.cuda.synchronize()
+    # reference on the CPU: fp32 math on the operands the kernels saw (weights rounded to bf16 tap by tap for the forward
+    # and the skip segment; the up segment's packed taps are rounded AFTER the fp32 sum -- within bf16 tolerance of it)
+    ur = u.clone().requires_grad_(True)
+    skr = sk.clone().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(torch.cat([F.interpolate(ur, scale_factor=2, mode='nearest'), skr], 1), wr, None, padding=1)
+    yr.backward(dy)
+    name = 'x'.join(map(str, shape))
+    check(name + ' y', yv.dense().float().cpu()[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    check(name + ' d skip', dcat.dense().float().cpu()[..., Cup:Cup + Cs].permute(0, 3, 1, 2), skr.grad, 'bf16')
+    check(name + ' d u (low resolution)', duv.dense().float().cpu()[..., :Cu].permute(0, 3, 1, 2), ur.grad, 'bf16')
+    assert Cup == Cu or float(duv.dense()[..., Cu:].abs().max()) == 0.0
+    check(name + ' dw', gw.cpu(), wr.grad, 'f32')
+    check(name + ' dw, second launch', gw1.cpu(), wr.grad, 'f32')
 
 
 @pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],

@@ -221,12 +221,15 @@ def test_fused_bn_reduce_in_data_gradient_host_logic():
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
-def test_subpixel_backward_plan_vs_reference_golden(golden_dir, monkeypatch):
+@pytest.mark.parametrize('segment_wgrad', [False, True])
+def test_subpixel_backward_plan_vs_reference_golden(golden_dir, monkeypatch, segment_wgrad):
     """The decoder blocks' backward by input segment (segnb.engine.UpCatConvOp): the upsampled segment's data and weight
     gradients computed on the low-resolution tensor through the ConvTranspose2d(4, 2, 1) identity, with masked weight
     pack / gradient unpack jobs on the reference's 3x3 parameter -- every gradient of the reference golden, fp32 on the
     ABI emulator (geometry, masks, pack / unpack index math, plan wiring; the kernels: tests/test_hip_ops.py)."""
+    from segnb.engine import UpCatConvOp
     monkeypatch.setenv('SEGNB_SUBPIXEL', '1')
+    monkeypatch.setattr(UpCatConvOp, 'segment_wgrad', segment_wgrad)
     g = np.load(os.path.join(golden_dir, 'zf_unet_tiny.npz'))
     x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
     m = _model(4, 0.0, 3.0)
