@@ -822,7 +822,7 @@ constexpr int PACK_LDS_FLOATS = 256 * 9 > 64 * 8 * 9 ? 256 * 9 : 64 * 8 * 9;   /
 // contiguous channel index; channel counts are padded to multiples of 8).
 template <bool IS_PACK>
 __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    __shared__ float tile[PACK_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float tile[PACK_LDS_FLOATS];
     __shared__ long long sFast[256], sSlow[64];         // element offset of each fast / slow channel of the tile, -1 = pad
     const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
     const TileGeom g = tile_geom(j);
@@ -848,6 +848,36 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         }
     }
     __syncthreads();
+    // Parameter side in 16-byte accesses when the tile's fast channels are a contiguous run of the tensor (consecutive real
+    // channels: everything but a tile that crosses a padding gap) and every row starts 16-byte aligned: dword accesses moved
+    // the 0.38 GB of a ZF_UNET pack at 2.5 TB/s
+    int nvalid = 0;
+    bool vec;
+    {
+        const int nfast = g.fast_is_c ? Cp : Mp;
+        const int lim = min(g.F, nfast - f0);
+        bool ok = true;
+        for (int i = threadIdx.x; i < g.F; i += 256) {
+            const long long v = sFast[i];
+            if (i < lim && v >= 0) ok = ok && v == sFast[0] + (long long)i * g.Tsrc;
+            if (v >= 0 && i > 0 && sFast[i - 1] < 0) ok = false;               // a gap inside the run
+        }
+        for (int i = threadIdx.x; i < g.S; i += 256) {
+            const long long v = sSlow[i];
+            if (v >= 0) ok = ok && ((v + (sFast[0] < 0 ? 0 : sFast[0])) & 3) == 0;
+        }
+        // count of valid fast channels (they form a prefix when ok)
+        int cnt = 0;
+        for (int i = threadIdx.x; i < g.F; i += 256) cnt += sFast[i] >= 0 ? 1 : 0;
+        __shared__ int sCnt;
+        if (threadIdx.x == 0) sCnt = 0;
+        __syncthreads();
+        if (cnt) atomicAdd(&sCnt, cnt);
+        vec = __syncthreads_and(ok ? 1 : 0) != 0;
+        nvalid = sCnt;
+        vec = vec && sFast[0] >= 0 && ((nvalid * g.Tsrc) & 3) == 0 && ((const uintptr_t)param & 15) == 0;
+    }
+    const int row4 = nvalid * g.Tsrc / 4;               // float4 per slow row on the vector path
     auto param_off = [&](int sl, int fa) -> long long {      // element offset of (slow, fast, tap 0) or -1
         const long long a = sSlow[sl], b = sFast[fa];
         return (a < 0 || b < 0) ? -1 : a + b;
@@ -875,6 +905,31 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         // parameter -> LDS, in parameter order (coalesced along the fast channel and the taps).  All of a lane's loads
         // are issued before the first LDS store (a rolled loop kept ONE 4-byte load per lane in flight: 2.5 TB/s)
         constexpr int MAXU = PACK_LDS_FLOATS / 256;
+        if (vec) {
+            constexpr int MAXU4 = (PACK_LDS_FLOATS / 4 + 255) / 256;
+            if (nvalid < g.F)                                    // padding channels of the tile read as zero
+                for (int i = threadIdx.x; i < n_param; i += 256) tile[i] = 0.f;
+            if (nvalid < g.F) __syncthreads();
+            float4 pv4[MAXU4];
+            const int n4 = g.S * row4;
+#pragma unroll
+            for (int u = 0; u < MAXU4; ++u) {
+                const int i = threadIdx.x + u * 256;
+                pv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < n4) {
+                    const int sl = i / row4, r = i - sl * row4;
+                    if (sSlow[sl] >= 0) pv4[u] = *reinterpret_cast<const float4*>(param + sSlow[sl] + sFast[0] + 4 * r);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MAXU4; ++u) {
+                const int i = threadIdx.x + u * 256;
+                if (i < n4) {
+                    const int sl = i / row4, r = i - sl * row4;
+                    *reinterpret_cast<float4*>(tile + sl * run + 4 * r) = pv4[u];
+                }
+            }
+        } else {
         float pv[MAXU];
 #pragma unroll
         for (int u = 0; u < MAXU; ++u) {
@@ -891,6 +946,7 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         for (int u = 0; u < MAXU; ++u) {
             const int i = threadIdx.x + u * 256;
             if (i < n_param) tile[i] = pv[u];
+        }
         }
         __syncthreads();
         // LDS -> packed, 8 consecutive cp per lane
@@ -995,6 +1051,33 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         }
         __syncthreads();
         constexpr int MAXU = PACK_LDS_FLOATS / 256;
+        if (vec) {
+            constexpr int MAXU4 = (PACK_LDS_FLOATS / 4 + 255) / 256;
+            float4 pv4[MAXU4];
+            const int n4 = g.S * row4;
+#pragma unroll
+            for (int u = 0; u < MAXU4; ++u) {
+                const int i = threadIdx.x + u * 256;
+                if (i < n4) {
+                    const int sl = i / row4, r = i - sl * row4;
+                    if (sSlow[sl] >= 0) pv4[u] = *reinterpret_cast<const float4*>(param + sSlow[sl] + sFast[0] + 4 * r);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MAXU4; ++u) {
+                const int i = threadIdx.x + u * 256;
+                if (i < n4) {
+                    const int sl = i / row4, r = i - sl * row4;
+                    if (sSlow[sl] >= 0) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(tile + sl * run + 4 * r);
+                        float4 o = pv4[u];
+                        o.x += t4.x; o.y += t4.y; o.z += t4.z; o.w += t4.w;
+                        *reinterpret_cast<float4*>(param + sSlow[sl] + sFast[0] + 4 * r) = o;
+                    }
+                }
+            }
+            return;
+        }
         float pv[MAXU];
         long long po[MAXU];
 #pragma unroll

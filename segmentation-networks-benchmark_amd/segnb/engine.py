@@ -639,7 +639,6 @@ class UpCatConvOp(object):
         assert not unpack and self._u is not None, 'segmented weight gradients are unpacked by the batched table'
         self.skip.wgrad(xv.slice(self.up_pad, self.sk_pad), dyv, grad_w, unpack=False)
         self.up.wgrad(self._u, dyv, grad_w, unpack=False)
-        self._u = None
 
     # ---- weight pack / gradient unpack jobs of all three ops (H, W: the convolution's own, high, resolution)
     def pack_jobs(self, H, W, N=None):

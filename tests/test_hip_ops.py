@@ -1004,7 +1004,8 @@ def test_upcat_segmented_backward_vs_torch(shape):
     Cup, Csp = cp.pad8(Cu), cp.pad8(Cs)
     wd = w.cuda()
     op = UpCatConvOp(rt, wd, None, [(Cu, Cup), (Cs, Csp)], need_dgrad=True)
-    op.segment_wgrad = True                            # (instance override: both segmented paths are exercised here)
+    op.segment_wgrad = True                            # (instance overrides: both segmented paths are exercised here,
+    op.force_segmented = True                          #  on the general kernels where no fast one serves the shape)
     PackTable(rt, op.pack_jobs(S, S), 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
     cat = View.alloc(rt, N, S, S, Cup + Csp)
     cat.dense()[..., :Cu] = F.interpolate(u, scale_factor=2, mode='nearest').permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
