@@ -108,6 +108,18 @@ int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const 
 int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout, float* dwp,
                              int nslab, segnb_stream_t stream);
 
+/* Weight gradient whose dout operand is not in memory: it is the BatchNorm-backward apply of the layer,
+ *     dout = round(a * (round(g * act'(z)) - c1 - yhat * c2)),   z = (y - mean) * scale + shift,  yhat = (y - mean) * invstd
+ * (lib/modules/abn/functions.py:118's dx, the arithmetic and roundings of segnb_bn_bwd_apply_direct), recomputed from the
+ * incoming gradient g and the pre-BatchNorm output y while the tile is staged.  For the FIRST convolution of a network
+ * (lib/models/zf_unet.py:44 conv_224.l1: no data gradient, so nothing else reads that tensor): the apply pass and its
+ * 103 MB tensor (bs=32, 224x224) leave the serial tail of backward.  coef: [4][Cp] of segnb_bn_finalize, bcoef: [3][Cp]
+ * of segnb_bn_bwd_finalize.  bf16, stride-1 3x3, <= 32 output channels (segnb_conv_wgrad_bnapply_ok). */
+int segnb_conv_wgrad_bnapply_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, const void* in, const void* gsrc, int ld_g,
+                             const void* y, int ld_y, const float* coef, const float* bcoef, int Cp, int act,
+                             float slope, float* dwp, int nslab, segnb_stream_t stream);
+
 /* Parameter-layout <-> packed-GEMM-layout.  Packed matrix is [Mp][ntaps][Cp]; element (mp,t,cp)
  * maps to w[mmap[mp]*s_m + cmap[cp]*s_c + tap_off[t]] (maps are device int32 arrays, -1 = padding).
  * tap_off is a HOST array of ntaps element offsets (kh*s_kh + kw*s_kw).
@@ -252,6 +264,11 @@ int segnb_bn_bwd_apply_fused_direct_acc(int dtype, const void* y, int ld_y, int 
 int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, const float* gamma,
                           const float* coef, float* bcoef, float* dgamma, float* dbeta,
                           int accumulate, segnb_stream_t stream);
+/* the same, clearing the layer's forward statistics buffer [SEGNB_STAT_REPLICAS][2][Cp] too (NULL: no) -- what the fused
+ * apply launches do on the way; for layers without an apply pass (segnb_conv_wgrad_bnapply) */
+int segnb_bn_bwd_finalize_clear(double* sums, int C, int Cp, double count, const float* gamma, const float* coef,
+                                float* bcoef, float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear,
+                                segnb_stream_t stream);
 
 /* dy = bcoef0 * (dz - bcoef1 - yhat*bcoef2) written to dy (may alias dz);
  * dbias[c] += sum dy (fp32 atomics; NULL to skip). */

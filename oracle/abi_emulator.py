@@ -195,6 +195,21 @@ class AbiEmulator(object):
             G[0, :, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
         return 0
 
+    def segnb_conv_wgrad_bnapply_ok(self, g, dtype):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.Co <= 32)
+
+    def segnb_conv_wgrad_bnapply(self, g, dtype, in_p, gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope, dwp, nslab, stream):
+        """segnb_bn_bwd_apply_direct into a temporary, then segnb_conv_wgrad on it"""
+        gg = _geom(g)
+        tmp = torch.zeros(gg.N * gg.Ho * gg.Wo * Cp, dtype=_tdt(dtype))
+        self.segnb_bn_bwd_apply_direct(dtype, y, ld_y, gg.N, gg.Ho, gg.Wo, Cp, coef, bcoef, act, slope, gsrc, ld_g,
+                                       tmp.data_ptr(), Cp, None, gg.Co, stream)
+        g2 = type(gg)()
+        ctypes.memmove(ctypes.addressof(g2), ctypes.addressof(gg), ctypes.sizeof(gg))
+        g2.ld_out = Cp
+        return self.segnb_conv_wgrad(g2, dtype, in_p, tmp.data_ptr(), dwp, nslab, stream)
+
     def segnb_conv_wgrad_partial(self, g, dtype, in_p, dout_p, dwp, nslab, stream):
         """partial slabs left unreduced: the emulated device splits the pixel range over the images (slab s = images
         s, s + nslab, ...); segnb_unpack_wgrad_multi sums them (job field nslab)"""
@@ -466,6 +481,12 @@ class AbiEmulator(object):
             B.copy_((B if accumulate else 0) + S[0, :C].float())
         SR.zero_()
         return 0
+
+    def segnb_bn_bwd_finalize_clear(self, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, clear, stream):
+        rc = self.segnb_bn_bwd_finalize(sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream)
+        if clear is not None:
+            _mem(clear, REPL * 2 * Cp, torch.float64).zero_()
+        return rc
 
     def segnb_bn_bwd_apply(self, dtype, y, ld_y, N, H, W, Cp, coef, bcoef, dz, ld_dz, dy, ld_dy, dbias, C, stream):
         dt = _tdt(dtype)

@@ -110,8 +110,22 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
+// bna (optional): the dy operand is not in memory -- it is the BatchNorm-backward apply of the layer, recomputed while
+// the tile is staged: dy = round(a (round(g act'(z)) - c1 - yhat c2)) from the incoming gradient g and the pre-BatchNorm
+// output y (segnb_conv_wgrad_bnapply; the arithmetic and roundings of bn_bwd_apply_kernel's direct form)
+struct segnb_wgrad_bnapply {
+    const void* g;
+    int ld_g;
+    const void* y;
+    int ld_y;
+    const float* coef;      // [4][Cp]: scale, shift, mean, invstd (segnb_bn_finalize)
+    const float* bcoef;     // [3][Cp]: a, c1, c2 (segnb_bn_bwd_finalize)
+    int Cp;
+    int act;
+    float slope;
+};
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream, bool partial = false);      // partial: leave the nslab slabs unreduced
+                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 
 // ------------------------------------------------------------------------------------------------

@@ -1399,6 +1399,37 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     return 0;
 }
 
+// weight gradient whose dy operand is the BatchNorm-backward apply of (g, y), recomputed in the kernel (first layer of a
+// network: nothing else reads that dy -- no data gradient -- so the apply pass and its tensor disappear)
+extern "C" int segnb_conv_wgrad_bnapply_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || wgrad_general_only()) return 0;
+    static const bool off = getenv("SEGNB_WGRAD_BNAPPLY") != nullptr && getenv("SEGNB_WGRAD_BNAPPLY")[0] == '0';
+    if (off || g->Co > 32 || g->Co % 8 != 0) return 0;
+    return segnb_wgrad_s1_slabs(g) > 0 ? 1 : 0;
+}
+
+extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, const void* in, const void* gsrc, int ld_g,
+                                        const void* y, int ld_y, const float* coef, const float* bcoef, int Cp, int act,
+                                        float slope, float* dwp, int nslab, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_wgrad_bnapply, g, dtype, in, gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope, dwp, nslab, stream);
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && gsrc && y && coef && bcoef && dwp, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_conv_wgrad_bnapply_ok(g, dtype), "geometry not served (segnb_conv_wgrad_bnapply_ok)");
+    SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
+    SEGNB_CHECK_ARG(Cp >= g->Co && ld_g >= g->Co && ld_y >= g->Co, "bad strides");
+    const segnb_wgrad_bnapply bna = {gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope};
+    const int rc = segnb_wgrad_s1_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_conv_wgrad_bnapply: no kernel for this geometry");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
 extern "C" int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                                         float* dwp, int nslab, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_partial, g, dtype, in, dout, dwp, nslab, stream);

@@ -565,6 +565,13 @@ __global__ void bn_bwd_finalize_kernel(const BnBwdParams p, const float* __restr
     p.bcoef[c] = a;
     p.bcoef[Cp + c] = c1;
     p.bcoef[2 * Cp + c] = c2;
+    if (p.zero_buf != nullptr) {        // (segnb_bn_bwd_finalize_clear: this layer's forward statistics, consumed by a fused forward)
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            p.zero_buf[(rp * 2) * Cp + c] = 0.0;
+            p.zero_buf[(rp * 2 + 1) * Cp + c] = 0.0;
+        }
+    }
 }
 
 template <typename T, bool ACC = false>       // ACC: dy += result (gradient of a multi-consumer tensor: no separate segnb_add pass)
@@ -1023,6 +1030,19 @@ extern "C" int segnb_bn_bwd_finalize(double* sums, int C, int Cp, double count, 
     SEGNB_PLAN_RECORD(segnb_bn_bwd_finalize, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream);
     SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
     BnBwdParams bp = {sums, count, gamma, dgamma, dbeta, C, accumulate, bcoef, nullptr};
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, bp, coef, Cp);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same, and the layer's FORWARD statistics buffer cleared (what the fused apply launches do on the way): for a layer
+// whose apply pass does not exist because its only consumer recomputes dy (segnb_conv_wgrad_bnapply)
+extern "C" int segnb_bn_bwd_finalize_clear(double* sums, int C, int Cp, double count, const float* gamma,
+                                           const float* coef, float* bcoef, float* dgamma, float* dbeta,
+                                           int accumulate, double* fwd_stats_to_clear, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_finalize_clear, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, stream);
+    SEGNB_CHECK_ARG(sums && coef && bcoef && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
+    BnBwdParams bp = {sums, count, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, bp, coef, Cp);
     SEGNB_LAUNCH_CHECK();
     return 0;

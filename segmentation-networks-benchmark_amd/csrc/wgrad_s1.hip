@@ -85,7 +85,10 @@ struct WgS1Args {
     int its_per_split;
     long long slab_stride;  // floats between the partial slabs of consecutive pixel splits
     int Ktot;               // 9 * Ci
+    segnb_wgrad_bnapply bna;    // BNA instantiations: dy recomputed from (g, y) while staging (bna.g != NULL)
 };
+
+__device__ __forceinline__ float wg_round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
 
 // one tap of one slab: wait for B_t of the current fragment set, MFMA, request B_t of the next set
 template <int T, int WAITN, bool MORE, int OB, int SXB>
@@ -254,9 +257,10 @@ constexpr bool wg_specialised() {
            (!SEGNB_WG_WS_DB || wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO)));
 }
 
-template <int BCO, int BCI, int R, int WT, bool FLAT = false>
+template <int BCO, int BCI, int R, int WT, bool FLAT = false, bool BNA = false>
 __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), 1) void conv_wgrad_s1x9_kernel(
     const WgS1Args a) {
+    static_assert(!BNA || (!FLAT && BCO == 32), "the recomputed dy operand is built for the thin 32 x 32 tiles");
     using TL = WgTile<R, WT, FLAT>;
     constexpr int TCO = BCO / 32, TCI = BCI / 32;
     constexpr int NSUB = TCO * TCI;
@@ -311,6 +315,24 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
         return;
     }
 
+    // BNA: constants of this thread's dy channel chunk (chunk index = tid % (BCO / 8) for every staged vector: 256 % (BCO / 8) == 0)
+    float k_mu[8], k_sc[8], k_sh[8], k_is[8], k_a[8], k_c1[8], k_c2[8], k_neg = 0.f;
+    if constexpr (BNA) {
+        static_assert(256 % (BCO / 8) == 0, "fixed chunk per thread");
+        const int chk = co0 + (tid % (BCO / 8)) * 8;
+        k_neg = a.bna.act == SEGNB_ACT_RELU ? 0.f : (a.bna.act == SEGNB_ACT_LEAKY ? a.bna.slope : 1.f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cch = chk + e < a.bna.Cp ? chk + e : 0;
+            k_sc[e] = a.bna.coef[cch];
+            k_sh[e] = a.bna.coef[a.bna.Cp + cch];
+            k_mu[e] = a.bna.coef[2 * a.bna.Cp + cch];
+            k_is[e] = a.bna.coef[3 * a.bna.Cp + cch];
+            k_a[e] = a.bna.bcoef[cch];
+            k_c1[e] = a.bna.bcoef[a.bna.Cp + cch];
+            k_c2[e] = a.bna.bcoef[2 * a.bna.Cp + cch];
+        }
+    }
     uint4 rx[XPT], ry[YPT];
     auto gload = [&](int it) {
         if constexpr (FLAT) {
@@ -366,8 +388,29 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
             const int ho = h0 + yr, wo = w0 + yc;
             const int ch = co0 + cc * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < YCH && ch < a.Co && ho < a.H && wo < a.W)
-                v = *reinterpret_cast<const uint4*>(a.dy + ((long long)(n * a.H + ho) * a.W + wo) * a.ld_dy + ch);
+            if (c < YCH && ch < a.Co && ho < a.H && wo < a.W) {
+                if constexpr (BNA) {
+                    // dy = BatchNorm-backward apply of (g, y), bit for bit what bn_bwd_apply_kernel (direct form) would have
+                    // stored: round(g act'(z)), then round(a (. - c1 - yhat c2)); the per-channel constants of the thread's
+                    // (fixed) channel chunk were loaded once, before the pixel loop
+                    const long long pix = (long long)(n * a.H + ho) * a.W + wo;
+                    float gv[8], yv[8], o[8];
+                    load8(reinterpret_cast<const bf16_t*>(a.bna.g) + pix * a.bna.ld_g + ch, gv);
+                    load8(reinterpret_cast<const bf16_t*>(a.bna.y) + pix * a.bna.ld_y + ch, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = (yv[e] - k_mu[e]) * k_sc[e] + k_sh[e] + 0.f;
+                        const float d = wg_round_bf16(gv[e] * 1.f * (z > 0.f ? 1.f : k_neg));
+                        const float yh = (yv[e] - k_mu[e]) * k_is[e];
+                        o[e] = k_a[e] * (d - k_c1[e] - yh * k_c2[e]);
+                    }
+                    bf16_t packed[8];
+                    store8(packed, o);
+                    v = *reinterpret_cast<const uint4*>(packed);
+                } else {
+                    v = *reinterpret_cast<const uint4*>(a.dy + ((long long)(n * a.H + ho) * a.W + wo) * a.ld_dy + ch);
+                }
+            }
             ry[u] = v;
         }
     };
@@ -664,14 +707,14 @@ int s1_slabs(int tiles, bool thin, bool flat = false) {
     return S < 1 ? 1 : S;
 }
 
-template <int BCO, int BCI, int R, int WT, bool FLAT = false>
+template <int BCO, int BCI, int R, int WT, bool FLAT = false, bool BNA = false>
 int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
     using TL = WgTile<R, WT, FLAT>;
     constexpr int tile_bytes = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
     constexpr int smem = (wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB) ? 2 * tile_bytes : tile_bytes;
     static_assert(smem <= 160 * 1024, "tiles fit the LDS");
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT, BNA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) segnb_set_error("wgrad_s1 hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -691,7 +734,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
     }
     a.its_per_split = (a.IT + S - 1) / S;
     a.slab_stride = (long long)a.Co * a.Ktot;
-    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT>), dim3(tiles * S),
+    hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT, BNA>), dim3(tiles * S),
                        dim3(wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), smem, stream, a);
     if (S > 1 && !partial) {
         const long long total = a.slab_stride;
@@ -751,9 +794,10 @@ int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
 // returns 1 when the launch was handled here, 0 when the geometry is not a stride-1 3x3 bf16 case
 // (caller falls through to the general kernel), <0 / hipError on failure
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream, bool partial) {
+                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna) {
     const S1Choice c = s1_choose(g);
     if (!c.cfg) return 0;
+    if (bna != nullptr && c.cfg != 1 && c.cfg != 6) return 0;      // (thin 32 x 32 tiles only)
     int dhmin = g->dh[0], dwmin = g->dw[0];
     for (int t = 1; t < 9; ++t) {
         dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
@@ -771,7 +815,14 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.Ktot = 9 * g->Ci;
+    a.bna = segnb_wgrad_bnapply{};
     int rc;
+    if (bna != nullptr) {
+        a.bna = *bna;
+        rc = c.cfg == 1 ? launch_s1<32, 32, 8, 32, false, true>(a, nslab, stream, partial)
+                        : launch_s1<32, 32, 16, 32, false, true>(a, nslab, stream, partial);
+        return rc ? rc : 1;
+    }
     if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream, partial);
     else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream, partial);
     else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream, partial);

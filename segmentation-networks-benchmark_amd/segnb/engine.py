@@ -457,6 +457,27 @@ class ConvOp(object):
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
                                    dxv.ptr, None, rt.stream), ex)
 
+    def wgrad_bnapply_ok(self, xv, yv):
+        """True when this convolution's weight gradient can recompute its dy operand -- the BatchNorm-backward apply of the
+        layer -- from (g, y) itself (segnb_conv_wgrad_bnapply): the apply pass then disappears for a layer without a data
+        gradient.  OFF by default (SEGNB_WGRAD_BNAPPLY=1 enables): measured on MI355X at the first layer of the timed
+        configuration, the register-staged thin weight-gradient kernel pays for the second operand stream and the
+        arithmetic with +100 us, exactly what the 104 us apply pass cost (5.32-5.34 vs 5.31 ms/step)."""
+        p = self.plan(xv.H, xv.W)
+        if self.transposed or len(p['fwd']) != 1 or os.environ.get('SEGNB_WGRAD_BNAPPLY', '0') == '0':
+            return False
+        g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+        return bool(nv.query('segnb_conv_wgrad_bnapply_ok', g, self.rt.code))
+
+    def wgrad_bnapply(self, xv, gv, yv, coef, bcoef, act, slope):
+        """the weight gradient with dy = BatchNorm-backward apply of (gv, yv); result left in the packed workspace"""
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        l = p['fwd'][0]
+        g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_wgrad_bnapply', g, rt.code, xv.ptr, gv.ptr, gv.ld, yv.ptr, yv.ld, nv.ptr(coef),
+                               nv.ptr(bcoef), self.Cop, act, slope, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream))
+
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
         workspace -- as UNREDUCED partial slabs (segnb_conv_wgrad_partial) -- for a later batched
@@ -831,6 +852,17 @@ class Stage(object):
                     vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
+        if (dx is None and direct and self._fused_fwd and self.defer_unpack and postponed is None
+                and isinstance(self.conv, ConvOp) and self.conv.wgrad_bnapply_ok(xv, yv)):
+            # FIRST layer of the network: no data gradient, so the only reader of dy is this layer's weight gradient -- it
+            # recomputes dy from (g, y) while staging its tiles (segnb_conv_wgrad_bnapply): the apply pass and its tensor are
+            # gone from the serial tail of backward (a 5 us finalize instead of a full pass over the largest activation)
+            nv.call('segnb_bn_bwd_finalize_clear', nv.ptr(self.sums), self.C, self.Cp, count, nv.ptr(self.bn.weight.detach()),
+                    nv.ptr(self.coef), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
+                    nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), rt.stream)
+            self._stats_stale = False
+            self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
+            return False
         if has_bn and self._fused_fwd and direct:
             nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),

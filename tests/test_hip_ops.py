@@ -980,6 +980,46 @@ def test_conv_full_size_vs_torch(shape, wg_cu_pct):
         check(name + ' dx vs torch', dxv.dense().float().cpu()[..., :Ci].permute(0, 3, 1, 2), xr.grad, 'bf16')
 
 
+@pytest.mark.parametrize('shape', [(32, 224, 224, 3, 32, 1), (2, 40, 56, 3, 32, 2), (3, 33, 47, 8, 24, 1), (2, 64, 64, 32, 32, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_wgrad_with_recomputed_bn_apply(shape):
+    """segnb_conv_wgrad_bnapply: the weight gradient of a layer whose dy operand -- the BatchNorm-backward apply of
+    (g, y), lib/modules/abn/functions.py:118 -- is recomputed while the tiles are staged (first layer of the network: the
+    apply pass disappears) == segnb_bn_bwd_apply_direct followed by segnb_conv_wgrad, bit for bit; incl. the first layer
+    of the timed configuration (bs=32 224x224, 3 -> 32)."""
+    N, H, W, Ci, Co, act = shape
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 3 + Co)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen).cuda()
+    Cip = cp.pad8(Ci)
+    op = ConvOp(rt, w, None, [(Ci, Cip)], 1, 1, False, need_dgrad=False)
+    xv = View.alloc(rt, N, H, W, Cip)
+    xv.dense()[..., :Ci].normal_()
+    yv = View.alloc(rt, N, H, W, op.Cop)
+    yv.t.normal_()
+    gv = View.alloc(rt, N, H, W, op.Cop)
+    gv.t.normal_()
+    Cp = op.Cop
+    coef = torch.stack([0.5 + torch.rand(Cp, generator=gen), 0.3 * torch.randn(Cp, generator=gen),
+                        0.2 * torch.randn(Cp, generator=gen), 0.5 + torch.rand(Cp, generator=gen)]).cuda()
+    bcoef = torch.stack([0.5 + torch.rand(Cp, generator=gen), 0.1 * torch.randn(Cp, generator=gen),
+                         0.1 * torch.randn(Cp, generator=gen)]).cuda()
+    assert op.wgrad_bnapply_ok(xv, yv)
+    slope = 0.01
+    dz = View.alloc(rt, N, H, W, Cp)
+    nv.call('segnb_bn_bwd_apply_direct', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), act, slope,
+            gv.ptr, gv.ld, dz.ptr, dz.ld, None, Co, rt.stream)
+    p = op.plan(H, W)
+    op.wgrad(xv, dz, torch.zeros_like(w), unpack=False)
+    ref = p['dwp'][0][0].clone()
+    p['dwp'][0].zero_()
+    op.wgrad_bnapply(xv, gv, yv, coef, bcoef, act, slope)
+    got = p['dwp'][0][0].clone()
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) > 0
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 # (N, high-resolution size, channels of the upsampled tensor, skip channels, output channels): the five decoder levels of
 # the timed configuration, a ragged toy, and sizes that take the general kernels (odd, non-multiples of 64)
 UPCAT_SHAPES = [(32, 14, 1024, 512, 512), (32, 28, 512, 256, 256), (32, 56, 256, 128, 128), (32, 112, 128, 64, 64),
