@@ -349,6 +349,18 @@ int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
  * would run on the general gather kernel.  A plan uses it to decide between the segmented and the plain data gradient of a
  * decoder block (segnb.engine.UpCatConvOp). */
 int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype);
+
+/* The FORWARD of such a segment on the low-resolution tensor u [N][H][W][Ci], ADDED to out [N][2H][2W][Co]:
+ *     out[n, 2Y + py, 2X + px, :] += sum_{a, b < 2} u[n, Y + py - 1 + a, X + px - 1 + b, :] . W[py, px][:, (a, b), :]
+ * = conv3x3(pad 1)(Upsample(scale_factor=2)(u)) (lib/models/zf_unet.py:42,78-90) through the ConvTranspose2d(4, 2, 1)
+ * identity, the four output phases in ONE launch; `out` holds the skip segment's convolution (+ bias) on entry.
+ * wpacked: [4 phases][CoW][4 taps][Ci] bf16 -- phase p = 2 py + px, the tap lists of the phase launches of a 4x4 / stride-2 /
+ * pad-1 transposed convolution (segnb.convplan.convt_fwd), summed from the 3x3 parameter by masked pack jobs.
+ * stats: BatchNorm statistics of the FINAL stored values (fp64 [SEGNB_STAT_REPLICAS][2][Co]) or NULL.  bf16, Ci % 64 == 0,
+ * Ci >= 128, Co > 32, W >= 12 (segnb_upconv_fprop_acc_ok); other shapes keep the 9-tap launch over the concat buffer. */
+int segnb_upconv_fprop_acc_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype);
+int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co,
+                           int CoW, void* out, int ld_out, double* stats, segnb_stream_t stream);
 int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,
                               const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream);
 

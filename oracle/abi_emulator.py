@@ -149,6 +149,34 @@ class AbiEmulator(object):
 
     # ---- data gradient + the BatchNorm-backward reduction of its output's producer (segnb_conv_fprop_bnreduce) = the two
     # separate entry points, composed
+    def segnb_upconv_fprop_acc_ok(self, N, H, W, Ci, Co, ld_out, dtype):
+        return 1                                            # (every shape: the segmented forward plan is exercised)
+
+    def segnb_upconv_fprop_acc(self, dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, out_p, ld_out, stats, stream):
+        """out[n, 2Y+py, 2X+px] += sum_taps u[n, Y+dh, X+dw] . W[phase][:, tap, :], tap lists of convt_fwd(4, 2, 1)"""
+        from segnb import convplan as cpl
+        dt = _tdt(dtype)
+        U = _nhwc(in_p, N, H, W, Ci, ld_in, dt).float()
+        O = _nhwc(out_p, N, 2 * H, 2 * W, Co, ld_out, dt)
+        Wm = _mem(wp, 4 * CoW * 4 * Ci, dt).view(4, CoW, 4, Ci).float()
+        _, launches, full = cpl.convt_fwd(H, W, 4, 4, 2, 1)
+        assert full and len(launches) == 4
+        Up = torch.nn.functional.pad(U, (0, 0, 1, 1, 1, 1))
+        res = O.float().clone()
+        for ph, l in enumerate(launches):
+            acc = torch.zeros(N, H, W, Co)
+            for t, (dh, dw, _, _) in enumerate(l.taps):
+                acc += Up[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W, :] @ Wm[ph, :Co, t, :].t()
+            res[:, l.oh0::2, l.ow0::2, :] += acc
+        stored = res.to(dt)
+        O.copy_(stored)
+        if stats is not None:
+            S = _mem(stats, REPL * 2 * Co, torch.float64).view(REPL, 2, Co)[0]
+            v = stored.double().reshape(-1, Co)
+            S[0] += v.sum(0)
+            S[1] += (v * v).sum(0)
+        return 0
+
     def segnb_conv_fprop_upd_ok(self, g, dtype):
         g = _geom(g)
         return int(g.ntaps == 16 and g.in_step == 2)       # (the emulator serves every geometry: the segmented plan is exercised)

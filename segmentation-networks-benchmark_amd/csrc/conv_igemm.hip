@@ -1312,6 +1312,37 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
     return 0;
 }
 
+// ---- forward of an Upsample(x2) -> conv3x3 segment on the low-resolution tensor, accumulating (fprop_dma.hip, WsCfg UP_ = 2)
+int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, unsigned in_bytes, const void* wpacked,
+                        unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream);
+
+extern "C" int segnb_upconv_fprop_acc_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype) {
+    if (dtype != SEGNB_BF16 || getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Ci % 64 != 0 || Ci < 128 || Co <= 32 || Co % 8 != 0 || W < 12) return 0;
+    return (((long long)N * 4 * H * W - 1) * ld_out + Co) * 2 < (1ll << 31) ? 1 : 0;
+}
+
+extern "C" int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked,
+                                      int Co, int CoW, void* out, int ld_out, double* stats, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_upconv_fprop_acc, dtype, N, H, W, Ci, ld_in, in, wpacked, Co, CoW, out, ld_out, stats, stream);
+    SEGNB_CHECK_ARG(in && wpacked && out, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_upconv_fprop_acc_ok(N, H, W, Ci, Co, ld_out, dtype), "shape not served (segnb_upconv_fprop_acc_ok)");
+    SEGNB_CHECK_ARG(CoW >= Co && ld_in >= Ci && ld_out >= Co, "bad strides");
+    const long long inb = (((long long)N * H * W - 1) * ld_in + Ci) * 2, wb = 4ll * CoW * 4 * Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    const int rc = segnb_fprop_upf_try(N, H, W, Ci, ld_in, in, (unsigned)inb, wpacked, (unsigned)wb, Co, CoW, out, ld_out, stats,
+                                       (hipStream_t)stream);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_upconv_fprop_acc: no kernel for this shape");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
 extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype) {
     if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g)) return 0;
     if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || !segnb_knob_bnreduce_fused()) return 0;

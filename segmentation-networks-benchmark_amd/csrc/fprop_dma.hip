@@ -63,8 +63,17 @@ __device__ unsigned long long g_stamps[3 * 256 * 4];
 // {0, 1}.  A K chunk = (plane, 64 channels) with a 2 x 2 tap window whose halo origin is shifted by (-py, -px): the
 // matrix waves see ONE tap geometry (window offsets {0,1}^2) for every chunk, the halo waves keep one set of per-lane source
 // offsets per plane (dz pixel (2 Yp + py, 2 Xp + px): a strided LDS-DMA gather, whole 128-byte channel rows).
-template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false, bool MF16_ = true, int NTAP_ = 9, bool UPD_ = false>
+//
+// UP_ = 2 (UPF): the FORWARD of such a segment, out[2 Y + py, 2 X + px] += sum_{a, b < 2} u[Y + py - 1 + a, X + px - 1 + b] . W[py,px][a,b]
+// (the four phase launches of the 4x4 / stride-2 transposed convolution as ONE launch): a block owns one (phase, 64-channel
+// tile) -- its weights and its halo origin (py - 1, px - 1) are fixed, the tile grid is the LOW-resolution one, the output
+// pixel table maps a tile row to the high-resolution pixel of its phase -- and ADDS to what the skip segment's launch left
+// in `out` (read at the start of a tile into 32 registers, added when the accumulators are staged; statistics on the sum).
+template <int BN_, int R_, int WT_, int CW_M_, bool TALL_ = false, bool MF16_ = true, int NTAP_ = 9, int UP_ = 0>
 struct WsCfg {
+    static constexpr bool UPD_ = UP_ == 1;
+    static constexpr bool UPF = UP_ == 2;
+    static_assert(UP_ == 0 || (NTAP_ == 4 && !TALL_ && MF16_), "up-sampled segment forms: 2 x 2 window, 16x16x32 form");
     static constexpr int BN = BN_, R = R_, WT = WT_;
     static constexpr int NTAP = NTAP_, KW = NTAP_ == 9 ? 3 : 2, KH = KW;
     static constexpr bool UPD = UPD_;
@@ -139,7 +148,16 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 
     const int L = xcd_remap_fd(blockIdx.x, gridDim.x);
     const int nt = L % a.NTL, gq = L / a.NTL;
-    const int n_base = nt * BN;
+    // n_base: first output channel of the block (output, bias, statistics); w_row0: its first row of the weight matrix
+    int n_base_ = nt * BN, w_row0_ = nt * BN, py_ = 0, px_ = 0;
+    if constexpr (C::UPF) {
+        const int ph = nt / a.NTLR, ct = nt - ph * a.NTLR;      // (phase, channel tile)
+        n_base_ = ct * BN;
+        w_row0_ = ph * a.CoW + ct * BN;
+        py_ = ph >> 1;
+        px_ = ph & 1;
+    }
+    const int n_base = n_base_, w_row0 = w_row0_, py = py_, px = px_;
 
     const i32x4_t rs_x = make_rsrc4(a.x, a.x_bytes);
     const i32x4_t rs_w = make_rsrc4(a.w, a.w_bytes);
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 const int row = ((lw & 1) * BPW + pb) * 8 + (lane >> 3);
                 const int q = lane & 7;
                 const int co = n_base + row;
-                b_voff[pb] = co < a.Co ? (unsigned)co * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
+                b_voff[pb] = co < a.Co ? (unsigned)(w_row0 + row) * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
             }
             auto fetch_b = [&](int c, int t, int stage) {
                 unsigned soff;
@@ -198,6 +216,10 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     const int pl = c / a.NCHP, sl = c - pl * a.NCHP;
                     const int t16 = (2 * (t >> 1) - (pl >> 1) + 1) * 4 + (2 * (t & 1) - (pl & 1) + 1);
                     soff = (unsigned)(t16 * a.Ci + sl * 64) * 2u;
+                } else if constexpr (C::UPF) {
+                    // window tap (ta, tb) = tap (1 - ta, 1 - tb) of the phase's packed list (segnb.convplan._scatter_phases
+                    // lists the kernel rows of a phase in ascending order = descending input offset)
+                    soff = (unsigned)((3 - t) * a.Ci + c * 64) * 2u;
                 } else {
                     soff = (unsigned)(t * a.Ci + c * 64) * 2u;
                 }
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         }
                     });
                 } else {
-                const int h0 = hb * R + a.dhmin, w0 = wb * WT + a.dwmin;
+                const int h0 = hb * R + (C::UPF ? py - 1 : a.dhmin), w0 = wb * WT + (C::UPF ? px - 1 : a.dwmin);
                 const unsigned base = (unsigned)(((n * a.Hi + h0) * a.Wi + w0) * a.ld_x * 2);
                 const unsigned hlim = live ? (unsigned)a.Hi : 0u;
         #pragma unroll
@@ -310,7 +332,10 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         #pragma unroll
                 for (int rr = t128; rr < BM; rr += C::NAW * 64) {
                     const int ho = hb * R + rr / WT, wo = wb * WT + rr % WT;
-                    sPix[table * BM + rr] = (live && ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
+                    if constexpr (C::UPF)       // the tile row's pixel of this block's phase in the high-resolution output
+                        sPix[table * BM + rr] = (live && ho < a.H && wo < a.W) ? (n * 2 * a.H + 2 * ho + py) * (2 * a.W) + 2 * wo + px : -1;
+                    else
+                        sPix[table * BM + rr] = (live && ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
                 }
             };
             auto fetch_a = [&](int p0, int p1, int c, int buf) {
@@ -464,17 +489,21 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         // START of the tap, older than the tap's first fragment wait, so they cost no wait of their own (as compiler
         // loads after the MFMAs they stalled on the look-ahead fragment reads in flight); the store and the statistics
         // run on registers after the MFMAs.
-        int row_pix = -1;
-        u32x4_t row_v = {0, 0, 0, 0};
+        int row_pix = -1, row_pix2 = -1;
+        u32x4_t row_v = {0, 0, 0, 0}, row_v2 = {0, 0, 0, 0};     // (second set: two store rows per step, short 2 x 2-window tiles)
         auto row_load = [&](int k, const int* tab) {           // staged row row0 + k * (MT / OC) of the previous tile
             const int row = row0 + k * (C::MT / OC);
             const unsigned a_pix = (unsigned)(size_t)(tab + row), a_v = (unsigned)(size_t)(sOut + row * OUT_ROW + cc * 16);
             asm volatile("ds_read_b32 %0, %1" : "=v"(row_pix) : "v"(a_pix));
             asm volatile("ds_read_b128 %0, %1" : "=v"(row_v) : "v"(a_v));
         };
-        auto row_store = [&]() {
-            const int opix = row_pix;
-            const u32x4_t v = row_v;
+        auto row_load2 = [&](int k, const int* tab) {
+            const int row = row0 + k * (C::MT / OC);
+            const unsigned a_pix = (unsigned)(size_t)(tab + row), a_v = (unsigned)(size_t)(sOut + row * OUT_ROW + cc * 16);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(row_pix2) : "v"(a_pix));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(row_v2) : "v"(a_v));
+        };
+        auto row_store_of = [&](int opix, const u32x4_t v) {
             const bool ok = cok && opix >= 0;
             const unsigned voff = ok ? (unsigned)opix * (unsigned)a.ld_out * 2u + (unsigned)(n_base + cc * 8) * 2u : OOB;
             if (!(DBG && (a.dbg & 8))) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (int)voff, 0, 0);
@@ -493,6 +522,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 }
             }
         };
+        auto row_store = [&]() { row_store_of(row_pix, row_v); };
         if constexpr (MF16) {
             // ---- 16x16x32 matrix stream: 2 K slices of 32 channels per tap; wave tile = TM16 x TN16 tiles of 16 pixels x
             // 16 channels (4 x 4: 16 MFMAs of 16 cycles per slice).  Two fragment sets (set = slice parity): the 8 reads of
@@ -518,6 +548,25 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             bool pending = false;
             for (; it < a.IT; it += a.GM, ++tile_no) {
                 f32x4_t acc[TM16][TN16];
+                // UPF: what the skip segment's launch left at this tile's output pixels (4 bf16 per accumulator quad),
+                // requested now, added when the accumulators are staged -- a whole tile later
+                uint2 prev[C::UPF ? TM16 : 1][C::UPF ? TN16 : 1];
+                if constexpr (C::UPF) {
+                    const int r16 = lane & 15, g4 = lane >> 4;
+                    const int* tab = sPix + (tile_no & 3) * BM;
+#pragma unroll
+                    for (int i = 0; i < TM16; ++i) {
+                        const int opix = tab[wm * C::WM + 16 * i + r16];
+#pragma unroll
+                        for (int j = 0; j < TN16; ++j) {
+                            const int ch = n_base + wn * C::WN + 16 * j + 4 * g4;
+                            uint2 v = make_uint2(0u, 0u);
+                            if (opix >= 0 && ch < a.Co)
+                                v = *reinterpret_cast<const uint2*>(a.out + (long long)opix * a.ld_out + ch);
+                            prev[i][j] = v;
+                        }
+                    }
+                }
                 for (int c = 0; c < a.NCH; ++c, ++cg) {
                     const int a_base = (cg & 1) * C::A_BYTES;
                     const bool drain = pending && c == 0;
@@ -537,12 +586,18 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         if constexpr (NTAP == 9) {
                             do_row = drain;
                         } else {
+                            // (a.RPS = 1: rows 0..RPT-1 on steps 1..RPT;  2: rows 2 k, 2 k + 1 on step k + 1 -- tiles of fewer
+                            // than RPT + 1 steps: 128 input channels)
                             const int si = c * NTAP + t;
-                            krow = si - 1;
-                            do_row = pending && si >= 1 && si <= C::RPT;
+                            krow = (si - 1) * a.RPS;
+                            do_row = pending && si >= 1 && krow < C::RPT;
                         }
                         if constexpr (row_tap9 || NTAP != 9)
-                            if (do_row) row_load(krow, sPix + ((tile_no + 3) & 3) * BM);
+                            if (do_row) {
+                                row_load(krow, sPix + ((tile_no + 3) & 3) * BM);
+                                if constexpr (NTAP != 9)
+                                    if (a.RPS == 2) row_load2(krow + 1, sPix + ((tile_no + 3) & 3) * BM);
+                            }
                         if (!(SEGNB_EXP & 4) && !(DBG && (a.dbg & 4))) {
                             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -580,8 +635,13 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         if constexpr (row_tap9 || NTAP != 9)
                             if (do_row) {
                                 if (DBG && (a.dbg & 4)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(row_pix), "+v"(row_v));     // older than the 8 look-ahead reads
+                                if constexpr (NTAP != 9)
+                                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(row_pix), "+v"(row_v), "+v"(row_pix2), "+v"(row_v2));
+                                else
+                                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(row_pix), "+v"(row_v));     // older than the 8 look-ahead reads
                                 row_store();
+                                if constexpr (NTAP != 9)
+                                    if (a.RPS == 2) row_store_of(row_pix2, row_v2);
                             }
                         if (wave == 0) FD_STAMP(0, cg * 9 + t, 2);
                         raw_barrier();
@@ -610,8 +670,16 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     for (int j = 0; j < TN16; ++j) {
                         const int col = wn * C::WN + 16 * j + 4 * g4;
                         uint2 pk;
+                        if constexpr (C::UPF) {
+                            const uint2 pv = prev[i][j];
+                            pk.x = pack2bf(acc[i][j][0] + __uint_as_float(pv.x << 16) + bv[j].x,
+                                           acc[i][j][1] + __uint_as_float(pv.x & 0xffff0000u) + bv[j].y);
+                            pk.y = pack2bf(acc[i][j][2] + __uint_as_float(pv.y << 16) + bv[j].z,
+                                           acc[i][j][3] + __uint_as_float(pv.y & 0xffff0000u) + bv[j].w);
+                        } else {
                         pk.x = pack2bf(ep(acc[i][j][0], sv[j].x, bv[j].x), ep(acc[i][j][1], sv[j].y, bv[j].y));
                         pk.y = pack2bf(ep(acc[i][j][2], sv[j].z, bv[j].z), ep(acc[i][j][3], sv[j].w, bv[j].w));
+                        }
                         *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
@@ -831,12 +899,40 @@ int launch_ws_upd(FdArgs& a, hipStream_t stream) {
     a.NTL = (a.Co + C::BN - 1) / C::BN;
     a.NCHP = a.Ci / 64;
     a.NCH = 4 * a.NCHP;
+    a.RPS = 1;
     if (a.NCH * C::NTAP - 1 < C::RPT) return NOT_HANDLED;       // the previous tile's store rows ride on steps 1..RPT
     int gm = segnb_knob_conv_cus() / a.NTL;
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
     hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
+    return 0;
+}
+
+// the forward of an up-sampled segment: four phases in one launch, accumulating (WsCfg UP_ = 2)
+template <class C>
+int launch_ws_upf(FdArgs& a, hipStream_t stream) {
+    static int attr_rc = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }();
+    if (attr_rc) return attr_rc;
+    a.HB = (a.H + C::R - 1) / C::R;
+    a.WB = (a.W + C::WT - 1) / C::WT;
+    a.IT = a.N * a.HB * a.WB;
+    a.NTLR = (a.Co + C::BN - 1) / C::BN;
+    a.NTL = 4 * a.NTLR;
+    a.NCH = a.Ci / 64;
+    a.NCHP = a.NCH;
+    a.RPS = a.NCH * C::NTAP - 1 < C::RPT ? 2 : 1;               // store rows per step
+    if ((a.NCH * C::NTAP - 1) * a.RPS < C::RPT) return NOT_HANDLED;
+    int gm = segnb_knob_conv_cus() / a.NTL;
+    if (gm < 1) gm = 1;
+    if (gm > a.IT) gm = a.IT;
+    a.GM = gm;
+    hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     return 0;
 }
 
@@ -866,8 +962,8 @@ int try_upd(const segnb_conv_geom* g, FdArgs& a, hipStream_t stream) {
     const long long it1 = (long long)g->N * ((g->Ho + 15) / 16) * ((g->Wo + 15) / 16);
     int cfg = segnb_knob_fprop_dma_cfg();
     if (cfg < 0) cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
-    if (cfg == 0) return launch_ws_upd<WsCfg<64, 8, 32, 4, false, true, 4, true>>(a, stream);
-    return launch_ws_upd<WsCfg<64, 16, 16, 4, false, true, 4, true>>(a, stream);
+    if (cfg == 0) return launch_ws_upd<WsCfg<64, 8, 32, 4, false, true, 4, 1>>(a, stream);
+    return launch_ws_upd<WsCfg<64, 16, 16, 4, false, true, 4, 1>>(a, stream);
 }
 
 int dispatch_fd(FdArgs& a, hipStream_t stream) {
@@ -915,6 +1011,51 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// out[n, 2 Y + py, 2 X + px, :] += sum_{a, b < 2} in[n, Y + py - 1 + a, X + px - 1 + b, :] . W[phase][:, tap, :]  for the four
+// phases (py, px); wpacked = [4][CoW][4][Ci] (phase-major, the tap lists of segnb.convplan.convt_fwd(4, 2, 1)); statistics of
+// the sums.  1 = launched, 0 = not served
+int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, unsigned in_bytes, const void* wpacked,
+                        unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream) {
+    if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
+    if (Ci % 64 != 0 || Ci < 128 || Co <= 32 || W < 12) return 0;
+    FdArgs a;
+    a.x = (const bf16_t*)in;
+    a.w = (const bf16_t*)wpacked;
+    a.x_bytes = in_bytes;
+    a.w_bytes = w_bytes;
+    a.bias = nullptr;
+    a.bias_n = 0;
+    a.out = (bf16_t*)out;
+    a.stats = stats;
+    a.N = N; a.H = H; a.W = W; a.Hi = H; a.Wi = W;
+    a.Ci = Ci; a.Co = Co; a.ld_x = ld_in; a.ld_out = ld_out;
+    a.CoW = CoW;
+    a.Ktot = 4 * Ci;
+    const long long ob = (((long long)N * 4 * H * W - 1) * ld_out + Co) * 2;
+    if (ob >= (1ll << 31)) return 0;
+    a.out_bytes = (unsigned)ob;
+    a.dhmin = a.dwmin = 0;
+    for (int t = 0; t < 9; ++t) a.dh[t] = a.dw[t] = 0;
+    a.dh[2] = a.dh[3] = 1;
+    a.dw[1] = a.dw[3] = 1;
+    a.dbg = 0;
+    a.bn_y = nullptr;
+    a.ep_act = -1;
+    a.ep_coef = nullptr;
+    a.ep_slope = 0.f;
+    const int ntl = 4 * ((Co + 63) / 64);
+    int gm = segnb_knob_conv_cus() / ntl;
+    if (gm < 1) gm = 1;
+    const long long it0 = (long long)N * ((H + 7) / 8) * ((W + 31) / 32);
+    const long long it1 = (long long)N * ((H + 15) / 16) * ((W + 15) / 16);
+    int cfg = segnb_knob_fprop_dma_cfg();
+    if (cfg < 0) cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
+    const int rc = cfg == 0 ? launch_ws_upf<WsCfg<64, 8, 32, 4, false, true, 4, 2>>(a, stream)
+                            : launch_ws_upf<WsCfg<64, 16, 16, 4, false, true, 4, 2>>(a, stream);
+    if (rc == NOT_HANDLED) return 0;
+    return rc ? rc : 1;
+}
 
 extern "C" int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype) {
     if (g == nullptr || dtype != SEGNB_BF16) return 0;

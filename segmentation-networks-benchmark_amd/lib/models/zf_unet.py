@@ -159,7 +159,6 @@ class _ZFUnetPlan(object):
             blk = getattr(module, name)
             seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
             self._add(name, blk, seg1, True, upcat=self.subpixel)
-        self.keep_u = self.subpixel and UpCatConvOp.segment_wgrad
         self._bufs = {}
         self._pack_tables = {}
         self._packed_key = None
@@ -204,7 +203,7 @@ class _ZFUnetPlan(object):
                 if self.subpixel:
                     # the tensor cat_i's first segment is upsampled from, at its own (half) resolution, and its gradient
                     h2, w2 = hs[i + 1]
-                    if self.keep_u:
+                    if self._low_res(i, N, H, W):
                         b['u_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
                     if self._seg(i, N, H, W):
                         b['du_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
@@ -242,6 +241,17 @@ class _ZFUnetPlan(object):
         """Does decoder level lvl run its first convolution's data gradient by segment at this input size?"""
         conv = self.stages[DECODER[4 - lvl]][0].conv
         return self.subpixel and conv.segmented(N, H >> lvl, W >> lvl)
+
+    def _low_res(self, lvl, N, H, W):
+        """Does decoder level lvl read the tensor its concat buffer's first segment is upsampled from (segmented forward or
+        weight gradient)?  -> the producer also writes it at its own resolution"""
+        conv = self.stages[DECODER[4 - lvl]][0].conv
+        return self.subpixel and conv.needs_low_res(N, H >> lvl, W >> lvl)
+
+    def _upsampled(self, lvl, N, H, W):
+        """Is the upsampled copy in the concat buffer of level lvl still read (9-tap forward or weight gradient)?"""
+        conv = self.stages[DECODER[4 - lvl]][0].conv
+        return not self.subpixel or conv.reads_upsampled(N, H >> lvl, W >> lvl)
 
     def _tables(self, H, W, N=None):
         """One-launch weight pack table and per-group gradient unpack tables for this input size (rebuilt if the
@@ -461,14 +471,17 @@ class _ZFUnetPlan(object):
                     s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
                     cur = b['p_%d' % (i + 1)]
                 else:
-                    s2.forward(b['a1_%d' % i], train, drop[name], up_out=b['cat_4'].slice(0, wp[5]), need_grad=need_grad,
-                               out=b['u_4'] if (self.keep_u and need_grad) else None)
+                    s2.forward(b['a1_%d' % i], train, drop[name], need_grad=need_grad,
+                               up_out=b['cat_4'].slice(0, wp[5]) if self._upsampled(4, N, H, W) else None, out=b.get('u_4'))
             for name, lvl in zip(DECODER, (4, 3, 2, 1, 0)):
                 s1, s2 = self.stages[name]
+                if self.subpixel:
+                    s1.conv.bind_up(b.get('u_%d' % lvl), b.get('du_%d' % lvl))
                 s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
                 if lvl > 0:
-                    s2.forward(b['b1_%d' % lvl], train, drop[name], up_out=b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]), need_grad=need_grad,
-                               out=b['u_%d' % (lvl - 1)] if (self.keep_u and need_grad) else None)
+                    s2.forward(b['b1_%d' % lvl], train, drop[name], need_grad=need_grad,
+                               up_out=(b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]) if self._upsampled(lvl - 1, N, H, W) else None),
+                               out=b.get('u_%d' % (lvl - 1)))
                 else:
                     s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
             head = self.module.conv_final

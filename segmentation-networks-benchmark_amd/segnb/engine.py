@@ -540,6 +540,27 @@ class UpConvOp(ConvOp):
         self.out_map = rt.int32(list(range(co)) + [-1] * (self.Cop - co))
         self._plans = {}
 
+    def plan(self, Hi, Wi):
+        p = ConvOp.plan(self, Hi, Wi)
+        if 'wp_fwd_all' not in p:
+            # the four phase matrices in ONE buffer [4][Cop][4 * Cip] (segnb_upconv_fprop_acc runs the phases as one launch)
+            p['wp_fwd_all'] = self.rt.zeros((len(p['fwd']), self.Cop, 4 * self.Cip))
+            p['wp_fwd'] = [p['wp_fwd_all'][i] for i in range(len(p['fwd']))]
+        return p
+
+    def fprop_acc_ok(self, uv, yv):
+        return bool(nv.query('segnb_upconv_fprop_acc_ok', uv.N, uv.H, uv.W, self.Cip, self.Cop, yv.ld, self.rt.code))
+
+    def fprop_acc(self, uv, yv, stats=None):
+        """yv += conv3x3(Upsample x2(uv)) on the low-resolution tensor, the four output phases in one launch; stats: the
+        BatchNorm statistics of the sums.  (Check fprop_acc_ok first.)"""
+        p, rt = self.plan(uv.H, uv.W), self.rt
+        assert uv.Cp == self.Cip and yv.Cp == self.Cop and (yv.H, yv.W) == (2 * uv.H, 2 * uv.W)
+        ex = 2.0 * uv.N * uv.H * uv.W * 16 * self.Ci * self.Co
+        _timed('conv_fprop', ex * self.algo_scale,
+               lambda: nv.call('segnb_upconv_fprop_acc', rt.code, uv.N, uv.H, uv.W, self.Cip, uv.ld, uv.ptr,
+                               nv.ptr(p['wp_fwd_all']), self.Cop, self.Cop, yv.ptr, yv.ld, nv.ptr(stats), rt.stream), ex)
+
     @classmethod
     def mask(cls, a, b):
         """bit mask over the nine 3x3 positions (kh * 3 + kw) summed into position (a, b) of the 4x4 kernel"""
@@ -583,6 +604,11 @@ class UpCatConvOp(object):
     The forward stays the one 9-tap launch over the concat buffer.  Presents ConvOp's interface to Stage; the plan binds
     the low-resolution views with bind_up() before backward."""
 
+    # SEGNB_SUBPIXEL_FWD=1: the forward by segment too (default: the one 9-tap launch over the concat buffer -- measured alone,
+    # tools/upcat_bench.py: 91 -> 78, 96 -> 90, 88 -> 94 us at the 28x28 / 56x56 / 112x112 decoder levels: the 2 x 2-window tiles
+    # are short (8-32 steps) and pay the tile epilogue as often; the step time does not move while the weight gradient still
+    # reads the upsampled copy)
+    segment_fwd = os.environ.get('SEGNB_SUBPIXEL_FWD', '0') != '0'
     # SEGNB_SUBPIXEL_WGRAD=1: the weight gradient by segment too (default: the one 9-tap launch over the concat buffer --
     # measured alone at the five decoder shapes of the timed configuration, tools/upcat_bench.py: the weight-gradient kernel's
     # fixed cost per launch (partial slabs + their reduction) eats the 4/9 of the upsampled segment's multiply-adds)
@@ -593,9 +619,8 @@ class UpCatConvOp(object):
         self.rt, self.weight, self.bias = rt, weight, bias
         # (full: also the PLAIN data gradient, for the input sizes whose low-resolution gather has no fast kernel)
         self.full = ConvOp(rt, weight, bias, in_segments, 1, 1, False, need_dgrad=need_dgrad)
-        self.skip = ConvOp(rt, weight, None, [(sk_real, sk_pad)], 1, 1, False, need_dgrad=True, ci_offset=up_real)
-        self.skip.pack_fwd = False
-        self.up = UpConvOp(rt, weight, up_real, up_pad, need_dgrad=True, pack_fwd=False)
+        self.skip = ConvOp(rt, weight, bias, [(sk_real, sk_pad)], 1, 1, False, need_dgrad=True, ci_offset=up_real)
+        self.up = UpConvOp(rt, weight, up_real, up_pad, need_dgrad=True, pack_fwd=True)
         self.needs_u = self.segment_wgrad        # the plan keeps the low-resolution tensor only for the segmented weight gradient
         self.up_pad, self.sk_pad = up_pad, sk_pad
         self.Co, self.Cop, self.Ci, self.Cip = self.full.Co, self.full.Cop, self.full.Ci, self.full.Cip
@@ -620,10 +645,36 @@ class UpCatConvOp(object):
         if v is None:
             p = self.up.plan(H // 2, W // 2)
             g = self.up._geom(p, 'd', 0, p['dg'][0], N, H, W, self.up.Cop, self.up.Cop, H // 2, W // 2, self.up.Cip, self.up.Cip)
-            v = self._seg[key] = self.force_segmented or bool(nv.query('segnb_conv_fprop_upd_ok', g, self.rt.code))
+            v = self._seg[key] = (self.force_segmented or (self.force_thin and self.Cop <= 32 and W >= 64) or
+                                  bool(nv.query('segnb_conv_fprop_upd_ok', g, self.rt.code)))
         return v
 
+    def fwd_segmented(self, N, H, W, ld_out=None):
+        """Is the forward at input size H x W computed by segment -- the skip segment's 9-tap launch, then the upsampled
+        segment on the low-resolution tensor accumulating into its output (segnb_upconv_fprop_acc)?"""
+        if not self.segment_fwd:
+            return False
+        key = ('f', N, H, W)
+        v = self._seg.get(key)
+        if v is None:
+            ld = self.Cop if ld_out is None else ld_out
+            v = self._seg[key] = bool(nv.query('segnb_upconv_fprop_acc_ok', N, H // 2, W // 2, self.up.Cip, self.up.Cop, ld,
+                                               self.rt.code))
+        return v
+
+    def reads_upsampled(self, N, H, W):
+        """Does anything still read the upsampled copy in the concat buffer at this size?  (the 9-tap forward or the 9-tap
+        weight gradient)"""
+        return not self.fwd_segmented(N, H, W) or not self.segment_wgrad
+
+    def needs_low_res(self, N, H, W):
+        """Does anything read the low-resolution tensor itself?  (the segmented forward or the segmented weight gradient)"""
+        return self.fwd_segmented(N, H, W) or self.segment_wgrad
+
     _seg = None
+    # thin output (<= 32 channels, the 224x224 level): the layer is HBM-bound on the 4x-sized upsampled gradient slice, and
+    # not writing / re-reading it pays even though the low-resolution gather then runs on the general kernel (A/B below)
+    force_thin = os.environ.get('SEGNB_SUBPIXEL_THIN', '1') != '0'
     force_segmented = os.environ.get('SEGNB_SUBPIXEL', 'auto') == 'force'
 
     # ---- forward: the whole 9-tap convolution over the concat buffer
@@ -634,10 +685,16 @@ class UpCatConvOp(object):
         return self.full.out_hw(Hi, Wi)
 
     def fprop(self, xv, yv, stats=None, epilogue=None):
+        if epilogue is None and self._u is not None and self.fwd_segmented(xv.N, xv.H, xv.W, yv.ld):
+            # skip segment (with the bias) -> yv, then the upsampled segment added on the low-resolution tensor; the
+            # BatchNorm statistics are taken by the second launch, on the sums
+            self.skip.fprop(xv.slice(self.up_pad, self.sk_pad), yv, None)
+            self.up.fprop_acc(self._u, yv, stats)
+            return
         return self.full.fprop(xv, yv, stats, epilogue)
 
     def act_epilogue_ok(self, H, W):
-        return self.full.act_epilogue_ok(H, W)
+        return False        # (inference keeps the separate activation pass for these five layers)
 
     def u8_direct_ok(self, *a):
         return False
@@ -664,11 +721,16 @@ class UpCatConvOp(object):
     # ---- weight pack / gradient unpack jobs of all three ops (H, W: the convolution's own, high, resolution)
     def pack_jobs(self, H, W, N=None):
         """N: the batch size the plan runs at (the fast-kernel query is per geometry); None = segmented wherever possible"""
-        seg = self.segmented(N, H, W) if N is not None else True
-        if not seg:
-            return self.full.pack_jobs(H, W)
-        fwd_only = [j for j in self.full.pack_jobs(H, W) if j['mmap'] is self.full.out_map]
-        return fwd_only + self.skip.pack_jobs(H, W) + self.up.pack_jobs(H // 2, W // 2)
+        dseg = self.segmented(N, H, W) if N is not None else True
+        fseg = self.fwd_segmented(N, H, W) if N is not None else self.segment_fwd
+        full, skip, up = self.full.pack_jobs(H, W), self.skip.pack_jobs(H, W), self.up.pack_jobs(H // 2, W // 2)
+
+        def pick(jobs, op, fwd):
+            return [j for j in jobs if (j['mmap'] is op.out_map) == fwd]
+        jobs = (pick(skip, self.skip, True) + pick(up, self.up, True)) if fseg else pick(full, self.full, True)
+        if self.need_dgrad:
+            jobs += (pick(skip, self.skip, False) + pick(up, self.up, False)) if dseg else pick(full, self.full, False)
+        return jobs
 
     def unpack_jobs(self, H, W, grad_w):
         if not self.segment_wgrad:

@@ -1046,7 +1046,9 @@ def test_upcat_segmented_backward_vs_torch(shape):
     op = UpCatConvOp(rt, wd, None, [(Cu, Cup), (Cs, Csp)], need_dgrad=True)
     op.segment_wgrad = True                            # (instance overrides: both segmented paths are exercised here,
     op.force_segmented = True                          #  on the general kernels where no fast one serves the shape)
-    PackTable(rt, op.pack_jobs(S, S), 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
+    op.segment_fwd = True
+    fwd9 = [j for j in op.full.pack_jobs(S, S) if j['mmap'] is op.full.out_map]       # + the 9-tap forward matrix (first fprop below)
+    PackTable(rt, op.pack_jobs(S, S, N) + fwd9, 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
     cat = View.alloc(rt, N, S, S, Cup + Csp)
     cat.dense()[..., :Cu] = F.interpolate(u, scale_factor=2, mode='nearest').permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
     cat.dense()[..., Cup:Cup + Cs] = sk.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
@@ -1058,8 +1060,18 @@ def test_upcat_segmented_backward_vs_torch(shape):
     dyv = View.alloc(rt, N, S, S, op.Cop)
     dyv.dense()[..., :Co] = dy.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
     yv = View.alloc(rt, N, S, S, op.Cop)
-    op.fprop(cat, yv)
+    op.fprop(cat, yv)                                  # (no low-resolution tensor bound yet: the one 9-tap launch)
     op.bind_up(uv, duv)
+    yseg, stats = None, None
+    if op.fwd_segmented(N, S, S, op.Cop):
+        # forward by segment: skip segment's 9-tap launch, then the upsampled segment added on the low-resolution tensor
+        yseg = View.alloc(rt, N, S, S, op.Cop)
+        yseg.t.fill_(3.0)
+        stats = rt.zeros((16, 2, op.Cop), torch.float64)
+        cat_noup = View.alloc(rt, N, S, S, Cup + Csp)          # the upsampled copy is NOT read: leave it as garbage
+        cat_noup.t.fill_(5.0)
+        cat_noup.dense()[..., Cup:] = cat.dense()[..., Cup:]
+        op.fprop(cat_noup, yseg, stats)
     op.dgrad(dyv, dcat)
     gw = torch.zeros_like(wd)
     op.wgrad(cat, dyv, gw, unpack=False)
@@ -1079,6 +1091,13 @@ def test_upcat_segmented_backward_vs_torch(shape):
     yr.backward(dy)
     name = 'x'.join(map(str, shape))
     check(name + ' y', yv.dense().float().cpu()[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+    if yseg is not None:
+        ys = yseg.dense().float().cpu()
+        check(name + ' y by segment', ys[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+        st = stats.sum(0).cpu()
+        yd = ys[..., :Co].double()
+        np.testing.assert_allclose(st[0, :Co].numpy(), yd.sum((0, 1, 2)).numpy(), rtol=1e-6, atol=1e-3)
+        np.testing.assert_allclose(st[1, :Co].numpy(), (yd * yd).sum((0, 1, 2)).numpy(), rtol=1e-6)
     check(name + ' d skip', dcat.dense().float().cpu()[..., Cup:Cup + Cs].permute(0, 3, 1, 2), skr.grad, 'bf16')
     check(name + ' d u (low resolution)', duv.dense().float().cpu()[..., :Cu].permute(0, 3, 1, 2), ur.grad, 'bf16')
     assert Cup == Cu or float(duv.dense()[..., Cu:].abs().max()) == 0.0

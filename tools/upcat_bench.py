@@ -61,8 +61,11 @@ def main():
         y = View.alloc(rt, N, S, S, Co)
         gw = torch.zeros_like(w)
         seg.bind_up(u, du)
+        fseg = seg.fwd_segmented(N, S, S, Co)
         res = {
             'fprop 9-tap': timed(lambda: plain.fprop(cat, y), args.reps),
+            'fprop skip': timed(lambda: seg.skip.fprop(cat.slice(Cu, Cs), y, None), args.reps),
+            'fprop up': timed(lambda: seg.up.fprop_acc(u, y, None), args.reps) if fseg else float('nan'),
             'dgrad 9-tap': timed(lambda: plain.dgrad(dy, dcat), args.reps),
             'dgrad skip': timed(lambda: seg.skip.dgrad(dy, dcat.slice(Cu, Cs)), args.reps),
             'dgrad up': timed(lambda: seg.up.dgrad(dy, du), args.reps),
