@@ -33,6 +33,7 @@ struct FdArgs {
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
     int NCHP;             // plane gather (WsCfg::UPD): 64-channel chunks per source plane (NCH = 4 * NCHP)
+    int P32;              // plane gather with 32-channel planes: a K chunk = two planes (halves of every LDS row)
     int RPS;              // 2 x 2-window forms: store rows of the previous tile carried per step (1 or 2)
     int NTLR, CoW;        // phase forward (WsCfg::UPF): channel tiles per phase (NTL = 4 * NTLR), weight rows per phase
     // fused BatchNorm-backward reduction in the epilogue of a DATA-GRADIENT launch (segnb_conv_fprop_bnreduce): the output

@@ -201,18 +201,37 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         if (wfetch) {
             // ---- loader-side per-lane constants --------------------------------------------------------------------
             unsigned b_voff[BPW];
+            unsigned b_sec = 0;      // (P32) bit pb: this lane's slot of piece pb holds the chunk's SECOND plane
         #pragma unroll
             for (int pb = 0; pb < BPW; ++pb) {
                 const int row = ((lw & 1) * BPW + pb) * 8 + (lane >> 3);
                 const int q = lane & 7;
+                b_sec |= (unsigned)(((q ^ ((row >> 1) & 7)) >> 2) & 1) << pb;
                 const int co = n_base + row;
                 b_voff[pb] = co < a.Co ? (unsigned)(w_row0 + row) * (unsigned)a.Ktot * 2u + (unsigned)((q ^ ((row >> 1) & 7)) * 16) : OOB;
+                if constexpr (C::UPD)
+                    if (a.P32 && co < a.Co)      // 32-channel planes: the row's K slots 0..3 / 4..7 belong to two planes (below)
+                        b_voff[pb] = (unsigned)(w_row0 + row) * (unsigned)a.Ktot * 2u + (unsigned)(((q ^ ((row >> 1) & 7)) & 3) * 16);
             }
+
             auto fetch_b = [&](int c, int t, int stage) {
                 unsigned soff;
                 if constexpr (C::UPD) {
                     // chunk c = (plane, 64-channel slice); tap (ta, tb) of plane (py, px) is tap (2 ta - py + 1, 2 tb - px + 1)
                     // of the 4 x 4 kernel (row-major tap list of segnb.convplan.convt_dgrad)
+                    if (a.P32) {
+                        // a chunk = planes 2 c and 2 c + 1, 32 channels each: the two halves of a weight row come from two taps of
+                        // the 4 x 4 kernel -- a per-lane offset instead of the scalar one
+                        const int pa_ = 2 * c, pb_ = 2 * c + 1;
+                        const int ta = (2 * (t >> 1) - (pa_ >> 1) + 1) * 4 + (2 * (t & 1) - (pa_ & 1) + 1);
+                        const int tb = (2 * (t >> 1) - (pb_ >> 1) + 1) * 4 + (2 * (t & 1) - (pb_ & 1) + 1);
+        #pragma unroll
+                        for (int pb = 0; pb < BPW; ++pb) {
+                            const unsigned off = (unsigned)(((b_sec >> pb & 1u) ? tb : ta) * 32) * 2u;
+                            dma16(lds0 + C::OFF_B + stage * C::B_STAGE + ((lw & 1) * BPW + pb) * 1024, b_voff[pb] + off, rs_w, 0u);
+                        }
+                        return;
+                    }
                     const int pl = c / a.NCHP, sl = c - pl * a.NCHP;
                     const int t16 = (2 * (t >> 1) - (pl >> 1) + 1) * 4 + (2 * (t & 1) - (pl & 1) + 1);
                     soff = (unsigned)(t16 * a.Ci + sl * 64) * 2u;
@@ -265,6 +284,9 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 const int key = C::XC % 2 == 0 ? xc : pix;        // swizzle key (see a_rd below)
                 a_rel[pa] = (unsigned)((xr * a.Wi + xc) * (C::UPD ? 2 : 1)) * (unsigned)a.ld_x * 2u +
                             (unsigned)((q ^ ((key >> 1) & 7)) * 16);
+                if constexpr (C::UPD)
+                    if (a.P32)       // 32-channel planes: slots 0..3 / 4..7 of a halo row come from the chunk's first / second plane
+                        a_rel[pa] = (unsigned)((xr * a.Wi + xc) * 2) * (unsigned)a.ld_x * 2u + (unsigned)(((q ^ ((key >> 1) & 7)) & 3) * 16);
                 a_xy[pa] = pix < C::NPIX ? (unsigned)xr | ((unsigned)xc << 16) : 0x7fff7fffu;      // never inside the image
             }
             auto set_fetch_tile = [&](int it, int table) {
@@ -316,6 +338,17 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                             a_voff[pl][pa] = ok ? base + a_rel[pa] : OOB;
                         }
                     });
+                    if (a.P32) {
+                        // chunk c reads plane 2 c in its first four slots and plane 2 c + 1 in the others: fold the four
+                        // plane sets into two per-chunk sets, lane by lane
+        #pragma unroll
+                        for (int pa = 0; pa < APW; ++pa) {
+                            const int xc = (int)(a_xy[pa] >> 16);
+                            const bool second = ((((int)lane & 7) ^ ((xc >> 1) & 7)) >> 2) != 0;
+                            a_voff[0][pa] = second ? a_voff[1][pa] : a_voff[0][pa];
+                            a_voff[1][pa] = second ? a_voff[3][pa] : a_voff[2][pa];
+                        }
+                    }
                 } else {
                 const int h0 = hb * R + (C::UPF ? py - 1 : a.dhmin), w0 = wb * WT + (C::UPF ? px - 1 : a.dwmin);
                 const unsigned base = (unsigned)(((n * a.Hi + h0) * a.Wi + w0) * a.ld_x * 2);
@@ -342,8 +375,13 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 int pl = 0;
                 unsigned soff = (unsigned)c * 128u;
                 if constexpr (C::UPD) {
-                    pl = c / a.NCHP;
-                    soff = (unsigned)(c - pl * a.NCHP) * 128u;
+                    if (a.P32) {
+                        pl = c;                  // (folded per-chunk sets, whole 32-channel planes: no slice offset)
+                        soff = 0u;
+                    } else {
+                        pl = c / a.NCHP;
+                        soff = (unsigned)(c - pl * a.NCHP) * 128u;
+                    }
                 }
                 auto go = [&](auto pl_c) {
                     constexpr int PL = decltype(pl_c)::value;
@@ -897,10 +935,11 @@ int launch_ws_upd(FdArgs& a, hipStream_t stream) {
     a.WB = (a.W + C::WT - 1) / C::WT;
     a.IT = a.N * a.HB * a.WB;
     a.NTL = (a.Co + C::BN - 1) / C::BN;
-    a.NCHP = a.Ci / 64;
-    a.NCH = 4 * a.NCHP;
-    a.RPS = 1;
-    if (a.NCH * C::NTAP - 1 < C::RPT) return NOT_HANDLED;       // the previous tile's store rows ride on steps 1..RPT
+    a.P32 = a.Ci == 32;
+    a.NCHP = a.P32 ? 1 : a.Ci / 64;
+    a.NCH = a.P32 ? 2 : 4 * a.NCHP;
+    a.RPS = a.NCH * C::NTAP - 1 < C::RPT ? 2 : 1;               // the previous tile's store rows ride on steps 1.., one or two each
+    if ((a.NCH * C::NTAP - 1) * a.RPS < C::RPT) return NOT_HANDLED;
     int gm = segnb_knob_conv_cus() / a.NTL;
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
@@ -926,6 +965,7 @@ int launch_ws_upf(FdArgs& a, hipStream_t stream) {
     a.NTL = 4 * a.NTLR;
     a.NCH = a.Ci / 64;
     a.NCHP = a.NCH;
+    a.P32 = 0;
     a.RPS = a.NCH * C::NTAP - 1 < C::RPT ? 2 : 1;               // store rows per step
     if ((a.NCH * C::NTAP - 1) * a.RPS < C::RPT) return NOT_HANDLED;
     int gm = segnb_knob_conv_cus() / a.NTL;
@@ -941,7 +981,7 @@ int launch_ws_upf(FdArgs& a, hipStream_t stream) {
 bool upd_geometry(const segnb_conv_geom* g) {
     if (g->ntaps != 16 || g->in_step != 2 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo) return false;
-    if (g->Ci % 64 != 0 || g->Co <= 32 || g->Wo < 12) return false;
+    if ((g->Ci % 64 != 0 && g->Ci != 32) || g->Co <= 32 || g->Wo < 12) return false;
     for (int t = 0; t < 16; ++t)
         if (g->dh[t] != t / 4 - 1 || g->dw[t] != t % 4 - 1) return false;
     return true;
