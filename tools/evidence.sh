@@ -4,7 +4,7 @@
 # Writes under gpurun_out/<tag>_*; the summaries that are judged are then copied into profiles/ (tools/evidence_collect.py).
 # rocprofv3: the python program directly after "--" (no env / bash -c hop), counters in passes of their own.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
@@ -21,6 +21,13 @@ for m in linknet34 fcdensenet103; do
   find $O/${TAG}_prof_$m -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_${m}_kernel_stats.csv
   rm -rf $O/${TAG}_prof_$m
 done
+# HBM traffic of the other model rows: the same two PMC passes per model
+for m in linknet34 fcdensenet103 unet16; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcf_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmcf_$m.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcw_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmcw_$m.log 2>&1
+  (cd $R && python3 tools/pmc_traffic.py $O/${TAG}_pmcf_$m $O/${TAG}_pmcw_$m $O/${TAG}_pmc_traffic_$m.json > $O/${TAG}_pmc_traffic_$m.log 2>&1)
+  rm -rf $O/${TAG}_pmcf_$m $O/${TAG}_pmcw_$m
+done
 cd $R
 python3 tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
 python3 tools/pmc_summary.py $O/${TAG}_pmc_sq1 conv_ > $O/${TAG}_pmc_conv_issue_wait.txt 2>&1
@@ -29,6 +36,10 @@ find $O/${TAG}_prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {}
 python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
 python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
+python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_trace.log 2>&1)
+python3 tools/trace_step.py $O/${TAG}_trace 12 list > $O/${TAG}_step_trace.txt 2>&1
+rm -rf $O/${TAG}_trace
 python3 tools/insitu.py > $O/${TAG}_insitu.txt 2>&1
 python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
 python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
