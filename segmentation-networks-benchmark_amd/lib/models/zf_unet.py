@@ -290,8 +290,14 @@ class _ZFUnetPlan(object):
             unpacks[gi].run()
         hook = getattr(self.module, '_grad_ready_hook', None)
         if hook is not None and gi < 2:
-            self._plan_cut(('ready', gi, side is not None))      # a recorded launch list is cut where the hook runs
-            hook(self.flat, los[gi], (side,) if side is not None else ())
+            # a recorded launch list is cut where the hook runs, and the hook itself runs OUTSIDE the recording: what it
+            # launches (the optimizer update of a bucket behind its all-reduce, DataParallel.fuse_optimizer) is issued by the
+            # live hook of every step -- recorded as well, a replay applied those updates twice
+            self._plan_cut(('ready', gi, side is not None), resume=False)
+            try:
+                hook(self.flat, los[gi], (side,) if side is not None else ())
+            finally:
+                self._plan_resume()
 
     _last_N = None
 
@@ -360,10 +366,19 @@ class _ZFUnetPlan(object):
         self._rec = []
         nv.plan_record_begin()
 
-    def _plan_cut(self, mark):
+    def _plan_cut(self, mark, resume=True):
         if self._rec is not None:
             handle, nops = nv.plan_record_end()
             self._rec.append((handle, nops, mark))
+            self._paused = not resume
+            if resume:
+                nv.plan_record_begin()
+
+    _paused = False
+
+    def _plan_resume(self):
+        if self._rec is not None and self._paused:
+            self._paused = False
             nv.plan_record_begin()
 
     def _plan_end(self, ckey):
@@ -382,7 +397,9 @@ class _ZFUnetPlan(object):
         if self._rec is None:
             return
         segs, self._rec = self._rec, None
-        nv.plan_record_abort()
+        if not self._paused:
+            nv.plan_record_abort()
+        self._paused = False
         for h, _, _ in segs:
             if h is not None:
                 try:

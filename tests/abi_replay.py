@@ -113,6 +113,10 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
     self-test of this harness that runs without a GPU)."""
     rec = _Recorder()
     orig_ptr, orig_call, orig_vptr = nv.ptr, nv.call, E.View.ptr
+    # the decoder blocks' data gradient by segment on BOTH sides (the device would segment only the sizes its fast kernel
+    # serves, the emulator every size: the two call sequences must be the same)
+    orig_force = E.UpCatConvOp.force_segmented
+    E.UpCatConvOp.force_segmented = True
 
     def ptr(t, offset_elems=0):
         rec.reg(t)
@@ -195,6 +199,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
     finally:
         nv.set_backend_for_testing(None)
         nv.ptr, nv.call, E.View.ptr = orig_ptr, orig_call, orig_vptr
+        E.UpCatConvOp.force_segmented = orig_force
         E.Runtime.overlap_wgrad = overlap
         _zf._ZFUnetPlan.use_cplan = cplan
         _net.HipNet.use_cplan = cplan_net

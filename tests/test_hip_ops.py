@@ -982,12 +982,13 @@ def test_conv_full_size_vs_torch(shape, wg_cu_pct):
 
 @pytest.mark.parametrize('shape', [(32, 224, 224, 3, 32, 1), (2, 40, 56, 3, 32, 2), (3, 33, 47, 8, 24, 1), (2, 64, 64, 32, 32, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
-def test_conv_wgrad_with_recomputed_bn_apply(shape):
+def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
     """segnb_conv_wgrad_bnapply: the weight gradient of a layer whose dy operand -- the BatchNorm-backward apply of
     (g, y), lib/modules/abn/functions.py:118 -- is recomputed while the tiles are staged (first layer of the network: the
     apply pass disappears) == segnb_bn_bwd_apply_direct followed by segnb_conv_wgrad, bit for bit; incl. the first layer
     of the timed configuration (bs=32 224x224, 3 -> 32)."""
     N, H, W, Ci, Co, act = shape
+    monkeypatch.setenv('SEGNB_WGRAD_BNAPPLY', '1')     # (off by default: measured neutral in the training step)
     rt = Runtime('cuda', 'bf16')
     gen = torch.Generator().manual_seed(H * 3 + Co)
     w = torch.randn(Co, Ci, 3, 3, generator=gen).cuda()

@@ -573,7 +573,8 @@ def test_bench_runs_over_rccl_single_rank():
         assert res['launch_plan'] == (cplan[0] == '1')
         assert res['optimizer_in_allreduce_epilogue'] == ('fused' in cplan)
         losses[cplan] = res['final_loss']
-    assert abs(losses['1'] - losses['0']) <= 2e-4 and abs(losses['1 fused'] - losses['0']) <= 2e-4
+    # the three launch modes run the same arithmetic in the same order: the same loss, bit for bit
+    assert losses['1'] == losses['0'] == losses['1 fused'], losses
 
 
 def test_bench_executor_model_over_rccl_single_rank():
