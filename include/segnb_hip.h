@@ -350,6 +350,26 @@ int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
  * decoder block (segnb.engine.UpCatConvOp). */
 int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype);
 
+/* VIRTUAL CONCAT.  The first convolution of a ZF_UNET decoder block reads torch.cat([Upsample(scale_factor=2)(u), skip], 1)
+ * (lib/models/zf_unet.py:42,78-90).  These entry points take the two tensors as they are: the first src->Cu input channels of
+ * the geometry are the NEAREST x2 upsample of src->u [N][Hi/2][Wi/2][ld_u] -- input pixel (h, w) of those channels is u pixel
+ * (h >> 1, w >> 1), resolved in the kernels' tile fetch -- and the remaining g->Ci - Cu channels come from `in`
+ * ([N][Hi][Wi][ld_in], the skip tensor, channel 0 = logical channel Cu).  The upsampled copy (4x the size of u) is never
+ * written or read.  Same weights / workspace layouts as segnb_conv_fprop / segnb_conv_wgrad over the concatenated input.
+ * segnb_conv_upcat_ok: 1 if BOTH are served for the geometry (bf16, stride-1 3x3, even Hi / Wi; Cu a multiple of the
+ * kernels' channel chunk); otherwise the caller materialises the upsampled copy and uses the plain entry points. */
+typedef struct {
+    const void* u;
+    int Cu;
+    int ld_u;
+} segnb_upcat_src;
+int segnb_conv_upcat_ok(const segnb_conv_geom* g, int dtype, int Cu);
+int segnb_conv_fprop_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
+                           const void* wpacked, const float* bias, int bias_n, void* out, double* stats,
+                           segnb_stream_t stream);
+int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
+                           const void* dout, float* dwp, int nslab, segnb_stream_t stream);
+
 /* The FORWARD of such a segment on the low-resolution tensor u [N][H][W][Ci], ADDED to out [N][2H][2W][Co]:
  *     out[n, 2Y + py, 2X + px, :] += sum_{a, b < 2} u[n, Y + py - 1 + a, X + px - 1 + b, :] . W[py, px][:, (a, b), :]
  * = conv3x3(pad 1)(Upsample(scale_factor=2)(u)) (lib/models/zf_unet.py:42,78-90) through the ConvTranspose2d(4, 2, 1)

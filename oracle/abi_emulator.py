@@ -149,6 +149,31 @@ class AbiEmulator(object):
 
     # ---- data gradient + the BatchNorm-backward reduction of its output's producer (segnb_conv_fprop_bnreduce) = the two
     # separate entry points, composed
+    # ---- virtual concat: cat([Upsample x2(u), skip]) materialised here, then the plain entry point
+    def segnb_conv_upcat_ok(self, g, dtype, Cu):
+        g = _geom(g)
+        return int(g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.Hi % 2 == 0 and g.Wi % 2 == 0 and 0 < Cu < g.Ci)
+
+    def _upcat(self, g, dtype, in_p, src):
+        gg, sc = _geom(g), _geom(src)
+        dt = _tdt(dtype)
+        Cs = gg.Ci - sc.Cu
+        U = _nhwc(sc.u, gg.N, gg.Hi // 2, gg.Wi // 2, sc.Cu, sc.ld_u, dt)
+        S = _nhwc(in_p, gg.N, gg.Hi, gg.Wi, Cs, gg.ld_in, dt)
+        cat = torch.cat([U.repeat_interleave(2, 1).repeat_interleave(2, 2), S], 3).contiguous()
+        g2 = type(gg)()
+        ctypes.memmove(ctypes.addressof(g2), ctypes.addressof(gg), ctypes.sizeof(gg))
+        g2.ld_in = gg.Ci
+        return g2, cat
+
+    def segnb_conv_fprop_upcat(self, g, dtype, in_p, src, wp, bias, bias_n, out_p, stats, stream):
+        g2, cat = self._upcat(g, dtype, in_p, src)
+        return self.segnb_conv_fprop(g2, dtype, cat.data_ptr(), wp, bias, bias_n, out_p, stats, stream)
+
+    def segnb_conv_wgrad_upcat(self, g, dtype, in_p, src, dout_p, dwp, nslab, stream):
+        g2, cat = self._upcat(g, dtype, in_p, src)
+        return self.segnb_conv_wgrad(g2, dtype, cat.data_ptr(), dout_p, dwp, nslab, stream)
+
     def segnb_upconv_fprop_acc_ok(self, N, H, W, Ci, Co, ld_out, dtype):
         return 1                                            # (every shape: the segmented forward plan is exercised)
 

@@ -62,6 +62,9 @@ inline const segnb_loss_spec* segnb_plan_keep(const segnb_loss_spec* g) {
 inline const segnb_bn_reduce_epilogue* segnb_plan_keep(const segnb_bn_reduce_epilogue* g) {
     return g ? (const segnb_bn_reduce_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
+inline const segnb_upcat_src* segnb_plan_keep(const segnb_upcat_src* g) {
+    return g ? (const segnb_upcat_src*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
 inline const segnb_act_epilogue* segnb_plan_keep(const segnb_act_epilogue* g) {
     return g ? (const segnb_act_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
@@ -101,12 +104,12 @@ int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpa
 // direct-to-LDS pipeline for Ci % 64 == 0 (fprop_dma.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                        hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
+                        hipStream_t stream, const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr);
 // resident-weights pipeline for the thin layers, Ci <= 96 and Co <= 96 (fprop_rw.hip)
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                        hipStream_t stream, const segnb_bn_reduce_epilogue* bn = nullptr,
-                       const segnb_act_epilogue* ep = nullptr);
+                       const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
@@ -125,7 +128,8 @@ struct segnb_wgrad_bnapply {
     float slope;
 };
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr);      // partial: leave the nslab slabs unreduced
+                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr,
+                       const segnb_upcat_src* uc = nullptr);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 
 // ------------------------------------------------------------------------------------------------

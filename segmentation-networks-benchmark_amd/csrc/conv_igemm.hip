@@ -1343,6 +1343,64 @@ extern "C" int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, in
     return rc;
 }
 
+// ---- virtual concat: cat([Upsample x2(u), skip]) read from the two tensors (include/segnb_hip.h)
+static bool wgrad_general_only();
+static bool upcat_geom_ok(const segnb_conv_geom* g, int dtype, int Cu) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || getenv("SEGNB_FPROP_GENERAL") != nullptr || wgrad_general_only()) return false;
+    if (!segnb_knob_fprop_dma() || g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
+    if (g->QH != g->Ho || g->QW != g->Wo || (g->Hi & 1) || (g->Wi & 1) || g->Hi != g->Ho || g->Wi != g->Wo || g->Wo < 12) return false;
+    if (Cu <= 0 || Cu >= g->Ci) return false;
+    const bool thin = g->Ci % 32 == 0 && g->Ci <= 96 && g->Co <= 64 && Cu % 32 == 0 && segnb_knob_fprop_rw();      // fprop_rw.hip
+    const bool wide = g->Ci % 64 == 0 && Cu % 64 == 0 && g->Co > 32;                                                  // fprop_dma.hip
+    if (!thin && !wide) return false;
+    return segnb_wgrad_s1_slabs(g) > 0;
+}
+
+extern "C" int segnb_conv_upcat_ok(const segnb_conv_geom* g, int dtype, int Cu) { return upcat_geom_ok(g, dtype, Cu) ? 1 : 0; }
+
+extern "C" int segnb_conv_fprop_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
+                                      const void* wpacked, const float* bias, int bias_n, void* out, double* stats,
+                                      segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_upcat, g, dtype, in, src, wpacked, bias, bias_n, out, stats, stream);
+    SEGNB_CHECK_ARG(in && src && src->u && wpacked && out, "NULL tensor");
+    SEGNB_CHECK_ARG(upcat_geom_ok(g, dtype, src->Cu), "geometry not served (segnb_conv_upcat_ok)");
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + (g->Ci - src->Cu)) * 2;
+    const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    int rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
+                                nullptr, nullptr, src);
+    if (rc == 0)
+        rc = segnb_fprop_dma_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
+                                 nullptr, src);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_conv_fprop_upcat: no kernel for this geometry");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
+extern "C" int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
+                                      const void* dout, float* dwp, int nslab, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_wgrad_upcat, g, dtype, in, src, dout, dwp, nslab, stream);
+    SEGNB_CHECK_ARG(in && src && src->u && dout && dwp, "NULL tensor");
+    SEGNB_CHECK_ARG(upcat_geom_ok(g, dtype, src->Cu), "geometry not served (segnb_conv_upcat_ok)");
+    SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
+    const int rc = segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, nullptr, src);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_conv_wgrad_upcat: no kernel for this geometry");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
 extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype) {
     if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g)) return 0;
     if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || !segnb_knob_bnreduce_fused()) return 0;

@@ -33,6 +33,12 @@ struct FdArgs {
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
     int NCHP;             // plane gather (WsCfg::UPD): 64-channel chunks per source plane (NCH = 4 * NCHP)
+    // virtual concat (segnb_conv_fprop_upcat): the first NCHU channel chunks of the input are the nearest-x2 upsample of
+    // u [N][Hi/2][Wi/2][ld_u] -- halo pixel (hi, wi) is fetched from u pixel (hi >> 1, wi >> 1) -- the others come from x
+    // (the skip tensor); the upsampled copy is never materialised (lib/models/zf_unet.py:42,78-90).  u == NULL: off
+    const bf16_t* u;
+    unsigned u_bytes;
+    int ld_u, NCHU, Hu, Wu;
     int P32;              // plane gather with 32-channel planes: a K chunk = two planes (halves of every LDS row)
     int RPS;              // 2 x 2-window forms: store rows of the previous tile carried per step (1 or 2)
     int NTLR, CoW;        // phase forward (WsCfg::UPF): channel tiles per phase (NTL = 4 * NTLR), weight rows per phase

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 
     const i32x4_t rs_x = make_rsrc4(a.x, a.x_bytes);
     const i32x4_t rs_w = make_rsrc4(a.w, a.w_bytes);
+    const i32x4_t rs_u = make_rsrc4(a.u != nullptr ? a.u : a.x, a.u != nullptr ? a.u_bytes : a.x_bytes);
 
     float* sScale = reinterpret_cast<float*>(smem + C::OFF_SCALE);
     for (int c = tid; c < BN; c += NT) {
@@ -276,6 +277,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             // tile stalled every wave of the block ~1800 cycles at the tile's last chunk: in-kernel stamps, tools/stamps.py).
             // The same call writes the tile's output pixel table (read by the store rows one tile later).
             unsigned a_rel[APW], a_xy[APW], a_voff[C::NPL][APW];
+            unsigned a_uoff[APW];         // virtual concat: the same halo pixels in the low-resolution tensor u
+            const bool vcat = a.u != nullptr;
         #pragma unroll
             for (int pa = 0; pa < APW; ++pa) {
                 const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
@@ -358,6 +361,13 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     const int hi = h0 + (int)(a_xy[pa] & 0xffffu), wi = w0 + (int)(a_xy[pa] >> 16);
                     const bool ok = (unsigned)hi < hlim && (unsigned)wi < (unsigned)a.Wi;
                     a_voff[0][pa] = ok ? base + a_rel[pa] : OOB;
+                    if (vcat) {      // nearest-x2 upsample = the pixel (hi >> 1, wi >> 1) of u, same channel slot
+                        const int pixl = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
+                        const int keyl = C::XC % 2 == 0 ? pixl % XC : pixl;
+                        a_uoff[pa] = ok ? (unsigned)((n * a.Hu + (hi >> 1)) * a.Wu + (wi >> 1)) * (unsigned)a.ld_u * 2u +
+                                              (unsigned)(((lane & 7) ^ ((keyl >> 1) & 7)) * 16)
+                                        : OOB;
+                    }
                 }
                 }
                 // output pixel of tile rows (-1 = outside the image): 128 halo-wave threads, BM / 128 rows each
@@ -381,6 +391,22 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     } else {
                         pl = c / a.NCHP;
                         soff = (unsigned)(c - pl * a.NCHP) * 128u;
+                    }
+                }
+                if constexpr (!C::UPD && !C::UPF && !C::TALL) {
+                    if (vcat) {
+                        if (c < a.NCHU) {           // a chunk of the (virtually) upsampled segment: fetched from u
+        #pragma unroll
+                            for (int pa = 0; pa < APW; ++pa) {
+                                if (pa >= p0 && pa < p1) {
+                                    const int piece = (lw & 1) + C::NAW * pa;
+                                    const unsigned dst = piece < C::APIECES ? lds0 + buf * C::A_BYTES + piece * 1024 : lds0 + C::OFF_DUMMY;
+                                    dma16(dst, a_uoff[pa], rs_u, (unsigned)c * 128u);
+                                }
+                            }
+                            return;
+                        }
+                        soff = (unsigned)(c - a.NCHU) * 128u;      // skip segment: x holds its channels from 0
                     }
                 }
                 auto go = [&](auto pl_c) {
@@ -1080,6 +1106,7 @@ int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, 
     a.dh[2] = a.dh[3] = 1;
     a.dw[1] = a.dw[3] = 1;
     a.dbg = 0;
+    a.u = nullptr;
     a.bn_y = nullptr;
     a.ep_act = -1;
     a.ep_coef = nullptr;
@@ -1112,7 +1139,7 @@ int segnb_fprop_dma_read_stamps(unsigned long long* host_dst) {
 // 1 = handled, 0 = not applicable (caller falls through to fprop_s1 / the general gather kernel), else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                        hipStream_t stream, const segnb_act_epilogue* ep) {
+                        hipStream_t stream, const segnb_act_epilogue* ep, const segnb_upcat_src* uc) {
     if (!segnb_knob_fprop_dma()) return 0;
     if (g->ntaps == 16 && ep == nullptr && stats == nullptr && bias == nullptr && segnb_knob_fprop_upd()) {
         FdArgs a;
@@ -1130,6 +1157,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         if (ob >= (1ll << 31)) return 0;
         a.out_bytes = (unsigned)ob;
         a.dbg = 0;
+        a.u = nullptr;
         a.bn_y = nullptr;
         a.ep_act = -1;
         a.ep_coef = nullptr;
@@ -1171,6 +1199,19 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.u = nullptr;
+    if (uc != nullptr) {
+        // virtual concat: in = the skip tensor (channels Cu.. of the logical input), uc->u = the low-resolution tensor
+        if (uc->Cu % 64 != 0 || uc->Cu <= 0 || uc->Cu >= g->Ci || (g->Hi & 1) || (g->Wi & 1) || g->Wo <= 8) return 0;
+        a.u = (const bf16_t*)uc->u;
+        a.ld_u = uc->ld_u;
+        a.NCHU = uc->Cu / 64;
+        a.Hu = g->Hi / 2;
+        a.Wu = g->Wi / 2;
+        const long long ub = (((long long)g->N * a.Hu * a.Wu - 1) * uc->ld_u + uc->Cu) * 2;
+        if (ub >= (1ll << 31)) return 0;
+        a.u_bytes = (unsigned)ub;
+    }
     a.bn_y = nullptr;
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
 
     const i32x4_t rs_x = make_rsrc4(a.x, a.x_bytes);
     const i32x4_t rs_w = make_rsrc4(a.w, a.w_bytes);
+    const i32x4_t rs_u = make_rsrc4(a.u != nullptr ? a.u : a.x, a.u != nullptr ? a.u_bytes : a.x_bytes);
 
     float* sScale = reinterpret_cast<float*>(smem + C::OFF_SCALE);
     for (int c = tid; c < BN; c += C::NT) {
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
         // the four border compares remain (recomputing pix / XC etc. per tile cost the fetch waves ~2000 cycles per
         // tile: more than the tile's MFMAs on the 32-channel layers).
         unsigned a_rel[APW], a_xy[APW], a_voff[APW];
+        unsigned a_uoff[APW];             // virtual concat (FdArgs::u): the same halo pixels in the low-resolution tensor
+        const bool vcat = a.u != nullptr;
 #pragma unroll
         for (int pa = 0; pa < APW; ++pa) {
             const int pix = (lw + NLW * pa) * 16 + (lane >> 2);
@@ -137,6 +140,12 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
                 const int hi = h0 + (int)(a_xy[pa] & 0xffffu), wi = w0 + (int)(a_xy[pa] >> 16);
                 const bool ok = (unsigned)hi < hlim && (unsigned)wi < (unsigned)a.Wi;
                 a_voff[pa] = ok ? base + a_rel[pa] : OOB;
+                if (vcat) {          // nearest-x2 upsample = pixel (hi >> 1, wi >> 1) of u, same channel slot
+                    const int pixl = (lw + NLW * pa) * 16 + (lane >> 2);
+                    a_uoff[pa] = ok ? (unsigned)((n * a.Hu + (hi >> 1)) * a.Wu + (wi >> 1)) * (unsigned)a.ld_u * 2u +
+                                          (unsigned)(((lane & 3) ^ ((pixl >> 2) & 3)) * 16)
+                                    : OOB;
+                }
             }
         };
         auto fetch_a = [&](int c, int stage) {
@@ -144,6 +153,11 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
             for (int pa = 0; pa < APW; ++pa) {
                 const int piece = lw + NLW * pa;
                 const unsigned dst = piece < C::APIECES ? lds0 + stage * C::A_STAGE + piece * 1024 : lds0 + C::OFF_DUMMY;
+                if (vcat) {          // chunks 0 .. NCHU-1 from u (upsampled on the way), the others from x = the skip tensor
+                    if (c < a.NCHU) dma16(dst, a_uoff[pa], rs_u, (unsigned)c * 64u);
+                    else dma16(dst, a_voff[pa], rs_x, (unsigned)(c - a.NCHU) * 64u);
+                    continue;
+                }
                 if (!(DBG && (a.dbg & 2))) dma16(dst, a_voff[pa], rs_x, (unsigned)c * 64u);
             }
         };
@@ -467,7 +481,8 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn, const segnb_act_epilogue* ep) {
+                       hipStream_t stream, const segnb_bn_reduce_epilogue* bn, const segnb_act_epilogue* ep,
+                       const segnb_upcat_src* uc) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_rw()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 96 || g->Wo < 12) return 0;
@@ -503,6 +518,19 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.u = nullptr;
+    if (uc != nullptr) {
+        // virtual concat: `in` = the skip tensor (logical channels Cu..), uc->u = the tensor the first Cu channels are upsampled from
+        if (uc->Cu % 32 != 0 || uc->Cu <= 0 || uc->Cu >= g->Ci || (g->Hi & 1) || (g->Wi & 1) || a.dbg) return 0;
+        a.u = (const bf16_t*)uc->u;
+        a.ld_u = uc->ld_u;
+        a.NCHU = uc->Cu / 32;
+        a.Hu = g->Hi / 2;
+        a.Wu = g->Wi / 2;
+        const long long ub = (((long long)g->N * a.Hu * a.Wu - 1) * uc->ld_u + uc->Cu) * 2;
+        if (ub >= (1ll << 31)) return 0;
+        a.u_bytes = (unsigned)ub;
+    }
     a.bn_y = nullptr;
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;

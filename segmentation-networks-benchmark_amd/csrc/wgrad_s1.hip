@@ -86,6 +86,10 @@ struct WgS1Args {
     long long slab_stride;  // floats between the partial slabs of consecutive pixel splits
     int Ktot;               // 9 * Ci
     segnb_wgrad_bnapply bna;    // BNA instantiations: dy recomputed from (g, y) while staging (bna.g != NULL)
+    // virtual concat (segnb_conv_wgrad_upcat): input channels [0, Cu) are the nearest-x2 upsample of u [N][Hi/2][Wi/2][ld_u]
+    // -- x-tile pixel (hi, wi) of those channels is u pixel (hi >> 1, wi >> 1) -- channels Cu.. come from x (the skip tensor)
+    const bf16_t* u;            // NULL: off
+    int Cu, ld_u;
 };
 
 __device__ __forceinline__ float wg_round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
@@ -345,8 +349,12 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                 const int hi = q / TL::W2 + a.dhmin, wi = q % TL::W2 + a.dwmin;
                 const int ch = ci0 + cc * 8;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < XCH && n < a.N && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-                    v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + ch);
+                if (c < XCH && n < a.N && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
+                    if (a.u != nullptr && ch < a.Cu)
+                        v = *reinterpret_cast<const uint4*>(a.u + ((long long)(n * (a.Hi >> 1) + (hi >> 1)) * (a.Wi >> 1) + (wi >> 1)) * a.ld_u + ch);
+                    else
+                        v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + (ch - (a.u != nullptr ? a.Cu : 0)));
+                }
                 rx[u] = v;
             }
 #pragma unroll
@@ -376,8 +384,12 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
             const int hi = h0 + a.dhmin + xr, wi = w0 + a.dwmin + xc;
             const int ch = ci0 + cc * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < XCH && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-                v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + ch);
+            if (c < XCH && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
+                if (a.u != nullptr && ch < a.Cu)
+                    v = *reinterpret_cast<const uint4*>(a.u + ((long long)(n * (a.Hi >> 1) + (hi >> 1)) * (a.Wi >> 1) + (wi >> 1)) * a.ld_u + ch);
+                else
+                    v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + (ch - (a.u != nullptr ? a.Cu : 0)));
+            }
             rx[u] = v;
         }
 #pragma unroll
@@ -794,9 +806,10 @@ int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
 // returns 1 when the launch was handled here, 0 when the geometry is not a stride-1 3x3 bf16 case
 // (caller falls through to the general kernel), <0 / hipError on failure
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna) {
+                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna, const segnb_upcat_src* uc) {
     const S1Choice c = s1_choose(g);
     if (!c.cfg) return 0;
+    if (uc != nullptr && (uc->Cu % 8 != 0 || uc->Cu <= 0 || uc->Cu >= g->Ci || (g->Hi & 1) || (g->Wi & 1))) return 0;
     if (bna != nullptr && c.cfg != 1 && c.cfg != 6) return 0;      // (thin 32 x 32 tiles only)
     int dhmin = g->dh[0], dwmin = g->dw[0];
     for (int t = 1; t < 9; ++t) {
@@ -815,6 +828,9 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.Ktot = 9 * g->Ci;
+    a.u = uc != nullptr ? (const bf16_t*)uc->u : nullptr;
+    a.Cu = uc != nullptr ? uc->Cu : 0;
+    a.ld_u = uc != nullptr ? uc->ld_u : 0;
     a.bna = segnb_wgrad_bnapply{};
     int rc;
     if (bna != nullptr) {

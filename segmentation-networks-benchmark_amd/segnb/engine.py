@@ -662,14 +662,42 @@ class UpCatConvOp(object):
                                                self.rt.code))
         return v
 
+    # SEGNB_VCAT=0: the upsampled copy is materialised in the concat buffer (round-2 data flow)
+    virtual_concat = os.environ.get('SEGNB_VCAT', '1') != '0'
+
+    def virtual(self, N, H, W):
+        """VIRTUAL CONCAT at this size: the forward and the weight gradient (9 taps over all input channels, as before) read
+        the upsampled segment from the LOW-resolution tensor -- the kernels' tile fetch maps pixel (h, w) to u pixel
+        (h >> 1, w >> 1) (segnb_conv_fprop_upcat / segnb_conv_wgrad_upcat) -- so the upsampled copy, 4x the size of u, is
+        neither written (by the BatchNorm pass of the block below) nor read."""
+        if not self.virtual_concat:
+            return False
+        key = ('v', N, H, W)
+        v = self._seg.get(key)
+        if v is None:
+            p = self.full.plan(H, W)
+            g = self.full._geom(p, 'f', 0, p['fwd'][0], N, H, W, self.full.Cip, self.full.Cip, H, W, self.full.Cop, self.full.Cop)
+            v = self._seg[key] = bool(nv.query('segnb_conv_upcat_ok', g, self.rt.code, self.up_pad))
+        return v
+
     def reads_upsampled(self, N, H, W):
-        """Does anything still read the upsampled copy in the concat buffer at this size?  (the 9-tap forward or the 9-tap
-        weight gradient)"""
+        """Does anything still read the upsampled copy in the concat buffer at this size?  (the plain 9-tap forward or weight
+        gradient)"""
+        if self.virtual(N, H, W):
+            return False
         return not self.fwd_segmented(N, H, W) or not self.segment_wgrad
 
     def needs_low_res(self, N, H, W):
-        """Does anything read the low-resolution tensor itself?  (the segmented forward or the segmented weight gradient)"""
-        return self.fwd_segmented(N, H, W) or self.segment_wgrad
+        """Does anything read the low-resolution tensor itself?  (virtual concat, segmented forward or weight gradient)"""
+        return self.virtual(N, H, W) or self.fwd_segmented(N, H, W) or self.segment_wgrad
+
+    def _upcat_args(self, xv):
+        """(geometry of the whole 9-tap convolution over the logical concat, skip view, segnb_upcat_src)"""
+        p = self.full.plan(xv.H, xv.W)
+        l = p['fwd'][0]
+        sk = xv.slice(self.up_pad, self.sk_pad)
+        src = nv.UpcatSrc(self._u.ptr, self.up_pad, self._u.ld)
+        return p, l, sk, src
 
     _seg = None
     # thin output (<= 32 channels, the 224x224 level): the layer is HBM-bound on the 4x-sized upsampled gradient slice, and
@@ -685,6 +713,14 @@ class UpCatConvOp(object):
         return self.full.out_hw(Hi, Wi)
 
     def fprop(self, xv, yv, stats=None, epilogue=None):
+        if epilogue is None and self._u is not None and self.virtual(xv.N, xv.H, xv.W):
+            p, l, sk, src = self._upcat_args(xv)
+            g = self.full._geom(p, 'fv', 0, l, xv.N, xv.H, xv.W, self.full.Cip, sk.ld, yv.H, yv.W, self.full.Cop, yv.ld)
+            b = self.bias.detach() if self.bias is not None else None
+            _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_fprop_upcat', g, self.rt.code, sk.ptr, src, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
+                                   self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), self.rt.stream))
+            return
         if epilogue is None and self._u is not None and self.fwd_segmented(xv.N, xv.H, xv.W, yv.ld):
             # skip segment (with the bias) -> yv, then the upsampled segment added on the low-resolution tensor; the
             # BatchNorm statistics are taken by the second launch, on the sums
@@ -712,6 +748,14 @@ class UpCatConvOp(object):
         self.up.dgrad(dyv, self._du)
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
+        if not self.segment_wgrad and self._u is not None and self.virtual(xv.N, xv.H, xv.W):
+            assert not unpack
+            p, l, sk, src = self._upcat_args(xv)
+            g = self.full._geom(p, 'fv', 0, l, xv.N, xv.H, xv.W, self.full.Cip, sk.ld, dyv.H, dyv.W, self.full.Cop, dyv.ld)
+            _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_wgrad_upcat', g, self.rt.code, sk.ptr, src, dyv.ptr, nv.ptr(p['dwp'][0]),
+                                   p['nslab'][0], self.rt.stream))
+            return
         if not self.segment_wgrad:
             return self.full.wgrad(xv, dyv, grad_w, unpack)
         assert not unpack and self._u is not None, 'segmented weight gradients are unpacked by the batched table'
@@ -722,7 +766,7 @@ class UpCatConvOp(object):
     def pack_jobs(self, H, W, N=None):
         """N: the batch size the plan runs at (the fast-kernel query is per geometry); None = segmented wherever possible"""
         dseg = self.segmented(N, H, W) if N is not None else True
-        fseg = self.fwd_segmented(N, H, W) if N is not None else self.segment_fwd
+        fseg = (self.fwd_segmented(N, H, W) and not self.virtual(N, H, W)) if N is not None else self.segment_fwd
         full, skip, up = self.full.pack_jobs(H, W), self.skip.pack_jobs(H, W), self.up.pack_jobs(H // 2, W // 2)
 
         def pick(jobs, op, fwd):

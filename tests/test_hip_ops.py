@@ -1048,8 +1048,9 @@ def test_upcat_segmented_backward_vs_torch(shape):
     op.segment_wgrad = True                            # (instance overrides: both segmented paths are exercised here,
     op.force_segmented = True                          #  on the general kernels where no fast one serves the shape)
     op.segment_fwd = True
-    fwd9 = [j for j in op.full.pack_jobs(S, S) if j['mmap'] is op.full.out_map]       # + the 9-tap forward matrix (first fprop below)
-    PackTable(rt, op.pack_jobs(S, S, N) + fwd9, 'segnb_pack_weight_multi', 'segnb_pack_weight').run()
+    # every packed matrix of the three ops (the plan packs only what its mode at this size reads: UpCatConvOp.pack_jobs)
+    PackTable(rt, op.full.pack_jobs(S, S) + op.skip.pack_jobs(S, S) + op.up.pack_jobs(S // 2, S // 2),
+              'segnb_pack_weight_multi', 'segnb_pack_weight').run()
     cat = View.alloc(rt, N, S, S, Cup + Csp)
     cat.dense()[..., :Cu] = F.interpolate(u, scale_factor=2, mode='nearest').permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
     cat.dense()[..., Cup:Cup + Cs] = sk.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
@@ -1063,15 +1064,29 @@ def test_upcat_segmented_backward_vs_torch(shape):
     yv = View.alloc(rt, N, S, S, op.Cop)
     op.fprop(cat, yv)                                  # (no low-resolution tensor bound yet: the one 9-tap launch)
     op.bind_up(uv, duv)
+    cat_noup = View.alloc(rt, N, S, S, Cup + Csp)              # the upsampled copy is NOT read below: leave it as garbage
+    cat_noup.t.fill_(5.0)
+    cat_noup.dense()[..., Cup:] = cat.dense()[..., Cup:]
+    # (a) VIRTUAL CONCAT: the 9-tap forward / weight gradient reading the upsampled segment from the low-resolution tensor
+    yvirt, vstats, gwv = None, None, None
+    op.virtual_concat, op.segment_wgrad = True, False
+    op._seg.clear()
+    if op.virtual(N, S, S):
+        yvirt = View.alloc(rt, N, S, S, op.Cop)
+        yvirt.t.fill_(3.0)
+        vstats = rt.zeros((16, 2, op.Cop), torch.float64)
+        op.fprop(cat_noup, yvirt, vstats)
+        gwv = torch.zeros_like(wd)
+        op.wgrad(cat_noup, dyv, gwv, unpack=False)
+        PackTable(rt, op.full.unpack_jobs(S, S, gwv), 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad').run()
+    # (b) forward BY SEGMENT: the skip segment's 9-tap launch, then the upsampled segment added on the low-resolution tensor
+    op.virtual_concat, op.segment_wgrad = False, True
+    op._seg.clear()
     yseg, stats = None, None
     if op.fwd_segmented(N, S, S, op.Cop):
-        # forward by segment: skip segment's 9-tap launch, then the upsampled segment added on the low-resolution tensor
         yseg = View.alloc(rt, N, S, S, op.Cop)
         yseg.t.fill_(3.0)
         stats = rt.zeros((16, 2, op.Cop), torch.float64)
-        cat_noup = View.alloc(rt, N, S, S, Cup + Csp)          # the upsampled copy is NOT read: leave it as garbage
-        cat_noup.t.fill_(5.0)
-        cat_noup.dense()[..., Cup:] = cat.dense()[..., Cup:]
         op.fprop(cat_noup, yseg, stats)
     op.dgrad(dyv, dcat)
     gw = torch.zeros_like(wd)
@@ -1092,13 +1107,20 @@ def test_upcat_segmented_backward_vs_torch(shape):
     yr.backward(dy)
     name = 'x'.join(map(str, shape))
     check(name + ' y', yv.dense().float().cpu()[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
-    if yseg is not None:
-        ys = yseg.dense().float().cpu()
-        check(name + ' y by segment', ys[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
-        st = stats.sum(0).cpu()
+    for tag, yvw, stw in (('by segment', yseg, stats), ('virtual concat', yvirt, vstats)):
+        if yvw is None:
+            continue
+        ys = yvw.dense().float().cpu()
+        check(name + ' y ' + tag, ys[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+        st = stw.sum(0).cpu()
         yd = ys[..., :Co].double()
         np.testing.assert_allclose(st[0, :Co].numpy(), yd.sum((0, 1, 2)).numpy(), rtol=1e-6, atol=1e-3)
         np.testing.assert_allclose(st[1, :Co].numpy(), (yd * yd).sum((0, 1, 2)).numpy(), rtol=1e-6)
+    if yvirt is not None:
+        # the same launches on the same operands as the 9-tap convolution over the materialised concat: the same bits
+        assert torch.equal(yvirt.dense()[..., :Co], yv.dense()[..., :Co])
+        check(name + ' dw virtual concat', gwv.cpu(), wr.grad, 'f32')
+    assert yvirt is not None or S // 2 < 12 or (Cu % 32) or (Cs % 32), 'virtual concat not served at a decoder shape' 
     check(name + ' d skip', dcat.dense().float().cpu()[..., Cup:Cup + Cs].permute(0, 3, 1, 2), skr.grad, 'bf16')
     check(name + ' d u (low resolution)', duv.dense().float().cpu()[..., :Cu].permute(0, 3, 1, 2), ur.grad, 'bf16')
     assert Cup == Cu or float(duv.dense()[..., Cu:].abs().max()) == 0.0

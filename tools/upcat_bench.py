@@ -61,9 +61,16 @@ def main():
         y = View.alloc(rt, N, S, S, Co)
         gw = torch.zeros_like(w)
         seg.bind_up(u, du)
+        seg.segment_fwd = True
+        seg.virtual_concat, seg.segment_wgrad = True, False
+        virt = seg.virtual(N, S, S)
+        tv = (timed(lambda: seg.fprop(cat, y), args.reps), timed(lambda: seg.wgrad(cat, dy, gw, unpack=False), args.reps)) if virt else (float('nan'),) * 2
+        seg.virtual_concat = False
+        seg._seg.clear()
         fseg = seg.fwd_segmented(N, S, S, Co)
         res = {
             'fprop 9-tap': timed(lambda: plain.fprop(cat, y), args.reps),
+            'fprop virt': tv[0], 'wgrad virt': tv[1],
             'fprop skip': timed(lambda: seg.skip.fprop(cat.slice(Cu, Cs), y, None), args.reps),
             'fprop up': timed(lambda: seg.up.fprop_acc(u, y, None), args.reps) if fseg else float('nan'),
             'dgrad 9-tap': timed(lambda: plain.dgrad(dy, dcat), args.reps),
