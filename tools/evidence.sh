@@ -40,6 +40,11 @@ python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_trace.log 2>&1)
 python3 tools/trace_step.py $O/${TAG}_trace 12 list > $O/${TAG}_step_trace.txt 2>&1
 rm -rf $O/${TAG}_trace
+# the same step replayed from ONE HIP graph (where does the two-branch overlap go?)
+python3 bench.py --graph on --no-cpu-baseline --no-kernel-timer > $O/${TAG}_bench_graph.json 2>/dev/null
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/bench.py --graph on --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_trace_graph.log 2>&1)
+python3 tools/trace_step.py $O/${TAG}_trace_graph 4 list > $O/${TAG}_step_trace_graph.txt 2>&1
+rm -rf $O/${TAG}_trace_graph
 python3 tools/insitu.py > $O/${TAG}_insitu.txt 2>&1
 python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
 python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
