@@ -5,10 +5,12 @@
   predict_tiled (the data flow)            inria_submit.py:237-257
 
 Pinned against the reference (tests/golden/tiles.npz, made by tests/golden/make_golden.py importing lib/tiles.py):
-the pyramid weights, margins / crops of several image shapes and merge().  split() / cut_patch() call
-cv2.copyMakeBorder(BORDER_REFLECT101), cv2 is absent from this image, so the border mode is restated as
-numpy.pad(mode='reflect') (same definition: mirror without repeating the edge pixel) and is pinned only through the
-split -> merge identity: PARITY UNPINNED for the padded pixels themselves.
+the pyramid weights, margins / crops of several image shapes and merge(); and (round 3) against
+tests/golden/augment.npz -- the reference's own split() / cut_patch() (lib/tiles.py:98-135) and tta_d4_aug /
+tta_d4_deaug (lib/augmentations.py:476-511) run on non-symmetric arrays by make_golden.py gen_augment: tiles, patches and
+the D4 pair bit for bit.  One dependency stays restated there: cv2 is absent from the image, so the generator gives the
+reference's code a copyMakeBorder that is numpy.pad(mode='reflect') (BORDER_REFLECT101: mirror without repeating the edge
+pixel -- SURVEY 8c); what is pinned is the reference's margin / crop / indexing logic around it.
 """
 import math
 
