@@ -364,6 +364,15 @@ typedef struct {
     int ld_u;
 } segnb_upcat_src;
 int segnb_conv_upcat_ok(const segnb_conv_geom* g, int dtype, int Cu);
+/* The DATA GRADIENT of such a layer (geometry g: dy -> gradient of the concatenated input) with the Upsample(x2) backward
+ * fused into its store pass: the first dst->Cu output channels are not stored at this resolution -- every 2 x 2 window is
+ * summed (fp32 sum of the four bf16 values, rounded once: exactly what summing the stored slice afterwards computes) and
+ * written to dst->u [N][Ho/2][Wo/2][ld_u], the gradient of u; the remaining channels go to `out` as usual (channel
+ * offsets unchanged: out's first Cu channels are left untouched).  For the thin, HBM-bound level (<= 96 output channels,
+ * fprop_rw.hip): the multiply-adds are not what bounds it, the 4x-sized gradient slice is.  *_ok: 1 if served. */
+int segnb_conv_fprop_upsum_ok(const segnb_conv_geom* g, int dtype, int Cu);
+int segnb_conv_fprop_upsum(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,
+                           const segnb_upcat_src* dst, segnb_stream_t stream);
 int segnb_conv_fprop_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
                            const void* wpacked, const float* bias, int bias_n, void* out, double* stats,
                            segnb_stream_t stream);

@@ -174,6 +174,29 @@ class AbiEmulator(object):
         g2, cat = self._upcat(g, dtype, in_p, src)
         return self.segnb_conv_wgrad(g2, dtype, cat.data_ptr(), dout_p, dwp, nslab, stream)
 
+    # ---- data gradient with the Upsample(x2) backward in its store pass: the plain entry point into a scratch copy, then
+    # the first Cu channels leave as 2 x 2 sums of the STORED (rounded) values, the others as they are
+    def segnb_conv_fprop_upsum_ok(self, g, dtype, Cu):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo and
+                   g.Ho % 2 == 0 and g.Wo % 2 == 0 and g.Wo >= 12 and g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 96 and
+                   g.Co % 8 == 0 and Cu % 8 == 0 and 0 < Cu < g.Co)
+
+    def segnb_conv_fprop_upsum(self, g, dtype, in_p, wp, out_p, dst, stream):
+        gg, d = _geom(g), _geom(dst)
+        dt = _tdt(dtype)
+        full = torch.zeros(gg.N, gg.Ho, gg.Wo, gg.Co, dtype=dt)
+        g2 = type(gg)()
+        ctypes.memmove(ctypes.addressof(g2), ctypes.addressof(gg), ctypes.sizeof(gg))
+        g2.ld_out = gg.Co
+        self.segnb_conv_fprop(g2, dtype, in_p, wp, None, 0, full.data_ptr(), None, stream)
+        O = _nhwc(out_p, gg.N, gg.Ho, gg.Wo, gg.Co, gg.ld_out, dt)
+        O[..., d.Cu:] = full[..., d.Cu:]
+        DU = _nhwc(d.u, gg.N, gg.Ho // 2, gg.Wo // 2, d.Cu, d.ld_u, dt)
+        f = full[..., :d.Cu].float()
+        DU.copy_((((f[:, 0::2, 0::2] + f[:, 0::2, 1::2]) + f[:, 1::2, 0::2]) + f[:, 1::2, 1::2]).to(dt))
+        return 0
+
     def segnb_upconv_fprop_acc_ok(self, N, H, W, Ci, Co, ld_out, dtype):
         return 1                                            # (every shape: the segmented forward plan is exercised)
 

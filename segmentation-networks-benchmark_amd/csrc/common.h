@@ -109,7 +109,8 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                        hipStream_t stream, const segnb_bn_reduce_epilogue* bn = nullptr,
-                       const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr);
+                       const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr,
+                       const segnb_upcat_src* upsum = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);

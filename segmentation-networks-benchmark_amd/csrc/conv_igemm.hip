@@ -1383,6 +1383,36 @@ extern "C" int segnb_conv_fprop_upcat(const segnb_conv_geom* g, int dtype, const
     return rc;
 }
 
+static bool upsum_geom_ok(const segnb_conv_geom* g, int dtype, int Cu) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || getenv("SEGNB_FPROP_GENERAL") != nullptr) return false;
+    if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || g->ntaps != 9 || g->in_step != 1 || g->out_step != 1) return false;
+    if (g->oh0 != 0 || g->ow0 != 0 || g->QH != g->Ho || g->QW != g->Wo || (g->Ho & 1) || (g->Wo & 1) || g->Wo < 12) return false;
+    return g->Ci % 32 == 0 && g->Ci <= 96 && g->Co <= 96 && g->Co % 8 == 0 && Cu % 8 == 0 && Cu > 0 && Cu < g->Co;
+}
+
+extern "C" int segnb_conv_fprop_upsum_ok(const segnb_conv_geom* g, int dtype, int Cu) { return upsum_geom_ok(g, dtype, Cu) ? 1 : 0; }
+
+extern "C" int segnb_conv_fprop_upsum(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,
+                                      const segnb_upcat_src* dst, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_upsum, g, dtype, in, wpacked, out, dst, stream);
+    SEGNB_CHECK_ARG(in && wpacked && out && dst && dst->u, "NULL tensor");
+    SEGNB_CHECK_ARG(upsum_geom_ok(g, dtype, dst->Cu), "geometry not served (segnb_conv_fprop_upsum_ok)");
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
+    const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    const int rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream,
+                                      nullptr, nullptr, nullptr, dst);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_conv_fprop_upsum: no kernel for this geometry");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
 extern "C" int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
                                       const void* dout, float* dwp, int nslab, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_upcat, g, dtype, in, src, dout, dwp, nslab, stream);

@@ -39,6 +39,12 @@ struct FdArgs {
     const bf16_t* u;
     unsigned u_bytes;
     int ld_u, NCHU, Hu, Wu;
+    // fused Upsample(x2) backward in the data gradient's store pass (segnb_conv_fprop_upsum, fprop_rw.hip): the first up_C
+    // output channels are NOT stored at this resolution -- each 2 x 2 window of the staged tile is summed (fp32 sum of the
+    // four bf16 values, rounded once: what the consumer's 2 x 2 sum of the stored slice computed) and written to up_out
+    // [N][H/2][W/2][up_ld]; the other channels are stored as usual.  up_out == NULL: off
+    bf16_t* up_out;
+    int up_C, up_ld;
     int P32;              // plane gather with 32-channel planes: a K chunk = two planes (halves of every LDS row)
     int RPS;              // 2 x 2-window forms: store rows of the previous tile carried per step (1 or 2)
     int NTLR, CoW;        // phase forward (WsCfg::UPF): channel tiles per phase (NTL = 4 * NTLR), weight rows per phase

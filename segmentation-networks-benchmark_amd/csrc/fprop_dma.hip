@@ -1107,6 +1107,7 @@ int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, 
     a.dw[1] = a.dw[3] = 1;
     a.dbg = 0;
     a.u = nullptr;
+    a.up_out = nullptr;
     a.bn_y = nullptr;
     a.ep_act = -1;
     a.ep_coef = nullptr;
@@ -1158,6 +1159,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.out_bytes = (unsigned)ob;
         a.dbg = 0;
         a.u = nullptr;
+        a.up_out = nullptr;
         a.bn_y = nullptr;
         a.ep_act = -1;
         a.ep_coef = nullptr;
@@ -1199,6 +1201,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.up_out = nullptr;
     a.u = nullptr;
     if (uc != nullptr) {
         // virtual concat: in = the skip tensor (channels Cu.. of the logical input), uc->u = the low-resolution tensor

@@ -224,7 +224,36 @@ __global__ __launch_bounds__(C::NT) void conv_fprop_rw_kernel(const FdArgs a) {
             if (DBG && (a.dbg & 8)) return;
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
             const int cc = ltid % OC, row0 = ltid / OC;
-            const bool cok = cc * 8 < a.Co && row0 < C::RG;      // (12 chunks per row: 120 of the 128 threads)
+            const int ocu = a.up_out != nullptr ? a.up_C / 8 : 0;      // leading chunks that leave through the 2 x 2 sums below
+            const bool cok = cc * 8 < a.Co && row0 < C::RG && cc >= ocu;      // (12 chunks per row: 120 of the 128 threads)
+            if (a.up_out != nullptr) {
+                // fused Upsample(x2) backward: one (2 x 2 window, 8-channel chunk) per thread and trip.  Tile origins and the
+                // image size are even (checked on the host): a window lies inside the image or outside it as a whole.
+                const int items = (BM / 4) * ocu;
+                for (int i = ltid; i < items; i += LT) {
+                    const int cu = i % ocu, q = i / ocu;
+                    const int m00 = (2 * (q / (WT / 2))) * WT + 2 * (q % (WT / 2));
+                    const int opix = tab[m00];
+                    if (opix < 0) continue;
+                    float acc8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+#pragma unroll
+                    for (int wq = 0; wq < 4; ++wq) {
+                        const int row = m00 + (wq >> 1) * WT + (wq & 1);
+                        const u32x4_t v4 = *reinterpret_cast<const u32x4_t*>(sOut + row * OUT_ROW + cu * 16);
+                        acc8[0] += __uint_as_float(v4.x << 16); acc8[1] += __uint_as_float(v4.x & 0xffff0000u);
+                        acc8[2] += __uint_as_float(v4.y << 16); acc8[3] += __uint_as_float(v4.y & 0xffff0000u);
+                        acc8[4] += __uint_as_float(v4.z << 16); acc8[5] += __uint_as_float(v4.z & 0xffff0000u);
+                        acc8[6] += __uint_as_float(v4.w << 16); acc8[7] += __uint_as_float(v4.w & 0xffff0000u);
+                    }
+                    const int hw = a.H * a.W;
+                    const int n = opix / hw, rem = opix - n * hw;
+                    const int ho = rem / a.W, wo = rem - ho * a.W;
+                    const long long lp = ((long long)n * (a.H >> 1) + (ho >> 1)) * (a.W >> 1) + (wo >> 1);
+                    store8(a.up_out + lp * a.up_ld + cu * 8, acc8);
+                }
+            }
 #pragma unroll
             for (int base = 0; base < C::RPT; base += 8) {
                 int opix[8];
@@ -482,7 +511,7 @@ int launch_rw(FdArgs& a, hipStream_t stream) {
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
                        hipStream_t stream, const segnb_bn_reduce_epilogue* bn, const segnb_act_epilogue* ep,
-                       const segnb_upcat_src* uc) {
+                       const segnb_upcat_src* uc, const segnb_upcat_src* upsum) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_rw()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 96 || g->Wo < 12) return 0;
@@ -518,6 +547,16 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
         a.dw[t] = g->dw[t] - dwmin;
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
+    a.up_out = nullptr;
+    if (upsum != nullptr) {
+        // (segnb_upcat_src reused as the destination: u = the low-resolution gradient, Cu = leading channels that go there)
+        if (upsum->Cu % 8 != 0 || upsum->Cu <= 0 || upsum->Cu >= g->Co || (g->Ho & 1) || (g->Wo & 1) || stats != nullptr ||
+            bn != nullptr || ep != nullptr || a.dbg)
+            return 0;
+        a.up_out = (bf16_t*)const_cast<void*>(upsum->u);
+        a.up_C = upsum->Cu;
+        a.up_ld = upsum->ld_u;
+    }
     a.u = nullptr;
     if (uc != nullptr) {
         // virtual concat: `in` = the skip tensor (logical channels Cu..), uc->u = the tensor the first Cu channels are upsampled from

@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 #define SEGNB_WG_WS_DB 0     // specialised blocks: 1 = two tile buffers (one barrier per iteration; same speed alone, but the
                             // 128 KB block keeps other kernels off the CU: +0.8 % step time beside the main stream)
 #endif
+#ifndef SEGNB_WG_PACE
+#define SEGNB_WG_PACE 0      // s_sleep argument (x 64 clocks) after each paced tile store (0: none)
+#endif
 #ifndef SEGNB_WG_TALL
 #define SEGNB_WG_TALL 1
 #endif
@@ -257,8 +260,15 @@ struct WgTile {
 template <int BCO, int BCI, int R, int WT, bool FLAT>
 constexpr bool wg_specialised() {
     using TL = WgTile<R, WT, FLAT>;
-    return SEGNB_WG_TS && BCO == 64 && BCI == 64 &&
-           (!SEGNB_WG_WS_DB || wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO)));
+    return SEGNB_WG_TS && BCO == 64 && BCI == 64;
+}
+// ... and with TWO tile buffers where they fit (SEGNB_WG_WS_DB): the fetch waves keep two tiles in flight in registers and store
+// the next one into the other buffer under the matrix waves' slab loop
+template <int BCO, int BCI, int R, int WT, bool FLAT>
+constexpr bool wg_ws_db() {
+    using TL = WgTile<R, WT, FLAT>;
+    return SEGNB_WG_WS_DB && wg_specialised<BCO, BCI, R, WT, FLAT>() &&
+           wg_double_buffered(TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO));
 }
 
 template <int BCO, int BCI, int R, int WT, bool FLAT = false, bool BNA = false>
@@ -282,7 +292,7 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
     // of iteration it's slab loop, under its MFMAs, and one barrier per iteration separates the buffers' roles
     // (single buffer: MFMA drain -> barrier -> stores -> barrier -> first fragment reads, all exposed, every iteration)
     constexpr int BUF = TL::XROWS * SX + TL::YROWS * SY;
-    constexpr bool DB = wg_double_buffered(BUF) && wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB;
+    constexpr bool DB = wg_ws_db<BCO, BCI, R, WT, FLAT>();
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
@@ -338,7 +348,8 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
         }
     }
     uint4 rx[XPT], ry[YPT];
-    auto gload = [&](int it) {
+    uint4 rx2[DB ? XPT : 1], ry2[DB ? YPT : 1];        // second tile in flight (double-buffered fetch waves)
+    auto gload_to = [&](int it, auto& rx, auto& ry) {
         if constexpr (FLAT) {
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
@@ -426,7 +437,11 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
             ry[u] = v;
         }
     };
-    auto lstore = [&](int bo) {
+    auto gload = [&](int it) { gload_to(it, rx, ry); };
+    // paced: (double-buffered fetch waves) a pause after every store, so that the tile trickles into the other buffer under the
+    // matrix waves' slab loop instead of arriving as one burst their fragment reads queue behind
+    auto lstore_from = [&](int bo, auto paced, const auto& rx, const auto& ry) {
+        constexpr bool PACED = decltype(paced)::value;
 #pragma unroll
         for (int u = 0; u < XPT; ++u) {
             const int c = tid + u * 256;
@@ -434,6 +449,7 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                 const int pix = c / (BCI / 8), cc = c - pix * (BCI / 8);
                 *reinterpret_cast<uint4*>(sX + bo + pix * SX + cc * 16) = rx[u];
             }
+            if constexpr (PACED && SEGNB_WG_PACE > 0) __builtin_amdgcn_s_sleep(SEGNB_WG_PACE);
         }
 #pragma unroll
         for (int u = 0; u < YPT; ++u) {
@@ -442,8 +458,12 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                 const int pix = c / (BCO / 8), cc = c - pix * (BCO / 8);
                 *reinterpret_cast<uint4*>(sY + bo + pix * SY + cc * 16) = ry[u];
             }
+            if constexpr (PACED && SEGNB_WG_PACE > 0) __builtin_amdgcn_s_sleep(SEGNB_WG_PACE);
         }
     };
+    auto lstore = [&](int bo, auto paced) { lstore_from(bo, paced, rx, ry); };
+    constexpr std::false_type burst{};
+    constexpr std::true_type paced{};
 
     // fragment addressing: 16-lane group g reads 4 pixel rows x 16 channels; lane 4q+p supplies the address of
     // pixel row q, channels 4p..4p+3 and receives channel (l&15) of the 4 rows (probe: tools/probe_tr.hip)
@@ -462,28 +482,34 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
         if (fetcher) {
             // fetch waves: tile it+1 -> registers -> the buffer the matrix waves are not reading; same barrier sequence
             gload(it_begin);
-            lstore(0);
-            __syncthreads();
-            int cur = 0;
-            for (int it = it_begin; it < it_end; ++it) {
-                if constexpr (DB) {
-                    if (it + 1 < it_end) {
-#if !(SEGNB_WG_EXP & 1)
-                        gload(it + 1);
-#endif
-                        lstore((cur ^ 1) * BUF);
-                    }
+            lstore(0, burst);
+            if constexpr (DB) {
+                // tiles it+1 (set A) and it+2 (set B) in flight; each iteration stores the older set into the buffer the matrix
+                // waves are not reading and re-issues that set two tiles ahead: a tile has two slab loops to land
+                if (it_begin + 1 < it_end) gload_to(it_begin + 1, rx, ry);
+                if (it_begin + 2 < it_end) gload_to(it_begin + 2, rx2, ry2);
+                __syncthreads();
+                int cur = 0;
+                for (int it = it_begin; it < it_end; it += 2) {
+                    if (it + 1 < it_end) lstore_from((cur ^ 1) * BUF, paced, rx, ry);
+                    if (it + 3 < it_end) gload_to(it + 3, rx, ry);
                     __syncthreads();
-                    cur ^= 1;
-                } else {
+                    if (it + 1 >= it_end) break;
+                    if (it + 2 < it_end) lstore_from(cur * BUF, paced, rx2, ry2);
+                    if (it + 4 < it_end) gload_to(it + 4, rx2, ry2);
+                    __syncthreads();
+                }
+                return;
+            }
+            __syncthreads();
+            for (int it = it_begin; it < it_end; ++it) {
 #if !(SEGNB_WG_EXP & 1)
-                    if (it + 1 < it_end) gload(it + 1);
+                if (it + 1 < it_end) gload(it + 1);
 #endif
-                    __syncthreads();                    // the matrix waves are done with this tile
-                    if (it + 1 < it_end) {
-                        lstore(0);
-                        __syncthreads();
-                    }
+                __syncthreads();                    // the matrix waves are done with this tile
+                if (it + 1 < it_end) {
+                    lstore(0, burst);
+                    __syncthreads();
                 }
             }
             return;
@@ -508,7 +534,7 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
 
     if constexpr (!TS) {
         gload(it_begin);
-        lstore(0);
+        lstore(0, burst);
     }
     __syncthreads();
     constexpr int SPW = NSLAB / KSPLIT;        // slabs per wave and iteration
@@ -535,7 +561,7 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                 const unsigned vac = va + bo;
                 auto mid = [&]() {
                     if constexpr (!TS) {
-                        if (more) lstore((cur ^ 1) * BUF);
+                        if (more) lstore((cur ^ 1) * BUF, burst);
                     }
                 };
 #if SEGNB_WG_EXP & 2
@@ -584,7 +610,7 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before anyone reads the accumulators
                 __syncthreads();                    // everyone done reading this iteration's tiles
                 if (it + 1 < it_end) {
-                    if constexpr (!TS) lstore(0);
+                    if constexpr (!TS) lstore(0, burst);
                     __syncthreads();
                 }
             }
@@ -723,7 +749,7 @@ template <int BCO, int BCI, int R, int WT, bool FLAT = false, bool BNA = false>
 int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
     using TL = WgTile<R, WT, FLAT>;
     constexpr int tile_bytes = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
-    constexpr int smem = (wg_specialised<BCO, BCI, R, WT, FLAT>() && SEGNB_WG_WS_DB) ? 2 * tile_bytes : tile_bytes;
+    constexpr int smem = wg_ws_db<BCO, BCI, R, WT, FLAT>() ? 2 * tile_bytes : tile_bytes;
     static_assert(smem <= 160 * 1024, "tiles fit the LDS");
     static int attr_rc = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT, BNA>),
@@ -783,7 +809,23 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
         if (g->Wo < 24) return c;
         c = {(g->Ho % 16 == 0 && g->Ho >= 64 && SEGNB_WG_TALL) ? 6 : 1, 32, 32};
     } else if (g->Wo > 16) {
-        c = {2, 64, 64};
+        // rows per iteration: 8, or 7, where they divide the image height (x tile 10 rows for 8, 9 for 7; half as many tile
+        // hand-overs per pixel), else 4 (6 for 4).  Measured alone over the 14 such layers of the timed configuration: 1788 ->
+        // 1667 us; in situ -0.6 % step time.  SEGNB_WG_ROWS=4 restores the short tiles.
+        static const int rows = [] {
+            const char* e = getenv("SEGNB_WG_ROWS");
+            return e ? atoi(e) : 8;
+        }();
+        // 16-column tiles where they cover the width exactly and 32-column tiles do not (112 = 7 x 16 against 4 x 32: an
+        // eighth of the slabs were padding); SEGNB_WG_W16=0: off
+        static const bool w16 = [] {
+            const char* e = getenv("SEGNB_WG_W16");
+            return e == nullptr || atoi(e) != 0;
+        }();
+        if (w16 && g->Wo % 16 == 0 && g->Wo % 32 != 0)
+            c = {3, 64, 64};
+        else
+            c = {(rows == 8 && g->Ho % 8 == 0) ? 7 : ((rows >= 7 && g->Ho % 7 == 0) ? 8 : 2), 64, 64};
     } else if (g->Wo == 14 && g->Ho == 14) {
         c = {5, 64, 64};
     } else if (g->Wo >= 12) {
@@ -842,6 +884,8 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream, partial);
     else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream, partial);
     else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 7) rc = launch_s1<64, 64, 8, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 8) rc = launch_s1<64, 64, 7, 32>(a, nslab, stream, partial);
     else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream, partial);
     else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream, partial);
     else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream, partial);

@@ -240,7 +240,7 @@ class _ZFUnetPlan(object):
     def _seg(self, lvl, N, H, W):
         """Does decoder level lvl run its first convolution's data gradient by segment at this input size?"""
         conv = self.stages[DECODER[4 - lvl]][0].conv
-        return self.subpixel and conv.segmented(N, H >> lvl, W >> lvl)
+        return self.subpixel and conv.writes_du(N, H >> lvl, W >> lvl)
 
     def _low_res(self, lvl, N, H, W):
         """Does decoder level lvl read the tensor its concat buffer's first segment is upsampled from (segmented forward or

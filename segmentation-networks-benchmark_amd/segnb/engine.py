@@ -638,7 +638,7 @@ class UpCatConvOp(object):
         low-resolution gather runs on a fast kernel (segnb_conv_fprop_upd_ok): on the general gather kernel it costs more
         than the 5/9 of the multiply-adds it saves (measured in situ: 198 / 103 us against 118 / 124 us plain at the
         224x224 / 14x14 decoder levels of the timed configuration)."""
-        if not self.need_dgrad:
+        if not self.need_dgrad or self.upsum(N, H, W):
             return False
         key = (N, H, W)
         v = self._seg.get(key)
@@ -648,6 +648,30 @@ class UpCatConvOp(object):
             v = self._seg[key] = (self.force_segmented or (self.force_thin and self.Cop <= 32 and W >= 64) or
                                   bool(nv.query('segnb_conv_fprop_upd_ok', g, self.rt.code)))
         return v
+
+    # SEGNB_UPSUM=0: no fused Upsample backward in the thin level's data gradient (the segmented form, or the plain one, instead)
+    fused_upsum = os.environ.get('SEGNB_UPSUM', '1') != '0'
+
+    def upsum(self, N, H, W):
+        """Is the data gradient at input size H x W the PLAIN 9-tap launch with the Upsample(x2) backward fused into its store
+        pass (segnb_conv_fprop_upsum)?  The thin, HBM-bound 224x224 level: all 36 multiply-adds per low-resolution pixel are
+        done -- they do not bound the kernel -- and the 4x-sized gradient slice is still neither written nor read."""
+        if not self.need_dgrad or not self.fused_upsum or self.force_segmented:
+            return False
+        key = ('s', N, H, W)
+        v = self._seg.get(key)
+        if v is None:
+            p = self.full.plan(H, W)
+            v = False
+            if len(p['dg']) == 1 and p['dg_full']:
+                g = self.full._geom(p, 'd', 0, p['dg'][0], N, H, W, self.Cop, self.Cop, H, W, self.Cip, self.Cip)
+                v = bool(nv.query('segnb_conv_fprop_upsum_ok', g, self.rt.code, self.up_pad))
+            self._seg[key] = v
+        return v
+
+    def writes_du(self, N, H, W):
+        """Does the data gradient at this size write the gradient of the low-resolution tensor itself (bind_up's du)?"""
+        return self.upsum(N, H, W) or self.segmented(N, H, W)
 
     def fwd_segmented(self, N, H, W, ld_out=None):
         """Is the forward at input size H x W computed by segment -- the skip segment's 9-tap launch, then the upsampled
@@ -741,6 +765,16 @@ class UpCatConvOp(object):
     # ---- backward, by segment
     def dgrad(self, dyv, dxv, bn_reduce=None):
         assert bn_reduce is None
+        if self.upsum(dxv.N, dxv.H, dxv.W):
+            assert self._du is not None
+            f, rt = self.full, self.rt
+            p = f.plan(dxv.H, dxv.W)
+            l = p['dg'][0]
+            g = f._geom(p, 'd', 0, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+            dst = nv.UpcatSrc(self._du.ptr, self.up_pad, self._du.ld)
+            _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                   lambda: nv.call('segnb_conv_fprop_upsum', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][0]), dxv.ptr, dst, rt.stream))
+            return
         if not self.segmented(dxv.N, dxv.H, dxv.W):
             return self.full.dgrad(dyv, dxv)
         assert self._du is not None

@@ -1024,7 +1024,8 @@ def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
 # (N, high-resolution size, channels of the upsampled tensor, skip channels, output channels): the five decoder levels of
 # the timed configuration, a ragged toy, and sizes that take the general kernels (odd, non-multiples of 64)
 UPCAT_SHAPES = [(32, 14, 1024, 512, 512), (32, 28, 512, 256, 256), (32, 56, 256, 128, 128), (32, 112, 128, 64, 64),
-                (32, 224, 64, 32, 32), (3, 12, 24, 12, 20), (2, 20, 64, 64, 64), (2, 36, 128, 64, 64)]
+                (32, 224, 64, 32, 32), (3, 12, 24, 12, 20), (2, 20, 64, 64, 64), (2, 36, 128, 64, 64),
+                (3, 36, 64, 32, 32), (2, 20, 16, 24, 32)]
 
 
 @pytest.mark.parametrize('shape', UPCAT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
@@ -1089,6 +1090,22 @@ def test_upcat_segmented_backward_vs_torch(shape):
         stats = rt.zeros((16, 2, op.Cop), torch.float64)
         op.fprop(cat_noup, yseg, stats)
     op.dgrad(dyv, dcat)
+    # (c) the PLAIN data gradient with the Upsample backward fused into its store pass (the thin 224x224 level)
+    op.force_segmented = False
+    op._seg.clear()
+    dcat_s, duv_s = None, None
+    if op.upsum(N, S, S):
+        dcat_s = View.alloc(rt, N, S, S, Cup + Csp)
+        dcat_s.t.fill_(9.0)
+        duv_s = View.alloc(rt, N, S // 2, S // 2, Cup)
+        duv_s.t.fill_(7.0)
+        op.bind_up(uv, duv_s)
+        assert op.writes_du(N, S, S) and not op.segmented(N, S, S)
+        op.dgrad(dyv, dcat_s)
+        op.bind_up(uv, duv)
+    assert dcat_s is not None or Co > 32 or (Co % 32), 'fused upsample backward not served at a thin decoder shape'
+    op.force_segmented = True
+    op._seg.clear()
     gw = torch.zeros_like(wd)
     op.wgrad(cat, dyv, gw, unpack=False)
     unp = PackTable(rt, op.unpack_jobs(S, S, gw), 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad')
@@ -1126,6 +1143,18 @@ def test_upcat_segmented_backward_vs_torch(shape):
     assert Cup == Cu or float(duv.dense()[..., Cu:].abs().max()) == 0.0
     check(name + ' dw', gw.cpu(), wr.grad, 'f32')
     check(name + ' dw, second launch', gw1.cpu(), wr.grad, 'f32')
+    if dcat_s is not None:
+        check(name + ' d skip (fused upsample backward)', dcat_s.dense().float().cpu()[..., Cup:Cup + Cs].permute(0, 3, 1, 2),
+              skr.grad, 'bf16')
+        check(name + ' d u (fused upsample backward)', duv_s.dense().float().cpu()[..., :Cu].permute(0, 3, 1, 2), ur.grad, 'bf16')
+        assert float((dcat_s.dense()[..., :Cup] - 9.0).abs().max()) == 0.0, 'the high-resolution slice is not to be written'
+        # = the plain data gradient's stored slice, summed 2 x 2 in fp32 and rounded once
+        dfull = View.alloc(rt, N, S, S, Cup + Csp)
+        op.full.dgrad(dyv, dfull)
+        f = dfull.dense()[..., :Cup].float()
+        ref = (((f[:, 0::2, 0::2] + f[:, 0::2, 1::2]) + f[:, 1::2, 0::2]) + f[:, 1::2, 1::2]).bfloat16()
+        assert torch.equal(duv_s.dense(), ref)
+        assert torch.equal(dcat_s.dense()[..., Cup:], dfull.dense()[..., Cup:])
 
 
 @pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],

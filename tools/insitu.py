@@ -61,13 +61,24 @@ def main():
     # gradient of each layer as the launcher issued them
     order_bwd = list(reversed(fwd_names))
     seen_f = 0
-    bw_f = [nm for nm in order_bwd if nm != 'enc0.l1']
+    bw_f = []
+    for nm in order_bwd:
+        if nm == 'enc0.l1':
+            continue
+        if nm.startswith('dec') and nm.endswith('l1'):
+            lvl = int(nm[3])
+            from lib.models.zf_unet import DECODER
+            conv = model.stages[DECODER[4 - lvl]][0].conv
+            if hasattr(conv, 'segmented') and conv.segmented(args.batch, args.size >> lvl, args.size >> lvl):
+                bw_f += [nm + ' skip', nm + ' up']      # the data gradient by segment: two launches
+                continue
+        bw_f.append(nm)
     for label, flops, a, b in fl:
         if label == 'conv_fprop':
             if seen_f < 22:
                 names.append('fprop ' + fwd_names[seen_f])
             else:
-                names.append('dgrad ' + bw_f[seen_f - 22])
+                names.append('dgrad ' + (bw_f[seen_f - 22] if seen_f - 22 < len(bw_f) else '?'))
             seen_f += 1
         else:
             names.append('wgrad ' + order_bwd[k_w])
