@@ -262,9 +262,13 @@ class _ZFUnetPlan(object):
         t = self._pack_tables.get((H, W))
         if t is None or t[0] != key:
             convs = self._conv_sizes(H, W)
-            pj = []
-            for conv, h, w in convs:
-                pj += conv.pack_jobs(h, w, N) if isinstance(conv, UpCatConvOp) else conv.pack_jobs(h, w)
+            pj_early, pj = [], []
+            for ci, (conv, h, w) in enumerate(convs):
+                jobs = conv.pack_jobs(h, w, N) if isinstance(conv, UpCatConvOp) else conv.pack_jobs(h, w)
+                if ci < self.PACK_EARLY:
+                    pj_early += jobs
+                else:
+                    pj += jobs
             unpacks, los = [], []
             for a, b in self.UNPACK_GROUPS:
                 uj = []
@@ -272,8 +276,8 @@ class _ZFUnetPlan(object):
                     uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
                 unpacks.append(PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
                 los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
-            t = (key, PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'), tuple(unpacks),
-                 tuple(los))
+            t = (key, (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
+                       PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight')), tuple(unpacks), tuple(los))
             self._pack_tables[(H, W)] = t
         return t
 
@@ -306,8 +310,30 @@ class _ZFUnetPlan(object):
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return
-        self._tables(H, W, N)[1].run()
+        # The matrices of the first PACK_EARLY convolutions (the 224x224 .. 28x28 encoder levels: 4 % of the parameters) are
+        # packed on the main stream; the rest -- needed from the 14x14 level on, ~0.6 ms into the forward -- on the side stream,
+        # idle during the forward, beside those levels.  The forward joins the side stream before its first late convolution
+        # (_join_late_pack, part of the recorded list).  OFF by default (SEGNB_PACK_OVERLAP=1 enables): measured 5.338 vs 5.356
+        # ms/step, 4 interleaved runs each -- the pack is HBM-bound and so are the 224x224 / 112x112 levels it runs beside
+        # (first convolution 37 -> 100 us): what the side stream takes off the main one comes back as slower kernels on it.
+        early, late = self._tables(H, W, N)[1]
+        early.run()
+        side = self.rt.side_stream() if self.PACK_OVERLAP else None
+        if side is not None:
+            nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
+            with torch.cuda.stream(side):
+                late.run()
+        else:
+            late.run()
         self._packed_key = key
+
+    PACK_EARLY = 8
+    PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
+
+    def _join_late_pack(self):
+        side = self.rt.side_stream() if self.PACK_OVERLAP else None
+        if side is not None:
+            nv.call('segnb_stream_join', self.rt.stream, side.cuda_stream)
 
     def _dropout_tables(self, b, N, train):
         """Per-block [N, Cp] multiplier tables (0 or 1/(1-p)); None when Dropout2d is inactive.  All eleven
@@ -482,6 +508,8 @@ class _ZFUnetPlan(object):
             cur = b['x']
             for i, name in enumerate(ENCODER):
                 s1, s2 = self.stages[name]
+                if 2 * i == self.PACK_EARLY:
+                    self._join_late_pack()
                 s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None)
                 if i < 5:
                     skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])

@@ -68,7 +68,7 @@ def main():
         if nm.startswith('dec') and nm.endswith('l1'):
             lvl = int(nm[3])
             from lib.models.zf_unet import DECODER
-            conv = model.stages[DECODER[4 - lvl]][0].conv
+            conv = model._engine.stages[DECODER[4 - lvl]][0].conv
             if hasattr(conv, 'segmented') and conv.segmented(args.batch, args.size >> lvl, args.size >> lvl):
                 bw_f += [nm + ' skip', nm + ' up']      # the data gradient by segment: two launches
                 continue
