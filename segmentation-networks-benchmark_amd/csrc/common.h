@@ -132,6 +132,10 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
                        hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr,
                        const segnb_upcat_src* uc = nullptr);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
+// strided / wide-window tile kernel (wgrad_s1.hip: conv_wgrad_sx_kernel): same protocol
+int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
+                       bool partial);
+int segnb_wgrad_sx_slabs(const segnb_conv_geom* g);
 
 // ------------------------------------------------------------------------------------------------
 // element helpers: 8 channels per thread ("chunk8"), fp32 math

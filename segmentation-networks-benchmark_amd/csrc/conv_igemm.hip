@@ -1474,6 +1474,8 @@ extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
     if (dtype == SEGNB_BF16 && !wgrad_general_only()) {
         const int s = segnb_wgrad_s1_slabs(g);
         if (s > 0) return s;
+        const int sx = segnb_wgrad_sx_slabs(g);
+        if (sx > 0) return sx;
     }
     return 1;
 }
@@ -1495,6 +1497,12 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
         rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        if (rc == 1) {
+            SEGNB_LAUNCH_CHECK();
+            return 0;
+        }
+        if (rc != 0) return rc;
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_sx_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;

@@ -836,6 +836,254 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
     return c;
 }
 
+
+// ================================================================================================================
+// Strided / wide-window weight gradients on the same tile scheme (LinkNet34's stem, linknet.py:16 -- ResNet34 conv1 7x7
+// stride 2, 3 -> 64 --, its transposed 3x3 stride-2 "finaldeconv1", linknet.py:41, and the 3x3 stride-2 first convolutions
+// of ResNet34's layer2..4): the general gather kernel fetched every x pixel once per tap as a separate 16-byte load.
+//   dW[co][t][ci] = sum_{n,h,w} dout[n,h,w,co] * in[n, S h + dh[t], S w + dw[t], ci]
+// ONE x tile with its (S (R-1) + KH) x (S (WT-1) + KW) halo and one dout tile per iteration feed ALL taps.  The GEMM's N
+// dimension is the flattened (tap, channel) index k' = t * BCI + ci: ds_read_b64_tr_b16 takes a per-lane address, so the 16
+// columns a lane group fetches may belong to different taps (BCI = 8: two taps) and consecutive K rows (output pixels) are
+// S pixels apart in the tile.  Wave w owns the 32-column tiles w, w + 4, ... of k' for all 64 dout channels.
+// ================================================================================================================
+struct WgSxArgs {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* dwp;
+    int N, H, W, Hi, Wi;
+    int Ci, Co, ld_x, ld_dy;
+    int dhmin, dwmin;
+    int ntaps;
+    int HB, WB, IT, TCI_TILES, its_per_split;
+    long long slab_stride;
+    int Ktot;
+    signed char dh[SEGNB_MAX_TAPS], dw[SEGNB_MAX_TAPS];     // minus (dhmin, dwmin)
+};
+
+constexpr int lds_stride_step(int channels, int step) {
+    // bytes; multiple of 16, >= 2*channels, step * stride == 64 or 192 (mod 256): the four K rows of a fragment read, `step`
+    // pixels apart, hit disjoint banks
+    int s = channels * 2;
+    while (!(((s * step) % 256) == 64 || ((s * step) % 256) == 192)) s += 16;
+    return s;
+}
+
+template <int S, int BCI, int R, int WT, int KH, int KW>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a) {
+    constexpr int BCO = 64;
+    constexpr int XR = (R - 1) * S + KH, XC = (WT - 1) * S + KW;
+    constexpr int SX = lds_stride_step(BCI, S), SY = lds_stride(BCO);
+    constexpr int NK = KH * KW * BCI;                  // columns k' of this block
+    constexpr int NT32 = (NK + 31) / 32, NTW = (NT32 + 3) / 4;
+    constexpr int NSLAB = R * WT / 16, SEGS = WT / 16;
+    constexpr int XCH = XR * XC * (BCI / 8), YCH = R * WT * (BCO / 8);
+    constexpr int XPT = (XCH + 255) / 256, YPT = (YCH + 255) / 256;
+    static_assert(WT % 16 == 0 && NTW <= 4, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sY = smem + XR * XC * SX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = blockIdx.x % a.TCI_TILES;
+    const int rest = blockIdx.x / a.TCI_TILES;
+    const int ncot = (a.Co + BCO - 1) / BCO;
+    const int mtile = rest % ncot, split = rest / ncot;
+    const int co0 = mtile * BCO, ci0 = ntile * BCI;
+    const int it_begin = split * a.its_per_split;
+    int it_end = it_begin + a.its_per_split;
+    if (it_end > a.IT) it_end = a.IT;
+    float* __restrict__ slab = a.dwp + (long long)split * a.slab_stride;
+
+    uint4 rx[XPT], ry[YPT];
+    auto gload = [&](int it) {
+        const int n = it / (a.HB * a.WB);
+        const int rem = it - n * (a.HB * a.WB);
+        const int hb = rem / a.WB, wb = rem - hb * a.WB;
+        const int h0 = hb * R, w0 = wb * WT;
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int c = tid + u * 256;
+            const int pix = c / (BCI / 8), cc = c - pix * (BCI / 8);
+            const int xr = pix / XC, xc = pix - xr * XC;
+            const int hi = h0 * S + a.dhmin + xr, wi = w0 * S + a.dwmin + xc;
+            const int ch = ci0 + cc * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < XCH && ch < a.Ci && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+                v = *reinterpret_cast<const uint4*>(a.x + ((long long)(n * a.Hi + hi) * a.Wi + wi) * a.ld_x + ch);
+            rx[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < YPT; ++u) {
+            const int c = tid + u * 256;
+            const int pix = c / (BCO / 8), cc = c - pix * (BCO / 8);
+            const int yr = pix / WT, yc = pix - yr * WT;
+            const int ho = h0 + yr, wo = w0 + yc;
+            const int ch = co0 + cc * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < YCH && ch < a.Co && ho < a.H && wo < a.W)
+                v = *reinterpret_cast<const uint4*>(a.dy + ((long long)(n * a.H + ho) * a.W + wo) * a.ld_dy + ch);
+            ry[u] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) {
+            const int c = tid + u * 256;
+            if (c < XCH) {
+                const int pix = c / (BCI / 8), cc = c - pix * (BCI / 8);
+                *reinterpret_cast<uint4*>(sX + pix * SX + cc * 16) = rx[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < YPT; ++u) {
+            const int c = tid + u * 256;
+            if (c < YCH) {
+                const int pix = c / (BCO / 8), cc = c - pix * (BCO / 8);
+                *reinterpret_cast<uint4*>(sY + pix * SY + cc * 16) = ry[u];
+            }
+        }
+    };
+
+    // fragment addressing (see conv_wgrad_s1x9_kernel): lane 4q+p of a 16-lane group supplies the address of K row q, columns
+    // 4p..4p+3 of the group's 16; here a column is k' = (tap, channel)
+    const int q = (lane & 15) >> 2, p = lane & 3, h = lane >> 5, cbase = 16 * ((lane >> 4) & 1);
+    const int a_off = (8 * h + q) * SY + (cbase + 4 * p) * 2;
+    int b_off[NTW];
+#pragma unroll
+    for (int jj = 0; jj < NTW; ++jj) {
+        int kp = 32 * (wave + 4 * jj) + cbase + 4 * p;
+        if (kp >= a.ntaps * BCI) kp = 0;                  // (columns past the last tap: computed on tap 0's data, never stored)
+        const int t = kp / BCI, ci = kp - t * BCI;
+        b_off[jj] = ((8 * h + q) * S + (int)a.dh[t] * XC + (int)a.dw[t]) * SX + ci * 2;
+    }
+    const int ntw = wave < NT32 - 4 * (NTW - 1) ? NTW : NTW - 1;      // 32-column tiles of this wave (wave-uniform)
+
+    f32x16_t acc[2][NTW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NTW; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    if (it_begin < it_end) {
+        gload(it_begin);
+        lstore();
+    }
+    __syncthreads();
+    for (int it = it_begin; it < it_end; ++it) {
+        if (it + 1 < it_end) gload(it + 1);
+#pragma unroll 2
+        for (int s = 0; s < NSLAB; ++s) {
+            const int row = s / SEGS, seg = s - row * SEGS;
+            const unsigned char* pa = sY + a_off + (row * WT + seg * 16) * SY;
+            const unsigned char* pb = sX + (row * S * XC + seg * 16 * S) * SX;
+            const bf16x8_t fa0 = tr_frag(pa, 4 * SY), fa1 = tr_frag(pa + 64, 4 * SY);
+#pragma unroll
+            for (int jj = 0; jj < NTW; ++jj) {
+                if (jj < ntw) {
+                    const bf16x8_t fb = tr_frag(pb + b_off[jj], 4 * S * SX);
+                    acc[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][jj], 0, 0, 0);
+                    acc[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][jj], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < it_end) {
+            lstore();
+            __syncthreads();
+        }
+    }
+    // D[i = co][j = k']: lane holds column lane & 31, rows (e & 3) + 8 (e >> 2) + 4 h.  Every (tile, split) block owns its piece
+    // of partial slab `split` (plain stores; an empty pixel range stores zeros)
+#pragma unroll
+    for (int jj = 0; jj < NTW; ++jj) {
+        if (jj >= ntw) continue;
+        const int kp = 32 * (wave + 4 * jj) + (lane & 31);
+        const int t = kp / BCI, ci = ci0 + kp - t * BCI;
+        if (kp >= a.ntaps * BCI || ci >= a.Ci) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < a.Co) slab[(long long)co * a.Ktot + t * a.Ci + ci] = acc[i][jj][e];
+            }
+    }
+}
+
+struct SxChoice {
+    int cfg;        // 0: not served.  1: 7x7 window stride 2, 8 channels (stem); 2: 3x3 stride 2, 32-channel tiles, 32 columns;
+                    // 3: the same on 16-column tiles (outputs narrower than 32); 4..7: 1x1 stride 1 (a plain dy^T x GEMM: the
+                    // pixels of the whole batch as ONE row of 256-pixel tiles) with 16 / 32 / 64 / 128 input channels per block
+    int bci;
+};
+SxChoice sx_choose(const segnb_conv_geom* g) {
+    SxChoice c = {0, 0};
+    static const bool off = getenv("SEGNB_WGRAD_SX") != nullptr && getenv("SEGNB_WGRAD_SX")[0] == '0';
+    if (off || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0 || g->QH != g->Ho || g->QW != g->Wo) return c;
+    if (g->in_step == 1 && g->ntaps == 1 && g->dh[0] == 0 && g->dw[0] == 0 && g->Hi == g->Ho && g->Wi == g->Wo &&
+        g->Ho * g->Wo >= 256) {                      // (per image: the choice may not depend on the batch size)
+        if (g->Ci <= 16) c = {4, 16};
+        else if (g->Ci <= 32) c = {5, 32};
+        else if (g->Ci < 96) c = {6, 64};
+        else c = {7, 128};
+        return c;
+    }
+    if (g->in_step != 2) return c;
+    int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
+    for (int t = 1; t < g->ntaps; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dhmax = g->dh[t] > dhmax ? g->dh[t] : dhmax;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+        dwmax = g->dw[t] > dwmax ? g->dw[t] : dwmax;
+    }
+    const int kh = dhmax - dhmin + 1, kw = dwmax - dwmin + 1;
+    if (g->ntaps != kh * kw) return c;
+    if (kh == 7 && kw == 7 && g->Ci == 8 && g->Wo >= 32) c = {1, 8};
+    else if (kh == 3 && kw == 3 && g->Ci % 32 == 0 && g->Wo >= 24) c = {2, 32};
+    else if (kh == 3 && kw == 3 && g->Ci % 32 == 0 && g->Wo >= 12) c = {3, 32};
+    return c;
+}
+
+template <int S, int BCI, int R, int WT, int KH, int KW>
+int launch_sx(WgSxArgs& a, int nslab, hipStream_t stream, bool partial) {
+    constexpr int XR = (R - 1) * S + KH, XC = (WT - 1) * S + KW;
+    constexpr int smem = XR * XC * lds_stride_step(BCI, S) + R * WT * lds_stride(64);
+    static_assert(smem <= 160 * 1024, "tiles fit the LDS");
+    static int attr_rc = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) segnb_set_error("wgrad_sx hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }();
+    if (attr_rc) return attr_rc;
+    a.HB = (a.H + R - 1) / R;
+    a.WB = (a.W + WT - 1) / WT;
+    a.IT = a.N * a.HB * a.WB;
+    a.TCI_TILES = (a.Ci + BCI - 1) / BCI;
+    const int tiles = ((a.Co + 63) / 64) * a.TCI_TILES;
+    const int S_ = s1_slabs(tiles, true);
+    if (S_ != nslab) {
+        segnb_set_error("segnb_conv_wgrad: workspace has %d slabs, this geometry needs %d (segnb_conv_wgrad_slabs)", nslab, S_);
+        return SEGNB_E_BADARG;
+    }
+    a.its_per_split = (a.IT + S_ - 1) / S_;
+    a.slab_stride = (long long)a.Co * a.Ktot;
+    hipLaunchKernelGGL((conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW>), dim3(tiles * S_), dim3(256), smem, stream, a);
+    if (S_ > 1 && !partial) {
+        const long long total = a.slab_stride;
+        if (S_ <= 16 && total % 4 == 0)
+            hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
+                               reinterpret_cast<float4*>(a.dwp), total / 4, S_);
+        else
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp, total, S_);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // partial slabs segnb_conv_wgrad writes for this geometry on the fast path (0: not a fast-path geometry)
@@ -889,5 +1137,51 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream, partial);
     else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream, partial);
     else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream, partial);
+    return rc ? rc : 1;
+}
+
+
+// the strided / wide-window tile kernel (conv_wgrad_sx_kernel): slabs it writes (0: geometry not served) and the launch
+int segnb_wgrad_sx_slabs(const segnb_conv_geom* g) {
+    const SxChoice c = sx_choose(g);
+    if (!c.cfg) return 0;
+    return s1_slabs(((g->Co + 63) / 64) * ((g->Ci + c.bci - 1) / c.bci), true);
+}
+
+int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
+                       bool partial) {
+    const SxChoice c = sx_choose(g);
+    if (!c.cfg) return 0;
+    int dhmin = g->dh[0], dwmin = g->dw[0];
+    for (int t = 1; t < g->ntaps; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+    }
+    WgSxArgs a;
+    a.x = (const bf16_t*)in;
+    a.dy = (const bf16_t*)dout;
+    a.dwp = dwp;
+    a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Hi = g->Hi; a.Wi = g->Wi;
+    a.Ci = g->Ci; a.Co = g->Co; a.ld_x = g->ld_in; a.ld_dy = g->ld_out;
+    a.dhmin = dhmin; a.dwmin = dwmin;
+    a.ntaps = g->ntaps;
+    for (int t = 0; t < g->ntaps; ++t) {
+        a.dh[t] = (signed char)(g->dh[t] - dhmin);
+        a.dw[t] = (signed char)(g->dw[t] - dwmin);
+    }
+    a.Ktot = g->ntaps * g->Ci;
+    int rc;
+    if (c.cfg >= 4) {
+        a.W = a.Wi = g->N * g->Ho * g->Wo;          // 1x1: no halo, the batch is one row of pixels
+        a.N = a.H = a.Hi = 1;
+        rc = c.cfg == 4 ? launch_sx<1, 16, 1, 256, 1, 1>(a, nslab, stream, partial)
+           : c.cfg == 5 ? launch_sx<1, 32, 1, 256, 1, 1>(a, nslab, stream, partial)
+           : c.cfg == 6 ? launch_sx<1, 64, 1, 256, 1, 1>(a, nslab, stream, partial)
+                        : launch_sx<1, 128, 1, 256, 1, 1>(a, nslab, stream, partial);
+        return rc ? rc : 1;
+    }
+    if (c.cfg == 1) rc = launch_sx<2, 8, 8, 32, 7, 7>(a, nslab, stream, partial);
+    else if (c.cfg == 2) rc = launch_sx<2, 32, 4, 32, 3, 3>(a, nslab, stream, partial);
+    else rc = launch_sx<2, 32, 8, 16, 3, 3>(a, nslab, stream, partial);
     return rc ? rc : 1;
 }

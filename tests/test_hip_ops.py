@@ -97,6 +97,22 @@ CONV_CASES = [
     ('2x2 head co1',     2, 40, 48, [(32, 32)],            1,  2, 1, 1, False),
     ('3x3 co6 cat',      1, 36, 40, [(12, 16), (6, 8)],    6,  3, 1, 1, False),
     ('3x3 s2 co8',       2, 48, 40, [(16, 16)],            8,  3, 2, 1, False),
+    # stride-2 windows wide / tall enough for the tile kernel of the strided weight gradients (conv_wgrad_sx_kernel): LinkNet34's
+    # stem (linknet.py:16), the 3x3 stride-2 convolutions of ResNet34's layer2..4, the transposed 3x3 stride-2 finaldeconv1
+    # (linknet.py:41: its weight gradient gathers dy with stride 2)
+    ('7x7 s2 stem tile', 2, 64, 72, [(3, 8)],              64, 7, 2, 3, False),
+    ('7x7 s2 stem ragged', 1, 70, 90, [(3, 8)],            40, 7, 2, 3, False),
+    ('3x3 s2 tile',      2, 50, 54, [(64, 64)],            128, 3, 2, 1, False),
+    ('3x3 s2 tile w16',  2, 28, 30, [(96, 96)],            72, 3, 2, 1, False),
+    ('convT 3x3 s2 tile', 2, 20, 26, [(64, 64)],           32, 3, 2, 0, True),
+    ('convT 3x3 s2 tile w16', 1, 14, 16, [(40, 40)],       64, 3, 2, 0, True),
+    # 1x1 stride 1 (LinkNet34's decoder blocks, linknet.py:27-35; FCDenseNet's transition-down, tiramisu.py:49): the batch as one
+    # row of 256-pixel tiles, 16 / 32 / 64 / 128 input channels per block
+    ('1x1 tile c16',     2, 20, 24, [(16, 16)],            64, 1, 1, 0, False),
+    ('1x1 tile c32',     1, 16, 17, [(32, 32)],            24, 1, 1, 0, False),
+    ('1x1 tile c40',     3, 16, 16, [(40, 40)],            72, 1, 1, 0, False),
+    ('1x1 tile c112',    1, 18, 20, [(112, 112)],          112, 1, 1, 0, False),
+    ('1x1 tile c304',    2, 16, 16, [(304, 304)],          304, 1, 1, 0, False),
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
 ]
@@ -177,6 +193,22 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
         off += padded
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, dtype)
     check(name + ' dW vs torch', gw_g, wr.grad, 'f32' if dtype == 'f32' else 'bf16', scale=float(wr.grad.abs().max()))
+
+
+SX_CASES = [c for c in CONV_CASES if ' tile' in c[0] or 'stem ragged' in c[0]]
+
+
+@pytest.mark.parametrize('case', SX_CASES, ids=[c[0] for c in SX_CASES])
+def test_strided_wgrad_takes_the_tile_kernel(case):
+    """The strided cases above are served by conv_wgrad_sx_kernel, not by the general gather kernel: only the tile kernels split
+    the pixel range into partial slabs (segnb_conv_wgrad_slabs > 1; the general kernel accumulates into one)."""
+    name, N, H, W, segs, Co, k, s, p, transposed = case
+    Ci = sum(r for r, _ in segs)
+    rt = Runtime('cuda', 'bf16')
+    w = torch.zeros((Ci, Co, k, k) if transposed else (Co, Ci, k, k), device='cuda')
+    op = ConvOp(rt, w, None, segs, s, p, transposed, need_dgrad=True)
+    assert len(SX_CASES) == 11
+    assert min(op.plan(H, W)['nslab']) > 1, op.plan(H, W)['nslab']
 
 
 DEEPK_CASES = [c for c in CONV_CASES if 'deep K' in c[0]]
