@@ -869,9 +869,10 @@ constexpr int lds_stride_step(int channels, int step) {
     return s;
 }
 
-template <int S, int BCI, int R, int WT, int KH, int KW>
+template <int S, int BCI, int R, int WT, int KH, int KW, int BCO = 64>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a) {
-    constexpr int BCO = 64;
+    constexpr int TCO = BCO / 32;
+    static_assert(BCO == 32 || BCO == 64, "dout channel tile");
     constexpr int XR = (R - 1) * S + KH, XC = (WT - 1) * S + KW;
     constexpr int SX = lds_stride_step(BCI, S), SY = lds_stride(BCO);
     constexpr int NK = KH * KW * BCI;                  // columns k' of this block
@@ -960,9 +961,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a)
     }
     const int ntw = wave < NT32 - 4 * (NTW - 1) ? NTW : NTW - 1;      // 32-column tiles of this wave (wave-uniform)
 
-    f32x16_t acc[2][NTW];
+    f32x16_t acc[TCO][NTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TCO; ++i)
 #pragma unroll
         for (int jj = 0; jj < NTW; ++jj)
 #pragma unroll
@@ -980,13 +981,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a)
             const int row = s / SEGS, seg = s - row * SEGS;
             const unsigned char* pa = sY + a_off + (row * WT + seg * 16) * SY;
             const unsigned char* pb = sX + (row * S * XC + seg * 16 * S) * SX;
-            const bf16x8_t fa0 = tr_frag(pa, 4 * SY), fa1 = tr_frag(pa + 64, 4 * SY);
+            bf16x8_t fa[TCO];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) fa[i] = tr_frag(pa + 64 * i, 4 * SY);
 #pragma unroll
             for (int jj = 0; jj < NTW; ++jj) {
                 if (jj < ntw) {
                     const bf16x8_t fb = tr_frag(pb + b_off[jj], 4 * S * SX);
-                    acc[0][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb, acc[0][jj], 0, 0, 0);
-                    acc[1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb, acc[1][jj], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i][jj], 0, 0, 0);
                 }
             }
         }
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a)
         const int t = kp / BCI, ci = ci0 + kp - t * BCI;
         if (kp >= a.ntaps * BCI || ci >= a.Ci) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = co0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1018,10 +1022,11 @@ struct SxChoice {
     int cfg;        // 0: not served.  1: 7x7 window stride 2, 8 channels (stem); 2: 3x3 stride 2, 32-channel tiles, 32 columns;
                     // 3: the same on 16-column tiles (outputs narrower than 32); 4..7: 1x1 stride 1 (a plain dy^T x GEMM: the
                     // pixels of the whole batch as ONE row of 256-pixel tiles) with 16 / 32 / 64 / 128 input channels per block
-    int bci;
+    int bci;        // 8: 2x2 window stride 1, at most 32 output channels (LinkNet34's finalconv3, linknet.py:45)
+    int bco = 64;
 };
 SxChoice sx_choose(const segnb_conv_geom* g) {
-    SxChoice c = {0, 0};
+    SxChoice c = {0, 0, 64};
     static const bool off = getenv("SEGNB_WGRAD_SX") != nullptr && getenv("SEGNB_WGRAD_SX")[0] == '0';
     if (off || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0 || g->QH != g->Ho || g->QW != g->Wo) return c;
     if (g->in_step == 1 && g->ntaps == 1 && g->dh[0] == 0 && g->dw[0] == 0 && g->Hi == g->Ho && g->Wi == g->Wo &&
@@ -1030,6 +1035,17 @@ SxChoice sx_choose(const segnb_conv_geom* g) {
         else if (g->Ci <= 32) c = {5, 32};
         else if (g->Ci < 96) c = {6, 64};
         else c = {7, 128};
+        return c;
+    }
+    if (g->in_step == 1) {
+        int hmin = g->dh[0], hmax = g->dh[0], wmin = g->dw[0], wmax = g->dw[0];
+        for (int t = 1; t < g->ntaps; ++t) {
+            hmin = g->dh[t] < hmin ? g->dh[t] : hmin;
+            hmax = g->dh[t] > hmax ? g->dh[t] : hmax;
+            wmin = g->dw[t] < wmin ? g->dw[t] : wmin;
+            wmax = g->dw[t] > wmax ? g->dw[t] : wmax;
+        }
+        if (g->ntaps == 4 && hmax - hmin == 1 && wmax - wmin == 1 && g->Ci % 32 == 0 && g->Co <= 32 && g->Wo >= 24) c = {8, 32, 32};
         return c;
     }
     if (g->in_step != 2) return c;
@@ -1048,13 +1064,13 @@ SxChoice sx_choose(const segnb_conv_geom* g) {
     return c;
 }
 
-template <int S, int BCI, int R, int WT, int KH, int KW>
+template <int S, int BCI, int R, int WT, int KH, int KW, int BCO = 64>
 int launch_sx(WgSxArgs& a, int nslab, hipStream_t stream, bool partial) {
     constexpr int XR = (R - 1) * S + KH, XC = (WT - 1) * S + KW;
-    constexpr int smem = XR * XC * lds_stride_step(BCI, S) + R * WT * lds_stride(64);
+    constexpr int smem = XR * XC * lds_stride_step(BCI, S) + R * WT * lds_stride(BCO);
     static_assert(smem <= 160 * 1024, "tiles fit the LDS");
     static int attr_rc = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW, BCO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) segnb_set_error("wgrad_sx hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -1064,7 +1080,7 @@ int launch_sx(WgSxArgs& a, int nslab, hipStream_t stream, bool partial) {
     a.WB = (a.W + WT - 1) / WT;
     a.IT = a.N * a.HB * a.WB;
     a.TCI_TILES = (a.Ci + BCI - 1) / BCI;
-    const int tiles = ((a.Co + 63) / 64) * a.TCI_TILES;
+    const int tiles = ((a.Co + BCO - 1) / BCO) * a.TCI_TILES;
     const int S_ = s1_slabs(tiles, true);
     if (S_ != nslab) {
         segnb_set_error("segnb_conv_wgrad: workspace has %d slabs, this geometry needs %d (segnb_conv_wgrad_slabs)", nslab, S_);
@@ -1072,7 +1088,7 @@ int launch_sx(WgSxArgs& a, int nslab, hipStream_t stream, bool partial) {
     }
     a.its_per_split = (a.IT + S_ - 1) / S_;
     a.slab_stride = (long long)a.Co * a.Ktot;
-    hipLaunchKernelGGL((conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW>), dim3(tiles * S_), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((conv_wgrad_sx_kernel<S, BCI, R, WT, KH, KW, BCO>), dim3(tiles * S_), dim3(256), smem, stream, a);
     if (S_ > 1 && !partial) {
         const long long total = a.slab_stride;
         if (S_ <= 16 && total % 4 == 0)
@@ -1145,7 +1161,7 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
 int segnb_wgrad_sx_slabs(const segnb_conv_geom* g) {
     const SxChoice c = sx_choose(g);
     if (!c.cfg) return 0;
-    return s1_slabs(((g->Co + 63) / 64) * ((g->Ci + c.bci - 1) / c.bci), true);
+    return s1_slabs(((g->Co + c.bco - 1) / c.bco) * ((g->Ci + c.bci - 1) / c.bci), true);
 }
 
 int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
@@ -1171,7 +1187,7 @@ int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dou
     }
     a.Ktot = g->ntaps * g->Ci;
     int rc;
-    if (c.cfg >= 4) {
+    if (c.cfg >= 4 && c.cfg <= 7) {
         a.W = a.Wi = g->N * g->Ho * g->Wo;          // 1x1: no halo, the batch is one row of pixels
         a.N = a.H = a.Hi = 1;
         rc = c.cfg == 4 ? launch_sx<1, 16, 1, 256, 1, 1>(a, nslab, stream, partial)
@@ -1180,7 +1196,8 @@ int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dou
                         : launch_sx<1, 128, 1, 256, 1, 1>(a, nslab, stream, partial);
         return rc ? rc : 1;
     }
-    if (c.cfg == 1) rc = launch_sx<2, 8, 8, 32, 7, 7>(a, nslab, stream, partial);
+    if (c.cfg == 8) rc = launch_sx<1, 32, 8, 32, 2, 2, 32>(a, nslab, stream, partial);
+    else if (c.cfg == 1) rc = launch_sx<2, 8, 8, 32, 7, 7>(a, nslab, stream, partial);
     else if (c.cfg == 2) rc = launch_sx<2, 32, 4, 32, 3, 3>(a, nslab, stream, partial);
     else rc = launch_sx<2, 32, 8, 16, 3, 3>(a, nslab, stream, partial);
     return rc ? rc : 1;

@@ -113,6 +113,7 @@ CONV_CASES = [
     ('1x1 tile c40',     3, 16, 16, [(40, 40)],            72, 1, 1, 0, False),
     ('1x1 tile c112',    1, 18, 20, [(112, 112)],          112, 1, 1, 0, False),
     ('1x1 tile c304',    2, 16, 16, [(304, 304)],          304, 1, 1, 0, False),
+    ('2x2 tile co24',    1, 30, 33, [(64, 64)],            24, 2, 1, 1, False),      # (and '2x2 head co1' above: linknet.py:45)
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
 ]
@@ -195,7 +196,7 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
     check(name + ' dW vs torch', gw_g, wr.grad, 'f32' if dtype == 'f32' else 'bf16', scale=float(wr.grad.abs().max()))
 
 
-SX_CASES = [c for c in CONV_CASES if ' tile' in c[0] or 'stem ragged' in c[0]]
+SX_CASES = [c for c in CONV_CASES if ' tile' in c[0] or 'stem ragged' in c[0] or c[0] == '2x2 head co1']
 
 
 @pytest.mark.parametrize('case', SX_CASES, ids=[c[0] for c in SX_CASES])
@@ -207,7 +208,7 @@ def test_strided_wgrad_takes_the_tile_kernel(case):
     rt = Runtime('cuda', 'bf16')
     w = torch.zeros((Ci, Co, k, k) if transposed else (Co, Ci, k, k), device='cuda')
     op = ConvOp(rt, w, None, segs, s, p, transposed, need_dgrad=True)
-    assert len(SX_CASES) == 11
+    assert len(SX_CASES) == 13
     assert min(op.plan(H, W)['nslab']) > 1, op.plan(H, W)['nslab']
 
 
