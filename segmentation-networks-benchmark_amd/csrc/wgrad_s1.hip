@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_sx_kernel(const WgSxArgs a)
 
 struct SxChoice {
     int cfg;        // 0: not served.  1: 7x7 window stride 2, 8 channels (stem); 2: 3x3 stride 2, 32-channel tiles, 32 columns;
-                    // 3: the same on 16-column tiles (outputs narrower than 32); 4..7: 1x1 stride 1 (a plain dy^T x GEMM: the
+                    // 3: the same on 16-column tiles (outputs narrower than 32); 9 / 10: 4x4 stride 2 likewise; 4..7: 1x1 stride 1 (a plain dy^T x GEMM: the
                     // pixels of the whole batch as ONE row of 256-pixel tiles) with 16 / 32 / 64 / 128 input channels per block
     int bci;        // 8: 2x2 window stride 1, at most 32 output channels (LinkNet34's finalconv3, linknet.py:45)
     int bco = 64;
@@ -1061,6 +1061,8 @@ SxChoice sx_choose(const segnb_conv_geom* g) {
     if (kh == 7 && kw == 7 && g->Ci == 8 && g->Wo >= 32) c = {1, 8};
     else if (kh == 3 && kw == 3 && g->Ci % 32 == 0 && g->Wo >= 24) c = {2, 32};
     else if (kh == 3 && kw == 3 && g->Ci % 32 == 0 && g->Wo >= 12) c = {3, 32};
+    else if (kh == 4 && kw == 4 && g->Ci % 32 == 0 && g->Wo >= 24) c = {9, 32};        // (UNet16's ConvTranspose2d(4, 2, 1), unet16.py:30)
+    else if (kh == 4 && kw == 4 && g->Ci % 32 == 0 && g->Wo >= 12) c = {10, 32};
     return c;
 }
 
@@ -1199,6 +1201,8 @@ int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dou
     if (c.cfg == 8) rc = launch_sx<1, 32, 8, 32, 2, 2, 32>(a, nslab, stream, partial);
     else if (c.cfg == 1) rc = launch_sx<2, 8, 8, 32, 7, 7>(a, nslab, stream, partial);
     else if (c.cfg == 2) rc = launch_sx<2, 32, 4, 32, 3, 3>(a, nslab, stream, partial);
+    else if (c.cfg == 9) rc = launch_sx<2, 32, 4, 32, 4, 4>(a, nslab, stream, partial);
+    else if (c.cfg == 10) rc = launch_sx<2, 32, 8, 16, 4, 4>(a, nslab, stream, partial);
     else rc = launch_sx<2, 32, 8, 16, 3, 3>(a, nslab, stream, partial);
     return rc ? rc : 1;
 }

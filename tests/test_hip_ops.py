@@ -113,6 +113,8 @@ CONV_CASES = [
     ('1x1 tile c40',     3, 16, 16, [(40, 40)],            72, 1, 1, 0, False),
     ('1x1 tile c112',    1, 18, 20, [(112, 112)],          112, 1, 1, 0, False),
     ('1x1 tile c304',    2, 16, 16, [(304, 304)],          304, 1, 1, 0, False),
+    ('convT 4x4 s2 tile', 2, 24, 26, [(72, 72)],           64, 4, 2, 1, True),       # (unet16.py:30)
+    ('convT 4x4 s2 tile w16', 1, 14, 12, [(64, 64)],       32, 4, 2, 1, True),
     ('2x2 tile co24',    1, 30, 33, [(64, 64)],            24, 2, 1, 1, False),      # (and '2x2 head co1' above: linknet.py:45)
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
@@ -208,7 +210,7 @@ def test_strided_wgrad_takes_the_tile_kernel(case):
     rt = Runtime('cuda', 'bf16')
     w = torch.zeros((Ci, Co, k, k) if transposed else (Co, Ci, k, k), device='cuda')
     op = ConvOp(rt, w, None, segs, s, p, transposed, need_dgrad=True)
-    assert len(SX_CASES) == 13
+    assert len(SX_CASES) == 15
     assert min(op.plan(H, W)['nslab']) > 1, op.plan(H, W)['nslab']
 
 
