@@ -388,6 +388,14 @@ int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const void* in, 
  * stats: BatchNorm statistics of the FINAL stored values (fp64 [SEGNB_STAT_REPLICAS][2][Co]) or NULL.  bf16, Ci % 64 == 0,
  * Ci >= 128, Co > 32, W >= 12 (segnb_upconv_fprop_acc_ok); other shapes keep the 9-tap launch over the concat buffer. */
 int segnb_upconv_fprop_acc_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype);
+/* The forward of a ConvTranspose2d(k=4, stride=2, pad=1) itself (unet16.py:30, DecoderBlock) on that kernel: the same four
+ * phases in one launch, but nothing is accumulated -- out = bias + the phase sums -- and bias (fp32, bias_n <= Co entries, or
+ * NULL / 0) is added in the accumulator staging.  wpacked = [4][CoW][4][Ci] as above (the packed matrices of
+ * segnb.convplan.convt_fwd(4, 2, 1)'s launches, contiguous).  *_ok: 1 if served (else the four phase launches of
+ * segnb_conv_fprop). */
+int segnb_upconv_fprop_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype);
+int segnb_upconv_fprop(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co, int CoW,
+                       const float* bias, int bias_n, void* out, int ld_out, double* stats, segnb_stream_t stream);
 int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co,
                            int CoW, void* out, int ld_out, double* stats, segnb_stream_t stream);
 int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,

@@ -225,6 +225,38 @@ class AbiEmulator(object):
             S[1] += (v * v).sum(0)
         return 0
 
+    def segnb_upconv_fprop_ok(self, N, H, W, Ci, Co, ld_out, dtype):
+        return int(dtype == BF16 and Ci % 64 == 0 and Ci >= 128 and W >= 12)
+
+    def segnb_upconv_fprop(self, dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, bias, bias_n, out_p, ld_out, stats, stream):
+        """out = bias + the four phase sums (ConvTranspose2d(4, 2, 1) forward): zero, then the accumulating form, bias folded
+        into the first rounding"""
+        dt = _tdt(dtype)
+        O = _nhwc(out_p, N, 2 * H, 2 * W, Co, ld_out, dt)
+        from segnb import convplan as cpl
+        U = _nhwc(in_p, N, H, W, Ci, ld_in, dt).float()
+        Wm = _mem(wp, 4 * CoW * 4 * Ci, dt).view(4, CoW, 4, Ci).float()
+        _, launches, full = cpl.convt_fwd(H, W, 4, 4, 2, 1)
+        assert full and len(launches) == 4
+        Up = torch.nn.functional.pad(U, (0, 0, 1, 1, 1, 1))
+        b = torch.zeros(Co)
+        if bias is not None and bias_n > 0:
+            b[:bias_n] = _mem(bias, bias_n, torch.float32)
+        res = torch.zeros(N, 2 * H, 2 * W, Co)
+        for ph, l in enumerate(launches):
+            acc = torch.zeros(N, H, W, Co)
+            for t, (dh, dw, _, _) in enumerate(l.taps):
+                acc += Up[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W, :] @ Wm[ph, :Co, t, :].t()
+            res[:, l.oh0::2, l.ow0::2, :] = acc + b
+        stored = res.to(dt)
+        O.copy_(stored)
+        if stats is not None:
+            S = _mem(stats, REPL * 2 * Co, torch.float64).view(REPL, 2, Co)[0]
+            v = stored.double().reshape(-1, Co)
+            S[0] += v.sum(0)
+            S[1] += (v * v).sum(0)
+        return 0
+
     def segnb_conv_fprop_upd_ok(self, g, dtype):
         g = _geom(g)
         return int(g.ntaps == 16 and g.in_step == 2)       # (the emulator serves every geometry: the segmented plan is exercised)

@@ -45,6 +45,7 @@ struct FdArgs {
     // [N][H/2][W/2][up_ld]; the other channels are stored as usual.  up_out == NULL: off
     bf16_t* up_out;
     int up_C, up_ld;
+    int no_prev;    // UPF: 1 = nothing to accumulate into (a transposed convolution's own forward: segnb_upconv_fprop)
     int P32;              // plane gather with 32-channel planes: a K chunk = two planes (halves of every LDS row)
     int RPS;              // 2 x 2-window forms: store rows of the previous tile carried per step (1 or 2)
     int NTLR, CoW;        // phase forward (WsCfg::UPF): channel tiles per phase (NTL = 4 * NTLR), weight rows per phase

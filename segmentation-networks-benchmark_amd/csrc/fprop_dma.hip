@@ -625,7 +625,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         for (int j = 0; j < TN16; ++j) {
                             const int ch = n_base + wn * C::WN + 16 * j + 4 * g4;
                             uint2 v = make_uint2(0u, 0u);
-                            if (opix >= 0 && ch < a.Co)
+                            if (opix >= 0 && ch < a.Co && !a.no_prev)
                                 v = *reinterpret_cast<const uint2*>(a.out + (long long)opix * a.ld_out + ch);
                             prev[i][j] = v;
                         }
@@ -1082,16 +1082,18 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
 // phases (py, px); wpacked = [4][CoW][4][Ci] (phase-major, the tap lists of segnb.convplan.convt_fwd(4, 2, 1)); statistics of
 // the sums.  1 = launched, 0 = not served
 int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, unsigned in_bytes, const void* wpacked,
-                        unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream) {
+                        unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream,
+                        const float* bias, int bias_n, int no_prev) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
-    if (Ci % 64 != 0 || Ci < 128 || Co <= 32 || W < 12) return 0;
+    if (Ci % 64 != 0 || Ci < 128 || (Co <= 32 && !no_prev) || W < 12) return 0;
     FdArgs a;
     a.x = (const bf16_t*)in;
     a.w = (const bf16_t*)wpacked;
     a.x_bytes = in_bytes;
     a.w_bytes = w_bytes;
-    a.bias = nullptr;
-    a.bias_n = 0;
+    a.bias = bias;
+    a.bias_n = bias_n;
+    a.no_prev = no_prev;
     a.out = (bf16_t*)out;
     a.stats = stats;
     a.N = N; a.H = H; a.W = W; a.Hi = H; a.Wi = W;
@@ -1160,6 +1162,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.dbg = 0;
         a.u = nullptr;
         a.up_out = nullptr;
+    a.no_prev = 0;
         a.bn_y = nullptr;
         a.ep_act = -1;
         a.ep_coef = nullptr;
@@ -1202,6 +1205,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     a.up_out = nullptr;
+    a.no_prev = 0;
     a.u = nullptr;
     if (uc != nullptr) {
         // virtual concat: in = the skip tensor (channels Cu.. of the logical input), uc->u = the low-resolution tensor

@@ -548,6 +548,7 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
     }
     a.dbg = segnb_knob_fprop_dma_dbg();
     a.up_out = nullptr;
+    a.no_prev = 0;
     if (upsum != nullptr) {
         // (segnb_upcat_src reused as the destination: u = the low-resolution gradient, Cu = leading channels that go there)
         if (upsum->Cu % 8 != 0 || upsum->Cu <= 0 || upsum->Cu >= g->Co || (g->Ho & 1) || (g->Wo & 1) || stats != nullptr ||

@@ -277,6 +277,12 @@ class ConvOp(object):
         p['fwd'], p['fwd_full'] = fwd, full
         p['dg'], p['dg_full'] = dg, dg_full
         p['wp_fwd'] = [rt.zeros((self.Cop, len(l.taps) * self.Cip)) for l in fwd]
+        if self.transposed and (self.KH, self.KW, self.stride, self.pad) == (4, 4, 2, 1) and len(fwd) == 4 and full and \
+                self.out_hw_override is None:
+            # ConvTranspose2d(4, 2, 1): the four phase matrices in ONE buffer [4][Cop][4 * Cip] -- segnb_upconv_fprop runs the
+            # phases as one launch where it serves the shape
+            p['wp_fwd_all'] = rt.zeros((4, self.Cop, 4 * self.Cip))
+            p['wp_fwd'] = [p['wp_fwd_all'][i] for i in range(4)]
         p['tapoff_fwd'] = [nv.int_array([a * self.KW + b for (_, _, a, b) in l.taps]) for l in fwd]
         if self.need_dgrad:
             p['wp_dg'] = [rt.zeros((self.Cip, len(l.taps) * self.Cop)) for l in dg]
@@ -392,6 +398,14 @@ class ConvOp(object):
             _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
                    lambda: nv.call('segnb_conv_fprop_act', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
                                    self.Co if b is not None else 0, yv.ptr, ep, rt.stream))
+            return
+        if type(self) is ConvOp and 'wp_fwd_all' in p and \
+                nv.query('segnb_upconv_fprop_ok', xv.N, xv.H, xv.W, self.Cip, self.Cop, yv.ld, rt.code):
+            ex = 2.0 * xv.N * xv.H * xv.W * 16 * self.Ci * self.Co
+            _timed('conv_fprop', ex,
+                   lambda: nv.call('segnb_upconv_fprop', rt.code, xv.N, xv.H, xv.W, self.Cip, xv.ld, xv.ptr,
+                                   nv.ptr(p['wp_fwd_all']), self.Cop, self.Cop, nv.ptr(b), self.Co if b is not None else 0,
+                                   yv.ptr, yv.ld, nv.ptr(stats), rt.stream))
             return
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)

@@ -115,6 +115,10 @@ CONV_CASES = [
     ('1x1 tile c304',    2, 16, 16, [(304, 304)],          304, 1, 1, 0, False),
     ('convT 4x4 s2 tile', 2, 24, 26, [(72, 72)],           64, 4, 2, 1, True),       # (unet16.py:30)
     ('convT 4x4 s2 tile w16', 1, 14, 12, [(64, 64)],       32, 4, 2, 1, True),
+    # ConvTranspose2d(4, 2, 1) forward as ONE launch of the four phases (segnb_upconv_fprop): >= 128 input channels
+    ('convT 4x4 s2 upf', 2, 16, 20, [(128, 128)],          64, 4, 2, 1, True),
+    ('convT 4x4 s2 upf co32', 1, 24, 24, [(192, 192)],     32, 4, 2, 1, True),
+    ('convT 4x4 s2 upf co24', 1, 14, 12, [(128, 128)],     24, 4, 2, 1, True),
     ('2x2 tile co24',    1, 30, 33, [(64, 64)],            24, 2, 1, 1, False),      # (and '2x2 head co1' above: linknet.py:45)
     ('convT 4x4 s2 p1',  2, 8,  9,  [(32, 32)],            32, 4, 2, 1, True),
     ('convT 3x3 s2 p0',  2, 7,  8,  [(48, 48)],            40, 3, 2, 0, True),
