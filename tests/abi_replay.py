@@ -117,6 +117,11 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
     # serves, the emulator every size: the two call sequences must be the same)
     orig_force = E.UpCatConvOp.force_segmented
     E.UpCatConvOp.force_segmented = True
+    # ... and the upsampled copy materialised on both sides (the device reads the low-resolution tensor only where
+    # segnb_conv_upcat_ok finds kernels for the channel counts, the emulator everywhere; the virtual concat has its own per-op
+    # test against the materialised form, test_hip_ops.py::test_upcat_segmented_backward_vs_torch)
+    orig_vcat = E.UpCatConvOp.virtual_concat
+    E.UpCatConvOp.virtual_concat = False
 
     def ptr(t, offset_elems=0):
         rec.reg(t)
@@ -200,6 +205,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
         nv.set_backend_for_testing(None)
         nv.ptr, nv.call, E.View.ptr = orig_ptr, orig_call, orig_vptr
         E.UpCatConvOp.force_segmented = orig_force
+        E.UpCatConvOp.virtual_concat = orig_vcat
         E.Runtime.overlap_wgrad = overlap
         _zf._ZFUnetPlan.use_cplan = cplan
         _net.HipNet.use_cplan = cplan_net
