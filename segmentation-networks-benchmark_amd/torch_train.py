@@ -127,14 +127,17 @@ def save_snapshot(model, optimizer, loss, epoch, train_history, snapshot_file):
 
 
 def restore_snapshot(model, optimizer, snapshot_file):
-    """torch_train.py:319-330 -> (start_epoch, train_history DataFrame, best_loss).  Checkpoints written by the
+    """torch_train.py:319-330 -> (start_epoch, train_history DataFrame -- the stored dict where pandas is absent --, best_loss).  Checkpoints written by the
     reference load here and vice versa (same keys, same state_dict names)."""
-    import pandas as pd
     checkpoint = torch.load(snapshot_file, map_location='cpu', weights_only=False)
     start_epoch = checkpoint['epoch'] + 1
     best_loss = checkpoint['loss']
     model.load_state_dict(checkpoint['model'])
     if optimizer is not None:
         optimizer.load_state_dict(checkpoint['optimizer'])
-    train_history = pd.DataFrame.from_dict(checkpoint['train_history'])
+    try:                                    # (the reference returns a DataFrame; without pandas the stored dict is returned as is)
+        import pandas as pd
+        train_history = pd.DataFrame.from_dict(checkpoint['train_history'])
+    except ImportError:
+        train_history = checkpoint['train_history']
     return start_epoch, train_history, best_loss

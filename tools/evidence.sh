@@ -1,7 +1,7 @@
 #!/bin/bash
 # The measurement set behind profiles/rNN_*: run on the GPU box from the repository root as
-#     bash tools/evidence.sh r02
-# Writes under gpurun_out/<tag>_*; the summaries that are judged are then copied into profiles/ (tools/evidence_collect.py).
+#     bash tools/evidence.sh r03
+# Writes under gpurun_out/<tag>_*; the summaries that are judged are then copied into profiles/ by hand.
 # rocprofv3: the python program directly after "--" (no env / bash -c hop), counters in passes of their own.
 set -u
 TAG=${1:-r03}
@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_f
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_pmc_sq2.log 2>&1
-for m in linknet34 fcdensenet103; do
+for m in linknet34 fcdensenet103 unet16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_$m -- python3 $R/bench.py --model $m --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timer > $O/${TAG}_prof_$m.log 2>&1
   find $O/${TAG}_prof_$m -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_${m}_kernel_stats.csv
   rm -rf $O/${TAG}_prof_$m
@@ -50,6 +50,7 @@ python3 tools/host_profile.py --plan-profile > $O/${TAG}_host_profile.txt 2>&1
 python3 tools/model_bench.py --steps 10 > $O/${TAG}_model_bench.txt 2>&1
 python3 tools/conv_sites.py --model linknet34 --top 30 > $O/${TAG}_conv_sites_linknet34.txt 2>&1
 python3 tools/conv_sites.py --model fcdensenet103 --top 30 > $O/${TAG}_conv_sites_fcdensenet103.txt 2>&1
+python3 tools/conv_sites.py --model unet16 --size 1024 --batch 4 --top 30 > $O/${TAG}_conv_sites_unet16.txt 2>&1
 for m in linknet34 fcdensenet103 unet16; do python3 bench.py --model $m --no-cpu-baseline >> $O/${TAG}_bench_models.json 2>/dev/null; done
 rm -rf $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq1 $O/${TAG}_pmc_sq2 $O/${TAG}_prof_stats
 echo evidence done
