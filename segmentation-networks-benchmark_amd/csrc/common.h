@@ -136,6 +136,9 @@ int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
                        bool partial);
 int segnb_wgrad_sx_slabs(const segnb_conv_geom* g);
+// forward / data gradient of strided, transposed-phase, 2x2, 1x1 and 16-channel-multiple convolutions on halo tiles (fprop_sx.hip)
+int segnb_fprop_sx_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n, void* out,
+                       double* stats, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // element helpers: 8 channels per thread ("chunk8"), fp32 math

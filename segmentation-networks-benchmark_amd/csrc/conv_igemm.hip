@@ -1293,6 +1293,8 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         }
         if (rc == 0 && !general_only && ep == nullptr)
             rc = segnb_fprop_s1_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
+        if (rc == 0 && !general_only && ep == nullptr)
+            rc = segnb_fprop_sx_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;
