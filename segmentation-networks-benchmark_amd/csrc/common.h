@@ -95,6 +95,7 @@ int segnb_knob_fprop_deepk();     // 1: conv_fprop_deepk_kernel serves the shape
 int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
+int segnb_knob_fprop_roll();     // 0: off, 1: conv_roll_kernel with 16-column strips, 2: 32-column strips (segnb_tune "fprop_roll")
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients
 int segnb_knob_conv_cus();        // CUs the persistent fprop / dgrad kernels size their grids for (segnb_tune "conv_cu_pct")
 int segnb_fprop_dma_read_stamps(unsigned long long* host_dst);
@@ -111,6 +112,10 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
                        hipStream_t stream, const segnb_bn_reduce_epilogue* bn = nullptr,
                        const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr,
                        const segnb_upcat_src* upsum = nullptr);
+// rolling-window kernel for the thin layers, weights in registers, no block-level synchronisation (fprop_roll.hip)
+int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked, unsigned w_bytes,
+                         const float* bias, int bias_n, void* out, double* stats, hipStream_t stream,
+                         const segnb_bn_reduce_epilogue* bn = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);

@@ -1279,6 +1279,8 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
         // (the affine + activation epilogue lives in the c8, rw, ws and general kernels: s1 is skipped for it)
         rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
+        if (rc == 0 && !general_only && ep == nullptr)
+            rc = segnb_fprop_roll_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats, (hipStream_t)stream);
         if (rc == 0 && !general_only)
             rc = segnb_fprop_rw_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats,
                                     (hipStream_t)stream, nullptr, ep);
@@ -1486,8 +1488,9 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
     const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
     SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
-    const int rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr,
-                                      (hipStream_t)stream, ep);
+    int rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+    if (rc == 0)
+        rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
     if (rc != 1) {
         segnb_set_error("segnb_conv_fprop_bnreduce: the fused kernel refused the launch (%d)", rc);
         return rc > 1 ? rc : SEGNB_E_BADARG;

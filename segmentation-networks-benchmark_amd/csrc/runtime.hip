@@ -205,6 +205,14 @@ int segnb_knob_fprop_dma_cfg() {
 }
 static int g_fprop_rw = 1;
 int segnb_knob_fprop_rw() { return g_fprop_rw && segnb_knob_fprop_dma_cfg() < 0; }
+static int g_fprop_roll = -2;      // conv_roll_kernel (fprop_roll.hip): 0 off, 1 = 16-column strips, 2 = 32-column strips
+int segnb_knob_fprop_roll() {
+    if (g_fprop_roll == -2) {
+        const char* e = getenv("SEGNB_FPROP_ROLL");
+        g_fprop_roll = e != nullptr ? atoi(e) : 2;
+    }
+    return segnb_knob_fprop_dma() ? g_fprop_roll : 0;
+}
 static int g_conv_cu_pct = 100;
 int segnb_knob_conv_cus() {
     const int n = segnb_num_cus() * g_conv_cu_pct / 100;
@@ -271,6 +279,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_dma_cfg") == 0) {
         g_fprop_dma_cfg = value < 0 ? -1 : value;
+        return 0;
+    }
+    if (strcmp(key, "fprop_roll") == 0) {
+        g_fprop_roll = value < 0 ? 0 : value;
         return 0;
     }
     if (strcmp(key, "fprop_rw") == 0) {

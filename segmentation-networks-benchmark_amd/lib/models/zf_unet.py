@@ -161,6 +161,7 @@ class _ZFUnetPlan(object):
             self._add(name, blk, seg1, True, upcat=self.subpixel)
         self._bufs = {}
         self._pack_tables = {}
+        self._retired_tables = []
         self._packed_key = None
         self._cplans = {}
         self.generation = 0
@@ -259,8 +260,13 @@ class _ZFUnetPlan(object):
         N = self._last_N if N is None else N
         self._last_N = N
         key = (N, H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr())
-        t = self._pack_tables.get((H, W))
+        # keyed by the FULL geometry: a recorded backward list / HIP graph holds the raw device pointer of its unpack job
+        # tables, so a forward at the same H x W with another batch size (validation, a partial last batch) must not
+        # replace -- and thereby free -- the tables a list recorded for the first batch size still points at
+        t = self._pack_tables.get((N, H, W))
         if t is None or t[0] != key:
+            if t is not None:
+                self._retired_tables.append(t)       # (lists recorded against the old flat buffers keep valid pointers)
             convs = self._conv_sizes(H, W)
             pj_early, pj = [], []
             for ci, (conv, h, w) in enumerate(convs):
@@ -278,7 +284,7 @@ class _ZFUnetPlan(object):
                 los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
             t = (key, (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
                        PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight')), tuple(unpacks), tuple(los))
-            self._pack_tables[(H, W)] = t
+            self._pack_tables[(N, H, W)] = t
         return t
 
     def _unpack_group(self, H, W, gi):

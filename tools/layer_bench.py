@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--mf16', type=int, default=None, help='segnb_tune fprop_mf16 (0/1)')
     ap.add_argument('--rwsw', type=int, default=None, help='segnb_tune rw_store_waves (2/4)')
     ap.add_argument('--nostats', type=int, default=None, help='segnb_tune fprop_nostats (0/1)')
+    ap.add_argument('--roll', type=int, default=None, help='segnb_tune fprop_roll (0/1/2)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     ap.add_argument('--wgrad-unpack', type=int, default=0,
                     help='1: time the per-layer unpack (packed fp32 workspace -> parameter-layout gradient) with the '
@@ -52,6 +53,8 @@ def main():
         nv.call('segnb_tune', b'fprop_mf16', args.mf16)
     if args.rw is not None:
         nv.call('segnb_tune', b'fprop_rw', args.rw)
+    if args.roll is not None:
+        nv.call('segnb_tune', b'fprop_roll', args.roll)
     if args.cfg is not None:
         nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
     f, N, S = 32, args.batch, args.size
