@@ -343,6 +343,44 @@ typedef struct {
 } segnb_bn_reduce_epilogue;
 int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
 
+/* CONSUMER-SIDE BatchNorm: a convolution (or weight-gradient) operand that is NOT in memory -- it is recomputed from what the
+ * producing layer left there while the kernel stages its input rows (conv_roll_kernel, fprop_roll.hip):
+ *   SEGNB_TF_ACT    operand = round(drop * act((src - mean) * scale + shift)): what segnb_bn_act_fwd would have written from the
+ *                   pre-BatchNorm tensor src (`in` of the launch) -- the _Conv3BN activation of lib/models/zf_unet.py:12-17 applied by
+ *                   the NEXT convolution's loads; the activated tensor never exists;
+ *   SEGNB_TF_BNBWD  operand = dy = a * (dz - c1 - yhat * c2), dz = src * drop * act'(z): what segnb_bn_bwd_apply(_direct) would
+ *                   have written from the incoming gradient src (`in`; with act = SEGNB_ACT_NONE: dz itself) and this layer's
+ *                   pre-BatchNorm output y -- the data gradient of a layer without its BatchNorm-backward apply pass
+ *                   (lib/modules/abn/functions.py:118 folded into the consumer).  Evaluated in fp32 in a folded form:
+ *                   equal to the two-launch form up to fp32 rounding before the one bf16 rounding (fprop_roll.hip).
+ * coef = [4][Cp] of segnb_bn_finalize, bcoef = [3][Cp] of segnb_bn_bwd_finalize, drop = [N][Cp] Dropout2d multipliers or NULL.
+ * Pixels outside the image are zero AFTER the transform (the zero padding of the convolution).  segnb_conv_fprop_tf takes the
+ * statistics / BatchNorm-reduce epilogues of segnb_conv_fprop / segnb_conv_fprop_bnreduce (stats, bn: either may be NULL). */
+#define SEGNB_TF_ACT 1
+#define SEGNB_TF_BNBWD 2
+typedef struct {
+    int kind;
+    const void* y;
+    int ld_y;
+    const float* coef;
+    const float* bcoef;
+    const float* drop;
+    int Cp;
+    int act;
+    float slope;
+} segnb_operand_tf;
+int segnb_conv_fprop_tf_ok(const segnb_conv_geom* g, int dtype, int kind);
+int segnb_conv_fprop_tf(const segnb_conv_geom* g, int dtype, const void* in, const segnb_operand_tf* tf, const void* wpacked,
+                        const float* bias, int bias_n, void* out, double* stats, const segnb_bn_reduce_epilogue* bn,
+                        segnb_stream_t stream);
+/* The weight gradient of such a layer (segnb_conv_wgrad's protocol, result in slab 0 of dwp): tf_in (SEGNB_TF_ACT or NULL) describes
+ * how `in` becomes the convolution's input x, tf_dout (SEGNB_TF_BNBWD or NULL) how `dout` (g or dz) and tf_dout->y become dy.  With
+ * both, the data gradient (segnb_conv_fprop_tf) and the weight gradient of a layer read the same three tensors -- g, y and the
+ * producing layer's y -- and neither the activated input nor dy is ever written (conv_wgrad_roll_kernel, wgrad_roll.hip). */
+int segnb_conv_wgrad_tf_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_wgrad_tf(const segnb_conv_geom* g, int dtype, const void* in, const segnb_operand_tf* tf_in, const void* dout,
+                        const segnb_operand_tf* tf_dout, float* dwp, int nslab, segnb_stream_t stream);
+
 /* 1 if segnb_conv_fprop serves this 4x4 / stride-2 gather (ntaps 16, in_step 2: the data gradient of an
  * Upsample(scale_factor=2) -> conv3x3 segment on the low-resolution grid, lib/models/zf_unet.py:42,78-90; also the data gradient
  * of ConvTranspose2d(4, 2, 1), unet16.py:38 / linknet.py:16) on the plane-gather form of the direct-to-LDS pipeline; 0: it

@@ -275,6 +275,59 @@ class AbiEmulator(object):
         return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, e.coef, e.act, e.slope, None,
                                             out_p, gg.ld_out, None, 0, None, 0, None, 0, e.sums, None, 0, stream)
 
+    # ---- operands recomputed on load (segnb_operand_tf): materialise the operand with the two-launch form, then the plain op
+    def segnb_conv_fprop_tf_ok(self, g, dtype, kind):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
+                   and g.Hi == g.Ho and g.Wi == g.Wo and g.Ci == 32 and g.Co <= 32 and kind in (1, 2))
+
+    def segnb_conv_wgrad_tf_ok(self, g, dtype):
+        return self.segnb_conv_fprop_tf_ok(g, dtype, 1)
+
+    def _tf_operand(self, tf, src, ld_src, N, H, W, C, dtype):
+        """-> dense [N,H,W,C] tensor of `dtype`: the operand a segnb_operand_tf describes"""
+        tf = _geom(tf)
+        assert tf.Cp == C, 'the emulator takes transforms over exactly the channels of the operand'
+        tmp = torch.zeros(N * H * W * C, dtype=_tdt(dtype))
+        if tf.kind == 1:
+            self.segnb_bn_act_fwd(dtype, src, ld_src, N, H, W, C, tf.coef, tf.act, tf.slope, tf.drop, tmp.data_ptr(), C,
+                                  None, 0, None, 0, None, 0, 0)
+        else:
+            assert tf.kind == 2 and not tf.drop
+            self.segnb_bn_bwd_apply_direct(dtype, tf.y, tf.ld_y, N, H, W, C, tf.coef, tf.bcoef, tf.act, tf.slope, src, ld_src,
+                                           tmp.data_ptr(), C, None, C, 0)
+        return tmp
+
+    @staticmethod
+    def _regeom(g, **kw):
+        g2 = type(g)()
+        ctypes.memmove(ctypes.addressof(g2), ctypes.addressof(g), ctypes.sizeof(g))
+        for k, v in kw.items():
+            setattr(g2, k, v)
+        return g2
+
+    def segnb_conv_fprop_tf(self, g, dtype, in_p, tf, wp, bias, bias_n, out_p, stats, bn, stream):
+        gg = _geom(g)
+        tmp = self._tf_operand(tf, in_p, gg.ld_in, gg.N, gg.Hi, gg.Wi, gg.Ci, dtype)
+        g2 = self._regeom(gg, ld_in=gg.Ci)
+        rc = self.segnb_conv_fprop(g2, dtype, tmp.data_ptr(), wp, bias, bias_n, out_p, stats, stream)
+        if rc or not bn:
+            return rc
+        e = _geom(bn)
+        return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, e.coef, e.act, e.slope, None,
+                                            out_p, gg.ld_out, None, 0, None, 0, None, 0, e.sums, None, 0, stream)
+
+    def segnb_conv_wgrad_tf(self, g, dtype, in_p, tf_in, dout_p, tf_dout, dwp, nslab, stream):
+        gg = _geom(g)
+        kw, keep = {}, []
+        if tf_in:
+            keep.append(self._tf_operand(tf_in, in_p, gg.ld_in, gg.N, gg.Hi, gg.Wi, gg.Ci, dtype))
+            in_p, kw['ld_in'] = keep[-1].data_ptr(), gg.Ci
+        if tf_dout:
+            keep.append(self._tf_operand(tf_dout, dout_p, gg.ld_out, gg.N, gg.Ho, gg.Wo, gg.Co, dtype))
+            dout_p, kw['ld_out'] = keep[-1].data_ptr(), gg.Co
+        return self.segnb_conv_wgrad(self._regeom(gg, **kw), dtype, in_p, dout_p, dwp, nslab, stream)
+
     # slab count of the emulated device: stride-1 3x3 bf16 launches write EMU_SLABS partial slabs (the HIP library
     # derives its count from the CU count); everything else accumulates into one zeroed slab
     EMU_SLABS = 3

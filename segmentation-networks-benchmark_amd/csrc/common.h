@@ -65,6 +65,9 @@ inline const segnb_bn_reduce_epilogue* segnb_plan_keep(const segnb_bn_reduce_epi
 inline const segnb_upcat_src* segnb_plan_keep(const segnb_upcat_src* g) {
     return g ? (const segnb_upcat_src*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
+inline const segnb_operand_tf* segnb_plan_keep(const segnb_operand_tf* g) {
+    return g ? (const segnb_operand_tf*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
 inline const segnb_act_epilogue* segnb_plan_keep(const segnb_act_epilogue* g) {
     return g ? (const segnb_act_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
@@ -115,7 +118,7 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
 // rolling-window kernel for the thin layers, weights in registers, no block-level synchronisation (fprop_roll.hip)
 int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked, unsigned w_bytes,
                          const float* bias, int bias_n, void* out, double* stats, hipStream_t stream,
-                         const segnb_bn_reduce_epilogue* bn = nullptr);
+                         const segnb_bn_reduce_epilogue* bn = nullptr, const segnb_operand_tf* tf = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);
@@ -137,6 +140,12 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
                        hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr,
                        const segnb_upcat_src* uc = nullptr);      // partial: leave the nslab slabs unreduced
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
+void segnb_slab_reduce(float* dwp, long long total, int nslab, hipStream_t stream);
+// rolling-window weight gradient of the thin layers (wgrad_roll.hip); tfx / tfd: operands recomputed on load (or NULL)
+bool segnb_wgrad_roll_applies(const segnb_conv_geom* g);
+int segnb_wgrad_roll_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
+                         bool partial, const segnb_operand_tf* tfx = nullptr, const segnb_operand_tf* tfd = nullptr);
+int segnb_knob_wgrad_roll();
 // strided / wide-window tile kernel (wgrad_s1.hip: conv_wgrad_sx_kernel): same protocol
 int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
                        bool partial);

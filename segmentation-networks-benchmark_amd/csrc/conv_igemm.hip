@@ -1533,7 +1533,9 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        if (rc == 0)
+            rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;
@@ -1589,6 +1591,35 @@ extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, con
     }
     if (rc == 0) {
         segnb_set_error("segnb_conv_wgrad_bnapply: no kernel for this geometry");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
+// weight gradient whose operands are recomputed on load (include/segnb_hip.h: segnb_operand_tf)
+extern "C" int segnb_conv_wgrad_tf_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || wgrad_general_only()) return 0;
+    return (segnb_wgrad_roll_applies(g) && segnb_wgrad_s1_slabs(g) > 0) ? 1 : 0;
+}
+
+extern "C" int segnb_conv_wgrad_tf(const segnb_conv_geom* g, int dtype, const void* in, const segnb_operand_tf* tf_in,
+                                   const void* dout, const segnb_operand_tf* tf_dout, float* dwp, int nslab,
+                                   segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_wgrad_tf, g, dtype, in, tf_in, dout, tf_dout, dwp, nslab, stream);
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_conv_wgrad_tf_ok(g, dtype), "geometry not served (segnb_conv_wgrad_tf_ok)");
+    SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
+    SEGNB_CHECK_ARG(tf_in == nullptr || (tf_in->kind == SEGNB_TF_ACT && tf_in->coef != nullptr && tf_in->Cp >= g->Ci), "bad input transform");
+    SEGNB_CHECK_ARG(tf_dout == nullptr || (tf_dout->kind == SEGNB_TF_BNBWD && tf_dout->coef && tf_dout->bcoef && tf_dout->y &&
+                                           tf_dout->drop == nullptr && tf_dout->Cp >= g->Co), "bad dout transform");
+    const int rc = segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, tf_in, tf_dout);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_conv_wgrad_tf: no kernel for this geometry");
         return SEGNB_E_UNSUPPORTED;
     }
     return rc;

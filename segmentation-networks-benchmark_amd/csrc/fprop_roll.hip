@@ -49,6 +49,19 @@ struct RollArgs {
     double* bn_sums;
     int bn_act;
     float bn_slope;
+    // transform of the input on its way into LDS (template parameter TF):
+    //   TF = 1  x holds the PRE-BatchNorm output y of the producing layer; the convolution's operand is
+    //           round(drop * act((y - mean) * scale + shift)) -- bn_act_fwd_kernel's expression -- and never exists in memory
+    //   TF = 2  x holds the gradient g (or dz) of this layer's activation, x2 its pre-BatchNorm output y; the operand is
+    //           dy = round(a * (dz - c1 - yhat * c2)), dz = round(g * drop * act'(z)) -- bn_bwd_apply_kernel's direct form
+    const bf16_t* x2;
+    unsigned x2_bytes;
+    int ld_x2;
+    const float* tf_coef;     // [4][tf_Cp]: scale, shift, mean, invstd (segnb_bn_finalize)
+    const float* tf_bcoef;    // [3][tf_Cp]: a, c1, c2 (segnb_bn_bwd_finalize); TF = 2 only
+    const float* tf_drop;     // [N][tf_Cp] Dropout2d multipliers or NULL
+    int tf_Cp, tf_act;
+    float tf_slope;
 };
 
 template <int CI>
@@ -64,22 +77,50 @@ __device__ __forceinline__ void unpack8(const u32x4_t& v, float (&f)[8]) {
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// 8 per-channel constants from an LDS table, re-read at every use: the index is laundered through an empty asm so that the
+// loop-invariant loads are not hoisted back into (40-56) registers
+__device__ __forceinline__ void lds_const8(const float* table, int idx, float (&v)[8]) {
+    asm volatile("" : "+v"(idx));
+    const float4 a = *reinterpret_cast<const float4*>(table + idx);
+    const float4 b = *reinterpret_cast<const float4*>(table + idx + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// ReLU of two packed bf16 values: a negative bf16 is a negative int16 (v_pk_max_i16; -0 -> +0)
+__device__ __forceinline__ unsigned relu_pk2bf(unsigned pk) {
+    const s16x2_t z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pk), z));
+}
+
 // KS: 32-channel K steps of the input (Ci = 32 * KS); COF: 16-channel output fragments (Co <= 16 * COF, COF even);
-// NF: 16-pixel fragments per strip row
-template <int KS, int COF, int NF, bool STATS, bool BNRED>
-__global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
+// NF: 16-pixel fragments per strip row; EPI: 0 plain, 1 BatchNorm statistics of the output, 2 BatchNorm-backward reduction
+// of the producing layer; TF: input transform (RollArgs); DL: rows of global loads in flight per wave (register sets);
+// WPS: waves per SIMD the register allocation is held to (2: <= 256 registers, 1: <= 512)
+template <int KS, int COF, int NF, int EPI, int TF, int DL, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
     constexpr int CI = 32 * KS, CPP = CI / 8, PXB = CI * 2, RW = 16 * NF + 2, ROWB = RW * PXB;
     constexpr int NLD = (RW * CPP + 63) / 64;
     constexpr int NP = COF / 2;                      // 32-channel output pairs
+    constexpr bool STATS = EPI == 1, BNRED = EPI == 2;
+    constexpr int UN = DL % 3 == 0 ? DL : 3 * DL;    // unroll: ring slot (i % 3) and register set (i % DL) both static
     static_assert(COF % 2 == 0, "output fragments are stored in pairs");
+    static_assert(TF == 0 || 64 % CPP == 0, "a lane's channel chunk must not depend on the load instruction");
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][3 * ROWB];
     __shared__ double red[2][16 * COF];
+    // per-channel constants of the input transform / the BatchNorm-reduce epilogue live in LDS, not in registers (the weights
+    // hold 72-144 of the 256): a lane re-reads the 8 values of its chunk where it uses them (same address in 16 lanes: broadcast)
+    __shared__ __attribute__((aligned(16))) float tfc[TF == 0 ? 1 : 5][TF == 0 ? 4 : CI];
+    __shared__ __attribute__((aligned(16))) float bnc[2][BNRED ? 16 * COF : 4];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* const my = smem[wave];
     const int n16 = lane & 15, g = lane >> 4;
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(TF == 2 ? a.x2 : a.x), 0, TF == 2 ? (int)a.x2_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
@@ -111,21 +152,17 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = h * 16 + g * 4 + e;
-            bs[h][e] = (a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;
+            bs[h][e] = (!BNRED && a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;      // (a data gradient has no bias)
         }
-    float bsc[NP][8], bsh[NP][8], bmu[NP][8];
+    // BatchNorm-reduce epilogue: z = y * sc + shh decides act'(z); the second sum is taken over dz * y (raw) and centred at
+    // the flush, in fp64: sum dz * (y - mean) = sum dz * y - mean * sum dz (two constants per channel instead of three)
     float bneg = 0.f;
     if constexpr (BNRED) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = p * 32 + cidx * 8 + e;
-                const bool in = c < a.Co;
-                bsc[p][e] = in ? a.bn_coef[c] : 0.f;
-                bsh[p][e] = in ? a.bn_coef[a.Co + c] : 0.f;
-                bmu[p][e] = in ? a.bn_coef[2 * a.Co + c] : 0.f;
-            }
+        for (int c = threadIdx.x; c < 16 * COF; c += 256) {
+            const bool in = c < a.Co;
+            bnc[0][c] = in ? a.bn_coef[c] : 0.f;
+            bnc[1][c] = in ? a.bn_coef[a.Co + c] - a.bn_coef[2 * a.Co + c] * a.bn_coef[c] : 0.f;
+        }
         bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
     }
     float s1[NP][8], s2[NP][8];
@@ -134,15 +171,40 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[p][e] = s2[p][e] = 0.f;
 
+    // ---- input transform: per-channel constants of THIS lane's chunk (lane & (CPP - 1): the same for every load)
+    // TF = 1: exactly bn_act_fwd_kernel's expression.  TF = 2 in a folded form (5 constants per channel instead of 7; the
+    // registers are the budget here): with z = y * sc + shh (shh = shift - mean * scale), sel = act'(z),
+    //   dy = a * (g * drop * sel) + (B * y + C),   B = -a * c2 * invstd,  C = a * (c2 * invstd * mean - c1)
+    // = a * (dz - c1 - yhat * c2) of bn_bwd_apply_kernel up to fp32 rounding (dz is not rounded to bf16 in between: it is
+    // exact for ReLU without dropout, the timed configuration's direct layers, and for dz inputs with act = NONE).
+    float tneg = 0.f;
+    const int tc0 = (lane % CPP) * 8;
+    if constexpr (TF != 0) {
+        for (int c = threadIdx.x; c < CI; c += 256) {
+            const float sc = a.tf_coef[c], sh = a.tf_coef[a.tf_Cp + c], mu = a.tf_coef[2 * a.tf_Cp + c];
+            tfc[0][c] = sc;
+            if constexpr (TF == 1) {
+                tfc[1][c] = sh;
+                tfc[2][c] = mu;
+            } else {
+                const float is = a.tf_coef[3 * a.tf_Cp + c];
+                const float ba = a.tf_bcoef[c], c1 = a.tf_bcoef[a.tf_Cp + c], c2 = a.tf_bcoef[2 * a.tf_Cp + c];
+                tfc[1][c] = sh - mu * sc;
+                tfc[2][c] = ba;
+                tfc[3][c] = -ba * c2 * is;
+                tfc[4][c] = ba * (c2 * is * mu - c1);
+            }
+        }
+        tneg = a.tf_act == SEGNB_ACT_RELU ? 0.f : (a.tf_act == SEGNB_ACT_LEAKY ? a.tf_slope : 1.f);
+    }
+    if (TF != 0 || BNRED) __syncthreads();
+
     // ---- per-lane constants of the row image
     int woff[NLD];                 // LDS byte offset this lane's chunk of load m lands at (-1: no chunk)
-    int wj[NLD], wc[NLD];
 #pragma unroll
     for (int m = 0; m < NLD; ++m) {
         const int L = 64 * m + lane;
         const int j = L / CPP, c = L % CPP;
-        wj[m] = j;
-        wc[m] = c;
         woff[m] = j < RW ? j * PXB + ((c ^ roll_sw<CI>(j)) << 4) : -1;
     }
     int roff[3][NF][KS];           // fragment (dx, f, ks): pixel j = 16 f + n16 + dx, chunk q = 4 ks + g
@@ -166,43 +228,128 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
         const int nin = rows + 2;
         const int c0 = strip * 16 * NF;
 
-        unsigned coff[NLD];
+        unsigned coff[NLD], coff2[NLD];
+        bool colv[NLD];
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
-            const int col = c0 - 1 + wj[m];
-            coff[m] = (woff[m] >= 0 && (unsigned)col < (unsigned)a.W) ? (unsigned)(col * a.ld_x * 2 + wc[m] * 16) : OOB;
+            const int L = 64 * m + lane;
+            const int col = c0 - 1 + L / CPP;
+            colv[m] = woff[m] >= 0 && (unsigned)col < (unsigned)a.W;
+            coff[m] = colv[m] ? (unsigned)(col * a.ld_x * 2 + (L % CPP) * 16) : OOB;
+            coff2[m] = (TF == 2 && colv[m]) ? (unsigned)(col * a.ld_x2 * 2 + (L % CPP) * 16) : OOB;
         }
-        u32x4_t ld[3][NLD];
+        // TF = 1: the Dropout2d multiplier of the image (>= 0) folds into the affine map, drop * act(z) = act(drop * z) for
+        // the "negative side scaled" activations: two constants per channel, in registers, and for ReLU the activation is one
+        // packed integer maximum on the rounded pair (bn_act_fwd_kernel rounds drop * act(z) computed from (y - mean) * scale
+        // + shift: the folded form differs by fp32 rounding before the one bf16 rounding)
+        float q1[8], q0[8];
+        if constexpr (TF == 1) {
+            float tsc[8], tsh[8], tmu[8];
+            lds_const8(tfc[0], tc0, tsc);
+            lds_const8(tfc[1], tc0, tsh);
+            lds_const8(tfc[2], tc0, tmu);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dm = a.tf_drop != nullptr ? a.tf_drop[n * a.tf_Cp + tc0 + e] : 1.f;
+                q1[e] = tsc[e] * dm;
+                q0[e] = (tsh[e] - tmu[e] * tsc[e]) * dm;
+            }
+        }
+        u32x4_t ld[DL][NLD], ld2[TF == 2 ? DL : 1][NLD];
         auto issue = [&](auto set_c, int i) {
             constexpr int set = decltype(set_c)::value;
             const int gi = r0 - 1 + i;
             const bool rv = i < nin && (unsigned)gi < (unsigned)a.H;
-            const unsigned rowbase = (unsigned)((n * a.H + gi) * a.W) * (unsigned)(a.ld_x * 2);
+            const unsigned pixrow = (unsigned)((n * a.H + gi) * a.W);
 #pragma unroll
             for (int m = 0; m < NLD; ++m) {
-                const unsigned voff = rv ? rowbase + coff[m] : OOB;
+                const unsigned voff = rv ? pixrow * (unsigned)(a.ld_x * 2) + coff[m] : OOB;
                 ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+                if constexpr (TF == 2) {
+                    const unsigned voff2 = rv ? pixrow * (unsigned)(a.ld_x2 * 2) + coff2[m] : OOB;
+                    ld2[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)voff2, 0, 0);
+                }
             }
         };
-        auto publish = [&](auto set_c) {          // row held in register set `set` -> ring slot `set`
-            constexpr int set = decltype(set_c)::value;
+        // row i held in register set `set` -> ring slot `slot`, transformed on the way
+        auto publish = [&](auto set_c, auto slot_c, int i) {
+            constexpr int set = decltype(set_c)::value, slot = decltype(slot_c)::value;
+            const int gi = r0 - 1 + i;
+            const bool rv = (unsigned)gi < (unsigned)a.H;      // rows outside the image are zero AFTER the transform
 #pragma unroll
-            for (int m = 0; m < NLD; ++m)
-                if (woff[m] >= 0) *reinterpret_cast<u32x4_t*>(my + set * ROWB + woff[m]) = ld[set][m];
+            for (int m = 0; m < NLD; ++m) {
+                u32x4_t v = ld[set][m];
+                if constexpr (TF == 1) {
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] * q1[e] + q0[e];
+                    const bool ok = rv && colv[m];
+                    if (tneg == 0.f) {             // ReLU (wave-uniform)
+                        v.x = ok ? relu_pk2bf(pack2bf(f[0], f[1])) : 0u;
+                        v.y = ok ? relu_pk2bf(pack2bf(f[2], f[3])) : 0u;
+                        v.z = ok ? relu_pk2bf(pack2bf(f[4], f[5])) : 0u;
+                        v.w = ok ? relu_pk2bf(pack2bf(f[6], f[7])) : 0u;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * tneg;
+                        v.x = ok ? pack2bf(f[0], f[1]) : 0u;
+                        v.y = ok ? pack2bf(f[2], f[3]) : 0u;
+                        v.z = ok ? pack2bf(f[4], f[5]) : 0u;
+                        v.w = ok ? pack2bf(f[6], f[7]) : 0u;
+                    }
+                } else if constexpr (TF == 2) {
+                    float gq[8], yq[8], tsc[8], tsh[8], tmu[8], tB[8], tC[8];
+                    unpack8(v, gq);
+                    unpack8(ld2[set][m], yq);
+                    lds_const8(tfc[0], tc0, tsc);
+                    lds_const8(tfc[1], tc0, tsh);
+                    lds_const8(tfc[2], tc0, tmu);
+                    lds_const8(tfc[3], tc0, tB);
+                    lds_const8(tfc[4], tc0, tC);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = yq[e] * tsc[e] + tsh[e];
+                        const float dzf = gq[e] * (z > 0.f ? 1.f : tneg);
+                        gq[e] = tmu[e] * dzf + (tB[e] * yq[e] + tC[e]);
+                    }
+                    const bool ok = rv && colv[m];
+                    v.x = ok ? pack2bf(gq[0], gq[1]) : 0u;
+                    v.y = ok ? pack2bf(gq[2], gq[3]) : 0u;
+                    v.z = ok ? pack2bf(gq[4], gq[5]) : 0u;
+                    v.w = ok ? pack2bf(gq[6], gq[7]) : 0u;
+                }
+                if (woff[m] >= 0) *reinterpret_cast<u32x4_t*>(my + slot * ROWB + woff[m]) = v;
+            }
         };
 
         f32x4_t acc[3][NF][COF];
-        u32x4_t yv[NF][NP];
+        u32x4_t yv[3][NF][NP];      // BatchNorm-reduce epilogue: y rows of the output rows, requested three steps ahead
 
-        issue(std::integral_constant<int, 0>{}, 0);
-        issue(std::integral_constant<int, 1>{}, 1);
-        issue(std::integral_constant<int, 2>{}, 2);
-        publish(std::integral_constant<int, 0>{});
-        issue(std::integral_constant<int, 0>{}, 3);
+        static_for<DL>([&](auto k_c) { issue(k_c, decltype(k_c)::value); });
+        publish(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        issue(std::integral_constant<int, 0>{}, DL);
 
-        // step i: row i is in ring slot U = i % 3 (and register set U is already reloading row i + 3)
+        auto issue_y = [&](auto set_c, int o) {
+            constexpr int set = decltype(set_c)::value;
+            const bool rvo = o >= 1 && o <= rows;
+            const unsigned prow = (unsigned)((n * a.H + r0 - 1 + o) * a.W);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int col = c0 + 16 * f + n16;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int ch = p * 32 + cidx * 8;
+                    const bool ok = rvo && col < a.W && ch < a.Co;
+                    const unsigned yoff = ok ? ((prow + (unsigned)col) * (unsigned)a.bn_ld + (unsigned)ch) * 2u : OOB;
+                    yv[set][f][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)yoff, 0, 0);
+                }
+            }
+        };
+        // step i (UI = i % UN): row i is in ring slot i % 3; row i + 1 waits in register set (i + 1) % DL
         auto step = [&](auto u_c, int i) {
-            constexpr int U = decltype(u_c)::value, U1 = (U + 1) % 3, U2 = (U + 2) % 3;
+            constexpr int UI = decltype(u_c)::value;
+            constexpr int U = UI % 3, U1 = (U + 1) % 3, U2 = (U + 2) % 3, S1 = (UI + 1) % DL;
             // -- E1: output row o = i - 2 (accumulator slot U1, final since step i - 1) leaves
             const int o = i - 2;
             const bool ev = o >= 1 && o <= rows;
@@ -230,10 +377,6 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
                         const bool ok = col < a.W && ch < a.Co;
                         const unsigned voff = ok ? ((prow + (unsigned)col) * (unsigned)a.ld_out + (unsigned)ch) * 2u : OOB;
                         __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)voff, 0, 0);
-                        if constexpr (BNRED) {
-                            const unsigned yoff = ok ? ((prow + (unsigned)col) * (unsigned)a.bn_ld + (unsigned)ch) * 2u : OOB;
-                            yv[f][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)yoff, 0, 0);
-                        }
                     }
                 }
             }
@@ -248,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
                         for (int ks = 0; ks < KS; ++ks)
                             fr[dx][f][ks] = *reinterpret_cast<const bf16x8_t*>(my + U * ROWB + roff[dx][f][ks]);
             }
-            // -- row i + 1 into the ring, its register set reloads row i + 4
-            if (i + 1 < nin) publish(std::integral_constant<int, U1>{});
-            if (i + 4 < nin) issue(std::integral_constant<int, U1>{}, i + 4);
+            // -- row i + 1 into the ring, its register set reloads row i + 1 + DL
+            if (i + 1 < nin) publish(std::integral_constant<int, S1>{}, std::integral_constant<int, U1>{}, i + 1);
+            if (i + 1 + DL < nin) issue(std::integral_constant<int, S1>{}, i + 1 + DL);
             // -- MFMAs: kernel row dy of input row i adds to output row i + 1 - dy
             if (i < nin) {
                 if (i + 1 <= rows) {
@@ -310,26 +453,26 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
                             }
                         } else {
                             // dz = round(g * act'(z)), z = (y - mean) * scale + shift: the arithmetic of bn_act_bwd_reduce_kernel
-                            float yq[8];
-                            unpack8(yv[f][p], yq);
+                            float yq[8], bsc[8], bsh[8];
+                            unpack8(yv[U1][f][p], yq);
+                            lds_const8(bnc[0], p * 32 + cidx * 8, bsc);
+                            lds_const8(bnc[1], p * 32 + cidx * 8, bsh);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                const float yc = yq[e] - bmu[p][e];
-                                const float z = yc * bsc[p][e] + bsh[p][e];
+                                const float z = yq[e] * bsc[e] + bsh[e];
                                 const float dv = bf16_bits_to_f32(f32_to_bf16_bits(v[e] * (z > 0.f ? 1.f : bneg))) * m;
                                 s1[p][e] += dv;
-                                s2[p][e] += dv * yc;
+                                s2[p][e] += dv * yq[e];
                             }
                         }
                     }
                 }
             }
+            // -- the y row of output row i + 1 (stored at step i + 3): set (i + 1) % 3 = U1, free since E2 above
+            if constexpr (BNRED) issue_y(std::integral_constant<int, U1>{}, i + 1);
         };
-        for (int ib = 0; ib < nin + 1; ib += 3) {
-            step(std::integral_constant<int, 0>{}, ib);
-            step(std::integral_constant<int, 1>{}, ib + 1);
-            step(std::integral_constant<int, 2>{}, ib + 2);
-        }
+        for (int ib = 0; ib < nin + 1; ib += UN)
+            static_for<UN>([&](auto u_c) { step(u_c, ib + decltype(u_c)::value); });
     }
 
     if constexpr (STATS || BNRED) {
@@ -338,10 +481,12 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v1 = s1[p][e], v2 = s2[p][e];
+                double v1 = (double)s1[p][e], v2 = (double)s2[p][e];
                 if constexpr (BNRED) {
                     const int c = p * 32 + cidx * 8 + e;
-                    v2 *= c < a.Co ? a.bn_coef[3 * a.Co + c] : 0.f;           // * invstd: sum dz * yhat
+                    const double mu = c < a.Co ? (double)a.bn_coef[2 * a.Co + c] : 0.0;
+                    const double is = c < a.Co ? (double)a.bn_coef[3 * a.Co + c] : 0.0;
+                    v2 = (v2 - mu * v1) * is;                                  // sum dz * (y - mean) * invstd = sum dz * yhat
                 }
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) {
@@ -349,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
                     v2 += __shfl_xor(v2, o);
                 }
                 if (n16 == 0) {
-                    atomicAdd(&red[0][p * 32 + cidx * 8 + e], (double)v1);
-                    atomicAdd(&red[1][p * 32 + cidx * 8 + e], (double)v2);
+                    atomicAdd(&red[0][p * 32 + cidx * 8 + e], v1);
+                    atomicAdd(&red[1][p * 32 + cidx * 8 + e], v2);
                 }
             }
         __syncthreads();
@@ -363,28 +508,29 @@ __global__ __launch_bounds__(256, 2) void conv_roll_kernel(const RollArgs a) {
     }
 }
 
-template <int KS, int COF, int NF>
+template <int KS, int COF, int NF, int TF, int DL, int WPS>
 int launch_roll(RollArgs& a, hipStream_t stream) {
     a.NSTRIP = (a.W + 16 * NF - 1) / (16 * NF);
-    // segment height: the whole launch should be about one round of the chip's wave slots (2 blocks x 4 waves per CU)
-    const int slots = segnb_num_cus() * 8;
-    int sr = a.H;
-    for (int nseg = 1; nseg <= a.H; ++nseg) {
-        sr = (a.H + nseg - 1) / nseg;
-        if ((long long)a.N * a.NSTRIP * nseg >= slots * 7 / 8 || sr <= 14) break;
-    }
+    // segment height: the whole launch should be about one round of the chip's wave slots (WPS blocks x 4 waves per CU)
+    // (the most segments per strip that still give every wave at most ONE task; short segments when even whole strips
+    // outnumber the wave slots)
+    const int slots = segnb_num_cus() * 4 * WPS;
+    int nseg = (int)(slots / ((long long)a.N * a.NSTRIP));
+    if (nseg < 1) nseg = (a.H + 15) / 16;
+    if (nseg > a.H) nseg = a.H;
+    const int sr = (a.H + nseg - 1) / nseg;
     a.SR = sr;
     a.NSEG = (a.H + sr - 1) / sr;
     a.NTASK = a.N * a.NSEG * a.NSTRIP;
     int blocks = (a.NTASK + 3) / 4;
-    const int maxb = segnb_num_cus() * 2;
+    const int maxb = segnb_num_cus() * WPS;
     if (blocks > maxb) blocks = maxb;
     if (a.stats != nullptr)
-        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, true, false>), dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 1, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
     else if (a.bn_y != nullptr)
-        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, false, true>), dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 2, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, false, false>), dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 0, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
     return 0;
 }
 
@@ -393,7 +539,7 @@ int launch_roll(RollArgs& a, hipStream_t stream) {
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked, unsigned w_bytes,
                          const float* bias, int bias_n, void* out, double* stats, hipStream_t stream,
-                         const segnb_bn_reduce_epilogue* bn) {
+                         const segnb_bn_reduce_epilogue* bn, const segnb_operand_tf* tf) {
     const int knob = segnb_knob_fprop_roll();
     if (!knob) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
@@ -424,6 +570,8 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     a.N = g->N; a.H = g->Ho; a.W = g->Wo;
     a.Ci = g->Ci; a.Co = g->Co; a.ld_x = g->ld_in; a.ld_out = g->ld_out;
     a.Ktot = 9 * g->Ci;
+    a.x2 = nullptr;
+    a.tf_coef = a.tf_bcoef = a.tf_drop = nullptr;
     a.bn_y = nullptr;
     if (bn != nullptr) {
         if (stats != nullptr) return 0;
@@ -437,8 +585,72 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
         a.bn_act = bn->act;
         a.bn_slope = bn->slope;
     }
+    int rc;
+    if (tf != nullptr) {
+        if (tf->Cp < g->Ci || tf->coef == nullptr) return 0;
+        a.tf_coef = tf->coef;
+        a.tf_bcoef = tf->bcoef;
+        a.tf_drop = tf->drop;
+        a.tf_Cp = tf->Cp;
+        a.tf_act = tf->act;
+        a.tf_slope = tf->slope;
+        if (tf->kind == SEGNB_TF_ACT) {
+            if (bn != nullptr) return 0;
+            rc = launch_roll<1, 2, 1, 1, 3, 2>(a, stream);
+        } else if (tf->kind == SEGNB_TF_BNBWD) {
+            if (tf->y == nullptr || tf->bcoef == nullptr || stats != nullptr || tf->ld_y % 8 != 0) return 0;
+            const long long yb = (((long long)g->N * g->Hi * g->Wi - 1) * tf->ld_y + g->Ci) * 2;
+            if (yb >= (1ll << 31)) return 0;
+            a.x2 = (const bf16_t*)tf->y;
+            a.x2_bytes = (unsigned)yb;
+            a.ld_x2 = tf->ld_y;
+            rc = launch_roll<1, 2, 1, 2, 3, 2>(a, stream);
+        } else {
+            return 0;
+        }
+        return rc ? rc : 1;
+    }
     // 32-column strips (more bytes in flight per wave, 6 % instead of 12 % halo columns) where the registers allow it: the
     // BatchNorm-reduce epilogue's per-channel constants do not fit beside them
-    const int rc = (knob == 2 && bn == nullptr) ? launch_roll<1, 2, 2>(a, stream) : launch_roll<1, 2, 1>(a, stream);
+    rc = (knob == 2 && bn == nullptr) ? launch_roll<1, 2, 2, 0, 3, 2>(a, stream) : launch_roll<1, 2, 1, 0, 3, 2>(a, stream);
     return rc ? rc : 1;
+}
+
+static bool roll_tf_geom_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || !segnb_knob_fprop_roll() || getenv("SEGNB_FPROP_GENERAL") != nullptr) return false;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != g->Ho || g->Wi != g->Wo) return false;
+    if (g->Ci != 32 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return false;
+    for (int t = 0; t < 9; ++t)
+        if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return false;
+    return (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2 < (1ll << 31);
+}
+
+// include/segnb_hip.h: convolution whose input operand is recomputed from what the producing layer left in memory
+extern "C" int segnb_conv_fprop_tf_ok(const segnb_conv_geom* g, int dtype, int kind) {
+    return (roll_tf_geom_ok(g, dtype) && (kind == SEGNB_TF_ACT || kind == SEGNB_TF_BNBWD)) ? 1 : 0;
+}
+
+extern "C" int segnb_conv_fprop_tf(const segnb_conv_geom* g, int dtype, const void* in, const segnb_operand_tf* tf,
+                                   const void* wpacked, const float* bias, int bias_n, void* out, double* stats,
+                                   const segnb_bn_reduce_epilogue* bn, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_tf, g, dtype, in, tf, wpacked, bias, bias_n, out, stats, bn, stream);
+    SEGNB_CHECK_ARG(g && in && tf && wpacked && out, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_tf_ok(g, dtype, tf->kind), "geometry not served (segnb_conv_fprop_tf_ok)");
+    SEGNB_CHECK_ARG(tf->coef != nullptr && tf->Cp >= g->Ci && tf->Cp % 8 == 0, "bad transform coefficients");
+    SEGNB_CHECK_ARG(tf->kind != SEGNB_TF_BNBWD || (tf->y != nullptr && tf->bcoef != nullptr && stats == nullptr && tf->drop == nullptr),
+                    "bad BNBWD transform (a dropout layer hands over dz with act = NONE)");
+    SEGNB_CHECK_ARG(tf->kind != SEGNB_TF_ACT || bn == nullptr, "a forward launch has no BatchNorm-reduce epilogue");
+    SEGNB_CHECK_ARG(bn == nullptr || (bn->y && bn->coef && bn->sums && bn->ld_y >= g->Co && bn->ld_y % 8 == 0), "bad epilogue");
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
+    const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    const int rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
+                                        bn, tf);
+    if (rc != 1) {
+        segnb_set_error("segnb_conv_fprop_tf: the kernel refused the launch (%d)", rc);
+        return rc > 1 ? rc : SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
 }

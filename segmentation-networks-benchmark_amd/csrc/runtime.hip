@@ -213,6 +213,14 @@ int segnb_knob_fprop_roll() {
     }
     return segnb_knob_fprop_dma() ? g_fprop_roll : 0;
 }
+static int g_wgrad_roll = -2;      // conv_wgrad_roll_kernel (wgrad_roll.hip): 0 off, 1 on
+int segnb_knob_wgrad_roll() {
+    if (g_wgrad_roll == -2) {
+        const char* e = getenv("SEGNB_WGRAD_ROLL");
+        g_wgrad_roll = e != nullptr ? atoi(e) : 1;
+    }
+    return g_wgrad_roll;
+}
 static int g_conv_cu_pct = 100;
 int segnb_knob_conv_cus() {
     const int n = segnb_num_cus() * g_conv_cu_pct / 100;
@@ -283,6 +291,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_roll") == 0) {
         g_fprop_roll = value < 0 ? 0 : value;
+        return 0;
+    }
+    if (strcmp(key, "wgrad_roll") == 0) {
+        g_wgrad_roll = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_rw") == 0) {

@@ -1104,6 +1104,15 @@ int launch_sx(WgSxArgs& a, int nslab, hipStream_t stream, bool partial) {
 
 }  // namespace
 
+// slab 0 += slabs 1 .. nslab - 1 of a [nslab][total] fp32 workspace, fixed order (shared with wgrad_roll.hip)
+void segnb_slab_reduce(float* dwp, long long total, int nslab, hipStream_t stream) {
+    if (nslab <= 16 && total % 4 == 0)
+        hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<float4*>(dwp), total / 4, nslab);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, dwp, total, nslab);
+}
+
 // partial slabs segnb_conv_wgrad writes for this geometry on the fast path (0: not a fast-path geometry)
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
     const S1Choice c = s1_choose(g);

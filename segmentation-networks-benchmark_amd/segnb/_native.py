@@ -44,6 +44,15 @@ class ActEpilogue(ctypes.Structure):
     _fields_ = [('coef', c_void_p), ('act', c_int), ('slope', c_float)]
 
 
+class OperandTf(ctypes.Structure):
+    """segnb_operand_tf"""
+    _fields_ = [('kind', c_int), ('y', c_void_p), ('ld_y', c_int), ('coef', c_void_p), ('bcoef', c_void_p),
+                ('drop', c_void_p), ('Cp', c_int), ('act', c_int), ('slope', c_float)]
+
+
+TF_ACT, TF_BNBWD = 1, 2
+
+
 class UpcatSrc(ctypes.Structure):
     """segnb_upcat_src"""
     _fields_ = [('u', c_void_p), ('Cu', c_int), ('ld_u', c_int)]
@@ -65,6 +74,10 @@ SIGNATURES = {
     'segnb_conv_fprop_upsum': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(UpcatSrc), _P],
     'segnb_conv_wgrad_upcat': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(UpcatSrc), _P, _P, c_int, _P],
     'segnb_conv_fprop_bnreduce': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
+    'segnb_conv_fprop_tf': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(OperandTf), _P, _P, c_int, _P, _P,
+                            ctypes.POINTER(BnReduceEpilogue), _P],
+    'segnb_conv_wgrad_tf': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(OperandTf), _P, ctypes.POINTER(OperandTf), _P,
+                            c_int, _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_conv_wgrad_partial': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_upconv_fprop': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
@@ -129,7 +142,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_conv_fprop_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

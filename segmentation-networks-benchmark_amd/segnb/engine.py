@@ -471,6 +471,71 @@ class ConvOp(object):
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][li]), None, 0,
                                    dxv.ptr, None, rt.stream), ex)
 
+    # ---- operands recomputed on load (segnb_operand_tf: consumer-side BatchNorm, fprop_roll.hip / wgrad_roll.hip) -------------
+    @staticmethod
+    def tf_act(coef, Cp, act, slope, drop=None):
+        """operand = round(drop * act(BatchNorm(src))): the activation pass of the producing layer, applied by the consumer"""
+        return nv.OperandTf(nv.TF_ACT, None, 0, nv.ptr(coef), None, nv.ptr(drop), Cp, act, slope)
+
+    @staticmethod
+    def tf_bnbwd(yv, coef, bcoef, act, slope):
+        """operand = dy = BatchNorm-backward apply of (src, yv); act = ACT_NONE when src is dz already"""
+        return nv.OperandTf(nv.TF_BNBWD, yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(bcoef), None, yv.Cp, act, slope)
+
+    def fprop_tf_ok(self, xv, yv):
+        p = self.plan(xv.H, xv.W)
+        if self.transposed or len(p['fwd']) != 1 or not p['fwd_full']:
+            return False
+        g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+        return bool(nv.query('segnb_conv_fprop_tf_ok', g, self.rt.code, nv.TF_ACT))
+
+    def fprop_tf(self, xv, tf, yv, stats=None):
+        """forward whose input operand is tf(xv) (xv: the producing layer's pre-BatchNorm output)"""
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        l = p['fwd'][0]
+        g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+        b = self.bias.detach() if self.bias is not None else None
+        _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_tf', g, rt.code, xv.ptr, tf, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
+                               self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), None, rt.stream))
+
+    def dgrad_tf_ok(self, dyv, dxv):
+        p = self.plan(dxv.H, dxv.W)
+        if not self.need_dgrad or len(p['dg']) != 1 or not p['dg_full']:
+            return False
+        g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+        return bool(nv.query('segnb_conv_fprop_tf_ok', g, self.rt.code, nv.TF_BNBWD))
+
+    def dgrad_tf(self, gv, tf, dxv, bn_reduce=None):
+        """data gradient whose dy operand is tf(gv) (gv: the gradient of this layer's activation, or dz); bn_reduce as dgrad()"""
+        p, rt = self.plan(dxv.H, dxv.W), self.rt
+        l = p['dg'][0]
+        g = self._geom(p, 'd', 0, l, gv.N, gv.H, gv.W, self.Cop, gv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+        ep = None
+        if bn_reduce is not None:
+            yv, coef, sums, act, slope = bn_reduce
+            ep = nv.BnReduceEpilogue(yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(sums), act, slope)
+        _timed('conv_fprop', 2.0 * gv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_tf', g, rt.code, gv.ptr, tf, nv.ptr(p['wp_dg'][0]), None, 0, dxv.ptr, None, ep,
+                               rt.stream))
+
+    def wgrad_tf_ok(self, xv, dyv):
+        p = self.plan(xv.H, xv.W)
+        if self.transposed or len(p['fwd']) != 1:
+            return False
+        g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
+        return bool(nv.query('segnb_conv_wgrad_tf_ok', g, self.rt.code))
+
+    def wgrad_tf(self, xv, tfx, dv, tfd):
+        """weight gradient with x = tfx(xv) and dy = tfd(dv) (either transform may be None); the result is left in the
+        packed workspace for the batched unpack, like wgrad(..., unpack=False)"""
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        l = p['fwd'][0]
+        g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dv.H, dv.W, self.Cop, dv.ld)
+        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd, nv.ptr(p['dwp'][0]), p['nslab'][0],
+                               rt.stream))
+
     def wgrad_bnapply_ok(self, xv, yv):
         """True when this convolution's weight gradient can recompute its dy operand -- the BatchNorm-backward apply of the
         layer -- from (g, y) itself (segnb_conv_wgrad_bnapply): the apply pass then disappears for a layer without a data

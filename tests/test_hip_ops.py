@@ -1460,3 +1460,126 @@ def test_conv_fprop_dma_tall_7x7(case):
     yr = F.conv2d(xr, w, b, padding=1)
     yr.backward(dy)
     check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+
+
+# ------------------------------------------------------------------------------------------------------
+# operands recomputed on load (segnb_operand_tf): rolling-window kernels of fprop_roll.hip / wgrad_roll.hip
+# ------------------------------------------------------------------------------------------------------
+def _ulp_close(name, got, ref, frac=2e-3):
+    """bf16 tensors produced by two evaluation orders of the same fp32 expression: equal but for single-ulp flips of a
+    small fraction of the elements (a rounding boundary between the two fp32 values)"""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    diff = (got - ref).abs()
+    ulp = ref.abs().clamp_min(1e-30) * 2.0 ** -7
+    assert bool((diff <= ulp + 1e-30).all()), '%s: more than one bf16 ulp apart (max %g)' % (name, float(diff.max()))
+    nbad = int((diff > 0).sum())
+    assert nbad <= frac * got.numel() + 4, '%s: %d of %d elements differ' % (name, nbad, got.numel())
+
+
+@pytest.mark.parametrize('shape', [(2, 40, 56, 32, 1), (3, 33, 47, 24, 2), (32, 224, 224, 32, 1)], ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_with_operands_recomputed_on_load(shape):
+    """conv3x3(act(BatchNorm(y0))) forward, its data gradient and its weight gradient with the activated input and dy never in
+    memory (segnb_conv_fprop_tf / segnb_conv_wgrad_tf) against the launches they replace: segnb_bn_act_fwd + segnb_conv_fprop,
+    segnb_bn_bwd_apply_direct + segnb_conv_fprop_bnreduce, segnb_conv_wgrad -- and against the emulator's restatement."""
+    N, H, W, C2, act = shape
+    C1 = 32
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 3 + C2)
+    w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    b2 = (torch.randn(C2, generator=gen) * 0.1).cuda()
+    op = ConvOp(rt, w2, b2, [(C1, C1)], 1, 1, False, True)
+    op.pack(H, W)
+    C2p = op.Cop
+    y0 = View.alloc(rt, N, H, W, C1)          # pre-BatchNorm output of the producing layer
+    y0.t.normal_()
+    y0b = View.alloc(rt, N, H, W, C1)         # pre-BatchNorm output of the layer before THAT one (BatchNorm-reduce epilogue)
+    y0b.t.normal_()
+    mk = lambda C: torch.stack([0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen),
+                                0.2 * torch.randn(C, generator=gen), 0.5 + torch.rand(C, generator=gen)]).cuda().contiguous()
+    coef0, coef2 = mk(C1), mk(C2p)
+    coef2[:, C2:] = 0
+    bcoef2 = torch.stack([coef2[0], 0.05 * torch.randn(C2p, generator=gen).cuda(), 0.05 * torch.randn(C2p, generator=gen).cuda()]).contiguous()
+    bcoef2[:, C2:] = 0
+    drop = (torch.rand(N, C1, generator=gen) > 0.3).float().mul(1.0 / 0.7).cuda().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    # ---- forward: reference = activation pass + convolution with statistics
+    a0 = View.alloc(rt, N, H, W, C1)
+    nv.call('segnb_bn_act_fwd', rt.code, y0.ptr, y0.ld, N, H, W, C1, nv.ptr(coef0), act, 0.01, nv.ptr(drop), a0.ptr, a0.ld,
+            None, 0, None, 0, None, 0, st)
+    y2r = View.alloc(rt, N, H, W, C2p)
+    sr = rt.zeros((16, 2, C2p), torch.float64)
+    op.fprop(a0, y2r, sr)
+    assert op.fprop_tf_ok(y0, y2r)
+    y2 = View.alloc(rt, N, H, W, C2p)
+    s2 = rt.zeros((16, 2, C2p), torch.float64)
+    op.fprop_tf(y0, ConvOp.tf_act(coef0, C1, act, 0.01, drop), y2, s2)
+    torch.cuda.synchronize()
+    # the activation is evaluated in a folded fp32 form (drop * scale and drop * (shift - mean * scale) per channel): its
+    # bf16 result differs from the activation pass's by single-ulp flips of a small fraction of the elements
+    check('y', y2.t, y2r.t, 'bf16')
+    assert float((y2.t.float() - y2r.t.float()).abs().mean() / y2r.t.float().abs().mean()) < 1e-3
+    sa, sb = s2.sum(0).cpu().numpy(), sr.sum(0).cpu().numpy()
+    np.testing.assert_allclose(sa, sb, rtol=2e-3, atol=2e-3 * float(np.abs(sb).max()))
+    # ---- backward: g = gradient of this layer's activation; reference = apply pass + data gradient (with reduce) + weight gradient
+    g2 = View.alloc(rt, N, H, W, C2p)
+    g2.t.normal_()
+    g2.dense()[..., C2:] = 0
+    dy = View.alloc(rt, N, H, W, C2p)
+    nv.call('segnb_bn_bwd_apply_direct', rt.code, y2r.ptr, y2r.ld, N, H, W, C2p, nv.ptr(coef2), nv.ptr(bcoef2), act, 0.01,
+            g2.ptr, g2.ld, dy.ptr, dy.ld, None, C2, st)
+    dxr = View.alloc(rt, N, H, W, C1)
+    sums_r = rt.zeros((16, 2, C1), torch.float64)
+    if C2 == 32:
+        op.dgrad(dy, dxr, bn_reduce=(y0b, coef0, sums_r, act, 0.01))
+    else:
+        op.dgrad(dy, dxr)
+    gwr = torch.zeros_like(w2)
+    op.wgrad(a0, dy, gwr)
+    assert op.wgrad_tf_ok(y0, g2)
+    has_dgrad = op.dgrad_tf_ok(g2, dxr)          # (the data gradient's K = this layer's output channels: 32 only)
+    assert has_dgrad == (C2 == 32)
+    tfd = ConvOp.tf_bnbwd(y2r, coef2, bcoef2, act, 0.01)
+    dx = View.alloc(rt, N, H, W, C1)
+    sums = rt.zeros((16, 2, C1), torch.float64)
+    if has_dgrad:
+        op.dgrad_tf(g2, tfd, dx, bn_reduce=(y0b, coef0, sums, act, 0.01))
+    op.wgrad_tf(y0, ConvOp.tf_act(coef0, C1, act, 0.01, drop), g2, tfd)
+    p = op.plan(H, W)
+    gw = torch.zeros_like(w2)
+    nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][0]), nv.ptr(gw), op.Cop, op.Cip, 9, op.s_out, op.s_in, p['tapoff_fwd'][0],
+            nv.ptr(op.out_map), nv.ptr(op.in_map), 1, st)
+    torch.cuda.synchronize()
+    # dy is evaluated in a folded fp32 form: the operand differs from the apply pass's by single bf16-ulp flips of a small
+    # fraction of its elements, so dx / dW agree to that
+    if has_dgrad:
+        check('dx', dx.t, dxr.t, 'bf16')
+        rel = float((dx.t.float() - dxr.t.float()).abs().mean() / dxr.t.float().abs().mean())
+        assert rel < 2e-3, rel
+        a_, b_ = sums.sum(0).cpu().numpy(), sums_r.sum(0).cpu().numpy()
+        assert np.abs(a_ - b_).max() <= 2e-3 * np.abs(b_).max(), (np.abs(a_ - b_).max(), np.abs(b_).max())
+    relw = float((gw - gwr).abs().max() / gwr.abs().max())
+    assert relw < 3e-3, relw
+    if N * H * W <= 20000:
+        with on_emulator():
+            cpu = lambda v: View(v.t.cpu(), v.N, v.H, v.W, v.Cp, v.ld, 0)
+            rte = Runtime('cpu', 'bf16')
+            ope = ConvOp(rte, w2.cpu(), b2.cpu(), [(C1, C1)], 1, 1, False, True)
+            ope.pack(H, W)
+            c0, c2, bc2, dr = coef0.cpu(), coef2.cpu(), bcoef2.cpu(), drop.cpu()
+            y0e, y2re, g2e, y0be = cpu(y0), cpu(y2r), cpu(g2), cpu(y0b)
+            y2e = View.alloc(rte, N, H, W, C2p)
+            ope.fprop_tf(y0e, ConvOp.tf_act(c0, C1, act, 0.01, dr), y2e)
+            check('y vs emulator', y2.t, y2e.t, 'bf16')
+            dxe = View.alloc(rte, N, H, W, C1)
+            se = torch.zeros((16, 2, C1), dtype=torch.float64)
+            tfde = ConvOp.tf_bnbwd(y2re, c2, bc2, act, 0.01)
+            if has_dgrad:
+                ope.dgrad_tf(g2e, tfde, dxe, bn_reduce=(y0be, c0, se, act, 0.01))
+            ope.wgrad_tf(y0e, ConvOp.tf_act(c0, C1, act, 0.01, dr), g2e, tfde)
+            pe = ope.plan(H, W)
+            gwe = torch.zeros_like(w2.cpu())
+            nv.call('segnb_unpack_wgrad', nv.ptr(pe['dwp'][0]), nv.ptr(gwe), ope.Cop, ope.Cip, 9, ope.s_out, ope.s_in,
+                    pe['tapoff_fwd'][0], nv.ptr(ope.out_map), nv.ptr(ope.in_map), 1, 0)
+        if has_dgrad:
+            check('dx vs emulator', dx.t, dxe.t, 'bf16')
+        assert float((gw.cpu() - gwe).abs().max() / gwe.abs().max()) < 3e-3

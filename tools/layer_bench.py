@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--rwsw', type=int, default=None, help='segnb_tune rw_store_waves (2/4)')
     ap.add_argument('--nostats', type=int, default=None, help='segnb_tune fprop_nostats (0/1)')
     ap.add_argument('--roll', type=int, default=None, help='segnb_tune fprop_roll (0/1/2)')
+    ap.add_argument('--wroll', type=int, default=None, help='segnb_tune wgrad_roll (0/1)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     ap.add_argument('--wgrad-unpack', type=int, default=0,
                     help='1: time the per-layer unpack (packed fp32 workspace -> parameter-layout gradient) with the '
@@ -55,6 +56,8 @@ def main():
         nv.call('segnb_tune', b'fprop_rw', args.rw)
     if args.roll is not None:
         nv.call('segnb_tune', b'fprop_roll', args.roll)
+    if args.wroll is not None:
+        nv.call('segnb_tune', b'wgrad_roll', args.wroll)
     if args.cfg is not None:
         nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
     f, N, S = 32, args.batch, args.size
