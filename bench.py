@@ -14,6 +14,12 @@ Prints ONE JSON line on rank 0.  Besides the throughput it carries
                  bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
   cpu_baseline : the oracle's CPU restatement of the same step (oracle/train_step_ref.py, kind "port") on this
                  box's host cores, bounded sample (B=4, a few steps) -- a reported baseline, not a target.
+  box          : what THIS box delivers on two fixed probes run before the timed region -- a compute-bound bf16 GEMM
+                 (TFLOP/s) and a 1 GB device copy (TB/s).  The boxes of the pool differ by 3-5 % in step time
+                 (MI355X_MICROARCH.md, DVFS give-back item 5); `value` / box figures lets two lines from different boxes
+                 be compared.
+  with_logging_syncs : the same step WITH the reference's per-batch logging (torch_train.py:195-210: loss .item(),
+                 gradient abs-max, two metrics, each a host sync) -- SURVEY 8d / BASELINE.md section 2's second number.
 """
 import argparse
 import json
@@ -53,9 +59,46 @@ def cpu_baseline(seconds_budget=20.0):
         train_step_ref.train_step(sd, x, y, 'bce_dice', lr=1e-3)
         n += 1
     dt = time.time() - t0
-    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': round(B * n / dt, 3), 'unit': 'images/s', 'cores': torch.get_num_threads(),
+            'threads': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'affinity_cores': ncpu, 'kind': 'port',
             'sample': 'oracle/train_step_ref.train_step, ZF_UNET fp32 B=4 224x224 bce_dice SGD, %d steps after '
                       '1 warm-up, torch %s CPU' % (n, torch.__version__)}
+
+
+def box_calibration(dev):
+    """Two fixed probes of the box the line was measured on (NOT part of the product: library GEMM and a device copy):
+    a 4096^3 bf16 GEMM repeated for ~50 ms -> TFLOP/s, a 1 GiB device-to-device copy -> TB/s (read + write bytes)."""
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        c = a @ b
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 40
+    e0.record()
+    for _ in range(iters):
+        c = a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1)
+    tf = 2.0 * 4096 ** 3 * iters / (gemm_ms * 1e-3) / 1e12
+    del a, b, c
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_ms = e0.elapsed_time(e1) / 5
+    tbs = 2.0 * (1 << 30) / (copy_ms * 1e-3) / 1e12
+    del src, dst
+    torch.cuda.empty_cache()
+    return {'gemm_bf16_4096_tflops': round(tf, 1), 'gemm_ms': round(gemm_ms, 1), 'copy_1GiB_TBps': round(tbs, 3),
+            'note': 'hipBLASLt bf16 GEMM 4096^3 x %d and a 1 GiB device copy (read + write bytes), before the timed region' % iters}
 
 
 def kernel_sources_digest():
@@ -178,6 +221,7 @@ def main():
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) if ws > 1 else 0)
     torch.cuda.set_device(dev)
     nv.load()
+    box = box_calibration(dev) if rank == 0 else None
 
     # (model constructor, images per GPU, size, algorithmic GFLOP per image fwd+bwd at that size -- SURVEY 8d)
     import warnings
@@ -291,6 +335,34 @@ def main():
             host_ms = t if host_ms is None else min(host_ms, t)
         torch.cuda.synchronize()
 
+    # ---- the same step WITH the reference's per-batch logging (torch_train.py:195-210): loss .item(), the global gradient
+    # abs-max ('train/grad/global_abs_max': one fused reduction over the flat gradient buffer here, a per-parameter loop of
+    # .abs().max().cpu().item() there), and the two metrics -- every one a host sync.  SURVEY 8d / BASELINE.md section 2.
+    logging_ms = None
+    if graph is None and ws == 1:
+        import torch_train as tt
+        mets = tt.default_metrics()
+
+        def step_logged():
+            opt.zero_grad()
+            out = model(x)
+            loss_l = crit(out, y)
+            (x.size(0) * loss_l).backward()
+            opt.step()
+            vals = [loss_l.cpu().item(), tt.grad_global_abs_max(model)]
+            for m in mets.values():
+                vals.append(m(out, y).cpu().item())
+            return vals
+
+        step_logged()
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        nlog = min(args.steps, 10)
+        for _ in range(nlog):
+            logged = step_logged()
+        torch.cuda.synchronize()
+        logging_ms = (time.perf_counter() - tl) / nlog * 1e3
+
     # ---- live per-kernel timing (HIP events on the launch stream).  Event records cannot sit inside a replayed
     # graph, so when the timed region ran from the graph the same step is run eagerly right after it, with the
     # events around every convolution launch; without a graph the events are recorded in the timed region itself.
@@ -338,6 +410,11 @@ def main():
                             any(e.get('state') == 'ready' for e in model._tape.plans.values())),
         'host_enqueue_ms_per_step': None if host_ms is None else round(host_ms, 3),
         'step_mfma_frac': round(value / ws * gflop_img / 1e3 / peak, 4),
+        'box': box,
+        'with_logging_syncs': None if logging_ms is None else {
+            'ms_per_step': round(logging_ms, 3), 'value': round(B / (logging_ms * 1e-3), 2), 'unit': 'images/s',
+            'what': 'the timed step + loss.item() + grad_global_abs_max + %d metrics, each a host sync '
+                    '(torch_train.py:195-210)' % len(mets)},
     }
     if timer is not None:
         summ = timer.summary()
@@ -347,21 +424,21 @@ def main():
         dom = max(summ, key=lambda k: summ[k][2])
         n, tot_ms, tot_fl = summ[dom]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        fams = {'conv_fprop': 'segnb_conv_fprop launches: conv_fprop_ws_kernel / conv_fprop_rw_kernel / '
+        fams = {'conv_fprop': 'segnb_conv_fprop launches: conv_fprop_ws_kernel / conv_roll_kernel / conv_fprop_rw_kernel / '
                               'conv_fprop_c8_kernel / conv_fprop_s1x9_kernel / conv_fprop_kernel (forward + data gradient)',
                 'conv_wgrad': 'segnb_conv_wgrad launches: conv_wgrad_s1x9_kernel / conv_wgrad_kernel'}
         out['kernel_sources_digest'] = kernel_sources_digest()
-        out['roofline'] = {'kernel': fams.get(dom, dom), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
-                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+        # `achieved` / `frac` count the FLOPs the launches EXECUTE; the ALGORITHMIC rate of SURVEY 8d (the reference's 3x3 taps
+        # over every input channel) is reported beside it -- where a launch issues fewer (the low-resolution data gradient
+        # of an upsampled segment: 16 instead of 36 multiply-adds per low-resolution pixel) the algorithmic figure is higher
+        ex_ratio = (timer.executed.get(dom, 0.0) / timer.algorithmic[dom]) if timer.algorithmic.get(dom) else 1.0
+        out['roofline'] = {'kernel': fams.get(dom, dom), 'bound': 'mfma', 'achieved': round(ach * ex_ratio, 2), 'peak': peak,
+                           'unit': 'TFLOP/s', 'frac': round(ach * ex_ratio / peak, 4),
+                           'algorithmic_tflops': round(ach, 2), 'algorithmic_frac': round(ach / peak, 4),
                            'traffic': pmc_traffic(dom, args.model),
                            'launches_per_step': n // timer_steps,
                            'avg_launch_us': round(tot_ms / n * 1e3, 2),
                            'flops_per_launch': round(tot_fl / n),
-                           # `achieved` counts the ALGORITHMIC FLOPs of SURVEY 8d (the reference's 3x3 taps over every input
-                           # channel); where a launch issues fewer -- the low-resolution data gradient of an upsampled segment:
-                           # 16 instead of 36 multiply-adds per low-resolution pixel -- the executed rate is lower:
-                           'executed_tflops': round(ach * (timer.executed.get(dom, 0.0) / timer.algorithmic[dom])
-                                                    if timer.algorithmic.get(dom) else ach, 2),
                            'share_of_step': round((tot_ms / timer_steps) / (dt * 1e3 / args.steps), 4)}
         out['kernels'] = {k: {'launches_per_step': v[0] // timer_steps, 'ms_per_step': round(v[1] / timer_steps, 3),
                               'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
@@ -378,9 +455,10 @@ def main():
         if algo_bytes:
             hbm['traffic_over_algorithmic'] = round(step_bytes / algo_bytes, 3)
     out['roofline_hbm'] = hbm
-    if 'roofline' in out and hbm.get('frac') is not None:
-        # the step sits under BOTH roofs at once; `bound` names the one it is closer to
-        out['roofline']['bound'] = 'hbm' if hbm['frac'] > out['step_mfma_frac'] else 'mfma'
+    if hbm.get('frac') is not None:
+        # the step sits under BOTH roofs at once (`roofline.frac` is a fraction of the MFMA peak, `roofline_hbm.frac` of the
+        # HBM peak); this names the one the whole step is closer to
+        out['step_bound'] = 'hbm' if hbm['frac'] > out['step_mfma_frac'] else 'mfma'
     if ws == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

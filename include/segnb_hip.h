@@ -258,6 +258,17 @@ int segnb_bn_bwd_apply_fused_direct_acc(int dtype, const void* y, int ld_y, int 
                                         const float* coef, const double* sums, const float* gamma, float* bcoef,
                                         float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
                                         float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
+/* The apply pass of a layer whose dz was never stored (segnb_bn_act_bwd_reduce with dz = NULL, now allowed for every source
+ * combination): the gradient sources are read again, dz is recomputed as the reduction pass computed it (MaxPool2d(2) routing to
+ * the first maximum, 2 x 2 sum of an upsampled gradient, Dropout2d multiplier, act') and dy = round(a * (dz - c1 - yhat * c2)) is
+ * written; (a, c1, c2), dgamma, dbeta and the clearing of the forward statistics as segnb_bn_bwd_apply_fused.  Reads
+ * sources + y, writes dy: one tensor write and one read less than reduce(-> dz) + apply(dz -> dy) (the backward phase of
+ * lib/modules/abn/functions.py:118 without the stored dz).  dy must not alias a source. */
+int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
+                                 const double* sums, const float* gamma, float* bcoef, float* dgamma, float* dbeta,
+                                 int accumulate, double* fwd_stats_to_clear, int act, float slope, const float* dropmul,
+                                 const void* g_direct, int ld_gd, const void* g_pool, int ld_gp, const void* g_up, int ld_gu,
+                                 void* dy, int ld_dy, segnb_stream_t stream);
 
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */

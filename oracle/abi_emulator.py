@@ -735,6 +735,18 @@ class AbiEmulator(object):
         return rc
 
     # ------------------------------------------------------------------------------------------ tiles
+    def segnb_bn_bwd_apply_fused_src(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                     accumulate, clear_stats, act, slope, dropmul, g_direct, ld_gd, g_pool, ld_gp, g_up, ld_gu,
+                                     dy, ld_dy, stream):
+        """dz recomputed from the sources (segnb_bn_act_bwd_reduce into a temporary, no sums), then segnb_bn_bwd_apply_fused"""
+        tmp = torch.zeros(N * H * W * Cp, dtype=_tdt(dtype))
+        rc = self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd, g_pool,
+                                          ld_gp, g_up, ld_gu, tmp.data_ptr(), Cp, None, None, 0, stream)
+        if rc:
+            return rc
+        return self.segnb_bn_bwd_apply_fused(dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
+                                             accumulate, clear_stats, tmp.data_ptr(), Cp, dy, ld_dy, stream)
+
     @staticmethod
     def _d4(k, t):
         """element k of tta_d4_aug applied to an [..., S, S] tensor (rot90 counter-clockwise, then fliplr)"""

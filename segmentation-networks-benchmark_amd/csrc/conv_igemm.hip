@@ -1533,7 +1533,7 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        rc = wgrad_general_only() ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 0)
             rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 1) {

@@ -332,15 +332,98 @@ __device__ __forceinline__ void block_channel_sum2(float (&a)[8], float (&b)[8],
     }
 }
 
+struct BnBwdParams {
+    const double* sums;         // [REPL][2][Cp]: sum dz, sum dz*yhat; read-only in the fused kernel
+    double count;
+    const float* gamma;
+    float* dgamma;
+    float* dbeta;
+    int C, accumulate;
+    float* bcoef;               // [3][Cp] out
+    double* zero_buf;           // fused only: the FORWARD statistics of this layer, cleared for the next step
+};
+
+// bcoef = (gamma*invstd, mean(dz), mean(dz*yhat)); `update` = this thread owns dgamma / dbeta of the channel
+__device__ __forceinline__ void bn_bwd_coef(const BnBwdParams& p, const float* __restrict__ coef, int Cp, int c,
+                                            bool update, float& a, float& c1, float& c2) {
+    a = c1 = c2 = 0.f;
+    if (c >= p.C) return;
+    double v1[REPL], v2[REPL];          // loads first (see bn_fwd_coef)
+#pragma unroll
+    for (int rp = 0; rp < REPL; ++rp) {
+        v1[rp] = p.sums[(rp * 2) * Cp + c];
+        v2[rp] = p.sums[(rp * 2 + 1) * Cp + c];
+    }
+    double sdz = 0.0, sdzy = 0.0;
+#pragma unroll
+    for (int rp = 0; rp < REPL; ++rp) {
+        sdz += v1[rp];
+        sdzy += v2[rp];
+    }
+    const float g = p.gamma != nullptr ? p.gamma[c] : 1.f;
+    a = g * coef[3 * Cp + c];
+    c1 = (float)(sdz / p.count);
+    c2 = (float)(sdzy / p.count);
+    if (update) {
+        if (p.dgamma != nullptr) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sdzy;
+        if (p.dbeta != nullptr) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sdz;
+    }
+}
+
+
+// APPLY mode of bn_act_bwd_reduce_kernel: (a, c1, c2) of the block's channels from the sums (fused finalize, exactly as
+// bn_bwd_apply_kernel does it: the blocks of column 0 publish them, write dgamma / dbeta and clear the forward statistics)
+// + invstd, per thread for its 8 channels.  Ends with a __syncthreads().
+__device__ __forceinline__ void apply_src_coefs(const BnBwdParams& bp, const float* __restrict__ coef, const EwShape& s, int tx,
+                                                int c0, float* sb3, float (&ap)[4][8]) {
+    const int nch = s.CT * 8;                   // (sb3: >= 3 * 32 * 8 floats of LDS)
+    if ((int)threadIdx.x < nch) {
+        const int c = blockIdx.y * nch + threadIdx.x;
+        float a = 0.f, c1 = 0.f, c2 = 0.f;
+        if (c < s.Cp) {
+            const bool owner = blockIdx.x == 0;
+            bn_bwd_coef(bp, coef, s.Cp, c, owner, a, c1, c2);
+            if (owner) {
+                bp.bcoef[c] = a;
+                bp.bcoef[s.Cp + c] = c1;
+                bp.bcoef[2 * s.Cp + c] = c2;
+                if (bp.zero_buf != nullptr) {
+#pragma unroll
+                    for (int rp = 0; rp < REPL; ++rp) {
+                        bp.zero_buf[(rp * 2) * s.Cp + c] = 0.0;
+                        bp.zero_buf[(rp * 2 + 1) * s.Cp + c] = 0.0;
+                    }
+                }
+            }
+        }
+        sb3[threadIdx.x] = a;
+        sb3[256 + threadIdx.x] = c1;
+        sb3[512 + threadIdx.x] = c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ap[0][e] = sb3[tx * 8 + e];
+        ap[1][e] = sb3[256 + tx * 8 + e];
+        ap[2][e] = sb3[512 + tx * 8 + e];
+        ap[3][e] = coef[3 * s.Cp + c0 + e];
+    }
+    __syncthreads();
+}
+
 // one pixel of the backward: gradient sources -> dz, channel sums.  s2 accumulates dz*(y-mean); the
 // caller multiplies by invstd once at the end.
-template <typename T, bool HAS_D, bool HAS_U>
+// APPLY: the second pass of a layer whose dz was never stored (segnb_bn_bwd_apply_fused_src): dz is recomputed from the
+// gradient sources exactly as the reduction pass computed it and leaves as dy = round(a * (dz - c1 - yhat * c2)); s1 = the
+// per-channel (a, c1), s2 = (c2, invstd) constants then (ap[0..3]), nothing is summed
+template <typename T, bool HAS_D, bool HAS_U, bool APPLY = false>
 __device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc)[8], const float (&sh)[8],
                                           const float (&mu)[8], const float (&dm)[8], int act, float slope,
                                           const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_up,
                                           int ld_gu, long long pix, long long up00, long long up_row, int c0,
                                           float (&g)[8], T* __restrict__ dz, int ld_dz, float (&s1)[8],
-                                          float (&s2)[8], const T* __restrict__ res, int ld_res) {
+                                          float (&s2)[8], const T* __restrict__ res, int ld_res,
+                                          const float (*ap)[8] = nullptr) {
     if (HAS_D) {
         float t[8];
         load8(g_direct + pix * ld_gd + c0, t);
@@ -374,24 +457,31 @@ __device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc
         const float yc = yv[e] - mu[e];
         const float z = yc * sc[e] + sh[e] + rv[e];
         const float dv = round_as(g[e] * dm[e] * act_grad(z, act, slope), dz);
-        d[e] = dv;
-        s1[e] += dv;
-        s2[e] += dv * yc;
+        if constexpr (APPLY) {
+            const float yh = yc * ap[3][e];
+            d[e] = round_as(ap[0][e] * (dv - ap[1][e] - yh * ap[2][e]), dz);
+        } else {
+            d[e] = dv;
+            s1[e] += dv;
+            s2[e] += dv * yc;
+        }
     }
-    if (dz != nullptr) store8(dz + pix * ld_dz + c0, d);      // NULL: sums only (segnb_bn_bwd_apply_direct recomputes dz)
+    if (dz != nullptr) store8(dz + pix * ld_dz + c0, d);      // NULL: sums only (the apply pass recomputes dz)
 }
 
-template <typename T, bool HAS_D, bool HAS_P, bool HAS_U>
+template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false>
 __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const T* __restrict__ y, int ld_y, EwShape s, const float* __restrict__ coef, int act, float slope,
     const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
     int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums,
-    const T* __restrict__ res, int ld_res) {
+    const T* __restrict__ res, int ld_res, const BnBwdParams bp) {
     __shared__ float sred[SRED_FLOATS];
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;
     const int c0 = active ? cc * 8 : 0;
+    float ap[4][8];
+    if constexpr (APPLY) apply_src_coefs(bp, coef, s, tx, c0, sred, ap);
     float sc[8], sh[8], mu[8];
     if (coef != nullptr) {          // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
         load8(coef + c0, sc);
@@ -472,9 +562,9 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                     if (!valid[r]) continue;
                     const int hh = 2 * h2 + r;
                     const long long pix = ((long long)n * s.H + hh) * s.W + w;
-                    bwd_pixel<T, false, HAS_U>(yv[r], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
+                    bwd_pixel<T, false, HAS_U, APPLY>(yv[r], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
                                                ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * w, up_row, c0,
-                                               r == 0 ? gtop : gbot, dz, ld_dz, s1, s2, res, ld_res);
+                                               r == 0 ? gtop : gbot, dz, ld_dz, s1, s2, res, ld_res, ap);
                 }
             }
         } else {
@@ -492,13 +582,13 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                 }
                 if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
                 load8(y + (long long)pix * ld_y + c0, yv);
-                bwd_pixel<T, HAS_D, HAS_U>(yv, sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
+                bwd_pixel<T, HAS_D, HAS_U, APPLY>(yv, sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
                                            ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz, ld_dz,
-                                           s1, s2, res, ld_res);
+                                           s1, s2, res, ld_res, ap);
             }
         }
     }
-    if (sums != nullptr) {
+    if (!APPLY && sums != nullptr) {
         if (coef != nullptr) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) s2[e] *= coef[3 * s.Cp + c0 + e];    // sum dz*(y-mean) * invstd = sum dz*yhat
@@ -508,44 +598,6 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
         }
         double* rep = sums + (long long)(blockIdx.x % REPL) * 2 * s.Cp;
         block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + s.Cp, sred);
-    }
-}
-
-struct BnBwdParams {
-    const double* sums;         // [REPL][2][Cp]: sum dz, sum dz*yhat; read-only in the fused kernel
-    double count;
-    const float* gamma;
-    float* dgamma;
-    float* dbeta;
-    int C, accumulate;
-    float* bcoef;               // [3][Cp] out
-    double* zero_buf;           // fused only: the FORWARD statistics of this layer, cleared for the next step
-};
-
-// bcoef = (gamma*invstd, mean(dz), mean(dz*yhat)); `update` = this thread owns dgamma / dbeta of the channel
-__device__ __forceinline__ void bn_bwd_coef(const BnBwdParams& p, const float* __restrict__ coef, int Cp, int c,
-                                            bool update, float& a, float& c1, float& c2) {
-    a = c1 = c2 = 0.f;
-    if (c >= p.C) return;
-    double v1[REPL], v2[REPL];          // loads first (see bn_fwd_coef)
-#pragma unroll
-    for (int rp = 0; rp < REPL; ++rp) {
-        v1[rp] = p.sums[(rp * 2) * Cp + c];
-        v2[rp] = p.sums[(rp * 2 + 1) * Cp + c];
-    }
-    double sdz = 0.0, sdzy = 0.0;
-#pragma unroll
-    for (int rp = 0; rp < REPL; ++rp) {
-        sdz += v1[rp];
-        sdzy += v2[rp];
-    }
-    const float g = p.gamma != nullptr ? p.gamma[c] : 1.f;
-    a = g * coef[3 * Cp + c];
-    c1 = (float)(sdz / p.count);
-    c2 = (float)(sdzy / p.count);
-    if (update) {
-        if (p.dgamma != nullptr) p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + (float)sdzy;
-        if (p.dbeta != nullptr) p.dbeta[c] = (p.accumulate ? p.dbeta[c] : 0.f) + (float)sdz;
     }
 }
 
@@ -988,8 +1040,8 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr, "NULL tensor");
     SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
-    SEGNB_CHECK_ARG(dz != nullptr || (g_direct && !g_pool && !g_up && !dropmul && !res && sums),
-                    "dz may be NULL only for a direct gradient without dropout / residual (sums-only pass)");
+    SEGNB_CHECK_ARG(dz != nullptr || sums != nullptr, "a pass without dz needs the sums (the apply pass recomputes dz: "
+                    "segnb_bn_bwd_apply_direct / segnb_bn_bwd_apply_fused_src)");
     SEGNB_CHECK_ARG(!(res && g_pool), "residual input and pooled gradient cannot be combined");
     const EwShape s = make_shape(N, H, W, Cp);
     const bool hd = g_direct != nullptr, hp = g_pool != nullptr, hu = g_up != nullptr;
@@ -999,7 +1051,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
 #define SEGNB_RED(TT, D, P, U)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U>), grid, dim3(NTHR), 0, (hipStream_t)stream,          \
                        (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
-                       (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res)
+                       (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res, BnBwdParams{})
 #define SEGNB_RED_ALL(TT)                                                       \
     switch (variant) {                                                          \
         case 1: SEGNB_RED(TT, true, false, false); break;                       \
@@ -1146,6 +1198,55 @@ extern "C" int segnb_bn_bwd_apply_fused_direct_acc(int dtype, const void* y, int
     BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
     return launch_bn_bwd_apply(dtype, y, ld_y, N, H, W, Cp, coef, nullptr, nullptr, 0, dy, ld_dy, nullptr, C, bp,
                                "segnb_bn_bwd_apply_fused_direct_acc", stream, g, ld_g, act, slope, true);
+}
+
+// Second pass of a layer whose dz was NEVER stored: the gradient sources are read again and dz recomputed exactly as
+// segnb_bn_act_bwd_reduce (dz = NULL) computed it for the sums -- MaxPool2d routing, Upsample sum, Dropout2d multiplier --
+// and dy = round(a * (dz - c1 - yhat * c2)) leaves; (a, c1, c2) come from the sums inside the launch as in
+// segnb_bn_bwd_apply_fused.  One tensor write and one tensor read less than reduce(-> dz) + apply(dz -> dy).
+extern "C" int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                            const float* coef, const double* sums, const float* gamma, float* bcoef,
+                                            float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
+                                            float slope, const float* dropmul, const void* g_direct, int ld_gd,
+                                            const void* g_pool, int ld_gp, const void* g_up, int ld_gu, void* dy, int ld_dy,
+                                            segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_bwd_apply_fused_src, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, act, slope, dropmul, g_direct, ld_gd, g_pool, ld_gp, g_up, ld_gu, dy, ld_dy, stream);
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y && coef && sums && bcoef && dy && C > 0 && Cp >= C, "NULL tensor / missing sums or coefficient buffer");
+    SEGNB_CHECK_ARG(g_direct || g_pool || g_up, "no gradient source");
+    SEGNB_CHECK_ARG(dy != g_direct && dy != g_pool && dy != g_up, "dy must not alias a gradient source (windows are re-read)");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const bool hd = g_direct != nullptr, hp = g_pool != nullptr, hu = g_up != nullptr;
+    const long long items = hp ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
+    const dim3 grid = make_grid(s, items);
+    const int variant = (hd ? 1 : 0) | (hp ? 2 : 0) | (hu ? 4 : 0);
+    const BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
+#define SEGNB_APS(TT, D, P, U)                                                                                      \
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U, true>), grid, dim3(NTHR), 0, (hipStream_t)stream,    \
+                       (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
+                       (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dy, ld_dy, nullptr, (const TT*)nullptr, 0, bp)
+#define SEGNB_APS_ALL(TT)                                                       \
+    switch (variant) {                                                          \
+        case 1: SEGNB_APS(TT, true, false, false); break;                       \
+        case 2: SEGNB_APS(TT, false, true, false); break;                       \
+        case 3: SEGNB_APS(TT, true, true, false); break;                        \
+        case 4: SEGNB_APS(TT, false, false, true); break;                       \
+        case 5: SEGNB_APS(TT, true, false, true); break;                        \
+        case 6: SEGNB_APS(TT, false, true, true); break;                        \
+        default: SEGNB_APS(TT, true, true, true); break;                        \
+    }
+    if (dtype == SEGNB_BF16) {
+        SEGNB_APS_ALL(bf16_t)
+    } else if (dtype == SEGNB_F32) {
+        SEGNB_APS_ALL(float)
+    } else {
+        segnb_set_error("segnb_bn_bwd_apply_fused_src: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+#undef SEGNB_APS_ALL
+#undef SEGNB_APS
+    SEGNB_LAUNCH_CHECK();
+    return 0;
 }
 
 // torch.optim.RMSprop (alpha, eps; no momentum / centering / weight decay) and torch.optim.Adam (betas, eps; no

@@ -213,11 +213,14 @@ int segnb_knob_fprop_roll() {
     }
     return segnb_knob_fprop_dma() ? g_fprop_roll : 0;
 }
-static int g_wgrad_roll = -2;      // conv_wgrad_roll_kernel (wgrad_roll.hip): 0 off, 1 on
+// conv_wgrad_roll_kernel (wgrad_roll.hip) for the plain segnb_conv_wgrad of the thin layers: 0 off (default), 1 on.  Measured
+// on MI355X: 59.4 us against 60.8 us of conv_wgrad_s1x9_kernel alone, 5.41 / 5.39 against 5.37 / 5.39 ms per step in situ
+// (profiles/r04_ab.txt) -- no gain, so the plain path stays on the tile kernel; segnb_conv_wgrad_tf always runs on it.
+static int g_wgrad_roll = -2;
 int segnb_knob_wgrad_roll() {
     if (g_wgrad_roll == -2) {
         const char* e = getenv("SEGNB_WGRAD_ROLL");
-        g_wgrad_roll = e != nullptr ? atoi(e) : 1;
+        g_wgrad_roll = e != nullptr ? atoi(e) : 0;
     }
     return g_wgrad_roll;
 }

@@ -299,15 +299,15 @@ __global__ __launch_bounds__(WR_WAVES * 64, 2) void conv_wgrad_roll_kernel(const
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                     for (int cf = 0; cf < 2; ++cf) {
-                        const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(xro[dx][cf] + xs));
-                        const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(xro[dx][cf] + xs + 16 * 64));
+                        const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(xro[dx][cf] + xs));
+                        const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(xro[dx][cf] + xs + 16 * 64));
                         Bf[dx * 2 + cf] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
             };
             // A operand: dy^T, 16 channels x 32 pixels; the fragment reads run one kernel row ahead of their MFMAs (the
             // compiler otherwise sinks every read next to its MFMA and the LDS latency is paid 18 times per row)
-            const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(dro + DS * WR_DROWB));
-            const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(dro + DS * WR_DROWB + 16 * 32));
+            const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(dro + DS * WR_DROWB));
+            const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(dro + DS * WR_DROWB + 16 * 32));
             const bf16x8_t A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
             bf16x8_t B0[6], B1[6], B2[6];
             read_group(std::integral_constant<int, 0>{}, B0);
@@ -401,7 +401,6 @@ int launch_wroll(WRollArgs& a, int nslab, hipStream_t stream) {
 }  // namespace
 
 bool segnb_wgrad_roll_applies(const segnb_conv_geom* g) {
-    if (!segnb_knob_wgrad_roll()) return false;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != g->Ho || g->Wi != g->Wo) return false;
     if (g->Ci != 32 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return false;

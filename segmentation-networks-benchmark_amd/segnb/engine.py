@@ -953,6 +953,12 @@ class Stage(object):
     follow it at :31,:41,:42.)"""
 
     direct_apply = os.environ.get('SEGNB_BN_DIRECT_APPLY', '1') != '0'
+    # Layers whose gradient has several sources, a pooled source or a Dropout2d multiplier: dz need not be stored either -- the
+    # apply pass re-reads the sources and recomputes it (segnb_bn_bwd_apply_fused_src: one tensor write and one read less per
+    # layer) for tensors of at least this many MB.  OFF (0) by default: measured on MI355X at 32 MB (the 224 x 224 / 112 x 112
+    # levels), same box, alternating runs, 5.36 / 5.33 ms per step with it against 5.29 / 5.30 without -- the pooled-window walk
+    # of the source pass runs at 3 TB/s where the plain apply pass it replaces runs at 6.4 (profiles/r04_ab.txt).
+    recompute_dz_min_mb = float(os.environ.get('SEGNB_BN_RECOMPUTE_DZ_MB', '0'))
 
     def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
@@ -1065,10 +1071,14 @@ class Stage(object):
         direct = (self.direct_apply and has_bn and g_direct is not None and g_pool is None and g_up is None
                   and dropmul is None)
         assert not reduced or direct, 'only a direct layer can be reduced by its producer'
+        mb = yv.N * yv.H * yv.W * self.Cp * (2 if rt.code == nv.BF16 else 4) / 1e6
+        recompute = (not direct and has_bn and self._fused_fwd and self.recompute_dz_min_mb > 0
+                     and mb >= self.recompute_dz_min_mb)
         if not reduced:
             nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                     self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
-                    vptr(g_up), vld(g_up), None if direct else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0, rt.stream)
+                    vptr(g_up), vld(g_up), None if (direct or recompute) else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0,
+                    rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
         if (dx is None and direct and self._fused_fwd and self.defer_unpack and postponed is None
@@ -1087,6 +1097,13 @@ class Stage(object):
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,
                     nv.ptr(self.stats), self.act, self.slope, g_direct.ptr, g_direct.ld, dz.ptr, dz.ld, rt.stream)
+            self._stats_stale = False
+        elif recompute:
+            nv.call('segnb_bn_bwd_apply_fused_src', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
+                    nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
+                    nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats),
+                    self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
+                    vptr(g_up), vld(g_up), dz.ptr, dz.ld, rt.stream)
             self._stats_stale = False
         elif has_bn and self._fused_fwd:
             nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,

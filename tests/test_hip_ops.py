@@ -1583,3 +1583,80 @@ def test_conv_with_operands_recomputed_on_load(shape):
         if has_dgrad:
             check('dx vs emulator', dx.t, dxe.t, 'bf16')
         assert float((gw.cpu() - gwe).abs().max() / gwe.abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('srcs', ['d+drop', 'd+pool+drop', 'up+drop', 'd+pool', 'd+up'])
+@pytest.mark.parametrize('shape', [(2, 10, 12, 24, nv.ACT_RELU), (3, 9, 7, 40, nv.ACT_LEAKY)], ids=['even relu', 'odd leaky'])
+def test_bn_bwd_apply_from_sources_equals_stored_dz(shape, srcs, dtype):
+    """segnb_bn_act_bwd_reduce(dz = NULL) + segnb_bn_bwd_apply_fused_src == reduce (dz stored) + segnb_bn_bwd_apply_fused, bit for
+    bit, for every source combination of the ZF_UNET plan (direct + Dropout2d, skip + MaxPool2d routing + Dropout2d, Upsample
+    sum): dz is never stored, the apply pass re-reads the sources (lib/models/zf_unet.py:25,31,41-42 backward)."""
+    N, H, W, C, act = shape
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(11)
+    y0 = torch.randn(N, H, W, C, generator=gen)
+    gd0 = torch.randn(N, H, W, C, generator=gen)
+    gp0 = torch.randn(N, H // 2, W // 2, C, generator=gen)
+    gu0 = torch.randn(N, 2 * H, 2 * W, C, generator=gen)
+    gamma = torch.rand(C, generator=gen) + 0.5
+    beta = torch.randn(C, generator=gen) * 0.2
+    drop0 = (torch.rand(N, C, generator=gen) > 0.3).float() / 0.7
+
+    def run(device, stored):
+        rt = Runtime(device, dtype)
+        dev = rt.device
+        def view(src, h, w):
+            v = View.alloc(rt, N, h, w, Cp)
+            v.dense()[..., :C] = src.to(dev, rt.tdtype)
+            return v
+        yv = view(y0, H, W)
+        gd = view(gd0, H, W) if 'd' in srcs.split('+') else None
+        gp = view(gp0, H // 2, W // 2) if 'pool' in srcs else None
+        gu = view(gu0, 2 * H, 2 * W) if 'up' in srcs else None
+        dm = None
+        if 'drop' in srcs:
+            dm = torch.ones(N, Cp, device=dev)
+            dm[:, :C] = drop0.to(dev)
+        stats = torch.zeros(16, 2, Cp, dtype=torch.float64, device=dev)
+        yy = yv.dense().double()
+        stats[0, 0] = yy.sum((0, 1, 2))
+        stats[0, 1] = (yy * yy).sum((0, 1, 2))
+        coef = rt.zeros((4, Cp), torch.float32)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        g_, b_ = gamma.to(dev), beta.to(dev)
+        nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(b_), 1e-5, 0.1,
+                nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1, nv.ptr(coef), rt.stream)
+        stats.fill_(3.0)                       # (the forward statistics a fused apply clears)
+        from segnb.engine import vld, vptr
+        dz = View.alloc(rt, N, H, W, Cp)
+        sums = rt.zeros((16, 2, Cp), torch.float64)
+        nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
+                vptr(gd), vld(gd), vptr(gp), vld(gp), vptr(gu), vld(gu), dz.ptr if stored else None, dz.ld, nv.ptr(sums), None, 0,
+                rt.stream)
+        bcoef = rt.zeros((3, Cp), torch.float32)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dyv = View.alloc(rt, N, H, W, Cp)
+        if stored:
+            nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(g_),
+                    nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 0, nv.ptr(stats), dz.ptr, dz.ld, dyv.ptr, dyv.ld, rt.stream)
+        else:
+            nv.call('segnb_bn_bwd_apply_fused_src', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums),
+                    nv.ptr(g_), nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 0, nv.ptr(stats), act, 0.01, nv.ptr(dm), vptr(gd),
+                    vld(gd), vptr(gp), vld(gp), vptr(gu), vld(gu), dyv.ptr, dyv.ld, rt.stream)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        assert float(stats.abs().max()) == 0.0
+        return dyv.dense().float().cpu(), dgam.cpu(), dbet.cpu(), bcoef.cpu()
+
+    a = run('cuda', True)
+    b = run('cuda', False)
+    for u, v in zip(a, b):
+        if dtype == 'bf16':
+            assert torch.equal(u, v)
+        else:                              # (fp32: no storage rounding between the two passes; fused multiply-adds may differ)
+            torch.testing.assert_close(u, v, rtol=2e-6, atol=2e-6 * float(v.abs().max()))
+    with on_emulator():
+        e = run('cpu', False)
+    check('dy vs emulator', b[0], e[0], dtype)
