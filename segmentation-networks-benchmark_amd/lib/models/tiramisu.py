@@ -11,13 +11,32 @@ center_crop (:86-90, offset always 0) is the iteration bound of the ConvTranspos
 one gradient buffer per stage buffer into which every consumer accumulates.
 
 Pre-activation BatchNorm (norm -> relu -> conv, :12-15) gets its batch statistics from segnb_bn_stats.
-Channel counts must be multiples of 8 (true for FCDenseNet67/103: growth 16, first conv 48).
+
+Channel layout: every tensor the kernels see has a multiple of 8 channels.  With a growth rate (or a first convolution)
+that is not one -- FCDenseNet57, growth 12, tiramisu.py:187-191 -- each layer's slice of the concat buffer is padded to the
+next multiple of 8 (12 -> 16, pad channels zero end to end): a prefix of the buffer is then a list of (real, padded) segments,
+which the convolutions take as their input channel map and the per-channel BatchNorm as one launch set per segment
+(segnb.net.bn_act).  With multiples of 8 (FCDenseNet67 / 103: growth 16, first convolution 48) every list collapses to one
+contiguous segment and the launches are exactly those of the unpadded plan.
 """
 import torch
 from torch import nn
 
 from segnb import _native as nv
-from segnb.net import Act, HipNet, bn_act, conv_unit, head_1x1
+from segnb import convplan as cp
+from segnb.net import Act, HipNet, bn_act, conv_unit, head_1x1, head_from_act
+
+
+def _merge(segs):
+    """[(real, padded), ...] -> one contiguous segment when nothing is padded"""
+    if all(r == p for r, p in segs):
+        t = sum(r for r, _ in segs)
+        return [(t, t)]
+    return list(segs)
+
+
+def _width(segs):
+    return sum(p for _, p in segs)
 
 
 def _holder_forward(self, *a, **k):
@@ -72,10 +91,6 @@ class FCDenseNet(HipNet):
     def __init__(self, in_channels=3, down_blocks=(5, 5, 5, 5, 5), up_blocks=(5, 5, 5, 5, 5), bottleneck_layers=5,
                  growth_rate=16, out_chans_first_conv=48, n_classes=12):
         super(FCDenseNet, self).__init__()
-        if growth_rate % 8 or out_chans_first_conv % 8:
-            raise NotImplementedError('growth_rate and out_chans_first_conv must be multiples of 8 on this engine '
-                                      '(FCDenseNet67 / 103 are; FCDenseNet57 with growth 12 is not wired by the '
-                                      'reference either, torch_train.py:127-128)')
         if len(down_blocks) != len(up_blocks):
             raise ValueError('down_blocks and up_blocks must have the same length')
         self.num_classes = n_classes
@@ -115,21 +130,26 @@ class FCDenseNet(HipNet):
         self._init_engine(in_channels)
 
     # ---- plan ------------------------------------------------------------------------------------------------
-    def _dense_layers(self, tape, layers, buf, gbuf, off0, cin, tag):
-        """Run DenseLayers in place inside buf: layer l reads channels [off0, off0+cin+l*g), writes the next g."""
+    def _dense_layers(self, tape, layers, buf, gbuf, off0, in_segs, tag):
+        """Run DenseLayers in place inside buf (padded channel offset off0): layer l reads the prefix in_segs + l growth
+        slices and writes the next slice (growth_rate real channels in pad8(growth_rate))."""
         g = self.growth_rate
+        gp = cp.pad8(g)
         for l, layer in enumerate(layers):
-            cl = cin + l * g
-            prefix = Act(buf.slice(off0, cl))
-            prefix.g = gbuf.slice(off0, cl) if gbuf is not None else None
-            a = bn_act(tape, prefix, layer.norm, nv.ACT_RELU, tag=tag + '.norm')
-            drop = tape.dropout_table(tape.site(tag + '.drop'), buf.N, g, layer.drop.p)
-            out = conv_unit(tape, a, layer.conv.weight, layer.conv.bias, [(cl, cl)], act=nv.ACT_NONE, dropmul=drop,
-                            out=buf.slice(off0 + cl, g), tag=tag + '.conv')
-            out.g = gbuf.slice(off0 + cl, g) if gbuf is not None else None
+            segs = list(in_segs) + [(g, gp)] * l
+            wl = _width(segs)
+            prefix = Act(buf.slice(off0, wl))
+            prefix.g = gbuf.slice(off0, wl) if gbuf is not None else None
+            ms = _merge(segs)
+            a = bn_act(tape, prefix, layer.norm, nv.ACT_RELU, tag=tag + '.norm', segs=ms if len(ms) > 1 else None)
+            drop = tape.dropout_table(tape.site(tag + '.drop'), buf.N, gp, layer.drop.p)
+            out = conv_unit(tape, a, layer.conv.weight, layer.conv.bias, ms, act=nv.ACT_NONE, dropmul=drop,
+                            out=buf.slice(off0 + wl, gp), tag=tag + '.conv')
+            out.g = gbuf.slice(off0 + wl, gp) if gbuf is not None else None
 
     def _build(self, tape, x, dlogits):
         g, nd = self.growth_rate, len(self.down_blocks)
+        gp = cp.pad8(g)
         N, H, W = x.v.N, x.v.H, x.v.W
         sizes = [(H, W)]
         for _ in range(nd):
@@ -137,73 +157,91 @@ class FCDenseNet(HipNet):
         if min(sizes[-1]) < 1:
             raise ValueError('input too small for %d poolings' % nd)
         need = tape.need_grad
-        # decoder stage i pairs with encoder block d = nd-1-i; convT widths prev_i
+        # encoder block d: its input (real channels cin[d]) + down_blocks[d] growth slices
+        cin = [self._first]
+        for n in self.down_blocks:
+            cin.append(cin[-1] + g * n)
+        block_segs = [[(cin[d], cp.pad8(cin[d]))] + [(g, gp)] * self.down_blocks[d] for d in range(nd)]
+        # decoder stage i pairs with encoder block d = nd-1-i; convT widths prev_i (real)
         prevs = [g * self.bottleneck_layers] + [g * n for n in self.up_blocks[:-1]]
+        stage_segs = []
         ubufs, gbufs = [], []
         for i in range(nd):
             d = nd - 1 - i
-            ch = prevs[i] + self._skips[i] + g * self.up_blocks[i]
+            segs = [(prevs[i], cp.pad8(prevs[i]))] + block_segs[d] + [(g, gp)] * self.up_blocks[i]
+            stage_segs.append(segs)
+            ch = _width(segs)
             ubufs.append(tape.view('U%d' % i, N, sizes[d][0], sizes[d][1], ch))
             gb = tape.view('GU%d' % i, N, sizes[d][0], sizes[d][1], ch) if need else None
             if gb is not None:
                 tape.rt.clear_view(gb)
             gbufs.append(gb)
         # ---- encoder: block d lives in the skip slice of its decoder stage buffer
-        cur = self._first
         inp, inp_seg = x, [(self._in_channels, x.v.Cp)]
         first = True
         for d in range(nd):
             i = nd - 1 - d
-            U, G, off0 = ubufs[i], gbufs[i], prevs[i]
+            U, G, off0 = ubufs[i], gbufs[i], cp.pad8(prevs[i])
+            cur, curp = cin[d], cp.pad8(cin[d])
             if first:
                 o = conv_unit(tape, inp, self.firstconv.weight, self.firstconv.bias, inp_seg, act=nv.ACT_NONE,
-                              out=U.slice(off0, cur), tag='firstconv')
+                              out=U.slice(off0, curp), tag='firstconv')
                 first = False
             else:
-                o = pooled_writer(U.slice(off0, cur))
-            o.g = G.slice(off0, cur) if G is not None else None
-            self._dense_layers(tape, self.denseBlocksDown[d].layers, U, G, off0, cur, 'down%d' % d)
-            cur += g * self.down_blocks[d]
-            full = Act(U.slice(off0, cur))
-            full.g = G.slice(off0, cur) if G is not None else None
+                o = pooled_writer(U.slice(off0, curp))
+            o.g = G.slice(off0, curp) if G is not None else None
+            self._dense_layers(tape, self.denseBlocksDown[d].layers, U, G, off0, block_segs[d][:1], 'down%d' % d)
+            cur = cin[d + 1]
+            wb = _width(block_segs[d])
+            full = Act(U.slice(off0, wb))
+            full.g = G.slice(off0, wb) if G is not None else None
             td = self.transDownBlocks[d]
-            a = bn_act(tape, full, td.norm, nv.ACT_RELU, tag='td%d.norm' % d)
-            drop = tape.dropout_table(tape.site('td%d.drop' % d), N, cur, td.drop.p)
+            ms = _merge(block_segs[d])
+            a = bn_act(tape, full, td.norm, nv.ACT_RELU, tag='td%d.norm' % d, segs=ms if len(ms) > 1 else None)
+            drop = tape.dropout_table(tape.site('td%d.drop' % d), N, cp.pad8(cur), td.drop.p)
             # conv1x1 -> dropout -> maxpool: the pooled tensor is the next block's input slice; a closure defers
             # the conv so that it can write its pooled output straight into the next buffer
-            def pooled_writer(dst, a=a, td=td, cur=cur, drop=drop, d=d):
-                _, p = conv_unit(tape, a, td.conv.weight, td.conv.bias, [(cur, cur)], stride=1, pad=0,
+            def pooled_writer(dst, a=a, td=td, ms=ms, drop=drop, d=d):
+                _, p = conv_unit(tape, a, td.conv.weight, td.conv.bias, ms, stride=1, pad=0,
                                  act=nv.ACT_NONE, dropmul=drop, pool=True, pool_out=dst, tag='td%d.conv' % d)
                 return p
         # ---- bottleneck (its own buffer: pooled input + new layers; only the new layers go on)
         nb = self.bottleneck_layers
-        B = tape.view('B', N, sizes[nd][0], sizes[nd][1], cur + g * nb)
-        GB = tape.view('GB', N, sizes[nd][0], sizes[nd][1], cur + g * nb) if need else None
+        cur, curp = cin[nd], cp.pad8(cin[nd])
+        B = tape.view('B', N, sizes[nd][0], sizes[nd][1], curp + gp * nb)
+        GB = tape.view('GB', N, sizes[nd][0], sizes[nd][1], curp + gp * nb) if need else None
         if GB is not None:
             tape.rt.clear_view(GB)
-        o = pooled_writer(B.slice(0, cur))
-        o.g = GB.slice(0, cur) if GB is not None else None
-        self._dense_layers(tape, self.bottleneck.bottleneck.layers, B, GB, 0, cur, 'bottleneck')
-        new = Act(B.slice(cur, g * nb))
-        new.g = GB.slice(cur, g * nb) if GB is not None else None
+        o = pooled_writer(B.slice(0, curp))
+        o.g = GB.slice(0, curp) if GB is not None else None
+        self._dense_layers(tape, self.bottleneck.bottleneck.layers, B, GB, 0, [(cur, curp)], 'bottleneck')
+        new, new_segs = Act(B.slice(curp, gp * nb)), [(g, gp)] * nb
+        new.g = GB.slice(curp, gp * nb) if GB is not None else None
         # ---- decoder
         for i in range(nd):
             U, G = ubufs[i], gbufs[i]
+            d = nd - 1 - i
             tu = self.transUpBlocks[i].convTrans
-            c = prevs[i]
-            o = conv_unit(tape, new, tu.weight, tu.bias, [(c, c)], stride=2, pad=0, transposed=True, act=nv.ACT_NONE,
-                          out=U.slice(0, c), out_hw=(U.H, U.W), tag='tu%d' % i)
-            o.g = G.slice(0, c) if G is not None else None
-            cin = c + self._skips[i]
-            self._dense_layers(tape, self.denseBlocksUp[i].layers, U, G, 0, cin, 'up%d' % i)
-            nn_ = g * self.up_blocks[i]
+            cpv = cp.pad8(prevs[i])
+            o = conv_unit(tape, new, tu.weight, tu.bias, _merge(new_segs), stride=2, pad=0, transposed=True, act=nv.ACT_NONE,
+                          out=U.slice(0, cpv), out_hw=(U.H, U.W), tag='tu%d' % i)
+            o.g = G.slice(0, cpv) if G is not None else None
+            in_segs = [(prevs[i], cpv)] + block_segs[d]
+            self._dense_layers(tape, self.denseBlocksUp[i].layers, U, G, 0, in_segs, 'up%d' % i)
+            m = self.up_blocks[i]
             if i + 1 < nd:
-                new = Act(U.slice(cin, nn_))
-                new.g = G.slice(cin, nn_) if G is not None else None
+                new, new_segs = Act(U.slice(_width(in_segs), gp * m)), [(g, gp)] * m
+                new.g = G.slice(_width(in_segs), gp * m) if G is not None else None
             else:
-                full = Act(U.slice(0, cin + nn_))
-                full.g = G.slice(0, cin + nn_) if G is not None else None
-        return head_1x1(tape, full, self.finalConv.weight, self.finalConv.bias, dlogits)
+                full = Act(U.slice(0, _width(stage_segs[i])))
+                full.g = G.slice(0, _width(stage_segs[i])) if G is not None else None
+                full_segs = _merge(stage_segs[i])
+        if len(full_segs) == 1:
+            return head_1x1(tape, full, self.finalConv.weight, self.finalConv.bias, dlogits)
+        # padded slices inside the last buffer: the 1x1 classifier runs as a general convolution over the segment list
+        o = conv_unit(tape, full, self.finalConv.weight, self.finalConv.bias, full_segs, stride=1, pad=0, act=nv.ACT_NONE,
+                      tag='finalConv')
+        return head_from_act(tape, o, self.num_classes, dlogits)
 
 
 def FCDenseNet57(n_classes):

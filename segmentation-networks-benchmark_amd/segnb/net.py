@@ -430,18 +430,19 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     return (oa, pa) if pool else oa
 
 
-def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
-    """PRE-activation BatchNorm + activation of an arbitrary tensor (tiramisu.py:12-13, 50-51)."""
+def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
+    """bn_act over ONE contiguous run of real channels (+ its padding); fields: (gamma, beta, running_mean, running_var,
+    num_batches_tracked or None, eps, momentum); grads_of() -> (dgamma, dbeta) fp32 views of the flat gradient buffer."""
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
     N, H, W, Cp = xv.N, xv.H, xv.W, xv.Cp
-    gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+    gamma, beta, rm, rv, nbt, eps, mom = fields
     C = gamma.numel()
     stats = tape.small(site + '/stats', (STAT_REPLICAS, 2, Cp), torch.float64)
     coef = tape.small(site + '/coef', (4, Cp), torch.float32)
     if tape.train:
         nv.call('segnb_bn_stats', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
-    ov = tape.view(site + '/a', N, H, W, Cp)
+    ov = out if out is not None else tape.view(site + '/a', N, H, W, Cp)
     fused = tape.fuses_finalize()
     if fused:
         sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
@@ -473,7 +474,7 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
             nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
                     oa.g.ptr, oa.g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
             fargs = (rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()),
-                     nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats),
+                     nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), 1, nv.ptr(stats),
                      act, slope, oa.g.ptr, oa.g.ld)
             if x.needs_grad and x.g is not None:
                 nv.call('segnb_bn_bwd_apply_fused_direct_acc', *(fargs + (x.g.ptr, x.g.ld, rt.stream)))
@@ -486,12 +487,50 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact'):
         nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
                 oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
         nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * H * W), nv.ptr(gamma.detach()), nv.ptr(coef),
-                nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
+                nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), 1, rt.stream)
         nv.call('segnb_bn_bwd_apply', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), dz.ptr, dz.ld,
                 dz.ptr, dz.ld, None, C, rt.stream)
         tape.contribute(x, dz)
 
     tape.record(backward)
+    return oa
+
+
+def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None):
+    """PRE-activation BatchNorm + activation of an arbitrary tensor (tiramisu.py:12-13, 50-51).
+
+    segs: [(real, padded), ...] when the tensor is a concat of padded slices whose real channels are the BatchNorm's
+    consecutive features (a dense block with a growth rate that is not a multiple of 8: tiramisu.py:187-191) -- BatchNorm is
+    per channel, so the layer runs as one launch set per slice on sub-views of the parameters; num_batches_tracked is
+    advanced by the first slice only."""
+    if segs is None or len(segs) == 1:
+        flat = tape.flat
+        return _bn_act_core(tape, x, _bn_fields(bn), lambda: (flat.grad_of(bn.weight), flat.grad_of(bn.bias)), act, slope, tag)
+    gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+    xv = x.v
+    assert sum(p for _, p in segs) == xv.Cp and sum(r for r, _ in segs) == gamma.numel(), (segs, xv.Cp, gamma.numel())
+    ov = tape.view(tape.site(tag) + '/a', xv.N, xv.H, xv.W, xv.Cp)
+    oa = Act(ov)
+    parts, roff, poff = [], 0, 0
+    for k, (real, padded) in enumerate(segs):
+        xs = Act(xv.slice(poff, padded), needs_grad=x.needs_grad)
+        xs.g = x.g.slice(poff, padded) if x.g is not None else None
+        sl = slice(roff, roff + real)
+        fields = (gamma[sl], beta[sl], rm[sl], rv[sl], nbt if k == 0 else None, eps, mom)
+
+        def grads_of(sl=sl):
+            flat = tape.flat
+            return flat.grad_of(bn.weight)[sl], flat.grad_of(bn.bias)[sl]
+        part = _bn_act_core(tape, xs, fields, grads_of, act, slope, '%s.s%d' % (tag, k), out=ov.slice(poff, padded))
+        parts.append((part, poff, padded))
+        roff += real
+        poff += padded
+
+    def bind():
+        for part, po, pd in parts:
+            part.g = oa.g.slice(po, pd) if oa.g is not None else None
+    # the slices' backward closures were recorded above and run AFTER this one (the tape runs in reverse): bind first
+    tape.record(bind)
     return oa
 
 

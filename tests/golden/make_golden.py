@@ -17,6 +17,7 @@ Fixtures
                           every parameter gradient of (B*bce_jaccard).backward(), BN running stats,
                           state after one SGD(1e-3) step, 5-step loss trajectory
   tiramisu_small.npz  G5  small FCDenseNet (reference tiramisu.py) 2x3x36x44: logits, loss, all gradients, buffers
+  tiramisu57_small.npz    FCDenseNet57 (growth 12) 2x3x64x64, seeded fill: logits, loss, gradient norms + probes, buffers
   zf_unet_224.npz     G2+G3  ZF_UNET() default (filters=32, Dropout2d 0.2 replay tables captured from the
                           reference's own RNG draw) B=4 224x224: loss / IoU / accuracy scalars, per-tensor
                           gradient L2 norms, probed logits and gradient entries
@@ -525,8 +526,22 @@ def gen_linknet():
     _run_and_record(m, x, y, 'linknet_small.npz', seed=34)
 
 
+def gen_tiramisu57():
+    """FCDenseNet57 (tiramisu.py:187-191: growth rate 12 -- NOT a multiple of 8 -- 4 layers per block) at 2x3x64x64 with the
+    seeded fill, Dropout2d off: the reference constructor the product pads slice by slice (12 -> 16 channels)."""
+    from lib.models.tiramisu import FCDenseNet57
+    m = FCDenseNet57(n_classes=1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    g = torch.Generator().manual_seed(57)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    y = (torch.rand(2, 1, 64, 64, generator=g) > 0.7).long()
+    _run_and_record(m, x, y, 'tiramisu57_small.npz', seed=57)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiles', 'augment', 'unet16', 'linknet']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiramisu57', 'tiles', 'augment', 'unet16', 'linknet']
     if 'augment' in which:
         gen_augment()
     if 'unet16' in which:
@@ -543,3 +558,5 @@ if __name__ == '__main__':
         gen_224()
     if 'tiramisu' in which:
         gen_tiramisu()
+    if 'tiramisu57' in which:
+        gen_tiramisu57()

@@ -102,6 +102,16 @@ def make_tiramisu(golden):
     return m, fwd, torch.from_numpy(golden['x']), torch.from_numpy(golden['y'])
 
 
+def make_tiramisu57_golden(golden):
+    """FCDenseNet57 (growth 12: padded slices) with the seeded fill the generator loaded into the reference's"""
+    from lib.models.tiramisu import FCDenseNet57
+    m = FCDenseNet57(n_classes=1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    return _load_seeded(m, golden)
+
+
 def check_tiramisu_golden(model, golden, device, dtype='f32'):
     """FCDenseNet vs the fixture produced by the REFERENCE's lib/models/tiramisu.py."""
     from lib.losses import BCEWithLogitsLossAndSmoothJaccard

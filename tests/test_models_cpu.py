@@ -42,8 +42,37 @@ def test_tiramisu_product_vs_reference_golden(golden_dir):
     mc.check_tiramisu_golden(m, g, 'cpu')
 
 
+def test_fcdensenet57_product_vs_reference_golden(golden_dir):
+    """FCDenseNet57(n_classes) of tiramisu.py:187-191 -- growth rate 12, every slice of the concat buffers padded to 16
+    channels, BatchNorm per slice -- against the fixture the reference's own FCDenseNet57 produced (make_golden.py)"""
+    g = np.load(os.path.join(golden_dir, 'tiramisu57_small.npz'))
+    m = mc.make_tiramisu57_golden(g)
+    assert sum(p.numel() for p in m.parameters()) == 1374865
+    mc.check_product_golden(m, g, 'cpu')
+
+
+def test_fcdensenet_any_growth_rate_vs_reference_module():
+    """growth rates / first-convolution widths that are not multiples of 8 (tiramisu.py:94-96 takes any) against the
+    state_dict-compatible torch restatement in oracle/tiramisu_ref.py"""
+    from lib.models.tiramisu import FCDenseNet
+    cfg = dict(in_channels=3, down_blocks=(1, 3), up_blocks=(3, 1), bottleneck_layers=1, growth_rate=10, out_chans_first_conv=12,
+               n_classes=2)
+    torch.manual_seed(3)
+    m = FCDenseNet(**cfg)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+    m.set_compute_dtype('f32').train()
+    x = torch.randn(2, 3, 20, 24)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ref = tiramisu_ref.forward(sd, x, cfg['down_blocks'], cfg['up_blocks'], cfg['bottleneck_layers'], True)
+    out = m(x)
+    np.testing.assert_allclose(out.detach().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_tiramisu_state_dict_and_factories():
-    from lib.models.tiramisu import FCDenseNet67, FCDenseNet103
+    from lib.models.tiramisu import FCDenseNet57, FCDenseNet67, FCDenseNet103
+    assert FCDenseNet57(n_classes=3).num_classes == 3
     m = FCDenseNet103(n_classes=1)
     assert sum(p.numel() for p in m.parameters()) == 9319521      # = the reference's FCDenseNet103(1) (probe; SURVEY 8a a4: ~9.3 M)
     assert 'denseBlocksDown.0.layers.0.norm.weight' in m.state_dict()

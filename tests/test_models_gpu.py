@@ -18,6 +18,14 @@ def test_tiramisu_f32_vs_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_fcdensenet57_vs_reference_golden(golden_dir, dtype):
+    """FCDenseNet57 (growth rate 12, tiramisu.py:187-191): padded slices + per-slice BatchNorm on the HIP kernels"""
+    g = np.load(os.path.join(golden_dir, 'tiramisu57_small.npz'))
+    m = mc.make_tiramisu57_golden(g)
+    print('fcdensenet57 %s dloss %.2e diou %.2e' % ((dtype,) + mc.check_product_golden(m, g, 'cuda', dtype)))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_unet16_vs_oracle(dtype):
     m, fwd, x, y = mc.make_unet16()
     print('unet16 %s cosine %.6f' % (dtype, mc.check_against_oracle(m, fwd, x, y, 'cuda', dtype)))
