@@ -269,6 +269,12 @@ int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, int N, int 
                                  int accumulate, double* fwd_stats_to_clear, int act, float slope, const float* dropmul,
                                  const void* g_direct, int ld_gd, const void* g_pool, int ld_gp, const void* g_up, int ld_gu,
                                  void* dy, int ld_dy, segnb_stream_t stream);
+/* InPlaceABN with the backend's affine form inside a fused plan (lib/models/linknet.py:12-21 on lib/modules/abn/functions.py:
+ * 94,112,118): segnb_abn_scale writes the effective scale out = |w| + eps that the BatchNorm entry points then take as their
+ * gamma; their dgamma output goes to a scratch vector, and segnb_abn_dscale adds sign(w) * dscale into the parameter's
+ * gradient (+1 for w > 0, -1 otherwise, as the backend) and clears the scratch. */
+int segnb_abn_scale(const float* w, float eps, float* out, int n, segnb_stream_t stream);
+int segnb_abn_dscale(const float* w, float* dscale, float* dw, int n, segnb_stream_t stream);
 
 /* sums -> bcoef fp32 [3][Cp] = (gamma*invstd, mean(dz), mean(dz*yhat)); dgamma/dbeta (C entries)
  * assigned or accumulated.  `sums` is CONSUMED (re-zeroed). */

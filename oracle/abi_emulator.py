@@ -747,6 +747,16 @@ class AbiEmulator(object):
         return self.segnb_bn_bwd_apply_fused(dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
                                              accumulate, clear_stats, tmp.data_ptr(), Cp, dy, ld_dy, stream)
 
+    def segnb_abn_scale(self, w, eps, out, n, stream):
+        _mem(out, n, torch.float32).copy_(_mem(w, n, torch.float32).abs() + eps)
+        return 0
+
+    def segnb_abn_dscale(self, w, dscale, dw, n, stream):
+        W, D = _mem(w, n, torch.float32), _mem(dscale, n, torch.float32)
+        _mem(dw, n, torch.float32).add_(torch.where(W > 0, D, -D))
+        D.zero_()
+        return 0
+
     @staticmethod
     def _d4(k, t):
         """element k of tta_d4_aug applied to an [..., S, S] tensor (rot90 counter-clockwise, then fliplr)"""

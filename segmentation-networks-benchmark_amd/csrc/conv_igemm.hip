@@ -1696,9 +1696,10 @@ extern "C" int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, l
     j.Mp = Mp; j.Cp = Cp; j.ntaps = ntaps; j.s_m = s_m; j.s_c = s_c;
     const bool fast_is_c = s_c < s_m;
     const long long tsrc = fast_is_c ? s_c : s_m;
-    // tiled kernel sized for parameter tensors of <= 3x3 positions; jobs with MORE packed taps than that are the masked
-    // ones (several packed taps per kernel position, PackJob.masked)
-    if (tsrc > 9 || (ntaps > 9 && ntaps > SEGNB_MAX_TAPS)) return -1;
+    // tiled kernel sized for parameter tensors of <= 3x3 positions.  An unmasked job has at most one packed tap per kernel
+    // position (ntaps <= tsrc <= 9); more packed taps than positions means a MASKED job (several packed taps per position,
+    // PackJob.masked: the 4 x 4 sub-pixel kernels, 16 taps) -- anything beyond that is refused
+    if (tsrc > 9 || ntaps > 16) return -1;
     if (fast_is_c) return ((Cp + 255) / 256) * Mp;
     return ((Mp + 7) / 8) * ((Cp + 63) / 64);
 }

@@ -6,6 +6,9 @@
 //        sum any of the losses/metrics needs; a second pass writes d(loss)/d(logits).
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
 
 constexpr int MAXK = 8;  // classes handled by the direct head kernels
@@ -410,18 +413,33 @@ extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, 
 }
 
 namespace {
-// device scratch of the head backward: one buffer per device, grown (never shrunk) on demand.  hipMalloc happens on the
-// first call of a geometry, i.e. in the eager / recording step; replayed launch lists find the same pointer.
-float* head_scratch(size_t bytes) {
-    constexpr int MAXDEV = 16;
-    static float* buf[MAXDEV] = {nullptr};
-    static size_t cap[MAXDEV] = {0};
+// device scratch of the head backward: one buffer per (device, stream), grown (never shrunk) on demand, behind a mutex.
+// Two head backwards that overlap on DIFFERENT streams (two models, a tape on a side stream) get different buffers; launches on
+// one stream are ordered by the stream.  hipMalloc happens on the first call of a geometry, i.e. in the eager / recording step;
+// replayed launch lists find the same pointer.
+float* head_scratch(size_t bytes, hipStream_t stream) {
+    struct Ent {
+        int dev;
+        hipStream_t stream;
+        float* buf;
+        size_t cap;
+    };
+    static std::mutex mu;
+    static std::vector<Ent> ents;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    if (hipGetDevice(&dev) != hipSuccess) {
         segnb_set_error("segnb_head_bwd: hipGetDevice failed");
         return nullptr;
     }
-    if (bytes > cap[dev]) {
+    std::lock_guard<std::mutex> lock(mu);
+    Ent* e = nullptr;
+    for (auto& it : ents)
+        if (it.dev == dev && it.stream == stream) e = &it;
+    if (e == nullptr) {
+        ents.push_back(Ent{dev, stream, nullptr, 0});
+        e = &ents.back();
+    }
+    if (bytes > e->cap) {
         // (the old buffer may still be read by launches in flight: it is left allocated -- a few hundred KB, at most a
         // handful of times per process)
         const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
@@ -430,10 +448,10 @@ float* head_scratch(size_t bytes) {
             segnb_set_error("segnb_head_bwd: scratch allocation of %zu bytes failed", want);
             return nullptr;
         }
-        buf[dev] = p;
-        cap[dev] = want;
+        e->buf = p;
+        e->cap = want;
     }
-    return buf[dev];
+    return e->buf;
 }
 }  // namespace
 
@@ -460,8 +478,8 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
         return SEGNB_E_BADARG;
     }
     // per-block partial sums of dw / db (summed in block order by head_bwd_finish_kernel): a library-owned scratch buffer
-    // per device, grown on demand -- launches on ONE stream per device are assumed (the training step's main stream)
-    float* part = head_scratch((size_t)gx * gy * K * (ct * 8 + 1) * sizeof(float));
+    // per (device, stream), grown on demand
+    float* part = head_scratch((size_t)gx * gy * K * (ct * 8 + 1) * sizeof(float), (hipStream_t)stream);
     if (part == nullptr) return SEGNB_E_BADARG;
     if (dtype == SEGNB_BF16)
         (K == 1 ? head_bwd_kernel<bf16_t, 1> : head_bwd_kernel<bf16_t, MAXK>)<<<grid, dim3(256), 0, (hipStream_t)stream>>>(

@@ -1249,6 +1249,38 @@ extern "C" int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, 
     return 0;
 }
 
+// InPlaceABN's backend affine (lib/modules/abn/functions.py:94,112,118 bind the first inplace_abn release): the scale the
+// kernels apply is |weight| + eps, and the weight gradient is sign(weight) * sum(dz * yhat).  Two C-element launches around the
+// BatchNorm entry points (which take the effective scale as their gamma): recordable in a launch list, no torch operator.
+__global__ void abn_scale_kernel(const float* __restrict__ w, float eps, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fabsf(w[i]) + eps;
+}
+__global__ void abn_dscale_kernel(const float* __restrict__ w, float* __restrict__ dscale, float* __restrict__ dw, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float d = dscale[i];
+        dw[i] += w[i] > 0.f ? d : -d;       // d(|w| + eps)/dw as the backend signs it: +1 for w > 0, -1 otherwise
+        dscale[i] = 0.f;                    // consumed: the buffer accumulates the next backward from zero
+    }
+}
+
+extern "C" int segnb_abn_scale(const float* w, float eps, float* out, int n, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_abn_scale, w, eps, out, n, stream);
+    SEGNB_CHECK_ARG(w && out && n > 0, "NULL tensor");
+    hipLaunchKernelGGL(abn_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, eps, out, n);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_abn_dscale(const float* w, float* dscale, float* dw, int n, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_abn_dscale, w, dscale, dw, n, stream);
+    SEGNB_CHECK_ARG(w && dscale && dw && n > 0, "NULL tensor");
+    hipLaunchKernelGGL(abn_dscale_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, dscale, dw, n);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
 // torch.optim.RMSprop (alpha, eps; no momentum / centering / weight decay) and torch.optim.Adam (betas, eps; no
 // amsgrad / weight decay) over the flat buffers: get_optimizer('rms' | 'adam') of torch_train.py:73-77
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, long long n,

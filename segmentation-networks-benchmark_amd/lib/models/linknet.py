@@ -97,10 +97,6 @@ class LinkNet34(HipNet):
         self.finalconv2 = nn.Conv2d(32, 32, 3)
         self.finalrelu2 = nn.LeakyReLU(inplace=True)
         self.finalconv3 = nn.Conv2d(32, num_classes, 2, padding=1)
-        if any(isinstance(m, InPlaceABN) and m.affine_form != 'gamma' for m in self.modules()):
-            # the fused plan hands the kernels the parameter itself as the BatchNorm scale (lib/modules/abn: affine form)
-            raise NotImplementedError("LinkNet34's fused plan implements affine_form='gamma' only "
-                                      "(SEGNB_ABN_AFFINE=abs_eps applies to the stand-alone InPlaceABN module)")
         self._init_engine(3)
 
     def _check_input(self, x):

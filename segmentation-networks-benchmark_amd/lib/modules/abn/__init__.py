@@ -17,7 +17,8 @@ return ``dweight = sign(weight) * sum(dz * yhat)``.  Both forms are offered:
     tests/golden/make_golden.py is BatchNorm2d + LeakyReLU);
   * ``affine_form='abs_eps'`` (or SEGNB_ABN_AFFINE=abs_eps): y = yhat * (|weight| + eps) + bias with the backend's
     gradient.  At the weight = 1 initialisation the two differ by the factor 1 + eps (1e-5 relative per layer), for
-    negative or near-zero weights outright.  Stand-alone module only: LinkNet34's fused plan keeps 'gamma'.
+    negative or near-zero weights outright.  Inside LinkNet34's fused plan the same form is served by two C-element
+    launches around the BatchNorm entry points (segnb_abn_scale / segnb_abn_dscale, segnb.net.conv_unit).
 ``InPlaceABNSync`` is instantiated by no model in the reference and is not provided.
 """
 import os

@@ -30,7 +30,13 @@ class AverageMeter(object):
 def find_optimal_lr(model, criterion, optimizer, dataloader):
     """LR range test (train_utils.py:36-69): 30 steps, lr = 1e-8 * 2^i, the step body of the training loop.
     Like the reference it never zeroes gradients between steps (they accumulate) and applies the schedule
-    through LambdaLR (so the optimizer's base lr multiplies the table, as there)."""
+    through LambdaLR (so the optimizer's base lr multiplies the table, as there).
+
+    DEVIATION, deliberate: the reference calls ``scheduler.step()`` BEFORE every step
+    (train_utils.py:49-55), so its step i runs at ``lrs[i + 1]`` while the returned table pairs ``loss[i]`` with
+    ``lrs[i]``, and its last step indexes ``lrs[30]`` -- one past the 30-entry table (an IndexError on the torch versions
+    this was checked against).  Here step i runs at ``lrs[i]``, the pairing the returned arrays state, and the
+    schedule is clamped at the last entry."""
     from torch.optim.lr_scheduler import LambdaLR
     lrs = np.array([1e-8 * 2.0 ** i for i in range(30)], dtype=np.float32)
     loss = np.zeros_like(lrs)

@@ -109,6 +109,8 @@ SIGNATURES = {
                                         _P, c_int, c_float, _P, c_int, _P, c_int, _P],
     'segnb_bn_bwd_apply_fused_src': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P,
                                      c_int, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P],
+    'segnb_abn_scale': [_P, c_float, _P, c_int, _P],
+    'segnb_abn_dscale': [_P, _P, _P, c_int, _P],
     'segnb_tiles_gather': [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P],
     'segnb_tiles_merge': [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],

@@ -1302,6 +1302,8 @@ class FlatParams(object):
         base = self.flat_g.data_ptr()
         views = self._gviews
         for p in self.param_list():
+            if not p.requires_grad:
+                continue                    # frozen (torch_train_ab.py:245-246): autograd would leave .grad alone too
             view = views[id(p)]
             if p.grad is None:
                 p.grad = view

@@ -293,6 +293,24 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     coef_buf = tape.small(site + '/coef', (4, Cp), torch.float32)
     has_bn = bn is not None
     use_batch_stats = has_bn and tape.train
+    # InPlaceABN with the backend's affine form (lib/modules/abn: affine_form='abs_eps'): the kernels take |w| + eps as gamma
+    # and hand dgamma to a scratch vector that segnb_abn_dscale signs into the parameter's gradient
+    abs_form = has_bn and getattr(bn, 'affine_form', 'gamma') == 'abs_eps' and bn.weight is not None
+
+    def eff_gamma():
+        if not abs_form:
+            return bn.weight.detach()
+        geff = tape.small(site + '/geff', (C,), torch.float32)
+        nv.call('segnb_abn_scale', nv.ptr(bn.weight.detach()), float(bn.eps), nv.ptr(geff), C, rt.stream)
+        return geff
+
+    def dgamma_target():
+        return tape.small(site + '/dgeff', (C,), torch.float32) if abs_form else tape.flat.grad_of(bn.weight)
+
+    def dgamma_done():
+        if abs_form:
+            nv.call('segnb_abn_dscale', nv.ptr(bn.weight.detach()), nv.ptr(tape.small(site + '/dgeff', (C,), torch.float32)),
+                    nv.ptr(tape.flat.grad_of(bn.weight)), C, rt.stream)
     # activation in the convolution's epilogue (segnb_conv_fprop_act): no BatchNorm (unet16.py:12-21, the linknet head), or
     # BatchNorm in inference -- with no residual, dropout or fused pooling in the way.  The backward of the no-BatchNorm
     # form reads the ACTIVATED tensor where it read the raw one: act'(z) has the sign of act(z).
@@ -303,7 +321,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         coef = None
         if has_bn:
             gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
-            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
+            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(eff_gamma()),
                     nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 0, nv.ptr(coef_buf), rt.stream)
             coef = coef_buf
         ov = ov_direct if ov_direct is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
@@ -348,7 +366,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         # backward sums are cleared here (segnb_bn_fwd_fused / segnb_bn_bwd_apply_fused, include/segnb_hip.h)
         gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
         sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
-        nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(stats), nv.ptr(gamma.detach()),
+        nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(stats), nv.ptr(eff_gamma()),
                 nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef_buf), nv.ptr(sums_f),
                 act, slope, nv.ptr(dropmul), ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0,
                 None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
@@ -357,7 +375,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     else:
         if has_bn:
             gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
-            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(gamma.detach()),
+            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(eff_gamma()),
                     nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
                     nv.ptr(coef_buf), rt.stream)
             coef = coef_buf
@@ -388,23 +406,24 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         count = float(N * Ho * Wo)
         dy = dz
         if has_bn:
-            gamma = bn.weight
+            gamma = tape.small(site + '/geff', (C,), torch.float32) if abs_form else bn.weight      # (geff: written by the forward)
             if res is not None:             # dz is also the residual branch's gradient: keep it intact
                 dy = tape.view(site + '/dy', N, Ho, Wo, Cp)
             if direct:
                 nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf),
-                        nv.ptr(sums), nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)),
+                        nv.ptr(sums), nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(dgamma_target()),
                         nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats), act, slope, oa.g.ptr, oa.g.ld, dy.ptr, dy.ld,
                         rt.stream)
             elif fused_bn:
                 nv.call('segnb_bn_bwd_apply_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf), nv.ptr(sums),
-                        nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)),
+                        nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(dgamma_target()),
                         nv.ptr(flat.grad_of(bn.bias)), 1, nv.ptr(stats), dz.ptr, dz.ld, dy.ptr, dy.ld, rt.stream)
             else:
                 nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, nv.ptr(gamma.detach()), nv.ptr(coef_buf),
-                        nv.ptr(bcoef), nv.ptr(flat.grad_of(bn.weight)), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
+                        nv.ptr(bcoef), nv.ptr(dgamma_target()), nv.ptr(flat.grad_of(bn.bias)), 1, rt.stream)
                 nv.call('segnb_bn_bwd_apply', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef_buf), nv.ptr(bcoef),
                         dz.ptr, dz.ld, dy.ptr, dy.ld, None, C, rt.stream)
+            dgamma_done()
         else:
             gb = flat.grad_of(bias) if bias is not None else None
             nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, None, nv.ptr(coef_buf), nv.ptr(bcoef),
@@ -818,18 +837,25 @@ class HipNet(nn.Module):
             self._dlogits[0] = dlogits
             recording = ent is not None and ent['state'] == 'fwd'
             segs, around = [], None
+            paused = [False]          # True while a cut's hook runs OUTSIDE the recording (nothing is open to abort then)
             if recording:
                 nv.plan_record_begin()
 
                 def around(do):
                     handle, nops = nv.plan_record_end()
-                    segs.append((handle, nops, do()))
+                    paused[0] = True
+                    segs.append([handle, nops, None])          # the ended segment is owned by `segs` before the hook can raise
+                    segs[-1][2] = do()
                     nv.plan_record_begin()
+                    paused[0] = False
             try:
                 tape.run_closures(around)
-            except BaseException:
+            except Exception:
+                # (KeyboardInterrupt / SystemExit propagate untouched: the entry is dropped by the `finally`-free path of the
+                # next step, which finds state 'fwd' without a backward and records again)
                 if recording:
-                    nv.plan_record_abort()
+                    if not paused[0]:
+                        nv.plan_record_abort()
                     for h, _, _ in segs:
                         if h is not None:
                             nv.call('segnb_plan_destroy', h)

@@ -451,3 +451,51 @@ def blob_batch(B, S, seed):
             y[b, 0][m] = 1
             x[b][:, m] += (0.8 + 0.4 * rng.rand(3, 1)).astype(np.float32)
     return torch.from_numpy(x), torch.from_numpy(y)
+
+
+def check_linknet_abs_eps_form(device, dtype='f32', size=64):
+    """LinkNet34 whose InPlaceABN layers use the backend's affine form (lib/modules/abn/functions.py:94,112,118: scale
+    |w| + eps, weight gradient signed) with NEGATIVE and near-zero weights, against the same network in the gamma form --
+    the path pinned to the reference golden -- carrying |w| + eps as its weights: equal logits, equal gradients but for the
+    sign on the InPlaceABN weights."""
+    import warnings
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.models.linknet import LinkNet34
+    from lib.modules.abn import InPlaceABN
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(21)
+        a = LinkNet34(num_classes=1)
+        torch.manual_seed(21)
+        b = LinkNet34(num_classes=1)
+    a.finaldrop1.p = b.finaldrop1.p = 0.0
+    gen = torch.Generator().manual_seed(5)
+    signs = {}
+    for (n, ma), (_, mb) in zip(a.named_modules(), b.named_modules()):
+        if isinstance(ma, InPlaceABN):
+            w = (torch.rand(ma.num_features, generator=gen) + 0.3) * torch.where(torch.rand(ma.num_features, generator=gen) > 0.5, 1.0, -1.0)
+            w[0] = 1e-7                                    # near zero: the gamma form would lose the channel
+            ma.affine_form = 'abs_eps'
+            with torch.no_grad():
+                ma.weight.copy_(w)
+                mb.weight.copy_(w.abs() + ma.eps)
+            signs[n + '.weight'] = torch.where(w > 0, 1.0, -1.0)
+    x = torch.randn(2, 3, size, size + 32, generator=gen)
+    y = (torch.rand(2, 1, size, size + 32, generator=gen) > 0.7).long()
+    outs, grads = [], []
+    for m in (a, b):
+        m.set_compute_dtype(dtype)
+        m.to(device).train()
+        out = m(x.to(device))
+        loss = BCEWithLogitsLossAndSmoothJaccard()(out, y.to(device))
+        (2 * loss).backward()
+        outs.append(out.detach().cpu())
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
+    tol = 1e-5 if dtype == 'f32' else 2e-2
+    assert float((outs[0] - outs[1]).abs().max()) <= tol * float(outs[1].abs().max())
+    gmax = max(float(g.abs().max()) for g in grads[1].values())
+    for n, gb in grads[1].items():
+        ga = grads[0][n]
+        if n in signs:
+            gb = gb * signs[n]
+        assert float((ga - gb).abs().max()) <= (1e-4 if dtype == 'f32' else 5e-2) * max(float(gb.abs().max()), 1e-3 * gmax), n

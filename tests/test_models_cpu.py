@@ -186,6 +186,10 @@ def test_inplace_abn_constructor_surface():
     mc.check_inplace_abn_surface('cpu')
 
 
+def test_linknet34_abs_eps_affine_form_inside_the_plan():
+    mc.check_linknet_abs_eps_form('cpu')
+
+
 def test_inplace_abn_abs_eps_affine_form():
     mc.check_inplace_abn_abs_form('cpu')
 
@@ -199,3 +203,42 @@ def test_replay_harness_self_consistent(golden_dir):
     n, rep = abi_replay.replay(lambda: mc.make_tiramisu(g)[0], x, y, BCEWithLogitsLossAndSmoothJaccard(), 'f32',
                                device='cpu')
     assert n > 200 and not rep, rep[:5]
+
+
+def test_frozen_parameters_keep_grad_none():
+    """requires_grad=False parameters (torch_train_ab.py:245-246 freezes a whole head; a fine-tuning script freezes the
+    encoder): their .grad stays None after backward, the trainable ones get the same gradients as in the unfrozen run, and an
+    optimizer over the trainable subset updates only those."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.models.zf_unet import ZF_UNET
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, 32, 32)
+    y = (torch.rand(2, 1, 32, 32) > 0.6).long()
+    grads = []
+    for freeze in (False, True):
+        torch.manual_seed(4)
+        m = ZF_UNET(dropout_val=0.0, filters=8).set_compute_dtype('f32').train()
+        if freeze:
+            for n, p in m.named_parameters():
+                if n.startswith('conv_'):
+                    p.requires_grad = False
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.1)
+        loss = BCEWithLogitsLossAndSmoothJaccard()(m(x), y)
+        (2 * loss).backward()
+        grads.append({n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()})
+        opt.step()
+        if freeze:
+            for n, p in m.named_parameters():
+                if n.startswith('conv_') and n != 'conv_final.weight' and n != 'conv_final.bias':
+                    assert p.grad is None, n
+                    assert torch.equal(p.detach(), before[n]), n
+    for n, g in grads[1].items():
+        if g is not None:
+            assert torch.allclose(g, grads[0][n], rtol=1e-5, atol=1e-7), n
+    assert any(g is not None for g in grads[1].values())
+    # a fully frozen model under grad mode is a plain forward (the afterburner script's use)
+    for p in m.parameters():
+        p.requires_grad = False
+    out = m(x)
+    assert not out.requires_grad
