@@ -966,8 +966,12 @@ class AbiEmulator(object):
         return 0
 
     def segnb_tune(self, key, value):
-        """kernel-selection knobs have no meaning on the CPU restatement"""
+        self.tuned = getattr(self, 'tuned', {})
+        self.tuned[key.decode() if isinstance(key, bytes) else key] = int(value)
         return 0
+
+    def segnb_device_cus(self):
+        return 256
 
     def segnb_debug_stamps(self, host_dst):
         return 0

@@ -514,7 +514,7 @@ int launch_roll(RollArgs& a, hipStream_t stream) {
     // segment height: the whole launch should be about one round of the chip's wave slots (WPS blocks x 4 waves per CU)
     // (the most segments per strip that still give every wave at most ONE task; short segments when even whole strips
     // outnumber the wave slots)
-    const int slots = segnb_num_cus() * 4 * WPS;
+    const int slots = segnb_knob_conv_cus() * 4 * WPS;       // (segnb_tune "conv_cu_pct": CUs left to a data-parallel job's collectives)
     int nseg = (int)(slots / ((long long)a.N * a.NSTRIP));
     if (nseg < 1) nseg = (a.H + 15) / 16;
     if (nseg > a.H) nseg = a.H;
@@ -523,7 +523,7 @@ int launch_roll(RollArgs& a, hipStream_t stream) {
     a.NSEG = (a.H + sr - 1) / sr;
     a.NTASK = a.N * a.NSEG * a.NSTRIP;
     int blocks = (a.NTASK + 3) / 4;
-    const int maxb = segnb_num_cus() * WPS;
+    const int maxb = segnb_knob_conv_cus() * WPS;
     if (blocks > maxb) blocks = maxb;
     if (a.stats != nullptr)
         hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 1, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);

@@ -210,7 +210,7 @@ class _ZFUnetPlan(object):
                         b['du_%d' % i] = View.alloc(rt, N, h2, w2, wp[i + 1])
         b['f0'] = View.alloc(rt, N, H, W, wp[0])
         b['df0'] = View.alloc(rt, N, H, W, wp[0])
-        b['logits'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
+        b['dlogits_in'] = torch.zeros((N, self.K, H, W), dtype=torch.float32, device=rt.device)
         sizes = [(n, self.stages[n][1].Cp) for n in ENCODER + DECODER]
         b['drop_flat'] = torch.ones(sum(N * c for _, c in sizes), dtype=torch.float32, device=rt.device)
         b['drop'], off = {}, 0
@@ -481,6 +481,13 @@ class _ZFUnetPlan(object):
         self._pack_if_needed(H, W, N)
         drop = self._dropout_tables(b, N, train)
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)
+        first = None
+        if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
+            first = (x, self.module.input_norm)          # the first convolution reads the image itself
+        else:
+            # the batch enters through ONE launch outside the recorded list (it reads the caller's tensor, whatever its
+            # address): NCHW fp32 / NHWC uint8 -> the padded NHWC buffer the list's first convolution reads
+            pack_input(rt, x, b['x'], self.module.input_norm)
         if ckey is not None:
             # statistics a fused training forward left unconsumed are cleared here, outside the recorded list
             for n in ENCODER + DECODER:
@@ -488,28 +495,18 @@ class _ZFUnetPlan(object):
                     if st.bn is not None and train and st._stats_stale:
                         st.stats.zero_()
                         st._stats_stale = False
-            xin = b.get('x_in')
-            if xin is None:
-                xin = b['x_in'] = torch.empty_like(x)
-            xin.copy_(x)                                  # the list reads the batch from ONE persistent tensor
-            x = xin
             plan = self._cplans.get(ckey)
             if plan is not None and plan[0] is not None:
                 self._plan_replay(plan)
                 self._last = (N, H, W) if need_grad else None
                 self._last_train = bool(train)
                 self.generation += 1
-                return b['logits'].clone()
+                return self._head(b, N, H, W)
             if plan is None:
                 self._plan_begin()
             else:
                 ckey = None                               # recorded before and found not replayable: eager
         try:
-            first = None
-            if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
-                first = (x, self.module.input_norm)          # the first convolution reads the image itself
-            else:
-                pack_input(rt, x, b['x'], self.module.input_norm)
             wp = self.wp
             cur = b['x']
             for i, name in enumerate(ENCODER):
@@ -535,10 +532,6 @@ class _ZFUnetPlan(object):
                                out=b.get('u_%d' % (lvl - 1)))
                 else:
                     s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
-            head = self.module.conv_final
-            logits = b['logits']
-            nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
-                    nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
         except BaseException:
             if ckey is not None:
                 self._plan_abort(ckey)
@@ -548,7 +541,20 @@ class _ZFUnetPlan(object):
         self._last = (N, H, W) if need_grad else None
         self.generation += 1                       # every forward overwrites the activation buffers
         self._last_train = bool(train)
-        return logits.clone()
+        return self._head(b, N, H, W)
+
+    def _head(self, b, N, H, W):
+        """The 1x1 classifier (zf_unet.py:58) as ONE launch outside the recorded list, straight into the tensor the caller
+        gets (the list would have to write a persistent buffer and the caller's copy would be a launch of its own); the
+        loss is told where this model wants d(loss)/d(logits) (segnb.seglosses.register_grad_buffer)."""
+        from segnb import seglosses
+        rt = self.rt
+        head = self.module.conv_final
+        logits = torch.empty((N, self.K, H, W), dtype=torch.float32, device=rt.device)
+        nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
+                nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+        seglosses.register_grad_buffer(logits, b['dlogits_in'])
+        return logits
 
     # ---- backward --------------------------------------------------------------------------------------
     def backward(self, dlogits):
@@ -566,10 +572,9 @@ class _ZFUnetPlan(object):
         drop_now = {n: self.stages[n][1]._saved[2] if self.stages[n][1]._saved is not None else None for n in ENCODER + DECODER}
         ckey = self._cplan_key('bwd', N, H, W, True, True, drop_now)
         if ckey is not None:
-            din = b.get('dlogits_in')
-            if din is None:
-                din = b['dlogits_in'] = torch.empty_like(dlogits)
-            din.copy_(dlogits)                            # (autograd hands over a different tensor every step)
+            din = b['dlogits_in']
+            if dlogits.data_ptr() != din.data_ptr():
+                din.copy_(dlogits)                        # (a loss that did not write into the registered buffer)
             dlogits = din
             plan = self._cplans.get(ckey)
             if plan is not None and plan[0] is not None:

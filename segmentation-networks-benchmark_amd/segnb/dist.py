@@ -16,6 +16,7 @@ import os
 import torch
 import torch.distributed as td
 
+from . import _native as nv
 from . import seglosses
 
 
@@ -70,9 +71,38 @@ class DataParallel(object):
         self._pending = []
         self._done_upto = None
         self._fused_opt = None
+        self.reserved_cus = 0
+        self.trace = None              # {'first_bucket': event, 'backward_end': event} when trace_overlap() was called
         if self.active:
             seglosses.DataParallelHooks.sums_allreduce = self._allreduce_sums
             seglosses.DataParallelHooks.grad_scale = float(self.ws)
+            self._reserve_cus()
+
+    def _reserve_cus(self):
+        """RCCL's all-reduce kernels need CUs of their own to run BESIDE the backward: the persistent convolution kernels
+        size their grids for every CU of the chip otherwise (one block per CU, resident for the whole launch), and a
+        collective launched behind them waits for blocks to retire.  With world > 1 the grids are sized for CUs - k
+        (SEGNB_DP_RESERVE_CUS, default 8: one CU per RCCL channel of a ring over the 7 xGMI links + 1).  UNMEASURED on
+        hardware (no multi-GPU node in this build's runs): the knob exists so that the first 8-GPU run can sweep it."""
+        k = int(os.environ.get('SEGNB_DP_RESERVE_CUS', '8'))
+        if k <= 0:
+            return
+        try:
+            cus = int(nv.query('segnb_device_cus'))
+        except Exception:
+            cus = 0
+        if cus <= k:
+            return
+        pct = max(10, (cus - k) * 100 // cus)
+        nv.call('segnb_tune', b'conv_cu_pct', pct)
+        self.reserved_cus = cus - cus * pct // 100
+
+    def trace_overlap(self):
+        """Record a HIP event in front of the FIRST gradient bucket's all-reduce (communication stream) and one at the end
+        of backward (compute stream) for the next backward: tests assert that the first collective is enqueued -- and can
+        start -- before the backward has finished (tests/test_zf_unet_gpu.py)."""
+        self.trace = {}
+        return self
 
     def fuse_optimizer(self, optimizer):
         """Fold the optimizer step into the all-reduce epilogue: each bucket's slice of the flat
@@ -183,6 +213,10 @@ class DataParallel(object):
         for ps in getattr(self, '_producers', ()):
             cs.wait_stream(ps)
         with torch.cuda.stream(cs):
+            if self.trace is not None and first:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(cs)
+                self.trace['first_bucket'] = ev
             if bf16:
                 wire = chunk.to(torch.bfloat16)       # (allocated on the communication stream: reused in stream order)
                 td.all_reduce(wire, op=td.ReduceOp.SUM)
@@ -202,6 +236,10 @@ class DataParallel(object):
             # this step's local ones -- a second all-reduce would multiply the earlier part by the world size
             raise RuntimeError('data parallel: gradients were accumulated across steps (no zero_grad between them); '
                                'zero the gradients every step, or all-reduce once after the last accumulation step')
+        if self.trace is not None and flat.flat_g.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(flat.flat_g.device))
+            self.trace['backward_end'] = ev
         self.grads_ready(flat, 0)          # (the plan joined its side stream before calling: no other producers)
         self._done_upto = None
         self._group_this_backward = None

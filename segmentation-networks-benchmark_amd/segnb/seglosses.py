@@ -80,6 +80,24 @@ def _recall(logits, target):
     return None
 
 
+# A model may name the buffer it wants d(loss)/d(logits) written into (its recorded backward list reads the gradient from ONE
+# persistent tensor): {data_ptr of the logits it returned: buffer}.  The loss backward then writes there instead of into a fresh
+# tensor that the model would have to copy (6 MB and a launch per step at 224 x 224 bs=32).  One entry: the latest forward.
+_grad_buffers = {}
+
+
+def register_grad_buffer(logits, buf):
+    _grad_buffers.clear()
+    _grad_buffers[logits.data_ptr()] = buf
+
+
+def _grad_buffer_for(x):
+    buf = _grad_buffers.get(x.data_ptr())
+    if buf is not None and buf.shape == x.shape and buf.dtype == x.dtype and buf.device == x.device:
+        return buf
+    return None
+
+
 def reduce_finalize(x, t, spec):
     """-> fin fp32[8] = (loss, soft IoU, pixel accuracy, GI, GU, bce mean, n, -) on the device."""
     sums = torch.zeros(8, dtype=torch.float64, device=x.device)
@@ -101,7 +119,7 @@ class SegLossFn(torch.autograd.Function):
         ctx.spec = spec
         ctx.save_for_backward(x, t, sums, fin)
         SegLossFn.last_fin = fin
-        return fin[0].clone()
+        return fin[0]                 # (a view of this call's own result vector: no copy launch)
 
     @staticmethod
     def backward(ctx, gout):
@@ -109,7 +127,9 @@ class SegLossFn(torch.autograd.Function):
         g = gout.detach().contiguous().float()
         if DataParallelHooks.grad_scale != 1.0:
             g = g * DataParallelHooks.grad_scale
-        dx = torch.empty_like(x)
+        dx = _grad_buffer_for(x)
+        if dx is None:
+            dx = torch.empty_like(x)
         cs = _cspec(ctx.spec)
         nv.call('segnb_seg_loss_bwd', nv.ptr(x), nv.ptr(t), x.numel(), nv.ptr(sums), nv.ptr(fin), cs, nv.ptr(g),
                 nv.ptr(dx), _stream(x))

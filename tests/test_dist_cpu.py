@@ -44,7 +44,11 @@ def _worker(rank, world, port, out_dir):
     from lib.losses import BCEWithLogitsLossAndSmoothJaccard
     torch.manual_seed(100 + rank)            # ranks start DIFFERENT: the broadcast must fix that
     m = ZF_UNET(dropout_val=0.0, filters=4).set_compute_dtype('f32').train()
+    emu = nv._test_backend
     dp = sdist.DataParallel(m, bucket_bytes=256 << 10)      # small buckets -> several all-reduces
+    # world > 1: the persistent convolution grids leave CUs to the collectives (segnb_tune conv_cu_pct; 256 emulated CUs,
+    # SEGNB_DP_RESERVE_CUS default 8 -> 96 % = 245 CUs, 11 reserved)
+    assert emu.tuned.get('conv_cu_pct') == 96 and dp.reserved_cus == 11, (getattr(emu, 'tuned', None), dp.reserved_cus)
     x, y = train_step_ref.synthetic_batch(4, 64, seed=77)
     xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
     with torch.no_grad():
