@@ -273,6 +273,13 @@ int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, int N, int 
  * 94,112,118): segnb_abn_scale writes the effective scale out = |w| + eps that the BatchNorm entry points then take as their
  * gamma; their dgamma output goes to a scratch vector, and segnb_abn_dscale adds sign(w) * dscale into the parameter's
  * gradient (+1 for w > 0, -1 otherwise, as the backend) and clears the scratch. */
+/* segnb_bn_finalize(training = 1) under the fused protocol of segnb_bn_fwd_fused, for a layer whose activation pass does not
+ * exist (its consumer applies BatchNorm + activation while it loads: segnb_conv_fprop_tf): coef and the running statistics are
+ * written, the forward statistics are LEFT for the layer's backward (segnb_bn_bwd_apply_fused*) to clear, the backward
+ * accumulators clear_sums [16][2][Cp] are cleared. */
+int segnb_bn_finalize_keep(const double* stats, int C, int Cp, double count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, long long* nbt, float* coef,
+                           double* clear_sums, segnb_stream_t stream);
 int segnb_abn_scale(const float* w, float eps, float* out, int n, segnb_stream_t stream);
 int segnb_abn_dscale(const float* w, float* dscale, float* dw, int n, segnb_stream_t stream);
 

@@ -536,6 +536,15 @@ class AbiEmulator(object):
         co[0, :C], co[1, :C], co[2, :C], co[3, :C] = scale, b, mean, invstd
         return 0
 
+    def segnb_bn_finalize_keep(self, stats, C, Cp, count, gamma, beta, eps, momentum, rm, rv, nbt, coef, clear_sums, stream):
+        """segnb_bn_finalize(training = 1) that leaves the statistics in place and clears the backward accumulators"""
+        keep = _mem(stats, REPL * 2 * Cp, torch.float64).clone()
+        rc = self.segnb_bn_finalize(stats, C, Cp, count, gamma, beta, eps, momentum, rm, rv, nbt, 1, coef, stream)
+        _mem(stats, REPL * 2 * Cp, torch.float64).copy_(keep)
+        if clear_sums is not None:
+            _mem(clear_sums, REPL * 2 * Cp, torch.float64).zero_()
+        return rc
+
     @staticmethod
     def _act(z, act, slope):
         if act == ACT_RELU:

@@ -74,6 +74,7 @@ struct BnFwdParams {
     int C, training;
     float* coef;                // [4][Cp] out
     double* zero_buf;           // fused only: the BACKWARD accumulators of this layer, cleared for this step
+    int keep_stats;             // segnb_bn_finalize_keep: the statistics are left for the backward to clear (fused protocol)
 };
 
 __device__ __forceinline__ void bn_fwd_coef(const BnFwdParams& p, int Cp, int c, bool update, float& scale,
@@ -120,7 +121,14 @@ __global__ void bn_finalize_kernel(const BnFwdParams p, int Cp) {
     if (c >= Cp) return;
     float scale, shift, mean, invstd;
     bn_fwd_coef(p, Cp, c, true, scale, shift, mean, invstd);
-    if (p.training && c < p.C) {            // the stand-alone finalize CONSUMES the statistics
+    if (p.zero_buf != nullptr) {            // (segnb_bn_finalize_keep: this layer's backward accumulators)
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            p.zero_buf[(rp * 2) * Cp + c] = 0.0;
+            p.zero_buf[(rp * 2 + 1) * Cp + c] = 0.0;
+        }
+    }
+    if (p.training && c < p.C && !p.keep_stats) {            // the stand-alone finalize CONSUMES the statistics
         double* st = const_cast<double*>(p.stats);
 #pragma unroll
         for (int rp = 0; rp < REPL; ++rp) {
@@ -971,6 +979,21 @@ extern "C" int segnb_bn_finalize(double* stats, int C, int Cp, double count, con
     SEGNB_CHECK_ARG(training ? stats != nullptr : (running_mean != nullptr && running_var != nullptr),
                     "missing statistics source");
     BnFwdParams fp = {stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, training, coef, nullptr};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, fp, Cp);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+// The finalize of a layer whose activation pass does not exist (its consumer applies the activation while it loads:
+// segnb_conv_fprop_tf): coefficients + running statistics as segnb_bn_finalize(training = 1), but under the FUSED protocol of
+// segnb_bn_fwd_fused -- the forward statistics stay for this layer's backward (segnb_bn_bwd_apply_fused*) to clear, and the
+// backward accumulators clear_sums are cleared here.
+extern "C" int segnb_bn_finalize_keep(const double* stats, int C, int Cp, double count, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
+                                      float* coef, double* clear_sums, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_finalize_keep, stats, C, Cp, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, coef, clear_sums, stream);
+    SEGNB_CHECK_ARG(stats != nullptr && coef != nullptr && C > 0 && Cp >= C && Cp % 8 == 0, "bad arguments");
+    BnFwdParams fp = {stats, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, 1, coef, clear_sums, 1};
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, (hipStream_t)stream, fp, Cp);
     SEGNB_LAUNCH_CHECK();
     return 0;

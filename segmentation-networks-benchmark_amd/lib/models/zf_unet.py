@@ -513,10 +513,15 @@ class _ZFUnetPlan(object):
                 s1, s2 = self.stages[name]
                 if 2 * i == self.PACK_EARLY:
                     self._join_late_pack()
-                s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None)
+                # consumer-side BatchNorm: where the block's second convolution can apply the first one's BatchNorm + ReLU
+                # while it loads (segnb_conv_fprop_tf: the thin 32 -> 32 level), that activated tensor is never written
+                defer = self._defer(s1, s2, cur, b['a1_%d' % i], train, need_grad)
+                y1 = s1.forward(cur, train, None, out=b['a1_%d' % i], need_grad=need_grad, u8=first if i == 0 else None,
+                                defer_act=defer)
+                x2, tf2 = (y1, s1.tf_out()) if defer else (b['a1_%d' % i], None)
                 if i < 5:
                     skip = b['cat_%d' % i].slice(wp[i + 1], wp[i])
-                    s2.forward(b['a1_%d' % i], train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad)
+                    s2.forward(x2, train, drop[name], out=skip, pool_out=b['p_%d' % (i + 1)], need_grad=need_grad, x_tf=tf2)
                     cur = b['p_%d' % (i + 1)]
                 else:
                     s2.forward(b['a1_%d' % i], train, drop[name], need_grad=need_grad,
@@ -525,13 +530,15 @@ class _ZFUnetPlan(object):
                 s1, s2 = self.stages[name]
                 if self.subpixel:
                     s1.conv.bind_up(b.get('u_%d' % lvl), b.get('du_%d' % lvl))
-                s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad)
+                defer = self._defer(s1, s2, b['cat_%d' % lvl], b['b1_%d' % lvl], train, need_grad)
+                y1 = s1.forward(b['cat_%d' % lvl], train, None, out=b['b1_%d' % lvl], need_grad=need_grad, defer_act=defer)
+                x2, tf2 = (y1, s1.tf_out()) if defer else (b['b1_%d' % lvl], None)
                 if lvl > 0:
-                    s2.forward(b['b1_%d' % lvl], train, drop[name], need_grad=need_grad,
+                    s2.forward(x2, train, drop[name], need_grad=need_grad,
                                up_out=(b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]) if self._upsampled(lvl - 1, N, H, W) else None),
-                               out=b.get('u_%d' % (lvl - 1)))
+                               out=b.get('u_%d' % (lvl - 1)), x_tf=tf2)
                 else:
-                    s2.forward(b['b1_0'], train, drop[name], out=b['f0'], need_grad=need_grad)
+                    s2.forward(x2, train, drop[name], out=b['f0'], need_grad=need_grad, x_tf=tf2)
         except BaseException:
             if ckey is not None:
                 self._plan_abort(ckey)
@@ -542,6 +549,15 @@ class _ZFUnetPlan(object):
         self.generation += 1                       # every forward overwrites the activation buffers
         self._last_train = bool(train)
         return self._head(b, N, H, W)
+
+    def _defer(self, s1, s2, x1, a1, train, need_grad):
+        """May the block's first stage skip its activation pass (its second convolution and that one's weight gradient
+        apply BatchNorm + ReLU to the raw output while they load)?"""
+        if self.rt.code != nv.BF16 or not s1.defer_act_ok(x1, train, need_grad) or not isinstance(s2.conv, ConvOp):
+            return False
+        y = s1.buffers(x1.N, a1.H, a1.W)['y']
+        y2 = s2.buffers(x1.N, a1.H, a1.W)['y']
+        return s2.conv.fprop_tf_ok(y, y2) and s2.conv.wgrad_tf_ok(y, y2)
 
     def _head(self, b, N, H, W):
         """The 1x1 classifier (zf_unet.py:58) as ONE launch outside the recorded list, straight into the tensor the caller

@@ -93,6 +93,7 @@ SIGNATURES = {
     'segnb_conv_fprop_u8': [ctypes.POINTER(ConvGeom), _P, c_int, c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                             _P, _P, c_int, _P, _P, _P, c_int, _P],
     'segnb_bn_finalize': [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, c_int, _P, _P],
+    'segnb_bn_finalize_keep': [_P, c_int, c_int, c_double, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P],
     'segnb_bn_act_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P,
                          c_int, _P, c_int, _P, c_int, _P],
     'segnb_bn_act_bwd_reduce': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int,

@@ -987,9 +987,24 @@ class Stage(object):
             self._bufs[key] = b
         return b
 
-    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True, u8=None):
+    def defer_act_ok(self, xv, train, need_grad):
+        """Can this stage skip its activation pass and leave BatchNorm + activation to the consumer's loads (defer_act)?"""
+        return bool(self.bn is not None and train and need_grad and self.fuse_finalize and self.consumer_fusion)
+
+    # BatchNorm + activation of a block's FIRST convolution applied by the second one while it loads its rows (conv_roll_kernel,
+    # segnb_conv_fprop_tf): the activated tensor between them is never written (-0.4 GB of HBM traffic per ZF_UNET step at
+    # bs=32).  OFF by default (SEGNB_CONSUMER_FUSION=1 enables): measured on MI355X, same box, alternating runs, 5.368 / 5.378
+    # ms per step with it against 5.373 / 5.384 without -- the two activation passes it removes (2 x ~38 us) come back as
+    # slower convolutions and weight gradients, whose loads now carry ~10 VALU operations per element (profiles/r04_ab.txt)
+    consumer_fusion = os.environ.get('SEGNB_CONSUMER_FUSION', '0') != '0'
+
+    def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True, u8=None, x_tf=None,
+                defer_act=False):
         """u8: (uint8 NHWC batch, InputNorm) -- this stage is the network's first convolution and reads the image
-        itself (segnb_conv_fprop_u8); xv then only RECEIVES the normalised pixels (for the weight gradient)."""
+        itself (segnb_conv_fprop_u8); xv then only RECEIVES the normalised pixels (for the weight gradient).
+        x_tf: xv is the PRE-BatchNorm output of the producing stage and x_tf the segnb_operand_tf that turns it into this
+        convolution's input (ConvOp.tf_act): forward and weight gradient apply it while they load.
+        defer_act: no activation pass -- the caller hands (y View, tf) of this stage to its consumer (returned by tf_out())."""
         rt = self.rt
         Ho, Wo = self.conv.out_hw(xv.H, xv.W)
         b = self.buffers(xv.N, Ho, Wo)
@@ -1014,12 +1029,25 @@ class Stage(object):
             self.conv.fprop(xv, out, None, epilogue=(coef, self.act, self.slope))
             self._saved = None
             return out
+        self._x_tf = x_tf
         if u8 is not None:
             self.conv.fprop_u8(u8[0], u8[1], yv, self.stats if use_batch_stats else None, xv if need_grad else None)
+        elif x_tf is not None:
+            self.conv.fprop_tf(xv, x_tf, yv, self.stats if use_batch_stats else None)
         else:
             self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
         coef = None
         fused = use_batch_stats and self.fuse_finalize and need_grad
+        if defer_act:
+            assert fused and dropmul is None and pool_out is None and up_out is None
+            bn = self.bn
+            nv.call('segnb_bn_finalize_keep', nv.ptr(self.stats), self.C, self.Cp, float(xv.N * Ho * Wo),
+                    nv.ptr(bn.weight.detach()), nv.ptr(bn.bias.detach()), BN_EPS, BN_MOMENTUM, nv.ptr(bn.running_mean),
+                    nv.ptr(bn.running_var), nv.ptr(bn.num_batches_tracked), nv.ptr(self.coef), nv.ptr(self.sums), rt.stream)
+            self._stats_stale = True
+            self._saved = (xv, yv, None, True)
+            self._fused_fwd = True
+            return yv
         if fused:
             # finalize folded into the activation pass (one launch less per layer and direction); the statistics are
             # cleared by this layer's backward (segnb_bn_bwd_apply_fused), the backward sums here
@@ -1046,6 +1074,10 @@ class Stage(object):
                 vld(up_out), None, 0, rt.stream)
         self._saved = (xv, yv, dropmul, coef is not None)
         return yv
+
+    def tf_out(self):
+        """the operand transform a consumer applies to this stage's pre-BatchNorm output (after forward(..., defer_act=True))"""
+        return ConvOp.tf_act(self.coef, self.Cp, self.act, self.slope)
 
     def reduce_in_producer(self):
         """-> the (y, coef, sums, act, slope) a data-gradient launch needs to do THIS layer's BatchNorm-backward
@@ -1129,15 +1161,25 @@ class Stage(object):
             # no BatchNorm: dy = dz, d(bias) = sum dz (accumulated through the dbeta slot)
             nv.call('segnb_bn_bwd_finalize', nv.ptr(self.sums), self.C, self.Cp, count, None, nv.ptr(self.coef),
                     nv.ptr(self.bcoef), None, nv.ptr(gbias), 1, rt.stream)
+        x_tf = getattr(self, '_x_tf', None)
+
+        def wgrad(unpack):
+            if x_tf is not None:
+                # the convolution's input is not in memory: recomputed from the producer's pre-BatchNorm output on load
+                assert self.defer_unpack and not unpack
+                grads.grad_of(self.conv.weight)                 # (noted as touched; the batched unpack writes it)
+                self.conv.wgrad_tf(xv, x_tf, dz, None)
+            else:
+                self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=unpack)
         side = rt.fork_side() if (self.defer_unpack and dx is not None and postponed is None) else None
         if postponed is not None and self.defer_unpack and dx is not None and rt.side_stream() is not None:
             # launched later by the plan (flush_postponed): x and dy of this layer stay untouched until then
-            postponed.append(lambda: self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False))
+            postponed.append(lambda: wgrad(False))
         elif side is not None:
             with torch.cuda.stream(side):
-                self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=False)
+                wgrad(False)
         else:
-            self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=not self.defer_unpack)
+            wgrad(not self.defer_unpack)
         fused = False
         if dx is not None:
             ep = fuse_reduce_of.reduce_in_producer() if fuse_reduce_of is not None else None
