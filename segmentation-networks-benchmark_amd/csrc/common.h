@@ -118,7 +118,8 @@ int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_byt
 // rolling-window kernel for the thin layers, weights in registers, no block-level synchronisation (fprop_roll.hip)
 int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked, unsigned w_bytes,
                          const float* bias, int bias_n, void* out, double* stats, hipStream_t stream,
-                         const segnb_bn_reduce_epilogue* bn = nullptr, const segnb_operand_tf* tf = nullptr);
+                         const segnb_bn_reduce_epilogue* bn = nullptr, const segnb_operand_tf* tf = nullptr,
+                         const segnb_upcat_src* uc = nullptr);
 // first layer: 8-channel (3 padded) input, <= 32 output channels (fprop_c8.hip)
 int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
                        void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep = nullptr);

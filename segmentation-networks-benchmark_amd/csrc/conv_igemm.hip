@@ -1403,7 +1403,10 @@ extern "C" int segnb_conv_fprop_upcat(const segnb_conv_geom* g, int dtype, const
     const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + (g->Ci - src->Cu)) * 2;
     const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
     SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
-    int rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
+    int rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
+                                  nullptr, nullptr, src);
+    if (rc == 0)
+        rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,
                                 nullptr, nullptr, src);
     if (rc == 0)
         rc = segnb_fprop_dma_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, bias, bias_n, out, stats, (hipStream_t)stream,

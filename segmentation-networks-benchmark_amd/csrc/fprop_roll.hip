@@ -49,6 +49,13 @@ struct RollArgs {
     double* bn_sums;
     int bn_act;
     float bn_slope;
+    // K split over the waves of a strip (template KSP > 1: wave k of a strip takes input channels [32 k, 32 k + 32) and the
+    // partial sums meet in LDS): the FIRST nchu 32-channel slices may come from the low-resolution tensor u -- the virtual concat
+    // of segnb_conv_fprop_upcat: pixel (h, w) of those channels is u pixel (h >> 1, w >> 1) -- the others from x (channel 0 of x =
+    // logical channel 32 * nchu)
+    const bf16_t* u;
+    unsigned u_bytes;
+    int ld_u, nchu, Hu, Wu;
     // transform of the input on its way into LDS (template parameter TF):
     //   TF = 1  x holds the PRE-BatchNorm output y of the producing layer; the convolution's operand is
     //           round(drop * act((y - mean) * scale + shift)) -- bn_act_fwd_kernel's expression -- and never exists in memory
@@ -98,8 +105,12 @@ __device__ __forceinline__ unsigned relu_pk2bf(unsigned pk) {
 // NF: 16-pixel fragments per strip row; EPI: 0 plain, 1 BatchNorm statistics of the output, 2 BatchNorm-backward reduction
 // of the producing layer; TF: input transform (RollArgs); DL: rows of global loads in flight per wave (register sets);
 // WPS: waves per SIMD the register allocation is held to (2: <= 256 registers, 1: <= 512)
-template <int KS, int COF, int NF, int EPI, int TF, int DL, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
+// KSP / CSP: waves per strip that split the INPUT channels (32 each; partial sums reduced through LDS, the epilogue of output row o
+// done by wave o % KSP) / the OUTPUT channels (16 * COF each, independent).  With a split a block is ONE strip (KSP * CSP waves)
+template <int KS, int COF, int NF, int EPI, int TF, int DL, int WPS, int KSP = 1, int CSP = 1>
+__global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void conv_roll_kernel(const RollArgs a) {
+    constexpr int WST = KSP * CSP, NWB = WST == 1 ? 4 : WST, SPB = NWB / WST, NTHR = NWB * 64;
+    static_assert(WST == 1 || (KS == 1 && TF == 0 && EPI != 2), "split strips: 32 input channels per wave, plain operands");
     constexpr int CI = 32 * KS, CPP = CI / 8, PXB = CI * 2, RW = 16 * NF + 2, ROWB = RW * PXB;
     constexpr int NLD = (RW * CPP + 63) / 64;
     constexpr int NP = COF / 2;                      // 32-channel output pairs
@@ -107,8 +118,11 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
     constexpr int UN = DL % 3 == 0 ? DL : 3 * DL;    // unroll: ring slot (i % 3) and register set (i % DL) both static
     static_assert(COF % 2 == 0, "output fragments are stored in pairs");
     static_assert(TF == 0 || 64 % CPP == 0, "a lane's channel chunk must not depend on the load instruction");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4][3 * ROWB];
-    __shared__ double red[2][16 * COF];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NWB][3 * ROWB];
+    __shared__ double red[2][16 * COF * CSP];
+    // K split: partial accumulator rows, [writer wave][row parity][fragment (f, h)][lane] float4
+    constexpr int XFR = NF * COF;
+    __shared__ __attribute__((aligned(16))) float xch[KSP > 1 ? KSP * 2 * XFR * 64 * 4 : 4];
     // per-channel constants of the input transform / the BatchNorm-reduce epilogue live in LDS, not in registers (the weights
     // hold 72-144 of the 256): a lane re-reads the 8 values of its chunk where it uses them (same address in 16 lanes: broadcast)
     __shared__ __attribute__((aligned(16))) float tfc[TF == 0 ? 1 : 5][TF == 0 ? 4 : CI];
@@ -117,6 +131,8 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* const my = smem[wave];
     const int n16 = lane & 15, g = lane >> 4;
+    const int sub = wave % WST, kpart = sub % KSP, cpart = sub / KSP, sidx = wave / WST;
+    const int co0 = cpart * 16 * COF;                   // first output channel of this wave
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
         const_cast<bf16_t*>(BNRED ? a.bn_y : a.x), 0, BNRED ? (int)a.bn_y_bytes : 0, 0x00020000);
 
     if (STATS || BNRED) {
-        for (int i = threadIdx.x; i < 2 * 16 * COF; i += 256) (&red[0][0])[i] = 0.0;
+        for (int i = threadIdx.x; i < 2 * 16 * COF * CSP; i += NTHR) (&red[0][0])[i] = 0.0;
         __syncthreads();
     }
 
@@ -139,8 +155,8 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
         for (int h = 0; h < COF; ++h)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int co = h * 16 + n16;
-                const unsigned off = co < a.Co ? (unsigned)(co * a.Ktot + a.tap[t] * a.Ci + ks * 32 + g * 8) * 2u : OOB;
+                const int co = co0 + h * 16 + n16;
+                const unsigned off = co < a.Co ? (unsigned)(co * a.Ktot + a.tap[t] * a.Ci + kpart * 32 + ks * 32 + g * 8) * 2u : OOB;
                 const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0);
                 Wf[t][h][ks] = __builtin_bit_cast(bf16x8_t, v);
             }
@@ -151,14 +167,14 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
     for (int h = 0; h < COF; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int co = h * 16 + g * 4 + e;
+            const int co = co0 + h * 16 + g * 4 + e;
             bs[h][e] = (!BNRED && a.bias != nullptr && co < a.bias_n) ? a.bias[co] : 0.f;      // (a data gradient has no bias)
         }
     // BatchNorm-reduce epilogue: z = y * sc + shh decides act'(z); the second sum is taken over dz * y (raw) and centred at
     // the flush, in fp64: sum dz * (y - mean) = sum dz * y - mean * sum dz (two constants per channel instead of three)
     float bneg = 0.f;
     if constexpr (BNRED) {
-        for (int c = threadIdx.x; c < 16 * COF; c += 256) {
+        for (int c = threadIdx.x; c < 16 * COF; c += NTHR) {
             const bool in = c < a.Co;
             bnc[0][c] = in ? a.bn_coef[c] : 0.f;
             bnc[1][c] = in ? a.bn_coef[a.Co + c] - a.bn_coef[2 * a.Co + c] * a.bn_coef[c] : 0.f;
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
     float tneg = 0.f;
     const int tc0 = (lane % CPP) * 8;
     if constexpr (TF != 0) {
-        for (int c = threadIdx.x; c < CI; c += 256) {
+        for (int c = threadIdx.x; c < CI; c += NTHR) {
             const float sc = a.tf_coef[c], sh = a.tf_coef[a.tf_Cp + c], mu = a.tf_coef[2 * a.tf_Cp + c];
             tfc[0][c] = sc;
             if constexpr (TF == 1) {
@@ -218,8 +234,14 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
                 roff[dx][f][ks] = j * PXB + (((4 * ks + g) ^ roll_sw<CI>(j)) << 4);
             }
 
-    const int nwaves = gridDim.x * 4;
-    for (int task = blockIdx.x * 4 + wave; task < a.NTASK; task += nwaves) {
+    // input source of this wave: x, or (virtual concat, K split) its slice of the low-resolution tensor u
+    const bool from_u = KSP > 1 && a.u != nullptr && kpart < a.nchu;
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(KSP > 1 && a.u != nullptr ? a.u : a.x), 0, KSP > 1 && a.u != nullptr ? (int)a.u_bytes : 0, 0x00020000);
+    const int src_ld = from_u ? a.ld_u : a.ld_x;
+    const int src_ch = from_u ? kpart * 32 : (KSP > 1 ? (kpart - (a.u != nullptr ? a.nchu : 0)) * 32 : 0);
+    const int nstrips = gridDim.x * SPB;
+    for (int task = blockIdx.x * SPB + sidx; task < a.NTASK; task += nstrips) {
         const int strip = task % a.NSTRIP;
         const int t2 = task / a.NSTRIP;
         const int seg = t2 % a.NSEG, n = t2 / a.NSEG;
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
             const int L = 64 * m + lane;
             const int col = c0 - 1 + L / CPP;
             colv[m] = woff[m] >= 0 && (unsigned)col < (unsigned)a.W;
-            coff[m] = colv[m] ? (unsigned)(col * a.ld_x * 2 + (L % CPP) * 16) : OOB;
+            coff[m] = colv[m] ? (unsigned)((from_u ? col >> 1 : col) * src_ld * 2 + src_ch * 2 + (L % CPP) * 16) : OOB;
             coff2[m] = (TF == 2 && colv[m]) ? (unsigned)(col * a.ld_x2 * 2 + (L % CPP) * 16) : OOB;
         }
         // TF = 1: the Dropout2d multiplier of the image (>= 0) folds into the affine map, drop * act(z) = act(drop * z) for
@@ -261,10 +283,13 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
             const int gi = r0 - 1 + i;
             const bool rv = i < nin && (unsigned)gi < (unsigned)a.H;
             const unsigned pixrow = (unsigned)((n * a.H + gi) * a.W);
+            const unsigned rowoff = from_u ? (unsigned)((n * a.Hu + (gi >> 1)) * a.Wu) * (unsigned)(a.ld_u * 2)
+                                           : pixrow * (unsigned)(a.ld_x * 2);
 #pragma unroll
             for (int m = 0; m < NLD; ++m) {
-                const unsigned voff = rv ? pixrow * (unsigned)(a.ld_x * 2) + coff[m] : OOB;
-                ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+                const unsigned voff = rv ? rowoff + coff[m] : OOB;
+                if (from_u) ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)voff, 0, 0);
+                else ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
                 if constexpr (TF == 2) {
                     const unsigned voff2 = rv ? pixrow * (unsigned)(a.ld_x2 * 2) + coff2[m] : OOB;
                     ld2[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)voff2, 0, 0);
@@ -352,7 +377,36 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
             constexpr int U = UI % 3, U1 = (U + 1) % 3, U2 = (U + 2) % 3, S1 = (UI + 1) % DL;
             // -- E1: output row o = i - 2 (accumulator slot U1, final since step i - 1) leaves
             const int o = i - 2;
-            const bool ev = o >= 1 && o <= rows;
+            const bool rowv = o >= 1 && o <= rows;
+            bool ev = rowv;
+            if constexpr (KSP > 1) {
+                // K split: every wave of the strip holds a partial sum of the row; wave o % KSP gathers the others' and does the
+                // row's epilogue (rotating: the epilogue work is spread over the waves).  One LDS barrier per step for the
+                // block (= the strip: all its waves run the same steps); slots alternate with the step's parity.
+                const bool owner = ((o + 3 * KSP) % KSP) == kpart;
+                float* const xw = xch + (size_t)((kpart * 2 + (i & 1)) * XFR) * 256;
+                if (rowv && !owner) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int h = 0; h < COF; ++h)
+                            *reinterpret_cast<f32x4_t*>(xw + ((f * COF + h) * 64 + lane) * 4) = acc[U1][f][h];
+                }
+                lds_barrier();
+                if (rowv && owner) {
+#pragma unroll
+                    for (int k2 = 1; k2 < KSP; ++k2) {
+                        const int kp = (kpart + k2) % KSP;
+                        const float* const xr = xch + (size_t)((kp * 2 + (i & 1)) * XFR) * 256;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+#pragma unroll
+                            for (int h = 0; h < COF; ++h)
+                                acc[U1][f][h] += *reinterpret_cast<const f32x4_t*>(xr + ((f * COF + h) * 64 + lane) * 4);
+                    }
+                }
+                ev = rowv && owner;
+            }
             u32x4_t P[NF][NP];
             if (ev) {
                 const int go = r0 - 1 + o;
@@ -373,7 +427,7 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
                         u32x4_t v;
                         v.x = r0s[0]; v.y = r1s[0]; v.z = r0s[1]; v.w = r1s[1];
                         P[f][p] = v;
-                        const int ch = p * 32 + cidx * 8;
+                        const int ch = co0 + p * 32 + cidx * 8;
                         const bool ok = col < a.W && ch < a.Co;
                         const unsigned voff = ok ? ((prow + (unsigned)col) * (unsigned)a.ld_out + (unsigned)ch) * 2u : OOB;
                         __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)voff, 0, 0);
@@ -494,14 +548,14 @@ __global__ __launch_bounds__(256, WPS) void conv_roll_kernel(const RollArgs a) {
                     v2 += __shfl_xor(v2, o);
                 }
                 if (n16 == 0) {
-                    atomicAdd(&red[0][p * 32 + cidx * 8 + e], v1);
-                    atomicAdd(&red[1][p * 32 + cidx * 8 + e], v2);
+                    atomicAdd(&red[0][co0 + p * 32 + cidx * 8 + e], v1);
+                    atomicAdd(&red[1][co0 + p * 32 + cidx * 8 + e], v2);
                 }
             }
         __syncthreads();
         double* const acc_out = BNRED ? a.bn_sums : a.stats;
-        for (int i = threadIdx.x; i < 2 * 16 * COF; i += 256) {
-            const int which = i / (16 * COF), col = i % (16 * COF);
+        for (int i = threadIdx.x; i < 2 * 16 * COF * CSP; i += NTHR) {
+            const int which = i / (16 * COF * CSP), col = i % (16 * COF * CSP);
             if (col < a.Co)
                 atomicAdd(&acc_out[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + col], red[which][col]);
         }
@@ -534,17 +588,52 @@ int launch_roll(RollArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// strips whose waves split the input channels (KSP) or the output channels (CSP): one block per strip
+template <int NF, int KSP, int CSP>
+int launch_roll_split(RollArgs& a, hipStream_t stream) {
+    constexpr int WST = KSP * CSP;
+    a.NSTRIP = (a.W + 16 * NF - 1) / (16 * NF);
+    const int per_cu = 8 / WST;                                  // strips in flight per CU at two waves per SIMD
+    const int slots = segnb_knob_conv_cus() * per_cu;
+    int nseg = (int)(slots / ((long long)a.N * a.NSTRIP));
+    if (nseg < 1) nseg = (a.H + 15) / 16;
+    if (nseg > a.H) nseg = a.H;
+    const int sr = (a.H + nseg - 1) / nseg;
+    a.SR = sr;
+    a.NSEG = (a.H + sr - 1) / sr;
+    a.NTASK = a.N * a.NSEG * a.NSTRIP;
+    int blocks = a.NTASK;
+    if (blocks > slots) blocks = slots;
+    if (a.stats != nullptr)
+        hipLaunchKernelGGL((conv_roll_kernel<1, 2, NF, 1, 0, 3, 2, KSP, CSP>), dim3(blocks), dim3(WST * 64), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_roll_kernel<1, 2, NF, 0, 0, 3, 2, KSP, CSP>), dim3(blocks), dim3(WST * 64), 0, stream, a);
+    return 0;
+}
+
 }  // namespace
 
 // 1 = handled, 0 = not applicable, else error
 int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked, unsigned w_bytes,
                          const float* bias, int bias_n, void* out, double* stats, hipStream_t stream,
-                         const segnb_bn_reduce_epilogue* bn, const segnb_operand_tf* tf) {
+                         const segnb_bn_reduce_epilogue* bn, const segnb_operand_tf* tf, const segnb_upcat_src* uc) {
     const int knob = segnb_knob_fprop_roll();
     if (!knob) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != g->Ho || g->Wi != g->Wo) return 0;
-    if (g->Ci != 32 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return 0;
+    if (g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return 0;
+    // 32 -> <= 32: one wave per strip.  Wider inputs (64, 96 -> <= 32: the waves of a strip split K) and wider outputs
+    // (32 -> 64, 96: they split the output channels) when nothing else rides on the launch
+    // Measured (MI355X, bs=32, profiles/r04_ab.txt): two-way splits pay -- 32 -> 64 @ 112 x 112 38.2 -> 28.5 us, 64 -> 32 32.2 -> 28.3
+    // us -- three-way splits do not: 96 -> 32 @ 224 x 224 with the K split 141 -> 208 us (three waves in lock step behind one
+    // barrier per row lose what independent waves hide), 32 -> 96 with the channel split 134 -> 167 us (every wave re-loads the
+    // whole input and writes a third of each pixel); those stay on conv_fprop_rw_kernel.  The virtual concat (uc) therefore
+    // never reaches this kernel.
+    if (uc != nullptr) return 0;
+    const bool plain1 = g->Ci == 32 && g->Co <= 32;
+    const bool ksplit = g->Ci == 64 && g->Co <= 32 && bn == nullptr && tf == nullptr && knob >= 2;
+    const bool csplit = g->Ci == 32 && g->Co == 64 && bn == nullptr && tf == nullptr && knob >= 2;
+    if (!plain1 && !ksplit && !csplit) return 0;
     RollArgs a;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {
@@ -573,6 +662,27 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     a.x2 = nullptr;
     a.tf_coef = a.tf_bcoef = a.tf_drop = nullptr;
     a.bn_y = nullptr;
+    a.u = nullptr;
+    a.u_bytes = 0;
+    a.ld_u = a.nchu = a.Hu = a.Wu = 0;
+    if (uc != nullptr) {
+        a.u = (const bf16_t*)uc->u;
+        a.ld_u = uc->ld_u;
+        a.nchu = uc->Cu / 32;
+        a.Hu = g->Hi / 2;
+        a.Wu = g->Wi / 2;
+        const long long ub = (((long long)g->N * a.Hu * a.Wu - 1) * uc->ld_u + uc->Cu) * 2;
+        if (ub >= (1ll << 31)) return 0;
+        a.u_bytes = (unsigned)ub;
+    }
+    if (ksplit) {
+        const int rc = launch_roll_split<2, 2, 1>(a, stream);
+        return rc ? rc : 1;
+    }
+    if (csplit) {
+        const int rc = launch_roll_split<2, 1, 2>(a, stream);
+        return rc ? rc : 1;
+    }
     if (bn != nullptr) {
         if (stats != nullptr) return 0;
         const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;

@@ -1228,11 +1228,17 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
     sums_f2 = rt.zeros((16, 2, C1), torch.float64)
     op.dgrad(dyv, dx_f, bn_reduce=(y1, coef, sums_f2, act, 0.01))
     torch.cuda.synchronize()
-    assert torch.equal(dx_f.t, dx_plain.t)
+    if C2 == 32:
+        assert torch.equal(dx_f.t, dx_plain.t)          # (the same kernel with and without the epilogue)
+    else:
+        # 64 -> 32: the plain data gradient runs on conv_roll_kernel with the K split over two waves, the fused one on
+        # conv_fprop_rw_kernel -- another summation order of the same products
+        check('dx fused vs plain', dx_f.t, dx_plain.t, 'bf16')
     a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
     scale = np.abs(b).max(axis=1, keepdims=True) + 1e-30
-    assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
-    np.testing.assert_allclose(a / scale, b / scale, atol=1e-4)
+    tight = C2 == 32          # (sums_ref is taken on dx_plain: the same values bit for bit only when the kernels are the same)
+    assert np.abs(a - b).max() <= (2e-5 if tight else 2e-3) * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
+    np.testing.assert_allclose(a / scale, b / scale, atol=1e-4 if tight else 3e-3)
     # fixed summation order inside a block, fp64 across blocks: run-to-run equal to fp64 rounding
     np.testing.assert_allclose(sums_f2.sum(0).cpu().numpy(), a, rtol=1e-12, atol=1e-9)
     if N * H * W <= 20000:

@@ -647,3 +647,41 @@ torch.distributed.destroy_process_group()
     res = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
     print('first bucket enqueued %.3f ms before the end of backward' % res['lead_ms'])
     assert res['lead_ms'] > 0.2 and np.isfinite(res['loss'])
+
+
+def test_consumer_side_batchnorm_matches_the_activation_pass():
+    """SEGNB_CONSUMER_FUSION: at the 224 x 224 level the second convolution of a block (and its weight gradient) applies the
+    first one's BatchNorm + ReLU while it loads (segnb_conv_fprop_tf / segnb_conv_wgrad_tf) -- the activated tensor of
+    zf_unet.py:12-17 between them is never written.  Same step as the plan with the activation passes: loss and logits to
+    bf16 rounding of a few elements, every gradient in the same direction."""
+    from lib.losses import BCEAndDiceLoss
+    from lib.models.zf_unet import ZF_UNET
+    from segnb import engine
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 224, 224, generator=g).cuda()
+    y = (torch.rand(4, 1, 224, 224, generator=g) > 0.7).long().cuda()
+    res = []
+    keep = engine.Stage.consumer_fusion
+    try:
+        for fus in (False, True):
+            engine.Stage.consumer_fusion = fus
+            torch.manual_seed(5)
+            m = ZF_UNET(dropout_val=0.0).cuda().train()
+            for _ in range(2):                     # (second step: the recorded lists replay)
+                m.zero_grad()
+                out = m(x)
+                loss = BCEAndDiceLoss()(out, y)
+                (4 * loss).backward()
+            torch.cuda.synchronize()
+            res.append((out.detach().float().cpu(), loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()}))
+    finally:
+        engine.Stage.consumer_fusion = keep
+    (o0, l0, g0), (o1, l1, g1) = res
+    assert abs(l0 - l1) < 2e-4, (l0, l1)
+    assert float((o0 - o1).abs().max()) < 3e-2 * float(o0.abs().max())
+    for n in g0:
+        a, b = g0[n].flatten(), g1[n].flatten()
+        if float(a.norm()) < 1e-6 * max(float(v.norm()) for v in g0.values()):
+            continue
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        assert cos > 0.98, (n, cos)
