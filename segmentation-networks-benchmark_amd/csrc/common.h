@@ -205,8 +205,13 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
+// two fp32 -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 through the vector conversion (two scalar
+// conversions + shift + or compile to four instructions; same RNE result)
+typedef float segnb_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 segnb_bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    const segnb_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, segnb_bf16x2_t));
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     uint4 u;

@@ -37,7 +37,9 @@ struct RollArgs {
     bf16_t* out;
     double* stats;
     unsigned x_bytes, w_bytes, out_bytes;
-    int N, H, W, Ci, Co, ld_x, ld_out, Ktot;
+    int N, H, W, Ci, Co, ld_x, ld_out, Ktot;      // H x W: the OUTPUT grid
+    int Hi, Wi;           // input tensor; input row of output row r under window row dy = r + dy + dhmin (dhmin = -1: padding 1,
+    int dhmin, dwmin;     // 0: no padding -- lib/models/linknet.py:60 -- -2: its data gradient)
     int tap[9];           // packed-matrix tap index of window position (dy, dx) at [dy * 3 + dx]
     int SR, NSEG, NSTRIP, NTASK;
     // fused BatchNorm-backward reduction of the layer that produced this data gradient's forward input
@@ -255,8 +257,8 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
             const int L = 64 * m + lane;
-            const int col = c0 - 1 + L / CPP;
-            colv[m] = woff[m] >= 0 && (unsigned)col < (unsigned)a.W;
+            const int col = c0 + a.dwmin + L / CPP;
+            colv[m] = woff[m] >= 0 && (unsigned)col < (unsigned)a.Wi;
             coff[m] = colv[m] ? (unsigned)((from_u ? col >> 1 : col) * src_ld * 2 + src_ch * 2 + (L % CPP) * 16) : OOB;
             coff2[m] = (TF == 2 && colv[m]) ? (unsigned)(col * a.ld_x2 * 2 + (L % CPP) * 16) : OOB;
         }
@@ -280,9 +282,9 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
         u32x4_t ld[DL][NLD], ld2[TF == 2 ? DL : 1][NLD];
         auto issue = [&](auto set_c, int i) {
             constexpr int set = decltype(set_c)::value;
-            const int gi = r0 - 1 + i;
-            const bool rv = i < nin && (unsigned)gi < (unsigned)a.H;
-            const unsigned pixrow = (unsigned)((n * a.H + gi) * a.W);
+            const int gi = r0 + a.dhmin + i;
+            const bool rv = i < nin && (unsigned)gi < (unsigned)a.Hi;
+            const unsigned pixrow = (unsigned)((n * a.Hi + gi) * a.Wi);
             const unsigned rowoff = from_u ? (unsigned)((n * a.Hu + (gi >> 1)) * a.Wu) * (unsigned)(a.ld_u * 2)
                                            : pixrow * (unsigned)(a.ld_x * 2);
 #pragma unroll
@@ -299,8 +301,8 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
         // row i held in register set `set` -> ring slot `slot`, transformed on the way
         auto publish = [&](auto set_c, auto slot_c, int i) {
             constexpr int set = decltype(set_c)::value, slot = decltype(slot_c)::value;
-            const int gi = r0 - 1 + i;
-            const bool rv = (unsigned)gi < (unsigned)a.H;      // rows outside the image are zero AFTER the transform
+            const int gi = r0 + a.dhmin + i;
+            const bool rv = (unsigned)gi < (unsigned)a.Hi;     // rows outside the image are zero AFTER the transform
 #pragma unroll
             for (int m = 0; m < NLD; ++m) {
                 u32x4_t v = ld[set][m];
@@ -620,8 +622,20 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     const int knob = segnb_knob_fprop_roll();
     if (!knob) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
-    if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != g->Ho || g->Wi != g->Wo) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo) return 0;
     if (g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return 0;
+    int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
+    for (int t = 1; t < 9; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dhmax = g->dh[t] > dhmax ? g->dh[t] : dhmax;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+        dwmax = g->dw[t] > dwmax ? g->dw[t] : dwmax;
+    }
+    if (dhmax - dhmin != 2 || dwmax - dwmin != 2) return 0;
+    // same-size (padding 1) everywhere; another padding (the valid 3 x 3 convolution of lib/models/linknet.py:60 and its data
+    // gradient: input and output grids differ) only for the plain one-wave form
+    const bool same = g->Hi == g->Ho && g->Wi == g->Wo && dhmin == -1 && dwmin == -1;
+    if (!same && (bn != nullptr || tf != nullptr || uc != nullptr || g->Ci != 32 || g->Co > 32)) return 0;
     // 32 -> <= 32: one wave per strip.  Wider inputs (64, 96 -> <= 32: the waves of a strip split K) and wider outputs
     // (32 -> 64, 96: they split the output channels) when nothing else rides on the launch
     // Measured (MI355X, bs=32, profiles/r04_ab.txt): two-way splits pay -- 32 -> 64 @ 112 x 112 38.2 -> 28.5 us, 64 -> 32 32.2 -> 28.3
@@ -637,12 +651,12 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     RollArgs a;
     bool seen[9] = {false, false, false, false, false, false, false, false, false};
     for (int t = 0; t < 9; ++t) {
-        if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
-        const int k = (g->dh[t] + 1) * 3 + (g->dw[t] + 1);
+        const int k = (g->dh[t] - dhmin) * 3 + (g->dw[t] - dwmin);
         if (seen[k]) return 0;
         seen[k] = true;
         a.tap[k] = t;
     }
+    a.Hi = g->Hi; a.Wi = g->Wi; a.dhmin = dhmin; a.dwmin = dwmin;
     a.x = (const bf16_t*)in;
     a.w = (const bf16_t*)wpacked;
     a.bias = bias;

@@ -143,16 +143,139 @@ __global__ void bn_finalize_kernel(const BnFwdParams p, int Cp) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// raw 8-channel chunk as loaded (16 bytes of bf16 / 32 bytes of fp32): the conversion to fp32 is deferred to the first use,
+// so that a thread can keep the loads of several pixels -- and its coefficient prologue -- in flight at once.  A pass over a
+// small tensor is ONE dependent round trip long instead of one per pixel (4 pixels per thread: 8.5 -> ~6 us at 7x7 .. 28x28)
 template <typename T>
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+    uint4 u;
+};
+template <>
+struct Raw8<float> {
+    float4 a, b;
+};
+__device__ __forceinline__ void load_raw(const bf16_t* p, Raw8<bf16_t>& r) { r.u = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void load_raw(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void unpack_raw(const Raw8<bf16_t>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack_raw(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;
+    v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+// v rounded to the storage type in place and stored (p may be NULL: rounding only).  bf16: one v_cvt_pk_bf16_f32 per channel
+// pair gives the stored dword, the rounded values are its two halves
+__device__ __forceinline__ void round_store8(float* p, float (&v)[8]) {
+    if (p != nullptr) store8(p, v);
+}
+__device__ __forceinline__ void round_store8(bf16_t* p, float (&v)[8]) {
+    uint4 u;
+    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+    u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    if (p != nullptr) *reinterpret_cast<uint4*>(p) = u;
+}
+
+// exact a / d for 0 <= a < 2^31 through a double reciprocal (8 instructions; the integer division sequence is ~35 and
+// the pooled kernels are VALU-bound): the truncated product is off by at most one, the remainder says which way
+struct FastDiv {
+    int d;
+    double inv;
+    __device__ __forceinline__ explicit FastDiv(int d_) : d(d_), inv(1.0 / (double)d_) {}
+    __device__ __forceinline__ int div(int a) const {
+        const int q = (int)((double)a * inv);
+        const int r = a - q * d;
+        return q + (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    }
+};
+
+template <typename T, bool POOL, bool RES>
 __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ y, int ld_y, EwShape s,
                                                           const float* __restrict__ coef, int act, float slope,
                                                           const float* __restrict__ dropmul, T* __restrict__ out,
                                                           int ld_out, T* __restrict__ pool_out, int ld_pool,
                                                           T* __restrict__ up_out, int ld_up,
                                                           const T* __restrict__ res, int ld_res, const BnFwdParams fp) {
+    constexpr int U = 2;            // pixels per trip (no pooling)
+    constexpr int UP = 2;           // row-pair items per trip (pooling)
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
-    const int c0 = cc < s.CPP ? cc * 8 : 0;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    constexpr bool pooling = POOL;
+    const int stride = gridDim.x * s.PY;
+    // (check_ew guarantees 4*N*H*W < 2^31: 32-bit pixel indices)
+    const int npix = s.N * s.H * s.W, hw = s.H * s.W;
+    // pooling: a thread owns one pixel COLUMN of a row pair (2 pixels), so the loads / stores of a wave are
+    // contiguous runs of a row; the 2x2 window maximum meets its horizontal partner (lane ^ CT: the row is walked
+    // over an even padded width) through one cross-lane exchange.  (A thread per 2x2 window touched half of every
+    // 128-byte line per instruction.)
+    const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
+    const int Hp = s.H >> 1, Wp = s.W >> 1;
+    const int nitems = s.N * H2 * We;
+    const FastDiv d_hw(hw), d_w(s.W), d_img(H2 * We), d_we(We);
+    int it0 = blockIdx.x * s.PY + ty;
+
+    // ---- loads of one trip: everything that does not depend on the coefficients
+    constexpr int NRAW = POOL ? 2 * UP : U;
+    Raw8<T> ry[NRAW], rr[RES ? NRAW : 1];
+    Raw8<float> rdm[POOL ? UP : U];
+    int nn[U];
+    auto issue_plain = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pix = i0 + u * stride;
+            const int pc = pix < npix ? pix : i0;
+            load_raw(y + (long long)pc * ld_y + c0, ry[u]);
+            if constexpr (RES) load_raw(res + (long long)pc * ld_res + c0, rr[u]);
+            nn[u] = (dropmul != nullptr || up_out != nullptr) ? d_hw.div(pc) : 0;
+            if (dropmul != nullptr) load_raw(dropmul + nn[u] * s.Cp + c0, rdm[u]);
+        }
+    };
+    // pooling: ry / rr [2 * i + r] = row r of item i; rdm[i]
+    int pn[UP], ph2[UP], pw[UP];
+    auto issue_pool = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const int it = i0 + i * stride;
+            const int ic = it < nitems ? it : i0;
+            pn[i] = d_img.div(ic);
+            const int rem = ic - pn[i] * (H2 * We);
+            ph2[i] = d_we.div(rem);
+            pw[i] = rem - ph2[i] * We;
+            if (dropmul != nullptr) load_raw(dropmul + pn[i] * s.Cp + c0, rdm[i]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int hh = 2 * ph2[i] + r;
+                if (hh < s.H && pw[i] < s.W) {
+                    const long long pix = ((long long)pn[i] * s.H + hh) * s.W + pw[i];
+                    load_raw(y + pix * ld_y + c0, ry[2 * i + r]);
+                    if constexpr (RES) load_raw(res + pix * ld_res + c0, rr[2 * i + r]);
+                }
+            }
+        }
+    };
+    // the first trip's loads go out BEFORE the coefficient prologue (statistics -> fp64 arithmetic -> LDS -> barrier):
+    // two latency chains overlapped instead of run back to back
+    if (active) {
+        if constexpr (!pooling) {
+            if (it0 < npix) issue_plain(it0);
+        } else {
+            if (it0 < nitems) issue_pool(it0);
+        }
+    }
+
     float sc[8], sh[8], mu[8];
     if (fp.coef != nullptr) {
         // fused finalize: every block derives the coefficients of its CT*8 channels from the statistics (one
@@ -187,14 +310,14 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
             scoef[2][threadIdx.x] = mean;
         }
         __syncthreads();
-        if (cc >= s.CPP) return;
+        if (!active) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sc[e] = scoef[0][tx * 8 + e];
             sh[e] = scoef[1][tx * 8 + e];
             mu[e] = scoef[2][tx * 8 + e];
         }
-    } else if (cc >= s.CPP) {
+    } else if (!active) {
         return;
     } else if (coef != nullptr) {   // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
         load8(coef + c0, sc);
@@ -208,98 +331,100 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
             mu[e] = 0.f;
         }
     }
-    if (pool_out == nullptr) {
+
+    if constexpr (!pooling) {
         // no pooling: consecutive threads take consecutive pixels, so every load / store instruction of a wave
-        // covers one contiguous run (the 2x2-window walk below touches half of every 128-byte line per instruction)
-        // (check_ew guarantees 4*N*H*W < 2^31: 32-bit pixel indices, no 64-bit divisions in the loop)
-        const int npix = s.N * s.H * s.W, hw = s.H * s.W;
-        const bool need_n = dropmul != nullptr || up_out != nullptr;
-        for (int pix = blockIdx.x * s.PY + ty; pix < npix; pix += gridDim.x * s.PY) {
-            const int n = need_n ? pix / hw : 0;
-            float dm[8], v[8];
+        // covers one contiguous run
+        while (it0 < npix) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dm[e] = 1.f;
-            if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
-            load8(y + (long long)pix * ld_y + c0, v);
-            if (res != nullptr) {
-                float rv[8];
-                load8(res + (long long)pix * ld_res + c0, rv);
+            for (int u = 0; u < U; ++u) {
+                const int pix = it0 + u * stride;
+                if (pix >= npix) break;
+                float dm[8], v[8], rv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
-            } else {
+                for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+                if (dropmul != nullptr) unpack_raw(rdm[u], dm);
+                unpack_raw(ry[u], v);
+                if constexpr (RES) {
+                    unpack_raw(rr[u], rv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope), out);
-            }
-            if (out != nullptr) store8(out + (long long)pix * ld_out + c0, v);
-            if (up_out != nullptr) {
-                const int rem = pix - n * hw;
-                const int hh = rem / s.W, ww = rem - hh * s.W;
-                const long long W2x = 2ll * s.W;
-                const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
-                store8(up_out + p00 * ld_up + c0, v);
-                store8(up_out + (p00 + 1) * ld_up + c0, v);
-                store8(up_out + (p00 + W2x) * ld_up + c0, v);
-                store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
-            }
-        }
-        return;
-    }
-    // pooling: a thread owns one pixel COLUMN of a row pair (2 pixels), so the loads / stores of a wave are
-    // contiguous runs of a row; the 2x2 window maximum meets its horizontal partner (lane ^ CT: the row is walked
-    // over an even padded width) through one cross-lane exchange.  (A thread per 2x2 window touched half of every
-    // 128-byte line per instruction.)
-    const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
-    const int Hp = s.H >> 1, Wp = s.W >> 1;
-    const int nitems = s.N * H2 * We;
-    for (int it = blockIdx.x * s.PY + ty; it < nitems; it += gridDim.x * s.PY) {
-        const int n = it / (H2 * We);
-        const int rem = it - n * (H2 * We);
-        const int h2 = rem / We, w = rem - h2 * We;
-        float dm[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dm[e] = 1.f;
-        if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
-        float mx[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const int hh = 2 * h2 + dy;
-            if (hh < s.H && w < s.W) {
-                const long long pix = ((long long)n * s.H + hh) * s.W + w;
-                float v[8], rv[8];
-                load8(y + pix * ld_y + c0, v);
-                if (res != nullptr) {
-                    load8(res + pix * ld_res + c0, rv);
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                    for (int e = 0; e < 8; ++e) v[e] = dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope);
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] = round_as(dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope), out);
-                    mx[e] = fmaxf(mx[e], v[e]);
-                }
-                if (out != nullptr) store8(out + pix * ld_out + c0, v);
+                round_store8(out != nullptr ? out + (long long)pix * ld_out + c0 : (T*)nullptr, v);
                 if (up_out != nullptr) {
+                    const int n = nn[u];
+                    const int rem = pix - n * hw;
+                    const int hh = d_w.div(rem), ww = rem - hh * s.W;
                     const long long W2x = 2ll * s.W;
-                    const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * w;
+                    const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * ww;
                     store8(up_out + p00 * ld_up + c0, v);
                     store8(up_out + (p00 + 1) * ld_up + c0, v);
                     store8(up_out + (p00 + W2x) * ld_up + c0, v);
                     store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
                 }
             }
+            it0 += U * stride;
+            if (it0 < npix) issue_plain(it0);
         }
-        // horizontal partner: columns w and w^1 are lanes l and l^CT of one wave (items are walked in pairs)
+        return;
+    } else {
+    while (it0 < nitems) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], s.CT));
-        if ((w & 1) == 0 && h2 < Hp && (w >> 1) < Wp) {
-            const long long pp = ((long long)n * Hp + h2) * Wp + (w >> 1);
-            store8(pool_out + pp * ld_pool + c0, mx);
+        for (int i = 0; i < UP; ++i) {
+            // (no early exit: the partner lane of the exchange below walks the same items -- nitems and the stride are
+            // even -- and an item past the end only skips its loads and stores)
+            const bool live = it0 + i * stride < nitems;
+            const int n = pn[i], h2 = ph2[i], w = pw[i];
+            float dm[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+            if (dropmul != nullptr) unpack_raw(rdm[i], dm);
+            float mx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int hh = 2 * h2 + r;
+                if (live && hh < s.H && w < s.W) {
+                    const long long pix = ((long long)n * s.H + hh) * s.W + w;
+                    float v[8], rv[8];
+                    unpack_raw(ry[2 * i + r], v);
+                    if constexpr (RES) {
+                        unpack_raw(rr[2 * i + r], rv);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e] + rv[e], act, slope);
+                    round_store8(out != nullptr ? out + pix * ld_out + c0 : (T*)nullptr, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], v[e]);
+                    if (up_out != nullptr) {
+                        const long long W2x = 2ll * s.W;
+                        const long long p00 = ((long long)n * 2 * s.H + 2 * hh) * W2x + 2 * w;
+                        store8(up_out + p00 * ld_up + c0, v);
+                        store8(up_out + (p00 + 1) * ld_up + c0, v);
+                        store8(up_out + (p00 + W2x) * ld_up + c0, v);
+                        store8(up_out + (p00 + W2x + 1) * ld_up + c0, v);
+                    }
+                }
+            }
+            // horizontal partner: columns w and w^1 are lanes l and l^CT of one wave (items are walked in pairs)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], s.CT));
+            if (live && (w & 1) == 0 && h2 < Hp && (w >> 1) < Wp) {
+                const long long pp = ((long long)n * Hp + h2) * Wp + (w >> 1);
+                store8(pool_out + pp * ld_pool + c0, mx);
+            }
         }
+        it0 += UP * stride;
+        if (it0 < nitems) issue_pool(it0);
+    }
     }
 }
 
@@ -419,62 +544,45 @@ __device__ __forceinline__ void apply_src_coefs(const BnBwdParams& bp, const flo
     __syncthreads();
 }
 
-// one pixel of the backward: gradient sources -> dz, channel sums.  s2 accumulates dz*(y-mean); the
-// caller multiplies by invstd once at the end.
+// one pixel of the backward once its operands are in registers: summed gradient g -> dz, channel sums.  s2 accumulates
+// dz*(y-mean); the caller multiplies by invstd once at the end.
 // APPLY: the second pass of a layer whose dz was never stored (segnb_bn_bwd_apply_fused_src): dz is recomputed from the
-// gradient sources exactly as the reduction pass computed it and leaves as dy = round(a * (dz - c1 - yhat * c2)); s1 = the
-// per-channel (a, c1), s2 = (c2, invstd) constants then (ap[0..3]), nothing is summed
-template <typename T, bool HAS_D, bool HAS_U, bool APPLY = false>
-__device__ __forceinline__ void bwd_pixel(const float (&yv)[8], const float (&sc)[8], const float (&sh)[8],
-                                          const float (&mu)[8], const float (&dm)[8], int act, float slope,
-                                          const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_up,
-                                          int ld_gu, long long pix, long long up00, long long up_row, int c0,
-                                          float (&g)[8], T* __restrict__ dz, int ld_dz, float (&s1)[8],
-                                          float (&s2)[8], const T* __restrict__ res, int ld_res,
-                                          const float (*ap)[8] = nullptr) {
-    if (HAS_D) {
-        float t[8];
-        load8(g_direct + pix * ld_gd + c0, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += t[e];
-    }
-    if (HAS_U) {
-        float t[8];
-        load8(g_up + up00 * ld_gu + c0, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += t[e];
-        load8(g_up + (up00 + 1) * ld_gu + c0, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += t[e];
-        load8(g_up + (up00 + up_row) * ld_gu + c0, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += t[e];
-        load8(g_up + (up00 + up_row + 1) * ld_gu + c0, t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] += t[e];
-    }
-    float d[8], rv[8];
-    if (res != nullptr) {
-        load8(res + pix * ld_res + c0, rv);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-    }
+// gradient sources exactly as the reduction pass computed it and leaves as dy = round(a * (dz - c1 - yhat * c2)); ap[0..3] =
+// the per-channel (a, c1, c2, invstd) constants then, nothing is summed
+template <typename T, bool APPLY>
+__device__ __forceinline__ void bwd_pixel_math(const float (&yv)[8], const float (&sc)[8], const float (&sh)[8],
+                                               const float (&mu)[8], const float (&dm)[8], int act, float slope,
+                                               const float (&g)[8], const float (&rv)[8], T* __restrict__ dz_at,
+                                               float (&s1)[8], float (&s2)[8], const float (*ap)[8]) {
+    float d[8], yc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float yc = yv[e] - mu[e];
-        const float z = yc * sc[e] + sh[e] + rv[e];
-        const float dv = round_as(g[e] * dm[e] * act_grad(z, act, slope), dz);
-        if constexpr (APPLY) {
-            const float yh = yc * ap[3][e];
-            d[e] = round_as(ap[0][e] * (dv - ap[1][e] - yh * ap[2][e]), dz);
-        } else {
-            d[e] = dv;
-            s1[e] += dv;
-            s2[e] += dv * yc;
+        yc[e] = yv[e] - mu[e];
+        const float z = yc[e] * sc[e] + sh[e] + rv[e];
+        d[e] = g[e] * dm[e] * act_grad(z, act, slope);
+    }
+    if constexpr (APPLY) {
+        round_store8((T*)nullptr, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float yh = yc[e] * ap[3][e];
+            d[e] = ap[0][e] * (d[e] - ap[1][e] - yh * ap[2][e]);
+        }
+        round_store8(dz_at, d);
+    } else {
+        round_store8(dz_at, d);          // NULL: sums only (the apply pass recomputes dz)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += d[e];
+            s2[e] += d[e] * yc[e];
         }
     }
-    if (dz != nullptr) store8(dz + pix * ld_dz + c0, d);      // NULL: sums only (the apply pass recomputes dz)
+}
+
+// order-preserving 16-bit key of a bf16 value (larger value <-> larger unsigned key)
+__device__ __forceinline__ unsigned bf16_order_key(unsigned b, bool nonneg) {
+    if (nonneg) return b;
+    return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
 }
 
 template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false>
@@ -484,10 +592,86 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     int ld_gp, const T* __restrict__ g_up, int ld_gu, T* __restrict__ dz, int ld_dz, double* __restrict__ sums,
     const T* __restrict__ res, int ld_res, const BnBwdParams bp) {
     __shared__ float sred[SRED_FLOATS];
+    constexpr int U = HAS_P ? (HAS_U ? 1 : 2) : 2;                    // items per trip
+    constexpr int NR = HAS_P ? 2 : 1;                                  // pixels (rows) per item
+    constexpr int NU = HAS_U ? 4 : 1;
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;
     const int c0 = active ? cc * 8 : 0;
+    const int stride = gridDim.x * s.PY;
+    const int npix = s.N * s.H * s.W, hw = s.H * s.W;      // 32-bit: check_ew bounds 4*N*H*W < 2^31
+    // 2x2 windows: MaxPool2d backward routes the pooled gradient to the FIRST maximum (scan order).  A thread
+    // owns one pixel column of a row pair (contiguous loads / stores per wave); the activations of the other
+    // column of its window come from lane ^ CT (items are walked over an even padded width, in pairs)
+    const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
+    const int Hp = s.H >> 1, Wp = s.W >> 1;
+    const int total = HAS_P ? s.N * H2 * We : npix;
+    const FastDiv d_hw(hw), d_w(s.W), d_img(H2 * We), d_we(We);
+    const long long up_row = 2ll * s.W;
+    const bool need_n = dropmul != nullptr || HAS_U;
+    int it0 = blockIdx.x * s.PY + ty;
+
+    // ---- the loads of one trip, all requested before the first use: [item][row]
+    Raw8<T> ry[U][NR], rg[U][NR], ru[U][NR][NU], rres[U], rgp[U];
+    Raw8<float> rdm[U];
+    int pn[U], ph[U], pw[U];            // image, row (row pair when pooling), column of the item
+    bool okr[U][NR];
+    auto issue = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int it = i0 + i * stride;
+            const int ic = it < total ? it : i0;
+            if constexpr (HAS_P) {
+                pn[i] = d_img.div(ic);
+                const int rem = ic - pn[i] * (H2 * We);
+                ph[i] = d_we.div(rem);
+                pw[i] = rem - ph[i] * We;
+            } else {
+                pn[i] = need_n ? d_hw.div(ic) : 0;
+                if constexpr (HAS_U) {
+                    const int rem = ic - pn[i] * hw;
+                    ph[i] = d_w.div(rem);
+                    pw[i] = rem - ph[i] * s.W;
+                } else {
+                    ph[i] = pw[i] = 0;
+                }
+            }
+            if (dropmul != nullptr) load_raw(dropmul + pn[i] * s.Cp + c0, rdm[i]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                long long pix;
+                if constexpr (HAS_P) {
+                    const int hh = 2 * ph[i] + r;
+                    okr[i][r] = hh < s.H && pw[i] < s.W;
+                    pix = ((long long)pn[i] * s.H + (okr[i][r] ? hh : 0)) * s.W + (okr[i][r] ? pw[i] : 0);
+                } else {
+                    okr[i][r] = true;
+                    pix = ic;
+                }
+                if (okr[i][r]) {
+                    load_raw(y + pix * ld_y + c0, ry[i][r]);
+                    if constexpr (HAS_D) load_raw(g_direct + pix * ld_gd + c0, rg[i][r]);
+                    if constexpr (HAS_U) {
+                        const int hh = HAS_P ? 2 * ph[i] + r : ph[i];
+                        const long long up00 = ((long long)pn[i] * 2 * s.H + 2 * hh) * up_row + 2 * pw[i];
+                        load_raw(g_up + up00 * ld_gu + c0, ru[i][r][0]);
+                        load_raw(g_up + (up00 + 1) * ld_gu + c0, ru[i][r][1]);
+                        load_raw(g_up + (up00 + up_row) * ld_gu + c0, ru[i][r][2]);
+                        load_raw(g_up + (up00 + up_row + 1) * ld_gu + c0, ru[i][r][3]);
+                    }
+                    if constexpr (!HAS_P)
+                        if (res != nullptr) load_raw(res + pix * ld_res + c0, rres[i]);
+                }
+            }
+            if constexpr (HAS_P) {
+                if (ph[i] < Hp && (pw[i] >> 1) < Wp)
+                    load_raw(g_pool + (((long long)pn[i] * Hp + ph[i]) * Wp + (pw[i] >> 1)) * ld_gp + c0, rgp[i]);
+            }
+        }
+    };
+    if (active && it0 < total) issue(it0);       // (before the APPLY prologue: two latency chains overlapped)
+
     float ap[4][8];
     if constexpr (APPLY) apply_src_coefs(bp, coef, s, tx, c0, sred, ap);
     float sc[8], sh[8], mu[8];
@@ -506,94 +690,109 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    const long long up_row = 2ll * s.W;
+    const bool nonneg = act == SEGNB_ACT_RELU;       // activations >= +0: the bf16 bit pattern orders them as it is
 
     if (active) {
-        if (HAS_P) {
-            // 2x2 windows: MaxPool2d backward routes the pooled gradient to the FIRST maximum (scan order).  A thread
-            // owns one pixel column of a row pair (contiguous loads / stores per wave); the activations of the other
-            // column of its window come from lane ^ CT (items are walked over an even padded width, in pairs)
-            const int H2 = (s.H + 1) >> 1, We = 2 * ((s.W + 1) >> 1);
-            const int Hp = s.H >> 1, Wp = s.W >> 1;
-            const int nitems = s.N * H2 * We;
-            for (int it = blockIdx.x * s.PY + ty; it < nitems; it += gridDim.x * s.PY) {
-                const int n = it / (H2 * We);
-                const int rem = it - n * (H2 * We);
-                const int h2 = rem / We, w = rem - h2 * We;
-                const int dx = w & 1, w2 = w >> 1;
+        while (it0 < total) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                // (pooling: no early exit -- the partner lane of the exchange walks the same items, `total` and the
+                // stride are even; an item past the end only skips its stores and sums)
+                const bool live = it0 + i * stride < total;
+                if (!HAS_P && !live) break;
                 float dm[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dm[e] = 1.f;
-                if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
-                // every load of the item is requested up front (y, the direct gradient and the pooled gradient):
-                // one memory round trip per item instead of two
-                float yv[2][8], av[2][8], gd[2][8], gp[8];
-                bool valid[2];
-                const bool pooled = h2 < Hp && w2 < Wp;
+                if (dropmul != nullptr) unpack_raw(rdm[i], dm);
+                float yv[NR][8], g[NR][8];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int hh = 2 * h2 + r;
-                    valid[r] = hh < s.H && w < s.W;
+                for (int r = 0; r < NR; ++r) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) yv[r][e] = gd[r][e] = 0.f;
-                    if (valid[r]) {
-                        const long long pix = ((long long)n * s.H + hh) * s.W + w;
-                        load8(y + pix * ld_y + c0, yv[r]);
-                        if (HAS_D) load8(g_direct + pix * ld_gd + c0, gd[r]);
+                    for (int e = 0; e < 8; ++e) yv[r][e] = g[r][e] = 0.f;
+                    if (okr[i][r]) {
+                        unpack_raw(ry[i][r], yv[r]);
+                        if constexpr (HAS_D) unpack_raw(rg[i][r], g[r]);
+                    }
+                }
+                if constexpr (HAS_P) {
+                    const int dx = pw[i] & 1;
+                    const bool pooled = ph[i] < Hp && (pw[i] >> 1) < Wp;
+                    float gp[8], a[2][8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gp[e] = 0.f;
+                    if (pooled) unpack_raw(rgp[i], gp);
+                    // the activations the forward pooled over, as it stored them
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            a[r][e] = dm[e] * act_fwd((yv[r][e] - mu[e]) * sc[e] + sh[e], act, slope);
+                    if constexpr (sizeof(T) == 2) {
+                        // bf16: the rounded activations compare as integers.  Window position k (scan order) gets the key
+                        // (ordered bits << 2) | (3 - k): all four keys differ, the largest is the FIRST maximum.  This lane
+                        // holds positions dx (top) and 2 + dx (bottom), the partner lane the other two -- with ITS keys
+                        const unsigned prio_t = 3u - (unsigned)dx, prio_b = 1u - (unsigned)dx;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const unsigned pt = pack2bf(a[0][e], a[0][e + 1]), pb = pack2bf(a[1][e], a[1][e + 1]);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const unsigned bt = h ? pt >> 16 : pt & 0xffffu, bb = h ? pb >> 16 : pb & 0xffffu;
+                                const unsigned kt = (bf16_order_key(bt, nonneg) << 2) | prio_t;
+                                const unsigned kb = (bf16_order_key(bb, nonneg) << 2) | prio_b;
+                                const unsigned kpt = __shfl_xor(kt, s.CT), kpb = __shfl_xor(kb, s.CT);
+                                const unsigned mo = max(kpt, kpb);
+                                if (pooled && kt > max(mo, kb)) g[0][e + h] += gp[e + h];
+                                if (pooled && kb > max(mo, kt)) g[1][e + h] += gp[e + h];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float ptop = __shfl_xor(a[0][e], s.CT), pbot = __shfl_xor(a[1][e], s.CT);
+                            // window in scan order: (0,0) (0,1) (1,0) (1,1); this lane's pixels are positions dx and 2+dx
+                            const float a0 = dx ? ptop : a[0][e], a1 = dx ? a[0][e] : ptop;
+                            const float a2 = dx ? pbot : a[1][e], a3 = dx ? a[1][e] : pbot;
+                            int am = 0;
+                            float m = a0;
+                            if (a1 > m) { m = a1; am = 1; }
+                            if (a2 > m) { m = a2; am = 2; }
+                            if (a3 > m) { m = a3; am = 3; }
+                            if (pooled && am == dx) g[0][e] += gp[e];
+                            if (pooled && am == 2 + dx) g[1][e] += gp[e];
+                        }
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gp[e] = 0.f;
-                if (pooled) load8(g_pool + (((long long)n * Hp + h2) * Wp + w2) * ld_gp + c0, gp);
+                for (int r = 0; r < NR; ++r) {
+                    if constexpr (HAS_U) {
+                        if (okr[i][r]) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                            for (int q = 0; q < 4; ++q) {
+                                float t[8];
+                                unpack_raw(ru[i][r][q], t);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        av[r][e] = round_as(dm[e] * act_fwd((yv[r][e] - mu[e]) * sc[e] + sh[e], act, slope), y);
-                float gtop[8], gbot[8];
+                                for (int e = 0; e < 8; ++e) g[r][e] += t[e];
+                            }
+                        }
+                    }
+                    if (!(live && okr[i][r])) continue;
+                    float rv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float ptop = __shfl_xor(av[0][e], s.CT), pbot = __shfl_xor(av[1][e], s.CT);
-                    // window in scan order: (0,0) (0,1) (1,0) (1,1); this lane's pixels are positions dx and 2+dx
-                    const float a0 = dx ? ptop : av[0][e], a1 = dx ? av[0][e] : ptop;
-                    const float a2 = dx ? pbot : av[1][e], a3 = dx ? av[1][e] : pbot;
-                    int am = 0;
-                    float m = a0;
-                    if (a1 > m) { m = a1; am = 1; }
-                    if (a2 > m) { m = a2; am = 2; }
-                    if (a3 > m) { m = a3; am = 3; }
-                    gtop[e] = ((pooled && am == dx) ? gp[e] : 0.f) + gd[0][e];
-                    gbot[e] = ((pooled && am == 2 + dx) ? gp[e] : 0.f) + gd[1][e];
-                }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (!valid[r]) continue;
-                    const int hh = 2 * h2 + r;
-                    const long long pix = ((long long)n * s.H + hh) * s.W + w;
-                    bwd_pixel<T, false, HAS_U, APPLY>(yv[r], sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
-                                               ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * w, up_row, c0,
-                                               r == 0 ? gtop : gbot, dz, ld_dz, s1, s2, res, ld_res, ap);
+                    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                    long long pix;
+                    if constexpr (HAS_P) {
+                        pix = ((long long)pn[i] * s.H + 2 * ph[i] + r) * s.W + pw[i];
+                    } else {
+                        pix = it0 + i * stride;
+                        if (res != nullptr) unpack_raw(rres[i], rv);
+                    }
+                    bwd_pixel_math<T, APPLY>(yv[r], sc, sh, mu, dm, act, slope, g[r], rv,
+                                             dz != nullptr ? dz + pix * ld_dz + c0 : (T*)nullptr, s1, s2, ap);
                 }
             }
-        } else {
-            const int npix = s.N * s.H * s.W, hw = s.H * s.W;      // 32-bit: check_ew bounds 4*N*H*W < 2^31
-            const bool need_n = dropmul != nullptr || HAS_U;
-            for (int pix = blockIdx.x * s.PY + ty; pix < npix; pix += gridDim.x * s.PY) {
-                const int n = need_n ? pix / hw : 0;
-                const int rem = pix - n * hw;
-                const int hh = HAS_U ? rem / s.W : 0, ww = HAS_U ? rem - hh * s.W : 0;
-                float dm[8], yv[8], g[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    dm[e] = 1.f;
-                    g[e] = 0.f;
-                }
-                if (dropmul != nullptr) load8(dropmul + n * s.Cp + c0, dm);
-                load8(y + (long long)pix * ld_y + c0, yv);
-                bwd_pixel<T, HAS_D, HAS_U, APPLY>(yv, sc, sh, mu, dm, act, slope, g_direct, ld_gd, g_up, ld_gu, pix,
-                                           ((long long)n * 2 * s.H + 2 * hh) * up_row + 2 * ww, up_row, c0, g, dz, ld_dz,
-                                           s1, s2, res, ld_res, ap);
-            }
+            it0 += U * stride;
+            if (it0 < total) issue(it0);
         }
     }
     if (!APPLY && sums != nullptr) {
@@ -649,6 +848,27 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
     const int cc = blockIdx.y * s.CT + tx;
     const bool active = cc < s.CPP;
     const int c0 = active ? cc * 8 : 0;
+    // four pixels per trip, all eight loads issued before the first use (one pixel per trip = one dependent round trip
+    // per wave in flight: beside the weight-gradient stream the pass ran at a third of its stand-alone rate); the first
+    // trip's loads go out BEFORE the coefficient prologue (sums -> fp64 arithmetic -> LDS -> barrier)
+    const long long npix = (long long)s.N * s.H * s.W;
+    const long long stride = (long long)gridDim.x * s.PY;
+    long long pix0 = (long long)blockIdx.x * s.PY + ty;
+    Raw8<T> ry[4], rd[4], ro[4];
+    auto issue = [&](long long p0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long pix = p0 + u * stride;
+            const long long pc = pix < npix ? pix : p0;
+            load_raw(y + pc * ld_y + c0, ry[u]);
+            if (g != nullptr)
+                load_raw(g + pc * ld_g + c0, rd[u]);
+            else
+                load_raw(dz + pc * ld_dz + c0, rd[u]);
+            if constexpr (ACC) load_raw(dy + pc * ld_dy + c0, ro[u]);
+        }
+    };
+    if (active && pix0 < npix) issue(pix0);
     if (bp.bcoef != nullptr) {
         // fused finalize (mirror of the forward kernel): every block derives (a, c1, c2) of its channels from the
         // sums; the blocks of column 0 publish them, write dgamma / dbeta and clear this layer's FORWARD statistics
@@ -690,49 +910,46 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
         c2[e] = bp.bcoef != nullptr ? sb3[2][tx * 8 + e] : bcoef[2 * s.Cp + c0 + e];
         sb[e] = 0.f;
     }
-    const long long npix = (long long)s.N * s.H * s.W;
     if (active) {
-        // four pixels per trip, all eight loads issued before the first use (one pixel per trip = one dependent
-        // round trip per wave in flight: beside the weight-gradient stream the pass ran at a third of its stand-alone rate)
-        const long long stride = (long long)gridDim.x * s.PY;
-        for (long long pix0 = (long long)blockIdx.x * s.PY + ty; pix0 < npix; pix0 += 4 * stride) {
-            float yv[4][8], d[4][8];
-            bool ok[4];
+        while (pix0 < npix) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long pix = pix0 + u * stride;
-                ok[u] = pix < npix;
-                const long long pc = ok[u] ? pix : pix0;
-                load8(y + pc * ld_y + c0, yv[u]);
-                if (g != nullptr)
-                    load8(g + pc * ld_g + c0, d[u]);
-                else
-                    load8(dz + pc * ld_dz + c0, d[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
+                if (pix >= npix) break;
+                float yv[8], d[8];
+                unpack_raw(ry[u], yv);
+                unpack_raw(rd[u], d);
                 if (g != nullptr) {
                     // dz was never written: recompute it from the incoming gradient exactly as the reduce pass did
                     // (same expression, same rounding to the storage type)
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        d[u][e] = round_as(d[u][e] * 1.f * act_grad((yv[u][e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope), dy);
+                        d[e] = d[e] * 1.f * act_grad((yv[e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope);
+                    round_store8((T*)nullptr, d);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float yh = (yv[u][e] - mu[e]) * is[e];
-                    d[u][e] = round_as(a[e] * (d[u][e] - c1[e] - yh * c2[e]), dy);
-                    sb[e] += d[u][e];
+                    const float yh = (yv[e] - mu[e]) * is[e];
+                    d[e] = a[e] * (d[e] - c1[e] - yh * c2[e]);
                 }
                 if constexpr (ACC) {          // (the rounded result added to the stored gradient, as segnb_add would)
+                    round_store8((T*)nullptr, d);
                     float old[8];
-                    load8(dy + (pix0 + u * stride) * ld_dy + c0, old);
+                    unpack_raw(ro[u], old);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) d[u][e] = __fadd_rn(old[e], d[u][e]);      // (no contraction with the product above)
+                    for (int e = 0; e < 8; ++e) {
+                        sb[e] += d[e];
+                        d[e] = __fadd_rn(old[e], d[e]);      // (no contraction with the product above)
+                    }
+                    store8(dy + pix * ld_dy + c0, d);
+                } else {
+                    round_store8(dy + pix * ld_dy + c0, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sb[e] += d[e];
                 }
-                store8(dy + (pix0 + u * stride) * ld_dy + c0, d[u]);
             }
+            pix0 += 4 * stride;
+            if (pix0 < npix) issue(pix0);
         }
     }
     if (dbias != nullptr) {
@@ -1038,18 +1255,26 @@ static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, i
     // pooling: one item per pixel column of a row pair, over an even padded width
     const long long items = pool_out != nullptr ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
     const dim3 grid = make_grid(s, items, pool_out != nullptr ? 2048 : 4096);
-    if (dtype == SEGNB_BF16)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
-                           ld_y, s, coef, act, slope, dropmul, (bf16_t*)out, ld_out, (bf16_t*)pool_out, ld_pool,
-                           (bf16_t*)up_out, ld_up, (const bf16_t*)res, ld_res, fp);
-    else if (dtype == SEGNB_F32)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y, ld_y,
-                           s, coef, act, slope, dropmul, (float*)out, ld_out, (float*)pool_out, ld_pool,
-                           (float*)up_out, ld_up, (const float*)res, ld_res, fp);
-    else {
+#define SEGNB_FWD(TT, P, R)                                                                                         \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<TT, P, R>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const TT*)y, ld_y, s, \
+                       coef, act, slope, dropmul, (TT*)out, ld_out, (TT*)pool_out, ld_pool, (TT*)up_out, ld_up,     \
+                       (const TT*)res, ld_res, fp)
+#define SEGNB_FWD_ALL(TT)                                            \
+    if (pool_out != nullptr) {                                       \
+        if (res != nullptr) SEGNB_FWD(TT, true, true); else SEGNB_FWD(TT, true, false);      \
+    } else {                                                         \
+        if (res != nullptr) SEGNB_FWD(TT, false, true); else SEGNB_FWD(TT, false, false);    \
+    }
+    if (dtype == SEGNB_BF16) {
+        SEGNB_FWD_ALL(bf16_t)
+    } else if (dtype == SEGNB_F32) {
+        SEGNB_FWD_ALL(float)
+    } else {
         segnb_set_error("%s: unknown dtype %d", who, dtype);
         return SEGNB_E_BADARG;
     }
+#undef SEGNB_FWD_ALL
+#undef SEGNB_FWD
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

@@ -77,6 +77,12 @@ CONV_CASES = [
     ('1x1 s2',           2, 16, 16, [(64, 64)],            128, 1, 2, 0, False),
     ('3x3 p0',           1, 13, 13, [(32, 32)],            32, 3, 1, 0, False),
     ('2x2 p1',           1, 11, 11, [(32, 32)],            8,  2, 1, 1, False),
+    # the rolling-window kernel (fprop_roll.hip): valid 3 x 3 convolution (linknet.py:60: Conv2d(32, 32, 3)) and its data gradient
+    # (input and output grids differ), 32 -> 64 / 64 -> 32 with the channels split over two waves of a strip
+    ('roll 3x3 p0',      2, 41, 45, [(32, 32)],            32, 3, 1, 0, False),
+    ('roll 3x3 p0 co24', 1, 36, 70, [(32, 32)],            24, 3, 1, 0, False),
+    ('roll 32->64',      2, 33, 47, [(32, 32)],            64, 3, 1, 1, False),
+    ('roll 64->32',      2, 33, 47, [(64, 64)],            32, 3, 1, 1, False),
     # stride-1 3x3 shapes that take the transposing-LDS-read weight-gradient kernel (wgrad_s1.hip)
     ('3x3 s1x9 thin',    2, 21, 37, [(32, 32)],            32, 3, 1, 1, False),
     ('3x3 s1x9 thin cat', 1, 16, 56, [(64, 64), (30, 32)], 24, 3, 1, 1, False),

@@ -64,7 +64,22 @@ def main():
 
         apply_ = lambda: nv.call('segnb_bn_bwd_apply', rt.code, y.ptr, y.ld, N, hw, hw, C, nv.ptr(coef), nv.ptr(bcoef),
                                  dz.ptr, dz.ld, dz.ptr, dz.ld, None, C, rt.stream)
-        cases = [('fwd', fwd(o=out), 2.0), ('fwd+pool+drop', fwd(o=out, p=pool, d=drop), 2.25),
+        # the fused entry points the training step uses (finalize inside the pass): statistics of N(0, 1) data
+        stats = rt.zeros((16, 2, C), torch.float64)
+        stats[0, 1] = float(N * hw * hw)
+        gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+        rm, rv, nbt = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros(1, dtype=torch.long, device='cuda')
+        dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        fcoef = rt.zeros((4, C), torch.float32)
+        fbcoef = rt.zeros((3, C), torch.float32)
+        stats2 = rt.zeros((16, 2, C), torch.float64)
+        fwd_fused = lambda: nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, hw, hw, C, C, nv.ptr(stats), nv.ptr(gamma),
+                                    nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(fcoef), None,
+                                    nv.ACT_RELU, 0.0, None, out.ptr, out.ld, None, 0, None, 0, None, 0, rt.stream)
+        apply_fused = lambda: nv.call('segnb_bn_bwd_apply_fused', rt.code, y.ptr, y.ld, N, hw, hw, C, C, nv.ptr(coef),
+                                      nv.ptr(sums), nv.ptr(gamma), nv.ptr(fbcoef), nv.ptr(dgam), nv.ptr(dbet), 1,
+                                      nv.ptr(stats2), dz.ptr, dz.ld, dz.ptr, dz.ld, rt.stream)
+        cases = [('fwd', fwd(o=out), 2.0), ('fwd(fused)', fwd_fused, 2.0), ('apply(fused)', apply_fused, 3.0), ('fwd+pool+drop', fwd(o=out, p=pool, d=drop), 2.25),
                  ('red(d)', red(gd=g), 3.0), ('red(d+pool)', red(gd=g, gpp=gp, d=drop), 3.25), ('apply', apply_, 3.0)]
         cases += [('red(pool)', red(gpp=gp), 2.25), ('red(d+pool,nodrop)', red(gd=g, gpp=gp), 3.25)]
         if up is not None:
