@@ -821,12 +821,11 @@ constexpr int PACK_LDS_FLOATS = 256 * 9 > 64 * 8 * 9 ? 256 * 9 : 64 * 8 * 9;   /
 // tail of a dependent-load chain) and the packed side moves 16 bytes per lane (8 bf16 / 4 fp32 along the
 // contiguous channel index; channel counts are padded to multiples of 8).
 template <bool IS_PACK>
-__global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    __shared__ __attribute__((aligned(16))) float tile[PACK_LDS_FLOATS];
-    __shared__ long long sFast[256], sSlow[64];         // element offset of each fast / slow channel of the tile, -1 = pad
-    const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
+__device__ __forceinline__ void pack_tile(const PackJob* __restrict__ jobs, int njobs, int bid, float* tile, long long* sFast,
+                                          long long* sSlow, int& sCnt) {
+    const PackJob& j = jobs[find_job(jobs, njobs, bid)];
     const TileGeom g = tile_geom(j);
-    const int tb = blockIdx.x - j.block_start;
+    const int tb = bid - j.block_start;
     const int tf = tb % g.nF, ts = tb / g.nF;
     const int f0 = tf * g.F, s0 = ts * g.S;
     const int run = g.F * g.Tsrc;                    // contiguous floats per slow index on the parameter side
@@ -869,7 +868,6 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
         // count of valid fast channels (they form a prefix when ok)
         int cnt = 0;
         for (int i = threadIdx.x; i < g.F; i += 256) cnt += sFast[i] >= 0 ? 1 : 0;
-        __shared__ int sCnt;
         if (threadIdx.x == 0) sCnt = 0;
         __syncthreads();
         if (cnt) atomicAdd(&sCnt, cnt);
@@ -1097,6 +1095,19 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
             if (po[u] >= 0) param[po[u]] = pv[u] + tile[threadIdx.x + u * 256];
+    }
+}
+
+// One block per tile, or (grid < total: segnb_tune "pack_blocks" / SEGNB_PACK_BLOCKS) persistent blocks that walk the tiles: a
+// pack launched BESIDE the forward's first levels on few CUs takes its time without taking their HBM bandwidth
+template <bool IS_PACK>
+__global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restrict__ jobs, int njobs, int total) {
+    __shared__ __attribute__((aligned(16))) float tile[PACK_LDS_FLOATS];
+    __shared__ long long sFast[256], sSlow[64];         // element offset of each fast / slow channel of the tile, -1 = pad
+    __shared__ int sCnt;
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        pack_tile<IS_PACK>(jobs, njobs, b, tile, sFast, sSlow, sCnt);
+        if (b + (int)gridDim.x < total) __syncthreads();
     }
 }
 
@@ -1710,8 +1721,11 @@ extern "C" int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, l
 extern "C" int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_pack_weight_multi, jobs, njobs, total_blocks, stream);
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
-    hipLaunchKernelGGL(pack_tiled_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const PackJob*)jobs, njobs);
+    int grid = total_blocks;
+    const int cap = segnb_knob_pack_blocks();
+    if (cap > 0 && grid > cap) grid = cap;
+    hipLaunchKernelGGL(pack_tiled_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs, total_blocks);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
@@ -1720,7 +1734,7 @@ extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_b
     SEGNB_PLAN_RECORD(segnb_unpack_wgrad_multi, jobs, njobs, total_blocks, stream);
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
     hipLaunchKernelGGL(pack_tiled_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const PackJob*)jobs, njobs);
+                       (const PackJob*)jobs, njobs, total_blocks);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

@@ -585,7 +585,7 @@ __device__ __forceinline__ unsigned bf16_order_key(unsigned b, bool nonneg) {
     return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
 }
 
-template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false>
+template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false, bool RES = false>
 __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const T* __restrict__ y, int ld_y, EwShape s, const float* __restrict__ coef, int act, float slope,
     const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
@@ -613,7 +613,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     int it0 = blockIdx.x * s.PY + ty;
 
     // ---- the loads of one trip, all requested before the first use: [item][row]
-    Raw8<T> ry[U][NR], rg[U][NR], ru[U][NR][NU], rres[U], rgp[U];
+    static_assert(!(RES && HAS_P), "residual input and pooled gradient cannot be combined");
+    Raw8<T> ry[U][NR], rg[U][NR], ru[U][NR][NU], rres[RES ? U : 1], rgp[U];
     Raw8<float> rdm[U];
     int pn[U], ph[U], pw[U];            // image, row (row pair when pooling), column of the item
     bool okr[U][NR];
@@ -660,8 +661,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                         load_raw(g_up + (up00 + up_row) * ld_gu + c0, ru[i][r][2]);
                         load_raw(g_up + (up00 + up_row + 1) * ld_gu + c0, ru[i][r][3]);
                     }
-                    if constexpr (!HAS_P)
-                        if (res != nullptr) load_raw(res + pix * ld_res + c0, rres[i]);
+                    if constexpr (RES) load_raw(res + pix * ld_res + c0, rres[i]);
                 }
             }
             if constexpr (HAS_P) {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                         pix = ((long long)pn[i] * s.H + 2 * ph[i] + r) * s.W + pw[i];
                     } else {
                         pix = it0 + i * stride;
-                        if (res != nullptr) unpack_raw(rres[i], rv);
+                        if constexpr (RES) unpack_raw(rres[i], rv);
                     }
                     bwd_pixel_math<T, APPLY>(yv[r], sc, sh, mu, dm, act, slope, g[r], rv,
                                              dz != nullptr ? dz + pix * ld_dz + c0 : (T*)nullptr, s1, s2, ap);
@@ -1296,19 +1296,21 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
     const long long items = hp ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
     const dim3 grid = make_grid(s, items);
     const int variant = (hd ? 1 : 0) | (hp ? 2 : 0) | (hu ? 4 : 0);
-#define SEGNB_RED(TT, D, P, U)                                                                                      \
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U>), grid, dim3(NTHR), 0, (hipStream_t)stream,          \
+#define SEGNB_RED(TT, D, P, U, R)                                                                                   \
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U, false, R>), grid, dim3(NTHR), 0, (hipStream_t)stream, \
                        (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
                        (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res, BnBwdParams{})
+#define SEGNB_RED_R(TT, D, U)                                                                                       \
+    if (res != nullptr) SEGNB_RED(TT, D, false, U, true); else SEGNB_RED(TT, D, false, U, false)
 #define SEGNB_RED_ALL(TT)                                                       \
     switch (variant) {                                                          \
-        case 1: SEGNB_RED(TT, true, false, false); break;                       \
-        case 2: SEGNB_RED(TT, false, true, false); break;                       \
-        case 3: SEGNB_RED(TT, true, true, false); break;                        \
-        case 4: SEGNB_RED(TT, false, false, true); break;                       \
-        case 5: SEGNB_RED(TT, true, false, true); break;                        \
-        case 6: SEGNB_RED(TT, false, true, true); break;                        \
-        default: SEGNB_RED(TT, true, true, true); break;                        \
+        case 1: SEGNB_RED_R(TT, true, false); break;                            \
+        case 2: SEGNB_RED(TT, false, true, false, false); break;                \
+        case 3: SEGNB_RED(TT, true, true, false, false); break;                 \
+        case 4: SEGNB_RED_R(TT, false, true); break;                            \
+        case 5: SEGNB_RED_R(TT, true, true); break;                             \
+        case 6: SEGNB_RED(TT, false, true, true, false); break;                 \
+        default: SEGNB_RED(TT, true, true, true, false); break;                 \
     }
     if (dtype == SEGNB_BF16) {
         SEGNB_RED_ALL(bf16_t)
@@ -1319,6 +1321,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
         return SEGNB_E_BADARG;
     }
 #undef SEGNB_RED_ALL
+#undef SEGNB_RED_R
 #undef SEGNB_RED
     SEGNB_LAUNCH_CHECK();
     return 0;

@@ -216,6 +216,17 @@ int segnb_knob_fprop_roll() {
 // conv_wgrad_roll_kernel (wgrad_roll.hip) for the plain segnb_conv_wgrad of the thin layers: 0 off (default), 1 on.  Measured
 // on MI355X: 59.4 us against 60.8 us of conv_wgrad_s1x9_kernel alone, 5.41 / 5.39 against 5.37 / 5.39 ms per step in situ
 // (profiles/r04_ab.txt) -- no gain, so the plain path stays on the tile kernel; segnb_conv_wgrad_tf always runs on it.
+// blocks of the batched weight pack (segnb_pack_weight_multi): 0 = one per tile; > 0: that many persistent blocks (a pack running
+// beside the forward's first levels, SEGNB_PACK_OVERLAP=1, throttled to a share of the HBM bandwidth)
+static int g_pack_blocks = -2;
+int segnb_knob_pack_blocks() {
+    if (g_pack_blocks == -2) {
+        const char* e = getenv("SEGNB_PACK_BLOCKS");
+        g_pack_blocks = e != nullptr ? atoi(e) : 0;
+    }
+    return g_pack_blocks;
+}
+
 static int g_wgrad_roll = -2;
 int segnb_knob_wgrad_roll() {
     if (g_wgrad_roll == -2) {
@@ -294,6 +305,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_roll") == 0) {
         g_fprop_roll = value < 0 ? 0 : value;
+        return 0;
+    }
+    if (strcmp(key, "pack_blocks") == 0) {
+        g_pack_blocks = value < 0 ? 0 : value;
         return 0;
     }
     if (strcmp(key, "wgrad_roll") == 0) {

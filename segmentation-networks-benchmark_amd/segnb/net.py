@@ -24,11 +24,17 @@ from .engine import (BN_EPS, BN_MOMENTUM, STAT_REPLICAS, ConvOp, FlatParams, Inp
 
 
 class Act(object):
-    """Activation tensor: forward view + gradient view accumulated during backward."""
-    __slots__ = ('v', 'g', 'needs_grad')
+    """Activation tensor: forward view + gradient view accumulated during backward.
+
+    consumers: how many operators read this tensor in the forward (Tape.consume); producer: set by conv_unit when the tensor is
+    act(BatchNorm(conv)) with nothing else in the way -- (y View, coef, sums, act, slope), what segnb_conv_fprop_bnreduce needs to
+    do that layer's BatchNorm-backward reduction in the epilogue of the ONE consumer's data gradient; g_is_dz: that happened,
+    .g holds dz = act'(z) * gradient and the producer's sums are complete."""
+    __slots__ = ('v', 'g', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
 
     def __init__(self, v, needs_grad=True):
         self.v, self.g, self.needs_grad = v, None, needs_grad
+        self.consumers, self.producer, self.g_is_dz = 0, None, False
 
 
 class Tape(object):
@@ -127,6 +133,15 @@ class Tape(object):
     def record(self, fn):
         if self.need_grad:
             self.back.append(fn)
+
+    # SEGNB_NET_FUSE_REDUCE=0: every BatchNorm-backward reduction as a pass of its own (A/B)
+    fuse_reduce = os.environ.get('SEGNB_NET_FUSE_REDUCE', '1') != '0'
+
+    def consume(self, *acts):
+        """An operator of the forward reads these tensors (each will receive one gradient contribution from it)."""
+        for a in acts:
+            if a is not None:
+                a.consumers += 1
 
     def contribute(self, act, gview):
         if not act.needs_grad:
@@ -270,6 +285,24 @@ def _bn_fields(bn):
             float(getattr(bn, 'eps', BN_EPS)), float(getattr(bn, 'momentum', BN_MOMENTUM) or BN_MOMENTUM))
 
 
+def _data_gradient(tape, conv, x, dy, site):
+    """dx of a convolution handed to its input.  When the input is the activated BatchNorm output of ONE convolution and this
+    is its only consumer (Act.producer / .consumers), the launch's epilogue also does that layer's BatchNorm-backward reduction
+    (segnb_conv_fprop_bnreduce, as ZF_UNET's second convolutions do: linknet.py:41-62 via dilated_resnet's BasicBlock): what arrives
+    is dz, and the producer skips its reduction pass."""
+    xv = x.v
+    dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
+    pr = x.producer
+    if (pr is not None and tape.fuse_reduce and x.consumers == 1 and x.g is None and x.needs_grad
+            and conv.dgrad_bnreduce_ok(dy, dx)):
+        yv, coef, sums, act, slope = pr
+        conv.dgrad(dy, dx, bn_reduce=(yv, coef, sums, act, slope))
+        x.g_is_dz = True
+    else:
+        conv.dgrad(dy, dx)
+    tape.contribute(x, dx)
+
+
 def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=False, bn=None, act=nv.ACT_RELU,
               slope=0.01, dropmul=None, out=None, pool=False, pool_out=None, res=None, out_hw=None, tag='conv'):
     """conv / conv-transpose -> [BatchNorm] -> (+res) -> activation -> [Dropout2d multipliers] [-> MaxPool2d(2)].
@@ -280,6 +313,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     site = tape.site(tag)
     conv = tape.cached(site + '/op', lambda: ConvOp(rt, weight, bias, in_segments, stride, pad, transposed,
                                                     need_dgrad=x.needs_grad, out_hw=out_hw))
+    tape.consume(x, res)
     xv = x.v
     plan = conv.plan(xv.H, xv.W)
     tape.register_conv(conv, xv.H, xv.W)
@@ -349,9 +383,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                 conv.wgrad(xv, dz, flat.grad_of(weight), unpack=False)
             tape.defer_unpack(conv, xv.H, xv.W, flat.grad_of(weight))
             if x.needs_grad:
-                dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
-                conv.dgrad(dz, dx)
-                tape.contribute(x, dx)
+                _data_gradient(tape, conv, x, dz, site)
 
         if not has_bn:
             tape.record(backward_fused)
@@ -384,6 +416,9 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                 0 if res is None else res.v.ld, rt.stream)
     oa = Act(ov)
     pa = Act(pv) if pool else None
+    if fused_bn and not pool and res is None and dropmul is None and tape.need_grad:
+        # (the sums buffer is the one this layer's backward reads; cleared by segnb_bn_fwd_fused above)
+        oa.producer = (y, coef_buf, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
     def backward():
         if oa.g is None and (pa is None or pa.g is None):
@@ -399,10 +434,15 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         # one direct gradient source and nothing else in the way: dz stays in registers (sums-only reduce, then the apply
         # launch recomputes it from the incoming gradient -- segnb_bn_bwd_apply_fused_direct, as ZF_UNET's first convolutions)
         direct = fused_bn and gp is None and res is None and dropmul is None and oa.g is not None
-        nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
-                nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
-                0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
-                rt.stream)
+        if oa.g_is_dz:
+            # the one consumer's data gradient did the reduction in its epilogue (_data_gradient): oa.g IS dz
+            direct, dz = False, oa.g
+            oa.g_is_dz = False
+        else:
+            nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
+                    nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
+                    0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
+                    rt.stream)
         count = float(N * Ho * Wo)
         dy = dz
         if has_bn:
@@ -441,9 +481,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             conv.wgrad(xv, dy, flat.grad_of(weight), unpack=False)
         tape.defer_unpack(conv, xv.H, xv.W, flat.grad_of(weight))
         if x.needs_grad:
-            dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
-            conv.dgrad(dy, dx)
-            tape.contribute(x, dx)
+            _data_gradient(tape, conv, x, dy, site)
 
     tape.record(backward)
     return (oa, pa) if pool else oa
@@ -454,6 +492,7 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
     num_batches_tracked or None, eps, momentum); grads_of() -> (dgamma, dbeta) fp32 views of the flat gradient buffer."""
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
+    tape.consume(x)
     N, H, W, Cp = xv.N, xv.H, xv.W, xv.Cp
     gamma, beta, rm, rv, nbt, eps, mom = fields
     C = gamma.numel()
@@ -556,6 +595,7 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None):
 def maxpool(tape, x, k, stride, pad, tag='pool'):
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
+    tape.consume(x)
     Ho, Wo = (xv.H + 2 * pad - k) // stride + 1, (xv.W + 2 * pad - k) // stride + 1
     ov = tape.view(site + '/o', xv.N, Ho, Wo, xv.Cp)
     # argmax positions recorded by the forward for the backward (a re-scanning backward costs 36 loads per pixel)
@@ -580,6 +620,7 @@ def add(tape, a, b, tag='add'):
     """out = a + b (linknet.py:77-79); both inputs receive the output gradient unchanged."""
     rt, av, bv = tape.rt, a.v, b.v
     site = tape.site(tag)
+    tape.consume(a, b)
     ov = tape.view(site + '/o', av.N, av.H, av.W, av.Cp)
     nv.call('segnb_add', rt.code, av.ptr, av.ld, bv.ptr, bv.ld, ov.ptr, ov.ld, av.N, av.H, av.W, av.Cp, rt.stream)
     oa = Act(ov)
@@ -603,6 +644,7 @@ def add(tape, a, b, tag='add'):
 def concat(tape, pieces, cat_view):
     """pieces: [(Act, channel offset)] already WRITTEN into slices of cat_view (zero-copy torch.cat)."""
     ca = Act(cat_view)
+    tape.consume(*[act for act, _ in pieces])
 
     def backward():
         if ca.g is None:
@@ -618,6 +660,7 @@ def head_1x1(tape, x, weight, bias, dlogits_ref, tag='head'):
     """1x1 classifier -> fp32 NCHW logits (unet16.py:111, tiramisu.py:162-164)."""
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
+    tape.consume(x)
     K, C = weight.shape[0], weight.shape[1]
     logits = tape.cached((site, xv.N, xv.H, xv.W), lambda: torch.zeros((xv.N, K, xv.H, xv.W), dtype=torch.float32,
                                                                        device=rt.device))
@@ -641,6 +684,7 @@ def head_from_act(tape, x, K, dlogits_ref, tag='headconv'):
     NHWC -> fp32 NCHW forward, fp32 NCHW gradient -> NHWC backward."""
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
+    tape.consume(x)
     logits = tape.cached((site, xv.N, xv.H, xv.W), lambda: torch.zeros((xv.N, K, xv.H, xv.W), dtype=torch.float32,
                                                                        device=rt.device))
     nv.call('segnb_nhwc_to_nchw_f32', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, K, nv.ptr(logits), rt.stream)
