@@ -475,6 +475,25 @@ int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int 
                    const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                    float* db, segnb_stream_t stream);
 
+/* The network's LAST BatchNorm + activation (+ Dropout2d) layer and the classifier behind it as ONE pass over the layer's
+ * pre-BatchNorm output y, in both directions (zf_unet.py:56-58,91-93: double_conv_layer -> Conv2d(filters, num_classes, 1);
+ * autograd's BatchNorm / ReLU / Dropout2d / Conv2d backward nodes of the same lines):
+ *   segnb_bn_fwd_fused_head = segnb_bn_fwd_fused (same finalize protocol, same rounding of the activated values to the storage
+ *     type) + segnb_head_fwd on those values; out may be NULL -- the activated tensor then never exists in memory;
+ *   segnb_head_bn_bwd = segnb_head_bwd (da rounded to the storage type as it would have been stored; dw / db accumulate, the
+ *     activated values recomputed from y) + segnb_bn_act_bwd_reduce (dz stored, sums accumulated).  The layer's apply pass
+ *     (segnb_bn_bwd_apply_fused on dz) follows as usual.
+ * segnb_head_fused_ok: 1..4 classes, Cp / 8 a power of two <= 32. */
+int segnb_head_fused_ok(int K, int Cp);
+int segnb_bn_fwd_fused_head(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const double* stats,
+                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* nbt, float* coef, double* bwd_sums_to_clear, int act, float slope,
+                            const float* dropmul, void* out, int ld_out, const float* head_w, const float* head_b, int K,
+                            float* logits, segnb_stream_t stream);
+int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef, int act,
+                      float slope, const float* dropmul, const float* head_w, int K, const float* dlogits, void* dz, int ld_dz,
+                      double* sums, float* dw, float* db, segnb_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-pixel binary losses and metrics (lib/losses.py:7-101, lib/metrics.py:9-43).
  *   loss = (w_bce*bce2 + w_focal*focal + w_jaccard*jaccard + w_sjaccard*smooth_jaccard + w_dice*dice)/norm

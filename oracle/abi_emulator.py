@@ -855,6 +855,41 @@ class AbiEmulator(object):
         return 0
 
     # ------------------------------------------------------------------------------------------ head
+    # ---- the last BatchNorm + activation layer and the classifier behind it as one pass (the two-launch forms, composed)
+    def segnb_head_fused_ok(self, K, Cp):
+        cpp = Cp // 8
+        return int(1 <= K <= 4 and Cp % 8 == 0 and 8 <= Cp <= 256 and cpp & (cpp - 1) == 0)
+
+    def segnb_bn_fwd_fused_head(self, dtype, y, ld_y, N, H, W, C, Cp, stats, gamma, beta, eps, momentum, rm, rv, nbt, coef,
+                                clear_sums, act, slope, dropmul, out, ld_out, head_w, head_b, K, logits, stream):
+        if not self.segnb_head_fused_ok(K, Cp):
+            return -1
+        tmp = torch.zeros(N * H * W * Cp, dtype=_tdt(dtype))
+        rc = self.segnb_bn_fwd_fused(dtype, y, ld_y, N, H, W, C, Cp, stats, gamma, beta, eps, momentum, rm, rv, nbt, coef,
+                                     clear_sums, act, slope, dropmul, tmp.data_ptr(), Cp, None, 0, None, 0, None, 0, stream)
+        if rc:
+            return rc
+        if out is not None:
+            _nhwc(out, N, H, W, Cp, ld_out, _tdt(dtype)).copy_(tmp.view(N, H, W, Cp))
+        return self.segnb_head_fwd(dtype, tmp.data_ptr(), Cp, N, H, W, C, head_w, head_b, K, logits, stream)
+
+    def segnb_head_bn_bwd(self, dtype, y, ld_y, N, H, W, C, Cp, coef, act, slope, dropmul, head_w, K, dlogits, dz, ld_dz, sums,
+                          dw, db, stream):
+        if not self.segnb_head_fused_ok(K, Cp):
+            return -1
+        dt = _tdt(dtype)
+        a = torch.zeros(N * H * W * Cp, dtype=dt)            # the activated tensor, recomputed
+        rc = self.segnb_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, a.data_ptr(), Cp, None, 0, None, 0,
+                                   None, 0, stream)
+        if rc:
+            return rc
+        da = torch.zeros(N * H * W * Cp, dtype=dt)
+        rc = self.segnb_head_bwd(dtype, a.data_ptr(), Cp, N, H, W, C, Cp, head_w, K, dlogits, da.data_ptr(), Cp, dw, db, stream)
+        if rc:
+            return rc
+        return self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, da.data_ptr(), Cp, None, 0,
+                                            None, 0, dz, ld_dz, sums, None, 0, stream)
+
     def segnb_head_fwd(self, dtype, a, ld_a, N, H, W, C, w, bias, K, logits, stream):
         A = _nhwc(a, N, H, W, C, ld_a, _tdt(dtype)).float()
         Wm = _mem(w, K * C, torch.float32).view(K, C)

@@ -455,6 +455,12 @@ float* head_scratch(size_t bytes, hipStream_t stream) {
 }
 }  // namespace
 
+// (for segnb_head_bn_bwd, norm_act.hip: the same partial-sum protocol)
+float* segnb_head_scratch(size_t bytes, hipStream_t stream) { return head_scratch(bytes, stream); }
+void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream) {
+    head_bwd_finish_kernel<<<dim3(K * C + K), dim3(64), 0, stream>>>(part, gx, gy, K, C, CT, dw, db);
+}
+
 extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
                               const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                               float* db, segnb_stream_t stream) {

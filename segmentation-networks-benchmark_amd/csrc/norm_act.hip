@@ -200,13 +200,26 @@ struct FastDiv {
     }
 };
 
-template <typename T, bool POOL, bool RES>
+// the 1x1 classifier on the activated values of the pass (segnb_bn_fwd_fused_head): fp32 NCHW logits
+struct HeadFwd {
+    const float* w;     // [K][C]
+    const float* b;     // [K] or NULL
+    float* logits;      // [N][K][H][W]
+    int K, C;
+};
+
+// HK > 0: the network's LAST activation pass also evaluates the 1x1 classifier (zf_unet.py:58,93) on the values it produces --
+// the lanes that hold a pixel's channel chunks (CT consecutive lanes; the launcher requires CT == Cp / 8) add their partial dot
+// products with a shuffle tree -- and `out` may be NULL: the activated tensor then never exists in memory
+template <typename T, bool POOL, bool RES, int HK = 0>
 __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ y, int ld_y, EwShape s,
                                                           const float* __restrict__ coef, int act, float slope,
                                                           const float* __restrict__ dropmul, T* __restrict__ out,
                                                           int ld_out, T* __restrict__ pool_out, int ld_pool,
                                                           T* __restrict__ up_out, int ld_up,
-                                                          const T* __restrict__ res, int ld_res, const BnFwdParams fp) {
+                                                          const T* __restrict__ res, int ld_res, const BnFwdParams fp,
+                                                          const HeadFwd hd = HeadFwd{}) {
+    static_assert(HK == 0 || !POOL, "the classifier reads the un-pooled activation");
     constexpr int U = 2;            // pixels per trip (no pooling)
     constexpr int UP = 2;           // row-pair items per trip (pooling)
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
             const int pc = pix < npix ? pix : i0;
             load_raw(y + (long long)pc * ld_y + c0, ry[u]);
             if constexpr (RES) load_raw(res + (long long)pc * ld_res + c0, rr[u]);
-            nn[u] = (dropmul != nullptr || up_out != nullptr) ? d_hw.div(pc) : 0;
+            nn[u] = (dropmul != nullptr || up_out != nullptr || HK > 0) ? d_hw.div(pc) : 0;
             if (dropmul != nullptr) load_raw(dropmul + nn[u] * s.Cp + c0, rdm[u]);
         }
     };
@@ -332,6 +345,13 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
         }
     }
 
+    float hw8[HK > 0 ? HK : 1][8];
+    if constexpr (HK > 0) {
+#pragma unroll
+        for (int k = 0; k < HK; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hw8[k][e] = (k < hd.K && c0 + e < hd.C) ? hd.w[k * hd.C + c0 + e] : 0.f;
+    }
     if constexpr (!pooling) {
         // no pooling: consecutive threads take consecutive pixels, so every load / store instruction of a wave
         // covers one contiguous run
@@ -355,6 +375,23 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
                     for (int e = 0; e < 8; ++e) v[e] = dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope);
                 }
                 round_store8(out != nullptr ? out + (long long)pix * ld_out + c0 : (T*)nullptr, v);
+                if constexpr (HK > 0) {
+                    float pk[HK];
+#pragma unroll
+                    for (int k = 0; k < HK; ++k) {
+                        pk[k] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pk[k] = fmaf(v[e], hw8[k][e], pk[k]);
+                        for (int off = 1; off < s.CT; off <<= 1) pk[k] += __shfl_xor(pk[k], off);
+                    }
+                    if (tx == 0) {
+                        const int rem = pix - nn[u] * hw;
+#pragma unroll
+                        for (int k = 0; k < HK; ++k)
+                            if (k < hd.K)
+                                hd.logits[((long long)nn[u] * hd.K + k) * hw + rem] = pk[k] + (hd.b != nullptr ? hd.b[k] : 0.f);
+                    }
+                }
                 if (up_out != nullptr) {
                     const int n = nn[u];
                     const int rem = pix - n * hw;
@@ -808,6 +845,136 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     }
 }
 
+// Head backward THROUGH the last layer's activation, with that layer's BatchNorm-backward reduction, in one pass over its
+// pre-BatchNorm output y (segnb_head_bn_bwd): per pixel da = sum_k dlogits_k w_k (rounded as segnb_head_bwd stores it), dz =
+// round(da * drop * act'(z)) -> stored, (sum dz, sum dz * yhat) -> sums, and the classifier's own gradients dw_k += dlogits_k * a,
+// db_k += dlogits_k with a = round(drop * act(z)) RECOMPUTED from y -- the activated tensor a and its gradient da never exist in
+// memory (segnb_head_bwd reads a and writes da, segnb_bn_act_bwd_reduce reads da and y and writes dz: 5 tensor passes -> 2).
+// Thread mapping and the reproducible dw / db protocol are head_bwd_kernel's (head_loss.hip).
+template <typename T, int KM>
+__global__ __launch_bounds__(NTHR) void head_bn_bwd_kernel(const T* __restrict__ y, int ld_y, EwShape s,
+                                                           const float* __restrict__ coef, int act, float slope,
+                                                           const float* __restrict__ dropmul, const float* __restrict__ w, int C,
+                                                           int K, const float* __restrict__ dl, T* __restrict__ dz, int ld_dz,
+                                                           double* __restrict__ sums, float* __restrict__ part) {
+    __shared__ float sred[SRED_FLOATS];
+    constexpr int U = 2;
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    const int stride = gridDim.x * s.PY;
+    const int npix = s.N * s.H * s.W, hw = s.H * s.W;
+    const FastDiv d_hw(hw);
+    float wv[KM][8], gw[KM][8], gb[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        gb[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wv[k][e] = (k < K && c0 + e < C) ? w[k * C + c0 + e] : 0.f;
+            gw[k][e] = 0.f;
+        }
+    }
+    float sc[8], sh[8], mu[8], s1[8], s2[8];
+    load8(coef + c0, sc);
+    load8(coef + s.Cp + c0, sh);
+    load8(coef + 2 * s.Cp + c0, mu);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if (active) {
+        for (int it0 = blockIdx.x * s.PY + ty; it0 < npix; it0 += U * stride) {
+            Raw8<T> ry[U];
+            Raw8<float> rdm[U];
+            float g[U][KM];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = it0 + u * stride;
+                const int pc = pix < npix ? pix : it0;
+                load_raw(y + (long long)pc * ld_y + c0, ry[u]);
+                const int n = (dropmul != nullptr || KM > 1) ? d_hw.div(pc) : 0;
+                if (dropmul != nullptr) load_raw(dropmul + n * s.Cp + c0, rdm[u]);
+                if (KM == 1) {
+                    g[u][0] = dl[pc];
+                } else {
+                    const int r = pc - n * hw;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) g[u][k] = k < K ? dl[((long long)n * K + k) * hw + r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pix = it0 + u * stride;
+                if (pix >= npix) break;
+                float yv[8], dm[8], a[8], d[8], yc[8], z[8];
+                unpack_raw(ry[u], yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+                if (dropmul != nullptr) unpack_raw(rdm[u], dm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    yc[e] = yv[e] - mu[e];
+                    z[e] = yc[e] * sc[e] + sh[e];
+                    a[e] = dm[e] * act_fwd(z[e], act, slope);
+                    d[e] = 0.f;
+                }
+                round_store8((T*)nullptr, a);
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        const float gk = g[u][k];
+                        gb[k] += gk;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            d[e] = fmaf(gk, wv[k][e], d[e]);
+                            gw[k][e] = fmaf(gk, a[e], gw[k][e]);
+                        }
+                    }
+                round_store8((T*)nullptr, d);                    // da as segnb_head_bwd would have stored it
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = d[e] * dm[e] * act_grad(z[e] + 0.f, act, slope);
+                round_store8(dz + (long long)pix * ld_dz + c0, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += d[e];
+                    s2[e] += d[e] * yc[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s2[e] *= coef[3 * s.Cp + c0 + e];        // sum dz*(y-mean) * invstd = sum dz*yhat
+    double* rep = sums + (long long)(blockIdx.x % REPL) * 2 * s.Cp;
+    block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + s.Cp, sred);
+    // ---- dw / db: the PY pixel lanes of a channel chunk summed in lane order through LDS, class by class; every block writes
+    // its partial sums to its own row of `part`, segnb_head_bwd_finish adds the rows in block order (bitwise reproducible)
+    const int CT = s.CT, PY = s.PY;
+    float* sg = sred;
+    float* prow = part + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * (K * (CT * 8 + 1));
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+        if (k < K) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sg[(ty * CT + tx) * 8 + e] = gw[k][e];
+            __syncthreads();
+            if ((int)threadIdx.x < CT * 8) {
+                float sum = 0.f;
+                for (int j = 0; j < PY; ++j) sum += sg[j * CT * 8 + threadIdx.x];
+                prow[k * (CT * 8 + 1) + threadIdx.x] = sum;
+            }
+            __syncthreads();
+            if (tx == 0) sg[ty] = gb[k];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float sum = 0.f;
+                for (int j = 0; j < PY; ++j) sum += sg[j];
+                prow[k * (CT * 8 + 1) + CT * 8] = sum;
+            }
+        }
+}
+
+
 __global__ void bn_bwd_finalize_kernel(const BnBwdParams p, const float* __restrict__ coef, int Cp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Cp) return;
@@ -1219,7 +1386,7 @@ extern "C" int segnb_bn_finalize_keep(const double* stats, int C, int Cp, double
 static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                              int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
                              int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
-                             const char* who, segnb_stream_t stream);
+                             const char* who, segnb_stream_t stream, const HeadFwd* hd = nullptr);
 
 extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                 const float* coef, int act, float slope, const float* dropmul, void* out,
@@ -1245,13 +1412,56 @@ extern "C" int segnb_bn_fwd_fused(int dtype, const void* y, int ld_y, int N, int
                              up_out, ld_up, res, ld_res, fp, "segnb_bn_fwd_fused", stream);
 }
 
+extern "C" int segnb_head_fused_ok(int K, int Cp) {
+    if (K < 1 || K > 4 || Cp < 8 || Cp % 8 != 0 || Cp > 256) return 0;
+    const int cpp = Cp / 8;
+    return (cpp & (cpp - 1)) == 0;
+}
+
+extern "C" int segnb_bn_fwd_fused_head(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                       const double* stats, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, long long* nbt, float* coef,
+                                       double* bwd_sums_to_clear, int act, float slope, const float* dropmul, void* out,
+                                       int ld_out, const float* head_w, const float* head_b, int K, float* logits,
+                                       segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_fwd_fused_head, dtype, y, ld_y, N, H, W, C, Cp, stats, gamma, beta, eps, momentum, running_mean, running_var, nbt, coef, bwd_sums_to_clear, act, slope, dropmul, out, ld_out, head_w, head_b, K, logits, stream);
+    SEGNB_CHECK_ARG(stats != nullptr && coef != nullptr && C > 0 && Cp >= C, "missing statistics / coefficient buffer");
+    SEGNB_CHECK_ARG(segnb_head_fused_ok(K, Cp), "classifier variant: 1..4 classes, Cp / 8 a power of two <= 32 (segnb_head_fused_ok)");
+    BnFwdParams fp = {stats, (double)N * H * W, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, 1, coef,
+                      bwd_sums_to_clear};
+    const HeadFwd hd = {head_w, head_b, logits, K, C};
+    return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, nullptr, act, slope, dropmul, out, ld_out, nullptr, 0, nullptr, 0,
+                             nullptr, 0, fp, "segnb_bn_fwd_fused_head", stream, &hd);
+}
+
 static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                              int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
                              int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
-                             const char* who, segnb_stream_t stream) {
+                             const char* who, segnb_stream_t stream, const HeadFwd* hd) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out), "NULL tensor");
+    SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out || hd), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
+    if (hd != nullptr) {
+        // the classifier variant: a pixel's channel chunks are CT consecutive lanes of one wave (one block column)
+        SEGNB_CHECK_ARG(pool_out == nullptr && res == nullptr && s.CT == s.CPP && hd->K >= 1 && hd->K <= 4 && hd->w && hd->logits,
+                        "classifier variant: no pooling / residual, Cp / 8 a power of two <= 32, 1..4 classes (segnb_head_fused_ok)");
+        const dim3 grid = make_grid(s, (long long)N * H * W, 4096);
+#define SEGNB_FWDH(TT, HKK)                                                                                         \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<TT, false, false, HKK>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const TT*)y, \
+                       ld_y, s, coef, act, slope, dropmul, (TT*)out, ld_out, (TT*)nullptr, 0, (TT*)up_out, ld_up,    \
+                       (const TT*)nullptr, 0, fp, *hd)
+        if (dtype == SEGNB_BF16) {
+            if (hd->K == 1) SEGNB_FWDH(bf16_t, 1); else SEGNB_FWDH(bf16_t, 4);
+        } else if (dtype == SEGNB_F32) {
+            if (hd->K == 1) SEGNB_FWDH(float, 1); else SEGNB_FWDH(float, 4);
+        } else {
+            segnb_set_error("%s: unknown dtype %d", who, dtype);
+            return SEGNB_E_BADARG;
+        }
+#undef SEGNB_FWDH
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
     // pooling: one item per pixel column of a row pair, over an even padded width
     const long long items = pool_out != nullptr ? (long long)N * ((H + 1) / 2) * (2 * ((W + 1) / 2)) : (long long)N * H * W;
     const dim3 grid = make_grid(s, items, pool_out != nullptr ? 2048 : 4096);
@@ -1324,6 +1534,37 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
 #undef SEGNB_RED_R
 #undef SEGNB_RED
     SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
+                                 int act, float slope, const float* dropmul, const float* head_w, int K, const float* dlogits,
+                                 void* dz, int ld_dz, double* sums, float* dw, float* db, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_bn_bwd, dtype, y, ld_y, N, H, W, C, Cp, coef, act, slope, dropmul, head_w, K, dlogits, dz, ld_dz, sums, dw, db, stream);
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y && coef && head_w && dlogits && dz && sums && C > 0 && Cp >= C, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_head_fused_ok(K, Cp), "1..4 classes, Cp / 8 a power of two <= 32 (segnb_head_fused_ok)");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+    float* part = segnb_head_scratch((size_t)grid.x * grid.y * K * (s.CT * 8 + 1) * sizeof(float), (hipStream_t)stream);
+    if (part == nullptr) return SEGNB_E_BADARG;
+#define SEGNB_HBB(TT, KMM)                                                                                          \
+    hipLaunchKernelGGL((head_bn_bwd_kernel<TT, KMM>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const TT*)y, ld_y, s, coef, \
+                       act, slope, dropmul, head_w, C, K, dlogits, (TT*)dz, ld_dz, sums, part)
+    if (dtype == SEGNB_BF16) {
+        if (K == 1) SEGNB_HBB(bf16_t, 1); else SEGNB_HBB(bf16_t, 4);
+    } else if (dtype == SEGNB_F32) {
+        if (K == 1) SEGNB_HBB(float, 1); else SEGNB_HBB(float, 4);
+    } else {
+        segnb_set_error("segnb_head_bn_bwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+#undef SEGNB_HBB
+    SEGNB_LAUNCH_CHECK();
+    if (dw != nullptr || db != nullptr) {
+        segnb_head_bwd_finish(part, (int)grid.x, (int)grid.y, K, C, s.CT, dw, db, (hipStream_t)stream);
+        SEGNB_LAUNCH_CHECK();
+    }
     return 0;
 }
 

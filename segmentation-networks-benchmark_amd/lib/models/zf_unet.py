@@ -480,6 +480,8 @@ class _ZFUnetPlan(object):
         b = self.buffers(N, H, W)
         self._pack_if_needed(H, W, N)
         drop = self._dropout_tables(b, N, train)
+        hf = self._head_fusable(train, need_grad)
+        self._last_head_fused = hf
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)
         first = None
         if u8 and self.stages[ENCODER[0]][0].conv.u8_direct_ok(N, H, W, self.wp[0]):
@@ -501,7 +503,7 @@ class _ZFUnetPlan(object):
                 self._last = (N, H, W) if need_grad else None
                 self._last_train = bool(train)
                 self.generation += 1
-                return self._head(b, N, H, W)
+                return self._head(b, N, H, W, hf)
             if plan is None:
                 self._plan_begin()
             else:
@@ -537,6 +539,9 @@ class _ZFUnetPlan(object):
                     s2.forward(x2, train, drop[name], need_grad=need_grad,
                                up_out=(b['cat_%d' % (lvl - 1)].slice(0, wp[lvl]) if self._upsampled(lvl - 1, N, H, W) else None),
                                out=b.get('u_%d' % (lvl - 1)), x_tf=tf2)
+                elif hf:
+                    # the last activation pass runs with the classifier (_head): the activated tensor is never written
+                    s2.forward(x2, train, drop[name], need_grad=need_grad, x_tf=tf2, defer_act='head')
                 else:
                     s2.forward(x2, train, drop[name], out=b['f0'], need_grad=need_grad, x_tf=tf2)
         except BaseException:
@@ -548,7 +553,18 @@ class _ZFUnetPlan(object):
         self._last = (N, H, W) if need_grad else None
         self.generation += 1                       # every forward overwrites the activation buffers
         self._last_train = bool(train)
-        return self._head(b, N, H, W)
+        return self._head(b, N, H, W, hf)
+
+    # SEGNB_HEAD_FUSION=0: the last BatchNorm / activation pass and the classifier as separate launches (A/B)
+    HEAD_FUSION = os.environ.get('SEGNB_HEAD_FUSION', '1') != '0'
+
+    def _head_fusable(self, train, need_grad):
+        """A differentiated training forward whose last stage folds its finalize: that stage's activation pass and the 1x1
+        classifier are ONE launch (segnb_bn_fwd_fused_head), and so are the classifier's backward and the stage's
+        BatchNorm-backward reduction (segnb_head_bn_bwd) -- the activated tensor and its gradient never exist in memory."""
+        s2 = self.stages[DECODER[-1]][1]
+        return bool(self.HEAD_FUSION and train and need_grad and s2.bn is not None and s2.fuse_finalize
+                    and nv.query('segnb_head_fused_ok', self.K, self.wp[0]))
 
     def _defer(self, s1, s2, x1, a1, train, need_grad):
         """May the block's first stage skip its activation pass (its second convolution and that one's weight gradient
@@ -559,7 +575,7 @@ class _ZFUnetPlan(object):
         y2 = s2.buffers(x1.N, a1.H, a1.W)['y']
         return s2.conv.fprop_tf_ok(y, y2) and s2.conv.wgrad_tf_ok(y, y2)
 
-    def _head(self, b, N, H, W):
+    def _head(self, b, N, H, W, fused=False):
         """The 1x1 classifier (zf_unet.py:58) as ONE launch outside the recorded list, straight into the tensor the caller
         gets (the list would have to write a persistent buffer and the caller's copy would be a launch of its own); the
         loss is told where this model wants d(loss)/d(logits) (segnb.seglosses.register_grad_buffer)."""
@@ -567,8 +583,11 @@ class _ZFUnetPlan(object):
         rt = self.rt
         head = self.module.conv_final
         logits = torch.empty((N, self.K, H, W), dtype=torch.float32, device=rt.device)
-        nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
-                nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
+        if fused:
+            self.stages[DECODER[-1]][1].head_forward(head.weight.detach(), head.bias.detach(), self.K, logits)
+        else:
+            nv.call('segnb_head_fwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0],
+                    nv.ptr(head.weight.detach()), nv.ptr(head.bias.detach()), self.K, nv.ptr(logits), rt.stream)
         seglosses.register_grad_buffer(logits, b['dlogits_in'])
         return logits
 
@@ -587,6 +606,8 @@ class _ZFUnetPlan(object):
         accumulate_in_place = flat.begin_backward()
         drop_now = {n: self.stages[n][1]._saved[2] if self.stages[n][1]._saved is not None else None for n in ENCODER + DECODER}
         ckey = self._cplan_key('bwd', N, H, W, True, True, drop_now)
+        if ckey is not None:
+            ckey = ckey + (bool(getattr(self, '_last_head_fused', False)),)
         if ckey is not None:
             din = b['dlogits_in']
             if dlogits.data_ptr() != din.data_ptr():
@@ -607,9 +628,14 @@ class _ZFUnetPlan(object):
             if self.BWD_CONV_CU_PCT != 100:
                 nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
             head = self.module.conv_final
-            nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
-                    nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
-                    nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
+            hf = bool(getattr(self, '_last_head_fused', False))
+            if hf:
+                self.stages[DECODER[-1]][1].head_backward(head.weight.detach(), self.K, dlogits, flat.grad_of(head.weight),
+                                                          flat.grad_of(head.bias))
+            else:
+                nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
+                        nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
+                        nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
             # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
             # they would run beside) are held back until the dependent chain has reached the deep levels.
             # (measured on one box: 0 -> 6.34 ms/step, 2 -> 6.31 ms/step, but the convolutions of the dependent chain then run
@@ -621,7 +647,9 @@ class _ZFUnetPlan(object):
                 hold = post if lvl < npost else None
                 # the first convolution of a block has ONE direct gradient source -- the data gradient of the second one: that
                 # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
-                if lvl == 0:
+                if lvl == 0 and hf:
+                    red = s2.backward(flat, dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1, dz_ready=True)
+                elif lvl == 0:
                     red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
                 elif self._seg(lvl - 1, N, H, W):
                     # the level above handed the gradient of this block's output over at THIS resolution (du)

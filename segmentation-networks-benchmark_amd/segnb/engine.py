@@ -1038,6 +1038,14 @@ class Stage(object):
             self.conv.fprop(xv, yv, self.stats if use_batch_stats else None)
         coef = None
         fused = use_batch_stats and self.fuse_finalize and need_grad
+        if defer_act == 'head':
+            # the network's last layer: its activation pass is launched by the plan together with the classifier behind it
+            # (head_forward: segnb_bn_fwd_fused_head), outside any recorded list -- the logits go to a fresh tensor
+            assert fused and pool_out is None and up_out is None
+            self._stats_stale = True
+            self._saved = (xv, yv, dropmul, True)
+            self._fused_fwd = True
+            return yv
         if defer_act:
             assert fused and dropmul is None and pool_out is None and up_out is None
             bn = self.bn
@@ -1075,6 +1083,26 @@ class Stage(object):
         self._saved = (xv, yv, dropmul, coef is not None)
         return yv
 
+    def head_forward(self, head_w, head_b, K, logits, out=None):
+        """BatchNorm (finalize folded in) + activation (+ Dropout2d) of this stage's convolution output AND the 1x1 classifier on
+        the activated values, one launch (after forward(..., defer_act='head')); out: optional View for the activated tensor."""
+        rt, bn = self.rt, self.bn
+        xv, yv, dropmul, _ = self._saved
+        nv.call('segnb_bn_fwd_fused_head', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.stats),
+                nv.ptr(bn.weight.detach()), nv.ptr(bn.bias.detach()), BN_EPS, BN_MOMENTUM, nv.ptr(bn.running_mean),
+                nv.ptr(bn.running_var), nv.ptr(bn.num_batches_tracked), nv.ptr(self.coef), nv.ptr(self.sums), self.act,
+                self.slope, nv.ptr(dropmul), vptr(out), vld(out), nv.ptr(head_w), nv.ptr(head_b), K, nv.ptr(logits), rt.stream)
+
+    def head_backward(self, head_w, K, dlogits, dw, db):
+        """d(logits) through the classifier, this stage's activation / Dropout2d and its BatchNorm-backward reduction in one pass
+        over y (segnb_head_bn_bwd): leaves dz in the stage's buffer and the sums complete -- backward(..., dz_ready=True) next."""
+        rt = self.rt
+        xv, yv, dropmul, _ = self._saved
+        dz = self.buffers(yv.N, yv.H, yv.W)['dz']
+        nv.call('segnb_head_bn_bwd', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef), self.act,
+                self.slope, nv.ptr(dropmul), nv.ptr(head_w), K, nv.ptr(dlogits), dz.ptr, dz.ld, nv.ptr(self.sums), nv.ptr(dw),
+                nv.ptr(db), rt.stream)
+
     def tf_out(self):
         """the operand transform a consumer applies to this stage's pre-BatchNorm output (after forward(..., defer_act=True))"""
         return ConvOp.tf_act(self.coef, self.Cp, self.act, self.slope)
@@ -1089,7 +1117,7 @@ class Stage(object):
         return (yv, self.coef, self.sums, self.act, self.slope)
 
     def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None, reduced=False,
-                 fuse_reduce_of=None):
+                 fuse_reduce_of=None, dz_ready=False):
         """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
         input gradient, or None (first layer).  reduced: the reduction pass of this layer was already done by the
         data-gradient launch that produced g_direct.  fuse_reduce_of: the Stage whose activation gradient dx is -- if
@@ -1100,13 +1128,14 @@ class Stage(object):
         coef = self.coef if has_bn else None
         # A single direct gradient source, no dropout: dz never goes to memory -- the reduce pass only sums, the apply
         # pass recomputes dz from g (segnb_bn_bwd_apply_direct): one tensor write less per such layer.
+        # dz_ready: head_backward() already left dz in the buffer and completed the sums (no gradient source tensor at all)
         direct = (self.direct_apply and has_bn and g_direct is not None and g_pool is None and g_up is None
-                  and dropmul is None)
+                  and dropmul is None and not dz_ready)
         assert not reduced or direct, 'only a direct layer can be reduced by its producer'
         mb = yv.N * yv.H * yv.W * self.Cp * (2 if rt.code == nv.BF16 else 4) / 1e6
-        recompute = (not direct and has_bn and self._fused_fwd and self.recompute_dz_min_mb > 0
+        recompute = (not direct and not dz_ready and has_bn and self._fused_fwd and self.recompute_dz_min_mb > 0
                      and mb >= self.recompute_dz_min_mb)
-        if not reduced:
+        if not reduced and not dz_ready:
             nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                     self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
                     vptr(g_up), vld(g_up), None if (direct or recompute) else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0,

@@ -28,8 +28,8 @@ class Act(object):
 
     consumers: how many operators read this tensor in the forward (Tape.consume); producer: set by conv_unit when the tensor is
     act(BatchNorm(conv)) with nothing else in the way -- (y View, coef, sums, act, slope), what segnb_conv_fprop_bnreduce needs to
-    do that layer's BatchNorm-backward reduction in the epilogue of the ONE consumer's data gradient; g_is_dz: that happened,
-    .g holds dz = act'(z) * gradient and the producer's sums are complete."""
+    do that layer's BatchNorm-backward reduction in the epilogue of the ONE consumer's data gradient; g_is_dz: that happened
+    (the producer's sums are complete; .g is still the plain gradient, the direct apply form recomputes dz from it)."""
     __slots__ = ('v', 'g', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
 
     def __init__(self, v, needs_grad=True):
@@ -288,8 +288,8 @@ def _bn_fields(bn):
 def _data_gradient(tape, conv, x, dy, site):
     """dx of a convolution handed to its input.  When the input is the activated BatchNorm output of ONE convolution and this
     is its only consumer (Act.producer / .consumers), the launch's epilogue also does that layer's BatchNorm-backward reduction
-    (segnb_conv_fprop_bnreduce, as ZF_UNET's second convolutions do: linknet.py:41-62 via dilated_resnet's BasicBlock): what arrives
-    is dz, and the producer skips its reduction pass."""
+    (segnb_conv_fprop_bnreduce, as ZF_UNET's second convolutions do: linknet.py:41-62 via dilated_resnet's BasicBlock): the
+    producer then skips its reduction pass."""
     xv = x.v
     dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
     pr = x.producer
@@ -435,8 +435,9 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         # launch recomputes it from the incoming gradient -- segnb_bn_bwd_apply_fused_direct, as ZF_UNET's first convolutions)
         direct = fused_bn and gp is None and res is None and dropmul is None and oa.g is not None
         if oa.g_is_dz:
-            # the one consumer's data gradient did the reduction in its epilogue (_data_gradient): oa.g IS dz
-            direct, dz = False, oa.g
+            # the one consumer's data gradient did the reduction in its epilogue (_data_gradient): the sums are complete and
+            # oa.g is the plain gradient, from which the apply launch recomputes dz (the direct form; producer => direct)
+            assert direct
             oa.g_is_dz = False
         else:
             nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,

@@ -20,7 +20,7 @@ import segnb.engine as E
 
 
 BIG_BYTES = 4 << 20
-BIG_WRITERS = ('segnb_unpack_wgrad', 'segnb_bn_bwd_finalize', 'segnb_head_bwd', 'segnb_sgd_step')
+BIG_WRITERS = ('segnb_unpack_wgrad', 'segnb_bn_bwd_finalize', 'segnb_head_bwd', 'segnb_head_bn_bwd', 'segnb_sgd_step')
 
 
 class _Recorder(object):
@@ -90,7 +90,7 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
 
 # (argument position -> entry points) whose fp64 argument is a [REPL][2][Cp] replicated accumulator: the emulator
 # fills replica 0, the HIP kernels spread blocks over all 16; only the sum over replicas is defined by the ABI
-_REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats'), 19: ('segnb_bn_act_bwd_reduce',), 0: ()}
+_REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats'), 19: ('segnb_bn_act_bwd_reduce',), 17: ('segnb_head_bn_bwd',), 0: ()}
 
 
 def run_step(model, x, y, loss_fn, device, dtype):
@@ -108,7 +108,8 @@ def run_step(model, x, y, loss_fn, device, dtype):
 def replay(make_model, x, y, loss_fn, dtype, device='cuda',
            flip_ops=('segnb_bn_act_fwd', 'segnb_bn_act_bwd_reduce', 'segnb_bn_bwd_apply', 'segnb_bn_bwd_apply_direct',
                      'segnb_bn_bwd_finalize',
-                     'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused', 'segnb_bn_bwd_apply_fused_direct')):
+                     'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused', 'segnb_bn_bwd_apply_fused_direct',
+                     'segnb_bn_fwd_fused_head', 'segnb_head_bn_bwd')):
     """Returns (number of calls, list of failure strings).  device='cpu' replays the emulator against itself (a
     self-test of this harness that runs without a GPU)."""
     rec = _Recorder()

@@ -499,3 +499,63 @@ def check_linknet_abs_eps_form(device, dtype='f32', size=64):
         if n in signs:
             gb = gb * signs[n]
         assert float((ga - gb).abs().max()) <= (1e-4 if dtype == 'f32' else 5e-2) * max(float(gb.abs().max()), 1e-3 * gmax), n
+
+
+def check_executor_fused_reduce(device, size=32):
+    """segnb.net: conv -> BatchNorm -> ReLU -> conv.  The second convolution is the ONLY consumer of the first one's activated
+    output, so its data gradient does that layer's BatchNorm-backward reduction in its epilogue (segnb_conv_fprop_bnreduce via
+    net._data_gradient, the wiring of linknet.py:41-62's basic blocks) -- against the same step with every reduction as a pass of
+    its own (Tape.fuse_reduce off).  Same kernels' arithmetic, bf16: gradients agree to rounding of the sums."""
+    from torch import nn
+    from segnb import net as _net
+    from segnb import _native as nv
+    from segnb import convplan as cp
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+
+    class Toy(_net.HipNet):
+        def __init__(self):
+            super(Toy, self).__init__()
+            self.c1, self.b1 = nn.Conv2d(3, 32, 3, padding=1), nn.BatchNorm2d(32)
+            self.c2, self.b2 = nn.Conv2d(32, 32, 3, padding=1), nn.BatchNorm2d(32)
+            self.final = nn.Conv2d(32, 1, 1)
+            self.fused_seen = 0
+            self._init_engine(3)
+
+        def _build(self, tape, x, dlogits):
+            a1 = _net.conv_unit(tape, x, self.c1.weight, self.c1.bias, [(3, cp.pad8(3))], bn=self.b1, act=nv.ACT_RELU, tag='c1')
+            a2 = _net.conv_unit(tape, a1, self.c2.weight, self.c2.bias, [(32, 32)], bn=self.b2, act=nv.ACT_RELU, tag='c2')
+            self._a1 = a1
+            return _net.head_1x1(tape, a2, self.final.weight, self.final.bias, dlogits)
+
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, size, size, generator=gen)
+    y = (torch.rand(2, 1, size, size, generator=gen) > 0.6).long()
+    res = []
+    keep = _net.Tape.fuse_reduce
+    try:
+        for fuse in (True, False):
+            _net.Tape.fuse_reduce = fuse
+            torch.manual_seed(11)
+            m = Toy().to(device).train()
+            taken = []
+            orig = _net.ConvOp.dgrad
+
+            def spy(self, dyv, dxv, bn_reduce=None, _orig=orig, _taken=taken):
+                _taken.append(bn_reduce is not None)
+                return _orig(self, dyv, dxv, bn_reduce=bn_reduce)
+            _net.ConvOp.dgrad = spy
+            try:
+                out = m(x.to(device))
+                loss = BCEWithLogitsLossAndSmoothJaccard()(out, y.to(device))
+                (2 * loss).backward()
+            finally:
+                _net.ConvOp.dgrad = orig
+            assert any(taken) == fuse, (fuse, taken)            # the fused launch was (not) taken
+            res.append((out.detach().cpu(), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}))
+    finally:
+        _net.Tape.fuse_reduce = keep
+    (oa, ga), (ob, gb) = res
+    assert torch.equal(oa, ob)
+    gmax = max(float(g.abs().max()) for g in gb.values())
+    for n in gb:
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-2 * max(float(gb[n].abs().max()), 1e-3 * gmax), n

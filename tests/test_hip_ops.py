@@ -1672,3 +1672,77 @@ def test_bn_bwd_apply_from_sources_equals_stored_dz(shape, srcs, dtype):
     with on_emulator():
         e = run('cpu', False)
     check('dy vs emulator', b[0], e[0], dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 20, 24, 32, 1, True), (3, 9, 7, 64, 3, False), (2, 16, 12, 16, 2, True), (1, 33, 40, 8, 4, True)],
+                         ids=lambda s: 'N%d_%dx%d_C%d_K%d_%s' % (s[:5] + ('drop' if s[5] else 'nodrop',)))
+def test_last_layer_and_classifier_in_one_pass(shape, dtype):
+    """segnb_bn_fwd_fused_head == segnb_bn_fwd_fused + segnb_head_fwd and segnb_head_bn_bwd == segnb_head_bwd +
+    segnb_bn_act_bwd_reduce (zf_unet.py:56-58,91-93 and their backward): the activated tensor and its gradient never go to
+    memory.  dz, the activated values and the published coefficients are bit-equal (same expressions, same rounding points);
+    logits / dw / db / sums differ by summation order only."""
+    N, H, W, C, K, use_drop = shape
+    rt = Runtime('cuda', dtype)
+    Cp = cp.pad8(C)
+    assert nv.query('segnb_head_fused_ok', K, Cp) == 1 and nv.query('segnb_head_fused_ok', 5, Cp) == 0
+    gen = torch.Generator().manual_seed(31 * C + H + K)
+    yv = _view_from(rt, torch.randn(N, H, W, C, generator=gen) * 1.5 + 0.3, Cp)
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(C, generator=gen)).cuda()
+    hw_ = (0.3 * torch.randn(K, C, generator=gen)).cuda()
+    hb = (0.1 * torch.randn(K, generator=gen)).cuda()
+    dl = torch.randn(N, K, H, W, generator=gen).cuda()
+    dm = None
+    if use_drop:
+        dm = torch.ones(N, Cp, device='cuda')
+        dm[:, :C] = ((torch.rand(N, C, generator=gen) > 0.3).float() / 0.7).cuda()
+    act = nv.ACT_RELU
+    res = {}
+    for fused in (False, True):
+        stats = rt.zeros((16, 2, Cp), torch.float64)
+        nv.call('segnb_bn_stats', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
+        sums = rt.zeros((16, 2, Cp), torch.float64)
+        sums.fill_(7.0)                                   # the forward clears them
+        coef = rt.zeros((4, Cp), torch.float32)
+        rm, rvv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+        a = View.alloc(rt, N, H, W, Cp)
+        logits = torch.zeros(N, K, H, W, device='cuda')
+        dz = View.alloc(rt, N, H, W, Cp)
+        dw, db = torch.ones(K, C, device='cuda'), torch.ones(K, device='cuda')          # accumulate on top of 1
+        head = (nv.ptr(stats), nv.ptr(gamma), nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), nv.ptr(coef),
+                nv.ptr(sums), act, 0.01, nv.ptr(dm))
+        if fused:
+            nv.call('segnb_bn_fwd_fused_head', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, *head, a.ptr, a.ld, nv.ptr(hw_),
+                    nv.ptr(hb), K, nv.ptr(logits), rt.stream)
+            logits2 = torch.zeros_like(logits)            # and without the activated tensor
+            stats2, coef2 = stats.clone(), rt.zeros((4, Cp), torch.float32)
+            rm2, rv2, nbt2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+            nv.call('segnb_bn_fwd_fused_head', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(stats2), nv.ptr(gamma),
+                    nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm2), nv.ptr(rv2), nv.ptr(nbt2), nv.ptr(coef2), None, act, 0.01, nv.ptr(dm),
+                    None, 0, nv.ptr(hw_), nv.ptr(hb), K, nv.ptr(logits2), rt.stream)
+            torch.cuda.synchronize()
+            assert torch.equal(logits, logits2) and torch.equal(coef, coef2)
+            assert float(sums.abs().max()) == 0.0
+            nv.call('segnb_head_bn_bwd', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
+                    nv.ptr(hw_), K, nv.ptr(dl), dz.ptr, dz.ld, nv.ptr(sums), nv.ptr(dw), nv.ptr(db), rt.stream)
+        else:
+            nv.call('segnb_bn_fwd_fused', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, *head, a.ptr, a.ld, None, 0, None, 0, None, 0,
+                    rt.stream)
+            nv.call('segnb_head_fwd', rt.code, a.ptr, a.ld, N, H, W, C, nv.ptr(hw_), nv.ptr(hb), K, nv.ptr(logits), rt.stream)
+            da = View.alloc(rt, N, H, W, Cp)
+            nv.call('segnb_head_bwd', rt.code, a.ptr, a.ld, N, H, W, C, Cp, nv.ptr(hw_), K, nv.ptr(dl), da.ptr, da.ld,
+                    nv.ptr(dw), nv.ptr(db), rt.stream)
+            nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm),
+                    da.ptr, da.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+        torch.cuda.synchronize()
+        res[fused] = dict(a=a.t.clone(), logits=logits.clone(), coef=coef.clone(), rm=rm.clone(), rv=rvv.clone(), nbt=int(nbt),
+                          dz=dz.t.clone(), sums=sums.sum(0).clone(), dw=dw.clone(), db=db.clone())
+    u, f = res[False], res[True]
+    assert torch.equal(u['a'], f['a']) and torch.equal(u['coef'], f['coef']) and torch.equal(u['dz'], f['dz'])
+    assert torch.equal(u['rm'], f['rm']) and torch.equal(u['rv'], f['rv']) and u['nbt'] == f['nbt'] == 1
+    torch.testing.assert_close(f['logits'], u['logits'], rtol=1e-5, atol=1e-5 * float(u['logits'].abs().max()))
+    torch.testing.assert_close(f['dw'], u['dw'], rtol=1e-4, atol=1e-4 * float(u['dw'].abs().max()))
+    torch.testing.assert_close(f['db'], u['db'], rtol=1e-4, atol=1e-4 * float(u['db'].abs().max()))
+    torch.testing.assert_close(f['sums'], u['sums'], rtol=1e-6, atol=1e-6 * float(u['sums'].abs().max()))

@@ -186,6 +186,10 @@ def test_inplace_abn_constructor_surface():
     mc.check_inplace_abn_surface('cpu')
 
 
+def test_executor_reduce_in_the_consumers_data_gradient():
+    mc.check_executor_fused_reduce('cpu')
+
+
 def test_linknet34_abs_eps_affine_form_inside_the_plan():
     mc.check_linknet_abs_eps_form('cpu')
 

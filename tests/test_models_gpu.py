@@ -25,6 +25,10 @@ def test_fcdensenet57_vs_reference_golden(golden_dir, dtype):
     print('fcdensenet57 %s dloss %.2e diou %.2e' % ((dtype,) + mc.check_product_golden(m, g, 'cuda', dtype)))
 
 
+def test_executor_reduce_in_the_consumers_data_gradient():
+    mc.check_executor_fused_reduce('cuda')
+
+
 def test_linknet34_abs_eps_affine_form_inside_the_plan():
     """lib/modules/abn/functions.py:94-118 form (scale |w| + eps, signed weight gradient) inside LinkNet34's fused plan"""
     mc.check_linknet_abs_eps_form('cuda')
