@@ -190,6 +190,8 @@ def main():
                     help='zf_unet = the headline metric (BASELINE.json); the others time the remaining SURVEY 8d rows at '
                          'their own sizes: linknet34 512x512 bs=16, fcdensenet103 256x256 bs=8, unet16 1024x1024 bs=4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-box', action='store_true',
+                    help='skip the box calibration probes (profiling runs: their GEMM / copy kernels would be counted)')
     ap.add_argument('--fuse-optimizer', action='store_true',
                     help='N > 1: SGD update of each gradient bucket behind its all-reduce (segnb.dist.DataParallel.fuse_optimizer)')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -221,7 +223,7 @@ def main():
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) if ws > 1 else 0)
     torch.cuda.set_device(dev)
     nv.load()
-    box = box_calibration(dev) if rank == 0 else None
+    box = box_calibration(dev) if (rank == 0 and not args.no_box) else None
 
     # (model constructor, images per GPU, size, algorithmic GFLOP per image fwd+bwd at that size -- SURVEY 8d)
     import warnings

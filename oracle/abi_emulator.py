@@ -947,6 +947,14 @@ class AbiEmulator(object):
         S[6] += float(n)
         return 0
 
+    def segnb_seg_loss_reduce_finalize(self, logits, target, n, spec, work, out, stream):
+        """reduce + finalize; the work buffer comes in zeroed and leaves zeroed"""
+        sp = _geom(spec)
+        rc = self.segnb_seg_loss_reduce(logits, target, n, float(sp.focal_gamma), work, stream)
+        rc = rc or self.segnb_seg_loss_finalize(work, spec, out, stream)
+        _mem(work, 16, torch.float64).zero_()
+        return rc
+
     def segnb_seg_loss_finalize(self, sums, spec, out, stream):
         sp = _geom(spec)
         S = _mem(sums, 8, torch.float64).tolist()

@@ -216,9 +216,40 @@ __device__ __forceinline__ PixTerms pix_terms(float x, float t, float gamma = 2.
     return o;
 }
 
+__device__ __forceinline__ void loss_finalize_math(const double* sums, const segnb_loss_spec& sp, float* __restrict__ out) {
+    const double n = sums[6];
+    const double I = sums[2], U = sums[3] + sums[4];
+    const double bce = sp.bce_sum ? sums[0] : sums[0] / n;
+    const double focal = sp.focal_mean ? sums[1] / n : sums[1];
+    const double eps = (double)sp.eps, sm = (double)sp.smooth;
+    const double Dj = U - I + eps, Ds = U - I + sm, Dd = U + eps;
+    const double jac = 1.0 - I / Dj;
+    const double sjac = 1.0 - (I + sm) / Ds;
+    const double dice = 1.0 - 2.0 * I / Dd;
+    const double loss = ((double)sp.w_bce * bce + (double)sp.w_focal * focal + (double)sp.w_jaccard * jac +
+                         (double)sp.w_sjaccard * sjac + (double)sp.w_dice * dice) / (double)sp.norm;
+    // d(loss)/dI and d(loss)/dU of the region terms (before the 1/norm factor)
+    const double GI = (double)sp.w_jaccard * (-(U + eps) / (Dj * Dj)) + (double)sp.w_sjaccard * (-(U + 2.0 * sm) / (Ds * Ds)) +
+                      (double)sp.w_dice * (-2.0 / Dd);
+    const double GU = (double)sp.w_jaccard * (I / (Dj * Dj)) + (double)sp.w_sjaccard * ((I + sm) / (Ds * Ds)) +
+                      (double)sp.w_dice * (2.0 * I / (Dd * Dd));
+    out[0] = (float)loss;
+    out[1] = (float)(I / (U - I + 1e-7));   // JaccardScore, metrics.py:14-20
+    out[2] = (float)(sums[5] / n);          // PixelAccuracy, metrics.py:30-40
+    out[3] = (float)GI;
+    out[4] = (float)GU;
+    out[5] = (float)bce;
+    out[6] = (float)n;
+    out[7] = 0.f;
+}
+
+// FIN: the LAST block to finish (a ticket counter behind the sums) turns the sums into the result vector and leaves the work
+// buffer zeroed for the next call -- zero fill, reduction and finalize in one launch (segnb_seg_loss_reduce_finalize)
+template <bool FIN>
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ x,
                                                           const long long* __restrict__ tg, long long n,
-                                                          double* __restrict__ sums, int vec, float gamma) {
+                                                          double* __restrict__ sums, int vec, float gamma,
+                                                          segnb_loss_spec sp, float* __restrict__ fin) {
     double s[6] = {0, 0, 0, 0, 0, 0};
     auto term = [&](float xv, long long tgv) {
         const float t = tgv != 0 ? 1.f : 0.f;
@@ -261,34 +292,31 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
         atomicAdd(&sums[threadIdx.x], v);
     }
     if (threadIdx.x == 6 && blockIdx.x == 0) atomicAdd(&sums[6], (double)n);
+    if constexpr (FIN) {
+        __shared__ int last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* ticket = reinterpret_cast<unsigned*>(sums + 8);
+            last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+        }
+        __syncthreads();
+        if (last && threadIdx.x == 0) {
+            __threadfence();
+            double tot[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) tot[k] = atomicAdd(&sums[k], 0.0);      // (coherent read of what every block added)
+            loss_finalize_math(tot, sp, fin);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) sums[k] = 0.0;
+            *reinterpret_cast<unsigned*>(sums + 8) = 0u;
+        }
+    }
 }
 
 __global__ void loss_finalize_kernel(const double* __restrict__ sums, segnb_loss_spec sp, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double n = sums[6];
-    const double I = sums[2], U = sums[3] + sums[4];
-    const double bce = sp.bce_sum ? sums[0] : sums[0] / n;
-    const double focal = sp.focal_mean ? sums[1] / n : sums[1];
-    const double eps = (double)sp.eps, sm = (double)sp.smooth;
-    const double Dj = U - I + eps, Ds = U - I + sm, Dd = U + eps;
-    const double jac = 1.0 - I / Dj;
-    const double sjac = 1.0 - (I + sm) / Ds;
-    const double dice = 1.0 - 2.0 * I / Dd;
-    const double loss = ((double)sp.w_bce * bce + (double)sp.w_focal * focal + (double)sp.w_jaccard * jac +
-                         (double)sp.w_sjaccard * sjac + (double)sp.w_dice * dice) / (double)sp.norm;
-    // d(loss)/dI and d(loss)/dU of the region terms (before the 1/norm factor)
-    const double GI = (double)sp.w_jaccard * (-(U + eps) / (Dj * Dj)) + (double)sp.w_sjaccard * (-(U + 2.0 * sm) / (Ds * Ds)) +
-                      (double)sp.w_dice * (-2.0 / Dd);
-    const double GU = (double)sp.w_jaccard * (I / (Dj * Dj)) + (double)sp.w_sjaccard * ((I + sm) / (Ds * Ds)) +
-                      (double)sp.w_dice * (2.0 * I / (Dd * Dd));
-    out[0] = (float)loss;
-    out[1] = (float)(I / (U - I + 1e-7));   // JaccardScore, metrics.py:14-20
-    out[2] = (float)(sums[5] / n);          // PixelAccuracy, metrics.py:30-40
-    out[3] = (float)GI;
-    out[4] = (float)GU;
-    out[5] = (float)bce;
-    out[6] = (float)n;
-    out[7] = 0.f;
+    loss_finalize_math(sums, sp, out);
 }
 
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ x, const long long* __restrict__ tg,
@@ -435,6 +463,17 @@ float* head_scratch(size_t bytes, hipStream_t stream) {
     Ent* e = nullptr;
     for (auto& it : ents)
         if (it.dev == dev && it.stream == stream) e = &it;
+    // A stream that is being CAPTURED into a HIP graph cannot allocate (hipMalloc invalidates the capture): the graph takes the
+    // buffer the eager warm-up steps of this device used (bench.py --graph on / torch.cuda.graph run eager steps first; the
+    // graph's replays and eager steps of the same model never overlap)
+    hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+    if ((e == nullptr || bytes > e->cap) && hipStreamIsCapturing(stream, &cap_st) == hipSuccess &&
+        cap_st == hipStreamCaptureStatusActive) {
+        for (auto& it : ents)
+            if (it.dev == dev && it.cap >= bytes) return it.buf;
+        segnb_set_error("segnb_head_bwd: no scratch buffer to capture with -- run one eager step before capturing a graph");
+        return nullptr;
+    }
     if (e == nullptr) {
         ents.push_back(Ent{dev, stream, nullptr, 0});
         e = &ents.back();
@@ -510,7 +549,22 @@ extern "C" int segnb_seg_loss_reduce(const float* logits, const long long* targe
     int grid = ceil_div(n, 256 * 4);
     if (grid > 512) grid = 512;
     const int vec = (((uintptr_t)logits | (uintptr_t)target) & 15) == 0;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, sums, vec, focal_gamma);
+    hipLaunchKernelGGL(loss_reduce_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, sums, vec,
+                       focal_gamma, segnb_loss_spec{}, (float*)nullptr);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_seg_loss_reduce_finalize(const float* logits, const long long* target, long long n,
+                                              const segnb_loss_spec* spec, double* work, float* out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_seg_loss_reduce_finalize, logits, target, n, spec, work, out, stream);
+    SEGNB_CHECK_ARG(logits && target && spec && work && out && n > 0, "bad arguments");
+    SEGNB_CHECK_ARG(spec->norm != 0.f, "loss norm must be non-zero");
+    int grid = ceil_div(n, 256 * 4);
+    if (grid > 512) grid = 512;
+    const int vec = (((uintptr_t)logits | (uintptr_t)target) & 15) == 0;
+    hipLaunchKernelGGL(loss_reduce_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, work, vec,
+                       spec->focal_gamma, *spec, out);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

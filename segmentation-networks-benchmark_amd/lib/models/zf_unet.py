@@ -282,8 +282,12 @@ class _ZFUnetPlan(object):
                     uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
                 unpacks.append(PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
                 los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
-            t = (key, (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
-                       PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight')), tuple(unpacks), tuple(los))
+            if self.PACK_OVERLAP or os.environ.get('SEGNB_PACK_SPLIT', '0') != '0':
+                packs = (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
+                         PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'))
+            else:                                    # everything on the main stream: ONE launch
+                packs = (PackTable(self.rt, pj_early + pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'), None)
+            t = (key, packs, tuple(unpacks), tuple(los))
             self._pack_tables[(N, H, W)] = t
         return t
 
@@ -329,7 +333,7 @@ class _ZFUnetPlan(object):
             nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
             with torch.cuda.stream(side):
                 late.run()
-        else:
+        elif late is not None:
             late.run()
         self._packed_key = key
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     'segnb_head_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     'segnb_head_bwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P],
     'segnb_seg_loss_reduce': [_P, _P, c_ll, c_float, _P, _P],
+    'segnb_seg_loss_reduce_finalize': [_P, _P, c_ll, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_seg_loss_map': [_P, _P, c_ll, c_int, c_float, _P, _P],
     'segnb_seg_loss_map_bwd': [_P, _P, c_ll, c_int, c_float, _P, _P, _P],
     'segnb_absmax_f32': [_P, c_ll, _P, _P],

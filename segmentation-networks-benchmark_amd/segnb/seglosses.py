@@ -11,6 +11,8 @@ extra passes over the logits.
 """
 import weakref
 
+import os
+
 import torch
 
 from . import _native as nv
@@ -98,11 +100,25 @@ def _grad_buffer_for(x):
     return None
 
 
+# SEGNB_LOSS_ONE_LAUNCH=0: zero fill, segnb_seg_loss_reduce and segnb_seg_loss_finalize as three launches (A/B)
+_ONE_LAUNCH = os.environ.get('SEGNB_LOSS_ONE_LAUNCH', '1') != '0'
+_loss_work = {}       # (device index, stream) -> 16 zeroed doubles: the sums + ticket of segnb_seg_loss_reduce_finalize
+
+
 def reduce_finalize(x, t, spec):
     """-> fin fp32[8] = (loss, soft IoU, pixel accuracy, GI, GU, bce mean, n, -) on the device."""
-    sums = torch.zeros(8, dtype=torch.float64, device=x.device)
     fin = torch.empty(8, dtype=torch.float32, device=x.device)
     st = _stream(x)
+    if DataParallelHooks.sums_allreduce is None and _ONE_LAUNCH:
+        # one device: zero fill + reduction + finalize are ONE launch (the work buffer is left zeroed by the launch itself; one
+        # per stream: two losses evaluated on different streams must not share sums)
+        key = (x.device.index, st)
+        work = _loss_work.get(key)
+        if work is None:
+            work = _loss_work[key] = torch.zeros(16, dtype=torch.float64, device=x.device)
+        nv.call('segnb_seg_loss_reduce_finalize', nv.ptr(x), nv.ptr(t), x.numel(), _cspec(spec), nv.ptr(work), nv.ptr(fin), st)
+        return work, fin
+    sums = torch.zeros(8, dtype=torch.float64, device=x.device)
     nv.call('segnb_seg_loss_reduce', nv.ptr(x), nv.ptr(t), x.numel(), float(spec[10]), nv.ptr(sums), st)
     if DataParallelHooks.sums_allreduce is not None:
         DataParallelHooks.sums_allreduce(sums)

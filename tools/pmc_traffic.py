@@ -57,7 +57,7 @@ def main():
                     'WRITE_SIZE_KiB_per_launch': round(w_launch, 2),
                     'traffic_bytes_per_launch': round((2.0 * f_launch + w_launch) * 1024.0)}
     # ABI-level groups (bench.py times launches per C-ABI entry point: segnb_conv_fprop = image-tile + general kernel)
-    groups = {'conv_fprop': ('conv_fprop_kernel', 'conv_fprop_s1x9_kernel', 'conv_fprop_ws_kernel', 'conv_fprop_rw_kernel', 'conv_fprop_c8_kernel'),
+    groups = {'conv_fprop': ('conv_fprop_kernel', 'conv_fprop_s1x9_kernel', 'conv_fprop_ws_kernel', 'conv_fprop_rw_kernel', 'conv_fprop_c8_kernel', 'conv_roll_kernel'),
               'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_s1x9_kernel')}
     for gname, fams in groups.items():
         nf = sum(fe.get(f, [0, 0.0])[0] for f in fams)
