@@ -475,6 +475,31 @@ int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int 
                    const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                    float* db, segnb_stream_t stream);
 
+/* Statistics of a concat prefix WITHOUT a pass over the prefix (FCDenseNet's dense blocks, tiramisu.py:9-44: layer l normalises
+ * [input | slice 1 .. slice l-1] with its own BatchNorm; the batch statistics of those channels are the same for every layer).
+ * One table [REPLICAS][2][ld] per concat buffer, channel c of the buffer at column c:
+ *   segnb_bn_stats_ld        segnb_bn_stats into channel range [stats, stats + Cp) of a table with row stride stats_ld
+ *   segnb_bn_act_fwd_stats   segnb_bn_act_fwd (no pooling / upsampling / residual) that also accumulates the statistics of the
+ *                            tensor it WRITES into such a range -- the pass that writes a slice sums it
+ *   segnb_bn_fwd_fused_ld    segnb_bn_fwd_fused whose statistics are such a range (row stride stats_ld)
+ * The table is cleared by the caller once per step (not by the backward of any one layer: several layers read it). */
+int segnb_bn_stats_ld(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats, int stats_ld,
+                      segnb_stream_t stream);
+int segnb_bn_act_fwd_stats(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef, int act,
+                           float slope, const float* dropmul, void* out, int ld_out, double* out_stats, int out_stats_ld,
+                           segnb_stream_t stream);
+int segnb_bn_fwd_fused_ld(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const double* stats,
+                          int stats_ld, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, long long* nbt, float* coef, double* bwd_sums_to_clear, int act, float slope,
+                          const float* dropmul, void* out, int ld_out, segnb_stream_t stream);
+
+/* Bias gradients of many convolutions WITHOUT BatchNorm in one launch (the executor models' backward: unet16.py:12-21,
+ * tiramisu.py:14,52 -- Conv2d(bias=True) followed by no normalisation): job = {double* sums [REPLICAS][2][Cp] as
+ * segnb_bn_act_bwd_reduce accumulated them; float* gb [C] or NULL; int C, Cp} (segnb_bias_grad_job_bytes() bytes each, on the
+ * device): gb += sum over the replicas of row 0, then the sums are cleared -- segnb_bn_bwd_finalize(gamma = NULL) per layer. */
+int segnb_bias_grad_job_bytes(void);
+int segnb_bias_grad_multi(const void* jobs, int njobs, segnb_stream_t stream);
+
 /* The network's LAST BatchNorm + activation (+ Dropout2d) layer and the classifier behind it as ONE pass over the layer's
  * pre-BatchNorm output y, in both directions (zf_unet.py:56-58,91-93: double_conv_layer -> Conv2d(filters, num_classes, 1);
  * autograd's BatchNorm / ReLU / Dropout2d / Conv2d backward nodes of the same lines):

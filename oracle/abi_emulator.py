@@ -826,6 +826,33 @@ class AbiEmulator(object):
         S[1] += (v * v).sum(0)
         return 0
 
+    # ---- statistics as a channel range of a wider [REPL][2][ld] table (FCDenseNet's concat prefixes)
+    @staticmethod
+    def _stats_range(stats, Cp, ld):
+        """[REPL][2][Cp] strided view of the range"""
+        flat = _mem(stats, (REPL * 2 - 1) * ld + Cp, torch.float64)
+        return flat.as_strided((REPL, 2, Cp), (2 * ld, ld, 1))
+
+    def segnb_bn_stats_ld(self, dtype, x, ld, N, H, W, Cp, stats, stats_ld, stream):
+        v = _nhwc(x, N, H, W, Cp, ld, _tdt(dtype)).double().reshape(-1, Cp)
+        S = self._stats_range(stats, Cp, stats_ld)[0]
+        S[0] += v.sum(0)
+        S[1] += (v * v).sum(0)
+        return 0
+
+    def segnb_bn_act_fwd_stats(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, out_stats,
+                               out_stats_ld, stream):
+        rc = self.segnb_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, None, 0, None, 0,
+                                   None, 0, stream)
+        return rc or self.segnb_bn_stats_ld(dtype, out, ld_out, N, H, W, Cp, out_stats, out_stats_ld, stream)
+
+    def segnb_bn_fwd_fused_ld(self, dtype, y, ld_y, N, H, W, C, Cp, stats, stats_ld, gamma, beta, eps, momentum, rm, rv, nbt,
+                              coef, clear_sums, act, slope, dropmul, out, ld_out, stream):
+        dense = self._stats_range(stats, Cp, stats_ld).contiguous().clone()       # the range as a [REPL][2][Cp] table of its own
+        return self.segnb_bn_fwd_fused(dtype, y, ld_y, N, H, W, C, Cp, dense.data_ptr(), gamma, beta, eps, momentum, rm, rv,
+                                       nbt, coef, clear_sums, act, slope, dropmul, out, ld_out, None, 0, None, 0, None, 0,
+                                       stream)
+
     def segnb_maxpool_fwd(self, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, idx, stream):
         dt = _tdt(dtype)
         X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2)
@@ -856,6 +883,21 @@ class AbiEmulator(object):
 
     # ------------------------------------------------------------------------------------------ head
     # ---- the last BatchNorm + activation layer and the classifier behind it as one pass (the two-launch forms, composed)
+    def segnb_bias_grad_job_bytes(self):
+        return 24
+
+    def segnb_bias_grad_multi(self, jobs, njobs, stream):
+        import ctypes
+        raw = (ctypes.c_uint8 * (24 * njobs)).from_address(jobs)
+        tab = np.frombuffer(bytes(raw), dtype=np.dtype([('sums', '<u8'), ('gb', '<u8'), ('C', '<i4'), ('Cp', '<i4')]))
+        for j in tab:
+            C, Cp = int(j['C']), int(j['Cp'])
+            S = _mem(int(j['sums']), REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)
+            if int(j['gb']):
+                _mem(int(j['gb']), C, torch.float32).add_(S[:, 0, :C].sum(0).float())
+            S.zero_()
+        return 0
+
     def segnb_head_fused_ok(self, K, Cp):
         cpp = Cp // 8
         return int(1 <= K <= 4 and Cp % 8 == 0 and 8 <= Cp <= 256 and cpp & (cpp - 1) == 0)

@@ -75,6 +75,7 @@ struct BnFwdParams {
     float* coef;                // [4][Cp] out
     double* zero_buf;           // fused only: the BACKWARD accumulators of this layer, cleared for this step
     int keep_stats;             // segnb_bn_finalize_keep: the statistics are left for the backward to clear (fused protocol)
+    int stats_ld;               // channel stride between the [REPL][2] rows of `stats` (0: Cp) -- a channel RANGE of a wider table
 };
 
 __device__ __forceinline__ void bn_fwd_coef(const BnFwdParams& p, int Cp, int c, bool update, float& scale,
@@ -84,10 +85,11 @@ __device__ __forceinline__ void bn_fwd_coef(const BnFwdParams& p, int Cp, int c,
     double mu, var;
     if (p.training) {
         double v1[REPL], v2[REPL];
+        const int SL = p.stats_ld > 0 ? p.stats_ld : Cp;
 #pragma unroll
         for (int rp = 0; rp < REPL; ++rp) {
-            v1[rp] = p.stats[(rp * 2) * Cp + c];
-            v2[rp] = p.stats[(rp * 2 + 1) * Cp + c];
+            v1[rp] = p.stats[(rp * 2) * SL + c];
+            v2[rp] = p.stats[(rp * 2 + 1) * SL + c];
         }
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -143,6 +145,43 @@ __global__ void bn_finalize_kernel(const BnFwdParams p, int Cp) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// block-level per-channel reduction helper: thread (tx,ty) holds v[8] for chunk tx; result summed over
+// ty and atomically added (fp64) to dst[chan] for chan < Cp.  Deterministic: butterfly over the lanes of a
+// wave that share tx, one LDS slot per wave, fixed-order fp64 sum over the waves (only the final fp64 atomics
+// across blocks are unordered: 1e-16 relative).
+constexpr int SRED_FLOATS = (NTHR / 64) * 2 * 32 * 8;
+__device__ __forceinline__ void block_channel_sum2(float (&a)[8], float (&b)[8], const EwShape& s, int tx,
+                                                   int chunk_base, double* __restrict__ dst0,
+                                                   double* __restrict__ dst1, float* sred) {
+    // sred: [NTHR/64][2][CT*8] floats in LDS
+    for (int off = s.CT; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] += __shfl_xor(a[e], off);
+            b[e] += __shfl_xor(b[e], off);
+        }
+    }
+    const int nch = s.CT * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < s.CT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sred[wave * 2 * nch + tx * 8 + e] = a[e];
+            sred[wave * 2 * nch + nch + tx * 8 + e] = b[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * nch; i += NTHR) {
+        const int which = i / nch, idx = i - which * nch;
+        const int ch = chunk_base * 8 + idx;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; ++w) t += (double)sred[w * 2 * nch + i];
+        if (ch < s.Cp) atomicAdd((which == 0 ? dst0 : dst1) + ch, t);
+    }
+}
+
 // raw 8-channel chunk as loaded (16 bytes of bf16 / 32 bytes of fp32): the conversion to fp32 is deferred to the first use,
 // so that a thread can keep the loads of several pixels -- and its coefficient prologue -- in flight at once.  A pass over a
 // small tensor is ONE dependent round trip long instead of one per pixel (4 pixels per thread: 8.5 -> ~6 us at 7x7 .. 28x28)
@@ -211,15 +250,28 @@ struct HeadFwd {
 // HK > 0: the network's LAST activation pass also evaluates the 1x1 classifier (zf_unet.py:58,93) on the values it produces --
 // the lanes that hold a pixel's channel chunks (CT consecutive lanes; the launcher requires CT == Cp / 8) add their partial dot
 // products with a shuffle tree -- and `out` may be NULL: the activated tensor then never exists in memory
-template <typename T, bool POOL, bool RES, int HK = 0>
+// SOUT: the pass also accumulates the per-channel sum / sum of squares of the values it WRITES into a statistics table (a channel
+// range of a wider [REPL][2][ld] table): the BatchNorm layers that will read this tensor as part of a concat prefix find its
+// statistics there and never pass over it again (FCDenseNet's dense blocks, tiramisu.py:9-44: every layer normalises the whole prefix)
+struct OutStats {
+    double* p;
+    int ld;
+};
+
+template <typename T, bool POOL, bool RES, int HK = 0, bool SOUT = false>
 __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ y, int ld_y, EwShape s,
                                                           const float* __restrict__ coef, int act, float slope,
                                                           const float* __restrict__ dropmul, T* __restrict__ out,
                                                           int ld_out, T* __restrict__ pool_out, int ld_pool,
                                                           T* __restrict__ up_out, int ld_up,
                                                           const T* __restrict__ res, int ld_res, const BnFwdParams fp,
-                                                          const HeadFwd hd = HeadFwd{}) {
+                                                          const HeadFwd hd = HeadFwd{}, const OutStats so = OutStats{}) {
     static_assert(HK == 0 || !POOL, "the classifier reads the un-pooled activation");
+    static_assert(!SOUT || !POOL, "output statistics: the plain walk only");
+    __shared__ float sred_o[SOUT ? SRED_FLOATS : 1];
+    float os1[8], os2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) os1[e] = os2[e] = 0.f;
     constexpr int U = 2;            // pixels per trip (no pooling)
     constexpr int UP = 2;           // row-pair items per trip (pooling)
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
@@ -323,14 +375,14 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
             scoef[2][threadIdx.x] = mean;
         }
         __syncthreads();
-        if (!active) return;
+        if (!active && !SOUT) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sc[e] = scoef[0][tx * 8 + e];
             sh[e] = scoef[1][tx * 8 + e];
             mu[e] = scoef[2][tx * 8 + e];
         }
-    } else if (!active) {
+    } else if (!active && !SOUT) {
         return;
     } else if (coef != nullptr) {   // six 16-byte loads in flight at once (element-wise selects serialise 24 dword loads)
         load8(coef + c0, sc);
@@ -355,6 +407,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
     if constexpr (!pooling) {
         // no pooling: consecutive threads take consecutive pixels, so every load / store instruction of a wave
         // covers one contiguous run
+        if (SOUT && !active) it0 = npix;
         while (it0 < npix) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -375,6 +428,13 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
                     for (int e = 0; e < 8; ++e) v[e] = dm[e] * act_fwd((v[e] - mu[e]) * sc[e] + sh[e], act, slope);
                 }
                 round_store8(out != nullptr ? out + (long long)pix * ld_out + c0 : (T*)nullptr, v);
+                if constexpr (SOUT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        os1[e] += v[e];
+                        os2[e] += v[e] * v[e];
+                    }
+                }
                 if constexpr (HK > 0) {
                     float pk[HK];
 #pragma unroll
@@ -406,6 +466,10 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
             }
             it0 += U * stride;
             if (it0 < npix) issue_plain(it0);
+        }
+        if constexpr (SOUT) {
+            double* rep = so.p + (long long)(blockIdx.x % REPL) * 2 * so.ld;
+            block_channel_sum2(os1, os2, s, tx, blockIdx.y * s.CT, rep, rep + so.ld, sred_o);
         }
         return;
     } else {
@@ -462,43 +526,6 @@ __global__ __launch_bounds__(NTHR) void bn_act_fwd_kernel(const T* __restrict__ 
         it0 += UP * stride;
         if (it0 < nitems) issue_pool(it0);
     }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// block-level per-channel reduction helper: thread (tx,ty) holds v[8] for chunk tx; result summed over
-// ty and atomically added (fp64) to dst[chan] for chan < Cp.  Deterministic: butterfly over the lanes of a
-// wave that share tx, one LDS slot per wave, fixed-order fp64 sum over the waves (only the final fp64 atomics
-// across blocks are unordered: 1e-16 relative).
-constexpr int SRED_FLOATS = (NTHR / 64) * 2 * 32 * 8;
-__device__ __forceinline__ void block_channel_sum2(float (&a)[8], float (&b)[8], const EwShape& s, int tx,
-                                                   int chunk_base, double* __restrict__ dst0,
-                                                   double* __restrict__ dst1, float* sred) {
-    // sred: [NTHR/64][2][CT*8] floats in LDS
-    for (int off = s.CT; off < 64; off <<= 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            a[e] += __shfl_xor(a[e], off);
-            b[e] += __shfl_xor(b[e], off);
-        }
-    }
-    const int nch = s.CT * 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < s.CT) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            sred[wave * 2 * nch + tx * 8 + e] = a[e];
-            sred[wave * 2 * nch + nch + tx * 8 + e] = b[e];
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * nch; i += NTHR) {
-        const int which = i / nch, idx = i - which * nch;
-        const int ch = chunk_base * 8 + idx;
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < NTHR / 64; ++w) t += (double)sred[w * 2 * nch + i];
-        if (ch < s.Cp) atomicAdd((which == 0 ? dst0 : dst1) + ch, t);
     }
 }
 
@@ -1169,7 +1196,7 @@ __global__ __launch_bounds__(NTHR) void add_kernel(const T* __restrict__ a, int 
 // pre-activation BatchNorm of tiramisu.py:12,50)
 template <typename T>
 __global__ __launch_bounds__(NTHR) void bn_stats_kernel(const T* __restrict__ x, int ld, EwShape s,
-                                                        double* __restrict__ stats) {
+                                                        double* __restrict__ stats, int stats_ld) {
     __shared__ float sred[SRED_FLOATS];
     const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
     const int cc = blockIdx.y * s.CT + tx;
@@ -1189,8 +1216,8 @@ __global__ __launch_bounds__(NTHR) void bn_stats_kernel(const T* __restrict__ x,
                 s2[e] += v[e] * v[e];
             }
         }
-    double* rep = stats + (long long)(blockIdx.x % REPL) * 2 * s.Cp;
-    block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + s.Cp, sred);
+    double* rep = stats + (long long)(blockIdx.x % REPL) * 2 * stats_ld;
+    block_channel_sum2(s1, s2, s, tx, blockIdx.y * s.CT, rep, rep + stats_ld, sred);
 }
 
 // MaxPool2d(k, stride, pad) forward (floor mode) and its gather-form backward: every input pixel checks the
@@ -1386,7 +1413,7 @@ extern "C" int segnb_bn_finalize_keep(const double* stats, int C, int Cp, double
 static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                              int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
                              int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
-                             const char* who, segnb_stream_t stream, const HeadFwd* hd = nullptr);
+                             const char* who, segnb_stream_t stream, const HeadFwd* hd = nullptr, const OutStats* so = nullptr);
 
 extern "C" int segnb_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp,
                                 const float* coef, int act, float slope, const float* dropmul, void* out,
@@ -1410,6 +1437,35 @@ extern "C" int segnb_bn_fwd_fused(int dtype, const void* y, int ld_y, int N, int
                       bwd_sums_to_clear};
     return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, nullptr, act, slope, dropmul, out, ld_out, pool_out, ld_pool,
                              up_out, ld_up, res, ld_res, fp, "segnb_bn_fwd_fused", stream);
+}
+
+// segnb_bn_act_fwd that also ACCUMULATES the per-channel statistics (sum, sum of squares, fp64, replicated) of the tensor it
+// writes into channel range [0, Cp) of a table with row stride out_stats_ld; and segnb_bn_fwd_fused whose statistics are such a
+// range.  FCDenseNet's dense blocks (tiramisu.py:9-44): the statistics of a concat prefix are those of its slices, which do not
+// change from layer to layer -- each slice is summed once, by the pass that writes it.
+extern "C" int segnb_bn_act_fwd_stats(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
+                                      int act, float slope, const float* dropmul, void* out, int ld_out, double* out_stats,
+                                      int out_stats_ld, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_act_fwd_stats, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, out_stats, out_stats_ld, stream);
+    SEGNB_CHECK_ARG(out != nullptr && out_stats != nullptr, "NULL tensor");
+    BnFwdParams fp = {};
+    const OutStats so = {out_stats, out_stats_ld};
+    return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, out, ld_out, nullptr, 0, nullptr, 0,
+                             nullptr, 0, fp, "segnb_bn_act_fwd_stats", stream, nullptr, &so);
+}
+
+extern "C" int segnb_bn_fwd_fused_ld(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
+                                     const double* stats, int stats_ld, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, long long* nbt, float* coef,
+                                     double* bwd_sums_to_clear, int act, float slope, const float* dropmul, void* out,
+                                     int ld_out, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_fwd_fused_ld, dtype, y, ld_y, N, H, W, C, Cp, stats, stats_ld, gamma, beta, eps, momentum, running_mean, running_var, nbt, coef, bwd_sums_to_clear, act, slope, dropmul, out, ld_out, stream);
+    SEGNB_CHECK_ARG(stats != nullptr && coef != nullptr && out != nullptr && C > 0 && Cp >= C && stats_ld >= Cp,
+                    "missing statistics / coefficient buffer, or a statistics stride below Cp");
+    BnFwdParams fp = {stats, (double)N * H * W, gamma, beta, eps, momentum, running_mean, running_var, nbt, C, 1, coef,
+                      bwd_sums_to_clear, 0, stats_ld};
+    return launch_bn_act_fwd(dtype, y, ld_y, N, H, W, Cp, nullptr, act, slope, dropmul, out, ld_out, nullptr, 0, nullptr, 0,
+                             nullptr, 0, fp, "segnb_bn_fwd_fused_ld", stream);
 }
 
 extern "C" int segnb_head_fused_ok(int K, int Cp) {
@@ -1437,10 +1493,31 @@ extern "C" int segnb_bn_fwd_fused_head(int dtype, const void* y, int ld_y, int N
 static int launch_bn_act_fwd(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef,
                              int act, float slope, const float* dropmul, void* out, int ld_out, void* pool_out,
                              int ld_pool, void* up_out, int ld_up, const void* res, int ld_res, const BnFwdParams& fp,
-                             const char* who, segnb_stream_t stream, const HeadFwd* hd) {
+                             const char* who, segnb_stream_t stream, const HeadFwd* hd, const OutStats* so) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(y != nullptr && (out || pool_out || up_out || hd), "NULL tensor");
     const EwShape s = make_shape(N, H, W, Cp);
+    if (so != nullptr) {
+        // the variant that also accumulates the statistics of what it writes
+        SEGNB_CHECK_ARG(hd == nullptr && pool_out == nullptr && res == nullptr && so->p != nullptr && so->ld >= Cp,
+                        "output statistics: no pooling / residual / classifier, statistics stride >= Cp");
+        const dim3 grid = make_grid(s, (long long)N * H * W, 2048);
+#define SEGNB_FWDS(TT)                                                                                              \
+    hipLaunchKernelGGL((bn_act_fwd_kernel<TT, false, false, 0, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const TT*)y, \
+                       ld_y, s, coef, act, slope, dropmul, (TT*)out, ld_out, (TT*)nullptr, 0, (TT*)up_out, ld_up,    \
+                       (const TT*)nullptr, 0, fp, HeadFwd{}, *so)
+        if (dtype == SEGNB_BF16) {
+            SEGNB_FWDS(bf16_t);
+        } else if (dtype == SEGNB_F32) {
+            SEGNB_FWDS(float);
+        } else {
+            segnb_set_error("%s: unknown dtype %d", who, dtype);
+            return SEGNB_E_BADARG;
+        }
+#undef SEGNB_FWDS
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
     if (hd != nullptr) {
         // the classifier variant: a pixel's channel chunks are CT consecutive lanes of one wave (one block column)
         SEGNB_CHECK_ARG(pool_out == nullptr && res == nullptr && s.CT == s.CPP && hd->K >= 1 && hd->K <= 4 && hd->w && hd->logits,
@@ -1565,6 +1642,43 @@ extern "C" int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int 
         segnb_head_bwd_finish(part, (int)grid.x, (int)grid.y, K, C, s.CT, dw, db, (hipStream_t)stream);
         SEGNB_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// The bias gradients of MANY convolutions without BatchNorm in one launch: job j adds the replicated sums of dz (what
+// segnb_bn_act_bwd_reduce accumulated) into the bias gradient and clears the sums for the next step -- what one
+// segnb_bn_bwd_finalize(gamma = NULL) launch per layer did (FCDenseNet103: 238 launches of 4 us per step on the dependent chain;
+// nothing reads a bias gradient before the end of backward).
+struct BiasGradJob {
+    double* sums;      // [REPL][2][Cp]
+    float* gb;         // [C] or NULL (no bias: the sums are only cleared)
+    int C, Cp;
+};
+__global__ __launch_bounds__(256) void bias_grad_multi_kernel(const BiasGradJob* __restrict__ jobs) {
+    const BiasGradJob j = jobs[blockIdx.x];
+    for (int c = threadIdx.x; c < j.Cp; c += blockDim.x) {
+        double v[REPL];
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) v[rp] = j.sums[(rp * 2) * j.Cp + c];
+        double t = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) t += v[rp];
+        if (c < j.C && j.gb != nullptr) j.gb[c] += (float)t;
+#pragma unroll
+        for (int rp = 0; rp < REPL; ++rp) {
+            j.sums[(rp * 2) * j.Cp + c] = 0.0;
+            j.sums[(rp * 2 + 1) * j.Cp + c] = 0.0;
+        }
+    }
+}
+
+extern "C" int segnb_bias_grad_job_bytes(void) { return (int)sizeof(BiasGradJob); }
+
+extern "C" int segnb_bias_grad_multi(const void* jobs, int njobs, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bias_grad_multi, jobs, njobs, stream);
+    SEGNB_CHECK_ARG(jobs != nullptr && njobs > 0, "bad job table");
+    hipLaunchKernelGGL(bias_grad_multi_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const BiasGradJob*)jobs);
+    SEGNB_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1863,19 +1977,34 @@ extern "C" int segnb_add(int dtype, const void* a, int ld_a, const void* b, int 
     return 0;
 }
 
+static int launch_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats, int stats_ld,
+                           const char* who, segnb_stream_t stream) {
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(x && stats && stats_ld >= Cp, "NULL tensor / statistics stride below the channel count");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x, ld, s, stats, stats_ld);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)x, ld, s, stats, stats_ld);
+    else {
+        segnb_set_error("%s: unknown dtype %d", who, dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats,
                               segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_bn_stats, dtype, x, ld, N, H, W, Cp, stats, stream);
-    if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(x && stats, "NULL tensor");
-    const EwShape s = make_shape(N, H, W, Cp);
-    const dim3 grid = make_grid(s, (long long)N * H * W);
-    SEGNB_DISPATCH_T(
-        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x, ld, s, stats),
-        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)x, ld, s, stats),
-        "segnb_bn_stats")
-    SEGNB_LAUNCH_CHECK();
-    return 0;
+    return launch_bn_stats(dtype, x, ld, N, H, W, Cp, stats, Cp, "segnb_bn_stats", stream);
+}
+
+extern "C" int segnb_bn_stats_ld(int dtype, const void* x, int ld, int N, int H, int W, int Cp, double* stats, int stats_ld,
+                                 segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_stats_ld, dtype, x, ld, N, H, W, Cp, stats, stats_ld, stream);
+    return launch_bn_stats(dtype, x, ld, N, H, W, Cp, stats, stats_ld, "segnb_bn_stats_ld", stream);
 }
 
 extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,

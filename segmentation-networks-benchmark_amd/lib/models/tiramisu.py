@@ -19,11 +19,14 @@ which the convolutions take as their input channel map and the per-channel Batch
 (segnb.net.bn_act).  With multiples of 8 (FCDenseNet67 / 103: growth 16, first convolution 48) every list collapses to one
 contiguous segment and the launches are exactly those of the unpadded plan.
 """
+import os
+
 import torch
 from torch import nn
 
 from segnb import _native as nv
 from segnb import convplan as cp
+from segnb.engine import STAT_REPLICAS
 from segnb.net import Act, HipNet, bn_act, conv_unit, head_1x1, head_from_act
 
 
@@ -130,9 +133,19 @@ class FCDenseNet(HipNet):
         self._init_engine(in_channels)
 
     # ---- plan ------------------------------------------------------------------------------------------------
-    def _dense_layers(self, tape, layers, buf, gbuf, off0, in_segs, tag):
+    # Prefix statistics summed ONCE per slice (tiramisu.py:9-44: every DenseLayer's BatchNorm covers the whole concat prefix, whose
+    # batch statistics do not change from layer to layer): one table per concat buffer, each slice's share accumulated by the pass
+    # that writes it (segnb_bn_act_fwd_stats / segnb_bn_stats_ld), read as a channel range by every layer
+    # (segnb_bn_fwd_fused_ld).  SEGNB_TIRAMISU_STATS_CACHE=0: a statistics pass over the prefix per layer (A/B)
+    cache_prefix_stats = os.environ.get('SEGNB_TIRAMISU_STATS_CACHE', '1') != '0'
+
+    def _dense_layers(self, tape, layers, buf, gbuf, off0, in_segs, tag, tbl=None):
         """Run DenseLayers in place inside buf (padded channel offset off0): layer l reads the prefix in_segs + l growth
-        slices and writes the next slice (growth_rate real channels in pad8(growth_rate))."""
+        slices and writes the next slice (growth_rate real channels in pad8(growth_rate)).  tbl: (flat table tensor, element
+        offset of the buffer's channel 0, row stride) of the buffer's statistics table, or None."""
+
+        def src(ch):
+            return None if tbl is None else (tbl[0], tbl[1] + ch, tbl[2])
         g = self.growth_rate
         gp = cp.pad8(g)
         for l, layer in enumerate(layers):
@@ -141,10 +154,11 @@ class FCDenseNet(HipNet):
             prefix = Act(buf.slice(off0, wl))
             prefix.g = gbuf.slice(off0, wl) if gbuf is not None else None
             ms = _merge(segs)
-            a = bn_act(tape, prefix, layer.norm, nv.ACT_RELU, tag=tag + '.norm', segs=ms if len(ms) > 1 else None)
+            a = bn_act(tape, prefix, layer.norm, nv.ACT_RELU, tag=tag + '.norm', segs=ms if len(ms) > 1 else None,
+                       stats_src=src(off0))
             drop = tape.dropout_table(tape.site(tag + '.drop'), buf.N, gp, layer.drop.p)
             out = conv_unit(tape, a, layer.conv.weight, layer.conv.bias, ms, act=nv.ACT_NONE, dropmul=drop,
-                            out=buf.slice(off0 + wl, gp), tag=tag + '.conv')
+                            out=buf.slice(off0 + wl, gp), tag=tag + '.conv', out_stats=src(off0 + wl))
             out.g = gbuf.slice(off0 + wl, gp) if gbuf is not None else None
 
     def _build(self, tape, x, dlogits):
@@ -176,6 +190,18 @@ class FCDenseNet(HipNet):
             if gb is not None:
                 tape.rt.clear_view(gb)
             gbufs.append(gb)
+        # ---- statistics tables of the concat buffers (stage buffers 0 .. nd-1, then the bottleneck buffer), cleared once per
+        # step by Tape.begin()
+        nb = self.bottleneck_layers
+        bott_w = cp.pad8(cin[nd]) + gp * nb
+        tbls = [None] * (nd + 1)
+        if self.cache_prefix_stats and tape.fuses_finalize():
+            widths = [_width(sg) for sg in stage_segs] + [bott_w]
+            for k, wd in enumerate(widths):
+                tbls[k] = (tape.step_zeroed('prefix_stats%d' % k, (STAT_REPLICAS, 2, wd), torch.float64), 0, wd)
+
+        def src(k, ch):
+            return None if tbls[k] is None else (tbls[k][0], tbls[k][1] + ch, tbls[k][2])
         # ---- encoder: block d lives in the skip slice of its decoder stage buffer
         inp, inp_seg = x, [(self._in_channels, x.v.Cp)]
         first = True
@@ -185,36 +211,36 @@ class FCDenseNet(HipNet):
             cur, curp = cin[d], cp.pad8(cin[d])
             if first:
                 o = conv_unit(tape, inp, self.firstconv.weight, self.firstconv.bias, inp_seg, act=nv.ACT_NONE,
-                              out=U.slice(off0, curp), tag='firstconv')
+                              out=U.slice(off0, curp), tag='firstconv', out_stats=src(i, off0))
                 first = False
             else:
-                o = pooled_writer(U.slice(off0, curp))
+                o = pooled_writer(U.slice(off0, curp), src(i, off0))
             o.g = G.slice(off0, curp) if G is not None else None
-            self._dense_layers(tape, self.denseBlocksDown[d].layers, U, G, off0, block_segs[d][:1], 'down%d' % d)
+            self._dense_layers(tape, self.denseBlocksDown[d].layers, U, G, off0, block_segs[d][:1], 'down%d' % d, tbls[i])
             cur = cin[d + 1]
             wb = _width(block_segs[d])
             full = Act(U.slice(off0, wb))
             full.g = G.slice(off0, wb) if G is not None else None
             td = self.transDownBlocks[d]
             ms = _merge(block_segs[d])
-            a = bn_act(tape, full, td.norm, nv.ACT_RELU, tag='td%d.norm' % d, segs=ms if len(ms) > 1 else None)
+            a = bn_act(tape, full, td.norm, nv.ACT_RELU, tag='td%d.norm' % d, segs=ms if len(ms) > 1 else None,
+                       stats_src=src(i, off0))
             drop = tape.dropout_table(tape.site('td%d.drop' % d), N, cp.pad8(cur), td.drop.p)
             # conv1x1 -> dropout -> maxpool: the pooled tensor is the next block's input slice; a closure defers
             # the conv so that it can write its pooled output straight into the next buffer
-            def pooled_writer(dst, a=a, td=td, ms=ms, drop=drop, d=d):
+            def pooled_writer(dst, st, a=a, td=td, ms=ms, drop=drop, d=d):
                 _, p = conv_unit(tape, a, td.conv.weight, td.conv.bias, ms, stride=1, pad=0,
-                                 act=nv.ACT_NONE, dropmul=drop, pool=True, pool_out=dst, tag='td%d.conv' % d)
+                                 act=nv.ACT_NONE, dropmul=drop, pool=True, pool_out=dst, tag='td%d.conv' % d, out_stats=st)
                 return p
         # ---- bottleneck (its own buffer: pooled input + new layers; only the new layers go on)
-        nb = self.bottleneck_layers
         cur, curp = cin[nd], cp.pad8(cin[nd])
         B = tape.view('B', N, sizes[nd][0], sizes[nd][1], curp + gp * nb)
         GB = tape.view('GB', N, sizes[nd][0], sizes[nd][1], curp + gp * nb) if need else None
         if GB is not None:
             tape.rt.clear_view(GB)
-        o = pooled_writer(B.slice(0, curp))
+        o = pooled_writer(B.slice(0, curp), src(nd, 0))
         o.g = GB.slice(0, curp) if GB is not None else None
-        self._dense_layers(tape, self.bottleneck.bottleneck.layers, B, GB, 0, [(cur, curp)], 'bottleneck')
+        self._dense_layers(tape, self.bottleneck.bottleneck.layers, B, GB, 0, [(cur, curp)], 'bottleneck', tbls[nd])
         new, new_segs = Act(B.slice(curp, gp * nb)), [(g, gp)] * nb
         new.g = GB.slice(curp, gp * nb) if GB is not None else None
         # ---- decoder
@@ -224,10 +250,10 @@ class FCDenseNet(HipNet):
             tu = self.transUpBlocks[i].convTrans
             cpv = cp.pad8(prevs[i])
             o = conv_unit(tape, new, tu.weight, tu.bias, _merge(new_segs), stride=2, pad=0, transposed=True, act=nv.ACT_NONE,
-                          out=U.slice(0, cpv), out_hw=(U.H, U.W), tag='tu%d' % i)
+                          out=U.slice(0, cpv), out_hw=(U.H, U.W), tag='tu%d' % i, out_stats=src(i, 0))
             o.g = G.slice(0, cpv) if G is not None else None
             in_segs = [(prevs[i], cpv)] + block_segs[d]
-            self._dense_layers(tape, self.denseBlocksUp[i].layers, U, G, 0, in_segs, 'up%d' % i)
+            self._dense_layers(tape, self.denseBlocksUp[i].layers, U, G, 0, in_segs, 'up%d' % i, tbls[i])
             m = self.up_blocks[i]
             if i + 1 < nd:
                 new, new_segs = Act(U.slice(_width(in_segs), gp * m)), [(g, gp)] * m

@@ -14,6 +14,7 @@ routing, batched pack/unpack).
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -53,6 +54,8 @@ class Tape(object):
         self._pack_table = None
         self._unpack_tables = {}
         self._unpack_pending = []
+        self._bias_pending, self._bias_tables = [], {}
+        self._zero_each_step = {}      # key -> tensor cleared by begin() (statistics tables several layers read: nobody's backward owns them)
         self._cuts = {}
         self._drop_sites, self._drop_pools = {}, {}
         self.plans = {}            # recorded launch lists (HipNet._run / _run_backward)
@@ -87,7 +90,10 @@ class Tape(object):
                 t.zero_()
             self.stats_pending = False
         self.train, self.need_grad = train, need_grad
+        for t in self._zero_each_step.values():
+            t.zero_()
         self.back, self._seq = [], 0
+        self._bias_pending = []
         self.fused_stats = []
         for p, pool in self._drop_pools.items():
             pool['drawn'] = pool['used'] if train else 0
@@ -129,6 +135,14 @@ class Tape(object):
 
     def small(self, key, shape, dtype):
         return self.cached((key, tuple(shape)), lambda: self.rt.zeros(shape, dtype))
+
+    def step_zeroed(self, key, shape, dtype):
+        """A small buffer that is zero at the start of every step (cleared in begin(), outside any recorded list)."""
+        k = (key, tuple(shape))
+        t = self._zero_each_step.get(k)
+        if t is None:
+            t = self._zero_each_step[k] = self.rt.zeros(shape, dtype)
+        return t
 
     def record(self, fn):
         if self.need_grad:
@@ -235,8 +249,37 @@ class Tape(object):
         self.stats_pending = False
         self.rt.join_side()               # the weight gradients ran on the side stream
 
+    # SEGNB_NET_BATCH_BIAS=0: one segnb_bn_bwd_finalize launch per bias gradient (A/B)
+    batch_bias = os.environ.get('SEGNB_NET_BATCH_BIAS', '1') != '0'
+
+    def defer_bias_grad(self, sums, C, Cp, gb, count, coef_buf, bcoef):
+        """The bias gradient of a convolution without BatchNorm (sum of dz, accumulated in `sums` by the reduction pass): joined to
+        the ONE segnb_bias_grad_multi launch that goes with the next batched unpack (nothing reads a bias gradient earlier)."""
+        if not self.batch_bias:
+            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, None, nv.ptr(coef_buf), nv.ptr(bcoef), None, nv.ptr(gb), 1,
+                    self.rt.stream)
+            return
+        self._bias_pending.append((sums, C, Cp, gb))
+
+    def _run_bias_grads(self, group):
+        if not self._bias_pending:
+            return
+        key = tuple((s.data_ptr(), 0 if g is None else g.data_ptr()) for s, _, _, g in self._bias_pending)
+        t = self._bias_tables.get(group)
+        if t is None or t[0] != key:
+            dt = np.dtype([('sums', '<u8'), ('gb', '<u8'), ('C', '<i4'), ('Cp', '<i4')])
+            assert dt.itemsize == nv.query('segnb_bias_grad_job_bytes'), 'BiasGradJob layout drifted from the ABI'
+            rows = np.zeros(len(self._bias_pending), dtype=dt)
+            for i, (sm, C, Cp, gb) in enumerate(self._bias_pending):
+                rows[i] = (sm.data_ptr(), 0 if gb is None else gb.data_ptr(), C, Cp)
+            tab = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy()).to(self.rt.device)
+            t = self._bias_tables[group] = (key, tab, len(rows), list(self._bias_pending))
+        nv.call('segnb_bias_grad_multi', nv.ptr(t[1]), t[2], self.rt.stream)
+        self._bias_pending = []
+
     def run_unpack(self, group='end'):
         """Batched unpack of the weight gradients launched since the last one (group: which cut of the backward this is)."""
+        self._run_bias_grads(group)
         if self._unpack_pending:
             key = (tuple((id(c), h, w) for c, h, w, _ in self._unpack_pending), self.flat.flat_g.data_ptr())
             t = self._unpack_tables.get(group)
@@ -303,11 +346,21 @@ def _data_gradient(tape, conv, x, dy, site):
     tape.contribute(x, dx)
 
 
+def _sum_into(tape, v, out_stats):
+    """statistics of View v into the channel range out_stats = (table, element offset, row stride) (segnb_bn_stats_ld)"""
+    table, off, ld = out_stats
+    nv.call('segnb_bn_stats_ld', tape.rt.code, v.ptr, v.ld, v.N, v.H, v.W, v.Cp, nv.ptr(table, off), ld, tape.rt.stream)
+
+
 def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=False, bn=None, act=nv.ACT_RELU,
-              slope=0.01, dropmul=None, out=None, pool=False, pool_out=None, res=None, out_hw=None, tag='conv'):
+              slope=0.01, dropmul=None, out=None, pool=False, pool_out=None, res=None, out_hw=None, tag='conv',
+              out_stats=None):
     """conv / conv-transpose -> [BatchNorm] -> (+res) -> activation -> [Dropout2d multipliers] [-> MaxPool2d(2)].
 
     out: optional View to write the activated output into (a slice of a concat buffer).
+    out_stats: (fp64 table, element offset, row stride) -- the per-channel statistics of the FINAL output (the pooled one when
+    pool is set) are accumulated into that channel range (the slice's share of its concat buffer's statistics table: bn_act's
+    stats_src), by the pass that writes it where there is one.
     Returns Act, or (Act, pooled Act) when pool is set."""
     rt = tape.rt
     site = tape.site(tag)
@@ -360,6 +413,8 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             coef = coef_buf
         ov = ov_direct if ov_direct is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
         conv.fprop(xv, ov, None, epilogue=(coef, act, slope))
+        if out_stats is not None:
+            _sum_into(tape, ov, out_stats)
         oa = Act(ov)
 
         def backward_fused():
@@ -373,8 +428,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
                     oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
-            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, float(N * Ho * Wo), None, nv.ptr(coef_buf), nv.ptr(bcoef),
-                    None, nv.ptr(gb), 1, rt.stream)
+            tape.defer_bias_grad(sums, C, Cp, gb, float(N * Ho * Wo), coef_buf, bcoef)
             side = rt.fork_side()
             if side is not None:
                 with torch.cuda.stream(side):
@@ -411,9 +465,17 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                     nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
                     nv.ptr(coef_buf), rt.stream)
             coef = coef_buf
-        nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
-                ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
-                0 if res is None else res.v.ld, rt.stream)
+        if out_stats is not None and pv is None and res is None:
+            # the pass that writes the slice also sums it
+            nv.call('segnb_bn_act_fwd_stats', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+                    ov.ptr, ov.ld, nv.ptr(out_stats[0], out_stats[1]), out_stats[2], rt.stream)
+            out_stats = None
+        else:
+            nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+                    ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
+                    0 if res is None else res.v.ld, rt.stream)
+    if out_stats is not None:
+        _sum_into(tape, pv if pool else ov, out_stats)
     oa = Act(ov)
     pa = Act(pv) if pool else None
     if fused_bn and not pool and res is None and dropmul is None and tape.need_grad:
@@ -467,8 +529,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             dgamma_done()
         else:
             gb = flat.grad_of(bias) if bias is not None else None
-            nv.call('segnb_bn_bwd_finalize', nv.ptr(sums), C, Cp, count, None, nv.ptr(coef_buf), nv.ptr(bcoef),
-                    None, nv.ptr(gb), 1, rt.stream)
+            tape.defer_bias_grad(sums, C, Cp, gb, count, coef_buf, bcoef)
         if res is not None:
             tape.contribute(res, dz)
         # the weight gradient (and its unpack) only READ x and dy, and nothing reads dW before the end of backward: side
@@ -488,9 +549,11 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     return (oa, pa) if pool else oa
 
 
-def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
+def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None, stats_src=None):
     """bn_act over ONE contiguous run of real channels (+ its padding); fields: (gamma, beta, running_mean, running_var,
-    num_batches_tracked or None, eps, momentum); grads_of() -> (dgamma, dbeta) fp32 views of the flat gradient buffer."""
+    num_batches_tracked or None, eps, momentum); grads_of() -> (dgamma, dbeta) fp32 views of the flat gradient buffer.
+    stats_src: (table, element offset, row stride) -- the batch statistics of x are ALREADY in that channel range of its concat
+    buffer's table (summed slice by slice as the slices were written: conv_unit's out_stats): no pass over x for them."""
     rt, xv = tape.rt, x.v
     site = tape.site(tag)
     tape.consume(x)
@@ -499,11 +562,17 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
     C = gamma.numel()
     stats = tape.small(site + '/stats', (STAT_REPLICAS, 2, Cp), torch.float64)
     coef = tape.small(site + '/coef', (4, Cp), torch.float32)
-    if tape.train:
+    fused = tape.fuses_finalize()
+    cached = stats_src is not None and fused
+    if tape.train and not cached:
         nv.call('segnb_bn_stats', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
     ov = out if out is not None else tape.view(site + '/a', N, H, W, Cp)
-    fused = tape.fuses_finalize()
-    if fused:
+    if cached:
+        sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+        nv.call('segnb_bn_fwd_fused_ld', rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(stats_src[0], stats_src[1]), stats_src[2],
+                nv.ptr(gamma.detach()), nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef),
+                nv.ptr(sums_f), act, slope, None, ov.ptr, ov.ld, rt.stream)
+    elif fused:
         sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         nv.call('segnb_bn_fwd_fused', rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(stats), nv.ptr(gamma.detach()),
                 nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums_f), act,
@@ -518,7 +587,7 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
 
     def backward():
         if oa.g is None:
-            if fused:
+            if fused and not cached:
                 stats.zero_()
                 tape.unplannable = True
             return
@@ -533,7 +602,7 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
             nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
                     oa.g.ptr, oa.g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
             fargs = (rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()),
-                     nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), 1, nv.ptr(stats),
+                     nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), 1, None if cached else nv.ptr(stats),
                      act, slope, oa.g.ptr, oa.g.ld)
             if x.needs_grad and x.g is not None:
                 nv.call('segnb_bn_bwd_apply_fused_direct_acc', *(fargs + (x.g.ptr, x.g.ld, rt.stream)))
@@ -555,7 +624,7 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None):
     return oa
 
 
-def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None):
+def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None, stats_src=None):
     """PRE-activation BatchNorm + activation of an arbitrary tensor (tiramisu.py:12-13, 50-51).
 
     segs: [(real, padded), ...] when the tensor is a concat of padded slices whose real channels are the BatchNorm's
@@ -564,7 +633,8 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None):
     advanced by the first slice only."""
     if segs is None or len(segs) == 1:
         flat = tape.flat
-        return _bn_act_core(tape, x, _bn_fields(bn), lambda: (flat.grad_of(bn.weight), flat.grad_of(bn.bias)), act, slope, tag)
+        return _bn_act_core(tape, x, _bn_fields(bn), lambda: (flat.grad_of(bn.weight), flat.grad_of(bn.bias)), act, slope, tag,
+                            stats_src=stats_src)
     gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
     xv = x.v
     assert sum(p for _, p in segs) == xv.Cp and sum(r for r, _ in segs) == gamma.numel(), (segs, xv.Cp, gamma.numel())
@@ -580,7 +650,8 @@ def bn_act(tape, x, bn, act=nv.ACT_RELU, slope=0.01, tag='bnact', segs=None):
         def grads_of(sl=sl):
             flat = tape.flat
             return flat.grad_of(bn.weight)[sl], flat.grad_of(bn.bias)[sl]
-        part = _bn_act_core(tape, xs, fields, grads_of, act, slope, '%s.s%d' % (tag, k), out=ov.slice(poff, padded))
+        part = _bn_act_core(tape, xs, fields, grads_of, act, slope, '%s.s%d' % (tag, k), out=ov.slice(poff, padded),
+                            stats_src=None if stats_src is None else (stats_src[0], stats_src[1] + poff, stats_src[2]))
         parts.append((part, poff, padded))
         roff += real
         poff += padded

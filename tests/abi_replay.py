@@ -90,7 +90,8 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
 
 # (argument position -> entry points) whose fp64 argument is a [REPL][2][Cp] replicated accumulator: the emulator
 # fills replica 0, the HIP kernels spread blocks over all 16; only the sum over replicas is defined by the ABI
-_REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats'), 19: ('segnb_bn_act_bwd_reduce',), 17: ('segnb_head_bn_bwd',), 0: ()}
+_REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats', 'segnb_bn_stats_ld'), 19: ('segnb_bn_act_bwd_reduce',),
+               17: ('segnb_head_bn_bwd',), 13: ('segnb_bn_act_fwd_stats',), 0: ()}
 
 
 def run_step(model, x, y, loss_fn, device, dtype):
@@ -109,7 +110,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
            flip_ops=('segnb_bn_act_fwd', 'segnb_bn_act_bwd_reduce', 'segnb_bn_bwd_apply', 'segnb_bn_bwd_apply_direct',
                      'segnb_bn_bwd_finalize',
                      'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused', 'segnb_bn_bwd_apply_fused_direct',
-                     'segnb_bn_fwd_fused_head', 'segnb_head_bn_bwd')):
+                     'segnb_bn_fwd_fused_head', 'segnb_head_bn_bwd', 'segnb_bn_fwd_fused_ld', 'segnb_bn_act_fwd_stats')):
     """Returns (number of calls, list of failure strings).  device='cpu' replays the emulator against itself (a
     self-test of this harness that runs without a GPU)."""
     rec = _Recorder()

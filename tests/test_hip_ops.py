@@ -1746,3 +1746,64 @@ def test_last_layer_and_classifier_in_one_pass(shape, dtype):
     torch.testing.assert_close(f['dw'], u['dw'], rtol=1e-4, atol=1e-4 * float(u['dw'].abs().max()))
     torch.testing.assert_close(f['db'], u['db'], rtol=1e-4, atol=1e-4 * float(u['db'].abs().max()))
     torch.testing.assert_close(f['sums'], u['sums'], rtol=1e-6, atol=1e-6 * float(u['sums'].abs().max()))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_prefix_statistics_table(dtype):
+    """tiramisu.py:9-44: a DenseLayer's BatchNorm covers the whole concat prefix.  The statistics of the prefix are those of its
+    slices: segnb_bn_act_fwd_stats sums the slice it writes into its range of the buffer's table, segnb_bn_stats_ld sums a slice
+    somebody else wrote, segnb_bn_fwd_fused_ld reads a prefix range -- together == segnb_bn_stats over the prefix +
+    segnb_bn_fwd_fused (coefficients to fp64 summation order, the activated tensor to the storage rounding)."""
+    rt = Runtime('cuda', dtype)
+    N, H, W = 2, 12, 10
+    widths = [24, 16, 16]                      # block input + two growth slices, all multiples of 8
+    Cb = sum(widths)
+    gen = torch.Generator().manual_seed(77)
+    buf = View.alloc(rt, N, H, W, Cb)
+    buf.t.zero_()
+    table = rt.zeros((16, 2, Cb), torch.float64)
+    off = 0
+    dm = torch.ones(N, 16, device='cuda')
+    dm[:, :] = ((torch.rand(N, 16, generator=gen) > 0.3).float() / 0.7).cuda()
+    for k, wd in enumerate(widths):
+        src = _view_from(rt, torch.randn(N, H, W, wd, generator=gen) * (1 + k) + 0.1 * k, wd)
+        sl = buf.slice(off, wd)
+        if k == 0:             # written by something else (a convolution epilogue): summed by a pass of its own
+            nv.call('segnb_add', rt.code, None, 0, src.ptr, src.ld, sl.ptr, sl.ld, N, H, W, wd, rt.stream)
+            nv.call('segnb_bn_stats_ld', rt.code, sl.ptr, sl.ld, N, H, W, wd, nv.ptr(table, off), Cb, rt.stream)
+        else:                  # written by the Dropout2d pass of the layer's convolution: that pass sums it
+            nv.call('segnb_bn_act_fwd_stats', rt.code, src.ptr, src.ld, N, H, W, wd, None, nv.ACT_NONE, 0.0, nv.ptr(dm),
+                    sl.ptr, sl.ld, nv.ptr(table, off), Cb, rt.stream)
+        off += wd
+    # a layer over the first two slices (prefix of 40 channels), one over all three
+    for wl in (widths[0] + widths[1], Cb):
+        pre = buf.slice(0, wl)
+        gamma = (1 + 0.2 * torch.randn(wl, generator=gen)).cuda()
+        beta = (0.1 * torch.randn(wl, generator=gen)).cuda()
+        outs = []
+        for cached in (False, True):
+            coef = rt.zeros((4, wl), torch.float32)
+            sums = rt.zeros((16, 2, wl), torch.float64)
+            rm, rvv = torch.zeros(wl, device='cuda'), torch.ones(wl, device='cuda')
+            nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+            a = View.alloc(rt, N, H, W, wl)
+            if cached:
+                before = table.clone()
+                nv.call('segnb_bn_fwd_fused_ld', rt.code, pre.ptr, pre.ld, N, H, W, wl, wl, nv.ptr(table), Cb, nv.ptr(gamma),
+                        nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums), nv.ACT_RELU,
+                        0.0, None, a.ptr, a.ld, rt.stream)
+                torch.cuda.synchronize()
+                assert torch.equal(table, before)            # read-only: the next layer reads it again
+            else:
+                stats = rt.zeros((16, 2, wl), torch.float64)
+                nv.call('segnb_bn_stats', rt.code, pre.ptr, pre.ld, N, H, W, wl, nv.ptr(stats), rt.stream)
+                nv.call('segnb_bn_fwd_fused', rt.code, pre.ptr, pre.ld, N, H, W, wl, wl, nv.ptr(stats), nv.ptr(gamma),
+                        nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm), nv.ptr(rvv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums), nv.ACT_RELU,
+                        0.0, None, a.ptr, a.ld, None, 0, None, 0, None, 0, rt.stream)
+            torch.cuda.synchronize()
+            outs.append((coef.clone(), a.t.clone().float(), rm.clone(), rvv.clone()))
+        (c0, a0, m0, v0), (c1, a1, m1, v1) = outs
+        torch.testing.assert_close(c1, c0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(v1, v0, rtol=1e-5, atol=1e-7)
+        check('activated prefix', a1, a0, dtype)

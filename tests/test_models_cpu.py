@@ -206,7 +206,7 @@ def test_replay_harness_self_consistent(golden_dir):
     _, _, x, y = mc.make_tiramisu(g)
     n, rep = abi_replay.replay(lambda: mc.make_tiramisu(g)[0], x, y, BCEWithLogitsLossAndSmoothJaccard(), 'f32',
                                device='cpu')
-    assert n > 200 and not rep, rep[:5]
+    assert n > 150 and not rep, rep[:5]          # (185 ABI calls: the bias gradients are one batched launch)
 
 
 def test_frozen_parameters_keep_grad_none():
