@@ -144,6 +144,12 @@ int segnb_pack_job_bytes(void);
 int segnb_pack_job_blocks(int Mp, int Cp, int ntaps, long long s_m, long long s_c);
 int segnb_pack_weight_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
+/* the same job table for the jobs segnb_pack_job_blocks refuses (parameter tensors with more than 3 x 3 positions: the 7 x 7 stem
+ * of linknet.py:13-20 / dilated_resnet.py, the 4 x 4 ConvTranspose2d of unet16.py:40-47): element-wise kernels,
+ * segnb_pack_elem_job_blocks(Mp, Cp, ntaps) blocks per job; unpack ADDS to the gradient and clears the workspace */
+int segnb_pack_elem_job_blocks(int Mp, int Cp, int ntaps);
+int segnb_pack_weight_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
+int segnb_unpack_wgrad_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 
 /* NCHW fp32 network input -> NHWC `dtype`, channels zero-padded to Cp (torch_train.py:177 hands the
  * model a float32 [N,3,H,W] batch, lib/common.py:70). */

@@ -501,6 +501,28 @@ class AbiEmulator(object):
                                     int(j['mmap']), int(j['cmap']), 1, stream)
         return 0
 
+    # element-wise batched forms (jobs segnb_pack_job_blocks refuses): the single-job calls, job by job
+    def segnb_pack_elem_job_blocks(self, Mp, Cp, ntaps):
+        if Mp <= 0 or Cp <= 0 or ntaps < 1 or ntaps > 64:
+            return -1
+        return (Mp * ntaps * Cp + 1023) // 1024
+
+    def segnb_pack_weight_elem_multi(self, jobs, njobs, total_blocks, stream):
+        for j in self._jobs(jobs, njobs):
+            assert not int(j['masked'])
+            self.segnb_pack_weight(int(j['w']), int(j['packed']), int(j['dtype']), int(j['Mp']), int(j['Cp']),
+                                   int(j['ntaps']), int(j['s_m']), int(j['s_c']),
+                                   [int(v) for v in j['tap_off'][:int(j['ntaps'])]], int(j['mmap']), int(j['cmap']), stream)
+        return 0
+
+    def segnb_unpack_wgrad_elem_multi(self, jobs, njobs, total_blocks, stream):
+        for j in self._jobs(jobs, njobs):
+            assert not int(j['masked']) and int(j['nslab']) <= 1
+            self.segnb_unpack_wgrad(int(j['packed']), int(j['w']), int(j['Mp']), int(j['Cp']), int(j['ntaps']),
+                                    int(j['s_m']), int(j['s_c']), [int(v) for v in j['tap_off'][:int(j['ntaps'])]],
+                                    int(j['mmap']), int(j['cmap']), 1, stream)
+        return 0
+
     def segnb_pack_input_nchw(self, x, N, C, H, W, out, dtype, Cp, ld_out, stream):
         X = _mem(x, N * C * H * W, torch.float32).view(N, C, H, W)
         O = _nhwc(out, N, H, W, Cp, ld_out, _tdt(dtype))

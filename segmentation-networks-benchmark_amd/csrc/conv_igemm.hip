@@ -1111,6 +1111,38 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
     }
 }
 
+// Element-wise batched forms for the jobs the tiled kernel does not take (parameter tensors with more than 3 x 3 positions: the
+// 7 x 7 stem, the 4 x 4 transposed convolutions): the same job table, PACKW_ITEMS packed elements per thread, block -> job by
+// binary search.  One launch instead of one ctypes call + launch per job (LinkNet34: 21 of them at every step's start).
+constexpr int PACKW_ITEMS = 4;
+template <bool IS_PACK>
+__global__ __launch_bounds__(256) void pack_elem_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const PackJob& j = jobs[find_job(jobs, njobs, blockIdx.x)];
+    const long long total = (long long)j.Mp * j.ntaps * j.Cp;
+    const long long base = (long long)(blockIdx.x - j.block_start) * (256 * PACKW_ITEMS);
+    float* param = const_cast<float*>(j.w);
+#pragma unroll
+    for (int u = 0; u < PACKW_ITEMS; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= total) continue;
+        const int cp = (int)(i % j.Cp);
+        const long long q = i / j.Cp;
+        const int t = (int)(q % j.ntaps);
+        const int mp = (int)(q / j.ntaps);
+        const int m = j.mmap[mp], c = j.cmap[cp];
+        if (IS_PACK) {
+            float v = 0.f;
+            if (m >= 0 && c >= 0) v = param[m * j.s_m + c * j.s_c + j.tap_off[t]];
+            if (j.dtype == SEGNB_BF16) reinterpret_cast<bf16_t*>(j.packed)[i] = Elem<bf16_t>::from_f32(v);
+            else reinterpret_cast<float*>(j.packed)[i] = v;
+        } else {
+            float* dwp = reinterpret_cast<float*>(j.packed);
+            if (m >= 0 && c >= 0) param[m * j.s_m + c * j.s_c + j.tap_off[t]] += dwp[i];
+            dwp[i] = 0.f;   // workspace is consumed: ready for the next step's atomics without a memset
+        }
+    }
+}
+
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W,
                                   int Cp, int ld) {
@@ -1735,6 +1767,29 @@ extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_b
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
     hipLaunchKernelGGL(pack_tiled_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs, total_blocks);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_pack_elem_job_blocks(int Mp, int Cp, int ntaps) {
+    if (Mp <= 0 || Cp <= 0 || ntaps < 1 || ntaps > SEGNB_MAX_TAPS) return -1;
+    return (int)(((long long)Mp * ntaps * Cp + 256 * PACKW_ITEMS - 1) / (256 * PACKW_ITEMS));
+}
+
+extern "C" int segnb_pack_weight_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_pack_weight_elem_multi, jobs, njobs, total_blocks, stream);
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
+    hipLaunchKernelGGL(pack_elem_multi_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_unpack_wgrad_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_unpack_wgrad_elem_multi, jobs, njobs, total_blocks, stream);
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
+    hipLaunchKernelGGL(pack_elem_multi_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob*)jobs, njobs);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

@@ -906,14 +906,32 @@ class PackTable(object):
     model packed (or every gradient unpacked) by ONE launch.  jobs: dicts with the fields of PACK_JOB_DTYPE
     (tensors for the pointer fields)."""
 
+    # SEGNB_PACK_ELEM_MULTI=0: the jobs the tiled kernel refuses as one ctypes call + launch each (A/B)
+    elem_multi = os.environ.get('SEGNB_PACK_ELEM_MULTI', '1') != '0'
+
     def __init__(self, rt, jobs, entry, single_entry):
         assert PACK_JOB_DTYPE.itemsize == nv.query('segnb_pack_job_bytes'), 'PackJob layout drifted from the ABI'
         rows, self.singles, self._keep = [], [], []
+        erows, eblocks = [], 0               # element-wise batched table (parameter tensors wider than 3 x 3)
         blocks = 0
         for j in jobs:
             nb = nv.query('segnb_pack_job_blocks', j['Mp'], j['Cp'], j['ntaps'], j['s_m'], j['s_c'])
-            if nb < 0:                       # kernels wider than 3x3: per-job launch
-                self.singles.append(j)
+            if nb < 0:                       # kernels wider than 3x3: the element-wise kernels, still ONE launch for all of them
+                enb = nv.query('segnb_pack_elem_job_blocks', j['Mp'], j['Cp'], j['ntaps']) if self.elem_multi else -1
+                if enb < 0 or j.get('masked') or j.get('nslab', 1) > 1:
+                    self.singles.append(j)
+                    continue
+                row = np.zeros((), dtype=PACK_JOB_DTYPE)
+                for f in ('w', 'packed', 'mmap', 'cmap'):
+                    row[f] = j[f].data_ptr()
+                    self._keep.append(j[f])
+                for f in ('s_m', 's_c', 'Mp', 'Cp', 'ntaps', 'dtype'):
+                    row[f] = j[f]
+                row['nslab'] = 1
+                row['tap_off'][:len(j['tap_off'])] = j['tap_off']
+                row['block_start'] = eblocks
+                eblocks += enb
+                erows.append(row)
                 continue
             row = np.zeros((), dtype=PACK_JOB_DTYPE)
             for f in ('w', 'packed', 'mmap', 'cmap'):
@@ -932,10 +950,17 @@ class PackTable(object):
         if rows:
             tab = np.array(rows, dtype=PACK_JOB_DTYPE)
             self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
+        self.etable, self.en, self.eblocks = None, len(erows), eblocks
+        self.eentry = 'segnb_pack_weight_elem_multi' if entry == 'segnb_pack_weight_multi' else 'segnb_unpack_wgrad_elem_multi'
+        if erows:
+            tab = np.array(erows, dtype=PACK_JOB_DTYPE)
+            self.etable = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
 
     def run(self):
         if self.table is not None:
             nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
+        if self.etable is not None:
+            nv.call(self.eentry, nv.ptr(self.etable), self.en, self.eblocks, self.rt.stream)
         for j in self.singles:
             assert not j.get('masked'), 'masked jobs exist in the batched form only'
             tap = nv.int_array(j['tap_off'])
