@@ -263,9 +263,12 @@ class AbiEmulator(object):
 
     def segnb_conv_fprop_bnreduce_ok(self, g, dtype):
         g = _geom(g)
-        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and
-                   g.QW == g.Wo and g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and g.Wo >= 12 and
-                   not (g.Co > 32 and g.Ci > 32))
+        if not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
+                and g.Co % 8 == 0 and g.Wo >= 12):
+            return 0
+        if g.Ci % 64 == 0 and g.Ci >= 192 and g.Co > 32 and getattr(self, 'tuned', {}).get('ws_bnreduce', 0):      # the wide-layer variant
+            return 1
+        return int(g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and not (g.Co > 32 and g.Ci > 32))
 
     def segnb_conv_fprop_bnreduce(self, g, dtype, in_p, wp, out_p, ep, stream):
         gg, e = _geom(g), _geom(ep)

@@ -101,6 +101,7 @@ int segnb_knob_fprop_rw();
 // head backward's per-(device, stream) partial-sum scratch and its fixed-order finish launch (head_loss.hip)
 float* segnb_head_scratch(size_t bytes, hipStream_t stream);
 void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream);
+int segnb_knob_ws_bnreduce();    // conv_fprop_ws_kernel's BatchNorm-reduce variant (segnb_tune "ws_bnreduce")
 int segnb_knob_pack_blocks();    // persistent blocks of segnb_pack_weight_multi (0: one block per tile)
 int segnb_knob_fprop_roll();     // 0: off, 1: conv_roll_kernel with 16-column strips, 2: 32-column strips (segnb_tune "fprop_roll")
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients
@@ -112,7 +113,8 @@ int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpa
 // direct-to-LDS pipeline for Ci % 64 == 0 (fprop_dma.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,
-                        hipStream_t stream, const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr);
+                        hipStream_t stream, const segnb_act_epilogue* ep = nullptr, const segnb_upcat_src* uc = nullptr,
+                        const segnb_bn_reduce_epilogue* bn = nullptr);
 // resident-weights pipeline for the thin layers, Ci <= 96 and Co <= 96 (fprop_rw.hip)
 int segnb_fprop_rw_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                        unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,

@@ -1517,9 +1517,18 @@ extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype)
     if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g)) return 0;
     if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || !segnb_knob_bnreduce_fused()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
-    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 64 || g->Co % 8 != 0 || g->Wo < 12) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Co % 8 != 0 || g->Wo < 12) return 0;
     for (int t = 0; t < 9; ++t)
         if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
+    // wide layers: conv_fprop_ws_kernel's BatchNorm-reduce variant (the halo waves take the sums): >= 3 K chunks of 64 channels,
+    // 64-channel output tiles, the 16x16x32 form with row-major taps (segnb_tune "ws_bnreduce" / SEGNB_WS_BNREDUCE)
+    if (g->Ci % 64 == 0 && g->Ci >= 192 && g->Co > 32 && segnb_knob_ws_bnreduce() && segnb_knob_fprop_mf16() &&
+        segnb_knob_fprop_dma_cfg() < 2) {
+        bool row_major = true;
+        for (int t = 0; t < 9; ++t) row_major = row_major && g->dw[t] == g->dw[t % 3] && g->dh[t] == g->dh[3 * (t / 3)];
+        if (row_major) return 1;
+    }
+    if (g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 64) return 0;
     if (g->Co > 32 && g->Ci > 32) return 0;      // (the 64-wide tile keeps one 32-channel chunk of weights resident)
     return 1;
 }
@@ -1534,9 +1543,15 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
     const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
     SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
-    int rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
-    if (rc == 0)
-        rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+    int rc = 0;
+    if (g->Ci <= 96) {
+        rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+        if (rc == 0)
+            rc = segnb_fprop_rw_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+    } else {
+        rc = segnb_fprop_dma_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, nullptr,
+                                 nullptr, ep);
+    }
     if (rc != 1) {
         segnb_set_error("segnb_conv_fprop_bnreduce: the fused kernel refused the launch (%d)", rc);
         return rc > 1 ? rc : SEGNB_E_BADARG;

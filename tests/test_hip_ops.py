@@ -1202,15 +1202,21 @@ def test_upcat_segmented_backward_vs_torch(shape):
         assert torch.equal(dcat_s.dense()[..., Cup:], dfull.dense()[..., Cup:])
 
 
-@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],
+@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1),
+                                   # wide layers: conv_fprop_ws_kernel's variant (the halo waves take the sums; >= 3 K chunks)
+                                   (2, 28, 28, 128, 192, 1), (3, 20, 36, 64, 256, 2), (2, 14, 14, 256, 192, 1), (8, 56, 56, 128, 320, 1),
+                                   (32, 28, 28, 256, 256, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
-def test_conv_dgrad_with_fused_bn_reduce(shape):
+def test_conv_dgrad_with_fused_bn_reduce(shape, request):
     """segnb_conv_fprop_bnreduce: the data-gradient launch whose epilogue does the BatchNorm-backward reduction of the
     layer that produced its input (the edz_eydz phase of lib/modules/abn/functions.py:112 folded into
     the producer of dz).  dx is bit-identical to the plain data gradient; the sums equal segnb_bn_act_bwd_reduce on that
     dx (same per-element arithmetic, another summation order) and the emulator's."""
     N, H, W, C1, C2, act = shape           # layer 1: ? -> C1 (BatchNorm, act);  layer 2: C1 -> C2
     rt = Runtime('cuda', 'bf16')
+    if C2 >= 192:                          # the wide-layer variant is an option (measured slower in the step: off by default)
+        nv.call('segnb_tune', b'ws_bnreduce', 1)
+        request.addfinalizer(lambda: nv.call('segnb_tune', b'ws_bnreduce', 0))
     gen = torch.Generator().manual_seed(H * 7 + C2)
     w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
     op = ConvOp(rt, w2, None, [(C1, C1)], 1, 1, False, True)
@@ -1234,7 +1240,7 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
     sums_f2 = rt.zeros((16, 2, C1), torch.float64)
     op.dgrad(dyv, dx_f, bn_reduce=(y1, coef, sums_f2, act, 0.01))
     torch.cuda.synchronize()
-    if C2 == 32:
+    if C2 == 32 or C2 >= 192:
         assert torch.equal(dx_f.t, dx_plain.t)          # (the same kernel with and without the epilogue)
     else:
         # 64 -> 32: the plain data gradient runs on conv_roll_kernel with the K split over two waves, the fused one on
@@ -1242,7 +1248,7 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
         check('dx fused vs plain', dx_f.t, dx_plain.t, 'bf16')
     a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
     scale = np.abs(b).max(axis=1, keepdims=True) + 1e-30
-    tight = C2 == 32          # (sums_ref is taken on dx_plain: the same values bit for bit only when the kernels are the same)
+    tight = C2 == 32 or C2 >= 192    # (sums_ref is taken on dx_plain: the same values bit for bit only when the kernels are the same)
     assert np.abs(a - b).max() <= (2e-5 if tight else 2e-3) * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
     np.testing.assert_allclose(a / scale, b / scale, atol=1e-4 if tight else 3e-3)
     # fixed summation order inside a block, fp64 across blocks: run-to-run equal to fp64 rounding
