@@ -282,7 +282,13 @@ class _ZFUnetPlan(object):
                     uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
                 unpacks.append(PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
                 los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
-            if self.PACK_OVERLAP or os.environ.get('SEGNB_PACK_SPLIT', '0') != '0':
+            if self.PACK_DG_SIDE:
+                # the matrices of the DATA GRADIENTS are not needed before the backward: packed on the side stream (idle in the
+                # forward) beside the forward matrices' pack and the first levels; the backward joins before its first launch
+                alljobs = pj_early + pj
+                packs = (PackTable(self.rt, [j for j in alljobs if j.get('form') != 'd'], 'segnb_pack_weight_multi', 'segnb_pack_weight'),
+                         PackTable(self.rt, [j for j in alljobs if j.get('form') == 'd'], 'segnb_pack_weight_multi', 'segnb_pack_weight'))
+            elif self.PACK_OVERLAP or os.environ.get('SEGNB_PACK_SPLIT', '0') != '0':
                 packs = (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
                          PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'))
             else:                                    # everything on the main stream: ONE launch
@@ -328,7 +334,8 @@ class _ZFUnetPlan(object):
         # (first convolution 37 -> 100 us): what the side stream takes off the main one comes back as slower kernels on it.
         early, late = self._tables(H, W, N)[1]
         early.run()
-        side = self.rt.side_stream() if self.PACK_OVERLAP else None
+        side = self.rt.side_stream() if (self.PACK_OVERLAP or self.PACK_DG_SIDE) else None
+        self._dg_pack_on_side = bool(self.PACK_DG_SIDE and side is not None)
         if side is not None:
             nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
             with torch.cuda.stream(side):
@@ -339,9 +346,11 @@ class _ZFUnetPlan(object):
 
     PACK_EARLY = 8
     PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
+    PACK_DG_SIDE = os.environ.get('SEGNB_PACK_DG_SIDE', '0') != '0'
+    _dg_pack_on_side = False
 
     def _join_late_pack(self):
-        side = self.rt.side_stream() if self.PACK_OVERLAP else None
+        side = self.rt.side_stream() if (self.PACK_OVERLAP and not self.PACK_DG_SIDE) else None
         if side is not None:
             nv.call('segnb_stream_join', self.rt.stream, side.cuda_stream)
 
@@ -631,6 +640,9 @@ class _ZFUnetPlan(object):
         try:
             if self.BWD_CONV_CU_PCT != 100:
                 nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
+            if self.PACK_DG_SIDE and rt.side_stream() is not None:
+                # the data gradients' matrices were packed on the side stream (recorded: a replayed list waits too)
+                nv.call('segnb_stream_join', rt.stream, rt.side_stream().cuda_stream)
             head = self.module.conv_final
             hf = bool(getattr(self, '_last_head_fused', False))
             if hf:

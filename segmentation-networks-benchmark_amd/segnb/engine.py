@@ -352,12 +352,12 @@ class ConvOp(object):
         jobs = []
         for li, l in enumerate(p['fwd'] if self.pack_fwd else ()):
             jobs.append(dict(w=w, packed=p['wp_fwd'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
-                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code,
+                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code, form='f',
                              tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         if self.need_dgrad:
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=w, packed=p['wp_dg'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
-                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code,
+                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code, form='d',
                                  tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         return jobs
 
@@ -655,12 +655,12 @@ class UpConvOp(ConvOp):
         for li, l in enumerate(p['fwd'] if self.pack_fwd else ()):
             # ConvOp's transposed naming: the forward matrix is [Co][taps][Ci]
             jobs.append(dict(w=w, packed=p['wp_fwd'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
-                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code, masked=True,
+                             s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=rt.code, masked=True, form='f',
                              tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]))
         if self.need_dgrad:
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=w, packed=p['wp_dg'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
-                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code, masked=True,
+                                 s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=rt.code, masked=True, form='d',
                                  tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]))
         return jobs
 
