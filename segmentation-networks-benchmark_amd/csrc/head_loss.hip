@@ -50,6 +50,53 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, 
     }
 }
 
+// head forward for WIDE activations (C > 64: the FCDenseNet head reads 256 channels, tiramisu.py:162-164): with one thread per pixel a
+// load instruction of a wave touched 64 different 512-byte pixels (1.1 TB/s); here CT consecutive lanes hold the 8-channel chunks
+// of ONE pixel (a wave reads whole pixels, contiguous), each lane walks the chunks tx, tx + CT, ... and the lanes' partial dot
+// products meet in a shuffle tree.  KM = compile-time bound of the class count.
+template <typename T, int KM>
+__global__ __launch_bounds__(256) void head_fwd_wide_kernel(const T* __restrict__ a, int ld_a, long long npix, long long hw, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ bias, int K,
+                                                            float* __restrict__ logits, int CT) {
+    extern __shared__ float sww[];  // [K][C8] (zero-padded)
+    const int PY = 256 / CT;
+    const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const int CPP = (C + 7) >> 3, C8 = CPP * 8;
+    for (int i = threadIdx.x; i < K * C8; i += blockDim.x) {
+        const int k = i / C8, c = i - k * C8;
+        sww[i] = c < C ? w[k * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (long long pix = (long long)blockIdx.x * PY + ty; pix < npix; pix += (long long)gridDim.x * PY) {
+        float acc[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) acc[k] = 0.f;
+        for (int cc = tx; cc < CPP; cc += CT) {
+            float v[8];
+            load8(a + pix * ld_a + cc * 8, v);
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(sww + k * C8 + cc * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(sww + k * C8 + cc * 8 + 4);
+                    acc[k] = fmaf(v[0], w0.x, acc[k]); acc[k] = fmaf(v[1], w0.y, acc[k]);
+                    acc[k] = fmaf(v[2], w0.z, acc[k]); acc[k] = fmaf(v[3], w0.w, acc[k]);
+                    acc[k] = fmaf(v[4], w1.x, acc[k]); acc[k] = fmaf(v[5], w1.y, acc[k]);
+                    acc[k] = fmaf(v[6], w1.z, acc[k]); acc[k] = fmaf(v[7], w1.w, acc[k]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            for (int off = 1; off < CT; off <<= 1) acc[k] += __shfl_xor(acc[k], off);
+        if (tx == 0) {
+            const long long n = pix / hw, r = pix - n * hw;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) logits[(n * K + k) * hw + r] = acc[k] + (bias != nullptr ? bias[k] : 0.f);
+        }
+    }
+}
+
 // head backward: da[pix][c] = sum_k dl[pix][k] w[k][c]; dw[k][c] += sum_pix dl[pix][k] a[pix][c]; db[k] += sum dl
 // thread (tx = 8-channel chunk, ty = pixel lane), same mapping as the norm/act kernels.
 // KM = compile-time bound of the class count: 1 for binary heads (the per-class register arrays sized for MAXK = 8
@@ -422,6 +469,29 @@ extern "C" int segnb_head_fwd(int dtype, const void* a, int ld_a, int N, int H, 
     SEGNB_CHECK_ARG(K >= 1 && K <= MAXK, "head supports 1..8 classes");
     SEGNB_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && ld_a % 8 == 0 && ld_a >= ((C + 7) & ~7), "bad shape");
     const long long npix = (long long)N * H * W;
+    if (C > 64) {
+        // wide activations: chunk-per-lane walk (whole pixels per wave)
+        const int cpp = (C + 7) / 8;
+        int ct = 1;
+        while (ct < cpp && ct < 32) ct <<= 1;
+        const int py = 256 / ct;
+        long long gx = (npix + py - 1) / py;
+        if (gx > 4096) gx = 4096;
+        const size_t wsm = (size_t)K * cpp * 8 * sizeof(float);
+        SEGNB_CHECK_ARG(wsm <= 48 * 1024, "head: K * C too large");
+        if (dtype == SEGNB_BF16)
+            (K == 1 ? head_fwd_wide_kernel<bf16_t, 1> : head_fwd_wide_kernel<bf16_t, MAXK>)<<<dim3((unsigned)gx), dim3(256), wsm, (hipStream_t)stream>>>(
+                (const bf16_t*)a, ld_a, npix, (long long)H * W, C, w, bias, K, logits, ct);
+        else if (dtype == SEGNB_F32)
+            (K == 1 ? head_fwd_wide_kernel<float, 1> : head_fwd_wide_kernel<float, MAXK>)<<<dim3((unsigned)gx), dim3(256), wsm, (hipStream_t)stream>>>(
+                (const float*)a, ld_a, npix, (long long)H * W, C, w, bias, K, logits, ct);
+        else {
+            segnb_set_error("segnb_head_fwd: unknown dtype %d", dtype);
+            return SEGNB_E_BADARG;
+        }
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
     int grid = ceil_div(npix, 256);
     if (grid > 4096) grid = 4096;
     const int smem = K * ((C + 7) & ~7) * 4;

@@ -486,7 +486,8 @@ def test_bn_fused_finalize_equals_separate_launches(case, dtype):
 # head, losses, SGD, input packing
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 16, 16, 32, 1), (1, 9, 13, 20, 3), (2, 8, 8, 48, 2)])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32, 1), (1, 9, 13, 20, 3), (2, 8, 8, 48, 2),
+                                   (2, 12, 20, 256, 1), (1, 7, 9, 272, 5), (2, 6, 10, 72, 2)])     # > 64 channels: the wide forward kernel
 def test_head_fwd_bwd(shape, dtype):
     N, H, W, C, K = shape
     Cp = cp.pad8(C)
