@@ -492,6 +492,8 @@ class _ZFUnetPlan(object):
             N, C, H, W = x.shape
         b = self.buffers(N, H, W)
         self._pack_if_needed(H, W, N)
+        if train and need_grad:
+            self.flat.prezero(rt)
         drop = self._dropout_tables(b, N, train)
         hf = self._head_fusable(train, need_grad)
         self._last_head_fused = hf

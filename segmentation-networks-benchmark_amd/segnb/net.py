@@ -864,6 +864,8 @@ class HipNet(nn.Module):
     def _run(self, x, need_grad):
         tape = self._tape
         tape.begin(self.training, need_grad)
+        if self.training and need_grad:
+            tape.flat.prezero(tape.rt)          # the coming backward's gradient-buffer clear, on the side stream beside the forward
         if x.dtype == torch.uint8:
             N, H, W, C = x.shape
         else:
