@@ -685,3 +685,54 @@ def test_consumer_side_batchnorm_matches_the_activation_pass():
             continue
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
         assert cos > 0.98, (n, cos)
+
+
+def test_gradient_buffer_cleared_beside_the_forward_and_classifier_fusion_are_invisible():
+    """Two host-side schedules that must not change a number (torch_train.py:180-190: zero_grad -> model -> loss -> backward):
+    FlatParams.prezero (the flat gradient buffer cleared on the side stream during the forward instead of at the start of
+    backward) and the fused last-layer / classifier launches (segnb_bn_fwd_fused_head, segnb_head_bn_bwd).  Three steps with
+    zero_grad() between them; and the accumulate-in-place mode (no zero_grad: every .grad aliases the buffer, which must NOT be
+    cleared -- lib/train_utils.py:54-65) on top."""
+    from lib.losses import BCEAndDiceLoss
+    from lib.models.zf_unet import ZF_UNET, _ZFUnetPlan as ZFUnetEngine
+    from segnb import engine
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 64, 96, generator=g).cuda()
+    y = (torch.rand(4, 1, 64, 96, generator=g) > 0.7).long().cuda()
+    keep = engine.FlatParams.prezero_grads, ZFUnetEngine.HEAD_FUSION
+    res = {}
+    try:
+        for mode in ((True, True), (False, True), (True, False)):
+            engine.FlatParams.prezero_grads, ZFUnetEngine.HEAD_FUSION = mode
+            torch.manual_seed(2)
+            m = ZF_UNET(dropout_val=0.0, filters=16).cuda().train()
+            out_g = []
+            for step in range(3):
+                m.zero_grad()
+                loss = BCEAndDiceLoss()(m(x), y)
+                (4 * loss).backward()
+                out_g.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+            # accumulation: no zero_grad -> gradients add up in place
+            loss = BCEAndDiceLoss()(m(x), y)
+            (4 * loss).backward()
+            torch.cuda.synchronize()
+            acc = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+            res[mode] = (out_g, acc, float(loss.detach()))
+    finally:
+        engine.FlatParams.prezero_grads, ZFUnetEngine.HEAD_FUSION = keep
+    ref_g, ref_acc, ref_loss = res[(False, True)]
+    pre_g, pre_acc, pre_loss = res[(True, True)]
+    assert pre_loss == ref_loss
+    for step in range(3):
+        for n in ref_g[step]:
+            assert torch.equal(pre_g[step][n], ref_g[step][n]), (step, n)        # the clear moved, nothing else
+    for n in ref_acc:
+        assert torch.equal(pre_acc[n], ref_acc[n]), n
+        # accumulated = twice the single-step gradient (same weights, same batch, no dropout) to fp32 rounding of the sums
+        torch.testing.assert_close(ref_acc[n], 2 * ref_g[2][n], rtol=2e-2, atol=2e-3 * float(ref_g[2][n].abs().max()) + 1e-12)
+    # classifier fusion: same dz bit for bit, dw / db / sums in another summation order
+    unf_g, _, unf_loss = res[(True, False)]
+    assert abs(unf_loss - pre_loss) < 1e-5
+    gmax = max(float(v.abs().max()) for v in unf_g[2].values())
+    for n in unf_g[2]:
+        torch.testing.assert_close(pre_g[2][n], unf_g[2][n], rtol=2e-2, atol=2e-3 * max(float(unf_g[2][n].abs().max()), 1e-3 * gmax))
