@@ -846,10 +846,10 @@ class HipNet(nn.Module):
         from . import engine
         tape = self._tape
         rt = tape.rt
-        if not self.use_cplan or rt.device.type != 'cuda' or engine.TIMER is not None or x.dtype == torch.uint8:
+        if not self.use_cplan or rt.device.type != 'cuda' or engine.TIMER is not None:
             return None
         side = rt.side_stream()
-        return (tuple(x.shape), bool(self.training), bool(need_grad), rt.stream, side.cuda_stream if side is not None else 0,
+        return (tuple(x.shape), x.dtype, bool(self.training), bool(need_grad), rt.stream, side.cuda_stream if side is not None else 0,
                 tape.flat.flat_p.data_ptr(), tape.flat.flat_g.data_ptr(), tuple(b.data_ptr() for b in tape.flat.buffer_list()),
                 tuple(sorted((p, pool['used']) for p, pool in tape._drop_pools.items())) if self.training else (),
                 tape._ready_hook() is not None)
@@ -873,16 +873,16 @@ class HipNet(nn.Module):
         key = self._plan_key(x, need_grad)
         ent, recording = None, False
         self._plan_live = None
+        # the batch enters through ONE launch outside the recorded list (it reads the caller's tensor, whatever its address):
+        # NCHW fp32 / NHWC uint8 -> the padded NHWC buffer the list's first convolution reads
+        cin_p = cp.pad8(C)
+        xin = tape.view('input', N, H, W, cin_p)
+        pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         if key is not None:
             ent = tape.plans.get(key)
             if ent is None:
                 ent = tape.plans[key] = {'state': 'seen'}                  # first step of this key: eager
             else:
-                xin_t = ent.get('x_in')
-                if xin_t is None:
-                    xin_t = ent['x_in'] = torch.empty_like(x)
-                xin_t.copy_(x)                                              # the list reads the batch from ONE tensor
-                x = xin_t
                 if ent['state'] == 'ready':
                     nv.call('segnb_plan_run', ent['fwd'])
                     tape.back = []
@@ -894,9 +894,6 @@ class HipNet(nn.Module):
                     self._plan_drop(ent)                                    # (a recorded forward whose backward never ran)
                     nv.plan_record_begin()
                     recording = True
-        cin_p = cp.pad8(C)
-        xin = tape.view('input', N, H, W, cin_p)
-        pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         self._dlogits = [None]
         tape.unplannable = False
         try:
