@@ -548,7 +548,7 @@ int segnb_seg_loss_reduce(const float* logits, const long long* target, long lon
 int segnb_seg_loss_finalize(const double* sums, const segnb_loss_spec* spec, float* out,
                             segnb_stream_t stream);
 /* segnb_seg_loss_reduce + segnb_seg_loss_finalize (and the zero fill of the sums before them) as ONE launch on one device:
- * work = 16 doubles, ZERO on entry (allocate once, zeroed) and left zero on return -- the last block to finish turns the sums into
+ * work = 128 doubles, ZERO on entry (allocate once, zeroed) and left zero on return -- the last block to finish turns the sums into
  * `out` and clears them.  A data-parallel job keeps the two-launch form (the sums are all-reduced in between). */
 int segnb_seg_loss_reduce_finalize(const float* logits, const long long* target, long long n,
                                    const segnb_loss_spec* spec, double* work, float* out, segnb_stream_t stream);

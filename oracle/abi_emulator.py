@@ -1019,7 +1019,7 @@ class AbiEmulator(object):
         sp = _geom(spec)
         rc = self.segnb_seg_loss_reduce(logits, target, n, float(sp.focal_gamma), work, stream)
         rc = rc or self.segnb_seg_loss_finalize(work, spec, out, stream)
-        _mem(work, 16, torch.float64).zero_()
+        _mem(work, 128, torch.float64).zero_()
         return rc
 
     def segnb_seg_loss_finalize(self, sums, spec, out, stream):

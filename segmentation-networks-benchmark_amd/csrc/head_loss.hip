@@ -198,11 +198,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
 }
 
 // dw[k][c] += sum over the pixel blocks (fixed order) of their partial sums; db[k] likewise (channel-chunk row 0).
-// One wave per output element: lanes stride the blocks, then a fixed shuffle tree.
-__global__ __launch_bounds__(64) void head_bwd_finish_kernel(const float* __restrict__ part, int gx, int gy, int K, int C,
-                                                             int CT, float* __restrict__ dw, float* __restrict__ db) {
+// One 256-thread block per output element: lanes stride the blocks (up to 2048 rows: 8 dependent loads per lane instead of 32),
+// a fixed shuffle tree per wave, the four waves' sums added in wave order.
+__global__ __launch_bounds__(256) void head_bwd_finish_kernel(const float* __restrict__ part, int gx, int gy, int K, int C,
+                                                              int CT, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float sw4[4];
     const int o = blockIdx.x;                           // 0 .. K*C-1: weights, K*C .. K*C+K-1: biases
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x;
     const int row = K * (CT * 8 + 1);
     int k, by, idx;
     if (o < K * C) {
@@ -216,14 +218,17 @@ __global__ __launch_bounds__(64) void head_bwd_finish_kernel(const float* __rest
         idx = CT * 8;
     }
     float sum = 0.f;
-    for (int bx = lane; bx < gx; bx += 64) sum += part[(long long)(by * gx + bx) * row + k * (CT * 8 + 1) + idx];
+    for (int bx = t; bx < gx; bx += 256) sum += part[(long long)(by * gx + bx) * row + k * (CT * 8 + 1) + idx];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
-    if (lane == 0) {
+    if ((t & 63) == 0) sw4[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+        const float tot = ((sw4[0] + sw4[1]) + sw4[2]) + sw4[3];
         if (o < K * C) {
-            if (dw != nullptr) dw[o] += sum;
+            if (dw != nullptr) dw[o] += tot;
         } else if (db != nullptr) {
-            db[k] += sum;
+            db[k] += tot;
         }
     }
 }
@@ -290,6 +295,7 @@ __device__ __forceinline__ void loss_finalize_math(const double* sums, const seg
     out[7] = 0.f;
 }
 
+constexpr int LOSS_REPL = 8;       // replicas of the sums in the one-launch form (work buffer: LOSS_REPL * 8 + 1 doubles <= 128)
 // FIN: the LAST block to finish (a ticket counter behind the sums) turns the sums into the result vector and leaves the work
 // buffer zeroed for the next call -- zero fill, reduction and finalize in one launch (segnb_seg_loss_reduce_finalize)
 template <bool FIN>
@@ -334,29 +340,46 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
         if (lane == 0) sh[wave][k] = v;
     }
     __syncthreads();
+    // FIN: the sums live in LOSS_REPL replicas of 8 doubles (a block adds to replica blockIdx % LOSS_REPL: same-address atomics
+    // serialise, and this launch runs up to 2048 blocks), the ticket behind them
+    double* const dst = FIN ? sums + (blockIdx.x % LOSS_REPL) * 8 : sums;
+    // (FIN: RETURNING atomics -- the wave waits until they are performed at the device's coherence point, so the ticket below is
+    // taken after this block's sums without a __threadfence(): a fence writes the XCD's L2 back, and one per block made this
+    // launch 52 us at 512 blocks / 125 us at 2048, profiles/r04_ab.txt)
+    double ret = 0.0;
     if (threadIdx.x < 6) {
         const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-        atomicAdd(&sums[threadIdx.x], v);
+        ret = atomicAdd(&dst[threadIdx.x], v);
     }
-    if (threadIdx.x == 6 && blockIdx.x == 0) atomicAdd(&sums[6], (double)n);
+    if (threadIdx.x == 6 && blockIdx.x == 0) ret = atomicAdd(&dst[6], (double)n);
     if constexpr (FIN) {
         __shared__ int last;
-        __threadfence();
+        if (ret == -1.2345e300) fin[7] = 1.f;           // (never: keeps the returned values -- and the wait for them -- alive)
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned* ticket = reinterpret_cast<unsigned*>(sums + 8);
+            unsigned* ticket = reinterpret_cast<unsigned*>(sums + LOSS_REPL * 8);
             last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
         }
         __syncthreads();
-        if (last && threadIdx.x == 0) {
-            __threadfence();
-            double tot[7];
+        if (last) {
+            // the LAST block: every replica value through one coherent load per thread (56 loads in flight at once -- read back one
+            // by one with returning atomics they were 56 dependent round trips to the coherence point: ~50 us), summed by thread 0
+            __shared__ double stot[LOSS_REPL * 8];
+            if (threadIdx.x < LOSS_REPL * 8) {
+                stot[threadIdx.x] = __hip_atomic_load(&sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sums[threadIdx.x] = 0.0;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot[7];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) tot[k] = atomicAdd(&sums[k], 0.0);      // (coherent read of what every block added)
-            loss_finalize_math(tot, sp, fin);
-#pragma unroll
-            for (int k = 0; k < 7; ++k) sums[k] = 0.0;
-            *reinterpret_cast<unsigned*>(sums + 8) = 0u;
+                for (int k = 0; k < 7; ++k) {
+                    tot[k] = 0.0;
+                    for (int rp = 0; rp < LOSS_REPL; ++rp) tot[k] += stot[rp * 8 + k];
+                }
+                loss_finalize_math(tot, sp, fin);
+                *reinterpret_cast<unsigned*>(sums + LOSS_REPL * 8) = 0u;
+            }
         }
     }
 }
@@ -567,7 +590,7 @@ float* head_scratch(size_t bytes, hipStream_t stream) {
 // (for segnb_head_bn_bwd, norm_act.hip: the same partial-sum protocol)
 float* segnb_head_scratch(size_t bytes, hipStream_t stream) { return head_scratch(bytes, stream); }
 void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream) {
-    head_bwd_finish_kernel<<<dim3(K * C + K), dim3(64), 0, stream>>>(part, gx, gy, K, C, CT, dw, db);
+    head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, stream>>>(part, gx, gy, K, C, CT, dw, db);
 }
 
 extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
@@ -604,7 +627,7 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
             (const float*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (float*)da, ld_da, part, ct);
     SEGNB_LAUNCH_CHECK();
     if (dw != nullptr || db != nullptr) {
-        head_bwd_finish_kernel<<<dim3(K * C + K), dim3(64), 0, (hipStream_t)stream>>>(part, (int)gx, gy, K, C, ct, dw, db);
+        head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, (hipStream_t)stream>>>(part, (int)gx, gy, K, C, ct, dw, db);
         SEGNB_LAUNCH_CHECK();
     }
     return 0;
@@ -631,7 +654,7 @@ extern "C" int segnb_seg_loss_reduce_finalize(const float* logits, const long lo
     SEGNB_CHECK_ARG(logits && target && spec && work && out && n > 0, "bad arguments");
     SEGNB_CHECK_ARG(spec->norm != 0.f, "loss norm must be non-zero");
     int grid = ceil_div(n, 256 * 4);
-    if (grid > 512) grid = 512;
+    if (grid > 512) grid = 512;            // (measured: 512 blocks 23.7 us, 1024: 26.7, 2048: 31.5, 4096: 32.1 -- the per-block atomics)
     const int vec = (((uintptr_t)logits | (uintptr_t)target) & 15) == 0;
     hipLaunchKernelGGL(loss_reduce_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, n, work, vec,
                        spec->focal_gamma, *spec, out);

@@ -102,7 +102,7 @@ def _grad_buffer_for(x):
 
 # SEGNB_LOSS_ONE_LAUNCH=0: zero fill, segnb_seg_loss_reduce and segnb_seg_loss_finalize as three launches (A/B)
 _ONE_LAUNCH = os.environ.get('SEGNB_LOSS_ONE_LAUNCH', '1') != '0'
-_loss_work = {}       # (device index, stream) -> 16 zeroed doubles: the sums + ticket of segnb_seg_loss_reduce_finalize
+_loss_work = {}       # (device index, stream) -> 128 zeroed doubles: the sums + ticket of segnb_seg_loss_reduce_finalize
 
 
 def reduce_finalize(x, t, spec):
@@ -115,7 +115,7 @@ def reduce_finalize(x, t, spec):
         key = (x.device.index, st)
         work = _loss_work.get(key)
         if work is None:
-            work = _loss_work[key] = torch.zeros(16, dtype=torch.float64, device=x.device)
+            work = _loss_work[key] = torch.zeros(128, dtype=torch.float64, device=x.device)
         nv.call('segnb_seg_loss_reduce_finalize', nv.ptr(x), nv.ptr(t), x.numel(), _cspec(spec), nv.ptr(work), nv.ptr(fin), st)
         return work, fin
     sums = torch.zeros(8, dtype=torch.float64, device=x.device)
