@@ -347,6 +347,8 @@ class _ZFUnetPlan(object):
     PACK_EARLY = 8
     PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
     PACK_DG_SIDE = os.environ.get('SEGNB_PACK_DG_SIDE', '0') != '0'
+    DROP_ON_SIDE = os.environ.get('SEGNB_DROP_ON_SIDE', '0') != '0'      # Dropout2d masks drawn on the side stream (measured +-0 or slower: off)
+    _drop_wait = None
     _dg_pack_on_side = False
 
     def _join_late_pack(self):
@@ -364,7 +366,20 @@ class _ZFUnetPlan(object):
             return {n: None for n in names}
         tabs = b['drop']                         # {name: fp32 [N, Cp] view of one flat buffer}
         if ov is None:
-            b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
+            side = self.rt.side_stream() if self.DROP_ON_SIDE else None
+            if side is None:
+                b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
+                return tabs
+            # the two launches that draw the masks run on the side stream (idle in the forward) beside the weight pack; the main
+            # stream waits for them after the pack has been enqueued (forward()) -- 10 us off the start of every step
+            nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)      # (the last backward still read the tables)
+            ev = getattr(self, '_drop_event', None)
+            if ev is None:
+                ev = self._drop_event = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
+                ev.record(side)
+            self._drop_wait = ev
             return tabs
         out = {}
         for n in names:
@@ -491,10 +506,13 @@ class _ZFUnetPlan(object):
         else:
             N, C, H, W = x.shape
         b = self.buffers(N, H, W)
+        drop = self._dropout_tables(b, N, train)      # (first: on the side stream, beside the weight pack below)
         self._pack_if_needed(H, W, N)
+        if self._drop_wait is not None:
+            torch.cuda.current_stream(rt.device).wait_event(self._drop_wait)
+            self._drop_wait = None
         if train and need_grad:
             self.flat.prezero(rt)
-        drop = self._dropout_tables(b, N, train)
         hf = self._head_fusable(train, need_grad)
         self._last_head_fused = hf
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)
