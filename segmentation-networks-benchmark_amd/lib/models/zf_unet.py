@@ -347,6 +347,7 @@ class _ZFUnetPlan(object):
     PACK_EARLY = 8
     PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
     PACK_DG_SIDE = os.environ.get('SEGNB_PACK_DG_SIDE', '0') != '0'
+    TAIL_POSTPONE = os.environ.get('SEGNB_TAIL_POSTPONE', '0') != '0'
     DROP_ON_SIDE = os.environ.get('SEGNB_DROP_ON_SIDE', '0') != '0'      # Dropout2d masks drawn on the side stream (measured +-0 or slower: off)
     _drop_wait = None
     _dg_pack_on_side = False
@@ -708,9 +709,14 @@ class _ZFUnetPlan(object):
                 elif i == 5:
                     red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
                 else:
+                    # TAIL_POSTPONE: the last block's second weight gradient is held back until the first layer's apply pass is
+                    # out, then runs on the side stream BESIDE the first layer's weight gradient (main stream) instead of beside
+                    # that apply pass -- three HBM-bound launches in a row become two in parallel
+                    hold0 = [] if (i == 0 and self.TAIL_POSTPONE and rt.side_stream() is not None) else None
                     red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
-                                      dx=b['da1_%d' % i], fuse_reduce_of=s1)
-                s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red)
+                                      dx=b['da1_%d' % i], fuse_reduce_of=s1, postponed=hold0)
+                s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red,
+                            flush_before_wgrad=hold0 if i == 0 else None)
             if self.BWD_CONV_CU_PCT != 100:
                 nv.call('segnb_tune', b'conv_cu_pct', 100)
             rt.join_side()                        # the weight gradients ran on the side stream

@@ -1142,7 +1142,7 @@ class Stage(object):
         return (yv, self.coef, self.sums, self.act, self.slope)
 
     def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None, reduced=False,
-                 fuse_reduce_of=None, dz_ready=False):
+                 fuse_reduce_of=None, dz_ready=False, flush_before_wgrad=None):
         """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
         input gradient, or None (first layer).  reduced: the reduction pass of this layer was already done by the
         data-gradient launch that produced g_direct.  fuse_reduce_of: the Stage whose activation gradient dx is -- if
@@ -1225,6 +1225,10 @@ class Stage(object):
                 self.conv.wgrad_tf(xv, x_tf, dz, None)
             else:
                 self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=unpack)
+        if flush_before_wgrad:
+            # weight gradients another stage held back (postponed=...) go to the side stream NOW: behind this stage's apply pass,
+            # beside its own weight gradient (the tail of ZF_UNET's backward: both of the first block's weight gradients at once)
+            rt.flush_postponed(flush_before_wgrad)
         side = rt.fork_side() if (self.defer_unpack and dx is not None and postponed is None) else None
         if postponed is not None and self.defer_unpack and dx is not None and rt.side_stream() is not None:
             # launched later by the plan (flush_postponed): x and dy of this layer stay untouched until then
