@@ -10,6 +10,7 @@ The product never imports this file and has no CPU path.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -360,8 +361,16 @@ class AbiEmulator(object):
         return 0
 
     def segnb_conv_wgrad_bnapply_ok(self, g, dtype):
+        """(the library's rule: by default only where the first layer's rolling kernel serves -- 8 padded input channels, rows of
+        at least 32 pixels -- SEGNB_WGRAD_BNAPPLY=1 widens it to every thin stride-1 3x3 layer, =0 disables)"""
         g = _geom(g)
-        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.Co <= 32)
+        e = os.environ.get('SEGNB_WGRAD_BNAPPLY')
+        if e == '0' or not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.Co <= 32 and g.Co % 8 == 0):
+            return 0
+        same = g.Hi == g.Ho and g.Wi == g.Wo and g.QH == g.Ho and g.QW == g.Wo and g.oh0 == 0 and g.ow0 == 0
+        if g.Ci == 8 and g.Wo >= 32 and same and getattr(self, 'tuned', {}).get('wgrad_c8roll', 1):
+            return 1
+        return int(e is not None)
 
     def segnb_conv_wgrad_bnapply(self, g, dtype, in_p, gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope, dwp, nslab, stream):
         """segnb_bn_bwd_apply_direct into a temporary, then segnb_conv_wgrad on it"""

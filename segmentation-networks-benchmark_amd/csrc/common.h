@@ -153,6 +153,11 @@ bool segnb_wgrad_roll_applies(const segnb_conv_geom* g);
 int segnb_wgrad_roll_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
                          bool partial, const segnb_operand_tf* tfx = nullptr, const segnb_operand_tf* tfd = nullptr);
 int segnb_knob_wgrad_roll();
+// the first layer (8 padded input channels): conv_wgrad_c8roll_kernel; bna: dy recomputed from (g, y), dout ignored
+bool segnb_wgrad_c8roll_applies(const segnb_conv_geom* g);
+int segnb_wgrad_c8roll_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
+                           bool partial, const segnb_wgrad_bnapply* bna = nullptr);
+int segnb_knob_wgrad_c8roll();
 // strided / wide-window tile kernel (wgrad_s1.hip: conv_wgrad_sx_kernel): same protocol
 int segnb_wgrad_sx_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
                        bool partial);

@@ -1571,6 +1571,10 @@ extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
     if (check_geom(g)) return -1;
     if (dtype == SEGNB_BF16 && !wgrad_general_only()) {
         const int s = segnb_wgrad_s1_slabs(g);
+        if (s > 0 && segnb_knob_wgrad_c8roll() && segnb_wgrad_c8roll_applies(g)) {
+            static const int c8s = getenv("SEGNB_C8ROLL_SLABS") ? atoi(getenv("SEGNB_C8ROLL_SLABS")) : 0;
+            if (c8s > 0) return c8s;
+        }
         if (s > 0) return s;
         const int sx = segnb_wgrad_sx_slabs(g);
         if (sx > 0) return sx;
@@ -1595,6 +1599,8 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
         rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        if (rc == 0 && !wgrad_general_only() && segnb_knob_wgrad_c8roll() && segnb_wgrad_s1_slabs(g) > 0)
+            rc = segnb_wgrad_c8roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 0)
             rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
         if (rc == 1) {
@@ -1630,9 +1636,12 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
 // network: nothing else reads that dy -- no data gradient -- so the apply pass and its tensor disappear)
 extern "C" int segnb_conv_wgrad_bnapply_ok(const segnb_conv_geom* g, int dtype) {
     if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || wgrad_general_only()) return 0;
-    static const bool off = getenv("SEGNB_WGRAD_BNAPPLY") != nullptr && getenv("SEGNB_WGRAD_BNAPPLY")[0] == '0';
-    if (off || g->Co > 32 || g->Co % 8 != 0) return 0;
-    return segnb_wgrad_s1_slabs(g) > 0 ? 1 : 0;
+    // SEGNB_WGRAD_BNAPPLY: unset = only where the rolling first-layer kernel serves (conv_wgrad_c8roll_kernel: -0.85 % of the
+    // timed step), 1 = the thin tile kernel's variant too (measured neutral: profiles/r04_ab.txt), 0 = never
+    const char* e = getenv("SEGNB_WGRAD_BNAPPLY");
+    if ((e != nullptr && e[0] == '0') || g->Co > 32 || g->Co % 8 != 0 || segnb_wgrad_s1_slabs(g) <= 0) return 0;
+    if (segnb_knob_wgrad_c8roll() && segnb_wgrad_c8roll_applies(g)) return 1;
+    return e != nullptr ? 1 : 0;
 }
 
 extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, const void* in, const void* gsrc, int ld_g,
@@ -1645,7 +1654,8 @@ extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, con
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     SEGNB_CHECK_ARG(Cp >= g->Co && ld_g >= g->Co && ld_y >= g->Co, "bad strides");
     const segnb_wgrad_bnapply bna = {gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope};
-    const int rc = segnb_wgrad_s1_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna);
+    int rc = segnb_knob_wgrad_c8roll() ? segnb_wgrad_c8roll_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna) : 0;
+    if (rc == 0) rc = segnb_wgrad_s1_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna);
     if (rc == 1) {
         SEGNB_LAUNCH_CHECK();
         return 0;

@@ -249,6 +249,15 @@ int segnb_knob_wgrad_roll() {
     }
     return g_wgrad_roll;
 }
+// conv_wgrad_c8roll_kernel (wgrad_roll.hip) for the first layer's weight gradient (8 padded input channels): 1 on, 0 off
+static int g_wgrad_c8roll = -2;
+int segnb_knob_wgrad_c8roll() {
+    if (g_wgrad_c8roll == -2) {
+        const char* e = getenv("SEGNB_WGRAD_C8ROLL");
+        g_wgrad_c8roll = e != nullptr ? atoi(e) : 1;
+    }
+    return g_wgrad_c8roll;
+}
 static int g_conv_cu_pct = 100;
 int segnb_knob_conv_cus() {
     const int n = segnb_num_cus() * g_conv_cu_pct / 100;
@@ -331,6 +340,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wgrad_roll") == 0) {
         g_wgrad_roll = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "wgrad_c8roll") == 0) {
+        g_wgrad_c8roll = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_rw") == 0) {

@@ -398,6 +398,272 @@ int launch_wroll(WRollArgs& a, int nslab, hipStream_t stream) {
     return launch_wroll_dl<TFX, TFD, 4>(a, nslab, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The FIRST layer (8 padded input channels, lib/models/zf_unet.py:37 `double_conv_layer(input_channels, filters)`): the same
+// rolling scheme with 16-byte x pixels.  An N block of the MFMA is TWO TAPS x 8 channels (taps 2 nb, 2 nb + 1 in kernel-row
+// major order; the tenth half-block is computed and discarded), so a dy row costs 5 MFMAs per 16 output channels instead of
+// 18 and the kernel is bound by its operand streams alone.  The transposed read serves this directly: the two 8-lane halves
+// of a 16-lane group point at different pixels (and, for the pair that straddles two kernel rows, different ring slots).
+// TFD == 3: the dy operand is recomputed from (g, y) with the arithmetic and roundings of bn_bwd_apply_kernel's direct form
+// (segnb_conv_wgrad_bnapply: a first layer has no data gradient, so nothing else would read the tensor).
+constexpr int W8_XROWB = 608;                          // x row: 34 pixels x 16 B, padded so that a straddling pair's halves use disjoint banks
+constexpr int W8_SLAB_FLOATS = 32 * 9 * 8;
+
+template <int NW, int COH>
+constexpr int w8_wave_lds() { return 4 * W8_XROWB + 2 * 32 * 32 * COH; }
+template <int NW, int COH>
+constexpr int w8_smem() { return NW * w8_wave_lds<NW, COH>() + W8_SLAB_FLOATS * 4; }
+
+// COH: 16-channel halves of dy a wave owns (1: Co <= 16, 2: Co <= 32).  A wave loads WHOLE dy pixels -- every 128-byte line it
+// touches is used in full by one instruction -- and the x row of a strip is loaded once; splitting the dy channels over two
+// waves (as conv_wgrad_roll_kernel does) left both operand streams at half-used lines and the kernel at 3.6 TB/s.
+template <int TFD, int DL, int NW, int COH>
+__global__ __launch_bounds__(NW * 64, 1) void conv_wgrad_c8roll_kernel(const WRollArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WAVE_LDS = w8_wave_lds<NW, COH>(), DPXB = 32 * COH, DROWB = 32 * DPXB;
+    float* const slab = reinterpret_cast<float*>(smem + NW * WAVE_LDS);
+    constexpr int UN = 4 % DL == 0 ? 4 : 4 * DL;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const xr = smem + wave * WAVE_LDS;
+    unsigned char* const dr = xr + 4 * W8_XROWB;
+    const unsigned xr_l = (unsigned)(size_t)smem + (unsigned)(wave * WAVE_LDS);
+    const unsigned dr_l = xr_l + 4 * W8_XROWB;
+    const int n16 = lane & 15, kg = lane >> 4, q4 = n16 >> 2, p4 = n16 & 3;
+    const bool hi = (p4 >> 1) != 0;                      // second tap of a pair
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.d), 0, (int)a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(TFD == 3 ? a.d2 : a.d), 0, TFD == 3 ? (int)a.d2_bytes : 0, 0x00020000);
+
+    for (int i = threadIdx.x; i < W8_SLAB_FLOATS; i += NW * 64) slab[i] = 0.f;
+
+    // dy row image: 32 pixels x DPXB bytes, COH loads per row: load m, lane l -> 16-byte chunk 64 m + l of the row (pixel
+    // (64 m + l) / (2 COH), channel chunk (64 m + l) % (2 COH): the SAME chunk for every m)
+    const int dc0 = (lane & (2 * COH - 1)) * 8;
+    // per-channel constants of this lane's (fixed) dy chunk
+    float k_sc[8], k_sh[8], k_mu[8], k_is[8], k_a[8], k_c1[8], k_c2[8], k_neg = 0.f;
+    bool k_round = false;
+    if constexpr (TFD == 3) {
+        k_neg = a.tfd_act == SEGNB_ACT_RELU ? 0.f : (a.tfd_act == SEGNB_ACT_LEAKY ? a.tfd_slope : 1.f);
+        k_round = k_neg != 0.f && k_neg != 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = dc0 + e < a.tfd_Cp ? dc0 + e : 0;
+            k_sc[e] = a.tfd_coef[c];
+            k_sh[e] = a.tfd_coef[a.tfd_Cp + c];
+            k_mu[e] = a.tfd_coef[2 * a.tfd_Cp + c];
+            k_is[e] = a.tfd_coef[3 * a.tfd_Cp + c];
+            k_a[e] = a.tfd_bcoef[c];
+            k_c1[e] = a.tfd_bcoef[a.tfd_Cp + c];
+            k_c2[e] = a.tfd_bcoef[2 * a.tfd_Cp + c];
+        }
+    }
+    __syncthreads();
+
+    // transposed reads of x: block nb, half h -> tap k9 = 2 nb + h (kernel row k9 / 3, column shift k9 % 3); lane (kg, q4, p4)
+    // supplies pixel 16 r + 4 kg + q4 (+ the shift), channels 4 (p4 & 1) .. + 3 of its tap
+    unsigned xro[5];
+#pragma unroll
+    for (int nb = 0; nb < 5; ++nb) {
+        const int k9 = min(2 * nb + (hi ? 1 : 0), 8);
+        xro[nb] = xr_l + (unsigned)((k9 % 3 + 4 * kg + q4) * 16 + 8 * (p4 & 1));
+    }
+    // ... of dy: pixel 16 r + 4 kg + q4, channels 4 p4 .. + 3 of the 16-channel half
+    const unsigned dro = dr_l + (unsigned)((4 * kg + q4) * DPXB + (p4 >> 1) * 16 + 8 * (p4 & 1));
+
+    f32x4_t acc[COH][5];
+#pragma unroll
+    for (int h = 0; h < COH; ++h)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[h][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nstream = gridDim.x * NW;
+    for (int task = blockIdx.x * NW + wave; task < a.NTASK; task += nstream) {
+        const int strip = task % a.NSTRIP;
+        const int t2 = task / a.NSTRIP;
+        const int seg = t2 % a.NSEG, n = t2 / a.NSEG;
+        const int r0 = seg * a.SR;
+        const int rows = min(a.SR, a.H - r0);
+        const int c0 = strip * 32;
+
+        const int xcol = c0 - 1 + lane;
+        const bool xcolv = lane < WR_XPX && (unsigned)xcol < (unsigned)a.W;
+        const unsigned xcoff = xcolv ? (unsigned)(xcol * a.ld_x * 2) : OOB;
+        unsigned dcoff[COH], dcoff2[COH];
+        bool dcolv[COH];
+#pragma unroll
+        for (int m = 0; m < COH; ++m) {
+            const int dcol = c0 + (64 * m + lane) / (2 * COH);
+            dcolv[m] = dcol < a.W && dc0 < a.Co;
+            dcoff[m] = dcolv[m] ? (unsigned)(dcol * a.ld_d * 2 + dc0 * 2) : OOB;
+            dcoff2[m] = (TFD == 3 && dcolv[m]) ? (unsigned)(dcol * a.ld_d2 * 2 + dc0 * 2) : OOB;
+        }
+
+        u32x4_t lx[DL], ldd[DL][COH], ld2[TFD == 3 ? DL : 1][COH];
+        auto issue_x = [&](auto set_c, int j) {
+            constexpr int set = decltype(set_c)::value;
+            const int gr = r0 + j;
+            const bool rv = j <= rows && (unsigned)gr < (unsigned)a.H;
+            const unsigned pixrow = (unsigned)((n * a.H + gr) * a.W);
+            lx[set] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(rv ? pixrow * (unsigned)(a.ld_x * 2) + xcoff : OOB), 0, 0);
+        };
+        auto issue_d = [&](auto set_c, int i) {
+            constexpr int set = decltype(set_c)::value;
+            const bool rv = i < rows;
+            const unsigned pixrow = (unsigned)((n * a.H + r0 + i) * a.W);
+#pragma unroll
+            for (int m = 0; m < COH; ++m) {
+                ldd[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, (int)(rv ? pixrow * (unsigned)(a.ld_d * 2) + dcoff[m] : OOB), 0, 0);
+                if constexpr (TFD == 3)
+                    ld2[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_d2, (int)(rv ? pixrow * (unsigned)(a.ld_d2 * 2) + dcoff2[m] : OOB), 0, 0);
+            }
+        };
+        auto publish_x = [&](auto set_c, auto slot_c) {
+            constexpr int set = decltype(set_c)::value, slot = decltype(slot_c)::value;
+            if (lane < WR_XPX) *reinterpret_cast<u32x4_t*>(xr + slot * W8_XROWB + lane * 16) = lx[set];
+        };
+        auto publish_d = [&](auto set_c, auto slot_c, int i) {
+            constexpr int set = decltype(set_c)::value, slot = decltype(slot_c)::value;
+#pragma unroll
+            for (int m = 0; m < COH; ++m) {
+                u32x4_t v = ldd[set][m];
+                if constexpr (TFD == 3) {
+                    float gq[8], yq[8];
+                    unpack8w(v, gq);
+                    unpack8w(ld2[set][m], yq);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = (yq[e] - k_mu[e]) * k_sc[e] + k_sh[e] + 0.f;
+                        float d = gq[e] * 1.f * (z > 0.f ? 1.f : k_neg);
+                        if (k_round) d = __uint_as_float(pack2bf(d, 0.f) << 16);
+                        const float yh = (yq[e] - k_mu[e]) * k_is[e];
+                        gq[e] = k_a[e] * (d - k_c1[e] - yh * k_c2[e]);
+                    }
+                    const bool ok = i < rows && dcolv[m];
+                    v.x = ok ? pack2bf(gq[0], gq[1]) : 0u;
+                    v.y = ok ? pack2bf(gq[2], gq[3]) : 0u;
+                    v.z = ok ? pack2bf(gq[4], gq[5]) : 0u;
+                    v.w = ok ? pack2bf(gq[6], gq[7]) : 0u;
+                }
+                *reinterpret_cast<u32x4_t*>(dr + slot * DROWB + (64 * m + lane) * 16) = v;
+            }
+        };
+
+        static_for<DL>([&](auto k_c) { issue_x(k_c, -1 + decltype(k_c)::value); });
+        static_for<DL>([&](auto k_c) { issue_d(k_c, decltype(k_c)::value); });
+        publish_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        issue_x(std::integral_constant<int, 0>{}, -1 + DL);
+        publish_x(std::integral_constant<int, 1 % DL>{}, std::integral_constant<int, 1>{});
+        issue_x(std::integral_constant<int, 1 % DL>{}, DL);
+        publish_d(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        issue_d(std::integral_constant<int, 0>{}, DL);
+
+        // step i: x row i + 1 enters the ring (slot (i + 2) % 4), then dy row i (slot i % 2) meets x rows i - 1 .. i + 1
+        // (x row j in slot (j + 1) % 4: kernel row dyt of step i reads slot (i + dyt) % 4); dy row i + 1 is published behind
+        auto step = [&](auto u_c, int i) {
+            constexpr int UI = decltype(u_c)::value;
+            constexpr int XS_NEW = (UI + 2) % 4, XSET = (UI + 2) % DL, DS = UI % 2, DSET1 = (UI + 1) % DL;
+            if (i >= rows) return;
+            publish_x(std::integral_constant<int, XSET>{}, std::integral_constant<int, XS_NEW>{});
+            if (i + 1 + DL <= rows) issue_x(std::integral_constant<int, XSET>{}, i + 1 + DL);
+            bf16x8_t A[COH];
+#pragma unroll
+            for (int h = 0; h < COH; ++h) {
+                const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(dro + DS * DROWB + h * 32));
+                const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(dro + DS * DROWB + h * 32 + 16 * DPXB));
+                A[h] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            bf16x8_t B[5];
+            static_for<5>([&](auto nb_c) {
+                constexpr int nb = decltype(nb_c)::value;
+                constexpr int kA = 2 * nb, kB = nb == 4 ? 8 : 2 * nb + 1;
+                constexpr unsigned sA = ((UI + kA / 3) % 4) * W8_XROWB, sB = ((UI + kB / 3) % 4) * W8_XROWB;
+                const unsigned ad = xro[nb] + (sA == sB ? sA : (hi ? sB : sA));
+                const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)ad);
+                const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(uintptr_t)(ad + 16 * 16));
+                B[nb] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            });
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb)
+#pragma unroll
+                for (int h = 0; h < COH; ++h) acc[h][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[h], B[nb], acc[h][nb], 0, 0, 0);
+            if (i + 1 < rows) publish_d(std::integral_constant<int, DSET1>{}, std::integral_constant<int, (UI + 1) % 2>{}, i + 1);
+            if (i + 1 + DL < rows) issue_d(std::integral_constant<int, DSET1>{}, i + 1 + DL);
+        };
+        for (int ib = 0; ib < rows; ib += UN)
+            static_for<UN>([&](auto u_c) { step(u_c, ib + decltype(u_c)::value); });
+    }
+
+    // the block's slab: the waves add their accumulators in a fixed order (bitwise reproducible)
+    for (int turn = 0; turn < NW; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int nb = 0; nb < 5; ++nb) {
+                const int k9 = 2 * nb + (n16 >> 3);
+                if (k9 < 9) {
+                    const int t = a.tap[k9];
+#pragma unroll
+                    for (int h = 0; h < COH; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) slab[((h * 16 + kg * 4 + e) * 9 + t) * 8 + (n16 & 7)] += acc[h][nb][e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* const out = a.dwp + (long long)blockIdx.x * a.slab_stride;
+    for (int i = threadIdx.x; i < a.Co * 72; i += NW * 64) out[i] = slab[i];
+}
+
+template <int TFD, int DL, int NW, int COH>
+int launch_c8roll_nw(WRollArgs& a, int nslab, hipStream_t stream) {
+    static int attr_rc = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c8roll_kernel<TFD, DL, NW, COH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, w8_smem<NW, COH>());
+        if (e != hipSuccess) segnb_set_error("wgrad_c8roll hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }();
+    if (attr_rc) return attr_rc;
+    a.NCOH = 1;
+    a.NSTRIP = (a.W + 31) / 32;
+    // nslab blocks of NW waves, one (strip, row segment) task per wave where the shape allows it (conv_wgrad_roll_kernel)
+    const int streams = nslab * NW;
+    int nseg = (int)(streams / ((long long)a.N * a.NSTRIP));
+    if (nseg < 1) nseg = (a.H + 15) / 16;
+    if (nseg > a.H) nseg = a.H;
+    const int sr = (a.H + nseg - 1) / nseg;
+    a.SR = sr;
+    a.NSEG = (a.H + sr - 1) / sr;
+    a.NTASK = a.N * a.NSEG * a.NSTRIP;
+    hipLaunchKernelGGL((conv_wgrad_c8roll_kernel<TFD, DL, NW, COH>), dim3(nslab), dim3(NW * 64), (w8_smem<NW, COH>()), stream, a);
+    return 0;
+}
+
+template <int TFD, int COH>
+int launch_c8roll_coh(WRollArgs& a, int nslab, hipStream_t stream) {
+    static const int nw = [] {
+        const char* e = getenv("SEGNB_C8ROLL_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    static const int dl = [] {
+        const char* e = getenv("SEGNB_C8ROLL_DL");
+        return e ? atoi(e) : 2;
+    }();
+    // 8 waves of <= 256 registers (the recomputing variant holds 56 constants and two operand streams: 192); the plain variant
+    // takes the same partition, so that both sum in the same order (segnb_conv_wgrad_bnapply == apply pass + segnb_conv_wgrad
+    // bit for bit).  Measured (tools/c8_bench.py, us incl. the 6.7 us slab reduction): 8 waves 40.3 / 59.7, 16 waves 50.0 / 273.6
+    const bool w16 = nw == 16;
+    if (w16) return dl == 4 ? launch_c8roll_nw<TFD, 4, 16, COH>(a, nslab, stream) : launch_c8roll_nw<TFD, 2, 16, COH>(a, nslab, stream);
+    return dl == 4 ? launch_c8roll_nw<TFD, 4, 8, COH>(a, nslab, stream) : launch_c8roll_nw<TFD, 2, 8, COH>(a, nslab, stream);
+}
+
+template <int TFD>
+int launch_c8roll(WRollArgs& a, int nslab, hipStream_t stream) {
+    return a.Co <= 16 ? launch_c8roll_coh<TFD, 1>(a, nslab, stream) : launch_c8roll_coh<TFD, 2>(a, nslab, stream);
+}
 }  // namespace
 
 bool segnb_wgrad_roll_applies(const segnb_conv_geom* g) {
@@ -469,6 +735,72 @@ int segnb_wgrad_roll_try(const segnb_conv_geom* g, const void* in, const void* d
     else if (tfx != nullptr) rc = launch_wroll<1, 0>(a, nslab, stream);
     else if (tfd != nullptr) rc = launch_wroll<0, 2>(a, nslab, stream);
     else rc = launch_wroll<0, 0>(a, nslab, stream);
+    if (rc) return rc;
+    if (nslab > 1 && !partial) segnb_slab_reduce(dwp, a.slab_stride, nslab, stream);
+    return 1;
+}
+
+bool segnb_wgrad_c8roll_applies(const segnb_conv_geom* g) {
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Hi != g->Ho || g->Wi != g->Wo) return false;
+    if (g->Ci != 8 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32 || g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return false;
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return false;
+        const int k = (g->dh[t] + 1) * 3 + (g->dw[t] + 1);
+        if (seen[k]) return false;
+        seen[k] = true;
+    }
+    return true;
+}
+
+// the first layer's weight gradient (conv_wgrad_c8roll_kernel).  bna: dy recomputed from (g, y) (dout is then ignored)
+int segnb_wgrad_c8roll_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab, hipStream_t stream,
+                           bool partial, const segnb_wgrad_bnapply* bna) {
+    if (!segnb_wgrad_c8roll_applies(g) || nslab < 1) return 0;
+    WRollArgs a;
+    for (int t = 0; t < 9; ++t) a.tap[(g->dh[t] + 1) * 3 + (g->dw[t] + 1)] = t;
+    const long long npix = (long long)g->N * g->Ho * g->Wo;
+    a.x = (const bf16_t*)in;
+    a.ld_x = g->ld_in;
+    const long long xb = ((npix - 1) * g->ld_in + g->Ci) * 2;
+    long long db, d2b = 0;
+    if (bna != nullptr) {
+        if (bna->ld_g % 8 != 0 || bna->ld_y % 8 != 0 || bna->Cp < g->Co) return 0;
+        a.d = (const bf16_t*)bna->g;
+        a.ld_d = bna->ld_g;
+        a.d2 = (const bf16_t*)bna->y;
+        a.ld_d2 = bna->ld_y;
+        db = ((npix - 1) * bna->ld_g + g->Co) * 2;
+        d2b = ((npix - 1) * bna->ld_y + g->Co) * 2;
+        a.tfd_coef = bna->coef;
+        a.tfd_bcoef = bna->bcoef;
+        a.tfd_Cp = bna->Cp;
+        a.tfd_act = bna->act;
+        a.tfd_slope = bna->slope;
+    } else {
+        a.d = (const bf16_t*)dout;
+        a.ld_d = g->ld_out;
+        a.d2 = nullptr;
+        a.ld_d2 = 0;
+        db = ((npix - 1) * g->ld_out + g->Co) * 2;
+        a.tfd_coef = a.tfd_bcoef = nullptr;
+        a.tfd_Cp = 0;
+        a.tfd_act = 0;
+        a.tfd_slope = 0.f;
+    }
+    if (xb >= (1ll << 31) || db >= (1ll << 31) || d2b >= (1ll << 31)) return 0;
+    a.x_bytes = (unsigned)xb;
+    a.d_bytes = (unsigned)db;
+    a.d2_bytes = (unsigned)d2b;
+    a.dwp = dwp;
+    a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Ci = g->Ci; a.Co = g->Co;
+    a.Ktot = 9 * g->Ci;
+    a.slab_stride = (long long)g->Co * a.Ktot;
+    a.tfx_coef = a.tfx_drop = nullptr;
+    a.tfx_Cp = a.tfx_act = 0;
+    a.tfx_slope = 0.f;
+    const int rc = bna != nullptr ? launch_c8roll<3>(a, nslab, stream) : launch_c8roll<0>(a, nslab, stream);
     if (rc) return rc;
     if (nslab > 1 && !partial) segnb_slab_reduce(dwp, a.slab_stride, nslab, stream);
     return 1;

@@ -691,6 +691,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ dw
     if (grp == 0 && i < total) dwp[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// few elements x many slabs (the first layer: 2304 x 256): the 36 blocks above would each walk 64 slabs per thread, 16 dependent
+// round trips; 16 slab groups per block (1024 threads) and eight loads in flight per lane instead
+__global__ __launch_bounds__(1024) void slab_reduce_deep_kernel(float* __restrict__ dwp, long long total, int nslab) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+        int s = grp;
+        for (; s + 7 * 16 < nslab; s += 8 * 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += dwp[(long long)(s + 16 * k) * total + i];
+        }
+        for (; s < nslab; s += 16) a[0] += dwp[(long long)s * total + i];
+    }
+    part[grp][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (grp == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += part[g][lane];
+        dwp[i] = t;
+    }
+}
+
 // few slabs (<= 16: the layers with many tiles): one lane per FOUR consecutive elements, slabs summed in order.  The
 // 64-element blocks above are launch-rate bound there (4.7 M elements x 2 slabs = 74 k blocks: 23 us for 57 MB).
 __global__ __launch_bounds__(256) void slab_reduce_few_kernel(float4* __restrict__ dwp, long long total4, int nslab) {
@@ -1109,6 +1134,8 @@ void segnb_slab_reduce(float* dwp, long long total, int nslab, hipStream_t strea
     if (nslab <= 16 && total % 4 == 0)
         hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<float4*>(dwp), total / 4, nslab);
+    else if (total <= 4096 && nslab >= 128)
+        hipLaunchKernelGGL(slab_reduce_deep_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, stream, dwp, total, nslab);
     else
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, dwp, total, nslab);
 }

@@ -539,11 +539,11 @@ class ConvOp(object):
     def wgrad_bnapply_ok(self, xv, yv):
         """True when this convolution's weight gradient can recompute its dy operand -- the BatchNorm-backward apply of the
         layer -- from (g, y) itself (segnb_conv_wgrad_bnapply): the apply pass then disappears for a layer without a data
-        gradient.  OFF by default (SEGNB_WGRAD_BNAPPLY=1 enables): measured on MI355X at the first layer of the timed
-        configuration, the register-staged thin weight-gradient kernel pays for the second operand stream and the
-        arithmetic with +100 us, exactly what the 104 us apply pass cost (5.32-5.34 vs 5.31 ms/step)."""
+        gradient.  By default only the first layer's rolling kernel (8 padded input channels) takes it: 52.6 us against
+        52.5 us (apply pass) + 58.8 us (weight gradient on the stored dz) stand-alone, -0.85 % of the timed step;
+        SEGNB_WGRAD_BNAPPLY=1 adds the thin tile kernel's variant (measured neutral), =0 disables both."""
         p = self.plan(xv.H, xv.W)
-        if self.transposed or len(p['fwd']) != 1 or os.environ.get('SEGNB_WGRAD_BNAPPLY', '0') == '0':
+        if self.transposed or len(p['fwd']) != 1:
             return False
         g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
         return bool(nv.query('segnb_conv_wgrad_bnapply_ok', g, self.rt.code))

@@ -65,7 +65,8 @@ class _Recorder(object):
 
 def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
     ref, got = ref.double(), got.double().cpu()
-    if (name == 'segnb_conv_wgrad' and pos == 4) or (name == 'segnb_conv_wgrad_tf' and pos == 6):
+    if (name == 'segnb_conv_wgrad' and pos == 4) or (name == 'segnb_conv_wgrad_tf' and pos == 6) or \
+            (name == 'segnb_conv_wgrad_bnapply' and pos == 12):
         # the result is slab 0; the other slabs are scratch (and their COUNT differs between emulator and device)
         ref, got = ref.view(nslab[0], -1)[0], got.view(nslab[1], -1)[0]
     if name == 'segnb_conv_wgrad_partial' and pos == 4:
@@ -147,7 +148,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
                     # the weight-gradient workspace: slab counts differ between emulator and device; its
                     # pre-state is (consumed) zeros or dead partials on both sides
                     assert (name in ('segnb_conv_wgrad', 'segnb_conv_wgrad_partial', 'segnb_unpack_wgrad') and p in (0, 4)) or \
-                        (name == 'segnb_conv_wgrad_tf' and p == 6), (idx, name, p)
+                        (name == 'segnb_conv_wgrad_tf' and p == 6) or (name == 'segnb_conv_wgrad_bnapply' and p == 12), (idx, name, p)
                     continue
                 t.copy_(rt.to(t.device))
         orig_call(name, *args)
@@ -171,6 +172,8 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
             nslab = (rec.forced[idx][3][5], args[5]) if name in ('segnb_conv_wgrad', 'segnb_conv_wgrad_partial') else (1, 1)
             if name == 'segnb_conv_wgrad_tf':
                 nslab = (rec.forced[idx][3][7], args[7])
+            if name == 'segnb_conv_wgrad_bnapply':
+                nslab = (rec.forced[idx][3][13], args[13])
             ok, bad, worst = _cmp(name, p, rt, t, tol * (5 if loose and rt.dtype == torch.float64 else 1),
                                   3 if loose else 0, atol, nslab)
             if not ok:

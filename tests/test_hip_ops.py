@@ -83,6 +83,10 @@ CONV_CASES = [
     ('roll 3x3 p0 co24', 1, 36, 70, [(32, 32)],            24, 3, 1, 0, False),
     ('roll 32->64',      2, 33, 47, [(32, 32)],            64, 3, 1, 1, False),
     ('roll 64->32',      2, 33, 47, [(64, 64)],            32, 3, 1, 1, False),
+    # the first layer's rolling weight gradient (wgrad_roll.hip: conv_wgrad_c8roll_kernel, 8 padded input channels, rows of >= 32
+    # pixels): ragged strips and row segments, 24 and 16 output channels (one or two 16-channel halves per wave)
+    ('c8 roll ragged',   2, 37, 75, [(3, 8)],              24, 3, 1, 1, False),
+    ('c8 roll co16',     3, 9,  40, [(5, 8)],              16, 3, 1, 1, False),
     # stride-1 3x3 shapes that take the transposing-LDS-read weight-gradient kernel (wgrad_s1.hip)
     ('3x3 s1x9 thin',    2, 21, 37, [(32, 32)],            32, 3, 1, 1, False),
     ('3x3 s1x9 thin cat', 1, 16, 56, [(64, 64), (30, 32)], 24, 3, 1, 1, False),
@@ -1034,7 +1038,7 @@ def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
     apply pass disappears) == segnb_bn_bwd_apply_direct followed by segnb_conv_wgrad, bit for bit; incl. the first layer
     of the timed configuration (bs=32 224x224, 3 -> 32)."""
     N, H, W, Ci, Co, act = shape
-    monkeypatch.setenv('SEGNB_WGRAD_BNAPPLY', '1')     # (off by default: measured neutral in the training step)
+    monkeypatch.setenv('SEGNB_WGRAD_BNAPPLY', '1')     # (default: only the first layer's rolling kernel -- 8 input channels)
     rt = Runtime('cuda', 'bf16')
     gen = torch.Generator().manual_seed(H * 3 + Co)
     w = torch.randn(Co, Ci, 3, 3, generator=gen).cuda()
@@ -1052,6 +1056,11 @@ def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
     bcoef = torch.stack([0.5 + torch.rand(Cp, generator=gen), 0.1 * torch.randn(Cp, generator=gen),
                          0.1 * torch.randn(Cp, generator=gen)]).cuda()
     assert op.wgrad_bnapply_ok(xv, yv)
+    monkeypatch.delenv('SEGNB_WGRAD_BNAPPLY')
+    assert op.wgrad_bnapply_ok(xv, yv) == (Cip == 8 and W >= 32)
+    monkeypatch.setenv('SEGNB_WGRAD_BNAPPLY', '0')
+    assert not op.wgrad_bnapply_ok(xv, yv)
+    monkeypatch.setenv('SEGNB_WGRAD_BNAPPLY', '1')
     slope = 0.01
     dz = View.alloc(rt, N, H, W, Cp)
     nv.call('segnb_bn_bwd_apply_direct', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), nv.ptr(bcoef), act, slope,
