@@ -1176,6 +1176,8 @@ class Stage(object):
                     nv.ptr(self.coef), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
                     nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), rt.stream)
             self._stats_stale = False
+            if flush_before_wgrad:
+                rt.flush_postponed(flush_before_wgrad)      # (see below: held-back weight gradients run beside this one)
             self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
             return False
         if has_bn and self._fused_fwd and direct:
