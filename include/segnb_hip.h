@@ -148,6 +148,18 @@ int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_blocks, segn
  * of linknet.py:13-20 / dilated_resnet.py, the 4 x 4 ConvTranspose2d of unet16.py:40-47): element-wise kernels,
  * segnb_pack_elem_job_blocks(Mp, Cp, ntaps) blocks per job; unpack ADDS to the gradient and clears the workspace */
 int segnb_pack_elem_job_blocks(int Mp, int Cp, int ntaps);
+/* BOTH matrices of a plain 3x3 convolution from one read of its parameter (bf16 only): what the reference's
+ * nn.Conv2d(ci, co, 3) weight (lib/models/zf_unet.py:5-32) becomes at every step's start -- the forward matrix
+ * [Cop][9][Cip] and the data-gradient matrix [Cip][9][Cop].  `jobs`: DEVICE array of records, each
+ * segnb_pack_pair_job_bytes() long:
+ *   { const float* w; void* packed_fwd; void* packed_dgrad; int32 Ci, Co, Cip, Cop, block_start, pad;
+ *     int32 tap_fwd[9], tap_dgrad[9]; }      (tap_*[t] = kernel position kh * 3 + kw of packed tap t)
+ * sorted by block_start; a job owns segnb_pack_pair_job_blocks(Co, Ci, Cop, Cip) blocks (-1: bad shape).  packed_dgrad may be
+ * NULL (a layer without a data gradient: forward matrix only).  Real channel c is packed channel c; the padding channels are
+ * written as zeros. */
+int segnb_pack_pair_job_bytes(void);
+int segnb_pack_pair_job_blocks(int Co, int Ci, int Cop, int Cip);
+int segnb_pack_weight_pair_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 int segnb_pack_weight_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 int segnb_unpack_wgrad_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 

@@ -513,6 +513,33 @@ class AbiEmulator(object):
                                     int(j['mmap']), int(j['cmap']), 1, stream)
         return 0
 
+    # both matrices of a plain 3x3 convolution from one job record (segnb_pack_weight_pair_multi)
+    PAIR_JOB = np.dtype([('w', '<u8'), ('pf', '<u8'), ('pd', '<u8'), ('Ci', '<i4'), ('Co', '<i4'), ('Cip', '<i4'), ('Cop', '<i4'),
+                         ('block_start', '<i4'), ('pad_', '<i4'), ('tapf', '<i4', (9,)), ('tapd', '<i4', (9,))])
+
+    def segnb_pack_pair_job_bytes(self):
+        return self.PAIR_JOB.itemsize
+
+    def segnb_pack_pair_job_blocks(self, Co, Ci, Cop, Cip):
+        if Co <= 0 or Ci <= 0 or Cop < Co or Cip < Ci or Cop % 8 or Cip % 8:
+            return -1
+        return ((Cop + 31) // 32) * ((Cip + 63) // 64)
+
+    def segnb_pack_weight_pair_multi(self, jobs, njobs, total_blocks, stream):
+        raw = bytes((ctypes.c_char * (njobs * self.PAIR_JOB.itemsize)).from_address(int(jobs)))
+        for j in np.frombuffer(raw, dtype=self.PAIR_JOB):
+            Ci, Co, Cip, Cop = int(j['Ci']), int(j['Co']), int(j['Cip']), int(j['Cop'])
+            W = _mem(int(j['w']), Co * Ci * 9, torch.float32).view(Co, Ci, 9)
+            F = _mem(int(j['pf']), Cop * 9 * Cip, torch.bfloat16).view(Cop, 9, Cip)
+            F.zero_()
+            tf = torch.tensor([int(v) for v in j['tapf']]), torch.tensor([int(v) for v in j['tapd']])
+            F[:Co, :, :Ci] = W[:, :, tf[0]].permute(0, 2, 1).to(torch.bfloat16)
+            if int(j['pd']):                # (NULL: a layer without a data gradient)
+                D = _mem(int(j['pd']), Cip * 9 * Cop, torch.bfloat16).view(Cip, 9, Cop)
+                D.zero_()
+                D[:Ci, :, :Co] = W[:, :, tf[1]].permute(1, 2, 0).to(torch.bfloat16)
+        return 0
+
     # element-wise batched forms (jobs segnb_pack_job_blocks refuses): the single-job calls, job by job
     def segnb_pack_elem_job_blocks(self, Mp, Cp, ntaps):
         if Mp <= 0 or Cp <= 0 or ntaps < 1 or ntaps > 64:

@@ -777,13 +777,17 @@ struct __attribute__((aligned(8))) PackJob {
     int tap_off[SEGNB_MAX_TAPS];
 };
 
-__device__ __forceinline__ int find_job(const PackJob* jobs, int njobs, int b) {
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+// the job that owns block b (block_start ascending, job 0 starts at 0): every wave counts the starts <= b, 64 jobs per round trip
+// (a binary search was log2(njobs) DEPENDENT loads -- 6 for ZF_UNET's 46 jobs, most of a small tile's life)
+template <typename Job>
+__device__ __forceinline__ int find_job(const Job* jobs, int njobs, int b) {
+    const int lane = threadIdx.x & 63;
+    int cnt = 0;
+    for (int k = 0; k < njobs; k += 64) {
+        const bool le = k + lane < njobs && jobs[k + lane].block_start <= b;
+        cnt += __popcll(__ballot(le));
     }
-    return lo;
+    return __builtin_amdgcn_readfirstlane(cnt - 1);
 }
 
 // Tiled through LDS so that BOTH sides are coalesced.  The parameter tensor has the tap index fastest
@@ -1108,6 +1112,100 @@ __global__ __launch_bounds__(256) void pack_tiled_kernel(const PackJob* __restri
     for (int b = blockIdx.x; b < total; b += gridDim.x) {
         pack_tile<IS_PACK>(jobs, njobs, b, tile, sFast, sSlow, sCnt);
         if (b + (int)gridDim.x < total) __syncthreads();
+    }
+}
+
+// BOTH matrices of a plain 3 x 3 convolution from ONE read of its parameter (bf16): the forward matrix [Cop][9][Cip] and the
+// data-gradient matrix [Cip][9][Cop] (kernel positions in each form's own tap order).  At every step's start the two tiled
+// packs above read each fp32 parameter twice and their 9-KB tiles are a chain of dependent round trips (ZF_UNET: 88 us for
+// 252 MB read + 123 MB written, tools/pack_bench.py); here a block owns 32 output x 64 input channels (72 KB of the
+// parameter, 18 float4 loads per lane issued together), rounds once into an LDS tile and writes both forms from it in
+// 128-byte / 64-byte runs.  Channels are in place (no maps: real channel c = packed channel c, padding behind them).
+struct PackPairJob {
+    const float* w;        // [Co][Ci][3][3]
+    void* pf;              // bf16 [Cop][9][Cip]
+    void* pd;              // bf16 [Cip][9][Cop], or NULL: forward matrix only
+    int Ci, Co, Cip, Cop;
+    int block_start, pad_;
+    int tapf[9], tapd[9];  // kernel position kh * 3 + kw of packed tap t of either form
+};
+constexpr int PP_CO = 32, PP_CI = 64;
+constexpr int PP_RS = PP_CI * 9 + 4;          // LDS row in bf16 elements (rows 8-byte aligned; 8 rows apart = 16 banks apart)
+constexpr int PP_LOADS = PP_CO * PP_CI * 9 / 4 / 256;
+
+__global__ __launch_bounds__(256) void pack_pair_kernel(const PackPairJob* __restrict__ jobs, int njobs) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[PP_CO * PP_RS];
+    const PackPairJob& j = jobs[find_job(jobs, njobs, (int)blockIdx.x)];
+    const int tb = blockIdx.x - j.block_start;
+    const int nci = (j.Cip + PP_CI - 1) / PP_CI;
+    const int ci0 = (tb % nci) * PP_CI, co0 = (tb / nci) * PP_CO;
+    const int Ci = j.Ci, Co = j.Co, Cip = j.Cip, Cop = j.Cop;
+    const int nv = min(PP_CI, Ci - ci0);                    // real input channels of the tile (a multiple of 4, maybe <= 0)
+    const int run4 = nv > 0 ? nv * 9 / 4 : 0;               // float4 per parameter row
+    constexpr int ROW4 = PP_CI * 9 / 4;
+    float4 v[PP_LOADS];
+    if ((Ci & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < PP_LOADS; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            const int co_l = i / ROW4, r = i - co_l * ROW4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < run4 && co0 + co_l < Co)
+                v[u] = *reinterpret_cast<const float4*>(j.w + ((long long)(co0 + co_l) * Ci + ci0) * 9 + 4 * r);
+        }
+    } else {
+        // rows that are not 16-byte aligned (the first layer: 3 input channels): element loads, same tile image
+        const int runf = nv > 0 ? nv * 9 : 0;
+#pragma unroll
+        for (int u = 0; u < PP_LOADS; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            const int co_l = i / ROW4, r = i - co_l * ROW4;
+            const float* row = j.w + ((long long)(co0 + co_l) * Ci + ci0) * 9 + 4 * r;
+            const bool in = co0 + co_l < Co;
+            v[u].x = (in && 4 * r < runf) ? row[0] : 0.f;
+            v[u].y = (in && 4 * r + 1 < runf) ? row[1] : 0.f;
+            v[u].z = (in && 4 * r + 2 < runf) ? row[2] : 0.f;
+            v[u].w = (in && 4 * r + 3 < runf) ? row[3] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PP_LOADS; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int co_l = i / ROW4, r = i - co_l * ROW4;
+        uint2 pk;
+        pk.x = pack2bf(v[u].x, v[u].y);
+        pk.y = pack2bf(v[u].z, v[u].w);
+        *reinterpret_cast<uint2*>(tile + co_l * PP_RS + 4 * r) = pk;
+    }
+    __syncthreads();
+    unsigned short* const pf = reinterpret_cast<unsigned short*>(j.pf);
+    unsigned short* const pd = reinterpret_cast<unsigned short*>(j.pd);
+    // forward form: (co, t) rows of 64 input channels, 8 per lane
+    for (int gi = threadIdx.x; gi < PP_CO * 9 * (PP_CI / 8); gi += 256) {
+        const int c8 = gi % (PP_CI / 8), t = (gi / (PP_CI / 8)) % 9, co_l = gi / (9 * (PP_CI / 8));
+        const int co = co0 + co_l, ci = ci0 + c8 * 8;
+        if (co >= Cop || ci >= Cip) continue;
+        const unsigned short* src = tile + co_l * PP_RS + c8 * 72 + j.tapf[t];
+        uint4 o;
+        o.x = (unsigned)src[0] | ((unsigned)src[9] << 16);
+        o.y = (unsigned)src[18] | ((unsigned)src[27] << 16);
+        o.z = (unsigned)src[36] | ((unsigned)src[45] << 16);
+        o.w = (unsigned)src[54] | ((unsigned)src[63] << 16);
+        *reinterpret_cast<uint4*>(pf + ((long long)co * 9 + t) * Cip + ci) = o;
+    }
+    // data-gradient form: (ci, t) rows of 32 output channels, 8 per lane (pd == NULL: a layer without a data gradient)
+    if (pd == nullptr) return;
+    for (int gi = threadIdx.x; gi < PP_CI * 9 * (PP_CO / 8); gi += 256) {
+        const int o8 = gi % (PP_CO / 8), t = (gi / (PP_CO / 8)) % 9, ci_l = gi / (9 * (PP_CO / 8));
+        const int ci = ci0 + ci_l, co = co0 + o8 * 8;
+        if (ci >= Cip || co >= Cop) continue;
+        const unsigned short* src = tile + (o8 * 8) * PP_RS + ci_l * 9 + j.tapd[t];
+        uint4 o;
+        o.x = (unsigned)src[0] | ((unsigned)src[PP_RS] << 16);
+        o.y = (unsigned)src[2 * PP_RS] | ((unsigned)src[3 * PP_RS] << 16);
+        o.z = (unsigned)src[4 * PP_RS] | ((unsigned)src[5 * PP_RS] << 16);
+        o.w = (unsigned)src[6 * PP_RS] | ((unsigned)src[7 * PP_RS] << 16);
+        *reinterpret_cast<uint4*>(pd + ((long long)ci * 9 + t) * Cop + co) = o;
     }
 }
 
@@ -1792,6 +1890,22 @@ extern "C" int segnb_unpack_wgrad_multi(const void* jobs, int njobs, int total_b
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
     hipLaunchKernelGGL(pack_tiled_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const PackJob*)jobs, njobs, total_blocks);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_pack_pair_job_bytes(void) { return (int)sizeof(PackPairJob); }
+
+// blocks of one pair job, or -1 when the shape is not served (the two single-form jobs of segnb_pack_weight_multi then)
+extern "C" int segnb_pack_pair_job_blocks(int Co, int Ci, int Cop, int Cip) {
+    if (Co <= 0 || Ci <= 0 || Cop < Co || Cip < Ci || Cop % 8 != 0 || Cip % 8 != 0) return -1;
+    return ((Cop + PP_CO - 1) / PP_CO) * ((Cip + PP_CI - 1) / PP_CI);
+}
+
+extern "C" int segnb_pack_weight_pair_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_pack_weight_pair_multi, jobs, njobs, total_blocks, stream);
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
+    hipLaunchKernelGGL(pack_pair_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackPairJob*)jobs, njobs);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

@@ -291,8 +291,14 @@ class _ZFUnetPlan(object):
             elif self.PACK_OVERLAP or os.environ.get('SEGNB_PACK_SPLIT', '0') != '0':
                 packs = (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
                          PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'))
-            else:                                    # everything on the main stream: ONE launch
-                packs = (PackTable(self.rt, pj_early + pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'), None)
+            else:
+                # main stream: ONE launch of pair jobs (both matrices of a layer from one read of its parameter) + one of what
+                # they do not take.  The data-gradient matrices among the latter (the segmented decoder levels: masked jobs with
+                # few, slow blocks, 20 us of the step's start) are not needed before the backward: side stream, when there is one
+                defer = (lambda j: j.get('form') == 'd') if (self.LEFTOVER_DG_SIDE and self.rt.side_stream() is not None) else None
+                main = PackTable(self.rt, pj_early + pj, 'segnb_pack_weight_multi', 'segnb_pack_weight', defer=defer)
+                late = PackTable(self.rt, main.deferred, 'segnb_pack_weight_multi', 'segnb_pack_weight') if main.deferred else None
+                packs = (main, late)
             t = (key, packs, tuple(unpacks), tuple(los))
             self._pack_tables[(N, H, W)] = t
         return t
@@ -334,8 +340,10 @@ class _ZFUnetPlan(object):
         # (first convolution 37 -> 100 us): what the side stream takes off the main one comes back as slower kernels on it.
         early, late = self._tables(H, W, N)[1]
         early.run()
-        side = self.rt.side_stream() if (self.PACK_OVERLAP or self.PACK_DG_SIDE) else None
-        self._dg_pack_on_side = bool(self.PACK_DG_SIDE and side is not None)
+        side = self.rt.side_stream() if (self.PACK_OVERLAP or self.PACK_DG_SIDE or self.LEFTOVER_DG_SIDE) else None
+        self._dg_pack_on_side = bool((self.PACK_DG_SIDE or self.LEFTOVER_DG_SIDE) and side is not None)
+        if late is None:
+            side = None
         if side is not None:
             nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
             with torch.cuda.stream(side):
@@ -347,6 +355,7 @@ class _ZFUnetPlan(object):
     PACK_EARLY = 8
     PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
     PACK_DG_SIDE = os.environ.get('SEGNB_PACK_DG_SIDE', '0') != '0'
+    LEFTOVER_DG_SIDE = os.environ.get('SEGNB_PACK_LEFTOVER_SIDE', '1') != '0'      # (see _tables)
     TAIL_POSTPONE = os.environ.get('SEGNB_TAIL_POSTPONE', '0') != '0'
     DROP_ON_SIDE = os.environ.get('SEGNB_DROP_ON_SIDE', '0') != '0'      # Dropout2d masks drawn on the side stream (measured +-0 or slower: off)
     _drop_wait = None
@@ -661,7 +670,7 @@ class _ZFUnetPlan(object):
         try:
             if self.BWD_CONV_CU_PCT != 100:
                 nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
-            if self.PACK_DG_SIDE and rt.side_stream() is not None:
+            if (self.PACK_DG_SIDE or (self.LEFTOVER_DG_SIDE and not self.PACK_OVERLAP)) and rt.side_stream() is not None:
                 # the data gradients' matrices were packed on the side stream (recorded: a replayed list waits too)
                 nv.call('segnb_stream_join', rt.stream, rt.side_stream().cuda_stream)
             head = self.module.conv_final

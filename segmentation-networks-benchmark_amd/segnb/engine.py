@@ -901,6 +901,17 @@ PACK_JOB_DTYPE = np.dtype([('w', '<u8'), ('packed', '<u8'), ('mmap', '<u8'), ('c
                            ('tap_off', '<i4', (nv.MAX_TAPS,))])
 
 
+PACK_PAIR_DTYPE = np.dtype([('w', '<u8'), ('pf', '<u8'), ('pd', '<u8'), ('Ci', '<i4'), ('Co', '<i4'), ('Cip', '<i4'),
+                            ('Cop', '<i4'), ('block_start', '<i4'), ('pad_', '<i4'), ('tapf', '<i4', (9,)), ('tapd', '<i4', (9,))])
+
+
+def _identity_prefix(m):
+    """n when the channel map is 0 .. n-1 followed by padding (-1) only, else None"""
+    v = m.detach().cpu().tolist()
+    n = sum(1 for x in v if x >= 0)
+    return n if v[:n] == list(range(n)) else None
+
+
 class PackTable(object):
     """Device-side job table for segnb_pack_weight_multi / segnb_unpack_wgrad_multi: every weight matrix of a
     model packed (or every gradient unpacked) by ONE launch.  jobs: dicts with the fields of PACK_JOB_DTYPE
@@ -909,11 +920,23 @@ class PackTable(object):
     # SEGNB_PACK_ELEM_MULTI=0: the jobs the tiled kernel refuses as one ctypes call + launch each (A/B)
     elem_multi = os.environ.get('SEGNB_PACK_ELEM_MULTI', '1') != '0'
 
-    def __init__(self, rt, jobs, entry, single_entry):
+    def __init__(self, rt, jobs, entry, single_entry, defer=None):
+        """defer: predicate over the jobs that stay with the single-form kernels; those it selects are NOT put in this table but
+        returned in self.deferred (the caller runs them from a table of their own, e.g. on another stream)"""
         assert PACK_JOB_DTYPE.itemsize == nv.query('segnb_pack_job_bytes'), 'PackJob layout drifted from the ABI'
         rows, self.singles, self._keep = [], [], []
         erows, eblocks = [], 0               # element-wise batched table (parameter tensors wider than 3 x 3)
         blocks = 0
+        # the masked jobs (UpConvOp: a packed tap sums several kernel positions) have few, slow blocks: FIRST in the table, their
+        # blocks start with the launch and end inside it -- at the end of the table they were a 14 us tail of ZF_UNET's 102 us pack
+        # (tools/pack_bench.py: 3 jobs, 336 of 21168 blocks)
+        jobs = sorted(jobs, key=lambda j: 0 if j.get('masked') else 1)
+        self.ptable, self.pn, self.pblocks, self.paired_ids = None, 0, 0, set()
+        if entry == 'segnb_pack_weight_multi' and self.pair_pack:
+            jobs = self._pair(rt, jobs)
+        self.deferred = [j for j in jobs if defer(j)] if defer is not None else []
+        if self.deferred:
+            jobs = [j for j in jobs if not defer(j)]
         for j in jobs:
             nb = nv.query('segnb_pack_job_blocks', j['Mp'], j['Cp'], j['ntaps'], j['s_m'], j['s_c'])
             if nb < 0:                       # kernels wider than 3x3: the element-wise kernels, still ONE launch for all of them
@@ -956,7 +979,59 @@ class PackTable(object):
             tab = np.array(erows, dtype=PACK_JOB_DTYPE)
             self.etable = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
 
+    # SEGNB_PACK_PAIR=0: every matrix by its own job (A/B)
+    pair_pack = os.environ.get('SEGNB_PACK_PAIR', '1') != '0'
+
+    def _pair(self, rt, jobs):
+        """The forward and the data-gradient matrix of a plain 3x3 convolution (ConvOp.pack_jobs: form 'f' / 'd' on the same
+        parameter, channels in place) as ONE job of segnb_pack_weight_pair_multi: the parameter is read once.  Returns the jobs
+        that stay with the single-form kernels."""
+        by_w = {}
+        for j in jobs:
+            if (j.get('form') in ('f', 'd') and not j.get('masked') and j['ntaps'] == 9 and j['dtype'] == nv.BF16
+                    and j.get('nslab', 1) == 1 and sorted(j['tap_off']) == list(range(9))):
+                by_w.setdefault(j['w'].data_ptr(), []).append(j)
+        rows, taken, blocks = [], set(), 0
+        for js in by_w.values():
+            fs = [j for j in js if j['form'] == 'f']
+            if len(fs) != 1:
+                continue
+            jf = fs[0]
+            ci, co = _identity_prefix(jf['cmap']), _identity_prefix(jf['mmap'])
+            if ci is None or co is None or jf['s_c'] != 9 or jf['s_m'] != 9 * ci or jf['w'].numel() != co * ci * 9:
+                continue
+            # the data-gradient matrix of the same parameter, channels in place too (a segmented data gradient -- UpCatConvOp --
+            # keeps its own jobs: the forward matrix is then packed alone)
+            ds = [j for j in js if j['form'] == 'd' and j['s_m'] == 9 and j['s_c'] == 9 * ci and j['Mp'] == jf['Cp']
+                  and j['Cp'] == jf['Mp'] and j['mmap'] is jf['cmap'] and j['cmap'] is jf['mmap']]
+            jd = ds[0] if len(ds) == 1 else None
+            nb = nv.query('segnb_pack_pair_job_blocks', co, ci, jf['Mp'], jf['Cp'])
+            if nb < 0:
+                continue
+            row = np.zeros((), dtype=PACK_PAIR_DTYPE)
+            row['w'], row['pf'] = jf['w'].data_ptr(), jf['packed'].data_ptr()
+            row['pd'] = jd['packed'].data_ptr() if jd is not None else 0
+            self._keep += [jf['w'], jf['packed']] + ([jd['packed']] if jd is not None else [])
+            row['Ci'], row['Co'], row['Cip'], row['Cop'] = ci, co, jf['Cp'], jf['Mp']
+            row['tapf'][:] = jf['tap_off']
+            row['tapd'][:] = jd['tap_off'] if jd is not None else jf['tap_off']
+            row['block_start'] = blocks
+            blocks += nb
+            rows.append(row)
+            taken.add(id(jf))
+            if jd is not None:
+                taken.add(id(jd))
+        if rows:
+            assert PACK_PAIR_DTYPE.itemsize == nv.query('segnb_pack_pair_job_bytes'), 'PackPairJob layout drifted from the ABI'
+            tab = np.array(rows, dtype=PACK_PAIR_DTYPE)
+            self.ptable = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
+            self.pn, self.pblocks = len(rows), blocks
+        self.paired_ids = taken
+        return [j for j in jobs if id(j) not in taken]
+
     def run(self):
+        if self.ptable is not None:
+            nv.call('segnb_pack_weight_pair_multi', nv.ptr(self.ptable), self.pn, self.pblocks, self.rt.stream)
         if self.table is not None:
             nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
         if self.etable is not None:

@@ -685,6 +685,49 @@ def test_sgd_and_input_pack():
         assert float(out[..., 3:8].abs().max()) == 0.0 and float((out[..., 8:] - 7).abs().max()) == 0.0
 
 
+def test_both_matrices_of_a_convolution_from_one_read():
+    """segnb_pack_weight_pair_multi: the forward matrix [Cop][9][Cip] and the data-gradient matrix [Cip][9][Cop] of a plain
+    nn.Conv2d(ci, co, 3) weight (lib/models/zf_unet.py:5-32) from ONE read of the parameter == the two single-form packs, bit
+    for bit, incl. ragged tiles (co not a multiple of 32, ci not of 64), padded channels (written as zeros) and the widest
+    layers of the timed configuration, rows that are not 16-byte aligned (3 and 5 input channels) and a layer without a data
+    gradient; remapped channels (a padded concat) stay with the tiled pack."""
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(3)
+    specs = [([(32, 32)], 32, True), ([(4, 8)], 8, True), ([(100, 104)], 70, True), ([(64, 64), (32, 32)], 40, True),
+             ([(1024, 1024)], 512, True), ([(192, 192)], 200, True), ([(3, 8)], 32, True), ([(12, 16), (6, 8)], 16, False),
+             ([(30, 32)], 24, True), ([(5, 8)], 16, True)]
+    ops, pj = [], []
+    for k, (segs, co, _) in enumerate(specs):
+        ci = sum(r for r, _ in segs)
+        w = torch.randn(co, ci, 3, 3, generator=gen).cuda()
+        op = ConvOp(rt, w, None, segs, 1, 1, False, k != len(specs) - 1)      # (the last one: no data gradient, forward matrix only)
+        op.plan(16, 16)
+        ops.append(op)
+        pj += op.pack_jobs(16, 16)
+    mats = lambda op: op.plan(16, 16)['wp_fwd'] + op.plan(16, 16).get('wp_dg', [])
+    keep = PackTable.pair_pack
+    try:
+        PackTable.pair_pack = False
+        t0 = PackTable(rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight')
+        assert t0.pn == 0
+        t0.run()
+        torch.cuda.synchronize()
+        ref = [[t.clone() for t in mats(op)] for op in ops]
+        for op in ops:
+            for t in mats(op):
+                t.fill_(7.0)
+        PackTable.pair_pack = True
+        t1 = PackTable(rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight')
+        assert t1.pn == sum(1 for s in specs if s[2]), t1.pn
+        t1.run()
+        torch.cuda.synchronize()
+    finally:
+        PackTable.pair_pack = keep
+    for op, r, spec in zip(ops, ref, specs):
+        for t, rr in zip(mats(op), r):
+            assert torch.equal(t, rr), spec
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_batched_pack_unpack_equals_single_job_calls(dtype):
     """segnb_pack_weight_multi / segnb_unpack_wgrad_multi (LDS-tiled, one launch for many matrices) vs the
