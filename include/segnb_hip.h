@@ -332,6 +332,18 @@ int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, i
                                     float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
                                     float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
 
+/* Reduction + finalize + apply of a SMALL tensor in ONE launch: a block owns an 8-channel group and holds every pixel of it in
+ * registers (segnb_bn_bwd_owner_ok: N*H*W <= 8192 for bf16, 4096 for f32 -- the 14x14 / 7x7 levels of ZF_UNET at bs=32), so
+ * lib/modules/abn/functions.py:95-130's two sums, (a, c1, c2), dgamma / dbeta and dy = a (dz - c1 - yhat c2) with
+ * dz = round(g act'(z)) need no sums buffer, no atomics and a single read of y and g.  Single direct gradient source, no
+ * Dropout2d multiplier; the same values as segnb_bn_act_bwd_reduce (dz = NULL) + segnb_bn_bwd_apply_fused_direct up to the order
+ * of the sums (fp32 per thread, fp64 across the block, fixed order).  dy may alias g. */
+int segnb_bn_bwd_owner_ok(int dtype, int N, int H, int W, int Cp);
+int segnb_bn_bwd_owner(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
+                       const float* gamma, float* bcoef, float* dgamma, float* dbeta, int accumulate,
+                       double* fwd_stats_to_clear, int act, float slope, const void* g, int ld_g, void* dy, int ld_dy,
+                       segnb_stream_t stream);
+
 /* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a.
  * A NULL operand counts as zeros: (NULL, b) copies b, (NULL, NULL) clears out -- the strided copies / clears of the
  * executor as recordable launches (segnb_plan_*) */

@@ -794,6 +794,21 @@ class AbiEmulator(object):
         return rc or self.segnb_bn_bwd_apply_direct(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy,
                                                     ld_dy, None, C, stream)
 
+    def segnb_bn_bwd_owner_ok(self, dtype, N, H, W, Cp):
+        if os.environ.get('SEGNB_BN_OWNER', '0') == '0' or min(N, H, W, Cp) <= 0 or Cp % 8:
+            return 0
+        return int(N * H * W <= (8192 if dtype == BF16 else 4096))
+
+    def segnb_bn_bwd_owner(self, dtype, y, ld_y, N, H, W, C, Cp, coef, gamma, bcoef, dgamma, dbeta, accumulate, clear_stats,
+                           act, slope, g, ld_g, dy, ld_dy, stream):
+        """reduction (sums only, into a scratch buffer) + finalize + direct apply: one launch on the device"""
+        sums = torch.zeros(REPL * 2 * Cp, dtype=torch.float64)
+        rc = self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, None, g, ld_g, None, 0, None, 0,
+                                          None, 0, sums.data_ptr(), None, 0, stream)
+        return rc or self.segnb_bn_bwd_apply_fused_direct(dtype, y, ld_y, N, H, W, C, Cp, coef, sums.data_ptr(), gamma, bcoef,
+                                                          dgamma, dbeta, accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy,
+                                                          stream)
+
     def segnb_bn_bwd_apply_fused_direct_acc(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
                                             accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream):
         dt = _tdt(dtype)

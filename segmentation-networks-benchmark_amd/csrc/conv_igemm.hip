@@ -1669,10 +1669,6 @@ extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
     if (check_geom(g)) return -1;
     if (dtype == SEGNB_BF16 && !wgrad_general_only()) {
         const int s = segnb_wgrad_s1_slabs(g);
-        if (s > 0 && segnb_knob_wgrad_c8roll() && segnb_wgrad_c8roll_applies(g)) {
-            static const int c8s = getenv("SEGNB_C8ROLL_SLABS") ? atoi(getenv("SEGNB_C8ROLL_SLABS")) : 0;
-            if (c8s > 0) return c8s;
-        }
         if (s > 0) return s;
         const int sx = segnb_wgrad_sx_slabs(g);
         if (sx > 0) return sx;

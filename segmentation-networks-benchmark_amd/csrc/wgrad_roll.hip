@@ -654,7 +654,8 @@ int launch_c8roll_coh(WRollArgs& a, int nslab, hipStream_t stream) {
     }();
     // 8 waves of <= 256 registers (the recomputing variant holds 56 constants and two operand streams: 192); the plain variant
     // takes the same partition, so that both sum in the same order (segnb_conv_wgrad_bnapply == apply pass + segnb_conv_wgrad
-    // bit for bit).  Measured (tools/c8_bench.py, us incl. the 6.7 us slab reduction): 8 waves 40.3 / 59.7, 16 waves 50.0 / 273.6
+    // bit for bit).  Measured (tools/c8_bench.py, us incl. the 6.7 us slab reduction): 8 waves 40.3 / 59.7, 16 waves 50.0 / 273.6;
+    // 4-wave blocks on 512 slabs (two per CU, could share a CU with the side stream's kernels): 52.7 alone, +-0 in the step
     const bool w16 = nw == 16;
     if (w16) return dl == 4 ? launch_c8roll_nw<TFD, 4, 16, COH>(a, nslab, stream) : launch_c8roll_nw<TFD, 2, 16, COH>(a, nslab, stream);
     return dl == 4 ? launch_c8roll_nw<TFD, 4, 8, COH>(a, nslab, stream) : launch_c8roll_nw<TFD, 2, 8, COH>(a, nslab, stream);

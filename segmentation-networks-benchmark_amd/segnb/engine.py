@@ -1053,6 +1053,8 @@ class Stage(object):
     follow it at :31,:41,:42.)"""
 
     direct_apply = os.environ.get('SEGNB_BN_DIRECT_APPLY', '1') != '0'
+    # segnb_bn_bwd_owner for small tensors: OFF (measured slower than the two launches it replaces, see norm_act.hip)
+    bn_owner = os.environ.get('SEGNB_BN_OWNER', '0') != '0'
     # Layers whose gradient has several sources, a pooled source or a Dropout2d multiplier: dz need not be stored either -- the
     # apply pass re-reads the sources and recomputes it (segnb_bn_bwd_apply_fused_src: one tensor write and one read less per
     # layer) for tensors of at least this many MB.  OFF (0) by default: measured on MI355X at 32 MB (the 224 x 224 / 112 x 112
@@ -1235,14 +1237,18 @@ class Stage(object):
         mb = yv.N * yv.H * yv.W * self.Cp * (2 if rt.code == nv.BF16 else 4) / 1e6
         recompute = (not direct and not dz_ready and has_bn and self._fused_fwd and self.recompute_dz_min_mb > 0
                      and mb >= self.recompute_dz_min_mb)
-        if not reduced and not dz_ready:
+        # a small tensor with one direct gradient source: reduction, finalize and apply are ONE launch (segnb_bn_bwd_owner: a block
+        # owns an 8-channel group and keeps its pixels in registers)
+        owner = bool(direct and self._fused_fwd and not reduced and self.bn_owner
+                     and nv.query('segnb_bn_bwd_owner_ok', rt.code, yv.N, yv.H, yv.W, self.Cp))
+        if not reduced and not dz_ready and not owner:
             nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                     self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
                     vptr(g_up), vld(g_up), None if (direct or recompute) else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0,
                     rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
-        if (dx is None and direct and self._fused_fwd and self.defer_unpack and postponed is None
+        if (dx is None and direct and not owner and self._fused_fwd and self.defer_unpack and postponed is None
                 and isinstance(self.conv, ConvOp) and self.conv.wgrad_bnapply_ok(xv, yv)):
             # FIRST layer of the network: no data gradient, so the only reader of dy is this layer's weight gradient -- it
             # recomputes dy from (g, y) while staging its tiles (segnb_conv_wgrad_bnapply): the apply pass and its tensor are
@@ -1255,7 +1261,13 @@ class Stage(object):
                 rt.flush_postponed(flush_before_wgrad)      # (see below: held-back weight gradients run beside this one)
             self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
             return False
-        if has_bn and self._fused_fwd and direct:
+        if owner:
+            nv.call('segnb_bn_bwd_owner', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef),
+                    nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
+                    nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), self.act, self.slope, g_direct.ptr, g_direct.ld,
+                    dz.ptr, dz.ld, rt.stream)
+            self._stats_stale = False
+        elif has_bn and self._fused_fwd and direct:
             nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,
