@@ -626,6 +626,13 @@ int segnb_plan_end(void** plan_out, int* nops);
 int segnb_plan_run(void* plan);
 int segnb_plan_destroy(void* plan);
 int segnb_stream_fork(segnb_stream_t main_stream, segnb_stream_t side_stream);
+/* The same dependency without a marker packet between two dependent kernels of `main`: segnb_stream_fork_arm(main) BEFORE the last
+ * launch the side stream has to wait for, segnb_stream_fork_commit(main, side) after it.  When that launch is a BatchNorm-backward
+ * apply pass (segnb_bn_bwd_apply*, the launches lib/modules/abn/functions.py:118's dx precedes every weight gradient with) its
+ * completion event rides on the kernel's own dispatch; otherwise commit behaves as segnb_stream_fork.  (MI355X: +1.7 us instead of
+ * +5.5 us on the main queue per fork, tools/fork_cost.hip.)  Nothing else may be launched on `main` between that launch and commit. */
+int segnb_stream_fork_arm(segnb_stream_t main_stream);
+int segnb_stream_fork_commit(segnb_stream_t main_stream, segnb_stream_t side_stream);
 int segnb_stream_join(segnb_stream_t main_stream, segnb_stream_t side_stream);
 /* hipEventRecord(event, stream) as a recordable call: timing events inside a replayed launch list (bench.py) */
 int segnb_event_record(void* event, segnb_stream_t stream);

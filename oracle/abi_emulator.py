@@ -1129,6 +1129,12 @@ class AbiEmulator(object):
     def segnb_stream_fork(self, main, side):
         return 0
 
+    def segnb_stream_fork_arm(self, main):
+        return 0
+
+    def segnb_stream_fork_commit(self, main, side):
+        return 0
+
     def segnb_event_record(self, event, stream):
         return 0
 

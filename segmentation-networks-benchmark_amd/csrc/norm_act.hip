@@ -1584,7 +1584,7 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
     const dim3 grid = make_grid(s, items);
     const int variant = (hd ? 1 : 0) | (hp ? 2 : 0) | (hu ? 4 : 0);
 #define SEGNB_RED(TT, D, P, U, R)                                                                                   \
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U, false, R>), grid, dim3(NTHR), 0, (hipStream_t)stream, \
+    SEGNB_LAUNCH_FORKABLE((bn_act_bwd_reduce_kernel<TT, D, P, U, false, R>), grid, dim3(NTHR), 0, (hipStream_t)stream, \
                        (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
                        (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res, BnBwdParams{})
 #define SEGNB_RED_R(TT, D, U)                                                                                       \
@@ -1715,19 +1715,19 @@ static int launch_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H,
     const EwShape s = make_shape(N, H, W, Cp);
     const dim3 grid = make_grid(s, (long long)N * H * W, 1536);
     if (acc && dtype == SEGNB_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+        SEGNB_LAUNCH_FORKABLE((bn_bwd_apply_kernel<bf16_t, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp,
                            (const bf16_t*)g, ld_g, act, slope);
     else if (acc && dtype == SEGNB_F32)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
+        SEGNB_LAUNCH_FORKABLE((bn_bwd_apply_kernel<float, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
                            ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp,
                            (const float*)g, ld_g, act, slope);
     else if (dtype == SEGNB_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
+        SEGNB_LAUNCH_FORKABLE(bn_bwd_apply_kernel<bf16_t>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)y,
                            ld_y, s, coef, bcoef, (const bf16_t*)dz, ld_dz, (bf16_t*)dy, ld_dy, dbias, C, bp,
                            (const bf16_t*)g, ld_g, act, slope);
     else if (dtype == SEGNB_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
+        SEGNB_LAUNCH_FORKABLE(bn_bwd_apply_kernel<float>, grid, dim3(NTHR), 0, (hipStream_t)stream, (const float*)y,
                            ld_y, s, coef, bcoef, (const float*)dz, ld_dz, (float*)dy, ld_dy, dbias, C, bp,
                            (const float*)g, ld_g, act, slope);
     else {
@@ -1998,7 +1998,7 @@ extern "C" int segnb_bn_bwd_apply_fused_src(int dtype, const void* y, int ld_y, 
     const int variant = (hd ? 1 : 0) | (hp ? 2 : 0) | (hu ? 4 : 0);
     const BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
 #define SEGNB_APS(TT, D, P, U)                                                                                      \
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<TT, D, P, U, true>), grid, dim3(NTHR), 0, (hipStream_t)stream,    \
+    SEGNB_LAUNCH_FORKABLE((bn_act_bwd_reduce_kernel<TT, D, P, U, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, \
                        (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd,              \
                        (const TT*)g_pool, ld_gp, (const TT*)g_up, ld_gu, (TT*)dy, ld_dy, nullptr, (const TT*)nullptr, 0, bp)
 #define SEGNB_APS_ALL(TT)                                                       \

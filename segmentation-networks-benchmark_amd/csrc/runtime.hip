@@ -164,6 +164,45 @@ int wait_on(hipStream_t waiter, hipStream_t signaller, const char* who) {
     return 0;
 }
 }  // namespace
+// Armed fork: segnb_stream_fork_arm(main) before the LAST launch the side stream has to wait for, segnb_stream_fork_commit(main,
+// side) after it.  If that launch is one that can carry an event (SEGNB_LAUNCH_FORKABLE: the BatchNorm-backward apply passes) the
+// event is part of its dispatch packet and the main queue holds no marker between that kernel and the next one; otherwise -- no
+// such launch in between, or the stream is being captured into a graph -- commit is an ordinary segnb_stream_fork.
+namespace {
+thread_local hipEvent_t g_armed_ev = nullptr;
+thread_local hipStream_t g_armed_stream = nullptr;
+thread_local bool g_armed_taken = false;
+}  // namespace
+hipEvent_t segnb_take_armed_event(hipStream_t stream) {
+    if (g_armed_ev == nullptr || g_armed_taken || stream != g_armed_stream) return nullptr;
+    g_armed_taken = true;
+    return g_armed_ev;
+}
+extern "C" int segnb_stream_fork_arm(segnb_stream_t main_stream) {
+    SEGNB_PLAN_RECORD(segnb_stream_fork_arm, main_stream);
+    g_armed_ev = nullptr;
+    g_armed_taken = false;
+    static const bool off = getenv("SEGNB_FORK_ON_DISPATCH") != nullptr && getenv("SEGNB_FORK_ON_DISPATCH")[0] == '0';
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (off || hipStreamIsCapturing((hipStream_t)main_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0;
+    g_armed_ev = next_event();
+    g_armed_stream = (hipStream_t)main_stream;
+    return 0;
+}
+extern "C" int segnb_stream_fork_commit(segnb_stream_t main_stream, segnb_stream_t side_stream) {
+    SEGNB_PLAN_RECORD(segnb_stream_fork_commit, main_stream, side_stream);
+    const bool carried = g_armed_ev != nullptr && g_armed_taken && g_armed_stream == (hipStream_t)main_stream;
+    hipEvent_t ev = g_armed_ev;
+    g_armed_ev = nullptr;
+    g_armed_taken = false;
+    if (!carried) return wait_on((hipStream_t)side_stream, (hipStream_t)main_stream, "segnb_stream_fork_commit");
+    const hipError_t e = hipStreamWaitEvent((hipStream_t)side_stream, ev, 0);
+    if (e != hipSuccess) {
+        segnb_set_error("segnb_stream_fork_commit: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
 extern "C" int segnb_stream_fork(segnb_stream_t main_stream, segnb_stream_t side_stream) {
     SEGNB_PLAN_RECORD(segnb_stream_fork, main_stream, side_stream);
     return wait_on((hipStream_t)side_stream, (hipStream_t)main_stream, "segnb_stream_fork");

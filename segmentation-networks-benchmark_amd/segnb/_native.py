@@ -154,6 +154,8 @@ SIGNATURES = {
     'segnb_plan_run': [_P],
     'segnb_plan_destroy': [_P],
     'segnb_stream_fork': [_P, _P],
+    'segnb_stream_fork_arm': [_P],
+    'segnb_stream_fork_commit': [_P, _P],
     'segnb_event_record': [_P, _P],
     'segnb_stream_join': [_P, _P],
     'segnb_debug_stamps': [_P],

@@ -110,11 +110,22 @@ class Runtime(object):
             s = self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('SEGNB_SIDE_PRIORITY', '0')))
         return s
 
+    def arm_fork(self):
+        """Call right before the LAST launch a following fork_side() has to wait for: where that launch can carry an event (the
+        BatchNorm-backward apply passes) the fork costs the main queue no marker packet (segnb_stream_fork_arm / _commit)."""
+        if self.side_stream() is not None:
+            nv.call('segnb_stream_fork_arm', self.stream)
+            self._armed = True
+
     def fork_side(self):
         """-> side stream (made to wait for everything issued so far on the current stream) or None"""
         s = self.side_stream()
         if s is not None:
-            nv.call('segnb_stream_fork', self.stream, s.cuda_stream)       # (an ABI call: recordable in a launch plan)
+            if getattr(self, '_armed', False):
+                nv.call('segnb_stream_fork_commit', self.stream, s.cuda_stream)
+                self._armed = False
+            else:
+                nv.call('segnb_stream_fork', self.stream, s.cuda_stream)   # (an ABI call: recordable in a launch plan)
             self._side_busy = True
         return s
 
@@ -1261,6 +1272,9 @@ class Stage(object):
                 rt.flush_postponed(flush_before_wgrad)      # (see below: held-back weight gradients run beside this one)
             self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
             return False
+        # the weight gradient is forked to the side stream right behind the apply pass: its event rides on that launch
+        if self.defer_unpack and dx is not None and rt.side_stream() is not None and (postponed is None or flush_before_wgrad):
+            rt.arm_fork()
         if owner:
             nv.call('segnb_bn_bwd_owner', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef),
                     nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),

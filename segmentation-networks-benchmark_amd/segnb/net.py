@@ -424,7 +424,9 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
             sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
             bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
-            # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one
+            # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before the
+            # weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork)
+            rt.arm_fork()
             nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
                     oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
@@ -502,6 +504,8 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             assert direct
             oa.g_is_dz = False
         else:
+            if not has_bn and res is None:
+                rt.arm_fork()                # (no BatchNorm: this pass is the last launch before the weight gradient's fork)
             nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
                     nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
                     0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
@@ -512,6 +516,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             gamma = tape.small(site + '/geff', (C,), torch.float32) if abs_form else bn.weight      # (geff: written by the forward)
             if res is not None:             # dz is also the residual branch's gradient: keep it intact
                 dy = tape.view(site + '/dy', N, Ho, Wo, Cp)
+            if res is None and not abs_form:
+                # the apply pass is the LAST launch before the weight gradient's fork below: its event rides on that dispatch
+                # (engine.Runtime.arm_fork: no marker packet between the pass and the data gradient on this queue)
+                rt.arm_fork()
             if direct:
                 nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf),
                         nv.ptr(sums), nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(dgamma_target()),

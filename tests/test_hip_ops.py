@@ -1518,6 +1518,44 @@ def test_bn_backward_of_a_small_tensor_in_one_launch(shape, dtype, monkeypatch):
     assert float(got[0][..., C:].abs().max()) == 0.0 if Cp > C else True
 
 
+def test_fork_carried_by_the_apply_pass_orders_the_side_stream():
+    """segnb_stream_fork_arm / segnb_stream_fork_commit: the side stream waits for the BatchNorm-backward apply pass through an
+    event that rides on that kernel's own dispatch (no marker packet on the main queue) -- the weight gradient launched behind
+    every apply pass (zf_unet.py's backward through segnb.engine.Stage.backward) must see the finished dy.  A reader on the side
+    stream sums dy right behind the commit, 40 times with a different gradient each time; a reader that started early would see
+    values of the previous round.  Also: arm with NO carrying launch in between (commit falls back to an ordinary fork)."""
+    rt = Runtime('cuda', 'bf16')
+    N, H, W, C = 32, 112, 112, 64
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    y = View.alloc(rt, N, H, W, C)
+    g = View.alloc(rt, N, H, W, C)
+    dy = View.alloc(rt, N, H, W, C)
+    coef = rt.zeros((4, C), torch.float32)
+    coef[0] = 1.0
+    coef[3] = 1.0
+    bcoef = rt.zeros((3, C), torch.float32)
+    bcoef[0] = 1.0                                   # dy = 1 * (g - 0 - yhat * 0) = g
+    n = N * H * W * C
+    got = []
+    for it in range(1, 41):
+        carried = it % 4 != 0
+        g.t.fill_(float(it % 7 + 1))
+        nv.call('segnb_stream_fork_arm', rt.stream)
+        if carried:
+            nv.call('segnb_bn_bwd_apply_direct', rt.code, y.ptr, y.ld, N, H, W, C, nv.ptr(coef), nv.ptr(bcoef), nv.ACT_NONE, 0.0,
+                    g.ptr, g.ld, dy.ptr, dy.ld, None, C, rt.stream)
+        else:
+            nv.call('segnb_add', rt.code, None, 0, g.ptr, g.ld, dy.ptr, dy.ld, N, H, W, C, rt.stream)      # (cannot carry an event)
+        nv.call('segnb_stream_fork_commit', rt.stream, side.cuda_stream)
+        with torch.cuda.stream(side):
+            got.append((it, dy.t.sum(dtype=torch.float64)))
+        main.wait_stream(side)                       # the next round's fill must not overtake the reader
+    torch.cuda.synchronize()
+    for it, v in got:
+        assert float(v) == float(n * (it % 7 + 1)), (it, float(v))
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 9, 11, 32, nv.ACT_RELU), (3, 8, 8, 72, nv.ACT_LEAKY)], ids=['relu', 'leaky'])
 def test_bn_bwd_apply_direct_equals_two_pass(shape, dtype):
