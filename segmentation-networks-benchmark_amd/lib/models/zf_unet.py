@@ -331,7 +331,7 @@ class _ZFUnetPlan(object):
         key = (sum(p._version for p in self.flat.param_list()), self.flat.version, N, H, W,
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
-            return
+            return False
         # The matrices of the first PACK_EARLY convolutions (the 224x224 .. 28x28 encoder levels: 4 % of the parameters) are
         # packed on the main stream; the rest -- needed from the 14x14 level on, ~0.6 ms into the forward -- on the side stream,
         # idle during the forward, beside those levels.  The forward joins the side stream before its first late convolution
@@ -348,9 +348,12 @@ class _ZFUnetPlan(object):
             nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
             with torch.cuda.stream(side):
                 late.run()
+            self._packed_key = key
+            return True                              # (the side stream waits for everything issued before this forward)
         elif late is not None:
             late.run()
         self._packed_key = key
+        return False
 
     PACK_EARLY = 8
     PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
@@ -517,12 +520,12 @@ class _ZFUnetPlan(object):
             N, C, H, W = x.shape
         b = self.buffers(N, H, W)
         drop = self._dropout_tables(b, N, train)      # (first: on the side stream, beside the weight pack below)
-        self._pack_if_needed(H, W, N)
+        forked = self._pack_if_needed(H, W, N)
         if self._drop_wait is not None:
             torch.cuda.current_stream(rt.device).wait_event(self._drop_wait)
             self._drop_wait = None
         if train and need_grad:
-            self.flat.prezero(rt)
+            self.flat.prezero(rt, forked=bool(forked))
         hf = self._head_fusable(train, need_grad)
         self._last_head_fused = hf
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)

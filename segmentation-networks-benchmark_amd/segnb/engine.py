@@ -1505,8 +1505,9 @@ class FlatParams(object):
     # SEGNB_PREZERO_GRADS=0: the flat gradient buffer is cleared at the start of backward, on the dependent chain (A/B)
     prezero_grads = os.environ.get('SEGNB_PREZERO_GRADS', '1') != '0'
 
-    def prezero(self, rt):
-        """Called by a differentiated training forward: when the coming backward will have to clear the flat gradient buffer
+    def prezero(self, rt, forked=False):
+        """(forked: the caller has just made the side stream wait for this one -- no second marker on the main queue)
+        Called by a differentiated training forward: when the coming backward will have to clear the flat gradient buffer
         (no .grad aliases it: zero_grad()'s default, torch_train.py:180), clear it NOW on the side stream -- idle during the
         forward -- behind everything issued so far (the optimizer step / logging that read the last gradients).  126 MB for
         ZF_UNET: 18 us off the start of every backward."""
@@ -1516,7 +1517,8 @@ class FlatParams(object):
         side = rt.side_stream()
         if side is None:
             return
-        nv.call('segnb_stream_fork', rt.stream, side.cuda_stream)
+        if not forked:
+            nv.call('segnb_stream_fork', rt.stream, side.cuda_stream)
         ev = getattr(self, '_prezero_event', None)
         if ev is None:                     # ONE event, re-recorded every step (destroying an event may wait for it)
             ev = self._prezero_event = torch.cuda.Event()
