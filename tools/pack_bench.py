@@ -64,7 +64,6 @@ def main():
         us = a.elapsed_time(b) / args.reps * 1e3
         rd, wr = nbytes(js)
         if pair and name.startswith('all'):
-            tk = set(t._keep_ids) if hasattr(t, '_keep_ids') else set()
             for j in js:
                 if id(j) not in t.paired_ids:
                     print('   unpaired: form %s masked %s Mp %d Cp %d ntaps %d s_m %d s_c %d' % (
