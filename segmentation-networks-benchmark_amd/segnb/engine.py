@@ -139,6 +139,7 @@ class Runtime(object):
             del closures[:]
 
     def join_side(self):
+        self._armed = False                  # (an armed fork that never committed -- an exception in between -- dies here)
         if getattr(self, '_side_busy', False):
             nv.call('segnb_stream_join', self.stream, self._side.cuda_stream)
             self._side_busy = False
