@@ -270,3 +270,56 @@ def test_upconv_masks_are_the_transposed_convolution_identity():
     got = F.conv_transpose2d(u, wt, stride=2, padding=1)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
     assert sum(bin(UpConvOp.mask(a, b)).count('1') for a in range(4) for b in range(4)) == 36
+
+
+def test_pair_pack_and_first_layer_recompute_host_logic():
+    """Round-4 host logic on the emulator (bf16 ZF_UNET step, lib/models/zf_unet.py:37-38, torch_train.py:180-190):
+    (a) PackTable pairs the forward and the data-gradient matrix of every plain 3x3 convolution into ONE job of
+    segnb_pack_weight_pair_multi (the parameter is read once) and leaves masked / remapped jobs with the tiled pack -- the
+    packed matrices and every gradient are bit-identical to the step with the pairing off;
+    (b) the first layer (no data gradient) recomputes dy inside its weight gradient (segnb_conv_wgrad_bnapply, default where
+    the rolling kernel serves: 8 padded input channels, rows of >= 32 pixels) -- same gradients as with the apply pass
+    (SEGNB_WGRAD_BNAPPLY=0) to rounding, and the entry point is actually used."""
+    from lib.losses import BCEWithSigmoidLoss
+    from segnb.engine import PackTable
+    x, y = train_step_ref.synthetic_batch(2, 32, seed=5)
+    keep = PackTable.pair_pack
+    res = {}
+    try:
+        for mode, pair, env in (('default', True, None), ('unpaired', False, None), ('apply pass', True, '0')):
+            PackTable.pair_pack = pair
+            if env is None:
+                os.environ.pop('SEGNB_WGRAD_BNAPPLY', None)
+            else:
+                os.environ['SEGNB_WGRAD_BNAPPLY'] = env
+            be = abi_emulator.AbiEmulator()
+            n = {'pair': 0, 'bnapply': 0}
+            for name in ('segnb_pack_weight_pair_multi', 'segnb_conv_wgrad_bnapply'):
+                orig = getattr(be, name)
+
+                def counted(*a, _o=orig, _k=name):
+                    n['pair' if 'pair' in _k else 'bnapply'] += 1
+                    return _o(*a)
+                setattr(be, name, counted)
+            nv.set_backend_for_testing(be)
+            m = _model(16, 0.0, 3, 'bf16').train()
+            loss = BCEWithSigmoidLoss()(m(x), y)
+            loss.backward()
+            eng = m._engine
+            mats = []
+            for conv, h, w in eng._conv_sizes(32, 32):
+                if hasattr(conv, 'plan'):
+                    p = conv.plan(h, w)
+                    mats += [t.clone() for t in p.get('wp_fwd', [])] + [t.clone() for t in p.get('wp_dg', [])]
+            res[mode] = (n, {k: p.grad.clone() for k, p in m.named_parameters()}, mats)
+    finally:
+        PackTable.pair_pack = keep
+        os.environ.pop('SEGNB_WGRAD_BNAPPLY', None)
+    assert res['default'][0]['pair'] >= 1 and res['unpaired'][0]['pair'] == 0
+    assert res['default'][0]['bnapply'] == 1 and res['apply pass'][0]['bnapply'] == 0
+    for a, b in zip(res['default'][2], res['unpaired'][2]):
+        assert torch.equal(a, b)
+    for k in res['default'][1]:
+        assert torch.equal(res['default'][1][k], res['unpaired'][1][k]), k
+        torch.testing.assert_close(res['default'][1][k], res['apply pass'][1][k], rtol=2e-2,
+                                   atol=2e-3 * float(res['apply pass'][1][k].abs().max()) + 1e-12, msg=k)
