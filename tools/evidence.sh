@@ -37,6 +37,14 @@ python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
 python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
 python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1
+python3 tools/c8_bench.py > $O/${TAG}_c8_bench.txt 2>&1
+python3 tools/pack_bench.py > $O/${TAG}_pack_bench.txt 2>&1
+python3 tools/step_ramp.py > $O/${TAG}_step_ramp.txt 2>&1
+# cross-stream fork: cost of the marker packet vs an event on the kernel's own dispatch, and the ordering check
+mkdir -p tools/_bin
+[ -x tools/_bin/fork_cost ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/_bin/fork_cost tools/fork_cost.hip > /dev/null 2>&1
+[ -x tools/_bin/fork_check ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/_bin/fork_check tools/fork_check.hip > /dev/null 2>&1
+(./tools/_bin/fork_cost; ./tools/_bin/fork_check) > $O/${TAG}_fork_cost.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace.log 2>&1)
 python3 tools/trace_step.py $O/${TAG}_trace 12 list > $O/${TAG}_step_trace.txt 2>&1
 rm -rf $O/${TAG}_trace
