@@ -54,6 +54,11 @@ int segnb_device_cus(void);
  * (The weight-gradient launches read SEGNB_WG_CU_FRACTION / SEGNB_WG_CU_FRACTION_THIN once: share of the CUs their
  * pixel split is sized for, default 0.5 / 1.0; segnb_conv_wgrad_slabs reports the resulting slab count.) */
 int segnb_tune(const char* key, int value);
+/* segnb_tune("wg_cu_pct", pct) as a call that may sit inside a recorded launch list: the share (%) of the CUs the wide
+ * weight-gradient launches split their pixels for -- what segnb_conv_wgrad_slabs reports and what segnb_conv_wgrad* then expect as
+ * nslab -- from now on; 0 = the default (SEGNB_WG_CU_FRACTION, 0.5).  A convolution must be launched under the share its workspace
+ * was sized under.  (UNet16, unet16.py:50-108: 100 % -- its weight gradients are the longer stream; LinkNet34 loses 7 % with it.) */
+int segnb_wg_cu_share(int pct);
 /* Timing builds: in-kernel shader-clock stamps of block 0 of the last direct-to-LDS convolution launched with
  * "fprop_dma_dbg" = 32.  host_dst: HOST buffer of 3 x 256 x 4 unsigned 64-bit values ([wave role][tap][event]);
  * synchronises the device (tools/stamps.py). */

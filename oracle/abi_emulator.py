@@ -1141,6 +1141,9 @@ class AbiEmulator(object):
     def segnb_stream_join(self, main, side):
         return 0
 
+    def segnb_wg_cu_share(self, pct):
+        return self.segnb_tune('wg_cu_pct', pct)
+
     def segnb_tune(self, key, value):
         self.tuned = getattr(self, 'tuned', {})
         self.tuned[key.decode() if isinstance(key, bytes) else key] = int(value)

@@ -354,6 +354,16 @@ int segnb_knob_bnreduce_fused() {
 }
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
+// The share of the CUs the WIDE weight-gradient launches size their pixel split for (segnb_conv_wgrad_slabs and the launches
+// that follow), as a RECORDABLE call: a model whose side stream is the longer one (UNet16: 12 ms of weight gradients against a
+// 17 ms dependent chain that ends 1.7 ms earlier) takes all CUs for them, another in the same process keeps the default half;
+// a recorded launch list sets and restores the value around its weight gradients.  0 = the built-in / environment default.
+extern "C" int segnb_wg_cu_share(int pct) {
+    SEGNB_PLAN_RECORD(segnb_wg_cu_share, pct);
+    g_wg_cu_pct = pct < 0 ? 0 : (pct > 100 ? 100 : pct);
+    return 0;
+}
+
 extern "C" int segnb_tune(const char* key, int value) {
     SEGNB_PLAN_REFUSE("segnb_tune inside a recorded plan");
     SEGNB_CHECK_ARG(key != nullptr, "NULL key");

@@ -11,6 +11,8 @@ downloaded weights: pass a state_dict instead (load_state_dict works with the re
 Forward/backward run on the define-by-run executor (segnb.net): conv+ReLU units with fused MaxPool2d(2),
 ConvTranspose2d(4, stride 2, pad 1) as four output-parity gather launches, zero-copy concatenation.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -60,6 +62,11 @@ class DecoderBlock(nn.Module):
 
 
 class UNet16(HipNet):
+    # The weight gradients of this net (no BatchNorm passes on the dependent chain, 64-512 channel convolutions at 1024^2 .. 64^2) are
+    # the LONGER of the two streams: at the library's default share (half of the CUs) the chain ended 1.7 ms before them and
+    # waited (profiles/r04_ab.txt: 18.75 ms per step at 50 %, 17.98 at 75 %, 17.77 at 100 %; LinkNet34 loses 7 % at 100 %).
+    wg_cu_pct = int(os.environ.get('SEGNB_UNET16_WG_CU_PCT', '100')) or None
+
     def __init__(self, num_classes=1, num_filters=32, pretrained=False):
         super(UNet16, self).__init__()
         if pretrained == 'vgg':

@@ -149,6 +149,7 @@ SIGNATURES = {
     'segnb_seg_loss_finalize': [_P, ctypes.POINTER(LossSpec), _P, _P],
     'segnb_seg_loss_bwd': [_P, _P, c_ll, _P, _P, ctypes.POINTER(LossSpec), _P, _P, _P],
     'segnb_tune': [ctypes.c_char_p, c_int],
+    'segnb_wg_cu_share': [c_int],
     'segnb_plan_begin': [],
     'segnb_plan_end': [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int)],
     'segnb_plan_run': [_P],

@@ -305,12 +305,12 @@ class ConvOp(object):
         # slabs 1.. are scratch for the partial sums of the pixel ranges.
         if self.transposed:
             geoms = [self._make_geom(l, 1, Ho, Wo, self.Cop, self.Cop, Hi, Wi, self.Cip, self.Cip) for l in dg]
-            p['nslab'] = [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms]
+            p['nslab'] = self._under_wg_share(lambda: [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms])
             p['dwp'] = [rt.zeros((n, self.Cip, len(l.taps) * self.Cop), torch.float32)
                         for n, l in zip(p['nslab'], dg)]
         else:
             geoms = [self._make_geom(l, 1, Hi, Wi, self.Cip, self.Cip, Ho, Wo, self.Cop, self.Cop) for l in fwd]
-            p['nslab'] = [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms]
+            p['nslab'] = self._under_wg_share(lambda: [nv.query('segnb_conv_wgrad_slabs', g, rt.code) for g in geoms])
             p['dwp'] = [rt.zeros((n, self.Cop, len(l.taps) * self.Cip), torch.float32)
                         for n, l in zip(p['nslab'], fwd)]
         p['geoms'] = {}
@@ -548,6 +548,19 @@ class ConvOp(object):
                lambda: nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd, nv.ptr(p['dwp'][0]), p['nslab'][0],
                                rt.stream))
 
+    # share (%) of the CUs this convolution's weight gradient splits its pixels for; None = the library default.  Set before
+    # the first plan (the workspace is sized under it); every launch is bracketed by segnb_wg_cu_share (recordable)
+    wg_cu_pct = None
+
+    def _under_wg_share(self, fn):
+        if self.wg_cu_pct is None:
+            return fn()
+        nv.call('segnb_wg_cu_share', int(self.wg_cu_pct))
+        try:
+            return fn()
+        finally:
+            nv.call('segnb_wg_cu_share', 0)
+
     def wgrad_bnapply_ok(self, xv, yv):
         """True when this convolution's weight gradient can recompute its dy operand -- the BatchNorm-backward apply of the
         layer -- from (g, y) itself (segnb_conv_wgrad_bnapply): the apply pass then disappears for a layer without a data
@@ -582,7 +595,8 @@ class ConvOp(object):
                 g = self._geom(p, 'wt', li, l, xv.N, dyv.H, dyv.W, self.Cop, dyv.ld, xv.H, xv.W, self.Cip, xv.ld)
                 ex = 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co
                 _timed('conv_wgrad', ex * self.algo_scale,
-                       lambda: nv.call(entry, g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li], rt.stream),
+                       lambda: self._under_wg_share(lambda: nv.call(entry, g, rt.code, dyv.ptr, xv.ptr, nv.ptr(p['dwp'][li]),
+                                                                    p['nslab'][li], rt.stream)),
                        ex)
                 if unpack:
                     nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cip, self.Cop, len(l.taps),
@@ -592,8 +606,8 @@ class ConvOp(object):
         for li, l in enumerate(p['fwd']):
             g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-                   lambda: nv.call(entry, g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li],
-                                   rt.stream))
+                   lambda: self._under_wg_share(lambda: nv.call(entry, g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]),
+                                                                p['nslab'][li], rt.stream)))
             if unpack:
                 nv.call('segnb_unpack_wgrad', nv.ptr(p['dwp'][li]), nv.ptr(gw), self.Cop, self.Cip, len(l.taps),
                         self.s_out, self.s_in, p['tapoff_fwd'][li], nv.ptr(self.out_map), nv.ptr(self.in_map), 1,

@@ -38,6 +38,19 @@ class Act(object):
         self.consumers, self.producer, self.g_is_dz = 0, None, False
 
 
+class _HostStep(object):
+    """What a cut (or the end) of a backward launches from the host, outside the recorded lists: the batched bias gradients of
+    the convolutions without BatchNorm, then the batched unpack of the weight gradients.  run() repeats it in a replayed step."""
+
+    def __init__(self, rt, bias, unpack):
+        self.rt, self.bias, self.unpack = rt, bias, unpack
+
+    def run(self):
+        nv.call('segnb_bias_grad_multi', nv.ptr(self.bias[0]), self.bias[1], self.rt.stream)
+        if self.unpack is not None:
+            self.unpack.run()
+
+
 class Tape(object):
     def __init__(self, module, device, dtype):
         self.module = module
@@ -62,6 +75,8 @@ class Tape(object):
         # forward statistics that segnb_bn_fwd_fused left for this step's backward to clear (segnb_bn_bwd_apply_fused*):
         # if that backward never runs, begin() clears them before the next forward accumulates on top
         self.fused_stats, self.stats_pending = [], False
+        # share (%) of the CUs the model's weight gradients split their pixels for (HipNet.wg_cu_pct; None = the library default)
+        self.wg_cu_pct = getattr(module, 'wg_cu_pct', None)
 
     # BatchNorm finalize folded into the activation / apply launches of a differentiated training forward (one launch less
     # per layer and direction; A/B: SEGNB_FUSE_FINALIZE=0)
@@ -262,8 +277,10 @@ class Tape(object):
         self._bias_pending.append((sums, C, Cp, gb))
 
     def _run_bias_grads(self, group):
+        """-> the (job table, job count) launched, or None.  The caller keeps it: a replayed backward launches the same table
+        from its host-side step (HipNet._run_backward) -- the call is made outside the recorded lists, like the unpack."""
         if not self._bias_pending:
-            return
+            return None
         key = tuple((s.data_ptr(), 0 if g is None else g.data_ptr()) for s, _, _, g in self._bias_pending)
         t = self._bias_tables.get(group)
         if t is None or t[0] != key:
@@ -276,10 +293,18 @@ class Tape(object):
             t = self._bias_tables[group] = (key, tab, len(rows), list(self._bias_pending))
         nv.call('segnb_bias_grad_multi', nv.ptr(t[1]), t[2], self.rt.stream)
         self._bias_pending = []
+        return t[1], t[2]
 
     def run_unpack(self, group='end'):
-        """Batched unpack of the weight gradients launched since the last one (group: which cut of the backward this is)."""
-        self._run_bias_grads(group)
+        """Batched unpack of the weight gradients launched since the last one (group: which cut of the backward this is), behind
+        the batched bias gradients of the same span.  -> an object whose run() repeats both launches (a replayed step), or None."""
+        bias = self._run_bias_grads(group)
+        step = self._run_unpack_tables(group)
+        if bias is None:
+            return step
+        return _HostStep(self.rt, bias, step)
+
+    def _run_unpack_tables(self, group):
         if self._unpack_pending:
             key = (tuple((id(c), h, w) for c, h, w, _ in self._unpack_pending), self.flat.flat_g.data_ptr())
             t = self._unpack_tables.get(group)
@@ -364,8 +389,11 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     Returns Act, or (Act, pooled Act) when pool is set."""
     rt = tape.rt
     site = tape.site(tag)
-    conv = tape.cached(site + '/op', lambda: ConvOp(rt, weight, bias, in_segments, stride, pad, transposed,
-                                                    need_dgrad=x.needs_grad, out_hw=out_hw))
+    def make_op():
+        op = ConvOp(rt, weight, bias, in_segments, stride, pad, transposed, need_dgrad=x.needs_grad, out_hw=out_hw)
+        op.wg_cu_pct = tape.wg_cu_pct          # (the model's share of the CUs for its weight gradients; None = the library default)
+        return op
+    conv = tape.cached(site + '/op', make_op)
     tape.consume(x, res)
     xv = x.v
     plan = conv.plan(xv.H, xv.W)
@@ -803,6 +831,10 @@ class _NetFn(torch.autograd.Function):
 
 class HipNet(nn.Module):
     """Base of the executor-driven models: subclasses implement ``_build(tape, x_act, dlogits_ref) -> logits``."""
+
+    # share (%) of the CUs the weight gradients (side stream) split their pixels for; None = the library default (half, the
+    # other half left to the dependent chain).  A model whose side stream is the longer one overrides it (UNet16).
+    wg_cu_pct = None
 
     def _init_engine(self, in_channels):
         self.compute_dtype = 'bf16'

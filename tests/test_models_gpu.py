@@ -96,6 +96,62 @@ def test_training_steps_reduce_loss_all_models():
         assert losses[-1] < losses[0], (type(m).__name__, losses)
 
 
+def test_weight_gradient_cu_share_is_local_to_the_model():
+    """UNet16 takes ALL CUs for its weight gradients (HipNet.wg_cu_pct = 100 through segnb_wg_cu_share: its side stream is the
+    longer one, unet16.py:50-108), LinkNet34 in the same process keeps the library's default half: the share is set around the
+    planning and the launches of one model's convolutions -- eager and replayed -- and restored behind them.  Interleaved
+    training steps of both models (the second and third of each replay recorded launch lists) must leave the default in place
+    and give the gradients the models give alone."""
+    import warnings
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    from lib.models.linknet import LinkNet34
+    from lib.models.unet16 import UNet16
+    from segnb import _native as nv
+    from segnb import convplan as cp
+    from segnb.engine import ConvOp, Runtime
+    assert UNet16.wg_cu_pct == 100 and LinkNet34.wg_cu_pct is None
+    rt = Runtime('cuda', 'bf16')
+    probe = ConvOp(rt, torch.randn(128, 128, 3, 3).cuda(), None, [(128, 128)], 1, 1, False, True)
+    default = list(probe.plan(64, 64)['nslab'])
+    probe2 = ConvOp(rt, torch.randn(128, 128, 3, 3).cuda(), None, [(128, 128)], 1, 1, False, True)
+    probe2.wg_cu_pct = 100
+    assert probe2.plan(64, 64)['nslab'][0] > default[0]          # (a full share is more pixel splits)
+    x = torch.randn(2, 3, 128, 128).cuda()
+    y = (torch.rand(2, 1, 128, 128) > 0.7).long().cuda()
+    crit = BCEWithLogitsLossAndSmoothJaccard()
+
+    def step(m):
+        torch.manual_seed(7)                 # (LinkNet34 draws Dropout2d masks: the same ones every step)
+        m.zero_grad()
+        loss = crit(m(x), y)
+        (2 * loss).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(1)
+        u, l = UNet16().cuda().train(), LinkNet34().cuda().train()
+    alone = {}
+    for name, m in (('u', u), ('l', l)):
+        for _ in range(3):
+            alone[name] = step(m)
+    for it in range(3):
+        gu = step(u)
+        fresh = ConvOp(rt, torch.randn(128, 128, 3, 3).cuda(), None, [(128, 128)], 1, 1, False, True)
+        assert list(fresh.plan(64, 64)['nslab']) == default, 'UNet16 left its share behind'
+        gl = step(l)
+    for got, ref in ((gu, alone['u']), (gl, alone['l'])):
+        scale = max(float(v.norm()) for v in ref.values())
+        for k in ref:
+            if float(ref[k].norm()) < 1e-6 * scale:      # (a bias in front of a BatchNorm: an exactly zero gradient, noise on both sides)
+                continue
+            # (not bitwise: the BatchNorm sums are fp64 atomics and a flipped bf16 rounding travels down the net; a weight gradient
+            # computed under the wrong share -- slabs of another count -- would be off by whole slabs, not by rounding)
+            err = float((got[k] - ref[k]).norm() / (ref[k].norm() + 1e-20))
+            assert err < 2e-2, (k, err)
+
+
 @pytest.mark.parametrize('name', ['unet16', 'linknet34', 'fcdensenet67'])
 def test_launch_plans_replay_matches_eager(name):
     """segnb_plan_*: from the third step of a geometry on, the executor-driven models replay their recorded forward and
@@ -126,6 +182,8 @@ def test_launch_plans_replay_matches_eager(name):
                 opt.zero_grad()
                 loss = crit(m(xs[it % 3]), ys[it % 3])
                 (4 * loss).backward()
+                if it == 6:                # (a replayed step: EVERY gradient, incl. the batched bias gradients launched from the host)
+                    last_grads = {k: p.grad.detach().clone().cpu() for k, p in m.named_parameters() if p.grad is not None}
                 opt.step()
                 losses.append(loss.item())
             m.eval()
@@ -138,10 +196,14 @@ def test_launch_plans_replay_matches_eager(name):
                 assert any(e.get('nbwd', 0) > 10 for e in ready) and all(e['nfwd'] > 10 for e in ready)
             else:
                 assert not plans
-            res[mode] = (losses, evs)
+            res[mode] = (losses, evs, last_grads)
         finally:
             net.HipNet.use_cplan = True
-    (l1, e1), (l0, e0) = res[True], res[False]
+    (l1, e1, g1), (l0, e0, g0) = res[True], res[False]
+    scale = max(float(v.norm()) for v in g0.values())
+    for k in g0:
+        err = float((g1[k] - g0[k]).norm())
+        assert err <= 5e-2 * float(g0[k].norm()) + 1e-6 * scale, (k, err, float(g0[k].norm()), float(g1[k].norm()))
     np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-3)
     for a, b in zip(e1, e0):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
