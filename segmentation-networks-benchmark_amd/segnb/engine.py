@@ -545,8 +545,8 @@ class ConvOp(object):
         l = p['fwd'][0]
         g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dv.H, dv.W, self.Cop, dv.ld)
         _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-               lambda: nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd, nv.ptr(p['dwp'][0]), p['nslab'][0],
-                               rt.stream))
+               lambda: self._under_wg_share(lambda: nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd,
+                                                            nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)))
 
     # share (%) of the CUs this convolution's weight gradient splits its pixels for; None = the library default.  Set before
     # the first plan (the workspace is sized under it); every launch is bracketed by segnb_wg_cu_share (recordable)
