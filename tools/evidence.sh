@@ -48,6 +48,12 @@ mkdir -p tools/_bin
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace.log 2>&1)
 python3 tools/trace_step.py $O/${TAG}_trace 12 list > $O/${TAG}_step_trace.txt 2>&1
 rm -rf $O/${TAG}_trace
+# one traced step of each executor model (kernel families, queue gaps)
+for m in linknet34 fcdensenet103 unet16; do
+  (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_$m -- python3 $R/bench.py --model $m --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace_$m.log 2>&1)
+  python3 tools/trace_step.py $O/${TAG}_trace_$m 8 > $O/${TAG}_step_trace_$m.txt 2>&1
+  rm -rf $O/${TAG}_trace_$m
+done
 # the same step replayed from ONE HIP graph (where does the two-branch overlap go?)
 python3 bench.py --graph on --no-cpu-baseline --no-kernel-timer > $O/${TAG}_bench_graph.json 2>/dev/null
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/bench.py --graph on --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace_graph.log 2>&1)

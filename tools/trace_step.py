@@ -47,6 +47,19 @@ def main():
         print('queue %s: %d kernels, busy %.3f ms, span %.3f ms, positive gaps %d totalling %.3f ms (median %.1f us)'
               % (q, len(rs), busy / 1e6, (rs[-1][1] - rs[0][0]) / 1e6, len(pos), sum(pos) / 1e6,
                  sorted(pos)[len(pos) // 2] / 1e3 if pos else 0.0))
+    # gaps of the busiest queue by the kernels on either side: a gap that repeats behind ONE kernel family is a packet of the
+    # queue that is not a kernel (an event record, a wait) or a host-side step -- how the marker of the weight gradient's
+    # fork and UNet16's wait for its side stream (11.15) were found
+    main = max(byq.values(), key=len)
+    cls = defaultdict(lambda: [0, 0])
+    for i in range(len(main) - 1):
+        g = main[i + 1][0] - main[i][1]
+        if g > 2000:
+            cls[(main[i][2], main[i + 1][2])][0] += 1
+            cls[(main[i][2], main[i + 1][2])][1] += g
+    print('-- gaps > 2 us on the busiest queue, by (kernel before, kernel after)')
+    for (a, b), (n, t) in sorted(cls.items(), key=lambda kv: -kv[1][1])[:10]:
+        print('   %3d x  %8.1f us   after %-32s before %s' % (n, t / 1e3, a, b))
     for phase, sel in (('forward', lambda r: r[0] < lb), ('backward', lambda r: r[0] >= lb)):
         fam = defaultdict(lambda: [0, 0])
         for r in step:
