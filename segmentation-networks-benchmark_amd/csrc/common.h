@@ -112,6 +112,7 @@ int segnb_knob_fprop_deepk();     // 1: conv_fprop_deepk_kernel serves the shape
 int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
+int segnb_knob_fprop_ksplit();   // conv_fprop_ws_kernel split K: 0 off, 1 automatic (default), 2 / 4 forced where it applies
 // head backward's per-(device, stream) partial-sum scratch and its fixed-order finish launch (head_loss.hip)
 float* segnb_head_scratch(size_t bytes, hipStream_t stream);
 void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream);

@@ -64,6 +64,16 @@ struct FdArgs {
     const float* ep_coef;
     int ep_act;
     float ep_slope;
+    // split K (conv_fprop_ws_kernel<..., SPLITK>): KS blocks share one (pixel tile, channel tile), each walks NCH (= Ci / 64 / KS)
+    // input-channel chunks starting at chunk ks * NCH, publishes its fp32 accumulator tile as a 64 KB slab in ks_slab
+    // [tile][KS][4 waves][16 pieces][64 lanes][4] (write-through stores) and draws a ticket from ks_cnt[tile]; the block that draws
+    // KS - 1 adds the slabs in slice order and runs the ordinary epilogue (bias, rounding, statistics, stores).  KS = 1: off
+    int KS;
+    int ntmajor;          // block order: 1 = (channel tile, slice, pixel tile) -- the blocks of an XCD share WEIGHTS (7 x 7 level: the
+                          // weights are 6 x the activations); 0 = (pixel tile, channel tile) -- they share the input tile
+    float* ks_slab;
+    unsigned ks_slab_bytes;
+    int* ks_cnt;
     int dbg;              // timing builds (segnb_tune "fprop_dma_dbg"): 1 no weight fetches, 2 no halo fetches, 4 no MFMA +
                           // fragment reads, 8 no stores, 16 no fragment reads, 32 in-kernel stamps, 64 one stamp per tap
 };

@@ -36,6 +36,9 @@
 
 #include "fprop_dma.h"
 
+#include <mutex>
+#include <vector>
+
 #ifndef SEGNB_EXP
 #define SEGNB_EXP 0      // experiments on the production kernel (whole-file compile-time switches; never set in the build)
 #endif
@@ -114,7 +117,8 @@ struct WsCfg {
     static constexpr int OFF_PIX = OFF_DUMMY + 1024;
     static constexpr int OFF_BIAS = OFF_PIX + 4 * BM * 4;      // pixel tables of tiles k-1 (being stored), k, k+1, k+2 (set up)
     static constexpr int OFF_SCALE = OFF_BIAS + BN * 4;       // per-channel factor of the affine epilogue (1 when off)
-    static constexpr int SMEM = OFF_SCALE + BN * 4;
+    static constexpr int OFF_TICKET = OFF_SCALE + BN * 4;     // split K: the ticket the block drew (one word)
+    static constexpr int SMEM = OFF_TICKET + 16;
     static constexpr int RED_BYTES = MT * 16 * 8;
     static_assert(WM % 32 == 0 && WN % 32 == 0 && WAVES_M * WAVES_N == NCW, "wave tiling");
     static_assert(BPIECES % NBW == 0 && NBW + NAW == NLW, "fetch wave roles");
@@ -136,8 +140,10 @@ struct WsCfg {
 // during the first two chunks of the NEXT tile, dz = round(g * act'(z)) as bn_act_bwd_reduce_kernel computes it, sum dz and sum dz * yhat
 // per lane.  Needs at least THREE K chunks per tile (Ci >= 192): the pieces of tile i are consumed during the first two chunks of
 // tile i + 1, whose own requests go out in its last chunk into the same registers.
-template <class C, bool DBG, bool EP = false, bool STATS = true, bool BNR = false>
+// SPLITK: FdArgs::KS blocks per (pixel tile, channel tile), every block owns ONE tile slice (grid = tiles x KS); see FdArgs::KS
+template <class C, bool DBG, bool EP = false, bool STATS = true, bool BNR = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
+    static_assert(!SPLITK || (!BNR && !EP && !DBG && C::UP == 0 && C::NTAP == 9), "split K: plain 3 x 3 forward / data gradient");
     static_assert(!BNR || (!STATS && !EP && C::MF16 && C::NTAP == 9 && !C::TALL && C::UP == 0 && C::BN == 64 && C::BM == 256),
                   "BatchNorm-reduce variant: plain 3 x 3 data gradient, 16x16x32 form, 256-row x 64-channel tiles");
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
@@ -157,8 +163,31 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     const int lw = wave - C::NCW;                                   // loader index 0..3
     const int wm = (wave & 3) / C::WAVES_N, wn = (wave & 3) % C::WAVES_N;
 
-    const int L = xcd_remap_fd(blockIdx.x, gridDim.x);
-    const int nt = L % a.NTL, gq = L / a.NTL;
+    // consecutive L share an XCD (and its L2).  Default order: the NTL channel tiles of one pixel tile are neighbours (they
+    // read the same halo tiles).  ntmajor (tall tiles of the 7 x 7 level, where the weights are 6 x the activations and every
+    // XCD would pull ALL of them through the fabric -- 151 MB per 1024 -> 1024 launch, which bounded it): the GM pixel tiles
+    // of one (channel tile, slice) are neighbours, and so are the slices of a tile
+    int L_ = xcd_remap_fd(blockIdx.x, gridDim.x);
+    int ks_ = 0, nt_, gq_;
+    if (C::TALL && a.ntmajor) {
+        gq_ = L_ % a.GM;
+        L_ /= a.GM;
+        if constexpr (SPLITK) {
+            ks_ = L_ % a.KS;
+            L_ /= a.KS;
+        }
+        nt_ = L_;
+    } else {
+        if constexpr (SPLITK) {
+            ks_ = L_ % a.KS;
+            L_ /= a.KS;
+        }
+        nt_ = L_ % a.NTL;
+        gq_ = L_ / a.NTL;
+    }
+    const int ks = ks_;
+    const int c_off = SPLITK ? ks * a.NCH : 0;      // first input-channel chunk of this block
+    const int nt = nt_, gq = gq_;
     // n_base: first output channel of the block (output, bias, statistics); w_row0: its first row of the weight matrix
     int n_base_ = nt * BN, w_row0_ = nt * BN, py_ = 0, px_ = 0;
     if constexpr (C::UPF) {
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     // lists the kernel rows of a phase in ascending order = descending input offset)
                     soff = (unsigned)((3 - t) * a.Ci + c * 64) * 2u;
                 } else {
-                    soff = (unsigned)(t * a.Ci + c * 64) * 2u;
+                    soff = (unsigned)(t * a.Ci + (c + c_off) * 64) * 2u;
                 }
         #pragma unroll
                 for (int pb = 0; pb < BPW; ++pb)
@@ -403,7 +432,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         sPix[table * BM + rr] = (live && ho < a.H && wo < a.W) ? (n * a.H + ho) * a.W + wo : -1;
                 }
             };
-            auto fetch_a = [&](int p0, int p1, int c, int buf) {
+            auto fetch_a = [&](int p0, int p1, int c_, int buf) {
+                const int c = c_ + c_off;
                 int pl = 0;
                 unsigned soff = (unsigned)c * 128u;
                 if constexpr (C::UPD) {
@@ -613,6 +643,10 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // look-ahead fetches of the (absent) next tile
+        if constexpr (SPLITK) {       // the matrix waves' slab hand-over: slabs drained / ticket published
+            raw_barrier();
+            raw_barrier();
+        }
         raw_barrier();
         raw_barrier();
         raw_barrier();
@@ -735,6 +769,81 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             }
         };
         auto row_store = [&]() { row_store_of(row_pix, row_v); };
+        // ---- split K: slab hand-over of the one tile slice this block owns (MI355X_MICROARCH.md, inter-workgroup visibility: write-
+        // through stores, every storing wave drained, a workgroup barrier, ONE agent-scope add per block; the block whose add
+        // came last reads every slab with sc1 loads).  The sum runs over the slabs in slice order, the reducer's own included,
+        // so the result does not depend on which block arrives last.
+        bool ks_last = true;
+        const __amdgpu_buffer_rsrc_t rs_slab =
+            __builtin_amdgcn_make_buffer_rsrc(SPLITK ? a.ks_slab : nullptr, 0, SPLITK ? (int)a.ks_slab_bytes : 0, 0x00020000);
+        const unsigned ks_tile = (unsigned)(gq * a.NTL + nt);
+        const unsigned slab0 = ((ks_tile * (unsigned)a.KS) * 4u + (unsigned)(wave & 3)) * 16384u + (unsigned)lane * 16u;   // slice 0, piece 0
+        auto ks_publish = [&](auto&& piece) {              // piece(p): accumulator registers 4 p .. 4 p + 3 of this lane
+            unsigned own = slab0 + (unsigned)ks * 65536u;
+            asm volatile("" : "+v"(own));                  // (computed here: hoisted to the kernel's start the 16 offsets were spilled)
+            static_for<16>([&](auto p_c) {
+                constexpr int p = decltype(p_c)::value;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, piece(p_c)), rs_slab, (int)(own + p * 1024u), 0,
+                                                       16 /* sc1 */);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            raw_barrier();                                 // every storing wave has drained
+            int* const sTicket = reinterpret_cast<int*>(smem + C::OFF_TICKET);
+            if (tid == 0) {
+                const int tk = __hip_atomic_fetch_add(a.ks_cnt + ks_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == a.KS - 1) {
+                    __hip_atomic_store(a.ks_cnt + ks_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                sTicket[0] = tk;
+            }
+            lds_barrier();
+            return sTicket[0] == a.KS - 1;
+        };
+        // The reducer's sum: its own slice from registers, the others by sc1 loads, all of them in flight together (a slab read is a
+        // fabric round trip of ~2 us: four dependent batches cost the launch more than the split gained).  Fixed association
+        // whoever reduces: KS = 2: p0 + p1; KS = 4: (p0 + p1) + (p2 + p3) -- IEEE addition commutes, so which operand came from
+        // registers does not show.  get(p) / set(p, v): accumulator registers 4 p .. 4 p + 3 of this lane.
+        auto ks_load = [&](unsigned off) {
+            return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_slab, (int)off, 0, 16 /* sc1 */));
+        };
+        auto ks_combine = [&](auto&& get, auto&& set) {
+            unsigned base = slab0;
+            asm volatile("" : "+v"(base));
+            if (a.KS == 2) {
+                const unsigned other = base + (unsigned)(ks ^ 1) * 65536u;
+                static_for<2>([&](auto h_c) {               // (two batches of eight: 32 registers -- sixteen at once spilled)
+                    constexpr int h8 = decltype(h_c)::value * 8;
+                    f32x4_t o[8];
+                    static_for<8>([&](auto q_c) { constexpr int q = decltype(q_c)::value; o[q] = ks_load(other + (h8 + q) * 1024u); });
+                    static_for<8>([&](auto q_c) {
+                        constexpr int q = decltype(q_c)::value;
+                        set(std::integral_constant<int, h8 + q>{}, get(std::integral_constant<int, h8 + q>{}) + o[q]);
+                    });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                });
+            } else {
+                static_for<4>([&](auto h_c) {               // (four pieces x four slices per batch: 64 registers)
+                    constexpr int h8 = decltype(h_c)::value * 4;
+                    f32x4_t v[4][4];
+                    static_for<4>([&](auto q_c) {
+                        constexpr int q = decltype(q_c)::value;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[q][k] = ks_load(k != ks ? base + (unsigned)k * 65536u + (h8 + q) * 1024u : OOB);
+                    });
+                    static_for<4>([&](auto q_c) {
+                        constexpr int q = decltype(q_c)::value;
+                        const f32x4_t own = get(std::integral_constant<int, h8 + q>{});
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[q][k] = k == ks ? own : v[q][k];
+                        set(std::integral_constant<int, h8 + q>{}, (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+                    });
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next batch's loads start after this batch's sums)
+                });
+            }
+        };
         if constexpr (MF16) {
             // ---- 16x16x32 matrix stream: 2 K slices of 32 channels per tap; wave tile = TM16 x TN16 tiles of 16 pixels x
             // 16 channels (4 x 4: 16 MFMAs of 16 cycles per slice).  Two fragment sets (set = slice parity): the 8 reads of
@@ -866,6 +975,13 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 ws_wait1<0>(fx[0][2]);
                 ws_wait1<0>(fx[0][3]);
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);
+                if constexpr (SPLITK) {
+                    ks_last = ks_publish([&](auto p_c) { constexpr int p = decltype(p_c)::value; return acc[p / TN16][p % TN16]; });
+                    if (ks_last)
+                        ks_combine([&](auto p_c) { constexpr int p = decltype(p_c)::value; return acc[p / TN16][p % TN16]; },
+                                   [&](auto p_c, const f32x4_t v) { constexpr int p = decltype(p_c)::value; acc[p / TN16][p % TN16] = v; });
+                }
+                if (!SPLITK || ks_last) {
                 // accumulator tile (i, j): this lane holds channels 16 j + 4 g4 + {0..3} of pixel 16 i + r16
                 const int r16 = lane & 15, g4 = lane >> 4;
                 float4 bv[TN16], sv[TN16];
@@ -895,7 +1011,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         *reinterpret_cast<uint2*>(sOut + row * OUT_ROW + col * 2) = pk;
                     }
                 }
-                pending = true;
+                }
+                pending = !SPLITK || ks_last;
             }
             tile_no_out = tile_no;
             pending_out = pending;
@@ -991,6 +1108,22 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 ws_wait<0>(fr[1]);
                 ws_wait<0>(fr[2]);
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::);      // last MFMA results land before they are read
+                if constexpr (SPLITK) {
+                    static_assert(MF16 || TM * TN == 4, "split K: 16 accumulator quads per lane");
+                    auto quad = [&](auto p_c) {
+                        constexpr int p = decltype(p_c)::value, t = p >> 2, g = p & 3;
+                        const f32x16_t& s16 = acc[t / TN][t % TN];
+                        return f32x4_t{s16[4 * g], s16[4 * g + 1], s16[4 * g + 2], s16[4 * g + 3]};
+                    };
+                    ks_last = ks_publish(quad);
+                    if (ks_last)
+                        ks_combine(quad, [&](auto p_c, const f32x4_t v) {
+                            constexpr int p = decltype(p_c)::value, t = p >> 2, g = p & 3;
+                            f32x16_t& d16 = acc[t / TN][t % TN];
+                            d16[4 * g] = v[0]; d16[4 * g + 1] = v[1]; d16[4 * g + 2] = v[2]; d16[4 * g + 3] = v[3];
+                        });
+                }
+                if (!SPLITK || ks_last) {
                 float4 bv[TN][4];                                  // (one batch of LDS reads, not one round trip per quad)
     #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -1013,7 +1146,8 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         }
                     }
                 }
-                pending = true;
+                }
+                pending = !SPLITK || ks_last;
             }
             tile_no_out = tile_no;
             pending_out = pending;
@@ -1051,6 +1185,77 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     }
 }
 
+// split-K workspace: slabs + ticket counters per (device, stream), grown on demand (launches on one stream are ordered by the
+// stream; the counters are zeroed when allocated and every launch leaves them zero).  Allocation happens in the eager /
+// recording step of a geometry, replayed launch lists find the same pointers.
+int ksplit_workspace(hipStream_t stream, size_t slab_bytes, int ntiles, float** slab, int** cnt) {
+    struct Ent {
+        int dev;
+        hipStream_t stream;
+        float* slab;
+        size_t cap;
+        int* cnt;
+        int ncnt;
+    };
+    static std::mutex mu;
+    static std::vector<Ent> ents;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    Ent* e = nullptr;
+    for (auto& it : ents)
+        if (it.dev == dev && it.stream == stream) e = &it;
+    const bool grow = e == nullptr || slab_bytes > e->cap || ntiles > e->ncnt;
+    if (grow) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;   // no allocation under capture
+        if (e == nullptr) {
+            ents.push_back(Ent{dev, stream, nullptr, 0, nullptr, 0});
+            e = &ents.back();
+        }
+        // (old buffers may still be in use by launches in flight: left allocated -- a handful of times per process)
+        if (slab_bytes > e->cap) {
+            float* p = nullptr;
+            if (hipMalloc(&p, slab_bytes) != hipSuccess) return -1;
+            e->slab = p;
+            e->cap = slab_bytes;
+        }
+        if (ntiles > e->ncnt) {
+            const int want = ntiles < 1024 ? 1024 : ntiles;
+            int* c = nullptr;
+            if (hipMalloc(&c, (size_t)want * sizeof(int)) != hipSuccess) return -1;
+            if (hipMemset(c, 0, (size_t)want * sizeof(int)) != hipSuccess) return -1;
+            e->cnt = c;
+            e->ncnt = want;
+        }
+    }
+    *slab = e->slab;
+    *cnt = e->cnt;
+    return 0;
+}
+
+// split K pays where a launch has fewer (pixel tile, channel tile) pairs than half the CUs it may use: the 7 x 7 level of
+// lib/models/zf_unet.py:44-56 (8 tall row tiles x 8..16 channel tiles at bs = 32).  Returns the number of slices (1 = no split)
+template <class C>
+int ksplit_factor(const FdArgs& a, int it_total, int ntl, int nch) {
+    if (!C::TALL || !segnb_knob_fprop_ksplit()) return 1;
+    if (a.bn_y != nullptr || a.ep_act >= 0 || a.dbg || a.up_out != nullptr) return 1;
+    const long long tiles = (long long)it_total * ntl;
+    int cus = segnb_knob_conv_cus();
+    // A data gradient (no statistics) of a two-stream backward runs beside the weight-gradient stream, which sizes its launches
+    // for a share of the CUs (wgrad_s1.hip: s1_slabs): slices beyond the CUs that are left would queue behind their partners
+    // and only add the hand-over
+    static const int dgrad_pct = getenv("SEGNB_KSPLIT_DGRAD_PCT") != nullptr ? atoi(getenv("SEGNB_KSPLIT_DGRAD_PCT")) : 50;
+    if (a.stats == nullptr) cus = cus * dgrad_pct / 100;
+    int ks = 1;
+    if (tiles * 2 <= cus && nch % 2 == 0 && nch / 2 >= 2) ks = 2;
+    if (tiles * 4 <= cus && nch % 4 == 0 && nch / 4 >= 2) ks = 4;
+    const int forced = segnb_knob_fprop_ksplit();
+    if (forced > 1 && nch % forced == 0 && nch / forced >= 2 && (forced == 2 || forced == 4)) ks = forced;
+    if (tiles * ks * 65536ll >= (1ll << 31)) return 1;
+    return ks;
+}
+
 template <class C>
 int launch_ws(FdArgs& a, hipStream_t stream) {
     static int attr_rc = [] {
@@ -1070,6 +1275,14 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         }
+        if constexpr (C::TALL) {
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        }
         if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }();
@@ -1083,6 +1296,24 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     }
     a.NTL = (a.Co + C::BN - 1) / C::BN;
     a.NCH = a.Ci / 64;
+    a.KS = 1;
+    a.ntmajor = C::TALL && getenv("SEGNB_FPROP_NTMAJOR") != nullptr ? atoi(getenv("SEGNB_FPROP_NTMAJOR")) : (C::TALL ? 1 : 0);
+    if constexpr (C::TALL) {
+        const int ks = ksplit_factor<C>(a, a.IT, a.NTL, a.NCH);
+        if (ks > 1 && ksplit_workspace(stream, (size_t)a.IT * a.NTL * ks * 65536, a.IT * a.NTL, &a.ks_slab, &a.ks_cnt) == 0) {
+            // one tile slice per block: grid = tiles x KS, every block walks NCH / KS chunks
+            a.KS = ks;
+            a.NCH /= ks;
+            a.GM = a.IT;
+            a.ks_slab_bytes = (unsigned)((size_t)a.IT * a.NTL * ks * 65536);
+            const dim3 grid(a.IT * a.NTL * ks);
+            if (a.stats != nullptr || !segnb_knob_fprop_nostats())
+                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, true, false, true>), grid, dim3(C::NT), C::SMEM, stream, a);
+            else
+                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false, false, true>), grid, dim3(C::NT), C::SMEM, stream, a);
+            return 0;
+        }
+    }
     int gm = segnb_knob_conv_cus() / a.NTL;
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;

@@ -352,6 +352,15 @@ int segnb_knob_bnreduce_fused() {
     }
     return g_bnreduce_fused;
 }
+// split K of conv_fprop_ws_kernel (fprop_dma.hip: ksplit_factor): 0 off, 1 automatic (default), 2 / 4 forced (A/B: SEGNB_FPROP_KSPLIT)
+static int g_fprop_ksplit = -2;
+int segnb_knob_fprop_ksplit() {
+    if (g_fprop_ksplit == -2) {
+        const char* e = getenv("SEGNB_FPROP_KSPLIT");
+        g_fprop_ksplit = e != nullptr ? atoi(e) : 1;
+    }
+    return g_fprop_ksplit;
+}
 static int g_fprop_dma_dbg = 0;
 int segnb_knob_fprop_dma_dbg() { return g_fprop_dma_dbg; }
 // The share of the CUs the WIDE weight-gradient launches size their pixel split for (segnb_conv_wgrad_slabs and the launches
@@ -430,6 +439,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_mf16") == 0) {
         g_fprop_mf16 = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "fprop_ksplit") == 0) {
+        g_fprop_ksplit = value < 0 ? 0 : value;
         return 0;
     }
     if (strcmp(key, "fprop_dma_dbg") == 0) {      // timing builds only: results are WRONG when non-zero

@@ -1008,8 +1008,10 @@ def test_conv_fprop_dma_full_size_reproducible(shape):
     np.testing.assert_allclose(sts[0].numpy(), sts[4].numpy(), rtol=1e-3, atol=1e-3 * float(sts[4].abs().max()))
 
 
+# every distinct (size, Ci, Co) of the timed configuration (lib/models/zf_unet.py:44-56)
 FULL_SIZE_LAYERS = [(32, 224, 3, 32), (32, 224, 32, 32), (32, 112, 32, 64), (32, 112, 64, 64), (32, 56, 64, 128),
-                    (32, 28, 256, 256), (32, 14, 512, 512), (32, 7, 1024, 1024), (32, 14, 1536, 512),
+                    (32, 56, 128, 128), (32, 28, 128, 256), (32, 28, 256, 256), (32, 14, 256, 512), (32, 14, 512, 512),
+                    (32, 7, 512, 1024), (32, 7, 1024, 1024), (32, 14, 1536, 512),
                     (32, 28, 768, 256), (32, 56, 384, 128), (32, 112, 192, 64), (32, 224, 96, 32)]
 
 
@@ -1641,6 +1643,71 @@ def test_conv_fprop_dma_tall_7x7(case):
     yr = F.conv2d(xr, w, b, padding=1)
     yr.backward(dy)
     check(name + ' y vs torch', y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+
+
+@pytest.mark.parametrize('shape', [(32, 512, 1024), (32, 1024, 1024), (32, 1024, 512), (5, 256, 72), (9, 512, 200)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_fprop_split_k_7x7(shape):
+    """Split K of conv_fprop_ws_kernel at the 7 x 7 level (lib/models/zf_unet.py:50, 512 / 1024 channels): KS blocks share one
+    tile, publish fp32 slabs, the block whose ticket is last adds them in slice order.  Against F.conv2d on the CPU (the oracle);
+    KS = 2 / 4 against the unsplit launch (same bf16 outputs but for rounding-boundary flips, same statistics); bitwise equal
+    from launch to launch -- also with a second stream keeping half of the chip busy and the caches warm or flushed, the
+    conditions under which a stale slab would show."""
+    N, Ci, Co = shape
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(Ci + Co + N)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) * (2.0 / (Ci * 9)) ** 0.5).bfloat16().float()
+    b = torch.randn(Co, generator=gen) * 0.1
+    x = torch.randn(N, Ci, 7, 7, generator=gen).bfloat16().float()
+    op = ConvOp(rt, w.cuda(), b.cuda(), [(Ci, Ci)], 1, 1, False, need_dgrad=False)
+    op.pack(7, 7)
+    xv = View.alloc(rt, N, 7, 7, op.Cip)
+    xv.dense()[..., :Ci] = x.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+    yr = F.conv2d(x, w, b, padding=1)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device='cuda')
+    res = {}
+    try:
+        for ks in (0, 1, 2, 4):
+            nv.call('segnb_tune', b'fprop_ksplit', ks)
+            outs = []
+            for rep in range(6):
+                yv = View.alloc(rt, N, 7, 7, op.Cop)
+                yv.t.fill_(7.0)
+                stats = rt.zeros((16, 2, op.Cop), torch.float64)
+                if rep % 3 == 1:      # cold caches
+                    flush = torch.empty(160 << 20, dtype=torch.float32, device='cuda').fill_(1.0)
+                    del flush
+                if rep >= 3:          # uneven load: another queue holds CUs while the slices arrive
+                    with torch.cuda.stream(side):
+                        for _ in range(4):
+                            junk @ junk
+                op.fprop(xv, yv, stats)
+                torch.cuda.synchronize()
+                outs.append((yv.dense().clone(), stats.sum(0).cpu()))
+            for k in range(1, 6):
+                assert torch.equal(outs[0][0], outs[k][0]), 'ks=%d: launch %d differs from launch 0' % (ks, k)
+                np.testing.assert_allclose(outs[k][1].numpy(), outs[0][1].numpy(), rtol=1e-12)
+            res[ks] = outs[0]
+    finally:
+        nv.call('segnb_tune', b'fprop_ksplit', 1)
+    name = 'split-K 7x7 ' + 'x'.join(map(str, shape))
+    for ks in (0, 1, 2, 4):
+        y_g = res[ks][0].float().cpu()
+        check('%s ks=%d y vs torch' % (name, ks), y_g[..., :Co].permute(0, 3, 1, 2), yr, 'bf16')
+        assert op.Cop == Co or float(y_g[..., Co:].abs().max()) == 0.0
+        ys = yr.bfloat16().double()
+        st = res[ks][1]
+        np.testing.assert_allclose(st[0, :Co].numpy(), ys.sum((0, 2, 3)).numpy(), rtol=1e-3,
+                                   atol=2e-2 * float(ys.abs().max()) * (N * 49) ** 0.5)
+        np.testing.assert_allclose(st[1, :Co].numpy(), (ys * ys).sum((0, 2, 3)).numpy(), rtol=2e-3)
+    # the split sum is another fp32 evaluation order: outputs equal the unsplit launch's but for single-ulp flips (near zero:
+    # the absolute fp32 difference of a cancelling sum)
+    for ks in (2, 4):
+        got, ref = res[ks][0].float().cpu(), res[0][0].float().cpu()
+        diff = (got - ref).abs()
+        assert bool((diff <= ref.abs() * 2.0 ** -7 + 2e-5).all()), '%s ks=%d: more than one bf16 ulp from the unsplit launch' % (name, ks)
+        assert int((diff > 0).sum()) <= 2e-2 * got.numel()
 
 
 # ------------------------------------------------------------------------------------------------------

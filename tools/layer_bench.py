@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--nostats', type=int, default=None, help='segnb_tune fprop_nostats (0/1)')
     ap.add_argument('--roll', type=int, default=None, help='segnb_tune fprop_roll (0/1/2)')
     ap.add_argument('--wroll', type=int, default=None, help='segnb_tune wgrad_roll (0/1)')
+    ap.add_argument('--ksplit', type=int, default=None, help='segnb_tune fprop_ksplit (0 off / 1 auto / 2 / 4)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     ap.add_argument('--wgrad-unpack', type=int, default=0,
                     help='1: time the per-layer unpack (packed fp32 workspace -> parameter-layout gradient) with the '
@@ -60,6 +61,8 @@ def main():
         nv.call('segnb_tune', b'wgrad_roll', args.wroll)
     if args.cfg is not None:
         nv.call('segnb_tune', b'fprop_dma_cfg', args.cfg)
+    if args.ksplit is not None:
+        nv.call('segnb_tune', b'fprop_ksplit', args.ksplit)
     f, N, S = 32, args.batch, args.size
     w = [f, 2 * f, 4 * f, 8 * f, 16 * f, 32 * f]
     layers = []
