@@ -354,7 +354,12 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
     if (threadIdx.x == 6 && blockIdx.x == 0) ret = atomicAdd(&dst[6], (double)n);
     if constexpr (FIN) {
         __shared__ int last;
-        if (ret == -1.2345e300) fin[7] = 1.f;           // (never: keeps the returned values -- and the wait for them -- alive)
+        if (ret == -1.2345e300) fin[7] = 1.f;           // (never: keeps the returned values alive)
+        // the sums are agent-scope atomics (performed at the device's coherence point, like the ticket and the last block's
+        // loads): what the hand-over needs is ORDER -- this block's adds performed before its ticket is drawn.  An explicit
+        // wait for the returned values, invisible to the compiler's passes, instead of relying on where it places its own
+        // (ADVICE r4); tests/test_hip_ops.py pins the result against the three-launch form at 512 .. 2048 blocks
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned* ticket = reinterpret_cast<unsigned*>(sums + LOSS_REPL * 8);

@@ -173,8 +173,16 @@ thread_local hipEvent_t g_armed_ev = nullptr;
 thread_local hipStream_t g_armed_stream = nullptr;
 thread_local bool g_armed_taken = false;
 }  // namespace
+// Every SEGNB_LAUNCH_FORKABLE launch on the armed stream between arm and commit carries an event; commit waits on the one of the
+// LAST such launch (the stream is in order: it covers the earlier ones).  A second forkable launch used to find the event taken
+// and go out bare, so the side stream's dependency on it was silently dropped (today every caller issues exactly one).
 hipEvent_t segnb_take_armed_event(hipStream_t stream) {
-    if (g_armed_ev == nullptr || g_armed_taken || stream != g_armed_stream) return nullptr;
+    if (g_armed_ev == nullptr || stream != g_armed_stream) return nullptr;
+    if (g_armed_taken) {
+        hipEvent_t ev = next_event();        // (an event is recorded once per dispatch: a later launch takes a fresh one)
+        if (ev == nullptr) return nullptr;   // commit then waits on the earlier launch only -- and says so below
+        g_armed_ev = ev;
+    }
     g_armed_taken = true;
     return g_armed_ev;
 }

@@ -233,9 +233,8 @@ class _ZFUnetPlan(object):
     # (+ head), the two deepest encoder blocks (71 MB of the 126 MB of gradients), the rest.  Each group is unpacked
     # as soon as its weight gradients exist (on the side stream, beside the remaining backward) and handed to the
     # data-parallel hook, so its all-reduce overlaps the rest of backward.
-    # CUs (%) the persistent data-gradient kernels size their grids for while the weight gradients hold half of the chip
-    # (measured on one box: 100 -> 5.33 ms/step, 75 -> 5.43, 50 -> 5.45: smaller grids do not pay, left at 100)
-    BWD_CONV_CU_PCT = int(os.environ.get('SEGNB_BWD_CONV_CU_PCT', '100'))
+    # (sizing the persistent data-gradient grids for fewer CUs while the weight gradients hold half of the chip was measured in
+    # round 1: 100 % -> 5.33 ms/step, 75 % -> 5.43, 50 % -> 5.45; the knob is gone)
     UNPACK_GROUPS = ((2 * len(ENCODER), None), (8, 2 * len(ENCODER)), (0, 8))       # conv index ranges
 
     def _seg(self, lvl, N, H, W):
@@ -417,7 +416,7 @@ class _ZFUnetPlan(object):
     def _cplan_key(self, kind, N, H, W, train, need_grad, drop):
         from segnb import engine
         rt = self.rt
-        if not self.use_cplan or rt.device.type != 'cuda' or self.BWD_CONV_CU_PCT != 100:
+        if not self.use_cplan or rt.device.type != 'cuda':
             return None
         side = rt.side_stream()
         return (kind, N, H, W, bool(train), bool(need_grad), tuple(n for n in ENCODER + DECODER if drop[n] is not None),
@@ -671,8 +670,6 @@ class _ZFUnetPlan(object):
             else:
                 ckey = None
         try:
-            if self.BWD_CONV_CU_PCT != 100:
-                nv.call('segnb_tune', b'conv_cu_pct', self.BWD_CONV_CU_PCT)
             if (self.PACK_DG_SIDE or (self.LEFTOVER_DG_SIDE and not self.PACK_OVERLAP)) and rt.side_stream() is not None:
                 # the data gradients' matrices were packed on the side stream (recorded: a replayed list waits too)
                 nv.call('segnb_stream_join', rt.stream, rt.side_stream().cuda_stream)
@@ -729,8 +726,6 @@ class _ZFUnetPlan(object):
                                       dx=b['da1_%d' % i], fuse_reduce_of=s1, postponed=hold0)
                 s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red,
                             flush_before_wgrad=hold0 if i == 0 else None)
-            if self.BWD_CONV_CU_PCT != 100:
-                nv.call('segnb_tune', b'conv_cu_pct', 100)
             rt.join_side()                        # the weight gradients ran on the side stream
             self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
         except BaseException:

@@ -42,6 +42,9 @@ def init_from_env(backend=None):
     td.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
 
 
+_conv_cu_pct = 100        # what segnb_tune('conv_cu_pct') was last set to by this module (process-global knob)
+
+
 class DataParallel(object):
     """Attach gradient / loss-sum synchronisation to a segnb-engine model (in place; returns the model).
 
@@ -79,12 +82,13 @@ class DataParallel(object):
             self._reserve_cus()
 
     def _reserve_cus(self):
-        """RCCL's all-reduce kernels need CUs of their own to run BESIDE the backward: the persistent convolution kernels
-        size their grids for every CU of the chip otherwise (one block per CU, resident for the whole launch), and a
-        collective launched behind them waits for blocks to retire.  With world > 1 the grids are sized for CUs - k
-        (SEGNB_DP_RESERVE_CUS, default 8: one CU per RCCL channel of a ring over the 7 xGMI links + 1).  UNMEASURED on
-        hardware (no multi-GPU node in this build's runs): the knob exists so that the first 8-GPU run can sweep it."""
-        k = int(os.environ.get('SEGNB_DP_RESERVE_CUS', '8'))
+        """RCCL's all-reduce kernels run BESIDE the backward; the persistent convolution kernels size their grids for every
+        CU of the chip (one block per CU, resident for the whole launch).  SEGNB_DP_RESERVE_CUS = k > 0 sizes those grids for
+        CUs - k when world > 1.  Default 0: shrinking a grid does not reserve a CU for anybody (there is no CU mask), so it is
+        a certain loss of convolution throughput for a benefit nobody has measured -- the knob exists so that the
+        first 8-GPU run can sweep it.  The previous value is restored by detach()."""
+        global _conv_cu_pct
+        k = int(os.environ.get('SEGNB_DP_RESERVE_CUS', '0'))
         if k <= 0:
             return
         try:
@@ -94,7 +98,9 @@ class DataParallel(object):
         if cus <= k:
             return
         pct = max(10, (cus - k) * 100 // cus)
+        self._restore_conv_pct = _conv_cu_pct
         nv.call('segnb_tune', b'conv_cu_pct', pct)
+        _conv_cu_pct = pct
         self.reserved_cus = cus - cus * pct // 100
 
     def trace_overlap(self):
@@ -139,6 +145,10 @@ class DataParallel(object):
                 delattr(self.model, name)
         if self.active:
             seglosses.DataParallelHooks.reset()
+        if getattr(self, '_restore_conv_pct', None) is not None:
+            global _conv_cu_pct
+            nv.call('segnb_tune', b'conv_cu_pct', self._restore_conv_pct)
+            _conv_cu_pct, self._restore_conv_pct, self.reserved_cus = self._restore_conv_pct, None, 0
         self.active = False
         self.model._dp_track_accumulation = False
 

@@ -579,8 +579,9 @@ class ConvOp(object):
         l = p['fwd'][0]
         g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
         _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-               lambda: nv.call('segnb_conv_wgrad_bnapply', g, rt.code, xv.ptr, gv.ptr, gv.ld, yv.ptr, yv.ld, nv.ptr(coef),
-                               nv.ptr(bcoef), self.Cop, act, slope, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream))
+               lambda: self._under_wg_share(lambda: nv.call(
+                   'segnb_conv_wgrad_bnapply', g, rt.code, xv.ptr, gv.ptr, gv.ld, yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(bcoef),
+                   self.Cop, act, slope, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)))
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
@@ -892,8 +893,9 @@ class UpCatConvOp(object):
             p, l, sk, src = self._upcat_args(xv)
             g = self.full._geom(p, 'fv', 0, l, xv.N, xv.H, xv.W, self.full.Cip, sk.ld, dyv.H, dyv.W, self.full.Cop, dyv.ld)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-                   lambda: nv.call('segnb_conv_wgrad_upcat', g, self.rt.code, sk.ptr, src, dyv.ptr, nv.ptr(p['dwp'][0]),
-                                   p['nslab'][0], self.rt.stream))
+                   lambda: self.full._under_wg_share(lambda: nv.call(
+                       'segnb_conv_wgrad_upcat', g, self.rt.code, sk.ptr, src, dyv.ptr, nv.ptr(p['dwp'][0]), p['nslab'][0],
+                       self.rt.stream)))
             return
         if not self.segment_wgrad:
             return self.full.wgrad(xv, dyv, grad_w, unpack)

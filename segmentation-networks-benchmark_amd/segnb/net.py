@@ -1005,9 +1005,9 @@ class HipNet(nn.Module):
                     paused[0] = False
             try:
                 tape.run_closures(around)
-            except Exception:
-                # (KeyboardInterrupt / SystemExit propagate untouched: the entry is dropped by the `finally`-free path of the
-                # next step, which finds state 'fwd' without a backward and records again)
+            except BaseException:
+                # (KeyboardInterrupt / SystemExit too: an open recording would swallow every later ABI call of this thread and
+                # make segnb_plan_run / segnb_tune refuse -- a validation pass in a Ctrl-C handler would hit that)
                 if recording:
                     if not paused[0]:
                         nv.plan_record_abort()

@@ -94,7 +94,11 @@ def register_grad_buffer(logits, buf):
 
 
 def _grad_buffer_for(x):
-    buf = _grad_buffers.get(x.data_ptr())
+    """The registered buffer, handed out AT MOST ONCE per forward: a second loss term on the same logits
+    (``BCEWithSigmoidLoss()(out, y) + DiceLoss()(out, y)``), a second seg_loss call or a retained graph gets a fresh tensor --
+    two backward nodes returning the same storage would overwrite each other and autograd would add the tensor to itself
+    (ADVICE r4).  The model copies when the gradient it receives is not its buffer (ZF_UNET.backward)."""
+    buf = _grad_buffers.pop(x.data_ptr(), None)
     if buf is not None and buf.shape == x.shape and buf.dtype == x.dtype and buf.device == x.device:
         return buf
     return None
@@ -116,7 +120,13 @@ def reduce_finalize(x, t, spec):
         work = _loss_work.get(key)
         if work is None:
             work = _loss_work[key] = torch.zeros(128, dtype=torch.float64, device=x.device)
-        nv.call('segnb_seg_loss_reduce_finalize', nv.ptr(x), nv.ptr(t), x.numel(), _cspec(spec), nv.ptr(work), nv.ptr(fin), st)
+        try:
+            nv.call('segnb_seg_loss_reduce_finalize', nv.ptr(x), nv.ptr(t), x.numel(), _cspec(spec), nv.ptr(work), nv.ptr(fin), st)
+        except BaseException:
+            # the launch itself re-zeroes the buffer; one that failed may not have: the next loss on this stream starts from
+            # a fresh, zeroed one instead of inheriting partial sums or a ticket
+            _loss_work.pop(key, None)
+            raise
         return work, fin
     sums = torch.zeros(8, dtype=torch.float64, device=x.device)
     nv.call('segnb_seg_loss_reduce', nv.ptr(x), nv.ptr(t), x.numel(), float(spec[10]), nv.ptr(sums), st)

@@ -45,10 +45,17 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)            # ranks start DIFFERENT: the broadcast must fix that
     m = ZF_UNET(dropout_val=0.0, filters=4).set_compute_dtype('f32').train()
     emu = nv._test_backend
+    # SEGNB_DP_RESERVE_CUS = 8: the persistent convolution grids are sized for 96 % = 245 of the 256 emulated CUs (11 left to
+    # the collectives); detach() restores the previous value.  Default 0: nothing is touched (unmeasured on hardware: ADVICE r4)
+    os.environ['SEGNB_DP_RESERVE_CUS'] = '8'
+    dp0 = sdist.DataParallel(m, bucket_bytes=256 << 10)
+    assert emu.tuned.get('conv_cu_pct') == 96 and dp0.reserved_cus == 11, (getattr(emu, 'tuned', None), dp0.reserved_cus)
+    dp0.detach()
+    assert emu.tuned.get('conv_cu_pct') == 100 and dp0.reserved_cus == 0
+    del os.environ['SEGNB_DP_RESERVE_CUS']
+    emu.tuned.pop('conv_cu_pct')
     dp = sdist.DataParallel(m, bucket_bytes=256 << 10)      # small buckets -> several all-reduces
-    # world > 1: the persistent convolution grids leave CUs to the collectives (segnb_tune conv_cu_pct; 256 emulated CUs,
-    # SEGNB_DP_RESERVE_CUS default 8 -> 96 % = 245 CUs, 11 reserved)
-    assert emu.tuned.get('conv_cu_pct') == 96 and dp.reserved_cus == 11, (getattr(emu, 'tuned', None), dp.reserved_cus)
+    assert 'conv_cu_pct' not in emu.tuned and dp.reserved_cus == 0
     x, y = train_step_ref.synthetic_batch(4, 64, seed=77)
     xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
     with torch.no_grad():

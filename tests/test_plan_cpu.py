@@ -74,6 +74,35 @@ def test_tiny_forward_backward_vs_golden(golden_dir):
         np.testing.assert_allclose(b.numpy(), g['buf/' + n], rtol=1e-5, atol=1e-6, err_msg=n)
 
 
+def test_two_loss_terms_on_one_output_sum_their_gradients():
+    """``BCEWithSigmoidLoss()(out, y) + DiceLoss()(out, y)``: two backward nodes on the logits of one forward (lib/losses.py:7-53
+    composed by hand, as torch_train_reg.py adds a penalty to a loss).  The model's registered d(loss)/d(logits) buffer is handed
+    to ONE of them; the parameter gradients equal the sum of the gradients of the two terms taken alone (with the
+    buffer shared they were 2 x the gradient of the second term)."""
+    from lib.losses import BCEWithSigmoidLoss, DiceLoss
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 64, 64, generator=gen)
+    y = (torch.rand(2, 1, 64, 64, generator=gen) > 0.6).long()
+
+    def grads(which):
+        m = _model(4, 0.0, 11.0)
+        m.train()
+        out = m(x)
+        terms = {'bce': lambda: BCEWithSigmoidLoss()(out, y), 'dice': lambda: DiceLoss()(out, y)}
+        loss = sum(terms[k]() for k in which)
+        (2 * loss).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    g_b, g_d, g_sum = grads(['bce']), grads(['dice']), grads(['bce', 'dice'])
+    for n in g_sum:
+        ref = g_b[n] + g_d[n]
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((g_sum[n] - ref).abs().max()) <= 1e-4 * scale + 1e-9, n
+    # and the failure the fix removes is detectable: the sum is not 2 x either term
+    w = 'down_1.l1.conv.weight' if 'down_1.l1.conv.weight' in g_sum else next(n for n in g_sum if n.endswith('conv.weight'))
+    assert float((g_sum[w] - 2 * g_d[w]).abs().max()) > 1e-3 * float(g_sum[w].abs().max())
+
+
 def test_tiny_training_trajectory_with_torch_sgd(golden_dir):
     """The literal step body of torch_train.py:180-190 with torch.optim.SGD driving our module."""
     g = np.load(os.path.join(golden_dir, 'zf_unet_tiny.npz'))
