@@ -48,7 +48,9 @@ def cpu_baseline(seconds_budget=20.0):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 32)))    # beyond ~32 threads oneDNN slows down on this problem size
+    # thread count from the sweep on the GPU box's 256-core host (tools/cpu_sweep.py, profiles/r05_cpu_sweep.txt): 8 threads 12.0
+    # images/s, 16 -> 17.8, 32 -> 12.7, 64 -> 5.2, 128 -> 2.6, 256 -> 0.06 -- oneDNN's B=4 convolutions stop scaling at 16
+    torch.set_num_threads(max(1, min(ncpu, 16)))
     B, S = 4, 224
     x, y = train_step_ref.synthetic_batch(B, S, seed=1234)
     sd = zf_unet_ref.default_init_state(filters=32, seed=0)
@@ -177,6 +179,90 @@ def rendezvous_check(args):
     return 0 if int(ones.item()) == max(1, args.gpus) else 3
 
 
+def bench_tiled(args):
+    """BASELINE.json configs[4] at the size SURVEY 8d states: inria_submit.predict_tiled (/root/reference/inria_submit.py:237-257)
+    over a synthetic 5000 x 5000 x 3 uint8 image -- tile 1024, step 512 (81 tiles), D4 TTA (648 forward items), batch 4,
+    pyramid weights -- on segnb.tiled.predict_tiled with the default UNet16 (bf16, eval).  One "step" = one image.  Reports
+    tiles/s, ms per image, the GPU-time share of upload / gather / forward / logits copy / merge / download (HIP events between
+    the phases) and the fraction of the model's own eval-forward rate at batch 4 measured in the same process."""
+    import numpy as np
+    from segnb import dist as sdist
+    from segnb import _native as nv
+    from segnb.engine import InputNorm
+    from segnb.tiled import predict_tiled
+    import warnings
+    sdist.init_from_env()
+    ws, rank = sdist.world(), sdist.rank()
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) if ws > 1 else 0)
+    torch.cuda.set_device(dev)
+    nv.load()
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from lib.models.unet16 import UNet16
+        model = UNet16().set_compute_dtype(args.dtype).to(dev).eval()
+    S, B = args.size or 1024, args.batch or 4
+    side = args.image_size
+    rng = np.random.RandomState(1234)
+    image = rng.randint(0, 256, size=(side, side, 3), dtype=np.uint8)
+    norm = InputNorm(mean=(0.40, 0.42, 0.38), std=(0.19, 0.18, 0.18))       # (INRIA_MEAN / INRIA_STD stand-ins: lib/datasets/Inria.py:34)
+    # the model's own eval-forward rate at this batch (the ceiling predict_tiled is measured against)
+    x = torch.randn(B, 3, S, S, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nf = 30
+        for _ in range(nf):
+            model(x)
+        torch.cuda.synchronize()
+        fwd_ips = B * nf / (time.perf_counter() - t0)
+    for _ in range(max(1, args.warmup)):
+        predict_tiled(image, model, norm, S, B)
+    if ws > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    timing, t0 = {}, time.perf_counter()
+    for i in range(args.steps):
+        mask = predict_tiled(image, model, norm, S, B, timing=timing if i == args.steps - 1 else None)
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if ws > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    items = timing['nitems']
+    ms_img = dt / args.steps * 1e3
+    tiles_s = items * args.steps / dt
+    tot = sum(timing['ms'].values())
+    line = {
+        'metric': 'tile forwards/sec: predict_tiled (UNet16 %dx%d tiles, step %d, D4 TTA x8) over a %dx%dx3 uint8 image'
+                  % (S, S, S // 2, side, side),
+        'value': round(tiles_s, 2), 'unit': 'tiles/s', 'n_gpus': ws, 'steps': args.steps, 'warmup': max(1, args.warmup),
+        'ms_per_step': round(ms_img, 2), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[4]: TernausNet VGG16-UNet, lib/tiles.py sliding-window inference '
+                               '(inria_submit.predict_tiled), one step = one image', 'image': '%dx%dx3 uint8' % (side, side),
+                   'tile': S, 'tile_step': S // 2, 'tiles': timing['ntiles'], 'items_per_image': items, 'batch': B,
+                   'forward_batches_per_image': timing['batches'], 'weight': 'pyramid'},
+        'tiled': {'ms_per_image': round(ms_img, 2),
+                  'gpu_ms_by_phase_last_image': {k: round(v, 2) for k, v in timing['ms'].items()},
+                  'share_by_phase': {k: round(v / tot, 4) for k, v in timing['ms'].items()},
+                  'eval_forward_images_per_s_batch%d' % B: round(fwd_ips, 1),
+                  'fraction_of_eval_forward_ceiling': round(tiles_s / (fwd_ips * ws), 4),
+                  'note': 'gather of batch k+1 and the logits copy of batch k run on the launch stream between the forwards: '
+                          'together < 1 % of the image (share_by_phase), so no side stream is used; the merge is one launch '
+                          'at the end over the logits of all %d items kept in HBM' % items,
+                  'mask_mean': round(float(mask.mean()), 6)},
+    }
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,6 +286,10 @@ def main():
     ap.add_argument('--wire', default='f32', choices=['f32', 'bf16'],
                     help='N > 1: wire format of the gradient all-reduce buckets (bf16 halves the bytes on xGMI; the sum is '
                          'taken in bf16 by RCCL -- off by default: the headline keeps the fp32 exchange)')
+    ap.add_argument('--tiled', action='store_true',
+                    help='BASELINE.json configs[4] as a bench line: predict_tiled over a synthetic 5000x5000x3 uint8 image with '
+                         'UNet16 (tile 1024 / step 512 / D4 TTA / batch 4); one step = one image (default --steps 3 --warmup 1)')
+    ap.add_argument('--image-size', type=int, default=5000, help='--tiled: side of the synthetic image')
     ap.add_argument('--dry-run', action='store_true',
                     help='join the job, count the ranks (all-reduce of ones), print n_gpus / ranks_seen and stop')
     args = ap.parse_args()
@@ -209,6 +299,12 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.dry_run:
         sys.exit(rendezvous_check(args))
+    if args.tiled:
+        if '--steps' not in sys.argv:
+            args.steps = 3
+        if '--warmup' not in sys.argv:
+            args.warmup = 1
+        return bench_tiled(args)
 
     from segnb import dist as sdist
     from segnb import engine, optim

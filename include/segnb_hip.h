@@ -63,6 +63,13 @@ int segnb_wg_cu_share(int pct);
  * "fprop_dma_dbg" = 32.  host_dst: HOST buffer of 3 x 256 x 4 unsigned 64-bit values ([wave role][tap][event]);
  * synchronises the device (tools/stamps.py). */
 int segnb_debug_stamps(unsigned long long* host_dst);
+/* Replay guard (segnb.engine.ReplayGuard; SEGNB_REPLAY_GUARD=1): while segnb_tune("call_census", 1) is on, every top-level entry
+ * point executed on the calling thread -- called directly or from segnb_plan_run -- is counted by name.  Writes the census as
+ * "name count\n" lines into the HOST buffer buf (cap bytes, NUL-terminated, truncated if it does not fit) and clears it.
+ * A step replayed from recorded lists must execute exactly the launches the step that recorded them executed: a launch made by
+ * host code next to a recorded list and missing from the replay path shows as a difference (round 4's batched bias gradients
+ * were lost that way from the third step of a geometry on). */
+int segnb_debug_census(char* buf, int cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Generalised gather-convolution geometry.  One launch computes, for every image n and every
@@ -200,6 +207,12 @@ int segnb_conv_fprop_u8(const segnb_conv_geom* g, const unsigned char* img, int 
 int segnb_tiles_gather(const float* image, int H, int W, int C, int margin_top, int margin_left,
                        const int* crops_xy, int first_item, int count, int S, float* out,
                        segnb_stream_t stream);
+/* The same batch gathered from the UNNORMALISED uint8 HWC image (what cv2.imread hands inria_submit.py:298), NormalizeImage
+ * (lib/augmentations.py:452-460: (x * scale - mean) / std, inria_submit.py:238) in registers; mean / stdv: HOST arrays of C
+ * floats (C <= 8).  A 5000 x 5000 x 3 Inria image crosses PCIe as 75 MB instead of 300 MB.  Not recordable. */
+int segnb_tiles_gather_u8(const unsigned char* image, int H, int W, int C, int margin_top, int margin_left,
+                          const int* crops_xy, int first_item, int count, int S, float scale, const float* mean,
+                          const float* stdv, float* out, segnb_stream_t stream);
 
 /* logits: fp32 [ntiles*8][K][S][S] (model outputs of every item).  out: fp32 [H][W][K] = merge(deaug(sigmoid)):
  * per tile the mean over the 8 un-transformed predictions (float32, the reference's order), then the weighted

@@ -863,6 +863,14 @@ class AbiEmulator(object):
             O[b] = self._d4(k, t)
         return 0
 
+    def segnb_tiles_gather_u8(self, image, H, W, C, mt, ml, crops, first, count, S, scale, mean, stdv, out, stream):
+        # NormalizeImage of lib/augmentations.py:452-460 on the uint8 image, then the float gather
+        img = _mem(image, H * W * C, torch.uint8).view(H, W, C).float()
+        mean_t = torch.tensor([float(mean[c]) for c in range(C)])
+        istd_t = torch.tensor([1.0 / float(stdv[c]) for c in range(C)], dtype=torch.float32)
+        norm = ((img * float(scale) - mean_t) * istd_t).contiguous()
+        return self.segnb_tiles_gather(norm.data_ptr(), H, W, C, mt, ml, crops, first, count, S, out, stream)
+
     def segnb_tiles_merge(self, logits, K, S, crops, ntiles, step, nx, ny, weight, H, W, mt, ml, out, stream):
         L = _mem(logits, ntiles * 8 * K * S * S, torch.float32).view(ntiles, 8, K, S, S)
         cr = _mem(crops, 2 * ntiles, torch.int32).view(ntiles, 2)
@@ -1153,6 +1161,9 @@ class AbiEmulator(object):
         return 256
 
     def segnb_debug_stamps(self, host_dst):
+        return 0
+
+    def segnb_debug_census(self, buf, cap):       # (no launch lists on the CPU: nothing to compare)
         return 0
 
     def segnb_sgd_step(self, p, g, n, lr, stream):

@@ -93,12 +93,16 @@ inline void segnb_plan_record_call(const char* name, int (*fn)(P...), A... args)
 }
 // first statement of a recordable extern "C" entry point (entry points that take HOST arrays -- tap offsets, mean / std --
 // are not recordable: SEGNB_PLAN_REFUSE marks the plan being recorded as unusable)
+extern int g_segnb_census_on;          // segnb_tune("call_census"): count the top-level entry points by name (segnb_debug_census)
+void segnb_census(const char* name);
 #define SEGNB_PLAN_RECORD(fn, ...)                                                           \
     SegnbPlanScope plan_scope__;                                                             \
+    if (plan_scope__.top && g_segnb_census_on) segnb_census(#fn);                            \
     if (plan_scope__.top && segnb_plan_recording()) segnb_plan_record_call(#fn, fn, __VA_ARGS__)
 void segnb_plan_refuse(const char* why);
 #define SEGNB_PLAN_REFUSE(why)                                         \
     SegnbPlanScope plan_scope__;                                       \
+    if (plan_scope__.top && g_segnb_census_on) segnb_census(__func__); \
     if (plan_scope__.top && segnb_plan_recording()) segnb_plan_refuse(why)
 
 int segnb_num_cus();

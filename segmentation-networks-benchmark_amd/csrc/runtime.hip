@@ -100,6 +100,21 @@ void plan_profile_dump() {
 }
 }  // namespace
 
+// ---- call census (replay guard) ---------------------------------------------------------------------------------------
+int g_segnb_census_on = 0;
+namespace {
+thread_local std::map<std::string, long> g_census;
+}
+void segnb_census(const char* name) { ++g_census[name]; }
+extern "C" int segnb_debug_census(char* buf, int cap) {
+    SEGNB_CHECK_ARG(buf != nullptr && cap > 0, "NULL buffer");
+    std::string out;
+    for (auto& kv : g_census) out += kv.first + " " + std::to_string(kv.second) + "\n";
+    g_census.clear();
+    snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return 0;
+}
+
 extern "C" int segnb_plan_begin(void) {
     delete g_rec;            // (a recording abandoned by an exception on the host side)
     g_rec = new Plan();
@@ -447,6 +462,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_mf16") == 0) {
         g_fprop_mf16 = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "call_census") == 0) {
+        g_segnb_census_on = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_ksplit") == 0) {

@@ -49,6 +49,32 @@ __global__ void tiles_gather_kernel(const float* __restrict__ img, int H, int W,
     }
 }
 
+// the same gather from the uint8 image itself, NormalizeImage (lib/augmentations.py:452-460: (x * scale - mean) / std) in
+// registers: a 5000 x 5000 x 3 Inria image is uploaded as 75 MB instead of 300 MB and never exists as floats
+struct TileNorm {
+    float scale, mean[8], inv_std[8];
+};
+__global__ void tiles_gather_u8_kernel(const unsigned char* __restrict__ img, int H, int W, int C, int mt, int ml,
+                                       const int* __restrict__ crops, int first, int count, int S, TileNorm nm,
+                                       float* __restrict__ out) {
+    const long long total = (long long)count * C * S * S;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % S);
+        long long q = i / S;
+        const int r = (int)(q % S);
+        q /= S;
+        const int ch = (int)(q % C);
+        const int b = (int)(q / C);
+        const int item = first + b, tile = item >> 3, k = item & 7;
+        int sr, sc;
+        d4_src(k, S, r, c, sr, sc);
+        const int y = reflect101(crops[2 * tile + 1] + sr - mt, H);
+        const int x = reflect101(crops[2 * tile] + sc - ml, W);
+        out[i] = ((float)img[((long long)y * W + x) * C + ch] * nm.scale - nm.mean[ch]) * nm.inv_std[ch];
+    }
+}
+
 __global__ void tiles_merge_kernel(const float* __restrict__ logits, int K, int S, const int* __restrict__ crops,
                                    int ntiles, int step, int nx, int ny, const double* __restrict__ weight,
                                    int H, int W, int mt, int ml, float* __restrict__ out) {
@@ -112,6 +138,29 @@ extern "C" int segnb_tiles_gather(const float* image, int H, int W, int C, int m
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(tiles_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, H, W, C, margin_top,
                        margin_left, crops_xy, first_item, count, S, out);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_tiles_gather_u8(const unsigned char* image, int H, int W, int C, int margin_top, int margin_left,
+                                     const int* crops_xy, int first_item, int count, int S, float scale, const float* mean,
+                                     const float* stdv, float* out, segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_tiles_gather_u8 takes host mean / std arrays");
+    SEGNB_CHECK_ARG(image && crops_xy && out && mean && stdv && H > 1 && W > 1 && C > 0 && C <= 8 && S > 0 && count > 0 &&
+                        first_item >= 0,
+                    "bad arguments");
+    TileNorm nm;
+    nm.scale = scale;
+    for (int e = 0; e < 8; ++e) {
+        SEGNB_CHECK_ARG(e >= C || stdv[e] != 0.f, "std must be non-zero");
+        nm.mean[e] = e < C ? mean[e] : 0.f;
+        nm.inv_std[e] = e < C ? 1.0f / stdv[e] : 0.f;
+    }
+    const long long total = (long long)count * C * S * S;
+    int grid = ceil_div(total, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(tiles_gather_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, image, H, W, C, margin_top,
+                       margin_left, crops_xy, first_item, count, S, nm, out);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

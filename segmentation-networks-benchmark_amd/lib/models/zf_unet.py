@@ -159,6 +159,9 @@ class _ZFUnetPlan(object):
             blk = getattr(module, name)
             seg1 = [(widths[lvl + 1], self.wp[lvl + 1]), (widths[lvl], self.wp[lvl])]
             self._add(name, blk, seg1, True, upcat=self.subpixel)
+        from segnb.engine import ReplayGuard
+        self._guard_f, self._guard_b = ReplayGuard('ZF_UNET forward'), ReplayGuard('ZF_UNET backward')
+        self._guard_mode = (None, None)
         self._bufs = {}
         self._pack_tables = {}
         self._retired_tables = []
@@ -510,6 +513,15 @@ class _ZFUnetPlan(object):
 
     # ---- forward ---------------------------------------------------------------------------------------
     def forward(self, x, train, need_grad):
+        # (SEGNB_REPLAY_GUARD=1: a replayed forward must execute the launches of the forward that recorded its lists)
+        # The census starts where the two paths part (the list look-up): what precedes it -- Dropout2d tables, the weight pack when
+        # the parameters changed, the gradient-buffer clear, the input pack -- is the same host code either way
+        self._guard_mode, self._guard_active = (None, None), False
+        out = self._forward(x, train, need_grad)
+        self._guard_f.end(self._guard_active, *self._guard_mode)
+        return out
+
+    def _forward(self, x, train, need_grad):
         rt = self.rt
         self.flat.ensure(rt.device)
         u8 = x.dtype == torch.uint8
@@ -543,7 +555,9 @@ class _ZFUnetPlan(object):
                         st.stats.zero_()
                         st._stats_stale = False
             plan = self._cplans.get(ckey)
+            self._guard_active = self._guard_f.begin()
             if plan is not None and plan[0] is not None:
+                self._guard_mode = (ckey, 'replay')
                 self._plan_replay(plan)
                 self._last = (N, H, W) if need_grad else None
                 self._last_train = bool(train)
@@ -595,6 +609,8 @@ class _ZFUnetPlan(object):
             raise
         if ckey is not None:
             self._plan_end(ckey)
+            if self._cplans[ckey][0] is not None:
+                self._guard_mode = (ckey, 'record')
         self._last = (N, H, W) if need_grad else None
         self.generation += 1                       # every forward overwrites the activation buffers
         self._last_train = bool(train)
@@ -638,6 +654,12 @@ class _ZFUnetPlan(object):
 
     # ---- backward --------------------------------------------------------------------------------------
     def backward(self, dlogits):
+        self._guard_mode, self._guard_active = (None, None), False
+        out = self._backward(dlogits)
+        self._guard_b.end(self._guard_active, *self._guard_mode)
+        return out
+
+    def _backward(self, dlogits):
         rt, flat, wp = self.rt, self.flat, self.wp
         if self._last is None:
             raise RuntimeError('backward without a grad-enabled forward')
@@ -659,7 +681,9 @@ class _ZFUnetPlan(object):
                 din.copy_(dlogits)                        # (a loss that did not write into the registered buffer)
             dlogits = din
             plan = self._cplans.get(ckey)
+            self._guard_active = self._guard_b.begin()
             if plan is not None and plan[0] is not None:
+                self._guard_mode = (ckey, 'replay')
                 self._plan_replay(plan, H, W)
                 rt._side_busy = False
                 self._after_backward()
@@ -734,6 +758,8 @@ class _ZFUnetPlan(object):
             raise
         if ckey is not None:
             self._plan_end(ckey)
+            if self._cplans[ckey][0] is not None:
+                self._guard_mode = (ckey, 'record')
         self._after_backward()
         # gradients live in ONE flat buffer; parameter.grad tensors are views of it (installed here, not
         # returned through autograd, so they never get cloned and a flat optimizer / all-reduce can run)

@@ -126,6 +126,8 @@ SIGNATURES = {
     'segnb_abn_scale': [_P, c_float, _P, c_int, _P],
     'segnb_abn_dscale': [_P, _P, _P, c_int, _P],
     'segnb_tiles_gather': [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P],
+    'segnb_tiles_gather_u8': [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_float,
+                              ctypes.POINTER(c_float), ctypes.POINTER(c_float), _P, _P],
     'segnb_tiles_merge': [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'segnb_bn_stats': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
@@ -160,6 +162,7 @@ SIGNATURES = {
     'segnb_event_record': [_P, _P],
     'segnb_stream_join': [_P, _P],
     'segnb_debug_stamps': [_P],
+    'segnb_debug_census': [ctypes.c_char_p, c_int],
     'segnb_sgd_step': [_P, _P, c_ll, c_float, _P],
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
@@ -249,6 +252,20 @@ def plan_record_abort():
             call('segnb_plan_destroy', handle)
         except Exception:
             pass
+
+
+def census_read():
+    """{entry point: executions on this thread since the last read} while segnb_tune('call_census', 1) is on (cleared by the
+    read); {} on the CPU emulator, which has no launch lists."""
+    if _test_backend is not None:
+        return {}
+    buf = ctypes.create_string_buffer(1 << 16)
+    call('segnb_debug_census', buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, v = line.rsplit(' ', 1)
+        out[k] = int(v)
+    return out
 
 
 def query(name, *args):

@@ -70,6 +70,59 @@ def _timed(label, flops, fn, executed=None):
         TIMER.launch(label, flops, fn, executed)
 
 
+class ReplayGuard(object):
+    """Structural check of record / replay (SEGNB_REPLAY_GUARD=1, or ``ReplayGuard.enable()``; debug mode, GPU only).
+
+    A model's forward / backward is either run by the Python launcher while the library records its ABI calls, or replayed from
+    the recorded lists (segnb_plan_run) with whatever host code sits around them.  Nothing ties the two together: a launch that
+    the recording step makes from host code NEXT TO a list (after the recording was closed, or while it was paused) and that
+    the replay path forgets to repeat is silently missing from every later step -- round 4's batched bias gradients
+    (segnb_bias_grad_multi) disappeared that way and every convolution bias without a BatchNorm stopped training.
+    With the guard on, the library counts every top-level entry point it executes, by name, whether it was called directly or from
+    a replayed list (segnb_tune "call_census" / segnb_debug_census); the census of the step that RECORDED a (model, phase, key)
+    is kept and every REPLAYED step of that key must reproduce it exactly, or the step raises with the difference."""
+    enabled = os.environ.get('SEGNB_REPLAY_GUARD', '0') != '0'
+    _on = False
+    IGNORE = ('segnb_tune',)
+
+    @classmethod
+    def enable(cls, on=True):
+        cls.enabled = bool(on)
+        if not on and cls._on:
+            nv.call('segnb_tune', b'call_census', 0)
+            cls._on = False
+
+    def __init__(self, what):
+        self.what = what
+        self.ref = {}
+        self.checked = 0
+
+    def begin(self):
+        if not self.enabled or nv.has_test_backend():
+            return False
+        if not ReplayGuard._on:
+            nv.call('segnb_tune', b'call_census', 1)       # (process-wide switch: never inside a recording -- segnb_tune is refused there)
+            ReplayGuard._on = True
+        nv.census_read()
+        return True
+
+    def end(self, active, key, mode):
+        """mode: 'record' (this step recorded the lists of `key`), 'replay' (it ran from them) or anything else (eager: ignored)"""
+        if not active:
+            return
+        c = {k: v for k, v in nv.census_read().items() if k not in self.IGNORE}
+        if mode == 'record':
+            self.ref[key] = c
+        elif mode == 'replay' and key in self.ref:
+            ref = self.ref[key]
+            if c != ref:
+                diff = ['%s: recorded step %d, replayed step %d' % (k, ref.get(k, 0), c.get(k, 0))
+                        for k in sorted(set(ref) | set(c)) if ref.get(k, 0) != c.get(k, 0)]
+                raise RuntimeError('%s: a replayed step does not execute the launches of the step that recorded it -- %s'
+                                   % (self.what, '; '.join(diff)))
+            self.checked += 1
+
+
 class Runtime(object):
     """Per-model execution context: device, compute dtype, stream."""
 

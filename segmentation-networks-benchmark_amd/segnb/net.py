@@ -901,7 +901,23 @@ class HipNet(nn.Module):
                 nv.call('segnb_plan_destroy', h)
         ent['fwd'] = ent['bwd'] = None
 
+    def _guards(self):
+        g = getattr(self, '_replay_guards', None)
+        if g is None:
+            from .engine import ReplayGuard
+            g = self._replay_guards = (ReplayGuard(type(self).__name__ + ' forward'), ReplayGuard(type(self).__name__ + ' backward'))
+        return g
+
     def _run(self, x, need_grad):
+        # (SEGNB_REPLAY_GUARD=1: a replayed forward must execute the launches of the forward that recorded its list)
+        # the census starts where the two paths part (the list look-up): Tape.begin -- dropout pools, the weight pack when the
+        # parameters changed -- the gradient-buffer clear and the input pack are the same host code either way
+        self._guard_mode, self._guard_active = (None, None), False
+        out = self._run_(x, need_grad)
+        self._guards()[0].end(self._guard_active, *self._guard_mode)
+        return out
+
+    def _run_(self, x, need_grad):
         tape = self._tape
         tape.begin(self.training, need_grad)
         if self.training and need_grad:
@@ -920,10 +936,12 @@ class HipNet(nn.Module):
         pack_input(tape.rt, x, xin, getattr(self, 'input_norm', None))
         if key is not None:
             ent = tape.plans.get(key)
+            self._guard_active = self._guards()[0].begin()
             if ent is None:
                 ent = tape.plans[key] = {'state': 'seen'}                  # first step of this key: eager
             else:
                 if ent['state'] == 'ready':
+                    self._guard_mode = (key, 'replay')
                     nv.call('segnb_plan_run', ent['fwd'])
                     tape.back = []
                     tape.fused_stats = ent['fused_stats']
@@ -951,10 +969,17 @@ class HipNet(nn.Module):
             else:
                 ent.update(fwd=handle, logits=logits, nfwd=nops, state='fwd' if need_grad else 'ready',
                            fused_stats=list(tape.fused_stats))
+                self._guard_mode = (key, 'record')
                 self._plan_live = ent if need_grad else None
         return logits.clone()
 
     def _run_backward(self, dlogits):
+        self._guard_mode, self._guard_active = (None, None), False
+        out = self._run_backward_(dlogits)
+        self._guards()[1].end(self._guard_active, *self._guard_mode)
+        return out
+
+    def _run_backward_(self, dlogits):
         tape = self._tape
         if not tape.train and any(isinstance(m, nn.modules.batchnorm._BatchNorm) or type(m).__name__ == 'InPlaceABN'
                                   for m in tape.flat.module_list()):
@@ -969,7 +994,9 @@ class HipNet(nn.Module):
                 din = ent['dlogits_in'] = torch.empty_like(dlogits)
             din.copy_(dlogits)                                              # (autograd hands over a new tensor every step)
             dlogits = din
+        self._guard_active = self._guards()[1].begin() if ent is not None else False
         if ent is not None and ent['state'] == 'ready':
+            self._guard_mode = (id(ent), 'replay')
             for handle, cut in ent['bwd']:
                 nv.call('segnb_plan_run', handle)
                 if cut is not None:          # host work between two segments: partial unpack + the data-parallel hook
@@ -1028,6 +1055,7 @@ class HipNet(nn.Module):
                     ent['state'] = 'eager'
                 else:
                     ent.update(bwd=[(h, c) for h, _, c in segs], nbwd=sum(n for _, n, _ in segs), state='ready')
+                    self._guard_mode = (id(ent), 'record')
             table = tape.run_unpack()                                       # (7x7 / strided jobs take host tap arrays: eager)
             if recording and ent['state'] == 'ready':
                 ent['unpack'] = table

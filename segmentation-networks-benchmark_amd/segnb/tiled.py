@@ -34,21 +34,53 @@ def item_range(nitems, world, rank):
     return min(rank * chunk, nitems), min((rank + 1) * chunk, nitems), chunk
 
 
-def predict_tiled(image, model, test_transform, patch_size, batch_size, weight='pyramid'):
+def _as_normalize(t, C):
+    """(scale, mean, std) when `t` is nothing but a NormalizeImage (lib/augmentations.py:452-460) -- the object itself
+    (segnb.engine.InputNorm has the same fields) or the reference's ``Sequential([ImageOnly(NormalizeImage(..))])`` of
+    inria_submit.py:286-288 -- with one mean / std per channel; else None."""
+    for _ in range(3):
+        if all(hasattr(t, a) for a in ('scale', 'mean', 'std')):
+            mean, std = np.atleast_1d(np.asarray(t.mean, dtype=np.float32)), np.atleast_1d(np.asarray(t.std, dtype=np.float32))
+            if len(mean) == C and len(std) == C and C <= 8 and np.all(std != 0):
+                return float(t.scale), nv.float_array(mean), nv.float_array(std)
+            return None
+        inner = getattr(t, 'transforms', None)
+        if inner is not None and len(inner) == 1:
+            t = inner[0]
+        elif hasattr(t, 'trans') and type(t).__name__ == 'ImageOnly':
+            t = t.trans
+        else:
+            return None
+    return None
+
+
+def predict_tiled(image, model, test_transform, patch_size, batch_size, weight='pyramid', timing=None):
     """Same positional signature as inria_submit.predict_tiled (:237).  image: HxWxC array; ``test_transform`` is
     applied as ``image, _ = test_transform(image)`` (pass None for an already normalised image).  model: a
     segnb-backed module on a GPU, called in eval mode without autograd.  Returns the float32 HxW (K=1) or HxWxK
     probability mask."""
-    if test_transform is not None:
-        image, _ = test_transform(image)
-    image = np.ascontiguousarray(image, dtype=np.float32)
+    image = np.asarray(image)
     if image.ndim == 2:
         image = image[..., None]
+    # uint8 image + a NormalizeImage transform (inria_submit.py:238): the image is uploaded as it is and normalised by the
+    # gather kernel (segnb_tiles_gather_u8) -- 1/4 of the PCIe bytes and no host pass over 75 M values per Inria image
+    norm = _as_normalize(test_transform, image.shape[2]) if (image.dtype == np.uint8 and test_transform is not None) else None
+    if norm is not None:
+        image = np.ascontiguousarray(image)
+    else:
+        if test_transform is not None:
+            image, _ = test_transform(image)
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        if image.ndim == 2:
+            image = image[..., None]
     H, W, C = image.shape
     slicer = ImageSlicer(image.shape, patch_size, patch_size // 2, weight=weight)
     device = next(model.parameters()).device
     stream = torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+    ev = (lambda name: None) if timing is None else _Marks(timing, device)
+    ev('start')
     img = torch.from_numpy(image).to(device)
+    ev('upload')
     crops = torch.tensor([[c[0], c[1]] for c in slicer.crops], dtype=torch.int32, device=device)
     wt = torch.from_numpy(np.ascontiguousarray(slicer.compute_weight(patch_size), dtype=np.float64)).to(device)
     ntiles, S = len(slicer.crops), patch_size
@@ -65,24 +97,57 @@ def predict_tiled(image, model, test_transform, patch_size, batch_size, weight='
         x = torch.zeros((batch_size, C, S, S), dtype=torch.float32, device=device)
         for first in range(lo, max(hi, lo + 1), batch_size):
             count = min(batch_size, hi - first)
-            if count > 0:
+            if count > 0 and norm is not None:
+                nv.call('segnb_tiles_gather_u8', nv.ptr(img), H, W, C, slicer.margin_top, slicer.margin_left,
+                        nv.ptr(crops), first, count, S, norm[0], norm[1], norm[2], nv.ptr(x), stream)
+            elif count > 0:
                 nv.call('segnb_tiles_gather', nv.ptr(img), H, W, C, slicer.margin_top, slicer.margin_left,
                         nv.ptr(crops), first, count, S, nv.ptr(x), stream)
+            ev('gather')
             y = model(x)
+            ev('forward')
             if logits is None:
                 K = y.shape[1]
                 logits = torch.zeros((world * chunk, K, S, S), dtype=torch.float32, device=device)
             if count > 0:
                 logits[first:first + count] = y[:count]
+            ev('keep')
         if world > 1:
             parts = [logits[r * chunk:(r + 1) * chunk] for r in range(world)]
             td.all_gather(parts, parts[rank].clone())
         out = torch.empty((H, W, K), dtype=torch.float32, device=device)
         nv.call('segnb_tiles_merge', nv.ptr(logits), K, S, nv.ptr(crops), ntiles, slicer.tile_step, nx, ny, nv.ptr(wt),
                 H, W, slicer.margin_top, slicer.margin_left, nv.ptr(out), stream)
+        ev('merge')
     if was_training:
         model.train()
-    return out.cpu().numpy()
+    res = out.cpu().numpy()
+    ev('download')
+    if timing is not None:
+        ev.finish(ntiles=ntiles, nitems=nitems, batches=(max(hi, lo + 1) - lo + batch_size - 1) // batch_size)
+    return res
+
+
+class _Marks(object):
+    """predict_tiled(timing={}): HIP events between the phases (no synchronisation inside the loop); finish() fills the dict
+    with the GPU milliseconds per phase -- upload, gather, forward, keep (logits into the all-items buffer), merge, download."""
+
+    def __init__(self, out, device):
+        self.out, self.device, self.marks = out, device, []
+
+    def __call__(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        self.marks.append((name, e))
+
+    def finish(self, **extra):
+        torch.cuda.synchronize(self.device)
+        ms = {}
+        for (_, a), (name, b) in zip(self.marks[:-1], self.marks[1:]):
+            ms[name] = ms.get(name, 0.0) + a.elapsed_time(b)
+        self.out.update(extra)
+        self.out['ms'] = ms
+        self.out['total_ms'] = self.marks[0][1].elapsed_time(self.marks[-1][1])
 
 
 def pad_to_multiple(image, pad_size):

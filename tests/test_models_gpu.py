@@ -338,6 +338,17 @@ def test_unet16_1024_tiled_config():
     ref = tiles_ref.predict_tiled(img, logits_fn, 1024, 4)
     assert got.shape == (1100, 1300, 1) and np.isfinite(got).all()
     np.testing.assert_allclose(got[..., 0], ref[..., 0] if ref.ndim == 3 else ref, rtol=1e-5, atol=1e-5)
+    # (3) the uint8 image with a NormalizeImage transform (inria_submit.py:286-288), normalised inside the gather kernel
+    #     (segnb_tiles_gather_u8: what `bench.py --tiled` times on a 5000 x 5000 image) == the oracle fed the host-normalised image
+    from segnb.engine import InputNorm
+    img8 = rng.randint(0, 256, size=(1100, 1300, 3), dtype=np.uint8)
+    nm = InputNorm(mean=(0.40, 0.42, 0.38), std=(0.19, 0.18, 0.18))
+    timing = {}
+    got8 = predict_tiled(img8, m, nm, 1024, 4, timing=timing)
+    host = ((img8 * nm.scale - np.array(nm.mean, dtype=np.float32)) / np.array(nm.std, dtype=np.float32)).astype(np.float32)
+    ref8 = tiles_ref.predict_tiled(host, logits_fn, 1024, 4)
+    np.testing.assert_allclose(got8[..., 0], ref8[..., 0] if ref8.ndim == 3 else ref8, rtol=1e-4, atol=2e-4)
+    assert timing['nitems'] == 32 and set(timing['ms']) >= {'upload', 'gather', 'forward', 'merge', 'download'}
 
 
 def test_inplace_abn_standalone_gpu():

@@ -228,6 +228,49 @@ def test_predict_tiled_reference_positional_order():
     assert np.array_equal(got, ref)
 
 
+def test_predict_tiled_uint8_image_normalised_by_the_gather():
+    """A uint8 image with the reference's own transform object -- ``Sequential([ImageOnly(NormalizeImage(mean, std))])``,
+    inria_submit.py:286-288 -- is uploaded as bytes and normalised inside the gather (segnb_tiles_gather_u8; here the emulator):
+    the mask equals the host-normalised float image's to float32 rounding of (x * scale - mean) / std."""
+    from segnb.engine import InputNorm
+    from segnb.tiled import predict_tiled, _as_normalize
+
+    class NormalizeImage:                      # field-for-field the reference's class (lib/augmentations.py:452-460)
+        def __init__(self, scale=1. / 255., mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+            self.scale, self.mean, self.std = float(scale), np.array(mean, dtype=np.float32), np.array(std, dtype=np.float32)
+
+        def __call__(self, x):
+            return (x * self.scale - self.mean) / self.std
+
+    class ImageOnly:
+        def __init__(self, trans):
+            self.trans = trans
+
+        def __call__(self, x, mask=None):
+            return self.trans(x), mask
+
+    class Sequential:
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x, mask=None):
+            for t in self.transforms:
+                x, mask = t(x, mask)
+            return x, mask
+
+    rng = np.random.RandomState(7)
+    img = (rng.rand(45, 52, 3) * 255).astype(np.uint8)
+    tf = Sequential([ImageOnly(NormalizeImage(mean=(0.41, 0.43, 0.39), std=(0.2, 0.19, 0.21)))])
+    assert _as_normalize(tf, 3) is not None and _as_normalize(InputNorm(), 3) is not None
+    assert _as_normalize(tf, 1) is None and _as_normalize(lambda im: (im, None), 3) is None
+    model = _Lin(16)
+    t = {}
+    got = predict_tiled(img, model, tf, 16, 4)
+    ref = predict_tiled(tf(img)[0], model, None, 16, 4)          # the host-normalised float image through the float gather
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+    assert got.shape[:2] == (45, 52)
+
+
 def _tiled_worker(rank, world, port, out_dir):
     import os
     import sys

@@ -640,7 +640,7 @@ print(json.dumps({'lead_ms': t['first_bucket'].elapsed_time(t['backward_end']), 
 torch.distributed.destroy_process_group()
 """ % root
     env = dict(os.environ, SEGNB_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-               MASTER_ADDR='127.0.0.1', MASTER_PORT='29751')
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29751', SEGNB_DP_RESERVE_CUS='8')      # (the knob's default is 0)
     out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     import json
