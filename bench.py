@@ -255,9 +255,9 @@ def bench_tiled(args):
                   'share_by_phase': {k: round(v / tot, 4) for k, v in timing['ms'].items()},
                   'eval_forward_images_per_s_batch%d' % B: round(fwd_ips, 1),
                   'fraction_of_eval_forward_ceiling': round(tiles_s / (fwd_ips * ws), 4),
-                  'note': 'gather of batch k+1 and the logits copy of batch k run on the launch stream between the forwards: '
-                          'together < 1 % of the image (share_by_phase), so no side stream is used; the merge is one launch '
-                          'at the end over the logits of all %d items kept in HBM' % items,
+                  'note': ('gather of batch k+1 and the logits copy of batch k run on the launch stream between the forwards: '
+                          'together < 2 %% of the image (share_by_phase), so no side stream is used; the merge is one launch '
+                          'at the end over the logits of all %d items kept in HBM') % items,
                   'mask_mean': round(float(mask.mean()), 6)},
     }
     print(json.dumps(line))

@@ -203,7 +203,9 @@ def test_launch_plans_replay_matches_eager(name):
     scale = max(float(v.norm()) for v in g0.values())
     for k in g0:
         err = float((g1[k] - g0[k]).norm())
-        assert err <= 5e-2 * float(g0[k].norm()) + 1e-6 * scale, (k, err, float(g0[k].norm()), float(g1[k].norm()))
+        # (fp32 parity mode: the general weight-gradient kernel's float atomics and ReLUs within an ulp of zero make two runs of
+        # the SAME launcher differ by this much on the smallest tensors; a gradient missing from the replay is off by its norm)
+        assert err <= 5e-2 * float(g0[k].norm()) + 1e-5 * scale, (k, err, float(g0[k].norm()), float(g1[k].norm()))
     np.testing.assert_allclose(l1, l0, rtol=0, atol=2e-3)
     for a, b in zip(e1, e0):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
