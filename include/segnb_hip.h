@@ -114,12 +114,6 @@ int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const 
 int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype);
 int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                      float* dwp, int nslab, segnb_stream_t stream);
-/* The same, but the nslab partial slabs [nslab][Co][ntaps][Ci] are left UNREDUCED: the caller sums them where it consumes
- * them -- segnb_unpack_wgrad_multi with the job's nslab field -- instead of paying a reduction launch per layer that
- * writes the sum back only for the unpack to read it again. */
-int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout, float* dwp,
-                             int nslab, segnb_stream_t stream);
-
 /* Weight gradient whose dout operand is not in memory: it is the BatchNorm-backward apply of the layer,
  *     dout = round(a * (round(g * act'(z)) - c1 - yhat * c2)),   z = (y - mean) * scale + shift,  yhat = (y - mean) * invstd
  * (lib/modules/abn/functions.py:118's dx, the arithmetic and roundings of segnb_bn_bwd_apply_direct), recomputed from the
@@ -147,7 +141,7 @@ int segnb_unpack_wgrad(float* dwp, float* gw, int Mp, int Cp, int ntaps, long lo
  * array of njobs records, each segnb_pack_job_bytes() long:
  *   { const float* param_or_grad; void* packed; const int* mmap; const int* cmap; int64 s_m, s_c;
  *     int32 Mp, Cp, ntaps, dtype, block_start, nslab; int32 tap_off[SEGNB_MAX_TAPS]; }
- *     (nslab: unpack jobs only -- partial slabs to sum, see segnb_conv_wgrad_partial; 0 or 1 = a single slab)
+ *     (nslab: unpack jobs only -- partial slabs to sum in slab order; 0 or 1 = a single slab)
  * sorted by block_start; job k owns blocks [block_start_k, block_start_k + segnb_pack_job_blocks(...)) (LDS-tiled
  * transposes: both the parameter side and the packed side are accessed in contiguous runs).
  * segnb_pack_job_blocks returns -1 for kernels wider than 3x3 (use the single-job calls for those).
@@ -349,18 +343,6 @@ int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, i
                                     const float* coef, const double* sums, const float* gamma, float* bcoef,
                                     float* dgamma, float* dbeta, int accumulate, double* fwd_stats_to_clear, int act,
                                     float slope, const void* g, int ld_g, void* dy, int ld_dy, segnb_stream_t stream);
-
-/* Reduction + finalize + apply of a SMALL tensor in ONE launch: a block owns an 8-channel group and holds every pixel of it in
- * registers (segnb_bn_bwd_owner_ok: N*H*W <= 8192 for bf16, 4096 for f32 -- the 14x14 / 7x7 levels of ZF_UNET at bs=32), so
- * lib/modules/abn/functions.py:95-130's two sums, (a, c1, c2), dgamma / dbeta and dy = a (dz - c1 - yhat c2) with
- * dz = round(g act'(z)) need no sums buffer, no atomics and a single read of y and g.  Single direct gradient source, no
- * Dropout2d multiplier; the same values as segnb_bn_act_bwd_reduce (dz = NULL) + segnb_bn_bwd_apply_fused_direct up to the order
- * of the sums (fp32 per thread, fp64 across the block, fixed order).  dy may alias g. */
-int segnb_bn_bwd_owner_ok(int dtype, int N, int H, int W, int Cp);
-int segnb_bn_bwd_owner(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
-                       const float* gamma, float* bcoef, float* dgamma, float* dbeta, int accumulate,
-                       double* fwd_stats_to_clear, int act, float slope, const void* g, int ld_g, void* dy, int ld_dy,
-                       segnb_stream_t stream);
 
 /* out = a + b (skip ADD of linknet.py:77-79; gradient accumulation of multi-consumer tensors); out may alias a.
  * A NULL operand counts as zeros: (NULL, b) copies b, (NULL, NULL) clears out -- the strided copies / clears of the

@@ -267,8 +267,6 @@ class AbiEmulator(object):
         if not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
                 and g.Co % 8 == 0 and g.Wo >= 12):
             return 0
-        if g.Ci % 64 == 0 and g.Ci >= 192 and g.Co > 32 and getattr(self, 'tuned', {}).get('ws_bnreduce', 0):      # the wide-layer variant
-            return 1
         return int(g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and not (g.Co > 32 and g.Ci > 32))
 
     def segnb_conv_fprop_bnreduce(self, g, dtype, in_p, wp, out_p, ep, stream):
@@ -383,27 +381,6 @@ class AbiEmulator(object):
         g2.ld_out = Cp
         return self.segnb_conv_wgrad(g2, dtype, in_p, tmp.data_ptr(), dwp, nslab, stream)
 
-    def segnb_conv_wgrad_partial(self, g, dtype, in_p, dout_p, dwp, nslab, stream):
-        """partial slabs left unreduced: the emulated device splits the pixel range over the images (slab s = images
-        s, s + nslab, ...); segnb_unpack_wgrad_multi sums them (job field nslab)"""
-        if nslab != self.segnb_conv_wgrad_slabs(g, dtype):
-            return 1
-        if nslab == 1:
-            return self.segnb_conv_wgrad(g, dtype, in_p, dout_p, dwp, nslab, stream)
-        g = _geom(g)
-        dt = _tdt(dtype)
-        X = _nhwc(in_p, g.N, g.Hi, g.Wi, g.Ci, g.ld_in, dt)
-        D = _nhwc(dout_p, g.N, g.Ho, g.Wo, g.Co, g.ld_out, dt)
-        oh = torch.arange(g.QH) * g.out_step + g.oh0
-        ow = torch.arange(g.QW) * g.out_step + g.ow0
-        G = _mem(dwp, nslab * g.Co * g.ntaps * g.Ci, torch.float32).view(nslab, g.Co, g.ntaps, g.Ci)
-        G.zero_()
-        for n in range(g.N):
-            d = D[n:n + 1][:, oh[:, None], ow[None, :], :].float().reshape(-1, g.Co)
-            for t in range(g.ntaps):
-                G[n % nslab, :, t, :] += d.t() @ _gather(X[n:n + 1], g, t).reshape(-1, g.Ci)
-        return 0
-
     def _maps(self, Mp, Cp, ntaps, tap_off, mmap, cmap):
         mm = _mem(mmap, Mp, torch.int32).long()
         cm = _mem(cmap, Cp, torch.int32).long()
@@ -500,7 +477,7 @@ class AbiEmulator(object):
     def segnb_unpack_wgrad_multi(self, jobs, njobs, total_blocks, stream):
         for j in self._jobs(jobs, njobs):
             ns = int(j['nslab'])
-            if ns > 1:                      # partial slabs of segnb_conv_wgrad_partial: slab 0 += slabs 1.., in order
+            if ns > 1:                      # partial slabs (job field nslab > 1): slab 0 += slabs 1.., in order
                 n1 = int(j['Mp']) * int(j['ntaps']) * int(j['Cp'])
                 G = _mem(int(j['packed']), ns * n1, torch.float32).view(ns, n1)
                 for sl in range(1, ns):
@@ -793,21 +770,6 @@ class AbiEmulator(object):
             _mem(clear_stats, REPL * 2 * Cp, torch.float64).zero_()
         return rc or self.segnb_bn_bwd_apply_direct(dtype, y, ld_y, N, H, W, Cp, coef, bcoef, act, slope, g, ld_g, dy,
                                                     ld_dy, None, C, stream)
-
-    def segnb_bn_bwd_owner_ok(self, dtype, N, H, W, Cp):
-        if os.environ.get('SEGNB_BN_OWNER', '0') == '0' or min(N, H, W, Cp) <= 0 or Cp % 8:
-            return 0
-        return int(N * H * W <= (8192 if dtype == BF16 else 4096))
-
-    def segnb_bn_bwd_owner(self, dtype, y, ld_y, N, H, W, C, Cp, coef, gamma, bcoef, dgamma, dbeta, accumulate, clear_stats,
-                           act, slope, g, ld_g, dy, ld_dy, stream):
-        """reduction (sums only, into a scratch buffer) + finalize + direct apply: one launch on the device"""
-        sums = torch.zeros(REPL * 2 * Cp, dtype=torch.float64)
-        rc = self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, None, g, ld_g, None, 0, None, 0,
-                                          None, 0, sums.data_ptr(), None, 0, stream)
-        return rc or self.segnb_bn_bwd_apply_fused_direct(dtype, y, ld_y, N, H, W, C, Cp, coef, sums.data_ptr(), gamma, bcoef,
-                                                          dgamma, dbeta, accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy,
-                                                          stream)
 
     def segnb_bn_bwd_apply_fused_direct_acc(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta,
                                             accumulate, clear_stats, act, slope, g, ld_g, dy, ld_dy, stream):

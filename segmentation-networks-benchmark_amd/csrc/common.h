@@ -120,7 +120,6 @@ int segnb_knob_fprop_ksplit();   // conv_fprop_ws_kernel split K: 0 off, 1 autom
 // head backward's per-(device, stream) partial-sum scratch and its fixed-order finish launch (head_loss.hip)
 float* segnb_head_scratch(size_t bytes, hipStream_t stream);
 void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream);
-int segnb_knob_ws_bnreduce();    // conv_fprop_ws_kernel's BatchNorm-reduce variant (segnb_tune "ws_bnreduce")
 int segnb_knob_pack_blocks();    // persistent blocks of segnb_pack_weight_multi (0: one block per tile)
 int segnb_knob_fprop_roll();     // 0: off, 1: conv_roll_kernel with 16-column strips, 2: 32-column strips (segnb_tune "fprop_roll")
 int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of the CUs for the 64x64-tile weight gradients

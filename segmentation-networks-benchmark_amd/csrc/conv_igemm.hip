@@ -766,7 +766,7 @@ struct __attribute__((aligned(8))) PackJob {
     long long s_m, s_c;
     int Mp, Cp, ntaps, dtype;
     int block_start;         // first block of this job; jobs sorted by it
-    int nslab;               // unpack jobs: partial slabs to sum ([nslab][Mp][ntaps][Cp], segnb_conv_wgrad_partial); 0/1 = one
+    int nslab;               // unpack jobs: partial slabs to sum ([nslab][Mp][ntaps][Cp]); 0/1 = one
     // masked != 0: tap_off[t] is a BIT MASK over the (<= 9) kernel positions of the parameter tensor instead of one offset --
     //   pack  : packed(m, t, c) = sum over the set positions k of w(m, c, k)      (rounded once, after the fp32 sum)
     //   unpack: gw(m, c, k)    += sum over the taps t whose mask holds k of dwp(m, t, c)          (taps in order)
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void pack_tile(const PackJob* __restrict__ jobs, int 
                 const long long di = ((long long)mp * nt + t) * Cp + cp;
                 float v[8];
                 load8(dwp + di, v);
-                // partial slabs of the pixel splits (segnb_conv_wgrad_partial): summed here, in slab order, instead of by
+                // partial slabs of pixel splits (a job's nslab > 1): summed here, in slab order, instead of by
                 // a reduction launch per layer that wrote the sum back for this kernel to read again
                 const long long sstride = (long long)Mp * nt * Cp;
                 for (int sl = 1; sl < j.nslab; ++sl) {
@@ -1618,14 +1618,6 @@ extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype)
     if (g->QH != g->Ho || g->QW != g->Wo || g->Co % 8 != 0 || g->Wo < 12) return 0;
     for (int t = 0; t < 9; ++t)
         if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
-    // wide layers: conv_fprop_ws_kernel's BatchNorm-reduce variant (the halo waves take the sums): >= 3 K chunks of 64 channels,
-    // 64-channel output tiles, the 16x16x32 form with row-major taps (segnb_tune "ws_bnreduce" / SEGNB_WS_BNREDUCE)
-    if (g->Ci % 64 == 0 && g->Ci >= 192 && g->Co > 32 && segnb_knob_ws_bnreduce() && segnb_knob_fprop_mf16() &&
-        segnb_knob_fprop_dma_cfg() < 2) {
-        bool row_major = true;
-        for (int t = 0; t < 9; ++t) row_major = row_major && g->dw[t] == g->dw[t % 3] && g->dh[t] == g->dh[3 * (t / 3)];
-        if (row_major) return 1;
-    }
     if (g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 64) return 0;
     if (g->Co > 32 && g->Ci > 32) return 0;      // (the 64-wide tile keeps one 32-channel chunk of weights resident)
     return 1;
@@ -1657,8 +1649,6 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
-
-static thread_local bool g_wgrad_partial = false;      // set by segnb_conv_wgrad_partial around its call
 
 static bool wgrad_general_only() {
     static const bool v = getenv("SEGNB_WGRAD_GENERAL") != nullptr;   // A/B testing only
@@ -1692,17 +1682,17 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
         if (rc == 0 && !wgrad_general_only() && segnb_knob_wgrad_c8roll() && segnb_wgrad_s1_slabs(g) > 0)
-            rc = segnb_wgrad_c8roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+            rc = segnb_wgrad_c8roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
         if (rc == 0)
-            rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+            rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;
         }
         if (rc != 0) return rc;
-        rc = wgrad_general_only() ? 0 : segnb_wgrad_sx_try(g, in, dout, dwp, nslab, (hipStream_t)stream, g_wgrad_partial);
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_sx_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
         if (rc == 1) {
             SEGNB_LAUNCH_CHECK();
             return 0;
@@ -1787,15 +1777,6 @@ extern "C" int segnb_conv_wgrad_tf(const segnb_conv_geom* g, int dtype, const vo
         segnb_set_error("segnb_conv_wgrad_tf: no kernel for this geometry");
         return SEGNB_E_UNSUPPORTED;
     }
-    return rc;
-}
-
-extern "C" int segnb_conv_wgrad_partial(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
-                                        float* dwp, int nslab, segnb_stream_t stream) {
-    SEGNB_PLAN_RECORD(segnb_conv_wgrad_partial, g, dtype, in, dout, dwp, nslab, stream);
-    g_wgrad_partial = true;
-    const int rc = segnb_conv_wgrad(g, dtype, in, dout, dwp, nslab, stream);
-    g_wgrad_partial = false;
     return rc;
 }
 

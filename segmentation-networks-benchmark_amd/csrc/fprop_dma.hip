@@ -132,20 +132,13 @@ struct WsCfg {
 // code of the training kernels it cost 0.22 ms per step (5.62 vs 5.40 ms, same box)
 // STATS: BatchNorm statistics in the store rows (forward launches) -- data gradients take none and run the instantiation
 // without the 16 accumulator registers and ~32 VALU per stored row
-// BNR: the launch is a data gradient that also does the BatchNorm-backward REDUCTION of the layer that produced its forward
-// input (segnb_conv_fprop_bnreduce, FdArgs::bn_*).  The matrix waves are those of the plain data gradient (they stage and store g);
-// the two HALO waves, which issue a handful of DMA requests per tap and wait, take the sums: per tile each of their 128 lanes
-// owns 16 (row, 8-channel chunk) pieces -- y of those pixels is requested during the tile's LAST chunk (the pixel table of a tile
-// exists before its first tap) and lands under that chunk's one counted wait, the staged g rows are read back from LDS one per tap
-// during the first two chunks of the NEXT tile, dz = round(g * act'(z)) as bn_act_bwd_reduce_kernel computes it, sum dz and sum dz * yhat
-// per lane.  Needs at least THREE K chunks per tile (Ci >= 192): the pieces of tile i are consumed during the first two chunks of
-// tile i + 1, whose own requests go out in its last chunk into the same registers.
+// (A BatchNorm-backward REDUCTION variant of the data gradient -- the two halo waves taking the sums -- was built in round 4 and
+// measured slower in the step, ZF_UNET +1.6 %, LinkNet34 +2.8 %: DESIGN 11.10; removed in round 5.  fprop_rw.hip / fprop_roll.hip
+// keep their fused reductions.)
 // SPLITK: FdArgs::KS blocks per (pixel tile, channel tile), every block owns ONE tile slice (grid = tiles x KS); see FdArgs::KS
-template <class C, bool DBG, bool EP = false, bool STATS = true, bool BNR = false, bool SPLITK = false>
+template <class C, bool DBG, bool EP = false, bool STATS = true, bool SPLITK = false>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
-    static_assert(!SPLITK || (!BNR && !EP && !DBG && C::UP == 0 && C::NTAP == 9), "split K: plain 3 x 3 forward / data gradient");
-    static_assert(!BNR || (!STATS && !EP && C::MF16 && C::NTAP == 9 && !C::TALL && C::UP == 0 && C::BN == 64 && C::BM == 256),
-                  "BatchNorm-reduce variant: plain 3 x 3 data gradient, 16x16x32 form, 256-row x 64-channel tiles");
+    static_assert(!SPLITK || (!EP && !DBG && C::UP == 0 && C::NTAP == 9), "split K: plain 3 x 3 forward / data gradient");
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
     constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
     constexpr int OUT_ROW = C::OUT_ROW, NF = TM + TN;
@@ -318,7 +311,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
             // The same call writes the tile's output pixel table (read by the store rows one tile later).
             unsigned a_rel[APW], a_xy[APW], a_voff[C::NPL][APW];
             unsigned a_uoff[APW];         // virtual concat: the same halo pixels in the low-resolution tensor u
-            const bool vcat = !BNR && a.u != nullptr;      // (BNR: no virtual concat -- its offset array costs 21 registers)
+            const bool vcat = a.u != nullptr;
         #pragma unroll
             for (int pa = 0; pa < APW; ++pa) {
                 const int pix = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
@@ -400,18 +393,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 for (int pa = 0; pa < APW; ++pa) {
                     const int hi = h0 + (int)(a_xy[pa] & 0xffffu), wi = w0 + (int)(a_xy[pa] >> 16);
                     const bool ok = (unsigned)hi < hlim && (unsigned)wi < (unsigned)a.Wi;
-                    if constexpr (BNR) {
-                        // (the halo waves hold 64 registers of y here: the per-piece relative offset is recomputed per tile
-                        // instead of kept -- 21 registers for ~6 instructions per piece and tile)
-                        const int xr_ = (int)(a_xy[pa] & 0xffffu), xc_ = (int)(a_xy[pa] >> 16);
-                        const int pix_ = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
-                        const int key_ = C::XC % 2 == 0 ? xc_ : pix_;
-                        const unsigned rel = (unsigned)(xr_ * a.Wi + xc_) * (unsigned)a.ld_x * 2u +
-                                             (unsigned)(((lane & 7) ^ ((key_ >> 1) & 7)) * 16);
-                        a_voff[0][pa] = ok ? base + rel : OOB;
-                    } else {
-                        a_voff[0][pa] = ok ? base + a_rel[pa] : OOB;
-                    }
+                    a_voff[0][pa] = ok ? base + a_rel[pa] : OOB;
                     if (vcat) {      // nearest-x2 upsample = the pixel (hi >> 1, wi >> 1) of u, same channel slot
                         const int pixl = ((lw & 1) + C::NAW * pa) * 8 + (lane >> 3);
                         const int keyl = C::XC % 2 == 0 ? pixl % XC : pixl;
@@ -481,75 +463,6 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     go(std::integral_constant<int, 0>{});
                 }
             };
-            // ---- BatchNorm-reduce pieces of this lane (BNR)
-            typedef __attribute__((ext_vector_type(4))) unsigned hu32x4_t;
-            const int t128 = (lw & 1) * 64 + lane;
-            const int bcc = t128 & 7, br0 = t128 >> 3;         // 8-channel chunk of the 64-channel tile, first of 16 rows
-            const bool bcok = BNR && n_base + bcc * 8 < a.Co;
-            const unsigned char* const sOutH = smem + C::OFF_STG;
-            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<bf16_t*>(BNR ? a.bn_y : a.x), 0, BNR ? (int)a.bn_y_bytes : 0, 0x00020000);
-            float bs1[8], bs2[8], bmu[8], bsc[8], bsh[8];
-            float bneg = 0.f;
-            hu32x4_t yq[BNR ? 16 : 1];
-            if constexpr (BNR) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = n_base + bcc * 8 + e;
-                    const bool in = ch < a.Co;
-                    bsc[e] = in ? a.bn_coef[ch] : 0.f;
-                    bsh[e] = in ? a.bn_coef[a.Co + ch] : 0.f;
-                    bmu[e] = in ? a.bn_coef[2 * a.Co + ch] : 0.f;
-                    bs1[e] = bs2[e] = 0.f;
-                }
-                bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) yq[k] = hu32x4_t{0u, 0u, 0u, 0u};
-            }
-            auto bnr_req = [&](auto k_c, const int* tabp) {       // y of piece k of the tile whose pixel table is tabp
-                constexpr int k = decltype(k_c)::value;
-                const int pix = tabp[br0 + 16 * k];
-                const unsigned voff = (pix >= 0 && bcok) ? (unsigned)pix * (unsigned)a.bn_ld * 2u + (unsigned)(n_base + bcc * 8) * 2u : OOB;
-                yq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)voff, 0, 0);
-            };
-            auto bnr_piece = [&](auto k_c, const int* tabp) {     // sums of piece k: staged g row x its y
-                constexpr int k = decltype(k_c)::value;
-                const int row = br0 + 16 * k;
-                const int pix = tabp[row];
-                const hu32x4_t gv = *reinterpret_cast<const hu32x4_t*>(sOutH + row * OUT_ROW + bcc * 16);
-                const hu32x4_t yv = yq[k];
-                const float m = (pix >= 0 && bcok) ? 1.f : 0.f;
-                float gq[8], yf[8];
-                gq[0] = __uint_as_float(gv.x << 16); gq[1] = __uint_as_float(gv.x & 0xffff0000u);
-                gq[2] = __uint_as_float(gv.y << 16); gq[3] = __uint_as_float(gv.y & 0xffff0000u);
-                gq[4] = __uint_as_float(gv.z << 16); gq[5] = __uint_as_float(gv.z & 0xffff0000u);
-                gq[6] = __uint_as_float(gv.w << 16); gq[7] = __uint_as_float(gv.w & 0xffff0000u);
-                yf[0] = __uint_as_float(yv.x << 16); yf[1] = __uint_as_float(yv.x & 0xffff0000u);
-                yf[2] = __uint_as_float(yv.y << 16); yf[3] = __uint_as_float(yv.y & 0xffff0000u);
-                yf[4] = __uint_as_float(yv.z << 16); yf[5] = __uint_as_float(yv.z & 0xffff0000u);
-                yf[6] = __uint_as_float(yv.w << 16); yf[7] = __uint_as_float(yv.w & 0xffff0000u);
-                if (bneg == 0.f) {
-                    // ReLU (wave-uniform): round(g * 1) = g and round(g * 0) = 0 -- a select instead of multiply + round
-                    const bool live = pix >= 0 && bcok;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float yc = yf[e] - bmu[e];
-                        const float z = yc * bsc[e] + bsh[e];
-                        const float dv = (live && z > 0.f) ? gq[e] : 0.f;
-                        bs1[e] += dv;
-                        bs2[e] += dv * yc;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float yc = yf[e] - bmu[e];
-                        const float z = yc * bsc[e] + bsh[e];
-                        const float dv = bf16_bits_to_f32(f32_to_bf16_bits(gq[e] * (z > 0.f ? 1.f : bneg))) * m;
-                        bs1[e] += dv;
-                        bs2[e] += dv * yc;
-                    }
-                }
-            };
             set_fetch_tile(it, 0);
             fetch_a(0, APW, 0, 0);
             // During a tile's LAST chunk the first chunk of the next tile is fetched, so the per-lane offsets must
@@ -573,73 +486,18 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
                         if constexpr (t < C::A_STEPS)
                             if (!(SEGNB_EXP & 2) && !(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
-                        if constexpr (BNR) {
-                            // y of THIS tile's 16 pieces: requested in its last chunk, taps 0..6 (3 3 2 2 2 2 2), ahead of that
-                            // chunk's counted wait at tap 7
-                            if (last) {
-                                const int* tabc = sPix + (tile_no & 3) * BM;
-                                if constexpr (t == 0) { bnr_req(std::integral_constant<int, 0>{}, tabc); bnr_req(std::integral_constant<int, 1>{}, tabc); bnr_req(std::integral_constant<int, 2>{}, tabc); }
-                                if constexpr (t == 1) { bnr_req(std::integral_constant<int, 3>{}, tabc); bnr_req(std::integral_constant<int, 4>{}, tabc); bnr_req(std::integral_constant<int, 5>{}, tabc); }
-                                if constexpr (t >= 2 && t <= 6) { bnr_req(std::integral_constant<int, 2 * t + 2>{}, tabc); bnr_req(std::integral_constant<int, 2 * t + 3>{}, tabc); }
-                            }
-                            // the PREVIOUS tile's pieces: one per tap, taps 1..8 of the first chunk and 0..7 of the second (its staging
-                            // buffer was published by tap 0's barrier and is rewritten after this tile's last tap)
-                            if (tile_no > 0) {
-                                const int* tabp = sPix + ((tile_no + 3) & 3) * BM;
-                                if (c == 0) {
-                                    if constexpr (t >= 1) bnr_piece(std::integral_constant<int, t - 1>{}, tabp);
-                                } else if (c == 1) {
-                                    if constexpr (t <= 7) bnr_piece(std::integral_constant<int, 8 + t>{}, tabp);
-                                }
-                            }
-                        }
                         if constexpr (t == NTAP - 2)
                             if (next_last) set_fetch_tile(setup_it, setup_tab);
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
                         // the next chunk's halo tile is first read during the last tap (look-ahead slices of its tap 0)
                         if constexpr (t == NTAP - 2) {
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            if constexpr (BNR) {        // the y requests of this chunk have landed: settle their registers here
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(yq[k]));
-                            }
                         }
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 2);
                         if (!(SEGNB_EXP & 64) || t % 3 == 2) raw_barrier();      // (experiment 64: one barrier per kernel row -- WRONG results, timing only)
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 3);
                     });
                 }
-            }
-            if constexpr (BNR) {
-                // the last tile: staged behind barrier 1 of the tail; then the block's sums -> LDS -> one fp64 atomic per channel
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                raw_barrier();
-                if (tile_no > 0) {
-                    const int* tabp = sPix + ((tile_no + 3) & 3) * BM;
-                    static_for<16>([&](auto k_c) { bnr_piece(k_c, tabp); });
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                raw_barrier();                                  // (matrix threads: the last tile's rows are stored, staging consumed)
-                double* red = reinterpret_cast<double*>(smem);  // [128][16]
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ch = n_base + bcc * 8 + e;
-                    const float is = ch < a.Co ? a.bn_coef[3 * a.Co + ch] : 0.f;      // * invstd: sum dz * yhat
-                    red[t128 * 16 + e] = (double)bs1[e];
-                    red[t128 * 16 + 8 + e] = (double)(bs2[e] * is);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                raw_barrier();
-                {
-                    const int which = t128 >> 6, col = t128 & 63;      // 2 x 64 channels of the tile: one lane each
-                    const int c8 = col >> 3, e = col & 7;
-                    double sum = 0.0;
-                    for (int k = 0; k < 16; ++k) sum += red[(k * 8 + c8) * 16 + which * 8 + e];
-                    const int co = n_base + col;
-                    if (co < a.Co)
-                        atomicAdd(&a.bn_sums[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], sum);
-                }
-                return;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // look-ahead fetches of the (absent) next tile
@@ -1239,7 +1097,7 @@ int ksplit_workspace(hipStream_t stream, size_t slab_bytes, int ntiles, float** 
 template <class C>
 int ksplit_factor(const FdArgs& a, int it_total, int ntl, int nch) {
     if (!C::TALL || !segnb_knob_fprop_ksplit()) return 1;
-    if (a.bn_y != nullptr || a.ep_act >= 0 || a.dbg || a.up_out != nullptr) return 1;
+    if (a.ep_act >= 0 || a.dbg || a.up_out != nullptr) return 1;
     const long long tiles = (long long)it_total * ntl;
     int cus = segnb_knob_conv_cus();
     // A data gradient (no statistics) of a two-stream backward runs beside the weight-gradient stream, which sizes its launches
@@ -1270,17 +1128,12 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if constexpr (C::MF16 && C::NTAP == 9 && !C::TALL && C::UP == 0) {
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        }
         if constexpr (C::TALL) {
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true, false, true>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false, false, true>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         }
         if (e != hipSuccess) segnb_set_error("fprop_ws hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1308,9 +1161,9 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
             a.ks_slab_bytes = (unsigned)((size_t)a.IT * a.NTL * ks * 65536);
             const dim3 grid(a.IT * a.NTL * ks);
             if (a.stats != nullptr || !segnb_knob_fprop_nostats())
-                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, true, false, true>), grid, dim3(C::NT), C::SMEM, stream, a);
+                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, true, true>), grid, dim3(C::NT), C::SMEM, stream, a);
             else
-                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false, false, true>), grid, dim3(C::NT), C::SMEM, stream, a);
+                hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false, true>), grid, dim3(C::NT), C::SMEM, stream, a);
             return 0;
         }
     }
@@ -1318,16 +1171,6 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
-    if (a.bn_y != nullptr) {
-        // data gradient + BatchNorm-backward reduction of the producing layer (the halo waves take the sums)
-        if constexpr (C::MF16 && C::NTAP == 9 && !C::TALL && C::UP == 0) {
-            if (a.NCH < 3 || a.stats != nullptr || a.ep_act >= 0 || a.dbg || a.u != nullptr) return -12345;
-            hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, false, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
-            return 0;
-        } else {
-            return -12345;
-        }
-    }
     if (a.ep_act >= 0)            // (never with statistics: segnb_conv_fprop_act takes none)
         hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, true, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     else if (a.stats == nullptr && !a.dbg && segnb_knob_fprop_nostats())
@@ -1436,7 +1279,6 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         // 16 x 16 pixel tiles tie or beat 8 x 32 except for the widest data gradients.  Outputs of <= 32 channels
         // (half of every tile padding) and 7x7 images stay with fprop_s1 / the general kernel.
         if (a.Co <= 32) return NOT_HANDLED;
-        if (a.bn_y != nullptr && (a.W <= 8 || !segnb_knob_fprop_mf16())) return NOT_HANDLED;
         // 7 x 7 images (the deepest ZF_UNET level): tall-image tiles of 36 x 7 virtual pixels -- 8 row tiles x 16 channel
         // tiles = 128 blocks of 144 taps each beat the general kernel's 400 tiles of 64 x 64 (76 -> ~45 us for 1024 -> 1024)
         if (a.W <= 8) {
@@ -1463,7 +1305,6 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
             default: return NOT_HANDLED;
         }
     }
-    if (a.bn_y != nullptr) return NOT_HANDLED;      // (the BatchNorm-reduce variant exists in the 16x16x32 form only)
     switch (cfg) {
         case 0: return launch_ws<WsCfg<64, 8, 32, 4, false, false>>(a, stream);
         case 1: return launch_ws<WsCfg<64, 16, 16, 4, false, false>>(a, stream);
@@ -1541,7 +1382,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
                         hipStream_t stream, const segnb_act_epilogue* ep, const segnb_upcat_src* uc,
                         const segnb_bn_reduce_epilogue* bn) {
     if (!segnb_knob_fprop_dma()) return 0;
-    if (bn != nullptr && (g->ntaps != 9 || ep != nullptr || stats != nullptr || uc != nullptr || g->Ci < 192)) return 0;
+    if (bn != nullptr) return 0;      // (fused BatchNorm-backward reductions: fprop_rw.hip / fprop_roll.hip)
     if (g->ntaps == 16 && ep == nullptr && stats == nullptr && bias == nullptr && segnb_knob_fprop_upd()) {
         FdArgs a;
         a.x = (const bf16_t*)in;
@@ -1618,17 +1459,6 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.u_bytes = (unsigned)ub;
     }
     a.bn_y = nullptr;
-    if (bn != nullptr) {
-        const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;
-        if (yb >= (1ll << 31) || a.dbg) return 0;
-        a.bn_y = (const bf16_t*)bn->y;
-        a.bn_y_bytes = (unsigned)yb;
-        a.bn_ld = bn->ld_y;
-        a.bn_coef = bn->coef;
-        a.bn_sums = bn->sums;
-        a.bn_act = bn->act;
-        a.bn_slope = bn->slope;
-    }
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;
     a.ep_slope = ep != nullptr ? ep->slope : 0.f;

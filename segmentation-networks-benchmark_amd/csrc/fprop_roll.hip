@@ -51,13 +51,6 @@ struct RollArgs {
     double* bn_sums;
     int bn_act;
     float bn_slope;
-    // K split over the waves of a strip (template KSP > 1: wave k of a strip takes input channels [32 k, 32 k + 32) and the
-    // partial sums meet in LDS): the FIRST nchu 32-channel slices may come from the low-resolution tensor u -- the virtual concat
-    // of segnb_conv_fprop_upcat: pixel (h, w) of those channels is u pixel (h >> 1, w >> 1) -- the others from x (channel 0 of x =
-    // logical channel 32 * nchu)
-    const bf16_t* u;
-    unsigned u_bytes;
-    int ld_u, nchu, Hu, Wu;
     // transform of the input on its way into LDS (template parameter TF):
     //   TF = 1  x holds the PRE-BatchNorm output y of the producing layer; the convolution's operand is
     //           round(drop * act((y - mean) * scale + shift)) -- bn_act_fwd_kernel's expression -- and never exists in memory
@@ -236,12 +229,9 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
                 roff[dx][f][ks] = j * PXB + (((4 * ks + g) ^ roll_sw<CI>(j)) << 4);
             }
 
-    // input source of this wave: x, or (virtual concat, K split) its slice of the low-resolution tensor u
-    const bool from_u = KSP > 1 && a.u != nullptr && kpart < a.nchu;
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(KSP > 1 && a.u != nullptr ? a.u : a.x), 0, KSP > 1 && a.u != nullptr ? (int)a.u_bytes : 0, 0x00020000);
-    const int src_ld = from_u ? a.ld_u : a.ld_x;
-    const int src_ch = from_u ? kpart * 32 : (KSP > 1 ? (kpart - (a.u != nullptr ? a.nchu : 0)) * 32 : 0);
+    // K split (KSP > 1): wave k of a strip takes input channels [32 k, 32 k + 32), the partial sums meet in LDS
+    const int src_ld = a.ld_x;
+    const int src_ch = KSP > 1 ? kpart * 32 : 0;
     const int nstrips = gridDim.x * SPB;
     for (int task = blockIdx.x * SPB + sidx; task < a.NTASK; task += nstrips) {
         const int strip = task % a.NSTRIP;
@@ -259,7 +249,7 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
             const int L = 64 * m + lane;
             const int col = c0 + a.dwmin + L / CPP;
             colv[m] = woff[m] >= 0 && (unsigned)col < (unsigned)a.Wi;
-            coff[m] = colv[m] ? (unsigned)((from_u ? col >> 1 : col) * src_ld * 2 + src_ch * 2 + (L % CPP) * 16) : OOB;
+            coff[m] = colv[m] ? (unsigned)(col * src_ld * 2 + src_ch * 2 + (L % CPP) * 16) : OOB;
             coff2[m] = (TF == 2 && colv[m]) ? (unsigned)(col * a.ld_x2 * 2 + (L % CPP) * 16) : OOB;
         }
         // TF = 1: the Dropout2d multiplier of the image (>= 0) folds into the affine map, drop * act(z) = act(drop * z) for
@@ -285,13 +275,11 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
             const int gi = r0 + a.dhmin + i;
             const bool rv = i < nin && (unsigned)gi < (unsigned)a.Hi;
             const unsigned pixrow = (unsigned)((n * a.Hi + gi) * a.Wi);
-            const unsigned rowoff = from_u ? (unsigned)((n * a.Hu + (gi >> 1)) * a.Wu) * (unsigned)(a.ld_u * 2)
-                                           : pixrow * (unsigned)(a.ld_x * 2);
+            const unsigned rowoff = pixrow * (unsigned)(a.ld_x * 2);
 #pragma unroll
             for (int m = 0; m < NLD; ++m) {
                 const unsigned voff = rv ? rowoff + coff[m] : OOB;
-                if (from_u) ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)voff, 0, 0);
-                else ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+                ld[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
                 if constexpr (TF == 2) {
                     const unsigned voff2 = rv ? pixrow * (unsigned)(a.ld_x2 * 2) + coff2[m] : OOB;
                     ld2[set][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (int)voff2, 0, 0);
@@ -641,8 +629,7 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     // Measured (MI355X, bs=32, profiles/r04_ab.txt): two-way splits pay -- 32 -> 64 @ 112 x 112 38.2 -> 28.5 us, 64 -> 32 32.2 -> 28.3
     // us -- three-way splits do not: 96 -> 32 @ 224 x 224 with the K split 141 -> 208 us (three waves in lock step behind one
     // barrier per row lose what independent waves hide), 32 -> 96 with the channel split 134 -> 167 us (every wave re-loads the
-    // whole input and writes a third of each pixel); those stay on conv_fprop_rw_kernel.  The virtual concat (uc) therefore
-    // never reaches this kernel.
+    // whole input and writes a third of each pixel); those stay on conv_fprop_rw_kernel, and so does the virtual concat (uc).
     if (uc != nullptr) return 0;
     const bool plain1 = g->Ci == 32 && g->Co <= 32;
     const bool ksplit = g->Ci == 64 && g->Co <= 32 && bn == nullptr && tf == nullptr && knob >= 2;
@@ -676,19 +663,6 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     a.x2 = nullptr;
     a.tf_coef = a.tf_bcoef = a.tf_drop = nullptr;
     a.bn_y = nullptr;
-    a.u = nullptr;
-    a.u_bytes = 0;
-    a.ld_u = a.nchu = a.Hu = a.Wu = 0;
-    if (uc != nullptr) {
-        a.u = (const bf16_t*)uc->u;
-        a.ld_u = uc->ld_u;
-        a.nchu = uc->Cu / 32;
-        a.Hu = g->Hi / 2;
-        a.Wu = g->Wi / 2;
-        const long long ub = (((long long)g->N * a.Hu * a.Wu - 1) * uc->ld_u + uc->Cu) * 2;
-        if (ub >= (1ll << 31)) return 0;
-        a.u_bytes = (unsigned)ub;
-    }
     if (ksplit) {
         const int rc = launch_roll_split<2, 2, 1>(a, stream);
         return rc ? rc : 1;

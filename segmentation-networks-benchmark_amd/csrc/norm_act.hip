@@ -1780,175 +1780,8 @@ extern "C" int segnb_bn_bwd_apply_fused_acc(int dtype, const void* y, int ld_y, 
                                "segnb_bn_bwd_apply_fused_acc", stream, nullptr, 0, 0, 0.f, true);
 }
 
-// ------------------------------------------------------------------------------------------------
-// BatchNorm backward of a SMALL tensor in ONE launch (the 14 x 14 and 7 x 7 levels of ZF_UNET at bs=32: 6272 / 1568 pixels of
-// 512 / 1024 channels -- lib/modules/abn/functions.py:95-130 for lib/models/zf_unet.py:10-17).  A reduction pass and an apply
-// pass over 3-6 MB are two launches of ~10 us each, almost all of it launch + dependent round trips (sums -> atomics ->
-// next launch -> sums -> coefficients); here ONE BLOCK OWNS an 8-channel group: its 1024 threads hold every pixel of the group
-// (y and the incoming gradient g, <= 8 pixels per thread) in registers, sum dz and dz * yhat within the block (fp32 per thread,
-// fp64 across threads, fixed order: bitwise reproducible, no atomics, no sums buffer), derive (a, c1, c2), write dgamma / dbeta
-// and apply from the registers.  Each tensor is read once and dy written once.  Single direct gradient source, no dropout:
-// dz = round(g * act'(z)) as segnb_bn_act_bwd_reduce / segnb_bn_bwd_apply_fused_direct compute it.
-constexpr int OWN_THR = 1024;
-__device__ __forceinline__ void pack_raw(Raw8<bf16_t>& r, const float (&v)[8]) {      // (v already rounded: exact)
-    r.u.x = pack2bf(v[0], v[1]); r.u.y = pack2bf(v[2], v[3]);
-    r.u.z = pack2bf(v[4], v[5]); r.u.w = pack2bf(v[6], v[7]);
-}
-__device__ __forceinline__ void pack_raw(Raw8<float>& r, const float (&v)[8]) {
-    r.a = make_float4(v[0], v[1], v[2], v[3]);
-    r.b = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <typename T, int PPT>
-__global__ __launch_bounds__(OWN_THR) void bn_bwd_owner_kernel(const T* __restrict__ y, int ld_y, const T* g, int ld_g, T* dy,
-                                                               int ld_dy, int npix, int Cp, const float* __restrict__ coef,
-                                                               const BnBwdParams bp, int act, float slope) {
-    __shared__ double part[OWN_THR / 64][16];
-    __shared__ double tot[16];
-    const int c0 = blockIdx.x * 8;
-    Raw8<T> ry[PPT], rg[PPT];
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-        const int pix = threadIdx.x + u * OWN_THR;
-        const int pc = pix < npix ? pix : 0;
-        load_raw(y + (long long)pc * ld_y + c0, ry[u]);
-        load_raw(g + (long long)pc * ld_g + c0, rg[u]);
-    }
-    float sc[8], sh[8], mu[8], is[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = coef[c0 + e];
-        sh[e] = coef[Cp + c0 + e];
-        mu[e] = coef[2 * Cp + c0 + e];
-        is[e] = coef[3 * Cp + c0 + e];
-    }
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-        if (threadIdx.x + u * OWN_THR >= npix) break;
-        float yv[8], d[8];
-        unpack_raw(ry[u], yv);
-        unpack_raw(rg[u], d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = d[e] * 1.f * act_grad((yv[e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope);
-        round_store8((T*)nullptr, d);
-        pack_raw(rg[u], d);                 // dz replaces g in the registers: the apply below needs neither scale nor shift
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s1[e] += d[e];
-            s2[e] += d[e] * (yv[e] - mu[e]);
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {          // one value at a time: two live registers instead of thirty-two
-        double t = k < 8 ? (double)s1[k & 7] : (double)(s2[k & 7] * is[k & 7]);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-        if (lane == 0) part[wave][k] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        double t = 0.0;
-        for (int w = 0; w < OWN_THR / 64; ++w) t += part[w][threadIdx.x];
-        tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-    float a[8], c1[8], c2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const bool in = c < bp.C;
-        const float gm = in ? (bp.gamma != nullptr ? bp.gamma[c] : 1.f) : 0.f;
-        a[e] = in ? gm * is[e] : 0.f;
-        c1[e] = in ? (float)(tot[e] / bp.count) : 0.f;
-        c2[e] = in ? (float)(tot[8 + e] / bp.count) : 0.f;
-    }
-    if (threadIdx.x < 8) {
-        const int e = threadIdx.x, c = c0 + e;
-        if (c < bp.C) {
-            if (bp.dgamma != nullptr) bp.dgamma[c] = (bp.accumulate ? bp.dgamma[c] : 0.f) + (float)tot[8 + e];
-            if (bp.dbeta != nullptr) bp.dbeta[c] = (bp.accumulate ? bp.dbeta[c] : 0.f) + (float)tot[e];
-        }
-        if (c < Cp) {
-            const bool in = c < bp.C;
-            const float gm = in ? (bp.gamma != nullptr ? bp.gamma[c] : 1.f) : 0.f;
-            bp.bcoef[c] = in ? gm * coef[3 * Cp + c] : 0.f;
-            bp.bcoef[Cp + c] = in ? (float)(tot[e] / bp.count) : 0.f;
-            bp.bcoef[2 * Cp + c] = in ? (float)(tot[8 + e] / bp.count) : 0.f;
-            if (bp.zero_buf != nullptr) {
-#pragma unroll
-                for (int rp = 0; rp < REPL; ++rp) {
-                    bp.zero_buf[(rp * 2) * Cp + c] = 0.0;
-                    bp.zero_buf[(rp * 2 + 1) * Cp + c] = 0.0;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-        const int pix = threadIdx.x + u * OWN_THR;
-        if (pix >= npix) break;
-        float yv[8], d[8];
-        unpack_raw(ry[u], yv);
-        unpack_raw(rg[u], d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float yh = (yv[e] - mu[e]) * is[e];
-            d[e] = a[e] * (d[e] - c1[e] - yh * c2[e]);
-        }
-        round_store8(dy + (long long)pix * ld_dy + c0, d);
-    }
-}
-
-// OFF by default (SEGNB_BN_OWNER=1 enables).  Measured on MI355X (tools/bn_bench.py, bs=32): 40.2 us at 14 x 14 x 512 and 21.6 us
-// at 7 x 7 x 1024 against 18.0 / 18.2 us for the two launches it replaces -- a lane's 16 bytes per pixel pull a whole 128-byte
-// line through the CU's L1 (64 B / clock), so a block moves 8x its data and only Cp / 8 = 64-128 CUs work; owning 64 channels
-// (full lines) leaves 8-16 blocks.  Spreading the pixels of a channel over many CUs -- the two-pass form -- is what these
-// tensors need; the launch boundary between the passes is the price.  Kept as a tested option.
-static int bn_owner_knob() {
-    const char* e = getenv("SEGNB_BN_OWNER");
-    return e != nullptr ? atoi(e) : 0;
-}
-
-// 1 when segnb_bn_bwd_owner serves the tensor: every pixel of a channel group fits one block's registers
-extern "C" int segnb_bn_bwd_owner_ok(int dtype, int N, int H, int W, int Cp) {
-    if (!bn_owner_knob() || N <= 0 || H <= 0 || W <= 0 || Cp <= 0 || Cp % 8 != 0) return 0;
-    const long long npix = (long long)N * H * W;
-    if (dtype == SEGNB_BF16) return npix <= 8ll * OWN_THR ? 1 : 0;
-    if (dtype == SEGNB_F32) return npix <= 4ll * OWN_THR ? 1 : 0;
-    return 0;
-}
-
-extern "C" int segnb_bn_bwd_owner(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
-                                  const float* gamma, float* bcoef, float* dgamma, float* dbeta, int accumulate,
-                                  double* fwd_stats_to_clear, int act, float slope, const void* g, int ld_g, void* dy, int ld_dy,
-                                  segnb_stream_t stream) {
-    SEGNB_PLAN_RECORD(segnb_bn_bwd_owner, dtype, y, ld_y, N, H, W, C, Cp, coef, gamma, bcoef, dgamma, dbeta, accumulate, fwd_stats_to_clear, act, slope, g, ld_g, dy, ld_dy, stream);
-    if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y && coef && bcoef && g && dy && C > 0 && Cp >= C, "NULL tensor / missing coefficient buffer");
-    SEGNB_CHECK_ARG(segnb_bn_bwd_owner_ok(dtype, N, H, W, Cp), "tensor not served (segnb_bn_bwd_owner_ok)");
-    SEGNB_CHECK_ARG(ld_y >= Cp && ld_g >= Cp && ld_dy >= Cp && ld_y % 8 == 0 && ld_g % 8 == 0 && ld_dy % 8 == 0, "bad strides");
-    const BnBwdParams bp = {nullptr, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
-    const int npix = N * H * W;
-    const dim3 grid(Cp / 8), block(OWN_THR);
-#define SEGNB_OWN(TT, P)                                                                                              \
-    hipLaunchKernelGGL((bn_bwd_owner_kernel<TT, P>), grid, block, 0, (hipStream_t)stream, (const TT*)y, ld_y,         \
-                       (const TT*)g, ld_g, (TT*)dy, ld_dy, npix, Cp, coef, bp, act, slope)
-    if (dtype == SEGNB_BF16) {
-        if (npix <= 2 * OWN_THR) SEGNB_OWN(bf16_t, 2);
-        else if (npix <= 4 * OWN_THR) SEGNB_OWN(bf16_t, 4);
-        else if (npix <= 7 * OWN_THR) SEGNB_OWN(bf16_t, 7);
-        else SEGNB_OWN(bf16_t, 8);
-    } else {
-        if (npix <= 2 * OWN_THR) SEGNB_OWN(float, 2);
-        else SEGNB_OWN(float, 4);
-    }
-#undef SEGNB_OWN
-    SEGNB_LAUNCH_CHECK();
-    return 0;
-}
+// (A one-launch BatchNorm backward for small tensors -- a block owning an 8-channel group, every pixel in registers -- was built in
+// round 4 and measured slower than the two launches it replaced, 40 vs 18 us at 14 x 14 x 512: DESIGN 11.13; removed in round 5.)
 
 extern "C" int segnb_bn_bwd_apply_fused_direct(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp,
                                                const float* coef, const double* sums, const float* gamma,

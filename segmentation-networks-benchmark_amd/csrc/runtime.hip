@@ -289,20 +289,6 @@ int segnb_knob_pack_blocks() {
     return g_pack_blocks;
 }
 
-// conv_fprop_ws_kernel's BatchNorm-reduce variant for the wide data gradients (segnb_conv_fprop_bnreduce): 0 off (default), 1 on.
-// Measured on MI355X, one box, alternating runs: ZF_UNET 5.217 / 5.240 / 5.243 ms per step off vs 5.301 / 5.320 / 5.332 on (four
-// reductions at 28x28 / 14x14 fused), LinkNet34 7.868 vs 8.076 / 8.099 ms (nine basic blocks) -- the halo waves' extra work (the
-// y rows hold 64 of their registers: the allocation spills into the tap loop) stretches every tap of the launch by more than
-// the deleted reduction pass cost (profiles/r04_ab.txt).  Kept as a tested option.
-static int g_ws_bnreduce = -2;
-int segnb_knob_ws_bnreduce() {
-    if (g_ws_bnreduce == -2) {
-        const char* e = getenv("SEGNB_WS_BNREDUCE");
-        g_ws_bnreduce = e != nullptr ? atoi(e) : 0;
-    }
-    return g_ws_bnreduce;
-}
-
 static int g_wgrad_roll = -2;
 int segnb_knob_wgrad_roll() {
     if (g_wgrad_roll == -2) {
@@ -409,10 +395,6 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_roll") == 0) {
         g_fprop_roll = value < 0 ? 0 : value;
-        return 0;
-    }
-    if (strcmp(key, "ws_bnreduce") == 0) {
-        g_ws_bnreduce = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "pack_blocks") == 0) {

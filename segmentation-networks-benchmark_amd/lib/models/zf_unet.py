@@ -270,13 +270,9 @@ class _ZFUnetPlan(object):
             if t is not None:
                 self._retired_tables.append(t)       # (lists recorded against the old flat buffers keep valid pointers)
             convs = self._conv_sizes(H, W)
-            pj_early, pj = [], []
-            for ci, (conv, h, w) in enumerate(convs):
-                jobs = conv.pack_jobs(h, w, N) if isinstance(conv, UpCatConvOp) else conv.pack_jobs(h, w)
-                if ci < self.PACK_EARLY:
-                    pj_early += jobs
-                else:
-                    pj += jobs
+            pj = []
+            for conv, h, w in convs:
+                pj += conv.pack_jobs(h, w, N) if isinstance(conv, UpCatConvOp) else conv.pack_jobs(h, w)
             unpacks, los = [], []
             for a, b in self.UNPACK_GROUPS:
                 uj = []
@@ -284,23 +280,13 @@ class _ZFUnetPlan(object):
                     uj += conv.unpack_jobs(h, w, self.flat.grad_of(conv.weight))
                 unpacks.append(PackTable(self.rt, uj, 'segnb_unpack_wgrad_multi', 'segnb_unpack_wgrad'))
                 los.append(self.flat._off[id(convs[a][0].weight)][0])       # first flat offset of the group
-            if self.PACK_DG_SIDE:
-                # the matrices of the DATA GRADIENTS are not needed before the backward: packed on the side stream (idle in the
-                # forward) beside the forward matrices' pack and the first levels; the backward joins before its first launch
-                alljobs = pj_early + pj
-                packs = (PackTable(self.rt, [j for j in alljobs if j.get('form') != 'd'], 'segnb_pack_weight_multi', 'segnb_pack_weight'),
-                         PackTable(self.rt, [j for j in alljobs if j.get('form') == 'd'], 'segnb_pack_weight_multi', 'segnb_pack_weight'))
-            elif self.PACK_OVERLAP or os.environ.get('SEGNB_PACK_SPLIT', '0') != '0':
-                packs = (PackTable(self.rt, pj_early, 'segnb_pack_weight_multi', 'segnb_pack_weight'),
-                         PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight'))
-            else:
-                # main stream: ONE launch of pair jobs (both matrices of a layer from one read of its parameter) + one of what
-                # they do not take.  The data-gradient matrices among the latter (the segmented decoder levels: masked jobs with
-                # few, slow blocks, 20 us of the step's start) are not needed before the backward: side stream, when there is one
-                defer = (lambda j: j.get('form') == 'd') if (self.LEFTOVER_DG_SIDE and self.rt.side_stream() is not None) else None
-                main = PackTable(self.rt, pj_early + pj, 'segnb_pack_weight_multi', 'segnb_pack_weight', defer=defer)
-                late = PackTable(self.rt, main.deferred, 'segnb_pack_weight_multi', 'segnb_pack_weight') if main.deferred else None
-                packs = (main, late)
+            # main stream: ONE launch of pair jobs (both matrices of a layer from one read of its parameter) + one of what
+            # they do not take.  The data-gradient matrices among the latter (the segmented decoder levels: masked jobs with
+            # few, slow blocks, 20 us of the step's start) are not needed before the backward: side stream, when there is one
+            defer = (lambda j: j.get('form') == 'd') if self.rt.side_stream() is not None else None
+            main = PackTable(self.rt, pj, 'segnb_pack_weight_multi', 'segnb_pack_weight', defer=defer)
+            late = PackTable(self.rt, main.deferred, 'segnb_pack_weight_multi', 'segnb_pack_weight') if main.deferred else None
+            packs = (main, late)
             t = (key, packs, tuple(unpacks), tuple(los))
             self._pack_tables[(N, H, W)] = t
         return t
@@ -334,18 +320,13 @@ class _ZFUnetPlan(object):
                self.flat.flat_p.data_ptr())
         if key == self._packed_key:
             return False
-        # The matrices of the first PACK_EARLY convolutions (the 224x224 .. 28x28 encoder levels: 4 % of the parameters) are
-        # packed on the main stream; the rest -- needed from the 14x14 level on, ~0.6 ms into the forward -- on the side stream,
-        # idle during the forward, beside those levels.  The forward joins the side stream before its first late convolution
-        # (_join_late_pack, part of the recorded list).  OFF by default (SEGNB_PACK_OVERLAP=1 enables): measured 5.338 vs 5.356
-        # ms/step, 4 interleaved runs each -- the pack is HBM-bound and so are the 224x224 / 112x112 levels it runs beside
-        # (first convolution 37 -> 100 us): what the side stream takes off the main one comes back as slower kernels on it.
-        early, late = self._tables(H, W, N)[1]
-        early.run()
-        side = self.rt.side_stream() if (self.PACK_OVERLAP or self.PACK_DG_SIDE or self.LEFTOVER_DG_SIDE) else None
-        self._dg_pack_on_side = bool((self.PACK_DG_SIDE or self.LEFTOVER_DG_SIDE) and side is not None)
-        if late is None:
-            side = None
+        # ONE launch of pair jobs on the main stream; the single-form data-gradient matrices (segmented decoder levels) on the side
+        # stream, joined at the start of backward.  (Packing the late 96 % of the parameters on the side stream beside the first
+        # encoder levels was measured in round 3: 5.338 vs 5.356 ms, the pack is HBM-bound and so are those levels; removed.)
+        main, late = self._tables(H, W, N)[1]
+        main.run()
+        side = self.rt.side_stream() if late is not None else None
+        self._dg_pack_on_side = side is not None
         if side is not None:
             nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)
             with torch.cuda.stream(side):
@@ -357,19 +338,7 @@ class _ZFUnetPlan(object):
         self._packed_key = key
         return False
 
-    PACK_EARLY = 8
-    PACK_OVERLAP = os.environ.get('SEGNB_PACK_OVERLAP', '0') != '0'
-    PACK_DG_SIDE = os.environ.get('SEGNB_PACK_DG_SIDE', '0') != '0'
-    LEFTOVER_DG_SIDE = os.environ.get('SEGNB_PACK_LEFTOVER_SIDE', '1') != '0'      # (see _tables)
-    TAIL_POSTPONE = os.environ.get('SEGNB_TAIL_POSTPONE', '0') != '0'
-    DROP_ON_SIDE = os.environ.get('SEGNB_DROP_ON_SIDE', '0') != '0'      # Dropout2d masks drawn on the side stream (measured +-0 or slower: off)
-    _drop_wait = None
     _dg_pack_on_side = False
-
-    def _join_late_pack(self):
-        side = self.rt.side_stream() if (self.PACK_OVERLAP and not self.PACK_DG_SIDE) else None
-        if side is not None:
-            nv.call('segnb_stream_join', self.rt.stream, side.cuda_stream)
 
     def _dropout_tables(self, b, N, train):
         """Per-block [N, Cp] multiplier tables (0 or 1/(1-p)); None when Dropout2d is inactive.  All eleven
@@ -381,20 +350,7 @@ class _ZFUnetPlan(object):
             return {n: None for n in names}
         tabs = b['drop']                         # {name: fp32 [N, Cp] view of one flat buffer}
         if ov is None:
-            side = self.rt.side_stream() if self.DROP_ON_SIDE else None
-            if side is None:
-                b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
-                return tabs
-            # the two launches that draw the masks run on the side stream (idle in the forward) beside the weight pack; the main
-            # stream waits for them after the pack has been enqueued (forward()) -- 10 us off the start of every step
-            nv.call('segnb_stream_fork', self.rt.stream, side.cuda_stream)      # (the last backward still read the tables)
-            ev = getattr(self, '_drop_event', None)
-            if ev is None:
-                ev = self._drop_event = torch.cuda.Event()
-            with torch.cuda.stream(side):
-                b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
-                ev.record(side)
-            self._drop_wait = ev
+            b['drop_flat'].bernoulli_(1.0 - self.p_drop).mul_(1.0 / (1.0 - self.p_drop))
             return tabs
         out = {}
         for n in names:
@@ -532,9 +488,6 @@ class _ZFUnetPlan(object):
         b = self.buffers(N, H, W)
         drop = self._dropout_tables(b, N, train)      # (first: on the side stream, beside the weight pack below)
         forked = self._pack_if_needed(H, W, N)
-        if self._drop_wait is not None:
-            torch.cuda.current_stream(rt.device).wait_event(self._drop_wait)
-            self._drop_wait = None
         if train and need_grad:
             self.flat.prezero(rt, forked=bool(forked))
         hf = self._head_fusable(train, need_grad)
@@ -572,8 +525,6 @@ class _ZFUnetPlan(object):
             cur = b['x']
             for i, name in enumerate(ENCODER):
                 s1, s2 = self.stages[name]
-                if 2 * i == self.PACK_EARLY:
-                    self._join_late_pack()
                 # consumer-side BatchNorm: where the block's second convolution can apply the first one's BatchNorm + ReLU
                 # while it loads (segnb_conv_fprop_tf: the thin 32 -> 32 level), that activated tensor is never written
                 defer = self._defer(s1, s2, cur, b['a1_%d' % i], train, need_grad)
@@ -694,7 +645,7 @@ class _ZFUnetPlan(object):
             else:
                 ckey = None
         try:
-            if (self.PACK_DG_SIDE or (self.LEFTOVER_DG_SIDE and not self.PACK_OVERLAP)) and rt.side_stream() is not None:
+            if self._dg_pack_on_side and rt.side_stream() is not None:
                 # the data gradients' matrices were packed on the side stream (recorded: a replayed list waits too)
                 nv.call('segnb_stream_join', rt.stream, rt.side_stream().cuda_stream)
             head = self.module.conv_final
@@ -706,32 +657,26 @@ class _ZFUnetPlan(object):
                 nv.call('segnb_head_bwd', rt.code, b['f0'].ptr, b['f0'].ld, N, H, W, self.widths[0], wp[0],
                         nv.ptr(head.weight.detach()), self.K, nv.ptr(dlogits), b['df0'].ptr, b['df0'].ld,
                         nv.ptr(flat.grad_of(head.weight)), nv.ptr(flat.grad_of(head.bias)), rt.stream)
-            # The weight gradients of the first decoder levels (224x224 / 112x112: HBM-bound, like the BatchNorm passes
-            # they would run beside) are held back until the dependent chain has reached the deep levels.
-            # (measured on one box: 0 -> 6.34 ms/step, 2 -> 6.31 ms/step, but the convolutions of the dependent chain then run
-            # beside more weight-gradient work and their own launches stretch by 6 %: off by default)
-            npost = int(os.environ.get('SEGNB_WGRAD_POSTPONE', '0'))
-            post = []
+            # (Holding the weight gradients of the first decoder levels back until the dependent chain has reached the deep levels
+            # -- HBM-bound launches beside MFMA-bound ones -- was measured in rounds 1 and 3: the chain's convolutions then stretch
+            # by 6 %, step +1 %; so was holding the last block's second weight gradient back at the tail: +-0.  Both removed.)
             for name, lvl in zip(reversed(DECODER), (0, 1, 2, 3, 4)):
                 s1, s2 = self.stages[name]
-                hold = post if lvl < npost else None
                 # the first convolution of a block has ONE direct gradient source -- the data gradient of the second one: that
                 # launch also does its BatchNorm-backward reduction where a fused kernel serves the shape (fuse_reduce_of)
                 if lvl == 0 and hf:
-                    red = s2.backward(flat, dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1, dz_ready=True)
+                    red = s2.backward(flat, dx=b['db1_0'], fuse_reduce_of=s1, dz_ready=True)
                 elif lvl == 0:
-                    red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], postponed=hold, fuse_reduce_of=s1)
+                    red = s2.backward(flat, g_direct=b['df0'], dx=b['db1_0'], fuse_reduce_of=s1)
                 elif self._seg(lvl - 1, N, H, W):
                     # the level above handed the gradient of this block's output over at THIS resolution (du)
-                    red = s2.backward(flat, g_direct=b['du_%d' % (lvl - 1)], dx=b['db1_%d' % lvl], postponed=hold,
-                                      fuse_reduce_of=s1)
+                    red = s2.backward(flat, g_direct=b['du_%d' % (lvl - 1)], dx=b['db1_%d' % lvl], fuse_reduce_of=s1)
                 else:
                     red = s2.backward(flat, g_up=b['dcat_%d' % (lvl - 1)].slice(0, wp[lvl]), dx=b['db1_%d' % lvl],
-                                      postponed=hold, fuse_reduce_of=s1)
+                                      fuse_reduce_of=s1)
                 if self.subpixel:
                     s1.conv.bind_up(b.get('u_%d' % lvl), b.get('du_%d' % lvl))
-                s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], postponed=hold, reduced=red)
-            rt.flush_postponed(post)
+                s1.backward(flat, g_direct=b['db1_%d' % lvl], dx=b['dcat_%d' % lvl], reduced=red)
             self._unpack_group(H, W, 0)           # decoder (+ the head's gradients, written above on this stream)
             for i in (5, 4, 3, 2, 1, 0):
                 if i == 3:
@@ -742,14 +687,9 @@ class _ZFUnetPlan(object):
                 elif i == 5:
                     red = s2.backward(flat, g_up=b['dcat_4'].slice(0, wp[5]), dx=b['da1_5'], fuse_reduce_of=s1)
                 else:
-                    # TAIL_POSTPONE: the last block's second weight gradient is held back until the first layer's apply pass is
-                    # out, then runs on the side stream BESIDE the first layer's weight gradient (main stream) instead of beside
-                    # that apply pass -- three HBM-bound launches in a row become two in parallel
-                    hold0 = [] if (i == 0 and self.TAIL_POSTPONE and rt.side_stream() is not None) else None
                     red = s2.backward(flat, g_direct=b['dcat_%d' % i].slice(wp[i + 1], wp[i]), g_pool=b['dp_%d' % (i + 1)],
-                                      dx=b['da1_%d' % i], fuse_reduce_of=s1, postponed=hold0)
-                s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red,
-                            flush_before_wgrad=hold0 if i == 0 else None)
+                                      dx=b['da1_%d' % i], fuse_reduce_of=s1)
+                s1.backward(flat, g_direct=b['da1_%d' % i], dx=(b['dp_%d' % i] if i > 0 else None), reduced=red)
             rt.join_side()                        # the weight gradients ran on the side stream
             self._tables(H, W)[2][2].run()       # the remaining packed weight-gradient workspaces -> flat gradient buffer
         except BaseException:

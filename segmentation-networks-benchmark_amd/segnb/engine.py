@@ -182,15 +182,6 @@ class Runtime(object):
             self._side_busy = True
         return s
 
-    def flush_postponed(self, closures):
-        """run postponed side-stream launches now (the side stream first waits for everything issued so far)"""
-        if closures:
-            side = self.fork_side()
-            with torch.cuda.stream(side):
-                for fn in closures:
-                    fn()
-            del closures[:]
-
     def join_side(self):
         self._armed = False                  # (an armed fork that never committed -- an exception in between -- dies here)
         if getattr(self, '_side_busy', False):
@@ -277,11 +268,9 @@ class ConvOp(object):
     reference's weight tensor.
     """
 
-    # deferred unpack: leave the weight-gradient slabs unreduced and let the batched unpack sum them (SEGNB_WGRAD_PARTIAL=1).
-    # Measured on MI355X, same box: 5.63 ms/step with it against 5.39 without -- a layer with one channel tile has up to
-    # 128 slabs, which one unpack thread then walks serially on the critical path, where the reduction kernel spreads them
-    # over the chip beside the dependent chain: OFF by default.
-    partial_slabs = os.environ.get('SEGNB_WGRAD_PARTIAL', '0') != '0'
+    # (Leaving the weight-gradient slabs unreduced for the batched unpack to sum -- segnb_conv_wgrad_partial, round 2 -- measured
+    # 5.63 ms/step against 5.39: a layer with one channel tile has up to 128 slabs that one unpack thread walks serially on the
+    # critical path; removed in round 5.)
 
     algo_scale = 1.0        # algorithmic / executed FLOPs of a launch (UpConvOp: 9 / 4)
     pack_fwd = True         # False: the forward matrix is never used (the owner runs the forward through another op)
@@ -434,12 +423,12 @@ class ConvOp(object):
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
                                  s_c=self.s_out, Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32,
-                                 nslab=p['nslab'][li] if self.partial_slabs else 1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         else:
             for li, l in enumerate(p['fwd']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.out_map, cmap=self.in_map, s_m=self.s_out,
                                  s_c=self.s_in, Mp=self.Cop, Cp=self.Cip, ntaps=len(l.taps), dtype=nv.F32,
-                                 nslab=p['nslab'][li] if self.partial_slabs else 1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
+                                 nslab=1, tap_off=[a * self.KW + b for (_, _, a, b) in l.taps]))
         return jobs
 
     # ---- kernels ------------------------------------------------------------------------------------
@@ -638,11 +627,10 @@ class ConvOp(object):
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
-        workspace -- as UNREDUCED partial slabs (segnb_conv_wgrad_partial) -- for a later batched
-        segnb_unpack_wgrad_multi (unpack_jobs), which sums the slabs while it unpacks."""
+        workspace (slab 0) for a later batched segnb_unpack_wgrad_multi (unpack_jobs)."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         gw = grad_w
-        entry = 'segnb_conv_wgrad' if (unpack or not self.partial_slabs) else 'segnb_conv_wgrad_partial'
+        entry = 'segnb_conv_wgrad'
         if self.transposed:
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
@@ -748,7 +736,7 @@ class UpConvOp(ConvOp):
         p = self.plan(Hi, Wi)
         return [dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in, s_c=self.s_out,
                      Mp=self.Cip, Cp=self.Cop, ntaps=len(l.taps), dtype=nv.F32, masked=True,
-                     nslab=p['nslab'][li] if self.partial_slabs else 1,
+                     nslab=1,
                      tap_off=[self.mask(a, b) for (_, _, a, b) in l.taps]) for li, l in enumerate(p['dg'])]
 
 
@@ -1134,8 +1122,6 @@ class Stage(object):
     follow it at :31,:41,:42.)"""
 
     direct_apply = os.environ.get('SEGNB_BN_DIRECT_APPLY', '1') != '0'
-    # segnb_bn_bwd_owner for small tensors: OFF (measured slower than the two launches it replaces, see norm_act.hip)
-    bn_owner = os.environ.get('SEGNB_BN_OWNER', '0') != '0'
     # Layers whose gradient has several sources, a pooled source or a Dropout2d multiplier: dz need not be stored either -- the
     # apply pass re-reads the sources and recomputes it (segnb_bn_bwd_apply_fused_src: one tensor write and one read less per
     # layer) for tensors of at least this many MB.  OFF (0) by default: measured on MI355X at 32 MB (the 224 x 224 / 112 x 112
@@ -1299,8 +1285,8 @@ class Stage(object):
             return None
         return (yv, self.coef, self.sums, self.act, self.slope)
 
-    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, postponed=None, reduced=False,
-                 fuse_reduce_of=None, dz_ready=False, flush_before_wgrad=None):
+    def backward(self, grads, g_direct=None, g_pool=None, g_up=None, dx=None, reduced=False, fuse_reduce_of=None,
+                 dz_ready=False):
         """grads: FlatParams (gives the fp32 gradient view of each parameter).  dx: View to receive the
         input gradient, or None (first layer).  reduced: the reduction pass of this layer was already done by the
         data-gradient launch that produced g_direct.  fuse_reduce_of: the Stage whose activation gradient dx is -- if
@@ -1318,18 +1304,14 @@ class Stage(object):
         mb = yv.N * yv.H * yv.W * self.Cp * (2 if rt.code == nv.BF16 else 4) / 1e6
         recompute = (not direct and not dz_ready and has_bn and self._fused_fwd and self.recompute_dz_min_mb > 0
                      and mb >= self.recompute_dz_min_mb)
-        # a small tensor with one direct gradient source: reduction, finalize and apply are ONE launch (segnb_bn_bwd_owner: a block
-        # owns an 8-channel group and keeps its pixels in registers)
-        owner = bool(direct and self._fused_fwd and not reduced and self.bn_owner
-                     and nv.query('segnb_bn_bwd_owner_ok', rt.code, yv.N, yv.H, yv.W, self.Cp))
-        if not reduced and not dz_ready and not owner:
+        if not reduced and not dz_ready:
             nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.Cp, nv.ptr(coef),
                     self.act, self.slope, nv.ptr(dropmul), vptr(g_direct), vld(g_direct), vptr(g_pool), vld(g_pool),
                     vptr(g_up), vld(g_up), None if (direct or recompute) else dz.ptr, dz.ld, nv.ptr(self.sums), None, 0,
                     rt.stream)
         count = float(yv.N * yv.H * yv.W)
         gbias = grads.grad_of(self.conv.bias) if self.conv.bias is not None else None
-        if (dx is None and direct and not owner and self._fused_fwd and self.defer_unpack and postponed is None
+        if (dx is None and direct and self._fused_fwd and self.defer_unpack
                 and isinstance(self.conv, ConvOp) and self.conv.wgrad_bnapply_ok(xv, yv)):
             # FIRST layer of the network: no data gradient, so the only reader of dy is this layer's weight gradient -- it
             # recomputes dy from (g, y) while staging its tiles (segnb_conv_wgrad_bnapply): the apply pass and its tensor are
@@ -1338,20 +1320,12 @@ class Stage(object):
                     nv.ptr(self.coef), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
                     nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), rt.stream)
             self._stats_stale = False
-            if flush_before_wgrad:
-                rt.flush_postponed(flush_before_wgrad)      # (see below: held-back weight gradients run beside this one)
             self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
             return False
         # the weight gradient is forked to the side stream right behind the apply pass: its event rides on that launch
-        if self.defer_unpack and dx is not None and rt.side_stream() is not None and (postponed is None or flush_before_wgrad):
+        if self.defer_unpack and dx is not None and rt.side_stream() is not None:
             rt.arm_fork()
-        if owner:
-            nv.call('segnb_bn_bwd_owner', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef),
-                    nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
-                    nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), self.act, self.slope, g_direct.ptr, g_direct.ld,
-                    dz.ptr, dz.ld, rt.stream)
-            self._stats_stale = False
-        elif has_bn and self._fused_fwd and direct:
+        if has_bn and self._fused_fwd and direct:
             nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,
@@ -1398,15 +1372,8 @@ class Stage(object):
                 self.conv.wgrad_tf(xv, x_tf, dz, None)
             else:
                 self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=unpack)
-        if flush_before_wgrad:
-            # weight gradients another stage held back (postponed=...) go to the side stream NOW: behind this stage's apply pass,
-            # beside its own weight gradient (the tail of ZF_UNET's backward: both of the first block's weight gradients at once)
-            rt.flush_postponed(flush_before_wgrad)
-        side = rt.fork_side() if (self.defer_unpack and dx is not None and postponed is None) else None
-        if postponed is not None and self.defer_unpack and dx is not None and rt.side_stream() is not None:
-            # launched later by the plan (flush_postponed): x and dy of this layer stay untouched until then
-            postponed.append(lambda: wgrad(False))
-        elif side is not None:
+        side = rt.fork_side() if (self.defer_unpack and dx is not None) else None
+        if side is not None:
             with torch.cuda.stream(side):
                 wgrad(False)
         else:

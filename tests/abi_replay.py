@@ -69,10 +69,6 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
             (name == 'segnb_conv_wgrad_bnapply' and pos == 12):
         # the result is slab 0; the other slabs are scratch (and their COUNT differs between emulator and device)
         ref, got = ref.view(nslab[0], -1)[0], got.view(nslab[1], -1)[0]
-    if name == 'segnb_conv_wgrad_partial' and pos == 4:
-        # unreduced partial slabs: their count and the pixel ranges behind them differ between emulator and device; the
-        # ABI defines only their sum (what segnb_unpack_wgrad_multi consumes)
-        ref, got = ref.view(nslab[0], -1).sum(0), got.view(nslab[1], -1).sum(0)
     if ref.dtype == torch.float64 and ref.numel() % (2 * abi_emulator.REPL) == 0 and name in _REPLICATED.get(pos, ()):
         ref, got = ref.view(abi_emulator.REPL, -1).sum(0), got.view(abi_emulator.REPL, -1).sum(0)
     scale = float(ref.abs().max())
@@ -147,7 +143,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
                 if t.numel() != rt.numel():
                     # the weight-gradient workspace: slab counts differ between emulator and device; its
                     # pre-state is (consumed) zeros or dead partials on both sides
-                    assert (name in ('segnb_conv_wgrad', 'segnb_conv_wgrad_partial', 'segnb_unpack_wgrad') and p in (0, 4)) or \
+                    assert (name in ('segnb_conv_wgrad', 'segnb_unpack_wgrad') and p in (0, 4)) or \
                         (name == 'segnb_conv_wgrad_tf' and p == 6) or (name == 'segnb_conv_wgrad_bnapply' and p == 12), (idx, name, p)
                     continue
                 t.copy_(rt.to(t.device))
@@ -169,7 +165,7 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
                 # 1e-6 of sum|dz| (dz = argument 17 of the same call)
                 dz = [r for q, (k, r) in rpost if q == 17 and k == 'full']
                 atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
-            nslab = (rec.forced[idx][3][5], args[5]) if name in ('segnb_conv_wgrad', 'segnb_conv_wgrad_partial') else (1, 1)
+            nslab = (rec.forced[idx][3][5], args[5]) if name == 'segnb_conv_wgrad' else (1, 1)
             if name == 'segnb_conv_wgrad_tf':
                 nslab = (rec.forced[idx][3][7], args[7])
             if name == 'segnb_conv_wgrad_bnapply':

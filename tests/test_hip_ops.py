@@ -1257,21 +1257,15 @@ def test_upcat_segmented_backward_vs_torch(shape):
         assert torch.equal(dcat_s.dense()[..., Cup:], dfull.dense()[..., Cup:])
 
 
-@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1),
-                                   # wide layers: conv_fprop_ws_kernel's variant (the halo waves take the sums; >= 3 K chunks)
-                                   (2, 28, 28, 128, 192, 1), (3, 20, 36, 64, 256, 2), (2, 14, 14, 256, 192, 1), (8, 56, 56, 128, 320, 1),
-                                   (32, 28, 28, 256, 256, 1)],
+@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
-def test_conv_dgrad_with_fused_bn_reduce(shape, request):
+def test_conv_dgrad_with_fused_bn_reduce(shape):
     """segnb_conv_fprop_bnreduce: the data-gradient launch whose epilogue does the BatchNorm-backward reduction of the
     layer that produced its input (the edz_eydz phase of lib/modules/abn/functions.py:112 folded into
     the producer of dz).  dx is bit-identical to the plain data gradient; the sums equal segnb_bn_act_bwd_reduce on that
     dx (same per-element arithmetic, another summation order) and the emulator's."""
     N, H, W, C1, C2, act = shape           # layer 1: ? -> C1 (BatchNorm, act);  layer 2: C1 -> C2
     rt = Runtime('cuda', 'bf16')
-    if C2 >= 192:                          # the wide-layer variant is an option (measured slower in the step: off by default)
-        nv.call('segnb_tune', b'ws_bnreduce', 1)
-        request.addfinalizer(lambda: nv.call('segnb_tune', b'ws_bnreduce', 0))
     gen = torch.Generator().manual_seed(H * 7 + C2)
     w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
     op = ConvOp(rt, w2, None, [(C1, C1)], 1, 1, False, True)
@@ -1446,78 +1440,6 @@ def test_conv_fprop_rw(case):
         parts.append(dx_g[..., off:off + real])
         off += padded
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')
-
-
-@pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 9, 11, 32, 32, nv.ACT_RELU), (3, 8, 8, 70, 72, nv.ACT_LEAKY), (32, 14, 14, 512, 512, nv.ACT_RELU),
-                                   (32, 7, 7, 1024, 1024, nv.ACT_RELU), (5, 20, 40, 24, 24, nv.ACT_NONE), (8, 32, 32, 16, 16, nv.ACT_RELU)],
-                         ids=lambda s: 'x'.join(map(str, s)))
-def test_bn_backward_of_a_small_tensor_in_one_launch(shape, dtype, monkeypatch):
-    """segnb_bn_bwd_owner (a block owns an 8-channel group, every pixel in registers: reduction + finalize + apply in one launch,
-    lib/modules/abn/functions.py:95-130) == segnb_bn_act_bwd_reduce (sums only) + segnb_bn_bwd_apply_fused_direct: dy, dgamma,
-    dbeta, (a, c1, c2) up to the order of the sums, the forward statistics cleared; in place (dy aliasing g) as the training
-    step calls it; bitwise reproducible; and == the emulator.  Incl. the 14x14 / 7x7 levels of the timed configuration, padded
-    channels, ragged pixel counts, and the largest tensor a block can hold (8 pixels per thread)."""
-    N, H, W, C, Cp, act = shape
-    assert not nv.query('segnb_bn_bwd_owner_ok', nv.BF16, N, H, W, Cp)        # off by default (measured slower)
-    monkeypatch.setenv('SEGNB_BN_OWNER', '1')
-    if not nv.query('segnb_bn_bwd_owner_ok', nv.BF16 if dtype == 'bf16' else nv.F32, N, H, W, Cp):
-        assert dtype == 'f32' and N * H * W > 4096
-        pytest.skip('more pixels than a block holds in fp32')
-    gen = torch.Generator().manual_seed(C + H)
-    y0 = torch.randn(N, H, W, C, generator=gen) * 1.5 + 0.3
-    g0 = torch.randn(N, H, W, C, generator=gen)
-    gamma = torch.rand(C, generator=gen) + 0.5
-    beta = torch.randn(C, generator=gen) * 0.2
-
-    def run(device, owner):
-        rt = Runtime(device, dtype)
-        dev = rt.device
-        yv = View.alloc(rt, N, H, W, Cp)
-        yv.dense()[..., :C] = y0.to(dev, rt.tdtype)
-        gv = View.alloc(rt, N, H, W, Cp)
-        gv.dense()[..., :C] = g0.to(dev, rt.tdtype)
-        stats = torch.zeros(16, 2, Cp, dtype=torch.float64, device=dev)
-        yy = yv.dense().double()
-        stats[0, 0] = yy.sum((0, 1, 2))
-        stats[0, 1] = (yy * yy).sum((0, 1, 2))
-        coef = rt.zeros((4, Cp), torch.float32)
-        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        nbt = torch.zeros((), dtype=torch.int64, device=dev)
-        g_, b_ = gamma.to(dev), beta.to(dev)
-        nv.call('segnb_bn_finalize_keep', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(g_), nv.ptr(b_), 1e-5, 0.1,
-                nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef), None, rt.stream)
-        bcoef = rt.zeros((3, Cp), torch.float32)
-        dgam, dbet = torch.full((C,), 0.25, device=dev), torch.full((C,), -0.5, device=dev)      # (accumulated into)
-        if owner:
-            nv.call('segnb_bn_bwd_owner', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(g_), nv.ptr(bcoef),
-                    nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), act, 0.01, gv.ptr, gv.ld, gv.ptr, gv.ld, rt.stream)
-        else:
-            sums = rt.zeros((16, 2, Cp), torch.float64)
-            nv.call('segnb_bn_act_bwd_reduce', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(coef), act, 0.01, None,
-                    gv.ptr, gv.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
-            nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums),
-                    nv.ptr(g_), nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), act, 0.01, gv.ptr, gv.ld,
-                    gv.ptr, gv.ld, rt.stream)
-        if device != 'cpu':
-            torch.cuda.synchronize()
-        assert float(stats.abs().max()) == 0.0           # the forward statistics are consumed
-        return gv.dense().float().cpu(), dgam.cpu(), dbet.cpu(), bcoef.cpu()
-
-    ref = run('cuda', False)
-    got = run('cuda', True)
-    again = run('cuda', True)
-    for a, b in zip(got, again):
-        assert torch.equal(a, b)
-    with on_emulator():
-        emu = run('cpu', True)
-    n = float(N * H * W)
-    for name, other in (('two launches', ref), ('emulator', emu)):
-        check('dy vs ' + name, got[0], other[0], dtype)
-        for k, what in ((1, 'dgamma'), (2, 'dbeta')):
-            np.testing.assert_allclose(got[k].numpy(), other[k].numpy(), rtol=2e-4, atol=2e-5 * n ** 0.5 + 1e-6, err_msg=what)
-        np.testing.assert_allclose(got[3].numpy(), other[3].numpy(), rtol=2e-4, atol=2e-6, err_msg='bcoef')
-    assert float(got[0][..., C:].abs().max()) == 0.0 if Cp > C else True
 
 
 def test_fork_carried_by_the_apply_pass_orders_the_side_stream():

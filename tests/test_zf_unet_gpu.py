@@ -736,42 +736,3 @@ def test_gradient_buffer_cleared_beside_the_forward_and_classifier_fusion_are_in
     gmax = max(float(v.abs().max()) for v in unf_g[2].values())
     for n in unf_g[2]:
         torch.testing.assert_close(pre_g[2][n], unf_g[2][n], rtol=2e-2, atol=2e-3 * max(float(unf_g[2][n].abs().max()), 1e-3 * gmax))
-
-
-def test_launch_schedule_options_do_not_change_the_gradients():
-    """The side-stream schedule options of the backward tail (zf_unet.py _ZFUnetPlan: TAIL_POSTPONE holds the last block's second
-    weight gradient back and launches it beside the first layer's; DROP_ON_SIDE / PACK_DG_SIDE move the dropout tables and the
-    data-gradient weight pack to the side stream) reorder launches only: every gradient of torch_train.py:180-190's step is
-    bitwise what the default schedule gives, incl. the weight gradient that was held back (a schedule that drops a held-back
-    launch would leave that parameter's gradient at zero)."""
-    from lib.losses import BCEAndDiceLoss
-    from lib.models.zf_unet import ZF_UNET, _ZFUnetPlan as ZFUnetEngine
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(3, 3, 64, 64, generator=g).cuda()
-    y = (torch.rand(3, 1, 64, 64, generator=g) > 0.6).long().cuda()
-    names = ('TAIL_POSTPONE', 'DROP_ON_SIDE', 'PACK_DG_SIDE')
-    keep = tuple(getattr(ZFUnetEngine, n) for n in names)
-    res = {}
-    try:
-        for mode in ((False, False, False), (True, False, False), (False, True, True)):
-            for n, v in zip(names, mode):
-                setattr(ZFUnetEngine, n, v)
-            torch.manual_seed(4)
-            m = ZF_UNET(dropout_val=0.0, filters=16).cuda().train()
-            for step in range(2):                   # (the second step replays the recorded launch list)
-                m.zero_grad()
-                loss = BCEAndDiceLoss()(m(x), y)
-                (3 * loss).backward()
-            torch.cuda.synchronize()
-            res[mode] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
-    finally:
-        for n, v in zip(names, keep):
-            setattr(ZFUnetEngine, n, v)
-    ref = res[(False, False, False)]
-    for mode, got in res.items():
-        for n in ref:
-            if n.endswith('conv.weight'):       # (a convolution bias before BatchNorm has an exactly zero gradient)
-                assert float(ref[n].abs().max()) > 0, n
-            # (not bitwise: the BatchNorm sums are fp64 atomics, their order -- and the last bits of everything behind them --
-            # changes with what runs beside them)
-            torch.testing.assert_close(got[n], ref[n], rtol=1e-3, atol=1e-4 * float(ref[n].abs().max()) + 1e-12, msg=str((mode, n)))

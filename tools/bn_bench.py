@@ -79,9 +79,6 @@ def main():
         apply_fused = lambda: nv.call('segnb_bn_bwd_apply_fused', rt.code, y.ptr, y.ld, N, hw, hw, C, C, nv.ptr(coef),
                                       nv.ptr(sums), nv.ptr(gamma), nv.ptr(fbcoef), nv.ptr(dgam), nv.ptr(dbet), 1,
                                       nv.ptr(stats2), dz.ptr, dz.ld, dz.ptr, dz.ld, rt.stream)
-        owner = lambda: nv.call('segnb_bn_bwd_owner', rt.code, y.ptr, y.ld, N, hw, hw, C, C, nv.ptr(coef), nv.ptr(gamma),
-                                nv.ptr(fbcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats2), nv.ACT_RELU, 0.0, g.ptr, g.ld,
-                                dz.ptr, dz.ld, rt.stream)
         red_sums = lambda: nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, hw, hw, C, nv.ptr(coef), nv.ACT_RELU,
                                    0.0, None, g.ptr, g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
         apply_fd = lambda: nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, y.ptr, y.ld, N, hw, hw, C, C, nv.ptr(coef),
@@ -95,8 +92,6 @@ def main():
                  ('red(d)', red(gd=g), 3.0), ('red(d+pool)', red(gd=g, gpp=gp, d=drop), 3.25), ('apply', apply_, 3.0)]
         cases += [('red(pool)', red(gpp=gp), 2.25), ('red(d+pool,nodrop)', red(gd=g, gpp=gp), 3.25)]
         cases += [('red+apply(direct)', two_pass, 5.0)]
-        if nv.query('segnb_bn_bwd_owner_ok', rt.code, N, hw, hw, C):
-            cases += [('owner', owner, 3.0)]
         if up is not None:
             cases += [('fwd(up)', fwd(u=up, d=drop), 5.0), ('red(up)', red(guu=gu, d=drop), 6.0)]
         line = '%3dx%-3d C=%-4d' % (hw, hw, C)
