@@ -369,11 +369,8 @@ def main():
         opt.step()
         return loss
 
-    # (A/B knob: the dependent chain on a high-priority stream, SEGNB_MAIN_PRIORITY=-1, with the weight gradients beside it on
-    # a normal-priority one -- measured on MI355X: 5.60 ms/step either way, the dispatcher does not prefer the chain)
-    main_prio = int(os.environ.get('SEGNB_MAIN_PRIORITY', '0'))
-    if main_prio != 0:
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=main_prio))
+    # (the dependent chain on a high-priority stream with the weight gradients on a normal-priority one was measured in rounds 2
+    # and 4: the same step time either way, the dispatcher does not prefer the chain)
     loss = step()                          # builds the plan, flat buffers
     dp.broadcast_parameters(flat_of())
     for _ in range(max(0, args.warmup - 1)):

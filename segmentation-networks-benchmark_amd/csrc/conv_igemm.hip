@@ -706,9 +706,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_co8_kernel(const WgradArgs a, i
 }
 
 static bool wgrad_co8_applies(const segnb_conv_geom* g) {
-    static const bool off = getenv("SEGNB_WGRAD_CO8") != nullptr && getenv("SEGNB_WGRAD_CO8")[0] == '0';
     const int nslot = g->ntaps * (g->Ci / 8);
-    return !off && g->Co == 8 && nslot <= NT && (long long)g->N * g->QH * g->QW >= 1024;
+    return g->Co == 8 && nslot <= NT && (long long)g->N * g->QH * g->QW >= 1024;
 }
 
 // ================================================================================================
@@ -1332,7 +1331,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     const int cus = segnb_num_cus();
     // blocks per CU the pixel range is split for (measured on LinkNet34's 7x7 / transposed / 2x2 layers: 2 -> 5.53 ms of
     // weight gradients per step, 4 -> 5.19 ms, 8 -> 5.10 ms; step 10.7 -> 10.3 ms at 4)
-    static const int per_cu = getenv("SEGNB_WG_GENERAL_PER_CU") ? atoi(getenv("SEGNB_WG_GENERAL_PER_CU")) : 8;
+    constexpr int per_cu = 8;
     int S = (cus * per_cu + tiles - 1) / tiles;
     if (S < 1) S = 1;
     // keep at least 4 K steps per split so the pipeline prologue amortises
@@ -1493,8 +1492,7 @@ extern "C" int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, in
 // accumulate into, bias in the accumulator staging
 extern "C" int segnb_upconv_fprop_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype) {
     if (dtype != SEGNB_BF16 || getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
-    static const bool off = getenv("SEGNB_UPCONV_FPROP") != nullptr && getenv("SEGNB_UPCONV_FPROP")[0] == '0';
-    if (off || N <= 0 || H <= 0 || W <= 0 || Ci % 64 != 0 || Ci < 128 || Co % 8 != 0 || Co <= 0 || W < 12) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || Ci % 64 != 0 || Ci < 128 || Co % 8 != 0 || Co <= 0 || W < 12) return 0;
     return (((long long)N * 4 * H * W - 1) * ld_out + Co) * 2 < (1ll << 31) ? 1 : 0;
 }
 

@@ -279,7 +279,7 @@ int launch_fx(FxArgs& a, hipStream_t stream) {
     a.NCHUNK = (a.Ci + BCI - 1) / BCI;
     a.NCOT = (a.Co + BCO - 1) / BCO;
     // persistent blocks per co tile: two blocks per CU where two tiles fit the LDS (one's loads under the other's MFMAs)
-    static const int per_cu = getenv("SEGNB_FPROP_SX_PER_CU") ? atoi(getenv("SEGNB_FPROP_SX_PER_CU")) : (C::SMEM <= 80 * 1024 ? 2 : 1);
+    constexpr int per_cu = C::SMEM <= 80 * 1024 ? 2 : 1;
     int pbn = segnb_knob_conv_cus() * per_cu / a.NCOT;
     if (pbn < 1) pbn = 1;
     if (pbn > a.IT) pbn = a.IT;
@@ -292,8 +292,7 @@ int launch_fx(FxArgs& a, hipStream_t stream) {
 // 1 = launched, 0 = geometry not served (the caller falls through to the general gather kernel), else an error
 int segnb_fprop_sx_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n, void* out,
                        double* stats, hipStream_t stream) {
-    static const bool off = getenv("SEGNB_FPROP_SX") != nullptr && getenv("SEGNB_FPROP_SX")[0] == '0';
-    if (off || (g->in_step != 1 && g->in_step != 2) || g->QW < 24 || g->ntaps > 49) return 0;
+    if ((g->in_step != 1 && g->in_step != 2) || g->QW < 24 || g->ntaps > 49) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
     for (int t = 1; t < g->ntaps; ++t) {
         dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;

@@ -280,32 +280,14 @@ int segnb_knob_fprop_roll() {
 // (profiles/r04_ab.txt) -- no gain, so the plain path stays on the tile kernel; segnb_conv_wgrad_tf always runs on it.
 // blocks of the batched weight pack (segnb_pack_weight_multi): 0 = one per tile; > 0: that many persistent blocks (a pack running
 // beside the forward's first levels, SEGNB_PACK_OVERLAP=1, throttled to a share of the HBM bandwidth)
-static int g_pack_blocks = -2;
-int segnb_knob_pack_blocks() {
-    if (g_pack_blocks == -2) {
-        const char* e = getenv("SEGNB_PACK_BLOCKS");
-        g_pack_blocks = e != nullptr ? atoi(e) : 0;
-    }
-    return g_pack_blocks;
-}
+static int g_pack_blocks = 0;
+int segnb_knob_pack_blocks() { return g_pack_blocks; }
 
-static int g_wgrad_roll = -2;
-int segnb_knob_wgrad_roll() {
-    if (g_wgrad_roll == -2) {
-        const char* e = getenv("SEGNB_WGRAD_ROLL");
-        g_wgrad_roll = e != nullptr ? atoi(e) : 0;
-    }
-    return g_wgrad_roll;
-}
+static int g_wgrad_roll = 0;          // segnb_tune "wgrad_roll"
+int segnb_knob_wgrad_roll() { return g_wgrad_roll; }
 // conv_wgrad_c8roll_kernel (wgrad_roll.hip) for the first layer's weight gradient (8 padded input channels): 1 on, 0 off
-static int g_wgrad_c8roll = -2;
-int segnb_knob_wgrad_c8roll() {
-    if (g_wgrad_c8roll == -2) {
-        const char* e = getenv("SEGNB_WGRAD_C8ROLL");
-        g_wgrad_c8roll = e != nullptr ? atoi(e) : 1;
-    }
-    return g_wgrad_c8roll;
-}
+static int g_wgrad_c8roll = 1;        // segnb_tune "wgrad_c8roll"
+int segnb_knob_wgrad_c8roll() { return g_wgrad_c8roll; }
 static int g_conv_cu_pct = 100;
 int segnb_knob_conv_cus() {
     const int n = segnb_num_cus() * g_conv_cu_pct / 100;
@@ -337,22 +319,10 @@ int segnb_knob_fprop_upd() {
     }
     return g_fprop_upd;
 }
-static int g_fprop_nostats = -2;    // conv_fprop_ws_kernel: statistics-free instantiation for launches without statistics (A/B)
-int segnb_knob_fprop_nostats() {
-    if (g_fprop_nostats == -2) {
-        const char* e = getenv("SEGNB_FPROP_NOSTATS");
-        g_fprop_nostats = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
-    return g_fprop_nostats;
-}
-static int g_rw_store_waves = -2;   // store waves of conv_fprop_rw_kernel: 4 (default) or 2 (round 1)
-int segnb_knob_rw_store_waves() {
-    if (g_rw_store_waves == -2) {
-        const char* e = getenv("SEGNB_RW_STORE_WAVES");
-        g_rw_store_waves = (e != nullptr && e[0] == '2') ? 2 : 4;
-    }
-    return g_rw_store_waves;
-}
+static int g_fprop_nostats = 1;    // conv_fprop_ws_kernel: statistics-free instantiation for launches without statistics (A/B)
+int segnb_knob_fprop_nostats() { return g_fprop_nostats; }
+static int g_rw_store_waves = 4;   // store waves of conv_fprop_rw_kernel: 4 (default) or 2 (round 1)
+int segnb_knob_rw_store_waves() { return g_rw_store_waves; }
 static int g_bnreduce_fused = -2;  // data-gradient launches that also do the next BatchNorm-backward reduction (A/B: SEGNB_BNREDUCE_FUSED=0)
 int segnb_knob_bnreduce_fused() {
     if (g_bnreduce_fused == -2) {

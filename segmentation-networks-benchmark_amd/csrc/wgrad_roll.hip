@@ -389,12 +389,8 @@ int launch_wroll_dl(WRollArgs& a, int nslab, hipStream_t stream) {
 
 template <int TFX, int TFD>
 int launch_wroll(WRollArgs& a, int nslab, hipStream_t stream) {
-    static const int dl = [] {
-        const char* e = getenv("SEGNB_WROLL_DL");
-        return e ? atoi(e) : 0;
-    }();
     // rows of loads in flight per wave: four where the registers allow it (no transforms), two beside the transforms
-    if (TFX != 0 || TFD != 0 || dl == 2) return launch_wroll_dl<TFX, TFD, 2>(a, nslab, stream);
+    if (TFX != 0 || TFD != 0) return launch_wroll_dl<TFX, TFD, 2>(a, nslab, stream);
     return launch_wroll_dl<TFX, TFD, 4>(a, nslab, stream);
 }
 
@@ -644,14 +640,7 @@ int launch_c8roll_nw(WRollArgs& a, int nslab, hipStream_t stream) {
 
 template <int TFD, int COH>
 int launch_c8roll_coh(WRollArgs& a, int nslab, hipStream_t stream) {
-    static const int nw = [] {
-        const char* e = getenv("SEGNB_C8ROLL_WAVES");
-        return e ? atoi(e) : 0;
-    }();
-    static const int dl = [] {
-        const char* e = getenv("SEGNB_C8ROLL_DL");
-        return e ? atoi(e) : 2;
-    }();
+    constexpr int nw = 0, dl = 2;          // (block width / rows of loads in flight: the measured defaults; other values below are kept for reference)
     // 8 waves of <= 256 registers (the recomputing variant holds 56 constants and two operand streams: 192); the plain variant
     // takes the same partition, so that both sum in the same order (segnb_conv_wgrad_bnapply == apply pass + segnb_conv_wgrad
     // bit for bit).  Measured (tools/c8_bench.py, us incl. the 6.7 us slab reduction): 8 waves 40.3 / 59.7, 16 waves 50.0 / 273.6;

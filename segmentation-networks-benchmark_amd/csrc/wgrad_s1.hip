@@ -745,24 +745,15 @@ __global__ __launch_bounds__(256) void slab_reduce_few_kernel(float4* __restrict
 // half to the dependent chain (measured in situ: fraction 1 -> 5.69 ms/step, 0.75 -> 5.60, 0.5 -> 5.59, 0.4 -> 5.75,
 // 0.25 -> 6.3; two blocks per CU 5.91).  Half the blocks is also half the slab traffic.  The thin 32x32-tile launches
 // (224x224 / 112x112, HBM-bound) keep all CUs (1 -> 5.56, 0.5 -> 5.60, 0.25 -> 5.72 with the wide ones at 0.5).
-// SEGNB_WG_CU_FRACTION / SEGNB_WG_CU_FRACTION_THIN / SEGNB_WG_CU_FRACTION_FLAT (7x7 and 14x14 tiles; default = the
-// wide share: 0.25 .. 1 measured within +-0.5 %) override (read once).
+// SEGNB_WG_CU_FRACTION overrides the wide share (read once); the thin (HBM-bound) launches keep all CUs, the flattened 7x7 /
+// 14x14 tiles take the wide share (0.25 .. 1 measured within +-0.5 %).
 int s1_slabs(int tiles, bool thin, bool flat = false) {
     static const double frac_wide = [] {
         const char* e = getenv("SEGNB_WG_CU_FRACTION");
         const double r = e ? atof(e) : 0.5;
         return r <= 0.0 ? 1.0 : r;
     }();
-    static const double frac_thin = [] {
-        const char* e = getenv("SEGNB_WG_CU_FRACTION_THIN");
-        const double r = e ? atof(e) : 1.0;
-        return r <= 0.0 ? 1.0 : r;
-    }();
-    static const double frac_flat = [] {
-        const char* e = getenv("SEGNB_WG_CU_FRACTION_FLAT");
-        const double r = e ? atof(e) : -1.0;
-        return r;
-    }();
+    constexpr double frac_thin = 1.0, frac_flat = -1.0;
     const int pct = segnb_knob_wg_cu_pct();
     const double wide = pct > 0 ? pct / 100.0 : frac_wide;
     const double frac = thin ? frac_thin : ((flat && frac_flat > 0.0) ? frac_flat : wide);
@@ -837,16 +828,10 @@ S1Choice s1_choose(const segnb_conv_geom* g) {
         // rows per iteration: 8, or 7, where they divide the image height (x tile 10 rows for 8, 9 for 7; half as many tile
         // hand-overs per pixel), else 4 (6 for 4).  Measured alone over the 14 such layers of the timed configuration: 1788 ->
         // 1667 us; in situ -0.6 % step time.  SEGNB_WG_ROWS=4 restores the short tiles.
-        static const int rows = [] {
-            const char* e = getenv("SEGNB_WG_ROWS");
-            return e ? atoi(e) : 8;
-        }();
+        constexpr int rows = 8;
         // 16-column tiles where they cover the width exactly and 32-column tiles do not (112 = 7 x 16 against 4 x 32: an
         // eighth of the slabs were padding); SEGNB_WG_W16=0: off
-        static const bool w16 = [] {
-            const char* e = getenv("SEGNB_WG_W16");
-            return e == nullptr || atoi(e) != 0;
-        }();
+        constexpr bool w16 = true;
         if (w16 && g->Wo % 16 == 0 && g->Wo % 32 != 0)
             c = {3, 64, 64};
         else

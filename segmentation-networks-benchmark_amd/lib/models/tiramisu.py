@@ -136,8 +136,8 @@ class FCDenseNet(HipNet):
     # Prefix statistics summed ONCE per slice (tiramisu.py:9-44: every DenseLayer's BatchNorm covers the whole concat prefix, whose
     # batch statistics do not change from layer to layer): one table per concat buffer, each slice's share accumulated by the pass
     # that writes it (segnb_bn_act_fwd_stats / segnb_bn_stats_ld), read as a channel range by every layer
-    # (segnb_bn_fwd_fused_ld).  SEGNB_TIRAMISU_STATS_CACHE=0: a statistics pass over the prefix per layer (A/B)
-    cache_prefix_stats = os.environ.get('SEGNB_TIRAMISU_STATS_CACHE', '1') != '0'
+    # (segnb_bn_fwd_fused_ld).  cache_prefix_stats = False (class attribute): a statistics pass over the prefix per layer (A/B)
+    cache_prefix_stats = True
 
     def _dense_layers(self, tape, layers, buf, gbuf, off0, in_segs, tag, tbl=None):
         """Run DenseLayers in place inside buf (padded channel offset off0): layer l reads the prefix in_segs + l growth

@@ -65,7 +65,7 @@ class UNet16(HipNet):
     # The weight gradients of this net (no BatchNorm passes on the dependent chain, 64-512 channel convolutions at 1024^2 .. 64^2) are
     # the LONGER of the two streams: at the library's default share (half of the CUs) the chain ended 1.7 ms before them and
     # waited (profiles/r04_ab.txt: 18.75 ms per step at 50 %, 17.98 at 75 %, 17.77 at 100 %; LinkNet34 loses 7 % at 100 %).
-    wg_cu_pct = int(os.environ.get('SEGNB_UNET16_WG_CU_PCT', '100')) or None
+    wg_cu_pct = 100
 
     def __init__(self, num_classes=1, num_filters=32, pretrained=False):
         super(UNet16, self).__init__()

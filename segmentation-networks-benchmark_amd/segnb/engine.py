@@ -160,7 +160,7 @@ class Runtime(object):
             return None
         s = getattr(self, '_side', None)
         if s is None:
-            s = self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('SEGNB_SIDE_PRIORITY', '0')))
+            s = self._side = torch.cuda.Stream(device=self.device)
         return s
 
     def arm_fork(self):
@@ -432,8 +432,8 @@ class ConvOp(object):
         return jobs
 
     # ---- kernels ------------------------------------------------------------------------------------
-    # activation (and eval-mode BatchNorm) in the convolution's epilogue instead of a pass of its own (A/B: SEGNB_FPROP_ACT=0)
-    fuse_act = os.environ.get('SEGNB_FPROP_ACT', '1') != '0'
+    # activation (and eval-mode BatchNorm) in the convolution's epilogue instead of a pass of its own (A/B: class attribute fuse_act)
+    fuse_act = True
 
     def fprop(self, xv, yv, stats=None, epilogue=None):
         """epilogue: (coef or None, act, slope) -- segnb_conv_fprop_act: yv receives act(conv + bias) (coef None) or
@@ -751,15 +751,15 @@ class UpCatConvOp(object):
     The forward stays the one 9-tap launch over the concat buffer.  Presents ConvOp's interface to Stage; the plan binds
     the low-resolution views with bind_up() before backward."""
 
-    # SEGNB_SUBPIXEL_FWD=1: the forward by segment too (default: the one 9-tap launch over the concat buffer -- measured alone,
+    # segment_fwd = True (class attribute): the forward by segment too (default: the one 9-tap launch over the concat buffer -- measured alone,
     # tools/upcat_bench.py: 91 -> 78, 96 -> 90, 88 -> 94 us at the 28x28 / 56x56 / 112x112 decoder levels: the 2 x 2-window tiles
     # are short (8-32 steps) and pay the tile epilogue as often; the step time does not move while the weight gradient still
     # reads the upsampled copy)
-    segment_fwd = os.environ.get('SEGNB_SUBPIXEL_FWD', '0') != '0'
-    # SEGNB_SUBPIXEL_WGRAD=1: the weight gradient by segment too (default: the one 9-tap launch over the concat buffer --
+    segment_fwd = False
+    # segment_wgrad = True (class attribute): the weight gradient by segment too (default: the one 9-tap launch over the concat buffer --
     # measured alone at the five decoder shapes of the timed configuration, tools/upcat_bench.py: the weight-gradient kernel's
     # fixed cost per launch (partial slabs + their reduction) eats the 4/9 of the upsampled segment's multiply-adds)
-    segment_wgrad = os.environ.get('SEGNB_SUBPIXEL_WGRAD', '0') != '0'
+    segment_wgrad = False
 
     def __init__(self, rt, weight, bias, in_segments, need_dgrad=True):
         (up_real, up_pad), (sk_real, sk_pad) = in_segments
@@ -796,8 +796,8 @@ class UpCatConvOp(object):
                                   bool(nv.query('segnb_conv_fprop_upd_ok', g, self.rt.code)))
         return v
 
-    # SEGNB_UPSUM=0: no fused Upsample backward in the thin level's data gradient (the segmented form, or the plain one, instead)
-    fused_upsum = os.environ.get('SEGNB_UPSUM', '1') != '0'
+    # fused_upsum = False (class attribute): no fused Upsample backward in the thin level's data gradient (the segmented form, or the plain one, instead)
+    fused_upsum = True
 
     def upsum(self, N, H, W):
         """Is the data gradient at input size H x W the PLAIN 9-tap launch with the Upsample(x2) backward fused into its store
@@ -833,8 +833,8 @@ class UpCatConvOp(object):
                                                self.rt.code))
         return v
 
-    # SEGNB_VCAT=0: the upsampled copy is materialised in the concat buffer (round-2 data flow)
-    virtual_concat = os.environ.get('SEGNB_VCAT', '1') != '0'
+    # virtual_concat = False (class attribute): the upsampled copy is materialised in the concat buffer (round-2 data flow)
+    virtual_concat = True
 
     def virtual(self, N, H, W):
         """VIRTUAL CONCAT at this size: the forward and the weight gradient (9 taps over all input channels, as before) read
@@ -873,7 +873,7 @@ class UpCatConvOp(object):
     _seg = None
     # thin output (<= 32 channels, the 224x224 level): the layer is HBM-bound on the 4x-sized upsampled gradient slice, and
     # not writing / re-reading it pays even though the low-resolution gather then runs on the general kernel (A/B below)
-    force_thin = os.environ.get('SEGNB_SUBPIXEL_THIN', '1') != '0'
+    force_thin = True
     force_segmented = os.environ.get('SEGNB_SUBPIXEL', 'auto') == 'force'
 
     # ---- forward: the whole 9-tap convolution over the concat buffer
@@ -986,8 +986,8 @@ class PackTable(object):
     model packed (or every gradient unpacked) by ONE launch.  jobs: dicts with the fields of PACK_JOB_DTYPE
     (tensors for the pointer fields)."""
 
-    # SEGNB_PACK_ELEM_MULTI=0: the jobs the tiled kernel refuses as one ctypes call + launch each (A/B)
-    elem_multi = os.environ.get('SEGNB_PACK_ELEM_MULTI', '1') != '0'
+    # elem_multi = False (class attribute): the jobs the tiled kernel refuses as one ctypes call + launch each (A/B)
+    elem_multi = True
 
     def __init__(self, rt, jobs, entry, single_entry, defer=None):
         """defer: predicate over the jobs that stay with the single-form kernels; those it selects are NOT put in this table but
@@ -1048,8 +1048,8 @@ class PackTable(object):
             tab = np.array(erows, dtype=PACK_JOB_DTYPE)
             self.etable = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
 
-    # SEGNB_PACK_PAIR=0: every matrix by its own job (A/B)
-    pair_pack = os.environ.get('SEGNB_PACK_PAIR', '1') != '0'
+    # pair_pack = False (class attribute): every matrix by its own job (A/B)
+    pair_pack = True
 
     def _pair(self, rt, jobs):
         """The forward and the data-gradient matrix of a plain 3x3 convolution (ConvOp.pack_jobs: form 'f' / 'd' on the same
@@ -1121,13 +1121,13 @@ class Stage(object):
     nearest-x2 outputs.  (_Conv3BN of lib/models/zf_unet.py:5-17 plus the Dropout2d/pool/unpool that
     follow it at :31,:41,:42.)"""
 
-    direct_apply = os.environ.get('SEGNB_BN_DIRECT_APPLY', '1') != '0'
+    direct_apply = True
     # Layers whose gradient has several sources, a pooled source or a Dropout2d multiplier: dz need not be stored either -- the
     # apply pass re-reads the sources and recomputes it (segnb_bn_bwd_apply_fused_src: one tensor write and one read less per
     # layer) for tensors of at least this many MB.  OFF (0) by default: measured on MI355X at 32 MB (the 224 x 224 / 112 x 112
     # levels), same box, alternating runs, 5.36 / 5.33 ms per step with it against 5.29 / 5.30 without -- the pooled-window walk
     # of the source pass runs at 3 TB/s where the plain apply pass it replaces runs at 6.4 (profiles/r04_ab.txt).
-    recompute_dz_min_mb = float(os.environ.get('SEGNB_BN_RECOMPUTE_DZ_MB', '0'))
+    recompute_dz_min_mb = 0.0
 
     def __init__(self, rt, conv, bn=None, act=nv.ACT_RELU, slope=0.01, name=''):
         self.rt, self.conv, self.bn, self.act, self.slope, self.name = rt, conv, bn, act, slope, name
@@ -1539,8 +1539,8 @@ class FlatParams(object):
             self.flat_g.zero_()
         return False
 
-    # SEGNB_PREZERO_GRADS=0: the flat gradient buffer is cleared at the start of backward, on the dependent chain (A/B)
-    prezero_grads = os.environ.get('SEGNB_PREZERO_GRADS', '1') != '0'
+    # prezero_grads = False (class attribute): the flat gradient buffer is cleared at the start of backward, on the dependent chain (A/B)
+    prezero_grads = True
 
     def prezero(self, rt, forked=False):
         """(forked: the caller has just made the side stream wait for this one -- no second marker on the main queue)

@@ -163,8 +163,8 @@ class Tape(object):
         if self.need_grad:
             self.back.append(fn)
 
-    # SEGNB_NET_FUSE_REDUCE=0: every BatchNorm-backward reduction as a pass of its own (A/B)
-    fuse_reduce = os.environ.get('SEGNB_NET_FUSE_REDUCE', '1') != '0'
+    # fuse_reduce = False (class attribute): every BatchNorm-backward reduction as a pass of its own (A/B)
+    fuse_reduce = True
 
     def consume(self, *acts):
         """An operator of the forward reads these tensors (each will receive one gradient contribution from it)."""
@@ -264,8 +264,8 @@ class Tape(object):
         self.stats_pending = False
         self.rt.join_side()               # the weight gradients ran on the side stream
 
-    # SEGNB_NET_BATCH_BIAS=0: one segnb_bn_bwd_finalize launch per bias gradient (A/B)
-    batch_bias = os.environ.get('SEGNB_NET_BATCH_BIAS', '1') != '0'
+    # batch_bias = False (class attribute): one segnb_bn_bwd_finalize launch per bias gradient (A/B)
+    batch_bias = True
 
     def defer_bias_grad(self, sums, C, Cp, gb, count, coef_buf, bcoef):
         """The bias gradient of a convolution without BatchNorm (sum of dz, accumulated in `sums` by the reduction pass): joined to

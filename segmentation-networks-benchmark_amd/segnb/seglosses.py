@@ -104,8 +104,8 @@ def _grad_buffer_for(x):
     return None
 
 
-# SEGNB_LOSS_ONE_LAUNCH=0: zero fill, segnb_seg_loss_reduce and segnb_seg_loss_finalize as three launches (A/B)
-_ONE_LAUNCH = os.environ.get('SEGNB_LOSS_ONE_LAUNCH', '1') != '0'
+# _ONE_LAUNCH = False (module attribute): zero fill, segnb_seg_loss_reduce and segnb_seg_loss_finalize as three launches (A/B)
+_ONE_LAUNCH = True
 _loss_work = {}       # (device index, stream) -> 128 zeroed doubles: the sums + ticket of segnb_seg_loss_reduce_finalize
 
 

@@ -2,7 +2,7 @@
 """First-layer weight gradient (3 -> 32 at bs=32 224x224) stand-alone: the plain kernel on a stored dz, the apply pass that
 stores it, and the variant that recomputes dz from (g, y) (segnb_conv_wgrad_bnapply).  HIP events, mean of --reps launches.
 
-    SEGNB_WGRAD_C8ROLL=0/1 python tools/c8_bench.py [--reps 30]"""
+    python tools/c8_bench.py [--reps 30] [--c8roll 0|1]"""
 import argparse
 import os
 import sys
@@ -23,7 +23,9 @@ def main():
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--c8roll', type=int, default=1, help='segnb_tune wgrad_c8roll')
     args = ap.parse_args()
+    nv.call('segnb_tune', b'wgrad_c8roll', args.c8roll)
     rt = Runtime('cuda', 'bf16')
     N, H, W, Ci, Co = args.batch, args.size, args.size, 3, 32
     w = torch.randn(Co, Ci, 3, 3).cuda()
