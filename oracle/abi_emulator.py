@@ -265,7 +265,11 @@ class AbiEmulator(object):
     def segnb_conv_fprop_bnreduce_ok(self, g, dtype):
         g = _geom(g)
         if not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
-                and g.Co % 8 == 0 and g.Wo >= 12):
+                and g.Co % 8 == 0):
+            return 0
+        if g.Ci <= 24 and g.Co >= 32:          # a dense layer's data gradient (growth 16 -> the prefix): the general kernel's store pass
+            return 1
+        if g.Wo < 12:
             return 0
         return int(g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and not (g.Co > 32 and g.Ci > 32))
 

@@ -35,6 +35,16 @@ struct FpropArgs {
     double* stats;
     int M, Ktot, ksteps, MT, NTL, GM;
     unsigned in_bytes, w_bytes;          // extents of the two buffers (buffer-load bounds checks)
+    // fused BatchNorm-backward REDUCTION in the store pass of a data-gradient launch (segnb_conv_fprop_bnreduce; template BNR):
+    // the output is the gradient g of an activation a = act(BatchNorm(y)); with y the store threads accumulate sum dz and
+    // sum dz * yhat, dz = round(g * act'(z)) -- segnb_bn_act_bwd_reduce without its own pass over (g, y).  FCDenseNet's dense
+    // layers (tiramisu.py:9-20: norm -> relu -> conv): the data gradient 16 -> C of every layer, C up to ~1100
+    const void* bn_y;
+    int bn_ld;
+    const float* bn_coef;                // [4][Co]: scale, shift, mean, invstd (segnb_bn_finalize)
+    double* bn_sums;                     // [SEGNB_STAT_REPLICAS][2][Co]
+    int bn_act;
+    float bn_slope;
 };
 
 struct WgradArgs {
@@ -117,8 +127,9 @@ constexpr int fprop_smem_bytes() {
 // ================================================================================================
 // forward / data-gradient
 // ================================================================================================
-template <typename T, int BM, int BN, int WM, int WN, bool EP = false>      // EP: affine + activation epilogue (separate instantiation)
+template <typename T, int BM, int BN, int WM, int WN, bool EP = false, bool BNR = false>      // EP: affine + activation epilogue; BNR: FpropArgs::bn_y (separate instantiations)
 __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
+    static_assert(!BNR || (!EP && sizeof(T) == 2 && NT % (BN / 8) == 0 && NT >= 2 * BN), "BatchNorm-reduce store pass: bf16, one fixed channel chunk per thread");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int AI = BM / 32, BI = BN / 32;
@@ -162,6 +173,24 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     for (int j = 0; j < BI; ++j) {
         const int co = n_base + row0 + 32 * j;
         b_off[j] = co < g.Co ? (unsigned)(co * a.Ktot + c * EPC) * (unsigned)sizeof(T) : OOB_OFFSET;
+    }
+
+    // BNR: this thread stores channel chunk tid % OC of every row it stores: its two sums stay in registers, the per-channel
+    // constants (mean, scale, shift) of the block's BN channels in LDS (sStat: a BNR launch takes no forward statistics) --
+    // 24 registers that cost the 128 x 128 tile its second block per CU
+    float bs1[BNR ? 8 : 1], bs2[BNR ? 8 : 1];
+    float bneg = 0.f;
+    if constexpr (BNR) {
+        for (int c2 = tid; c2 < BN; c2 += NT) {
+            const int ch = n_base + c2;
+            const bool in = ch < g.Co;
+            sStat[c2] = in ? a.bn_coef[2 * g.Co + ch] : 0.f;          // mean
+            sStat[BN + c2] = in ? a.bn_coef[ch] : 0.f;                // scale
+            sStat[2 * BN + c2] = in ? a.bn_coef[g.Co + ch] : 0.f;     // shift
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
+        bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
     }
 
     for (int mt = gq; mt < a.MT; mt += a.GM) {
@@ -263,6 +292,22 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
             __syncthreads();
         }
 
+        // BNR: the y rows of the pixels this thread stores are requested NOW -- their latency runs under the staging below
+        // (requested inside the store loop they were RPT dependent round trips per tile: the launch took 2.4 x as long)
+        constexpr int RPT = BNR ? BM * (BN / 8) / NT : 1;
+        uint4 yq[RPT];
+        if constexpr (BNR) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int q = tid + k * NT;
+                const int row = q / (BN / 8), cc = q - row * (BN / 8);
+                const int opix = sRow[row].w;
+                const int co = n_base + cc * 8;
+                yq[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (opix >= 0 && co < g.Co)
+                    yq[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bn_y) + (long long)opix * a.bn_ld + co);
+            }
+        }
         // ---- epilogue: bias, round, stats, stage to LDS ------------------------------------------
         unsigned char* sOut = sTiles;
         float cs1[TN], cs2[TN];
@@ -321,13 +366,66 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
             for (int q = 0; q < BM / WM; ++q) st += (double)sStat[q * 2 * BN + tid];
         }
         constexpr int OC = BN / EPC;
-        for (int q = tid; q < BM * OC; q += NT) {
+        static_assert(!BNR || (BM * OC) % NT == 0, "BatchNorm-reduce: whole store rounds");
+#pragma unroll
+        for (int k = 0; k < (BNR ? RPT : 1); ++k)
+        for (int q = BNR ? tid + k * NT : tid; q < (BNR ? tid + k * NT + 1 : BM * OC); q += NT) {
             const int row = q / OC, cc = q - row * OC;
             const int opix = sRow[row].w;
             const int co = n_base + cc * EPC;
-            if (opix >= 0 && co < g.Co)
-                *reinterpret_cast<uint4*>(outT + (long long)opix * g.ld_out + co) =
-                    *reinterpret_cast<const uint4*>(sOut + row * OUT_ROW + cc * 16);
+            if (opix >= 0 && co < g.Co) {
+                const uint4 gv = *reinterpret_cast<const uint4*>(sOut + row * OUT_ROW + cc * 16);
+                *reinterpret_cast<uint4*>(outT + (long long)opix * g.ld_out + co) = gv;
+                if constexpr (BNR) {
+                    // dz = round(g * act'(z)), z = (y - mean) * scale + shift: bn_act_bwd_reduce_kernel's arithmetic on the
+                    // ROUNDED gradient this launch stores
+                    const uint4 yv = yq[k];
+                    float gq8[8], yf[8];
+                    gq8[0] = __uint_as_float(gv.x << 16); gq8[1] = __uint_as_float(gv.x & 0xffff0000u);
+                    gq8[2] = __uint_as_float(gv.y << 16); gq8[3] = __uint_as_float(gv.y & 0xffff0000u);
+                    gq8[4] = __uint_as_float(gv.z << 16); gq8[5] = __uint_as_float(gv.z & 0xffff0000u);
+                    gq8[6] = __uint_as_float(gv.w << 16); gq8[7] = __uint_as_float(gv.w & 0xffff0000u);
+                    yf[0] = __uint_as_float(yv.x << 16); yf[1] = __uint_as_float(yv.x & 0xffff0000u);
+                    yf[2] = __uint_as_float(yv.y << 16); yf[3] = __uint_as_float(yv.y & 0xffff0000u);
+                    yf[4] = __uint_as_float(yv.z << 16); yf[5] = __uint_as_float(yv.z & 0xffff0000u);
+                    yf[6] = __uint_as_float(yv.w << 16); yf[7] = __uint_as_float(yv.w & 0xffff0000u);
+                    float bmu[8], bsc[8], bsh[8];
+                    load8(sStat + cc * 8, bmu);
+                    load8(sStat + BN + cc * 8, bsc);
+                    load8(sStat + 2 * BN + cc * 8, bsh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yc = yf[e] - bmu[e];
+                        const float z = yc * bsc[e] + bsh[e];
+                        const float dv = bf16_bits_to_f32(f32_to_bf16_bits(gq8[e] * (z > 0.f ? 1.f : bneg)));
+                        bs1[e] += dv;
+                        bs2[e] += dv * yc;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BNR) {
+        // fixed-order block reduction (the threads of a channel chunk are tid = cc + k * OC), one fp64 atomic per channel
+        constexpr int OC = BN / 8;
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [NT][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid * 16 + e] = bs1[e];
+            red[tid * 16 + 8 + e] = bs2[e];
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid - which * BN;
+            const int c8 = col >> 3, e = col & 7;
+            double sum = 0.0;
+            for (int k = 0; k < NT / OC; ++k) sum += (double)red[(k * OC + c8) * 16 + which * 8 + e];
+            const int co = n_base + col;
+            if (co < g.Co) {
+                if (which == 1) sum *= (double)a.bn_coef[3 * g.Co + co];      // * invstd: sum dz * yhat
+                atomicAdd(&a.bn_sums[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * g.Co + co], sum);
+            }
         }
     }
     if (a.stats != nullptr && tid < 2 * BN) {
@@ -1277,9 +1375,13 @@ int set_smem(K kernel, int bytes) {
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_fprop(FpropArgs& a, hipStream_t stream) {
     constexpr int smem = fprop_smem_bytes<BM, BN, T>();
+    static_assert(smem >= NT * 16 * 4, "BatchNorm-reduce scratch");
     static int attr_rc = [] {
-        const int rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
-        return rc ? rc : set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, true>, smem);
+        int rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
+        if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, true>, smem);
+        if constexpr (sizeof(T) == 2)
+            if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, false, true>, smem);
+        return rc;
     }();
     if (attr_rc) return attr_rc;
     a.MT = ceil_div(a.M, BM);
@@ -1293,7 +1395,12 @@ int launch_fprop(FpropArgs& a, hipStream_t stream) {
     if (gm > a.MT) gm = a.MT;
     a.GM = gm;
     const int grid = a.GM * a.NTL;
-    if (a.ep_act >= 0)
+    if (a.bn_y != nullptr) {
+        if constexpr (sizeof(T) == 2)
+            hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, false, true>), dim3(grid), dim3(NT), smem, stream, a);
+        else
+            return SEGNB_E_UNSUPPORTED;
+    } else if (a.ep_act >= 0)
         hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, true>), dim3(grid), dim3(NT), smem, stream, a);
     else
         hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), smem, stream, a);
@@ -1312,7 +1419,9 @@ int dispatch_fprop(FpropArgs& a, hipStream_t stream) {
         return launch_fprop<T, 64, 64, 32, 32>(a, stream);
     }
     const long long t128 = ((M + 127) / 128) * ((Co + 127) / 128);
-    if (t128 >= want) return launch_fprop<T, 128, 128, 64, 64>(a, stream);
+    // (BatchNorm-reduce store pass: eight y rows in flight + the sums would leave the 128 x 128 tile one block per CU -- its K
+    // is 144 deep, the second read of the pixel rows by the narrower tile is cheap)
+    if (t128 >= want && a.bn_y == nullptr) return launch_fprop<T, 128, 128, 64, 64>(a, stream);
     const long long t64 = ((M + 127) / 128) * ((Co + 63) / 64);
     if (t64 >= want) return launch_fprop<T, 128, 64, 64, 32>(a, stream);
     return launch_fprop<T, 64, 64, 32, 32>(a, stream);
@@ -1371,7 +1480,8 @@ int check_geom(const segnb_conv_geom* g) {
 }  // namespace
 
 static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
-                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep);
+                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep,
+                           const segnb_bn_reduce_epilogue* bn = nullptr);
 
 extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                 const float* bias, int bias_n, void* out, double* stats,
@@ -1389,10 +1499,20 @@ extern "C" int segnb_conv_fprop_act(const segnb_conv_geom* g, int dtype, const v
 }
 
 static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
-                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep) {
+                           int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep,
+                           const segnb_bn_reduce_epilogue* bn) {
     if (int rc = check_geom(g)) return rc;
     SEGNB_CHECK_ARG(in && wpacked && out, "NULL tensor");
     FpropArgs a;
+    a.bn_y = nullptr;
+    if (bn != nullptr) {          // (the general kernel's BatchNorm-reduce store pass: segnb_conv_fprop_bnreduce)
+        a.bn_y = bn->y;
+        a.bn_ld = bn->ld_y;
+        a.bn_coef = bn->coef;
+        a.bn_sums = bn->sums;
+        a.bn_act = bn->act;
+        a.bn_slope = bn->slope;
+    }
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;
     a.ep_slope = ep != nullptr ? ep->slope : 0.f;
@@ -1416,7 +1536,8 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
-        static const bool general_only = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
+        static const bool general_env = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
+        const bool general_only = general_env || bn != nullptr;
         // (the affine + activation epilogue lives in the c8, rw, ws and general kernels: s1 is skipped for it)
         rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
         if (rc == 0 && !general_only && ep == nullptr)
@@ -1609,11 +1730,16 @@ extern "C" int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const
     return rc;
 }
 
+// few input channels -> many output channels: the data gradient of a dense layer (tiramisu.py:9-20, growth 16 -> the prefix);
+// the general gather kernel serves it, with the reduction in its store pass (conv_fprop_kernel<..., BNR>)
+static bool bnreduce_general(const segnb_conv_geom* g) { return g->Ci <= 24 && g->Co >= 32 && g->Co % 8 == 0; }
+
 extern "C" int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype) {
-    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g)) return 0;
-    if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || !segnb_knob_bnreduce_fused()) return 0;
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || !segnb_knob_bnreduce_fused()) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
-    if (g->QH != g->Ho || g->QW != g->Wo || g->Co % 8 != 0 || g->Wo < 12) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Co % 8 != 0) return 0;
+    if (bnreduce_general(g)) return 1;      // (the general gather kernel: any width, any tap offsets)
+    if (getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_rw() || g->Wo < 12) return 0;
     for (int t = 0; t < 9; ++t)
         if (g->dh[t] < -1 || g->dh[t] > 1 || g->dw[t] < -1 || g->dw[t] > 1) return 0;
     if (g->Ci % 32 != 0 || g->Ci > 96 || g->Co > 64) return 0;
@@ -1632,6 +1758,10 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
     SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
     int rc = 0;
+    if (bnreduce_general(g)) {
+        SEGNB_CHECK_ARG(ep->ld_y % 8 == 0 && (((long long)g->N * g->Ho * g->Wo - 1) * ep->ld_y + g->Co) * 2 < (1ll << 31), "bad y");
+        return conv_fprop_impl(g, dtype, in, wpacked, nullptr, 0, out, nullptr, stream, nullptr, ep);
+    }
     if (g->Ci <= 96) {
         rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
         if (rc == 0)

@@ -620,6 +620,10 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None, stats_src
         nv.call('segnb_bn_act_fwd', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None, ov.ptr, ov.ld,
                 None, 0, None, 0, None, 0, rt.stream)
     oa = Act(ov)
+    if fused and tape.need_grad and tape.train:
+        # the ONE consumer's data gradient may do this layer's BatchNorm-backward reduction in its store pass (_data_gradient:
+        # a dense layer's 16 -> prefix data gradient, tiramisu.py:9-20); the sums buffer was cleared by the fused forward above
+        oa.producer = (xv, coef, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
     def backward():
         if oa.g is None:
@@ -631,12 +635,15 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None, stats_src
         sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
         if fused:
-            # ONE gradient source, no dropout, no residual: dz never goes to memory -- a sums-only reduction, then the apply
-            # launch recomputes dz = act'(z) * g from the incoming gradient (the *_direct forms, as ZF_UNET's first
-            # convolutions) and, when the input has other consumers whose gradients are already in x.g, adds its result
-            # there (no segnb_add pass)
-            nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
-                    oa.g.ptr, oa.g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
+            # ONE gradient source, no dropout, no residual: dz never goes to memory -- a sums-only reduction (done by the
+            # consumer's data gradient where a fused kernel serves it: oa.g_is_dz), then the apply launch recomputes
+            # dz = act'(z) * g from the incoming gradient (the *_direct forms, as ZF_UNET's first convolutions) and, when the
+            # input has other consumers whose gradients are already in x.g, adds its result there (no segnb_add pass)
+            if oa.g_is_dz:
+                oa.g_is_dz = False
+            else:
+                nv.call('segnb_bn_act_bwd_reduce', rt.code, xv.ptr, xv.ld, N, H, W, Cp, nv.ptr(coef), act, slope, None,
+                        oa.g.ptr, oa.g.ld, None, 0, None, 0, None, 0, nv.ptr(sums), None, 0, rt.stream)
             fargs = (rt.code, xv.ptr, xv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()),
                      nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), 1, None if cached else nv.ptr(stats),
                      act, slope, oa.g.ptr, oa.g.ld)

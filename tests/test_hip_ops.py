@@ -1257,7 +1257,11 @@ def test_upcat_segmented_backward_vs_torch(shape):
         assert torch.equal(dcat_s.dense()[..., Cup:], dfull.dense()[..., Cup:])
 
 
-@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1)],
+@pytest.mark.parametrize('shape', [(3, 40, 56, 32, 32, 1), (2, 33, 47, 32, 32, 2), (32, 224, 224, 32, 32, 1), (2, 24, 40, 32, 64, 1),
+                                   # a dense layer's data gradient (tiramisu.py:9-20: growth 16 -> the concat prefix) on the
+                                   # general gather kernel's store pass: 8 x 8 maps, ragged channel tiles, FCDenseNet103's sizes
+                                   (2, 24, 40, 112, 16, 1), (3, 9, 11, 48, 16, 2), (8, 8, 8, 1072, 16, 1), (8, 16, 16, 656, 16, 1),
+                                   (8, 128, 128, 272, 16, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_dgrad_with_fused_bn_reduce(shape):
     """segnb_conv_fprop_bnreduce: the data-gradient launch whose epilogue does the BatchNorm-backward reduction of the
@@ -1289,7 +1293,7 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
     sums_f2 = rt.zeros((16, 2, C1), torch.float64)
     op.dgrad(dyv, dx_f, bn_reduce=(y1, coef, sums_f2, act, 0.01))
     torch.cuda.synchronize()
-    if C2 == 32 or C2 >= 192:
+    if C2 == 32 or C2 == 16:
         assert torch.equal(dx_f.t, dx_plain.t)          # (the same kernel with and without the epilogue)
     else:
         # 64 -> 32: the plain data gradient runs on conv_roll_kernel with the K split over two waves, the fused one on
@@ -1297,7 +1301,7 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
         check('dx fused vs plain', dx_f.t, dx_plain.t, 'bf16')
     a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
     scale = np.abs(b).max(axis=1, keepdims=True) + 1e-30
-    tight = C2 == 32 or C2 >= 192    # (sums_ref is taken on dx_plain: the same values bit for bit only when the kernels are the same)
+    tight = C2 == 32 or C2 == 16    # (sums_ref is taken on dx_plain: the same values bit for bit only when the kernels are the same)
     assert np.abs(a - b).max() <= (2e-5 if tight else 2e-3) * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
     np.testing.assert_allclose(a / scale, b / scale, atol=1e-4 if tight else 3e-3)
     # fixed summation order inside a block, fp64 across blocks: run-to-run equal to fp64 rounding

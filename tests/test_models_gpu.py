@@ -301,7 +301,7 @@ def test_replay_fcdensenet103_structure(dtype):
                 mod.p = 0.0
         return m
     n, rep = abi_replay.replay(make, x, y, BCEWithLogitsLossAndSmoothJaccard(), dtype)
-    assert n > 1000 and not rep, '%d of %d calls differ:\n%s' % (len(rep), n, '\n'.join(rep[:20]))
+    assert n > 900 and not rep, '%d of %d calls differ:\n%s' % (len(rep), n, '\n'.join(rep[:20]))
 
 
 def test_unet16_1024_tiled_config():
