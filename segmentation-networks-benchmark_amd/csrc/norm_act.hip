@@ -1027,6 +1027,16 @@ __global__ void bn_bwd_finalize_kernel(const BnBwdParams p, const float* __restr
     }
 }
 
+// The two per-element expressions of the apply pass, shared by both forms of the kernel (one expression tree = one contraction
+// decision of the compiler: the lean form stays bit-identical to this one, and to conv_wgrad_c8roll_kernel's recomputed dy)
+__device__ __forceinline__ float bn_dz_elem(float d, float yv, float mu, float sc, float sh, int act, float slope) {
+    return d * 1.f * act_grad((yv - mu) * sc + sh + 0.f, act, slope);
+}
+__device__ __forceinline__ float bn_apply_elem(float yv, float d, float mu, float is, float a, float c1, float c2) {
+    const float yh = (yv - mu) * is;
+    return a * (d - c1 - yh * c2);
+}
+
 template <typename T, bool ACC = false>       // ACC: dy += result (gradient of a multi-consumer tensor: no separate segnb_add pass)
 __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict__ y, int ld_y, EwShape s,
                                                             const float* __restrict__ coef,
@@ -1117,15 +1127,11 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
                     // dz was never written: recompute it from the incoming gradient exactly as the reduce pass did
                     // (same expression, same rounding to the storage type)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        d[e] = d[e] * 1.f * act_grad((yv[e] - mu[e]) * sc[e] + sh[e] + 0.f, act, slope);
+                    for (int e = 0; e < 8; ++e) d[e] = bn_dz_elem(d[e], yv[e], mu[e], sc[e], sh[e], act, slope);
                     round_store8((T*)nullptr, d);
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float yh = (yv[e] - mu[e]) * is[e];
-                    d[e] = a[e] * (d[e] - c1[e] - yh * c2[e]);
-                }
+                for (int e = 0; e < 8; ++e) d[e] = bn_apply_elem(yv[e], d[e], mu[e], is[e], a[e], c1[e], c2[e]);
                 if constexpr (ACC) {          // (the rounded result added to the stored gradient, as segnb_add would)
                     round_store8((T*)nullptr, d);
                     float old[8];
@@ -1156,6 +1162,12 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(const T* __restrict_
         }
     }
 }
+
+// (A LEAN form of this pass -- <= 96 registers, constants in LDS, so that its blocks become resident BESIDE a weight-gradient block,
+// which holds 416 of a SIMD lane's 512 registers -- was built and measured in round 5: beside a stream of wide weight gradients the
+// pass itself went from 38.4 to 31.8 us (tools/coresidency_probe.py: x 1.43 -> x 1.25 of its stand-alone time), the training step
+// from 4.835 to 4.869 ms (+0.7 %; LinkNet34 +1.5 %): the weight gradients it now shares CUs with finish later and the data gradients
+// behind the pass get fewer free CUs.  Removed; profiles/r05_ab.txt.)
 
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long long n, float lr) {
     const long long n4 = n >> 2;
