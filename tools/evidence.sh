@@ -34,6 +34,9 @@ python3 tools/pmc_summary.py $O/${TAG}_pmc_sq1 conv_ > $O/${TAG}_pmc_conv_issue_
 python3 tools/pmc_summary.py $O/${TAG}_pmc_sq2 conv_ > $O/${TAG}_pmc_conv_lds.txt 2>&1
 find $O/${TAG}_prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_bench_bs32_kernel_stats.csv
 python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
+python3 tools/prologue_gap.py > $O/${TAG}_prologue_gap.txt 2>&1
+python3 tools/coresidency_probe.py > $O/${TAG}_coresidency.txt 2>&1
+python3 bench.py --model unet16 --tiled > $O/${TAG}_bench_tiled.json 2>/dev/null
 python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
 python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1

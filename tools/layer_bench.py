@@ -35,6 +35,10 @@ def main():
     ap.add_argument('--nostats', type=int, default=None, help='segnb_tune fprop_nostats (0/1)')
     ap.add_argument('--roll', type=int, default=None, help='segnb_tune fprop_roll (0/1/2)')
     ap.add_argument('--wroll', type=int, default=None, help='segnb_tune wgrad_roll (0/1)')
+    ap.add_argument('--wg-all', type=int, default=1,
+                    help='1 (default): a second weight-gradient column with the pixel split sized for ALL CUs (segnb_tune wg_cu_pct 100); '
+                         'the first column is the training step\'s configuration -- the wide launches sized for half of the CUs, because '
+                         'they run beside the data-gradient chain')
     ap.add_argument('--ksplit', type=int, default=None, help='segnb_tune fprop_ksplit (0 off / 1 auto / 2 / 4)')
     ap.add_argument('--only', default='', help='comma-separated layer names')
     ap.add_argument('--wgrad-unpack', type=int, default=0,
@@ -93,7 +97,29 @@ def main():
         stats = rt.zeros((16, 2, op.Cop), torch.float64)
         flops = 2.0 * N * hw * hw * 9 * ci * co
         line = '%-9s %4dx%-4d %4d->%-4d' % (name, hw, hw, ci, co)
-        for what in args.what.split(','):
+        whats = args.what.split(',')
+        if args.wg_all and 'wgrad' in whats:
+            whats = whats + ['wgrad@allCUs']
+        for what in whats:
+            if what == 'wgrad@allCUs':
+                # the same layer with its pixel split (and workspace) planned for every CU
+                nv.call('segnb_tune', b'wg_cu_pct', 100)
+                op2 = ConvOp(rt, wt, torch.zeros(co, device='cuda'), segs, 1, 1, False, True)
+                op2.pack(hw, hw)
+                fn = lambda: op2.wgrad(xv, dyv, gw, unpack=bool(args.wgrad_unpack))
+                fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(args.reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                nv.call('segnb_tune', b'wg_cu_pct', 0)
+                us = a.elapsed_time(b) / args.reps * 1e3
+                tot[what] = tot.get(what, 0.0) + us
+                line += '  %s %7.1f us %6.0f TF' % (what, us, flops / us / 1e6)
+                continue
             fn = {'fprop': lambda: op.fprop(xv, yv, stats), 'dgrad': lambda: op.dgrad(dyv, dxv),
                   'wgrad': lambda: op.wgrad(xv, dyv, gw, unpack=bool(args.wgrad_unpack))}[what]
             fn()
