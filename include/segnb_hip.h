@@ -355,6 +355,14 @@ int segnb_bn_stats(int dtype, const void* x, int ld, int N, int H, int W, int Cp
                    segnb_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad), floor mode (resnet stem maxpool 3x3 s2 p1, linknet.py:44) and its backward
  * (gradient to the first maximum of each window) */
+/* nn.Upsample(scale_factor=2, mode='bilinear') (align_corners=False) of DecoderBlock's non-deconvolution branch
+ * (lib/models/unet16.py:42-46) and its backward (the exact transpose, gather form): x [N][H][W][Cp] -> out [N][2H][2W][Cp];
+ * g_out [N][2H][2W][Cp] -> dx [N][H][W][Cp].  H, W: the LOW-resolution size. */
+int segnb_upsample_bilinear2x_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, void* out, int ld_out,
+                                  segnb_stream_t stream);
+int segnb_upsample_bilinear2x_bwd(int dtype, const void* g_out, int ld_go, int N, int H, int W, int Cp, void* dx, int ld_dx,
+                                  segnb_stream_t stream);
+
 /* idx (optional, uint8 [N][Ho][Wo][Cp]): the forward records the window position a*k+b of each maximum; handed to the
  * backward it replaces the re-scan of every covering window (NULL on either side: the re-scanning backward). */
 int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,

@@ -903,6 +903,24 @@ class AbiEmulator(object):
                                        nbt, coef, clear_sums, act, slope, dropmul, out, ld_out, None, 0, None, 0, None, 0,
                                        stream)
 
+    def segnb_upsample_bilinear2x_fwd(self, dtype, x, ld_x, N, H, W, Cp, out, ld_out, stream):
+        # nn.Upsample(scale_factor=2, mode='bilinear') of lib/models/unet16.py:43 (align_corners=False)
+        dt = _tdt(dtype)
+        X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2)
+        U = torch.nn.functional.interpolate(X, scale_factor=2, mode='bilinear', align_corners=False)
+        _nhwc(out, N, 2 * H, 2 * W, Cp, ld_out, dt).copy_(U.permute(0, 2, 3, 1).to(dt))
+        return 0
+
+    def segnb_upsample_bilinear2x_bwd(self, dtype, g_out, ld_go, N, H, W, Cp, dx, ld_dx, stream):
+        dt = _tdt(dtype)
+        with torch.enable_grad():
+            X = torch.zeros(N, Cp, H, W, requires_grad=True)
+            U = torch.nn.functional.interpolate(X, scale_factor=2, mode='bilinear', align_corners=False)
+            G = _nhwc(g_out, N, 2 * H, 2 * W, Cp, ld_go, dt).float().permute(0, 3, 1, 2)
+            U.backward(G)
+        _nhwc(dx, N, H, W, Cp, ld_dx, dt).copy_(X.grad.permute(0, 2, 3, 1).to(dt))
+        return 0
+
     def segnb_maxpool_fwd(self, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, idx, stream):
         dt = _tdt(dtype)
         X = _nhwc(x, N, H, W, Cp, ld_x, dt).float().permute(0, 3, 1, 2)

@@ -16,11 +16,17 @@ import torch.nn.functional as F
 ENC_IDX = [[0, 2], [5, 7], [10, 12, 14], [17, 19, 21], [24, 26, 28]]
 
 
-def forward(sd, x):
+def forward(sd, x, is_deconv=True):
+    """is_deconv=False: every DecoderBlock on its other branch (unet16.py:42-46): Upsample(scale_factor=2, mode='bilinear') ->
+    conv3x3 + ReLU -> conv3x3 + ReLU (keys block.1.conv / block.2.conv); pinned by tests/golden/unet16_bilinear_small.npz, which
+    the reference's own DecoderBlock(is_deconv=False) instances produced inside the reference's UNet16."""
     def cr(prefix, h):
         return torch.relu(F.conv2d(h, sd[prefix + 'weight'], sd[prefix + 'bias'], padding=1))
 
     def dec(name, h):
+        if not is_deconv:
+            h = F.interpolate(h, scale_factor=2, mode='bilinear', align_corners=False)
+            return cr(name + '.block.2.conv.', cr(name + '.block.1.conv.', h))
         h = cr(name + '.block.0.conv.', h)
         return torch.relu(F.conv_transpose2d(h, sd[name + '.block.1.weight'], sd[name + '.block.1.bias'], stride=2,
                                              padding=1))

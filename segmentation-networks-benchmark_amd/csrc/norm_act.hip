@@ -2022,6 +2022,118 @@ extern "C" int segnb_bn_stats_ld(int dtype, const void* x, int ld, int N, int H,
     return launch_bn_stats(dtype, x, ld, N, H, W, Cp, stats, stats_ld, "segnb_bn_stats_ld", stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// nn.Upsample(scale_factor=2, mode='bilinear') of the DecoderBlock's non-deconvolution branch (lib/models/unet16.py:42-46;
+// align_corners=False, torch's default): output row 2i = 0.25 in[i-1] + 0.75 in[i], row 2i+1 = 0.75 in[i] + 0.25 in[i+1] with the
+// neighbour index clamped to the image (columns alike).  fp32 arithmetic in torch's order -- rows of column-interpolated values
+// -- rounded once.  The backward is the exact transpose in gather form: an input pixel collects from the <= 4 x 4 outputs that
+// read it, so no atomics and a fixed summation order.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilin_src(int o, int n, int& i0, int& i1, float& w0, float& w1) {
+    const int i = o >> 1;
+    if (o & 1) { i0 = i; i1 = i + 1 < n ? i + 1 : n - 1; w0 = 0.75f; w1 = 0.25f; }
+    else       { i0 = i > 0 ? i - 1 : 0; i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+template <typename T>
+__global__ __launch_bounds__(NTHR) void upsample_bilinear2x_fwd_kernel(const T* __restrict__ x, int ld_x, int N, int H, int W, int CPP,
+                                                                       T* __restrict__ out, int ld_out) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * Ho * Wo * CPP;
+    for (long long i = blockIdx.x * (long long)NTHR + threadIdx.x; i < total; i += (long long)gridDim.x * NTHR) {
+        const int cc = (int)(i % CPP);
+        long long q = i / CPP;
+        const int ox = (int)(q % Wo);
+        q /= Wo;
+        const int oy = (int)(q % Ho);
+        const int n = (int)(q / Ho);
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        bilin_src(oy, H, y0, y1, wy0, wy1);
+        bilin_src(ox, W, x0, x1, wx0, wx1);
+        float a[8], b[8], c[8], d[8], v[8];
+        const T* base = x + (long long)n * H * W * ld_x + cc * 8;
+        load8(base + ((long long)y0 * W + x0) * ld_x, a);
+        load8(base + ((long long)y0 * W + x1) * ld_x, b);
+        load8(base + ((long long)y1 * W + x0) * ld_x, c);
+        load8(base + ((long long)y1 * W + x1) * ld_x, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = wy0 * (wx0 * a[e] + wx1 * b[e]) + wy1 * (wx0 * c[e] + wx1 * d[e]);
+        store8(out + (((long long)n * Ho + oy) * Wo + ox) * ld_out + cc * 8, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(NTHR) void upsample_bilinear2x_bwd_kernel(const T* __restrict__ go, int ld_go, int N, int H, int W, int CPP,
+                                                                       T* __restrict__ dx, int ld_dx) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * H * W * CPP;
+    for (long long i = blockIdx.x * (long long)NTHR + threadIdx.x; i < total; i += (long long)gridDim.x * NTHR) {
+        const int cc = (int)(i % CPP);
+        long long q = i / CPP;
+        const int ix = (int)(q % W);
+        q /= W;
+        const int iy = (int)(q % H);
+        const int n = (int)(q / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int oy = 2 * iy - 2; oy <= 2 * iy + 3; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            int y0, y1;
+            float wy0, wy1;
+            bilin_src(oy, H, y0, y1, wy0, wy1);
+            const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 2 * ix - 2; ox <= 2 * ix + 3; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                int x0, x1;
+                float wx0, wx1;
+                bilin_src(ox, W, x0, x1, wx0, wx1);
+                const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+                if (wx == 0.f) continue;
+                float g[8];
+                load8(go + (((long long)n * Ho + oy) * Wo + ox) * ld_go + cc * 8, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (wy * wx) * g[e];
+            }
+        }
+        store8(dx + (((long long)n * H + iy) * W + ix) * ld_dx + cc * 8, acc);
+    }
+}
+
+extern "C" int segnb_upsample_bilinear2x_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, void* out, int ld_out,
+                                             segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_upsample_bilinear2x_fwd, dtype, x, ld_x, N, H, W, Cp, out, ld_out, stream);
+    if (int rc = check_ew(N, 2 * H, 2 * W, Cp)) return rc;
+    SEGNB_CHECK_ARG(x && out && ld_x >= Cp && ld_out >= Cp, "bad arguments");
+    int grid = ceil_div((long long)N * 4 * H * W * (Cp / 8), NTHR);
+    if (grid > 16384) grid = 16384;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(upsample_bilinear2x_fwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           ld_x, N, H, W, Cp / 8, (bf16_t*)out, ld_out),
+        hipLaunchKernelGGL(upsample_bilinear2x_fwd_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)x,
+                           ld_x, N, H, W, Cp / 8, (float*)out, ld_out),
+        "segnb_upsample_bilinear2x_fwd")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_upsample_bilinear2x_bwd(int dtype, const void* g_out, int ld_go, int N, int H, int W, int Cp, void* dx,
+                                             int ld_dx, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_upsample_bilinear2x_bwd, dtype, g_out, ld_go, N, H, W, Cp, dx, ld_dx, stream);
+    if (int rc = check_ew(N, 2 * H, 2 * W, Cp)) return rc;
+    SEGNB_CHECK_ARG(g_out && dx && ld_go >= Cp && ld_dx >= Cp, "bad arguments");
+    int grid = ceil_div((long long)N * H * W * (Cp / 8), NTHR);
+    if (grid > 16384) grid = 16384;
+    SEGNB_DISPATCH_T(
+        hipLaunchKernelGGL(upsample_bilinear2x_bwd_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const bf16_t*)g_out,
+                           ld_go, N, H, W, Cp / 8, (bf16_t*)dx, ld_dx),
+        hipLaunchKernelGGL(upsample_bilinear2x_bwd_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, (const float*)g_out,
+                           ld_go, N, H, W, Cp / 8, (float*)dx, ld_dx),
+        "segnb_upsample_bilinear2x_bwd")
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, int Cp, int k, int stride,
                                  int pad, void* out, int ld_out, unsigned char* idx, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_maxpool_fwd, dtype, x, ld_x, N, H, W, Cp, k, stride, pad, out, ld_out, idx, stream);

@@ -18,7 +18,7 @@ from torch import nn
 
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.net import HipNet, concat, conv_unit, head_1x1
+from segnb.net import HipNet, concat, conv_unit, head_1x1, upsample_bilinear2x
 
 VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
 
@@ -48,14 +48,21 @@ class ConvRelu(nn.Module):
 
 
 class DecoderBlock(nn.Module):
+    """unet16.py:24-49: conv3x3 + ReLU -> ConvTranspose2d(4, 2, 1) -> ReLU (is_deconv, what UNet16 builds), or
+    Upsample(x2, bilinear) -> conv3x3 + ReLU -> conv3x3 + ReLU; same attribute tree / state_dict keys either way."""
+
     def __init__(self, in_channels, middle_channels, out_channels, is_deconv=True):
         super(DecoderBlock, self).__init__()
-        if not is_deconv:
-            raise NotImplementedError('the bilinear branch is never selected by the reference (unet16.py:29 default)')
         self.in_channels = in_channels
-        self.block = nn.Sequential(ConvRelu(in_channels, middle_channels),
-                                   nn.ConvTranspose2d(middle_channels, out_channels, kernel_size=4, stride=2, padding=1),
-                                   nn.ReLU(inplace=True))
+        self.is_deconv = bool(is_deconv)
+        if is_deconv:
+            self.block = nn.Sequential(ConvRelu(in_channels, middle_channels),
+                                       nn.ConvTranspose2d(middle_channels, out_channels, kernel_size=4, stride=2, padding=1),
+                                       nn.ReLU(inplace=True))
+        else:
+            self.block = nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear'),
+                                       ConvRelu(in_channels, middle_channels),
+                                       ConvRelu(middle_channels, out_channels))
 
     def forward(self, x):
         raise RuntimeError('parameter holder; run the whole UNet16 (HIP executor)')
@@ -67,7 +74,9 @@ class UNet16(HipNet):
     # waited (profiles/r04_ab.txt: 18.75 ms per step at 50 %, 17.98 at 75 %, 17.77 at 100 %; LinkNet34 loses 7 % at 100 %).
     wg_cu_pct = 100
 
-    def __init__(self, num_classes=1, num_filters=32, pretrained=False):
+    def __init__(self, num_classes=1, num_filters=32, pretrained=False, is_deconv=True):
+        """is_deconv: the DecoderBlock branch (unet16.py:34-46).  The reference's UNet16 always builds the deconvolution branch
+        (:104-108 pass no flag); False selects its class's other, bilinear-upsampling branch for every decoder block."""
         super(UNet16, self).__init__()
         if pretrained == 'vgg':
             raise ValueError("pretrained='vgg' needs downloaded torchvision weights; load a state_dict instead")
@@ -82,11 +91,11 @@ class UNet16(HipNet):
         self.conv4 = nn.Sequential(e[17], self.relu, e[19], self.relu, e[21], self.relu)
         self.conv5 = nn.Sequential(e[24], self.relu, e[26], self.relu, e[28], self.relu)
         nf = num_filters
-        self.center = DecoderBlock(512, nf * 8 * 2, nf * 8)
-        self.dec5 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8)
-        self.dec4 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8)
-        self.dec3 = DecoderBlock(256 + nf * 8, nf * 4 * 2, nf * 2)
-        self.dec2 = DecoderBlock(128 + nf * 2, nf * 2 * 2, nf)
+        self.center = DecoderBlock(512, nf * 8 * 2, nf * 8, is_deconv)
+        self.dec5 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8, is_deconv)
+        self.dec4 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8, is_deconv)
+        self.dec3 = DecoderBlock(256 + nf * 8, nf * 4 * 2, nf * 2, is_deconv)
+        self.dec2 = DecoderBlock(128 + nf * 2, nf * 2 * 2, nf, is_deconv)
         self.dec1 = ConvRelu(64 + nf, nf)
         self.final = nn.Conv2d(nf, num_classes, kernel_size=1)
         self._nf = nf
@@ -121,6 +130,13 @@ class UNet16(HipNet):
                 cin = conv.out_channels
 
         def decoder_block(blk, inp, segs, out_view, tag):
+            if not blk.is_deconv:
+                # Upsample(x2, bilinear) -> ConvRelu -> ConvRelu (unet16.py:42-46).  A concat input is upsampled as one tensor
+                c1, c2 = blk.block[1].conv, blk.block[2].conv
+                up = upsample_bilinear2x(tape, inp, tag=tag + '.up')
+                mid = conv_unit(tape, up, c1.weight, c1.bias, segs, act=nv.ACT_RELU, tag=tag + '.conv1')
+                return conv_unit(tape, mid, c2.weight, c2.bias, [(c1.out_channels, cp.pad8(c1.out_channels))], act=nv.ACT_RELU,
+                                 out=out_view, tag=tag + '.conv2')
             c0, ct = blk.block[0].conv, blk.block[1]
             mid = conv_unit(tape, inp, c0.weight, c0.bias, segs, act=nv.ACT_RELU, tag=tag + '.conv')
             return conv_unit(tape, mid, ct.weight, ct.bias, [(c0.out_channels, cp.pad8(c0.out_channels))], stride=2,

@@ -129,6 +129,8 @@ SIGNATURES = {
     'segnb_tiles_merge': [_P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P],
     'segnb_bn_stats': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    'segnb_upsample_bilinear2x_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    'segnb_upsample_bilinear2x_bwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     'segnb_maxpool_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     'segnb_maxpool_bwd': [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     'segnb_nhwc_to_nchw_f32': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],

@@ -731,6 +731,26 @@ def maxpool(tape, x, k, stride, pad, tag='pool'):
     return oa
 
 
+def upsample_bilinear2x(tape, x, tag='up'):
+    """nn.Upsample(scale_factor=2, mode='bilinear') (unet16.py:43: DecoderBlock with is_deconv=False)."""
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    tape.consume(x)
+    ov = tape.view(site + '/o', xv.N, 2 * xv.H, 2 * xv.W, xv.Cp)
+    nv.call('segnb_upsample_bilinear2x_fwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, xv.Cp, ov.ptr, ov.ld, rt.stream)
+    oa = Act(ov)
+
+    def backward():
+        if oa.g is None or not x.needs_grad:
+            return
+        dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
+        nv.call('segnb_upsample_bilinear2x_bwd', rt.code, oa.g.ptr, oa.g.ld, xv.N, xv.H, xv.W, xv.Cp, dx.ptr, dx.ld, rt.stream)
+        tape.contribute(x, dx)
+
+    tape.record(backward)
+    return oa
+
+
 def add(tape, a, b, tag='add'):
     """out = a + b (linknet.py:77-79); both inputs receive the output gradient unchanged."""
     rt, av, bv = tape.rt, a.v, b.v

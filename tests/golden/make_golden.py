@@ -515,6 +515,28 @@ def gen_unet16():
     _run_and_record(m, x, y, 'unet16_small.npz', seed=16)
 
 
+def gen_unet16_bilinear():
+    """The reference's UNet16 (unet16.py:52-131) with every decoder block replaced by the reference's OWN
+    DecoderBlock(..., is_deconv=False) (unet16.py:42-46: Upsample(x2, bilinear) -> ConvRelu -> ConvRelu) -- UNet16's constructor
+    passes no flag (:104-108), so the blocks are swapped after construction, same channel arguments."""
+    _install_third_party_standins()
+    import warnings
+    from lib.models.unet16 import DecoderBlock, UNet16
+    nf = 8
+    m = UNet16(num_classes=1, num_filters=nf, pretrained=False)
+    m.center = DecoderBlock(512, nf * 8 * 2, nf * 8, is_deconv=False)
+    m.dec5 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8, is_deconv=False)
+    m.dec4 = DecoderBlock(512 + nf * 8, nf * 8 * 2, nf * 8, is_deconv=False)
+    m.dec3 = DecoderBlock(256 + nf * 8, nf * 4 * 2, nf * 2, is_deconv=False)
+    m.dec2 = DecoderBlock(128 + nf * 2, nf * 2 * 2, nf, is_deconv=False)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    y = (torch.rand(2, 1, 64, 96, generator=g) > 0.7).long()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')          # (nn.Upsample's align_corners notice)
+        _run_and_record(m, x, y, 'unet16_bilinear_small.npz', seed=17)
+
+
 def gen_linknet():
     _install_third_party_standins()
     from lib.models.linknet import LinkNet34                    # reference wiring, linknet.py:5-90
@@ -541,11 +563,13 @@ def gen_tiramisu57():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiramisu57', 'tiles', 'augment', 'unet16', 'linknet']
+    which = sys.argv[1:] or ['losses', 'tiny', '224', 'tiramisu', 'tiramisu57', 'tiles', 'augment', 'unet16', 'unet16_bilinear', 'linknet']
     if 'augment' in which:
         gen_augment()
     if 'unet16' in which:
         gen_unet16()
+    if 'unet16_bilinear' in which:
+        gen_unet16_bilinear()
     if 'linknet' in which:
         gen_linknet()
     if 'tiles' in which:

@@ -148,6 +148,13 @@ def make_unet16_golden(golden):
     return _load_seeded(m, golden), unet16_ref.forward
 
 
+def make_unet16_bilinear_golden(golden):
+    """UNet16 with every DecoderBlock on its bilinear branch (unet16.py:42-46; UNet16(..., is_deconv=False) here)"""
+    from lib.models.unet16 import UNet16
+    m = UNet16(num_filters=8, is_deconv=False)
+    return _load_seeded(m, golden), (lambda sd, x: unet16_ref.forward(sd, x, is_deconv=False))
+
+
 def make_linknet_golden(golden):
     from lib.models.linknet import LinkNet34
     with warnings.catch_warnings():

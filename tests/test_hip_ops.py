@@ -1446,6 +1446,34 @@ def test_conv_fprop_rw(case):
     check(name + ' dx vs torch', torch.cat(parts, -1).permute(0, 3, 1, 2), xr.grad, 'bf16')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 5, 7, 16), (1, 1, 9, 8), (3, 16, 16, 40), (4, 128, 128, 64)], ids=lambda s: 'x'.join(map(str, s)))
+def test_upsample_bilinear2x_vs_torch(shape, dtype):
+    """segnb_upsample_bilinear2x_fwd / _bwd == nn.Upsample(scale_factor=2, mode='bilinear') (lib/models/unet16.py:43) and its
+    autograd backward on the CPU (fp32 math on the same rounded operands); one-row / one-column images hit the clamped taps."""
+    N, H, W, C = shape
+    rt = Runtime('cuda', dtype)
+    gen = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(N, C, H, W, generator=gen)
+    go = torch.randn(N, C, 2 * H, 2 * W, generator=gen)
+    if dtype == 'bf16':
+        x, go = x.bfloat16().float(), go.bfloat16().float()
+    xv = View.alloc(rt, N, H, W, C)
+    xv.dense().copy_(x.permute(0, 2, 3, 1).to('cuda', rt.tdtype))
+    ov = View.alloc(rt, N, 2 * H, 2 * W, C)
+    gv = View.alloc(rt, N, 2 * H, 2 * W, C)
+    gv.dense().copy_(go.permute(0, 2, 3, 1).to('cuda', rt.tdtype))
+    dxv = View.alloc(rt, N, H, W, C)
+    nv.call('segnb_upsample_bilinear2x_fwd', rt.code, xv.ptr, xv.ld, N, H, W, C, ov.ptr, ov.ld, rt.stream)
+    nv.call('segnb_upsample_bilinear2x_bwd', rt.code, gv.ptr, gv.ld, N, H, W, C, dxv.ptr, dxv.ld, rt.stream)
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False)
+    yr.backward(go)
+    check('bilinear fwd', ov.dense().float().cpu().permute(0, 3, 1, 2), yr.detach(), dtype)
+    check('bilinear bwd', dxv.dense().float().cpu().permute(0, 3, 1, 2), xr.grad, dtype)
+
+
 def test_fork_carried_by_the_apply_pass_orders_the_side_stream():
     """segnb_stream_fork_arm / segnb_stream_fork_commit: the side stream waits for the BatchNorm-backward apply pass through an
     event that rides on that kernel's own dispatch (no marker packet on the main queue) -- the weight gradient launched behind

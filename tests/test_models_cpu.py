@@ -96,6 +96,17 @@ def test_unet16_oracle_and_product_vs_reference_golden(golden_dir):
     mc.check_product_golden(m, g, 'cpu')
 
 
+def test_unet16_bilinear_decoder_oracle_and_product_vs_reference_golden(golden_dir):
+    """DecoderBlock's other branch (unet16.py:42-46: Upsample(x2, bilinear) -> ConvRelu -> ConvRelu).  The fixture was produced by
+    the reference's UNet16 with its decoder blocks replaced by the reference's own DecoderBlock(is_deconv=False) instances
+    (make_golden.py gen_unet16_bilinear); pins the oracle's branch and the product's UNet16(is_deconv=False) on the emulator."""
+    g = np.load(os.path.join(golden_dir, 'unet16_bilinear_small.npz'))
+    m, fwd = mc.make_unet16_bilinear_golden(g)
+    assert 'center.block.1.conv.weight' in m.state_dict() and 'dec2.block.2.conv.bias' in m.state_dict()
+    mc.check_oracle_golden(fwd, fwd, m, g)
+    mc.check_product_golden(m, g, 'cpu')
+
+
 def test_linknet34_oracle_and_product_vs_reference_golden(golden_dir):
     """PIN of oracle/linknet_ref.py: the fixture was produced by the reference's linknet.py:5-90."""
     from oracle import linknet_ref

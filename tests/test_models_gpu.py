@@ -61,6 +61,15 @@ def test_unet16_vs_reference_golden(golden_dir, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_unet16_bilinear_decoder_vs_reference_golden(golden_dir, dtype):
+    """UNet16(is_deconv=False): DecoderBlock's bilinear branch (unet16.py:42-46) on the HIP path vs the fixture the reference's own
+    DecoderBlock(is_deconv=False) produced."""
+    g = np.load(os.path.join(golden_dir, 'unet16_bilinear_small.npz'))
+    m, _ = mc.make_unet16_bilinear_golden(g)
+    print('unet16 bilinear %s dloss %.2e diou %.2e' % ((dtype,) + mc.check_product_golden(m, g, 'cuda', dtype)))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_linknet34_vs_reference_golden(golden_dir, dtype):
     g = np.load(os.path.join(golden_dir, 'linknet_small.npz'))
     m, _ = mc.make_linknet_golden(g)
