@@ -513,6 +513,25 @@ int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int 
                    const float* w, int K, const float* dlogits, void* da, int ld_da, float* dw,
                    float* db, segnb_stream_t stream);
 
+/* Classifier head that is a SMALL CONVOLUTION over an activated tensor (linknet.py:62 `finalconv3 = nn.Conv2d(32, num_classes, 2,
+ * padding=1)`; a 1 x 1 head -- unet16.py:111 -- is kh = kw = 1, pad = 0), stride 1, zero padding `pad`:
+ *   logits[n][k][ho][wo] = bias[k] + sum_{i < kh, j < kw, c < C} a[n][ho - pad + i][wo - pad + j][c] * w[k][c][i][j]
+ * a: [N][Hi][Wi][ld_a] `dtype`; w: the PARAMETER itself, fp32 [K][C][kh][kw] (no packed copy); logits / dlogits: fp32 NCHW
+ * [N][K][Ho][Wo], Ho = Hi + 2 pad - kh + 1 (the reference's output layout).  Served when K * kh * kw <= 8 and C <= 64
+ * (segnb_head_conv_ok); otherwise the convolution runs as segnb_conv_fprop.
+ * _bwd: dw[k][c][i][j] += sum dlogits * a, db[k] += sum dlogits (fp32, the parameters' gradient layout; block-ordered partial
+ * sums: reproducible), da[n][h][w][c] = sum dlogits[n][k][h + pad - i][w + pad - j] * w[k][c][i][j] (channels C..Cp-1: zero).
+ * act < 0: da is that plain gradient.  act = SEGNB_ACT_NONE / RELU / LEAKY: `a` is the output of a convolution + activation WITHOUT
+ * BatchNorm (unet16.py:12-21 ConvRelu, linknet.py:58-61) whose only consumer is this head -- da is then dz = round(round(g) *
+ * act'(a)) (act' read from the sign of the activated value) and sums[r][0][c] += sum dz (fp64 [SEGNB_STAT_REPLICAS][2][Cp], that
+ * layer's bias-gradient sums): its segnb_bn_act_bwd_reduce pass over (g, a) is folded into this launch. */
+int segnb_head_conv_ok(int C, int K, int kh, int kw);
+int segnb_head_conv_fwd(int dtype, const void* a, int ld_a, int N, int Hi, int Wi, int C, const float* w, int kh, int kw, int pad,
+                        const float* bias, int K, float* logits, segnb_stream_t stream);
+int segnb_head_conv_bwd(int dtype, const void* a, int ld_a, int N, int Hi, int Wi, int C, int Cp, const float* w, int kh, int kw,
+                        int pad, int K, const float* dlogits, int act, float slope, void* da, int ld_da, float* dw, float* db,
+                        double* sums, segnb_stream_t stream);
+
 /* Statistics of a concat prefix WITHOUT a pass over the prefix (FCDenseNet's dense blocks, tiramisu.py:9-44: layer l normalises
  * [input | slice 1 .. slice l-1] with its own BatchNorm; the batch statistics of those channels are the same for every layer).
  * One table [REPLICAS][2][ld] per concat buffer, channel c of the buffer at column c:

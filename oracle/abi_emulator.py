@@ -1024,6 +1024,45 @@ class AbiEmulator(object):
             _mem(db, K, torch.float32).add_(DL.reshape(-1, K).sum(0))
         return 0
 
+    def segnb_head_conv_ok(self, C, K, kh, kw):
+        return int(K >= 1 and kh >= 1 and kw >= 1 and K * kh * kw <= 8 and 1 <= C <= 64)
+
+    def segnb_head_conv_fwd(self, dtype, a, ld_a, N, Hi, Wi, C, w, kh, kw, pad, bias, K, logits, stream):
+        A = _nhwc(a, N, Hi, Wi, C, ld_a, _tdt(dtype)).float().permute(0, 3, 1, 2)
+        Wm = _mem(w, K * C * kh * kw, torch.float32).view(K, C, kh, kw)
+        b = _mem(bias, K, torch.float32) if bias is not None else None
+        out = torch.nn.functional.conv2d(A, Wm, b, padding=pad)
+        _mem(logits, out.numel(), torch.float32).view(out.shape).copy_(out)
+        return 0
+
+    def segnb_head_conv_bwd(self, dtype, a, ld_a, N, Hi, Wi, C, Cp, w, kh, kw, pad, K, dlogits, act, slope, da, ld_da, dw, db,
+                            sums, stream):
+        dt = _tdt(dtype)
+        Av = _nhwc(a, N, Hi, Wi, Cp, ld_a, dt)
+        A = Av[..., :C].float().permute(0, 3, 1, 2)
+        Wm = _mem(w, K * C * kh * kw, torch.float32).view(K, C, kh, kw)
+        Ho, Wo = Hi + 2 * pad - kh + 1, Wi + 2 * pad - kw + 1
+        DL = _mem(dlogits, N * K * Ho * Wo, torch.float32).view(N, K, Ho, Wo)
+        if da is not None:
+            g = torch.nn.grad.conv2d_input((N, C, Hi, Wi), Wm, DL, padding=pad).permute(0, 2, 3, 1)
+            DA = _nhwc(da, N, Hi, Wi, Cp, ld_da, dt)
+            full = torch.zeros(N, Hi, Wi, Cp)
+            full[..., :C] = g
+            full = full.to(dt)
+            if act >= 0:
+                neg = 0.0 if act == ACT_RELU else (slope if act == ACT_LEAKY else 1.0)
+                full = torch.where(Av.float() > 0, full.float(), full.float() * neg).to(dt)
+                if sums is not None:
+                    S = _mem(sums, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)[0]
+                    S[0] += full.double().reshape(-1, Cp).sum(0)
+            DA.copy_(full)
+        if dw is not None:
+            _mem(dw, K * C * kh * kw, torch.float32).view(K, C, kh, kw).add_(
+                torch.nn.grad.conv2d_weight(A, (K, C, kh, kw), DL, padding=pad))
+        if db is not None:
+            _mem(db, K, torch.float32).add_(DL.sum((0, 2, 3)))
+        return 0
+
     # ------------------------------------------------------------------------------------------ loss
     @staticmethod
     def _terms(x, t, gamma=2.0):

@@ -197,23 +197,208 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// classifier head that is a SMALL CONVOLUTION over an activated tensor (linknet.py:62: Conv2d(32, classes, 2, padding=1); the
+// 1 x 1 heads are the one-position case).  Memory-bound: the general implicit-GEMM kernels spend a 32-wide channel tile on one
+// class (6 TFLOP/s, 2-3 x the time of one pass over the activations).
+//   forward : one thread per OUTPUT pixel, weights [class][position][C8] in LDS; the window positions re-read their neighbours'
+//             pixels from cache
+//   backward: head_bwd_kernel's mapping over the INPUT pixels with K * T virtual classes (class, window position): the gradient
+//             of virtual class (k, t) at input pixel (h, w) is dlogits[k] at output pixel (h + pad - t / kw, w + pad - t % kw).
+//             act >= 0: the result is dz = round(round(da) * act'(a)) of the convolution + activation that PRODUCED a (no
+//             BatchNorm in between: act' has the sign of the activated value) and the per-channel sums of dz go to `sums`
+//             (that layer's bias gradient) -- its segnb_bn_act_bwd_reduce pass folded into this one
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict__ a, int ld_a, int N, int Hi, int Wi, int C,
+                                                            const float* __restrict__ w, int kh, int kw, int pad,
+                                                            const float* __restrict__ bias, int K, int Ho, int Wo,
+                                                            float* __restrict__ logits) {
+    extern __shared__ float swc[];  // [K][T][C8]
+    const int C8 = (C + 7) & ~7, NT = kh * kw;
+    for (int i = threadIdx.x; i < K * NT * C8; i += blockDim.x) {
+        const int k = i / (NT * C8), r = i - k * (NT * C8), t = r / C8, c = r - t * C8;
+        swc[i] = c < C ? w[((long long)k * C + c) * NT + t] : 0.f;
+    }
+    __syncthreads();
+    const long long hw = (long long)Ho * Wo, npix = (long long)N * hw;
+    for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix; pix += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(pix / hw), r = (int)(pix - n * hw), ho = r / Wo, wo = r - ho * Wo;
+        float acc[MAXK];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const int hi = ho - pad + t / kw, wi = wo - pad + t % kw;
+            if ((unsigned)hi >= (unsigned)Hi || (unsigned)wi >= (unsigned)Wi) continue;
+            const T* src = a + ((long long)(n * Hi + hi) * Wi + wi) * ld_a;
+            for (int c0 = 0; c0 < C8; c0 += 8) {
+                float v[8];
+                load8(src + c0, v);
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k)
+                    if (k < K) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[k] = fmaf(v[e], swc[(k * NT + t) * C8 + c0 + e], acc[k]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) logits[((long long)n * K + k) * hw + r] = acc[k] + (bias != nullptr ? bias[k] : 0.f);
+    }
+}
+
+template <typename T, int KM>
+__global__ __launch_bounds__(256) void head_conv_bwd_kernel(const T* __restrict__ a, int ld_a, int N, int Hi, int Wi, int C, int Cp,
+                                                            const float* __restrict__ w, int kh, int kw, int pad, int K, int Ho,
+                                                            int Wo, const float* __restrict__ dl, int act, float slope,
+                                                            T* __restrict__ da, int ld_da, float* __restrict__ part,
+                                                            double* __restrict__ sums, int CT) {
+    __shared__ float sred[256 * 8];
+    const int PY = 256 / CT;
+    const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const int cc = blockIdx.y * CT + tx;
+    const bool active = cc * 8 < Cp;
+    const int c0 = active ? cc * 8 : 0;
+    const int NT = kh * kw, KT = K * NT;
+    // the pixel walk covers the union of the input and the output grid: every input pixel for da / dw, every output pixel for db
+    const int Hu = Hi > Ho ? Hi : Ho, Wu = Wi > Wo ? Wi : Wo;
+    const int npix = N * Hu * Wu;
+    float wv[KM][8];
+#pragma unroll
+    for (int j = 0; j < KM; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            wv[j][e] = (j < KT && c0 + e < C) ? w[((long long)(j / NT) * C + c0 + e) * NT + j % NT] : 0.f;
+    float gw[KM][8], gb[KM], sz[8];
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        gb[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gw[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sz[e] = 0.f;
+    if (active) {
+        const int stride = gridDim.x * PY;
+        for (int pix0 = blockIdx.x * PY + ty; pix0 < npix; pix0 += 2 * stride) {
+            float av[2][8], g[2][KM], gc[2][KM];
+            bool in_ok[2];
+            long long ioff[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pix = pix0 + u * stride;
+                const bool ok = pix < npix;
+                const int pc = ok ? pix : pix0;
+                const int n = pc / (Hu * Wu), r = pc - n * (Hu * Wu), h = r / Wu, x = r - h * Wu;
+                in_ok[u] = ok && h < Hi && x < Wi;
+                ioff[u] = ((long long)(n * Hi + (h < Hi ? h : 0)) * Wi + (x < Wi ? x : 0));
+                load8(a + ioff[u] * ld_a + c0, av[u]);
+#pragma unroll
+                for (int j = 0; j < KM; ++j) {
+                    float gv = 0.f;
+                    if (j < KT && in_ok[u]) {
+                        const int k = j / NT, t = j - k * NT;
+                        const int ho = h + pad - t / kw, wo = x + pad - t % kw;
+                        if ((unsigned)ho < (unsigned)Ho && (unsigned)wo < (unsigned)Wo)
+                            gv = dl[((long long)(n * K + k) * Ho + ho) * Wo + wo];
+                    }
+                    g[u][j] = gv;
+                    // the class's own gradient at output pixel (h, x): the bias gradient (class k rides in row k of the registers)
+                    gc[u][j] = (j < K && ok && h < Ho && x < Wo) ? dl[((long long)(n * K + j) * Ho + h) * Wo + x] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < KM; ++j) gb[j] += gc[u][j];
+                if (!in_ok[u]) continue;
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < KM; ++j)
+                    if (j < KT) {
+                        const float gj = g[u][j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            d[e] = fmaf(gj, wv[j][e], d[e]);
+                            gw[j][e] = fmaf(gj, av[u][e], gw[j][e]);
+                        }
+                    }
+                if (act >= 0) {
+                    const float neg = act == SEGNB_ACT_RELU ? 0.f : (act == SEGNB_ACT_LEAKY ? slope : 1.f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gr = round_as(d[e], da);
+                        d[e] = round_as(av[u][e] > 0.f ? gr : gr * neg, da);
+                        sz[e] += d[e];
+                    }
+                }
+                if (da != nullptr) store8(da + ioff[u] * ld_da + c0, d);
+            }
+        }
+    }
+    // ---- reproducible reduction of dw / db: as head_bwd_kernel (per-block partial sums, summed in block order by the finish kernel)
+    float* sg = sred;                                   // [PY][CT][8] floats = 8 KB
+    float* prow = part + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * (KT * (CT * 8 + 1));
+#pragma unroll
+    for (int j = 0; j < KM; ++j)
+        if (j < KT) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sg[(ty * CT + tx) * 8 + e] = gw[j][e];
+            __syncthreads();
+            if (threadIdx.x < CT * 8) {
+                float sum = 0.f;
+                for (int q = 0; q < PY; ++q) sum += sg[q * CT * 8 + threadIdx.x];
+                prow[j * (CT * 8 + 1) + threadIdx.x] = sum;
+            }
+            __syncthreads();
+            // bias of class j (j < K): accumulated in register row j, published in the class's position-0 row j * NT
+            if (tx == 0) sg[ty] = gb[j];
+            __syncthreads();
+            if (threadIdx.x == 0 && j < K) {
+                float sum = 0.f;
+                for (int q = 0; q < PY; ++q) sum += sg[q];
+                prow[(j * NT) * (CT * 8 + 1) + CT * 8] = sum;
+            }
+        }
+    if (act >= 0 && sums != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sg[(ty * CT + tx) * 8 + e] = sz[e];
+        __syncthreads();
+        if (threadIdx.x < CT * 8) {
+            double sum = 0.0;
+            for (int q = 0; q < PY; ++q) sum += (double)sg[q * CT * 8 + threadIdx.x];
+            const int c = blockIdx.y * CT * 8 + threadIdx.x;
+            if (c < Cp) atomicAdd(&sums[(long long)((blockIdx.x % SEGNB_STAT_REPLICAS) * 2) * Cp + c], sum);
+        }
+    }
+}
+
 // dw[k][c] += sum over the pixel blocks (fixed order) of their partial sums; db[k] likewise (channel-chunk row 0).
 // One 256-thread block per output element: lanes stride the blocks (up to 2048 rows: 8 dependent loads per lane instead of 32),
 // a fixed shuffle tree per wave, the four waves' sums added in wave order.
+// T > 1 (head_conv_bwd_kernel): the K rows of a block are K / T classes x T window positions, row j = class j / T, position
+// j % T, and dw is the parameter's own layout [class][C][T]; db is taken from the rows of position 0
 __global__ __launch_bounds__(256) void head_bwd_finish_kernel(const float* __restrict__ part, int gx, int gy, int K, int C,
-                                                              int CT, float* __restrict__ dw, float* __restrict__ db) {
+                                                              int CT, float* __restrict__ dw, float* __restrict__ db, int T) {
     __shared__ float sw4[4];
     const int o = blockIdx.x;                           // 0 .. K*C-1: weights, K*C .. K*C+K-1: biases
     const int t = threadIdx.x;
     const int row = K * (CT * 8 + 1);
     int k, by, idx;
+    int c = 0;
     if (o < K * C) {
         k = o / C;
-        const int c = o - k * C;
+        c = o - k * C;
         by = c / (CT * 8);
         idx = c - by * (CT * 8);
     } else {
-        k = o - K * C;
+        k = (o - K * C) * T;       // (class o - K C: its position-0 row)
         by = 0;
         idx = CT * 8;
     }
@@ -226,9 +411,9 @@ __global__ __launch_bounds__(256) void head_bwd_finish_kernel(const float* __res
     if (t == 0) {
         const float tot = ((sw4[0] + sw4[1]) + sw4[2]) + sw4[3];
         if (o < K * C) {
-            if (dw != nullptr) dw[o] += tot;
+            if (dw != nullptr) dw[((long long)(k / T) * C + c) * T + k % T] += tot;
         } else if (db != nullptr) {
-            db[k] += tot;
+            db[k / T] += tot;
         }
     }
 }
@@ -595,7 +780,7 @@ float* head_scratch(size_t bytes, hipStream_t stream) {
 // (for segnb_head_bn_bwd, norm_act.hip: the same partial-sum protocol)
 float* segnb_head_scratch(size_t bytes, hipStream_t stream) { return head_scratch(bytes, stream); }
 void segnb_head_bwd_finish(const float* part, int gx, int gy, int K, int C, int CT, float* dw, float* db, hipStream_t stream) {
-    head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, stream>>>(part, gx, gy, K, C, CT, dw, db);
+    head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, stream>>>(part, gx, gy, K, C, CT, dw, db, 1);
 }
 
 extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, int W, int C, int Cp,
@@ -632,7 +817,92 @@ extern "C" int segnb_head_bwd(int dtype, const void* a, int ld_a, int N, int H, 
             (const float*)a, ld_a, npix, (long long)H * W, C, Cp, w, K, dlogits, (float*)da, ld_da, part, ct);
     SEGNB_LAUNCH_CHECK();
     if (dw != nullptr || db != nullptr) {
-        head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, (hipStream_t)stream>>>(part, (int)gx, gy, K, C, ct, dw, db);
+        head_bwd_finish_kernel<<<dim3(K * C + K), dim3(256), 0, (hipStream_t)stream>>>(part, (int)gx, gy, K, C, ct, dw, db, 1);
+        SEGNB_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+
+extern "C" int segnb_head_conv_ok(int C, int K, int kh, int kw) {
+    return (K >= 1 && kh >= 1 && kw >= 1 && K * kh * kw <= MAXK && C >= 1 && C <= 64) ? 1 : 0;
+}
+
+extern "C" int segnb_head_conv_fwd(int dtype, const void* a, int ld_a, int N, int Hi, int Wi, int C, const float* w, int kh, int kw,
+                                   int pad, const float* bias, int K, float* logits, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_conv_fwd, dtype, a, ld_a, N, Hi, Wi, C, w, kh, kw, pad, bias, K, logits, stream);
+    SEGNB_CHECK_ARG(a && w && logits, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_head_conv_ok(C, K, kh, kw), "classes x window positions <= 8 and C <= 64 (segnb_head_conv_ok)");
+    SEGNB_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && pad >= 0 && ld_a % 8 == 0 && ld_a >= ((C + 7) & ~7), "bad shape");
+    const int Ho = Hi + 2 * pad - kh + 1, Wo = Wi + 2 * pad - kw + 1;
+    SEGNB_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
+    const long long npix = (long long)N * Ho * Wo;
+    SEGNB_CHECK_ARG(npix < (1ll << 30) && (long long)N * Hi * Wi < (1ll << 30), "pixel count exceeds the 32-bit index range");
+    int grid = ceil_div(npix, 256);
+    if (grid > 8192) grid = 8192;
+    const int smem = K * kh * kw * ((C + 7) & ~7) * 4;
+    if (dtype == SEGNB_BF16)
+        hipLaunchKernelGGL(head_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)a, ld_a, N, Hi,
+                           Wi, C, w, kh, kw, pad, bias, K, Ho, Wo, logits);
+    else if (dtype == SEGNB_F32)
+        hipLaunchKernelGGL(head_conv_fwd_kernel<float>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const float*)a, ld_a, N, Hi,
+                           Wi, C, w, kh, kw, pad, bias, K, Ho, Wo, logits);
+    else {
+        segnb_set_error("segnb_head_conv_fwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_head_conv_bwd(int dtype, const void* a, int ld_a, int N, int Hi, int Wi, int C, int Cp, const float* w, int kh,
+                                   int kw, int pad, int K, const float* dlogits, int act, float slope, void* da, int ld_da,
+                                   float* dw, float* db, double* sums, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_conv_bwd, dtype, a, ld_a, N, Hi, Wi, C, Cp, w, kh, kw, pad, K, dlogits, act, slope, da, ld_da, dw, db,
+                      sums, stream);
+    SEGNB_CHECK_ARG(a && w && dlogits, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_head_conv_ok(C, K, kh, kw), "classes x window positions <= 8 and C <= 64 (segnb_head_conv_ok)");
+    SEGNB_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && pad >= 0 && Cp % 8 == 0 && Cp >= C && ld_a % 8 == 0 && ld_a >= Cp, "bad shape");
+    SEGNB_CHECK_ARG(da == nullptr || (ld_da % 8 == 0 && ld_da >= Cp), "bad gradient stride");
+    SEGNB_CHECK_ARG(act < 0 || ((act == SEGNB_ACT_NONE || act == SEGNB_ACT_RELU || act == SEGNB_ACT_LEAKY) && da != nullptr),
+                    "act: -1 (plain gradient) or the producing layer's activation, with da");
+    if (dtype != SEGNB_BF16 && dtype != SEGNB_F32) {
+        segnb_set_error("segnb_head_conv_bwd: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+    const int Ho = Hi + 2 * pad - kh + 1, Wo = Wi + 2 * pad - kw + 1;
+    SEGNB_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
+    const int Hu = Hi > Ho ? Hi : Ho, Wu = Wi > Wo ? Wi : Wo;
+    const long long npix = (long long)N * Hu * Wu;
+    SEGNB_CHECK_ARG(npix < (1ll << 30), "pixel count exceeds the 32-bit index range");
+    const int KT = K * kh * kw;
+    const int CPP = Cp / 8;
+    int ct = 1;
+    while (ct < CPP && ct < 32) ct <<= 1;
+    const int gy = ceil_div(CPP, ct);
+    const int py = 256 / ct;
+    long long gx = (npix + py - 1) / py;
+    if (gx > 2048 / gy) gx = 2048 / gy;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    float* part = head_scratch((size_t)gx * gy * KT * (ct * 8 + 1) * sizeof(float), (hipStream_t)stream);
+    if (part == nullptr) return SEGNB_E_BADARG;
+#define SEGNB_HEAD_CONV_BWD(TT, KM_)                                                                                              \
+    head_conv_bwd_kernel<TT, KM_><<<grid, dim3(256), 0, (hipStream_t)stream>>>((const TT*)a, ld_a, N, Hi, Wi, C, Cp, w, kh, kw, pad, K, \
+                                                                              Ho, Wo, dlogits, act, slope, (TT*)da, ld_da, part, sums, ct)
+    if (dtype == SEGNB_BF16) {
+        if (KT == 1) SEGNB_HEAD_CONV_BWD(bf16_t, 1);
+        else if (KT <= 4) SEGNB_HEAD_CONV_BWD(bf16_t, 4);
+        else SEGNB_HEAD_CONV_BWD(bf16_t, MAXK);
+    } else {
+        if (KT == 1) SEGNB_HEAD_CONV_BWD(float, 1);
+        else if (KT <= 4) SEGNB_HEAD_CONV_BWD(float, 4);
+        else SEGNB_HEAD_CONV_BWD(float, MAXK);
+    }
+#undef SEGNB_HEAD_CONV_BWD
+    SEGNB_LAUNCH_CHECK();
+    if (dw != nullptr || db != nullptr) {
+        head_bwd_finish_kernel<<<dim3(KT * C + K), dim3(256), 0, (hipStream_t)stream>>>(part, (int)gx, gy, KT, C, ct, dw, db, kh * kw);
         SEGNB_LAUNCH_CHECK();
     }
     return 0;

@@ -21,7 +21,7 @@ from torch import nn
 from lib.modules.abn import InPlaceABN
 from segnb import _native as nv
 from segnb import convplan as cp
-from segnb.net import HipNet, add, conv_unit, head_from_act, maxpool
+from segnb.net import HipNet, add, conv_unit, head_conv, head_from_act, maxpool
 
 
 def _holder_forward(self, *a, **k):
@@ -147,6 +147,10 @@ class LinkNet34(HipNet):
                        transposed=True, act=nv.ACT_LEAKY, slope=lr1, tag='final.dc1')
         f4 = conv_unit(tape, f2, self.finalconv2.weight, self.finalconv2.bias, seg(32), stride=1, pad=0,
                        act=nv.ACT_LEAKY, slope=lr2, tag='final.c2')
+        # finalconv3 (linknet.py:62: Conv2d(32, num_classes, 2, padding=1)): a classifier with a 2 x 2 window -- on the head kernels
+        # where they serve it (one pass over f4 per direction; its backward also applies finalrelu2's mask), else as a convolution
+        if nv.query('segnb_head_conv_ok', 32, self.num_classes, 2, 2):
+            return head_conv(tape, f4, self.finalconv3.weight, self.finalconv3.bias, 1, dlogits, tag='final.c3')
         f5 = conv_unit(tape, f4, self.finalconv3.weight, self.finalconv3.bias, seg(32), stride=1, pad=1,
                        act=nv.ACT_NONE, tag='final.c3')
         return head_from_act(tape, f5, self.num_classes, dlogits)

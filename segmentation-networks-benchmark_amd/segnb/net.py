@@ -30,7 +30,10 @@ class Act(object):
     consumers: how many operators read this tensor in the forward (Tape.consume); producer: set by conv_unit when the tensor is
     act(BatchNorm(conv)) with nothing else in the way -- (y View, coef, sums, act, slope), what segnb_conv_fprop_bnreduce needs to
     do that layer's BatchNorm-backward reduction in the epilogue of the ONE consumer's data gradient; g_is_dz: that happened
-    (the producer's sums are complete; .g is still the plain gradient, the direct apply form recomputes dz from it)."""
+    (the producer's sums are complete; .g is still the plain gradient, the direct apply form recomputes dz from it).
+    coef None: the tensor is act(conv) WITHOUT BatchNorm (y = the activated tensor itself); a consumer that can apply act' while it
+    writes the gradient (the classifier heads: segnb_head_conv_bwd) then stores dz itself and sums it into `sums` -- g_is_dz then
+    means .g IS dz and the producer's segnb_bn_act_bwd_reduce pass is skipped."""
     __slots__ = ('v', 'g', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
 
     def __init__(self, v, needs_grad=True):
@@ -165,6 +168,8 @@ class Tape(object):
 
     # fuse_reduce = False (class attribute): every BatchNorm-backward reduction as a pass of its own (A/B)
     fuse_reduce = True
+    # fold_head_mask = False: the classifier heads return the plain gradient and the layer before them masks it in its own pass (A/B)
+    fold_head_mask = True
 
     def consume(self, *acts):
         """An operator of the forward reads these tensors (each will receive one gradient contribution from it)."""
@@ -361,6 +366,8 @@ def _data_gradient(tape, conv, x, dy, site):
     xv = x.v
     dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
     pr = x.producer
+    if pr is not None and pr[1] is None:          # (activation without BatchNorm: only the classifier heads fold that mask)
+        pr = None
     if (pr is not None and tape.fuse_reduce and x.consumers == 1 and x.g is None and x.needs_grad
             and conv.dgrad_bnreduce_ok(dy, dx)):
         yv, coef, sums, act, slope = pr
@@ -444,19 +451,27 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         if out_stats is not None:
             _sum_into(tape, ov, out_stats)
         oa = Act(ov)
+        if not has_bn and tape.need_grad:
+            # (sums: zero between steps -- segnb_bias_grad_multi clears what it reads)
+            oa.producer = (ov, None, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
         def backward_fused():
             if oa.g is None:
                 return
             flat = tape.flat
-            dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
             sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
             bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
-            # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before the
-            # weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork)
-            rt.arm_fork()
-            nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
-                    oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+            if oa.g_is_dz:
+                # the one consumer wrote dz = g * act'(a) and summed it (head_conv: segnb_head_conv_bwd)
+                oa.g_is_dz = False
+                dz = oa.g
+            else:
+                dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
+                # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before
+                # the weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork)
+                rt.arm_fork()
+                nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
+                        oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
             tape.defer_bias_grad(sums, C, Cp, gb, float(N * Ho * Wo), coef_buf, bcoef)
             side = rt.fork_side()
@@ -805,10 +820,59 @@ def head_1x1(tape, x, weight, bias, dlogits_ref, tag='head'):
     def backward():
         flat = tape.flat
         da = tape.view(site + '/da', xv.N, xv.H, xv.W, xv.Cp)
-        nv.call('segnb_head_bwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, xv.Cp, nv.ptr(weight.detach()), K,
-                nv.ptr(dlogits_ref[0]), da.ptr, da.ld, nv.ptr(flat.grad_of(weight)), nv.ptr(flat.grad_of(bias)),
-                rt.stream)
+        mask = _head_mask(tape, x, C, K, 1, 1)
+        if mask is not None:
+            sums, act, slope = mask
+            nv.call('segnb_head_conv_bwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, xv.Cp, nv.ptr(weight.detach()), 1, 1, 0, K,
+                    nv.ptr(dlogits_ref[0]), act, slope, da.ptr, da.ld, nv.ptr(flat.grad_of(weight)), nv.ptr(flat.grad_of(bias)),
+                    nv.ptr(sums), rt.stream)
+            x.g_is_dz = True
+        else:
+            nv.call('segnb_head_bwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, xv.Cp, nv.ptr(weight.detach()), K,
+                    nv.ptr(dlogits_ref[0]), da.ptr, da.ld, nv.ptr(flat.grad_of(weight)), nv.ptr(flat.grad_of(bias)),
+                    rt.stream)
         tape.contribute(x, da)
+
+    tape.record(backward)
+    return logits
+
+
+def _head_mask(tape, x, C, K, kh, kw):
+    """(sums, act, slope) when this head is the ONLY consumer of a convolution + activation without BatchNorm (unet16.py:110-111
+    dec1 -> final, linknet.py:58-62 finalrelu2 -> finalconv3) and the head kernels serve the shape: the head's backward then writes
+    that layer's dz and sums it (Act.producer with coef None), instead of a gradient the layer would mask in a pass of its own."""
+    pr = x.producer
+    if (pr is None or pr[1] is not None or not Tape.fold_head_mask or x.consumers != 1 or x.g is not None or not x.needs_grad
+            or not nv.query('segnb_head_conv_ok', C, K, kh, kw)):
+        return None
+    return pr[2], pr[3], pr[4]
+
+
+def head_conv(tape, x, weight, bias, pad, dlogits_ref, tag='headconv'):
+    """A classifier that is a small stride-1 convolution (linknet.py:62: Conv2d(32, num_classes, 2, padding=1)) -> fp32 NCHW logits,
+    on the head kernels (segnb_head_conv_fwd / _bwd; check segnb_head_conv_ok first): the parameter is read and its gradient written
+    in its own layout, no packed copies."""
+    rt, xv = tape.rt, x.v
+    site = tape.site(tag)
+    tape.consume(x)
+    K, C, kh, kw = weight.shape
+    Ho, Wo = xv.H + 2 * pad - kh + 1, xv.W + 2 * pad - kw + 1
+    logits = tape.cached((site, xv.N, xv.H, xv.W), lambda: torch.zeros((xv.N, K, Ho, Wo), dtype=torch.float32, device=rt.device))
+    nv.call('segnb_head_conv_fwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, nv.ptr(weight.detach()), kh, kw, pad,
+            nv.ptr(bias.detach()) if bias is not None else None, K, nv.ptr(logits), rt.stream)
+
+    def backward():
+        flat = tape.flat
+        da = tape.view(site + '/da', xv.N, xv.H, xv.W, xv.Cp) if x.needs_grad else None
+        mask = _head_mask(tape, x, C, K, kh, kw)
+        sums, act, slope = mask if mask is not None else (None, -1, 0.0)
+        nv.call('segnb_head_conv_bwd', rt.code, xv.ptr, xv.ld, xv.N, xv.H, xv.W, C, xv.Cp, nv.ptr(weight.detach()), kh, kw, pad, K,
+                nv.ptr(dlogits_ref[0]), act, slope, vptr(da), vld(da), nv.ptr(flat.grad_of(weight)),
+                nv.ptr(flat.grad_of(bias)) if bias is not None else None, nv.ptr(sums), rt.stream)
+        if mask is not None:
+            x.g_is_dz = True
+        if da is not None:
+            tape.contribute(x, da)
 
     tape.record(backward)
     return logits

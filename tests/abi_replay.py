@@ -88,7 +88,7 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
 # (argument position -> entry points) whose fp64 argument is a [REPL][2][Cp] replicated accumulator: the emulator
 # fills replica 0, the HIP kernels spread blocks over all 16; only the sum over replicas is defined by the ABI
 _REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats', 'segnb_bn_stats_ld'), 19: ('segnb_bn_act_bwd_reduce',),
-               17: ('segnb_head_bn_bwd',), 13: ('segnb_bn_act_fwd_stats',), 0: ()}
+               17: ('segnb_head_bn_bwd',), 13: ('segnb_bn_act_fwd_stats',), 20: ('segnb_head_conv_bwd',), 0: ()}
 
 
 def run_step(model, x, y, loss_fn, device, dtype):
@@ -164,6 +164,9 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
                 # channel sums that are analytically zero hold pure cancellation noise on both sides: floor at
                 # 1e-6 of sum|dz| (dz = argument 17 of the same call)
                 dz = [r for q, (k, r) in rpost if q == 17 and k == 'full']
+                atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
+            if name == 'segnb_head_conv_bwd' and p == 20:       # (the same floor; dz = argument 16)
+                dz = [r for q, (k, r) in rpost if q == 16 and k == 'full']
                 atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
             nslab = (rec.forced[idx][3][5], args[5]) if name == 'segnb_conv_wgrad' else (1, 1)
             if name == 'segnb_conv_wgrad_tf':

@@ -535,6 +535,72 @@ def test_head_fwd_bwd(shape, dtype):
     check('dw vs torch', dwg, wr.grad, 'f32')
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('act', [-1, nv.ACT_RELU, nv.ACT_LEAKY])
+@pytest.mark.parametrize('shape', [(2, 21, 19, 32, 1, 2, 2, 1),      # linknet.py:62 finalconv3: Conv2d(32, 1, 2, padding=1)
+                                   (2, 16, 24, 32, 1, 1, 1, 0),      # unet16.py:111 final: 1 x 1
+                                   (1, 9, 13, 20, 2, 2, 2, 1), (1, 11, 10, 64, 8, 1, 1, 0), (2, 8, 9, 16, 2, 1, 3, 1),
+                                   (1, 12, 12, 24, 1, 2, 2, 0)])
+def test_head_conv_fwd_bwd(shape, act, dtype):
+    """The classifier-as-a-small-convolution kernels against torch (forward, da, dw, db) and against the emulator; with act the
+    backward also applies the producing layer's activation mask and sums dz (that layer's bias gradient)."""
+    N, H, W, C, K, kh, kw, pad = shape
+    Cp = cp.pad8(C)
+    assert nv.query('segnb_head_conv_ok', C, K, kh, kw)
+    gen = torch.Generator().manual_seed(C + kh)
+    a = torch.randn(N, H, W, C, generator=gen)
+    w = torch.randn(K, C, kh, kw, generator=gen) * 0.2
+    b = torch.randn(K, generator=gen)
+    Ho, Wo = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
+    dl = torch.randn(N, K, Ho, Wo, generator=gen)
+    if dtype == 'bf16':
+        a = a.bfloat16().float()
+    slope = 0.01
+
+    def run(device):
+        rt = Runtime(device, dtype)
+        av = View.alloc(rt, N, H, W, Cp)
+        av.dense()[..., :C] = a.to(rt.device, rt.tdtype)
+        wd, bd, dld = w.to(rt.device), b.to(rt.device), dl.to(rt.device)
+        logits = torch.zeros(N, K, Ho, Wo, device=rt.device)
+        nv.call('segnb_head_conv_fwd', rt.code, av.ptr, av.ld, N, H, W, C, nv.ptr(wd), kh, kw, pad, nv.ptr(bd), K, nv.ptr(logits),
+                rt.stream)
+        da = View.alloc(rt, N, H, W, Cp)
+        da.dense().fill_(7.0)
+        dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+        sums = torch.zeros(16, 2, Cp, dtype=torch.float64, device=rt.device)
+        nv.call('segnb_head_conv_bwd', rt.code, av.ptr, av.ld, N, H, W, C, Cp, nv.ptr(wd), kh, kw, pad, K, nv.ptr(dld), act, slope,
+                da.ptr, da.ld, nv.ptr(dw), nv.ptr(db), nv.ptr(sums) if act >= 0 else None, rt.stream)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        return logits.cpu(), da.dense().float().cpu(), dw.cpu(), db.cpu(), sums.sum(0).cpu()
+
+    lg, dag, dwg, dbg, sg = run('cuda')
+    with on_emulator():
+        le, dae, dwe, dbe, se = run('cpu')
+    check('logits', lg, le, 'f32')
+    check('da', dag, dae, dtype)
+    check('dw', dwg, dwe, 'f32')
+    check('db', dbg, dbe, 'f32')
+    ar = a.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    out = F.conv2d(ar, wr, br, padding=pad)
+    out.backward(dl)
+    check('logits vs torch', lg, out, 'f32')
+    g = ar.grad.permute(0, 2, 3, 1)
+    if act >= 0:
+        g = torch.where(a > 0, g, g * (0.0 if act == nv.ACT_RELU else slope))
+    check('da vs torch', dag[..., :C], g, dtype)
+    assert float(dag[..., C:].abs().max()) == 0.0 if Cp > C else True
+    check('dw vs torch', dwg, wr.grad, 'f32')
+    check('db vs torch', dbg, br.grad, 'f32')
+    if act >= 0:
+        # the sums are those of the STORED dz values
+        check('sums', sg[0].float(), dag.double().reshape(-1, Cp).sum(0).float(), 'f32', scale=float(dag.abs().sum(dim=(0, 1, 2)).max()))
+        assert float(sg[1].abs().max()) == 0.0
+
+
 LOSS_NAMES = ['bce', 'jaccard', 'smooth_jaccard', 'dice', 'bce_jaccard', 'bce_dice', 'focal']
 
 
