@@ -404,6 +404,12 @@ typedef struct {
     float slope;
 } segnb_bn_reduce_epilogue;
 int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
+/* coef == NULL: the producing layer is a convolution + activation WITHOUT BatchNorm (linknet.py:58-61 finaldeconv1 -> finalrelu1 ->
+ * finalconv2, unet16.py:12-21) and y is its ACTIVATED output: the launch then stores out = dz = round(round(g) * act'(y)) (act' from
+ * the sign of the activated value) and sums[r][0][c] += sum dz -- that layer's segnb_bn_act_bwd_reduce pass (y, coef NULL, dz) folded
+ * into the data gradient that produces g.  _actmask_ok: 1 when a fused kernel serves the geometry (32 -> <= 32 channels, stride-1
+ * 3 x 3 window with any padding, width >= 32: conv_roll_kernel). */
+int segnb_conv_fprop_actmask_ok(const segnb_conv_geom* g, int dtype);
 
 /* CONSUMER-SIDE BatchNorm: a convolution (or weight-gradient) operand that is NOT in memory -- it is recomputed from what the
  * producing layer left there while the kernel stages its input rows (conv_roll_kernel, fprop_roll.hip):

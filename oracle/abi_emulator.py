@@ -273,11 +273,19 @@ class AbiEmulator(object):
             return 0
         return int(g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and not (g.Co > 32 and g.Ci > 32))
 
+    def segnb_conv_fprop_actmask_ok(self, g, dtype):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
+                   and g.Ci == 32 and g.Co <= 32 and g.Co % 8 == 0 and g.Wo >= 32)
+
     def segnb_conv_fprop_bnreduce(self, g, dtype, in_p, wp, out_p, ep, stream):
         gg, e = _geom(g), _geom(ep)
         rc = self.segnb_conv_fprop(g, dtype, in_p, wp, None, 0, out_p, None, stream)
         if rc:
             return rc
+        if not e.coef:          # activation mask of a layer without BatchNorm: out becomes dz
+            return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, None, e.act, e.slope, None,
+                                                out_p, gg.ld_out, None, 0, None, 0, out_p, gg.ld_out, e.sums, None, 0, stream)
         return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, e.coef, e.act, e.slope, None,
                                             out_p, gg.ld_out, None, 0, None, 0, None, 0, e.sums, None, 0, stream)
 

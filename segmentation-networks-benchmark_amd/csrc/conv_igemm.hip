@@ -158,8 +158,6 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     const int gq = L / a.NTL;
     const int n_base = nt * BN;
 
-    const T* __restrict__ inT = reinterpret_cast<const T*>(a.in);
-    const T* __restrict__ wT = reinterpret_cast<const T*>(a.w);
     T* __restrict__ outT = reinterpret_cast<T*>(a.out);
 
     if (tid < g.ntaps) sTap[tid] = make_int2(g.dh[tid], g.dw[tid]);
@@ -1751,13 +1749,24 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
                                          void* out, const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_fprop_bnreduce, g, dtype, in, wpacked, out, ep, stream);
     if (int rc = check_geom(g)) return rc;
-    SEGNB_CHECK_ARG(in && wpacked && out && ep && ep->y && ep->coef && ep->sums, "NULL argument");
-    SEGNB_CHECK_ARG(segnb_conv_fprop_bnreduce_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_bnreduce_ok)");
+    SEGNB_CHECK_ARG(in && wpacked && out && ep && ep->y && ep->sums, "NULL argument");
     SEGNB_CHECK_ARG(ep->ld_y >= g->Co && ep->ld_y % 8 == 0, "bad y stride");
     const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
     const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
     SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
     int rc = 0;
+    if (ep->coef == nullptr) {
+        // activation mask of a producing layer without BatchNorm: out = dz (conv_roll_kernel, EPI = 3)
+        SEGNB_CHECK_ARG(segnb_conv_fprop_actmask_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_actmask_ok)");
+        rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+        if (rc != 1) {
+            segnb_set_error("segnb_conv_fprop_bnreduce: the fused kernel refused the launch (%d)", rc);
+            return rc > 1 ? rc : SEGNB_E_BADARG;
+        }
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    SEGNB_CHECK_ARG(segnb_conv_fprop_bnreduce_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_bnreduce_ok)");
     if (bnreduce_general(g)) {
         SEGNB_CHECK_ARG(ep->ld_y % 8 == 0 && (((long long)g->N * g->Ho * g->Wo - 1) * ep->ld_y + g->Co) * 2 < (1ll << 31), "bad y");
         return conv_fprop_impl(g, dtype, in, wpacked, nullptr, 0, out, nullptr, stream, nullptr, ep);

@@ -98,18 +98,20 @@ __device__ __forceinline__ unsigned relu_pk2bf(unsigned pk) {
 
 // KS: 32-channel K steps of the input (Ci = 32 * KS); COF: 16-channel output fragments (Co <= 16 * COF, COF even);
 // NF: 16-pixel fragments per strip row; EPI: 0 plain, 1 BatchNorm statistics of the output, 2 BatchNorm-backward reduction
-// of the producing layer; TF: input transform (RollArgs); DL: rows of global loads in flight per wave (register sets);
+// of the producing layer, 3 the activation mask of a producing layer WITHOUT BatchNorm (bn_coef NULL: bn_y is the activated
+// tensor, the row is stored as dz = round(g * act'(y)) after the y row has landed -- behind the step's MFMAs instead of before
+// them -- and sum dz is accumulated); TF: input transform (RollArgs); DL: rows of global loads in flight per wave (register sets);
 // WPS: waves per SIMD the register allocation is held to (2: <= 256 registers, 1: <= 512)
 // KSP / CSP: waves per strip that split the INPUT channels (32 each; partial sums reduced through LDS, the epilogue of output row o
 // done by wave o % KSP) / the OUTPUT channels (16 * COF each, independent).  With a split a block is ONE strip (KSP * CSP waves)
 template <int KS, int COF, int NF, int EPI, int TF, int DL, int WPS, int KSP = 1, int CSP = 1>
 __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void conv_roll_kernel(const RollArgs a) {
     constexpr int WST = KSP * CSP, NWB = WST == 1 ? 4 : WST, SPB = NWB / WST, NTHR = NWB * 64;
-    static_assert(WST == 1 || (KS == 1 && TF == 0 && EPI != 2), "split strips: 32 input channels per wave, plain operands");
+    static_assert(WST == 1 || (KS == 1 && TF == 0 && EPI < 2), "split strips: 32 input channels per wave, plain operands");
     constexpr int CI = 32 * KS, CPP = CI / 8, PXB = CI * 2, RW = 16 * NF + 2, ROWB = RW * PXB;
     constexpr int NLD = (RW * CPP + 63) / 64;
     constexpr int NP = COF / 2;                      // 32-channel output pairs
-    constexpr bool STATS = EPI == 1, BNRED = EPI == 2;
+    constexpr bool STATS = EPI == 1, BNRED = EPI == 2 || EPI == 3, MASKST = EPI == 3;
     constexpr int UN = DL % 3 == 0 ? DL : 3 * DL;    // unroll: ring slot (i % 3) and register set (i % DL) both static
     static_assert(COF % 2 == 0, "output fragments are stored in pairs");
     static_assert(TF == 0 || 64 % CPP == 0, "a lane's channel chunk must not depend on the load instruction");
@@ -171,8 +173,13 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
     if constexpr (BNRED) {
         for (int c = threadIdx.x; c < 16 * COF; c += NTHR) {
             const bool in = c < a.Co;
-            bnc[0][c] = in ? a.bn_coef[c] : 0.f;
-            bnc[1][c] = in ? a.bn_coef[a.Co + c] - a.bn_coef[2 * a.Co + c] * a.bn_coef[c] : 0.f;
+            if constexpr (MASKST) {                    // z = y: the activated value carries the sign
+                bnc[0][c] = 1.f;
+                bnc[1][c] = 0.f;
+            } else {
+                bnc[0][c] = in ? a.bn_coef[c] : 0.f;
+                bnc[1][c] = in ? a.bn_coef[a.Co + c] - a.bn_coef[2 * a.Co + c] * a.bn_coef[c] : 0.f;
+            }
         }
         bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
     }
@@ -420,7 +427,7 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
                         const int ch = co0 + p * 32 + cidx * 8;
                         const bool ok = col < a.W && ch < a.Co;
                         const unsigned voff = ok ? ((prow + (unsigned)col) * (unsigned)a.ld_out + (unsigned)ch) * 2u : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)voff, 0, 0);
+                        if constexpr (!MASKST) __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (int)voff, 0, 0);
                     }
                 }
             }
@@ -499,6 +506,25 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
                             // dz = round(g * act'(z)), z = (y - mean) * scale + shift: the arithmetic of bn_act_bwd_reduce_kernel
                             float yq[8], bsc[8], bsh[8];
                             unpack8(yv[U1][f][p], yq);
+                            if constexpr (MASKST) {
+                                // the row leaves HERE, masked: dz = round(g * act'(y)), y the activated tensor itself
+                                unsigned pk[4];
+#pragma unroll
+                                for (int e = 0; e < 8; e += 2) {
+                                    const float d0 = v[e] * (yq[e] > 0.f ? 1.f : bneg), d1 = v[e + 1] * (yq[e + 1] > 0.f ? 1.f : bneg);
+                                    pk[e >> 1] = pack2bf(d0, d1);
+                                    s1[p][e] += __uint_as_float(pk[e >> 1] << 16) * m;
+                                    s1[p][e + 1] += __uint_as_float(pk[e >> 1] & 0xffff0000u) * m;
+                                }
+                                u32x4_t dzv;
+                                dzv.x = pk[0]; dzv.y = pk[1]; dzv.z = pk[2]; dzv.w = pk[3];
+                                const int col = c0 + 16 * f + n16, ch = co0 + p * 32 + cidx * 8;
+                                const bool ok = col < a.W && ch < a.Co;
+                                const unsigned voff =
+                                    ok ? (((unsigned)((n * a.H + r0 - 1 + o) * a.W) + (unsigned)col) * (unsigned)a.ld_out + (unsigned)ch) * 2u : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b128(dzv, rs_o, (int)voff, 0, 0);
+                                continue;
+                            }
                             lds_const8(bnc[0], p * 32 + cidx * 8, bsc);
                             lds_const8(bnc[1], p * 32 + cidx * 8, bsh);
 #pragma unroll
@@ -526,7 +552,9 @@ __global__ __launch_bounds__((KSP * CSP == 1 ? 4 : KSP * CSP) * 64, WPS) void co
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 double v1 = (double)s1[p][e], v2 = (double)s2[p][e];
-                if constexpr (BNRED) {
+                if constexpr (MASKST) {
+                    v2 = 0.0;
+                } else if constexpr (BNRED) {
                     const int c = p * 32 + cidx * 8 + e;
                     const double mu = c < a.Co ? (double)a.bn_coef[2 * a.Co + c] : 0.0;
                     const double is = c < a.Co ? (double)a.bn_coef[3 * a.Co + c] : 0.0;
@@ -571,7 +599,12 @@ int launch_roll(RollArgs& a, hipStream_t stream) {
     if (blocks > maxb) blocks = maxb;
     if (a.stats != nullptr)
         hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 1, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
-    else if (a.bn_y != nullptr)
+    else if (a.bn_y != nullptr && a.bn_coef == nullptr) {
+        if constexpr (TF == 0 && NF == 1)
+            hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 3, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
+        else
+            return -1;
+    } else if (a.bn_y != nullptr)
         hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 2, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((conv_roll_kernel<KS, COF, NF, 0, TF, DL, WPS>), dim3(blocks), dim3(256), 0, stream, a);
@@ -623,7 +656,9 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     // same-size (padding 1) everywhere; another padding (the valid 3 x 3 convolution of lib/models/linknet.py:60 and its data
     // gradient: input and output grids differ) only for the plain one-wave form
     const bool same = g->Hi == g->Ho && g->Wi == g->Wo && dhmin == -1 && dwmin == -1;
-    if (!same && (bn != nullptr || tf != nullptr || uc != nullptr || g->Ci != 32 || g->Co > 32)) return 0;
+    // (the epilogues address y by OUTPUT pixel: they do not care about the input grid)
+    if (!same && (tf != nullptr || uc != nullptr || g->Ci != 32 || g->Co > 32)) return 0;
+    if (bn != nullptr && bn->coef == nullptr && (tf != nullptr || g->Ci != 32 || g->Co > 32)) return 0;      // (activation mask: plain form)
     // 32 -> <= 32: one wave per strip.  Wider inputs (64, 96 -> <= 32: the waves of a strip split K) and wider outputs
     // (32 -> 64, 96: they split the output channels) when nothing else rides on the launch
     // Measured (MI355X, bs=32, profiles/r04_ab.txt): two-way splits pay -- 32 -> 64 @ 112 x 112 38.2 -> 28.5 us, 64 -> 32 32.2 -> 28.3
@@ -712,6 +747,31 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
     // BatchNorm-reduce epilogue's per-channel constants do not fit beside them
     rc = (knob == 2 && bn == nullptr) ? launch_roll<1, 2, 2, 0, 3, 2>(a, stream) : launch_roll<1, 2, 1, 0, 3, 2>(a, stream);
     return rc ? rc : 1;
+}
+
+// include/segnb_hip.h: segnb_conv_fprop_bnreduce with coef == NULL (the plain one-wave form of segnb_fprop_roll_try, any padding)
+extern "C" int segnb_conv_fprop_actmask_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || !segnb_knob_fprop_roll() || !segnb_knob_bnreduce_fused() ||
+        getenv("SEGNB_FPROP_GENERAL") != nullptr)
+        return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 32 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32) return 0;
+    if (g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return 0;
+    int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 1; t < 9; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dhmax = g->dh[t] > dhmax ? g->dh[t] : dhmax;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+        dwmax = g->dw[t] > dwmax ? g->dw[t] : dwmax;
+    }
+    if (dhmax - dhmin != 2 || dwmax - dwmin != 2) return 0;
+    for (int t = 0; t < 9; ++t) {
+        const int k = (g->dh[t] - dhmin) * 3 + (g->dw[t] - dwmin);
+        if (seen[k]) return 0;
+        seen[k] = true;
+    }
+    return (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2 < (1ll << 31) ? 1 : 0;
 }
 
 static bool roll_tf_geom_ok(const segnb_conv_geom* g, int dtype) {

@@ -210,42 +210,63 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
 //             BatchNorm in between: act' has the sign of the activated value) and the per-channel sums of dz go to `sums`
 //             (that layer's bias gradient) -- its segnb_bn_act_bwd_reduce pass folded into this one
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NTM>
 __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const T* __restrict__ a, int ld_a, int N, int Hi, int Wi, int C,
                                                             const float* __restrict__ w, int kh, int kw, int pad,
                                                             const float* __restrict__ bias, int K, int Ho, int Wo,
-                                                            float* __restrict__ logits) {
+                                                            float* __restrict__ logits, int CT) {
+    // CT consecutive lanes hold the 8-channel chunks of ONE pixel (a wave reads whole pixels, contiguous: with one thread per
+    // pixel every load instruction touched 64 pixels' lines, and the window multiplies the L1 traffic by its size); all window
+    // positions' loads go out before the first use; the lanes' partial dot products meet in a shuffle tree.
+    // NTM = compile-time bound of the window size.
     extern __shared__ float swc[];  // [K][T][C8]
-    const int C8 = (C + 7) & ~7, NT = kh * kw;
+    const int CPP = (C + 7) >> 3, C8 = CPP * 8, NT = kh * kw;
     for (int i = threadIdx.x; i < K * NT * C8; i += blockDim.x) {
         const int k = i / (NT * C8), r = i - k * (NT * C8), t = r / C8, c = r - t * C8;
         swc[i] = c < C ? w[((long long)k * C + c) * NT + t] : 0.f;
     }
     __syncthreads();
-    const long long hw = (long long)Ho * Wo, npix = (long long)N * hw;
-    for (long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x; pix < npix; pix += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(pix / hw), r = (int)(pix - n * hw), ho = r / Wo, wo = r - ho * Wo;
+    const int PY = 256 / CT;
+    const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const bool lane_ok = tx < CPP;
+    const int hw = Ho * Wo, npix = N * hw;
+    for (int pix = blockIdx.x * PY + ty; pix < npix; pix += gridDim.x * PY) {
+        const int n = pix / hw, r = pix - n * hw, ho = r / Wo, wo = r - ho * Wo;
+        float v[NTM][8];
+        bool ok[NTM];
+#pragma unroll
+        for (int t = 0; t < NTM; ++t) {
+            const int hi = ho - pad + t / kw, wi = wo - pad + t % kw;
+            ok[t] = t < NT && lane_ok && (unsigned)hi < (unsigned)Hi && (unsigned)wi < (unsigned)Wi;
+            const long long off = ok[t] ? ((long long)(n * Hi + hi) * Wi + wi) * ld_a + tx * 8 : 0;
+            load8(a + off, v[t]);
+        }
         float acc[MAXK];
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
-        for (int t = 0; t < NT; ++t) {
-            const int hi = ho - pad + t / kw, wi = wo - pad + t % kw;
-            if ((unsigned)hi >= (unsigned)Hi || (unsigned)wi >= (unsigned)Wi) continue;
-            const T* src = a + ((long long)(n * Hi + hi) * Wi + wi) * ld_a;
-            for (int c0 = 0; c0 < C8; c0 += 8) {
-                float v[8];
-                load8(src + c0, v);
 #pragma unroll
-                for (int k = 0; k < MAXK; ++k)
-                    if (k < K) {
+        for (int t = 0; t < NTM; ++t) {
+            if (!ok[t]) continue;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[k] = fmaf(v[e], swc[(k * NT + t) * C8 + c0 + e], acc[k]);
-                    }
-            }
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(swc + (k * NT + t) * C8 + tx * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(swc + (k * NT + t) * C8 + tx * 8 + 4);
+                    acc[k] = fmaf(v[t][0], w0.x, acc[k]); acc[k] = fmaf(v[t][1], w0.y, acc[k]);
+                    acc[k] = fmaf(v[t][2], w0.z, acc[k]); acc[k] = fmaf(v[t][3], w0.w, acc[k]);
+                    acc[k] = fmaf(v[t][4], w1.x, acc[k]); acc[k] = fmaf(v[t][5], w1.y, acc[k]);
+                    acc[k] = fmaf(v[t][6], w1.z, acc[k]); acc[k] = fmaf(v[t][7], w1.w, acc[k]);
+                }
         }
 #pragma unroll
         for (int k = 0; k < MAXK; ++k)
-            if (k < K) logits[((long long)n * K + k) * hw + r] = acc[k] + (bias != nullptr ? bias[k] : 0.f);
+            if (k < K)
+                for (int off = 1; off < CT; off <<= 1) acc[k] += __shfl_xor(acc[k], off);
+        if (tx == 0) {
+#pragma unroll
+            for (int k = 0; k < MAXK; ++k)
+                if (k < K) logits[((long long)n * K + k) * hw + r] = acc[k] + (bias != nullptr ? bias[k] : 0.f);
+        }
     }
 }
 
@@ -265,12 +286,20 @@ __global__ __launch_bounds__(256) void head_conv_bwd_kernel(const T* __restrict_
     // the pixel walk covers the union of the input and the output grid: every input pixel for da / dw, every output pixel for db
     const int Hu = Hi > Ho ? Hi : Ho, Wu = Wi > Wo ? Wi : Wo;
     const int npix = N * Hu * Wu;
-    float wv[KM][8];
+    // weights of the virtual classes: registers for one class (the 1 x 1 binary head), LDS beyond (32 registers per 4 classes
+    // cost the streaming pass its third wave per SIMD)
+    __shared__ float swv[KM > 1 ? KM * 64 : 1];
+    float wv1[8];
+    if constexpr (KM > 1) {
+        for (int i = threadIdx.x; i < KM * 64; i += 256) {
+            const int j = i >> 6, c = blockIdx.y * CT * 8 + (i & 63);
+            swv[i] = (j < KT && (i & 63) < CT * 8 && c < C) ? w[((long long)(j / NT) * C + c) * NT + j % NT] : 0.f;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int j = 0; j < KM; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            wv[j][e] = (j < KT && c0 + e < C) ? w[((long long)(j / NT) * C + c0 + e) * NT + j % NT] : 0.f;
+        for (int e = 0; e < 8; ++e) wv1[e] = (c0 + e < C) ? w[(long long)(c0 + e) * NT] : 0.f;
+    }
     float gw[KM][8], gb[KM], sz[8];
 #pragma unroll
     for (int j = 0; j < KM; ++j) {
@@ -281,13 +310,16 @@ __global__ __launch_bounds__(256) void head_conv_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) sz[e] = 0.f;
     if (active) {
+        // PPT pixels per trip, all their loads out before the first use (as head_bwd_kernel: one dependent load chain per wave in
+        // flight streams at 2 TB/s)
+        constexpr int PPT = KM <= 4 ? 4 : 2;
         const int stride = gridDim.x * PY;
-        for (int pix0 = blockIdx.x * PY + ty; pix0 < npix; pix0 += 2 * stride) {
-            float av[2][8], g[2][KM], gc[2][KM];
-            bool in_ok[2];
-            long long ioff[2];
+        for (int pix0 = blockIdx.x * PY + ty; pix0 < npix; pix0 += PPT * stride) {
+            float av[PPT][8], g[PPT][KM], gc[PPT][KM];
+            bool in_ok[PPT];
+            long long ioff[PPT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PPT; ++u) {
                 const int pix = pix0 + u * stride;
                 const bool ok = pix < npix;
                 const int pc = ok ? pix : pix0;
@@ -310,7 +342,7 @@ __global__ __launch_bounds__(256) void head_conv_bwd_kernel(const T* __restrict_
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < PPT; ++u) {
 #pragma unroll
                 for (int j = 0; j < KM; ++j) gb[j] += gc[u][j];
                 if (!in_ok[u]) continue;
@@ -321,9 +353,19 @@ __global__ __launch_bounds__(256) void head_conv_bwd_kernel(const T* __restrict_
                 for (int j = 0; j < KM; ++j)
                     if (j < KT) {
                         const float gj = g[u][j];
+                        float wj[8];
+                        if constexpr (KM > 1) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(swv + j * 64 + tx * 8);
+                            const float4 w1 = *reinterpret_cast<const float4*>(swv + j * 64 + tx * 8 + 4);
+                            wj[0] = w0.x; wj[1] = w0.y; wj[2] = w0.z; wj[3] = w0.w;
+                            wj[4] = w1.x; wj[5] = w1.y; wj[6] = w1.z; wj[7] = w1.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) wj[e] = wv1[e];
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            d[e] = fmaf(gj, wv[j][e], d[e]);
+                            d[e] = fmaf(gj, wj[e], d[e]);
                             gw[j][e] = fmaf(gj, av[u][e], gw[j][e]);
                         }
                     }
@@ -838,19 +880,31 @@ extern "C" int segnb_head_conv_fwd(int dtype, const void* a, int ld_a, int N, in
     SEGNB_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
     const long long npix = (long long)N * Ho * Wo;
     SEGNB_CHECK_ARG(npix < (1ll << 30) && (long long)N * Hi * Wi < (1ll << 30), "pixel count exceeds the 32-bit index range");
-    int grid = ceil_div(npix, 256);
-    if (grid > 8192) grid = 8192;
-    const int smem = K * kh * kw * ((C + 7) & ~7) * 4;
-    if (dtype == SEGNB_BF16)
-        hipLaunchKernelGGL(head_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)a, ld_a, N, Hi,
-                           Wi, C, w, kh, kw, pad, bias, K, Ho, Wo, logits);
-    else if (dtype == SEGNB_F32)
-        hipLaunchKernelGGL(head_conv_fwd_kernel<float>, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const float*)a, ld_a, N, Hi,
-                           Wi, C, w, kh, kw, pad, bias, K, Ho, Wo, logits);
-    else {
+    const int cpp = (C + 7) / 8;
+    int ct = 1;
+    while (ct < cpp) ct <<= 1;
+    const int py = 256 / ct;
+    long long gx = (npix + py - 1) / py;
+    if (gx > 16384) gx = 16384;
+    const int grid = (int)gx;
+    const int smem = K * kh * kw * cpp * 8 * 4;
+    const int nt = kh * kw;
+#define SEGNB_HEAD_CONV_FWD(TT, NTM_)                                                                                         \
+    hipLaunchKernelGGL((head_conv_fwd_kernel<TT, NTM_>), dim3(grid), dim3(256), smem, (hipStream_t)stream, (const TT*)a, ld_a, N, Hi, \
+                       Wi, C, w, kh, kw, pad, bias, K, Ho, Wo, logits, ct)
+    if (dtype == SEGNB_BF16) {
+        if (nt == 1) SEGNB_HEAD_CONV_FWD(bf16_t, 1);
+        else if (nt <= 4) SEGNB_HEAD_CONV_FWD(bf16_t, 4);
+        else SEGNB_HEAD_CONV_FWD(bf16_t, MAXK);
+    } else if (dtype == SEGNB_F32) {
+        if (nt == 1) SEGNB_HEAD_CONV_FWD(float, 1);
+        else if (nt <= 4) SEGNB_HEAD_CONV_FWD(float, 4);
+        else SEGNB_HEAD_CONV_FWD(float, MAXK);
+    } else {
         segnb_set_error("segnb_head_conv_fwd: unknown dtype %d", dtype);
         return SEGNB_E_BADARG;
     }
+#undef SEGNB_HEAD_CONV_FWD
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

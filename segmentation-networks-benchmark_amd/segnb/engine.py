@@ -445,13 +445,14 @@ class ConvOp(object):
             rt.clear_view(yv)
         b = self.bias.detach() if self.bias is not None else None
         if epilogue is not None:
-            assert stats is None and p['fwd_full'] and len(p['fwd']) == 1, 'one full-coverage launch, no statistics'
-            l = p['fwd'][0]
-            g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+            # (the phase launches of a transposed convolution write disjoint output parities: each applies the epilogue to its own)
+            assert stats is None and p['fwd_full'], 'full coverage, no statistics'
             ep = nv.ActEpilogue(nv.ptr(epilogue[0]), epilogue[1], epilogue[2])
-            _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-                   lambda: nv.call('segnb_conv_fprop_act', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
-                                   self.Co if b is not None else 0, yv.ptr, ep, rt.stream))
+            for li, l in enumerate(p['fwd']):
+                g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+                _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                       lambda: nv.call('segnb_conv_fprop_act', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
+                                       self.Co if b is not None else 0, yv.ptr, ep, rt.stream))
             return
         if type(self) is ConvOp and 'wp_fwd_all' in p and \
                 nv.query('segnb_upconv_fprop_ok', xv.N, xv.H, xv.W, self.Cip, self.Cop, yv.ld, rt.code):
@@ -469,9 +470,11 @@ class ConvOp(object):
                                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream), ex)
 
     def act_epilogue_ok(self, H, W):
-        """segnb_conv_fprop_act needs ONE launch that covers the whole output (not a phase-split transposed convolution)."""
+        """segnb_conv_fprop_act: one launch that covers the whole output, or the parity phases of a transposed convolution (disjoint
+        outputs, together everything: linknet.py:58 finaldeconv1) -- but not where the four phases run as ONE launch of the
+        direct-to-LDS kernel (segnb_upconv_fprop, no epilogue there: the separate activation pass costs less than four launches)."""
         p = self.plan(H, W)
-        return self.fuse_act and p['fwd_full'] and len(p['fwd']) == 1
+        return self.fuse_act and p['fwd_full'] and (len(p['fwd']) == 1 or (self.transposed and 'wp_fwd_all' not in p))
 
     def u8_direct_ok(self, N, H, W, ld_out):
         """True when segnb_conv_fprop_u8 serves this convolution as the network's first layer."""
@@ -504,9 +507,19 @@ class ConvOp(object):
         g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
         return bool(nv.query('segnb_conv_fprop_bnreduce_ok', g, self.rt.code))
 
+    def dgrad_actmask_ok(self, dyv, dxv):
+        """True when this data gradient can apply the activation mask of the conv + activation (no BatchNorm) that produced its
+        input and store dz (segnb_conv_fprop_bnreduce with coef None)."""
+        p = self.plan(dxv.H, dxv.W)
+        if not self.need_dgrad or len(p['dg']) != 1 or not p['dg_full']:
+            return False
+        g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
+        return bool(nv.query('segnb_conv_fprop_actmask_ok', g, self.rt.code))
+
     def dgrad(self, dyv, dxv, bn_reduce=None):
         """bn_reduce: (y View, coef, sums, act, slope) of the layer whose activation gradient dxv is -- its reduction
-        pass is then done by this launch's epilogue (check dgrad_bnreduce_ok first)."""
+        pass is then done by this launch's epilogue (check dgrad_bnreduce_ok first; coef None: the activation mask of a layer
+        without BatchNorm, dxv receives dz -- check dgrad_actmask_ok)."""
         p, rt = self.plan(dxv.H, dxv.W), self.rt
         assert self.need_dgrad and dyv.Cp == self.Cop and dxv.Cp == self.Cip
         if not p['dg_full']:
@@ -907,6 +920,9 @@ class UpCatConvOp(object):
         return False
 
     def dgrad_bnreduce_ok(self, dyv, dxv):
+        return False
+
+    def dgrad_actmask_ok(self, dyv, dxv):
         return False
 
     # ---- backward, by segment

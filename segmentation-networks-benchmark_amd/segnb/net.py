@@ -366,7 +366,15 @@ def _data_gradient(tape, conv, x, dy, site):
     xv = x.v
     dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
     pr = x.producer
-    if pr is not None and pr[1] is None:          # (activation without BatchNorm: only the classifier heads fold that mask)
+    if pr is not None and pr[1] is None:
+        # activation without BatchNorm (linknet.py:58-61): the data gradient stores dz = g * act'(a) and sums it where a fused kernel
+        # serves the shape; the producer then skips its mask pass (Act.g_is_dz)
+        if (tape.fuse_reduce and Tape.fold_head_mask and x.consumers == 1 and x.g is None and x.needs_grad
+                and conv.dgrad_actmask_ok(dy, dx)):
+            conv.dgrad(dy, dx, bn_reduce=pr)
+            x.g_is_dz = True
+            tape.contribute(x, dx)
+            return
         pr = None
     if (pr is not None and tape.fuse_reduce and x.consumers == 1 and x.g is None and x.needs_grad
             and conv.dgrad_bnreduce_ok(dy, dx)):

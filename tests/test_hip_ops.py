@@ -1382,6 +1382,63 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
         np.testing.assert_allclose(a / scale, e / scale, atol=2e-4)
 
 
+@pytest.mark.parametrize('shape', [(2, 40, 56, 32, 32, nv.ACT_RELU, 1), (3, 33, 47, 24, 32, nv.ACT_LEAKY, 1),
+                                   (2, 38, 45, 32, 32, nv.ACT_LEAKY, 0),       # linknet.py:60 finalconv2 = Conv2d(32, 32, 3): valid window
+                                   (16, 511, 511, 32, 32, nv.ACT_LEAKY, 0)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_dgrad_with_act_mask(shape):
+    """segnb_conv_fprop_bnreduce with coef NULL: the data gradient whose store pass applies the activation mask of the conv +
+    activation (no BatchNorm) that produced its input -- dx == segnb_bn_act_bwd_reduce(plain dx, activated tensor) bit for bit,
+    the sums equal that pass's (another summation order) and the emulator's."""
+    N, H, W, C1, C2, act, pad = shape        # layer 1: ? -> C1 channels, activation;  layer 2: C1 -> C2, 3 x 3, padding `pad`
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 7 + C2 + pad)
+    w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    op = ConvOp(rt, w2, None, [(C1, cp.pad8(C1))], 1, pad, False, True)
+    op.pack(H, W)
+    Ho, Wo = op.out_hw(H, W)
+    C1p = cp.pad8(C1)
+    dyv = View.alloc(rt, N, Ho, Wo, op.Cop)
+    dyv.t.normal_()
+    a1 = View.alloc(rt, N, H, W, C1p)          # the ACTIVATED output of layer 1
+    a1.t.normal_()
+    if act == nv.ACT_RELU:
+        a1.t.clamp_(min=0)
+    st = torch.cuda.current_stream().cuda_stream
+    dx_plain = View.alloc(rt, N, H, W, C1p)
+    op.dgrad(dyv, dx_plain)
+    dz_ref = View.alloc(rt, N, H, W, C1p)
+    sums_ref = rt.zeros((16, 2, C1p), torch.float64)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, a1.ptr, a1.ld, N, H, W, C1p, None, act, 0.01, None, dx_plain.ptr, dx_plain.ld,
+            None, 0, None, 0, dz_ref.ptr, dz_ref.ld, nv.ptr(sums_ref), None, 0, st)
+    assert op.dgrad_actmask_ok(dyv, dx_plain)
+    dz_f = View.alloc(rt, N, H, W, C1p)
+    sums_f = rt.zeros((16, 2, C1p), torch.float64)
+    op.dgrad(dyv, dz_f, bn_reduce=(a1, None, sums_f, act, 0.01))
+    torch.cuda.synchronize()
+    assert torch.equal(dz_f.t, dz_ref.t)
+    a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
+    assert np.abs(a[1]).max() == 0.0
+    assert np.abs(a[0] - b[0]).max() <= 2e-5 * float(np.abs(b[0]).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a[0] - b[0]).max()
+    if N * H * W <= 20000:
+        def run_emu():
+            r = Runtime('cpu', 'bf16')
+            ope = ConvOp(r, w2.cpu(), None, [(C1, C1p)], 1, pad, False, True)
+            ope.pack(H, W)
+            dye, ae, dze = View.alloc(r, N, Ho, Wo, ope.Cop), View.alloc(r, N, H, W, C1p), View.alloc(r, N, H, W, C1p)
+            dye.t.copy_(dyv.t.cpu())
+            ae.t.copy_(a1.t.cpu())
+            se = r.zeros((16, 2, C1p), torch.float64)
+            assert ope.dgrad_actmask_ok(dye, dze)
+            ope.dgrad(dye, dze, bn_reduce=(ae, None, se, act, 0.01))
+            return dze.t.float(), se.sum(0).numpy()
+        with on_emulator():
+            dz_e, s_e = run_emu()
+        check('dz vs emulator', dz_f.t, dz_e, 'bf16')
+        scale = np.abs(b[0]).max() + 1e-30
+        np.testing.assert_allclose(a[0] / scale, s_e[0] / scale, atol=2e-3)
+
+
 ACT_EP_CASES = [
     # name,                 N, H,  W,  segs,               Co, k, s, p, transposed
     ('ws 64->64 relu',      2, 24, 40, [(64, 64)],         64, 3, 1, 1, False),
@@ -1392,6 +1449,8 @@ ACT_EP_CASES = [
     ('general 1x1 40->24',  2, 19, 23, [(40, 40)],         24, 1, 1, 0, False),
     ('general 3x3 s2',      2, 21, 30, [(16, 16)],         48, 3, 2, 1, False),
     ('general 2x2 p1',      1, 15, 15, [(32, 32)],         8,  2, 1, 1, False),
+    # the parity phases of a transposed convolution, each with the epilogue on its own outputs (linknet.py:58 finaldeconv1)
+    ('phases T3x3 s2 leaky', 2, 12, 14, [(64, 64)],        32, 3, 2, 0, True),
 ]
 
 
@@ -1415,8 +1474,10 @@ def test_conv_fprop_act_epilogue(case, with_bn, dtype):
     with torch.no_grad():
         bn.weight.copy_(0.5 + torch.rand(Co, generator=gen)); bn.bias.copy_(0.2 * torch.randn(Co, generator=gen))
         bn.running_mean.copy_(0.1 * torch.randn(Co, generator=gen)); bn.running_var.copy_(0.5 + torch.rand(Co, generator=gen))
+    if transposed:
+        w = q(torch.randn(Ci, Co, k, k, generator=gen) * (2.0 / (Ci * k * k)) ** 0.5)
     with torch.no_grad():
-        ref = F.conv2d(x, w, b, stride=s, padding=p)
+        ref = F.conv_transpose2d(x, w, b, stride=s, padding=p) if transposed else F.conv2d(x, w, b, stride=s, padding=p)
         if with_bn:
             ref = bn(ref)
         ref = F.leaky_relu(ref, slope) if act == nv.ACT_LEAKY else torch.relu(ref)
