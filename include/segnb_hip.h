@@ -249,6 +249,11 @@ int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N, int H, in
                             const void* g_direct, int ld_gd, const void* g_pool, int ld_gp,
                             const void* g_up, int ld_gu, void* dz, int ld_dz, double* sums,
                             const void* res, int ld_res, segnb_stream_t stream);
+/* The same pass over TWO same-size gradient sources (a tensor with two consumers: the identity branches of linknet.py:41-62's
+ * BasicBlocks): g = round(g_direct + g_add) -- exactly what segnb_add would have stored -- without that pass over the three tensors. */
+int segnb_bn_act_bwd_reduce_add(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef, int act,
+                                float slope, const float* dropmul, const void* g_direct, int ld_gd, const void* g_add, int ld_ga,
+                                void* dz, int ld_dz, double* sums, const void* res, int ld_res, segnb_stream_t stream);
 /* (with a residual input, dz is also the gradient of the residual branch)
  * dz may be NULL when the only source is g_direct and there is no dropout table and no residual: a sums-only pass
  * (one tensor write less); the layer's dy then comes from segnb_bn_bwd_apply_direct. */

@@ -683,6 +683,13 @@ class AbiEmulator(object):
                 S[1] += (dd * yh).sum(0)
         return 0
 
+    def segnb_bn_act_bwd_reduce_add(self, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd, g_add, ld_ga,
+                                    dz, ld_dz, sums, res, ld_res, stream):
+        dt = _tdt(dtype)
+        g = (_nhwc(g_direct, N, H, W, Cp, ld_gd, dt).float() + _nhwc(g_add, N, H, W, Cp, ld_ga, dt).float()).to(dt).contiguous()
+        return self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g.data_ptr(), Cp, None, 0,
+                                            None, 0, dz, ld_dz, sums, res, ld_res, stream)
+
     def segnb_bn_bwd_finalize(self, sums, C, Cp, count, gamma, coef, bcoef, dgamma, dbeta, accumulate, stream):
         SR = _mem(sums, REPL * 2 * Cp, torch.float64).view(REPL, 2, Cp)
         S = SR.sum(0)

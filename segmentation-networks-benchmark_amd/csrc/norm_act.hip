@@ -649,7 +649,10 @@ __device__ __forceinline__ unsigned bf16_order_key(unsigned b, bool nonneg) {
     return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
 }
 
-template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false, bool RES = false>
+// HAS_A (segnb_bn_act_bwd_reduce_add; with HAS_D, without pooling / upsampling): a SECOND same-size gradient source, passed in the
+// g_up / ld_gu arguments: g = round(g_direct + g_add) -- what segnb_add would have stored -- without that pass (a tensor with two
+// consumers: the residual connections of linknet.py:41-62's encoder)
+template <typename T, bool HAS_D, bool HAS_P, bool HAS_U, bool APPLY = false, bool RES = false, bool HAS_A = false>
 __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
     const T* __restrict__ y, int ld_y, EwShape s, const float* __restrict__ coef, int act, float slope,
     const float* __restrict__ dropmul, const T* __restrict__ g_direct, int ld_gd, const T* __restrict__ g_pool,
@@ -678,7 +681,8 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
 
     // ---- the loads of one trip, all requested before the first use: [item][row]
     static_assert(!(RES && HAS_P), "residual input and pooled gradient cannot be combined");
-    Raw8<T> ry[U][NR], rg[U][NR], ru[U][NR][NU], rres[RES ? U : 1], rgp[U];
+    static_assert(!HAS_A || (HAS_D && !HAS_P && !HAS_U && !APPLY), "second source: the plain direct form");
+    Raw8<T> ry[U][NR], rg[U][NR], ru[U][NR][NU], rres[RES ? U : 1], rgp[U], ra[HAS_A ? U : 1][NR];
     Raw8<float> rdm[U];
     int pn[U], ph[U], pw[U];            // image, row (row pair when pooling), column of the item
     bool okr[U][NR];
@@ -717,6 +721,7 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                 if (okr[i][r]) {
                     load_raw(y + pix * ld_y + c0, ry[i][r]);
                     if constexpr (HAS_D) load_raw(g_direct + pix * ld_gd + c0, rg[i][r]);
+                    if constexpr (HAS_A) load_raw(g_up + pix * ld_gu + c0, ra[i][r]);
                     if constexpr (HAS_U) {
                         const int hh = HAS_P ? 2 * ph[i] + r : ph[i];
                         const long long up00 = ((long long)pn[i] * 2 * s.H + 2 * hh) * up_row + 2 * pw[i];
@@ -776,6 +781,12 @@ __global__ __launch_bounds__(NTHR) void bn_act_bwd_reduce_kernel(
                     if (okr[i][r]) {
                         unpack_raw(ry[i][r], yv[r]);
                         if constexpr (HAS_D) unpack_raw(rg[i][r], g[r]);
+                        if constexpr (HAS_A) {
+                            float t[8];
+                            unpack_raw(ra[i][r], t);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) g[r][e] = round_as(g[r][e] + t[e], (const T*)nullptr);
+                        }
                     }
                 }
                 if constexpr (HAS_P) {
@@ -1622,6 +1633,33 @@ extern "C" int segnb_bn_act_bwd_reduce(int dtype, const void* y, int ld_y, int N
 #undef SEGNB_RED_ALL
 #undef SEGNB_RED_R
 #undef SEGNB_RED
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int segnb_bn_act_bwd_reduce_add(int dtype, const void* y, int ld_y, int N, int H, int W, int Cp, const float* coef, int act,
+                                           float slope, const float* dropmul, const void* g_direct, int ld_gd, const void* g_add,
+                                           int ld_ga, void* dz, int ld_dz, double* sums, const void* res, int ld_res,
+                                           segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_bn_act_bwd_reduce_add, dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, g_direct, ld_gd, g_add, ld_ga, dz, ld_dz, sums, res, ld_res, stream);
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y != nullptr && g_direct != nullptr && g_add != nullptr, "NULL tensor");
+    SEGNB_CHECK_ARG(dz != nullptr || sums != nullptr, "a pass without dz needs the sums");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+#define SEGNB_RED_A(TT, R)                                                                                                     \
+    SEGNB_LAUNCH_FORKABLE((bn_act_bwd_reduce_kernel<TT, true, false, false, false, R, true>), grid, dim3(NTHR), 0, (hipStream_t)stream, \
+                          (const TT*)y, ld_y, s, coef, act, slope, dropmul, (const TT*)g_direct, ld_gd, (const TT*)nullptr, 0,    \
+                          (const TT*)g_add, ld_ga, (TT*)dz, ld_dz, sums, (const TT*)res, ld_res, BnBwdParams{})
+    if (dtype == SEGNB_BF16) {
+        if (res != nullptr) SEGNB_RED_A(bf16_t, true); else SEGNB_RED_A(bf16_t, false);
+    } else if (dtype == SEGNB_F32) {
+        if (res != nullptr) SEGNB_RED_A(float, true); else SEGNB_RED_A(float, false);
+    } else {
+        segnb_set_error("segnb_bn_act_bwd_reduce_add: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+#undef SEGNB_RED_A
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

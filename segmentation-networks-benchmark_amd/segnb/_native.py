@@ -97,6 +97,8 @@ SIGNATURES = {
                          c_int, _P, c_int, _P, c_int, _P],
     'segnb_bn_act_bwd_reduce': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int,
                                 _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P],
+    'segnb_bn_act_bwd_reduce_add': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P, c_int, _P,
+                                    c_int, _P, _P, c_int, _P],
     'segnb_bn_fwd_fused': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P,
                            _P, c_int, c_float, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P],
     'segnb_bn_bwd_apply_fused': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P,

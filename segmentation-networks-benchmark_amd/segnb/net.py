@@ -34,11 +34,32 @@ class Act(object):
     coef None: the tensor is act(conv) WITHOUT BatchNorm (y = the activated tensor itself); a consumer that can apply act' while it
     writes the gradient (the classifier heads: segnb_head_conv_bwd) then stores dz itself and sums it into `sums` -- g_is_dz then
     means .g IS dz and the producer's segnb_bn_act_bwd_reduce pass is skipped."""
-    __slots__ = ('v', 'g', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
+    __slots__ = ('v', '_g', '_g2', '_settle', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
 
     def __init__(self, v, needs_grad=True):
-        self.v, self.g, self.needs_grad = v, None, needs_grad
+        self.v, self._g, self._g2, self._settle, self.needs_grad = v, None, None, None, needs_grad
         self.consumers, self.producer, self.g_is_dz = 0, None, False
+
+    # The gradient.  A SECOND contribution is held back (Tape.contribute: _g2 + the launch that would add it): the convolution units
+    # hand both sources to their reduction pass (segnb_bn_act_bwd_reduce_add) instead of an add pass over three tensors; any other
+    # reader of .g gets the sum -- reading it launches the add.
+    @property
+    def g(self):
+        if self._g2 is not None:
+            settle, self._g2, self._settle = self._settle, None, None
+            settle()
+        return self._g
+
+    @g.setter
+    def g(self, v):
+        assert self._g2 is None
+        self._g = v
+
+    def take_sources(self):
+        """-> (g, g2 or None) WITHOUT adding them; the caller consumes both."""
+        g, g2 = self._g, self._g2
+        self._g2 = self._settle = None
+        return g, g2
 
 
 class _HostStep(object):
@@ -80,6 +101,7 @@ class Tape(object):
         self.fused_stats, self.stats_pending = [], False
         # share (%) of the CUs the model's weight gradients split their pixels for (HipNet.wg_cu_pct; None = the library default)
         self.wg_cu_pct = getattr(module, 'wg_cu_pct', None)
+        self.lazy_add = bool(getattr(module, 'lazy_add', False))
 
     # BatchNorm finalize folded into the activation / apply launches of a differentiated training forward (one launch less
     # per layer and direction; A/B: SEGNB_FUSE_FINALIZE=0)
@@ -177,15 +199,34 @@ class Tape(object):
             if a is not None:
                 a.consumers += 1
 
+    # lazy_add (per model: HipNet.lazy_add, default off): a SECOND gradient contribution to a tensor is held back for the reduction
+    # pass of the layer that produced it instead of being added at once.  Only for models whose gradient views never alias
+    # (FCDenseNet accumulates its dense blocks' contributions into slices of shared buffers, in place and in order: not there)
+    lazy_add = False
+
     def contribute(self, act, gview):
         if not act.needs_grad:
             return
-        if act.g is None:
+        if act._g is None:
             act.g = gview
-        else:
-            v = act.g
+            return
+
+        def add(v=act._g):
             nv.call('segnb_add', self.rt.code, v.ptr, v.ld, gview.ptr, gview.ld, v.ptr, v.ld, v.N, v.H, v.W, v.Cp,
                     self.rt.stream)
+        if self.lazy_add and act._g2 is None and not act.g_is_dz:
+            # held back: gview is a buffer of its call site that nothing writes again during this backward
+            act._g2, act._settle = gview, add
+        else:
+            act.g                      # (a third contribution: the pending one is added first, in arrival order)
+            add()
+
+    def sources(self, act, two_ok):
+        """-> (g, g2): the gradient of act as one or (two_ok, a held-back second contribution) two same-size views; without two_ok the
+        pending add runs now."""
+        if two_ok:
+            return act.take_sources()
+        return act.g, None
 
     def register_conv(self, conv, H, W):
         k = (id(conv), H, W)
@@ -464,7 +505,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             oa.producer = (ov, None, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
         def backward_fused():
-            if oa.g is None:
+            if oa._g is None:
                 return
             flat = tape.flat
             sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
@@ -475,11 +516,16 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                 dz = oa.g
             else:
                 dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
+                g1, g2 = tape.sources(oa, True)
                 # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before
                 # the weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork)
                 rt.arm_fork()
-                nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
-                        oa.g.ptr, oa.g.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+                if g2 is not None:
+                    nv.call('segnb_bn_act_bwd_reduce_add', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
+                            g1.ptr, g1.ld, g2.ptr, g2.ld, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+                else:
+                    nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
+                            g1.ptr, g1.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
             tape.defer_bias_grad(sums, C, Cp, gb, float(N * Ho * Wo), coef_buf, bcoef)
             side = rt.fork_side()
@@ -536,7 +582,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         oa.producer = (y, coef_buf, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
     def backward():
-        if oa.g is None and (pa is None or pa.g is None):
+        if oa._g is None and (pa is None or pa.g is None):
             if fused_bn:                     # nothing will clear the forward statistics: not a replayable backward
                 stats.zero_()
                 tape.unplannable = True
@@ -546,9 +592,12 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
         gp = pa.g if pa is not None else None
+        # (two gradient sources -- a tensor with two consumers, linknet.py:41-62's identity branches: both go to the reduction pass,
+        # segnb_bn_act_bwd_reduce_add, instead of an add pass first; not beside a pooled gradient)
+        og, og2 = tape.sources(oa, gp is None and not oa.g_is_dz)
         # one direct gradient source and nothing else in the way: dz stays in registers (sums-only reduce, then the apply
         # launch recomputes it from the incoming gradient -- segnb_bn_bwd_apply_fused_direct, as ZF_UNET's first convolutions)
-        direct = fused_bn and gp is None and res is None and dropmul is None and oa.g is not None
+        direct = fused_bn and gp is None and res is None and dropmul is None and og is not None and og2 is None
         if oa.g_is_dz:
             # the one consumer's data gradient did the reduction in its epilogue (_data_gradient): the sums are complete and
             # oa.g is the plain gradient, from which the apply launch recomputes dz (the direct form; producer => direct)
@@ -557,10 +606,15 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         else:
             if not has_bn and res is None:
                 rt.arm_fork()                # (no BatchNorm: this pass is the last launch before the weight gradient's fork)
-            nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
-                    nv.ptr(dropmul), vptr(oa.g), vld(oa.g), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
-                    0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
-                    rt.stream)
+            if og2 is not None:
+                nv.call('segnb_bn_act_bwd_reduce_add', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
+                        nv.ptr(dropmul), og.ptr, og.ld, og2.ptr, og2.ld, dz.ptr, dz.ld, nv.ptr(sums),
+                        None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
+            else:
+                nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
+                        nv.ptr(dropmul), vptr(og), vld(og), vptr(gp), vld(gp), None, 0, None if direct else dz.ptr,
+                        0 if direct else dz.ld, nv.ptr(sums), None if res is None else res.v.ptr, 0 if res is None else res.v.ld,
+                        rt.stream)
         count = float(N * Ho * Wo)
         dy = dz
         if has_bn:

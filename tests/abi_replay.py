@@ -88,7 +88,7 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
 # (argument position -> entry points) whose fp64 argument is a [REPL][2][Cp] replicated accumulator: the emulator
 # fills replica 0, the HIP kernels spread blocks over all 16; only the sum over replicas is defined by the ABI
 _REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats', 'segnb_bn_stats_ld'), 19: ('segnb_bn_act_bwd_reduce',),
-               17: ('segnb_head_bn_bwd',), 13: ('segnb_bn_act_fwd_stats',), 20: ('segnb_head_conv_bwd',), 0: ()}
+               17: ('segnb_head_bn_bwd', 'segnb_bn_act_bwd_reduce_add'), 13: ('segnb_bn_act_fwd_stats',), 20: ('segnb_head_conv_bwd',), 0: ()}
 
 
 def run_step(model, x, y, loss_fn, device, dtype):
@@ -104,7 +104,7 @@ def run_step(model, x, y, loss_fn, device, dtype):
 
 
 def replay(make_model, x, y, loss_fn, dtype, device='cuda',
-           flip_ops=('segnb_bn_act_fwd', 'segnb_bn_act_bwd_reduce', 'segnb_bn_bwd_apply', 'segnb_bn_bwd_apply_direct',
+           flip_ops=('segnb_bn_act_fwd', 'segnb_bn_act_bwd_reduce', 'segnb_bn_act_bwd_reduce_add', 'segnb_bn_bwd_apply', 'segnb_bn_bwd_apply_direct',
                      'segnb_bn_bwd_finalize',
                      'segnb_bn_fwd_fused', 'segnb_bn_bwd_apply_fused', 'segnb_bn_bwd_apply_fused_direct',
                      'segnb_bn_fwd_fused_head', 'segnb_head_bn_bwd', 'segnb_bn_fwd_fused_ld', 'segnb_bn_act_fwd_stats')):
@@ -164,6 +164,9 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
                 # channel sums that are analytically zero hold pure cancellation noise on both sides: floor at
                 # 1e-6 of sum|dz| (dz = argument 17 of the same call)
                 dz = [r for q, (k, r) in rpost if q == 17 and k == 'full']
+                atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
+            if name == 'segnb_bn_act_bwd_reduce_add' and p == 17:       # (the same floor; dz = argument 15)
+                dz = [r for q, (k, r) in rpost if q == 15 and k == 'full']
                 atol = 1e-6 * float(dz[0].double().abs().sum()) if dz else 0.0
             if name == 'segnb_head_conv_bwd' and p == 20:       # (the same floor; dz = argument 16)
                 dz = [r for q, (k, r) in rpost if q == 16 and k == 'full']

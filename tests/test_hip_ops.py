@@ -1382,6 +1382,47 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
         np.testing.assert_allclose(a / scale, e / scale, atol=2e-4)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('with_res', [False, True])
+@pytest.mark.parametrize('shape', [(2, 17, 23, 40), (1, 64, 64, 64), (16, 128, 128, 64)], ids=lambda s: 'x'.join(map(str, s)))
+def test_bn_act_bwd_reduce_two_sources(shape, with_res, dtype):
+    """segnb_bn_act_bwd_reduce_add(g1, g2) == segnb_add(g1, g2) followed by segnb_bn_act_bwd_reduce: dz bit for bit, the sums to
+    fp64 rounding of another block order (the identity branches of linknet.py:41-62: a tensor with two consumers)."""
+    N, H, W, C = shape
+    rt = Runtime('cuda', dtype)
+    y, g1, g2, r = (View.alloc(rt, N, H, W, C) for _ in range(4))
+    for v in (y, g1, g2, r):
+        v.t.normal_()
+    gen = torch.Generator().manual_seed(C)
+    coef = torch.stack([0.5 + torch.rand(C, generator=gen), 0.3 * torch.randn(C, generator=gen),
+                        0.2 * torch.randn(C, generator=gen), 0.5 + torch.rand(C, generator=gen)]).cuda().contiguous()
+    st = rt.stream
+    gs = View.alloc(rt, N, H, W, C)
+    nv.call('segnb_add', rt.code, g1.ptr, g1.ld, g2.ptr, g2.ld, gs.ptr, gs.ld, N, H, W, C, st)
+    dz_ref, dz = View.alloc(rt, N, H, W, C), View.alloc(rt, N, H, W, C)
+    s_ref, s_f = rt.zeros((16, 2, C), torch.float64), rt.zeros((16, 2, C), torch.float64)
+    rp, rl = (r.ptr, r.ld) if with_res else (None, 0)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, y.ptr, y.ld, N, H, W, C, nv.ptr(coef), nv.ACT_LEAKY, 0.01, None, gs.ptr, gs.ld,
+            None, 0, None, 0, dz_ref.ptr, dz_ref.ld, nv.ptr(s_ref), rp, rl, st)
+    nv.call('segnb_bn_act_bwd_reduce_add', rt.code, y.ptr, y.ld, N, H, W, C, nv.ptr(coef), nv.ACT_LEAKY, 0.01, None, g1.ptr, g1.ld,
+            g2.ptr, g2.ld, dz.ptr, dz.ld, nv.ptr(s_f), rp, rl, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dz.t, dz_ref.t)
+    a, b = s_f.sum(0).cpu().numpy(), s_ref.sum(0).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * float(np.abs(b).max()))
+    if N * H * W <= 20000:
+        with on_emulator():
+            rc = Runtime('cpu', dtype)
+            ye, g1e, g2e, re_, dze = (View.alloc(rc, N, H, W, C) for _ in range(5))
+            for d, srcv in ((ye, y), (g1e, g1), (g2e, g2), (re_, r)):
+                d.t.copy_(srcv.t.cpu())
+            se, ce = rc.zeros((16, 2, C), torch.float64), coef.cpu()
+            nv.call('segnb_bn_act_bwd_reduce_add', rc.code, ye.ptr, ye.ld, N, H, W, C, nv.ptr(ce), nv.ACT_LEAKY, 0.01, None, g1e.ptr,
+                    g1e.ld, g2e.ptr, g2e.ld, dze.ptr, dze.ld, nv.ptr(se), re_.ptr if with_res else None, re_.ld if with_res else 0,
+                    rc.stream)
+        check('dz vs emulator', dz.t, dze.t, dtype)
+
+
 @pytest.mark.parametrize('shape', [(2, 40, 56, 32, 32, nv.ACT_RELU, 1), (3, 33, 47, 24, 32, nv.ACT_LEAKY, 1),
                                    (2, 38, 45, 32, 32, nv.ACT_LEAKY, 0),       # linknet.py:60 finalconv2 = Conv2d(32, 32, 3): valid window
                                    (16, 511, 511, 32, 32, nv.ACT_LEAKY, 0)],
