@@ -192,6 +192,8 @@ class Tape(object):
     fuse_reduce = True
     # fold_head_mask = False: the classifier heads return the plain gradient and the layer before them masks it in its own pass (A/B)
     fold_head_mask = True
+    # fuse_act_pool = False: conv -> ReLU -> MaxPool2d(2) without BatchNorm as convolution + one pass that activates and pools (A/B)
+    fuse_act_pool = True
 
     def consume(self, *acts):
         """An operator of the forward reads these tensors (each will receive one gradient contribution from it)."""
@@ -486,7 +488,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     # BatchNorm in inference -- with no residual, dropout or fused pooling in the way.  The backward of the no-BatchNorm
     # form reads the ACTIVATED tensor where it read the raw one: act'(z) has the sign of act(z).
     ov_direct = out if out is not None else None
-    fuse = ((not has_bn or (not tape.train and not tape.need_grad)) and res is None and dropmul is None and not pool
+    # (a fused MaxPool2d(2) stays possible without BatchNorm under ReLU: the pooled tensor is then one more pass over the ACTIVATED
+    # output -- read a, write a / 4 -- instead of the activation pass -- read y, write a and a / 4; unet16.py:113-118)
+    fuse = ((not has_bn or (not tape.train and not tape.need_grad)) and res is None and dropmul is None
+            and (not pool or (not has_bn and act == nv.ACT_RELU and Tape.fuse_act_pool))
             and act in (nv.ACT_NONE, nv.ACT_RELU, nv.ACT_LEAKY) and conv.act_epilogue_ok(xv.H, xv.W))
     if fuse:
         coef = None
@@ -497,15 +502,21 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             coef = coef_buf
         ov = ov_direct if ov_direct is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
         conv.fprop(xv, ov, None, epilogue=(coef, act, slope))
+        pv = None
+        if pool:
+            pv = pool_out if pool_out is not None else tape.view(site + '/p', N, Ho // 2, Wo // 2, Cp)
+            nv.call('segnb_maxpool_fwd', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, 2, 2, 0, pv.ptr, pv.ld, None, rt.stream)
         if out_stats is not None:
-            _sum_into(tape, ov, out_stats)
+            _sum_into(tape, pv if pool else ov, out_stats)
         oa = Act(ov)
-        if not has_bn and tape.need_grad:
+        pa = Act(pv) if pool else None
+        if not has_bn and tape.need_grad and not pool:
             # (sums: zero between steps -- segnb_bias_grad_multi clears what it reads)
             oa.producer = (ov, None, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
 
         def backward_fused():
-            if oa._g is None:
+            gp = pa.g if pa is not None else None
+            if oa._g is None and gp is None:
                 return
             flat = tape.flat
             sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
@@ -516,16 +527,17 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                 dz = oa.g
             else:
                 dz = tape.view(site + '/dz', N, Ho, Wo, Cp)
-                g1, g2 = tape.sources(oa, True)
+                g1, g2 = tape.sources(oa, gp is None)
                 # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before
-                # the weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork)
+                # the weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork); the pooled gradient is
+                # routed to the window's first maximum of a, as the forward's pooling pass chose it
                 rt.arm_fork()
                 if g2 is not None:
                     nv.call('segnb_bn_act_bwd_reduce_add', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
                             g1.ptr, g1.ld, g2.ptr, g2.ld, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
                 else:
                     nv.call('segnb_bn_act_bwd_reduce', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
-                            g1.ptr, g1.ld, None, 0, None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
+                            vptr(g1), vld(g1), vptr(gp), vld(gp), None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
             tape.defer_bias_grad(sums, C, Cp, gb, float(N * Ho * Wo), coef_buf, bcoef)
             side = rt.fork_side()
@@ -540,7 +552,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
 
         if not has_bn:
             tape.record(backward_fused)
-        return oa
+        return (oa, pa) if pool else oa
     conv.fprop(xv, y, stats if use_batch_stats else None)
     coef = None
     ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
