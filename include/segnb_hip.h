@@ -507,6 +507,10 @@ int segnb_upconv_fprop_acc_ok(int N, int H, int W, int Ci, int Co, int ld_out, i
 int segnb_upconv_fprop_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype);
 int segnb_upconv_fprop(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co, int CoW,
                        const float* bias, int bias_n, void* out, int ld_out, double* stats, segnb_stream_t stream);
+/* ... with the activation that follows it (unet16.py:38-40: ConvTranspose2d -> ReLU) applied in the accumulator staging: out =
+ * act(bias + the phase sums); ep->coef must be NULL (no folded BatchNorm), ep->slope in [0, 1].  No statistics. */
+int segnb_upconv_fprop_act(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co, int CoW,
+                           const float* bias, int bias_n, void* out, int ld_out, const segnb_act_epilogue* ep, segnb_stream_t stream);
 int segnb_upconv_fprop_acc(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co,
                            int CoW, void* out, int ld_out, double* stats, segnb_stream_t stream);
 int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, void* out,

@@ -229,7 +229,13 @@ class AbiEmulator(object):
     def segnb_upconv_fprop_ok(self, N, H, W, Ci, Co, ld_out, dtype):
         return int(dtype == BF16 and Ci % 64 == 0 and Ci >= 128 and W >= 12)
 
-    def segnb_upconv_fprop(self, dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, bias, bias_n, out_p, ld_out, stats, stream):
+    def segnb_upconv_fprop_act(self, dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, bias, bias_n, out_p, ld_out, ep, stream):
+        e = _geom(ep)
+        assert not e.coef
+        return self.segnb_upconv_fprop(dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, bias, bias_n, out_p, ld_out, None, stream,
+                                       _act=(e.act, e.slope))
+
+    def segnb_upconv_fprop(self, dtype, N, H, W, Ci, ld_in, in_p, wp, Co, CoW, bias, bias_n, out_p, ld_out, stats, stream, _act=None):
         """out = bias + the four phase sums (ConvTranspose2d(4, 2, 1) forward): zero, then the accumulating form, bias folded
         into the first rounding"""
         dt = _tdt(dtype)
@@ -249,6 +255,11 @@ class AbiEmulator(object):
             for t, (dh, dw, _, _) in enumerate(l.taps):
                 acc += Up[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W, :] @ Wm[ph, :Co, t, :].t()
             res[:, l.oh0::2, l.ow0::2, :] = acc + b
+        if _act is not None:
+            if _act[0] == ACT_RELU:
+                res = torch.relu(res)
+            elif _act[0] == ACT_LEAKY:
+                res = torch.nn.functional.leaky_relu(res, _act[1])
         stored = res.to(dt)
         O.copy_(stored)
         if stats is not None:

@@ -1578,7 +1578,7 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
 // ---- forward of an Upsample(x2) -> conv3x3 segment on the low-resolution tensor, accumulating (fprop_dma.hip, WsCfg UP_ = 2)
 int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream,
-                        const float* bias = nullptr, int bias_n = 0, int no_prev = 0);
+                        const float* bias = nullptr, int bias_n = 0, int no_prev = 0, int ep_act = -1, float ep_slope = 0.f);
 
 extern "C" int segnb_upconv_fprop_acc_ok(int N, int H, int W, int Ci, int Co, int ld_out, int dtype) {
     if (dtype != SEGNB_BF16 || getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
@@ -1632,6 +1632,32 @@ extern "C" int segnb_upconv_fprop(int dtype, int N, int H, int W, int Ci, int ld
     }
     if (rc == 0) {
         segnb_set_error("segnb_upconv_fprop: no kernel for this shape");
+        return SEGNB_E_UNSUPPORTED;
+    }
+    return rc;
+}
+
+// the same with the activation of unet16.py:38-40 (ConvTranspose2d -> ReLU) in the accumulator staging: no pass over the output
+extern "C" int segnb_upconv_fprop_act(int dtype, int N, int H, int W, int Ci, int ld_in, const void* in, const void* wpacked, int Co,
+                                      int CoW, const float* bias, int bias_n, void* out, int ld_out, const segnb_act_epilogue* ep,
+                                      segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_upconv_fprop_act, dtype, N, H, W, Ci, ld_in, in, wpacked, Co, CoW, bias, bias_n, out, ld_out, ep, stream);
+    SEGNB_CHECK_ARG(in && wpacked && out && ep, "NULL tensor");
+    SEGNB_CHECK_ARG(ep->coef == nullptr && (ep->act == SEGNB_ACT_NONE || ep->act == SEGNB_ACT_RELU || ep->act == SEGNB_ACT_LEAKY),
+                    "activation only (no folded BatchNorm on this kernel)");
+    SEGNB_CHECK_ARG(ep->act != SEGNB_ACT_LEAKY || (ep->slope >= 0.f && ep->slope <= 1.f), "leaky slope outside [0, 1]");
+    SEGNB_CHECK_ARG(segnb_upconv_fprop_ok(N, H, W, Ci, Co, ld_out, dtype), "shape not served (segnb_upconv_fprop_ok)");
+    SEGNB_CHECK_ARG(CoW >= Co && ld_in >= Ci && ld_out >= Co && bias_n >= 0 && bias_n <= Co, "bad strides");
+    const long long inb = (((long long)N * H * W - 1) * ld_in + Ci) * 2, wb = 4ll * CoW * 4 * Ci * 2;
+    SEGNB_CHECK_ARG(inb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB (32-bit buffer offsets)");
+    const int rc = segnb_fprop_upf_try(N, H, W, Ci, ld_in, in, (unsigned)inb, wpacked, (unsigned)wb, Co, CoW, out, ld_out, nullptr,
+                                       (hipStream_t)stream, bias_n > 0 ? bias : nullptr, bias_n, 1, ep->act, ep->slope);
+    if (rc == 1) {
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rc == 0) {
+        segnb_set_error("segnb_upconv_fprop_act: no kernel for this shape");
         return SEGNB_E_UNSUPPORTED;
     }
     return rc;

@@ -253,6 +253,19 @@ int segnb_fprop_c8_try(const segnb_conv_geom* g, const void* in, const void* wpa
 static int c8_launch(const segnb_conv_geom* g, const void* in, const C8Norm* u8, const void* wpacked, const float* bias,
                      int bias_n, void* out, double* stats, hipStream_t stream, const segnb_act_epilogue* ep) {
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->Co > 32 && g->Co <= 64 && g->Co % 8 == 0 && g->Ci == 8 && stats == nullptr && u8 == nullptr &&
+        (ep == nullptr || ep->coef == nullptr)) {
+        // 33..64 output channels (unet16.py:73: VGG's 3 -> 64 at 1024 x 1024) as two launches over channel halves: the input is
+        // 16 bytes per pixel, the output 128 -- each launch re-reads the former and writes its half of the latter (285 us on the
+        // general kernel against 2 x ~75).  Without per-channel side tables only (statistics and a folded BatchNorm index by Co)
+        segnb_conv_geom h = *g;
+        h.Co = 32;
+        const int rc = c8_launch(&h, in, nullptr, wpacked, bias, bias_n < 32 ? bias_n : 32, out, nullptr, stream, ep);
+        if (rc != 1) return rc;
+        h.Co = g->Co - 32;
+        return c8_launch(&h, in, nullptr, (const bf16_t*)wpacked + 32 * 9 * 8, bias != nullptr && bias_n > 32 ? bias + 32 : nullptr,
+                         bias_n > 32 ? bias_n - 32 : 0, (bf16_t*)out + 32, nullptr, stream, ep);
+    }
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 8 || g->Co > 32 || g->Wo < 12) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
     for (int t = 1; t < 9; ++t) {

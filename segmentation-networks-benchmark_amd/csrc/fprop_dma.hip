@@ -211,6 +211,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
         sBias[c] = sh;
     }
     const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
+    const float upf_neg = ep_neg;
     auto ep = [&](float acc, float sc, float sh) {
         if constexpr (EP) {
             const float v = acc * sc + sh;
@@ -857,11 +858,15 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         const int col = wn * C::WN + 16 * j + 4 * g4;
                         uint2 pk;
                         if constexpr (C::UPF) {
+                            // (activation of a transposed convolution's own forward, segnb_upconv_fprop_act: max(v, v * neg) with
+                            // neg = 0 / slope / 1 -- the identity when no activation rides on the launch)
                             const uint2 pv = prev[i][j];
-                            pk.x = pack2bf(acc[i][j][0] + __uint_as_float(pv.x << 16) + bv[j].x,
-                                           acc[i][j][1] + __uint_as_float(pv.x & 0xffff0000u) + bv[j].y);
-                            pk.y = pack2bf(acc[i][j][2] + __uint_as_float(pv.y << 16) + bv[j].z,
-                                           acc[i][j][3] + __uint_as_float(pv.y & 0xffff0000u) + bv[j].w);
+                            const float v0 = acc[i][j][0] + __uint_as_float(pv.x << 16) + bv[j].x;
+                            const float v1 = acc[i][j][1] + __uint_as_float(pv.x & 0xffff0000u) + bv[j].y;
+                            const float v2 = acc[i][j][2] + __uint_as_float(pv.y << 16) + bv[j].z;
+                            const float v3 = acc[i][j][3] + __uint_as_float(pv.y & 0xffff0000u) + bv[j].w;
+                            pk.x = pack2bf(fmaxf(v0, v0 * upf_neg), fmaxf(v1, v1 * upf_neg));
+                            pk.y = pack2bf(fmaxf(v2, v2 * upf_neg), fmaxf(v3, v3 * upf_neg));
                         } else {
                         pk.x = pack2bf(ep(acc[i][j][0], sv[j].x, bv[j].x), ep(acc[i][j][1], sv[j].y, bv[j].y));
                         pk.y = pack2bf(ep(acc[i][j][2], sv[j].z, bv[j].z), ep(acc[i][j][3], sv[j].w, bv[j].w));
@@ -1320,7 +1325,7 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
 // the sums.  1 = launched, 0 = not served
 int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, int Co, int CoW, void* out, int ld_out, double* stats, hipStream_t stream,
-                        const float* bias, int bias_n, int no_prev) {
+                        const float* bias, int bias_n, int no_prev, int ep_act, float ep_slope) {
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_upd()) return 0;
     if (Ci % 64 != 0 || Ci < 128 || (Co <= 32 && !no_prev) || W < 12) return 0;
     FdArgs a;
@@ -1348,9 +1353,9 @@ int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, 
     a.u = nullptr;
     a.up_out = nullptr;
     a.bn_y = nullptr;
-    a.ep_act = -1;
+    a.ep_act = ep_act;          // (UPF: applied in the accumulator staging of this instantiation, not the EP one)
     a.ep_coef = nullptr;
-    a.ep_slope = 0.f;
+    a.ep_slope = ep_slope;
     const int ntl = 4 * ((Co + 63) / 64);
     int gm = segnb_knob_conv_cus() / ntl;
     if (gm < 1) gm = 1;

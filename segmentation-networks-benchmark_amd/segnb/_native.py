@@ -81,6 +81,8 @@ SIGNATURES = {
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_upconv_fprop': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     'segnb_upconv_fprop_acc': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
+    'segnb_upconv_fprop_act': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int,
+                               ctypes.POINTER(ActEpilogue), _P],
     'segnb_conv_wgrad_bnapply': [ctypes.POINTER(ConvGeom), c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_float, _P, c_int, _P],
     'segnb_pack_weight': [_P, _P, c_int, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, _P],
     'segnb_unpack_wgrad': [_P, _P, c_int, c_int, c_int, c_ll, c_ll, ctypes.POINTER(c_int), _P, _P, c_int, _P],

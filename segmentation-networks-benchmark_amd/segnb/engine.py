@@ -448,6 +448,14 @@ class ConvOp(object):
             # (the phase launches of a transposed convolution write disjoint output parities: each applies the epilogue to its own)
             assert stats is None and p['fwd_full'], 'full coverage, no statistics'
             ep = nv.ActEpilogue(nv.ptr(epilogue[0]), epilogue[1], epilogue[2])
+            if 'wp_fwd_all' in p:
+                # ConvTranspose2d(4, 2, 1): the four phases as one launch, the activation in its accumulator staging
+                assert epilogue[0] is None and self.upconv_act_ok(xv.N, xv.H, xv.W, yv.ld)
+                _timed('conv_fprop', 2.0 * xv.N * xv.H * xv.W * 16 * self.Ci * self.Co,
+                       lambda: nv.call('segnb_upconv_fprop_act', rt.code, xv.N, xv.H, xv.W, self.Cip, xv.ld, xv.ptr,
+                                       nv.ptr(p['wp_fwd_all']), self.Cop, self.Cop, nv.ptr(b), self.Co if b is not None else 0,
+                                       yv.ptr, yv.ld, ep, rt.stream))
+                return
             for li, l in enumerate(p['fwd']):
                 g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
                 _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
@@ -469,12 +477,26 @@ class ConvOp(object):
                    lambda: nv.call('segnb_conv_fprop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][li]), nv.ptr(b),
                                    self.Co if b is not None else 0, yv.ptr, nv.ptr(stats), rt.stream), ex)
 
-    def act_epilogue_ok(self, H, W):
-        """segnb_conv_fprop_act: one launch that covers the whole output, or the parity phases of a transposed convolution (disjoint
-        outputs, together everything: linknet.py:58 finaldeconv1) -- but not where the four phases run as ONE launch of the
-        direct-to-LDS kernel (segnb_upconv_fprop, no epilogue there: the separate activation pass costs less than four launches)."""
+    def upconv_act_ok(self, N, H, W, ld_out):
         p = self.plan(H, W)
-        return self.fuse_act and p['fwd_full'] and (len(p['fwd']) == 1 or (self.transposed and 'wp_fwd_all' not in p))
+        return (type(self) is ConvOp and 'wp_fwd_all' in p
+                and bool(nv.query('segnb_upconv_fprop_ok', N, H, W, self.Cip, self.Cop, ld_out, self.rt.code)))
+
+    def act_epilogue_ok(self, H, W, N=None, ld_out=None, coef=None):
+        """segnb_conv_fprop_act: one launch that covers the whole output, or the parity phases of a transposed convolution (disjoint
+        outputs, together everything: linknet.py:58 finaldeconv1).  A ConvTranspose2d(4, 2, 1) whose four phases run as ONE launch of
+        the direct-to-LDS kernel takes a plain activation there (segnb_upconv_fprop_act; needs N and the output stride) and
+        otherwise keeps the separate activation pass (it costs less than four launches of the general kernel)."""
+        p = self.plan(H, W)
+        if not (self.fuse_act and p['fwd_full']):
+            return False
+        if len(p['fwd']) == 1:
+            return True
+        if not self.transposed:
+            return False
+        if 'wp_fwd_all' in p:
+            return N is not None and coef is None and self.upconv_act_ok(N, H, W, ld_out)
+        return True
 
     def u8_direct_ok(self, N, H, W, ld_out):
         """True when segnb_conv_fprop_u8 serves this convolution as the network's first layer."""
@@ -913,7 +935,7 @@ class UpCatConvOp(object):
             return
         return self.full.fprop(xv, yv, stats, epilogue)
 
-    def act_epilogue_ok(self, H, W):
+    def act_epilogue_ok(self, H, W, *a):
         return False        # (inference keeps the separate activation pass for these five layers)
 
     def u8_direct_ok(self, *a):

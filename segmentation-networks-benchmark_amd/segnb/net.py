@@ -492,7 +492,8 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     # output -- read a, write a / 4 -- instead of the activation pass -- read y, write a and a / 4; unet16.py:113-118)
     fuse = ((not has_bn or (not tape.train and not tape.need_grad)) and res is None and dropmul is None
             and (not pool or (not has_bn and act == nv.ACT_RELU and Tape.fuse_act_pool))
-            and act in (nv.ACT_NONE, nv.ACT_RELU, nv.ACT_LEAKY) and conv.act_epilogue_ok(xv.H, xv.W))
+            and act in (nv.ACT_NONE, nv.ACT_RELU, nv.ACT_LEAKY)
+            and conv.act_epilogue_ok(xv.H, xv.W, N, out.ld if out is not None else Cp, bn))
     if fuse:
         coef = None
         if has_bn:
