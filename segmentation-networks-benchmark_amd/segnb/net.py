@@ -64,15 +64,27 @@ class Act(object):
 
 class _HostStep(object):
     """What a cut (or the end) of a backward launches from the host, outside the recorded lists: the batched bias gradients of
-    the convolutions without BatchNorm, then the batched unpack of the weight gradients.  run() repeats it in a replayed step."""
+    the convolutions without BatchNorm, then the batched unpack of the weight gradients.  run() repeats it in a replayed step.
+    end_side: this is the END of a backward whose weight gradients ran on the side stream -- the unpack goes behind the last of
+    them on that stream and the two streams join after it (Tape.finish)."""
 
-    def __init__(self, rt, bias, unpack):
-        self.rt, self.bias, self.unpack = rt, bias, unpack
+    def __init__(self, rt, bias, unpack, end_side=False, join=False):
+        self.rt, self.bias, self.unpack, self.end_side, self.join = rt, bias, unpack, end_side, join
 
     def run(self):
-        nv.call('segnb_bias_grad_multi', nv.ptr(self.bias[0]), self.bias[1], self.rt.stream)
+        if self.bias is not None:
+            nv.call('segnb_bias_grad_multi', nv.ptr(self.bias[0]), self.bias[1], self.rt.stream)
+        side = self.rt.side_stream() if self.join else None
+        if side is not None and not self.end_side:
+            nv.call('segnb_stream_join', self.rt.stream, side.cuda_stream)
         if self.unpack is not None:
-            self.unpack.run()
+            if self.end_side:
+                with torch.cuda.stream(side):
+                    self.unpack.run()
+            else:
+                self.unpack.run()
+        if side is not None and self.end_side:
+            nv.call('segnb_stream_join', self.rt.stream, side.cuda_stream)
 
 
 class Tape(object):
@@ -241,8 +253,31 @@ class Tape(object):
         self._unpack_pending.append((conv, H, W, grad_w))
 
     def backward(self):
-        self.run_closures()
-        self.run_unpack()
+        self.run_closures(join=False)
+        self.finish()
+
+    # unpack_on_side = False (class attribute): the end-of-backward unpack runs on the main stream, after the join (A/B)
+    unpack_on_side = True
+
+    def finish(self):
+        """End of a backward whose closures ran with join=False: the batched bias gradients on the current stream; the batched
+        unpack of the weight gradients BEHIND the last of them on the side stream (the dependent chain usually ends first: on the
+        main stream the unpack -- 0.1-0.27 ms for LinkNet34 / UNet16 -- was a serial tail of the step), then the join.
+        -> the object whose run() repeats this in a replayed step."""
+        rt = self.rt
+        busy = bool(getattr(rt, '_side_busy', False)) and rt.side_stream() is not None
+        on_side = busy and self.unpack_on_side
+        bias = self._run_bias_grads('end')
+        if on_side:
+            with torch.cuda.stream(rt.side_stream()):
+                step = self._run_unpack_tables('end')
+        else:
+            rt.join_side()
+            step = self._run_unpack_tables('end')
+        rt.join_side()
+        if bias is None and step is None and not busy:
+            return None
+        return _HostStep(rt, bias, step, end_side=on_side, join=busy)
 
     # ---- gradients handed to the data-parallel hook while backward is still running -----------------------------------
     # Parameters sit in the flat buffer in registration (= forward) order and the closures run in reverse, so the END of
@@ -269,9 +304,10 @@ class Tape(object):
                 k += 1
         self._cuts[nback] = cuts
 
-    def run_closures(self, around_cut=None):
+    def run_closures(self, around_cut=None, join=True):
         """around_cut(do): wraps the partial unpack + hook of a cut -- do() performs them and returns (unpack table or None,
-        flat offset, weight-gradient stream in use) -- so that HipNet can cut its recorded launch list there."""
+        flat offset, weight-gradient stream in use) -- so that HipNet can cut its recorded launch list there.
+        join=False: the caller joins the weight-gradient stream itself (Tape.finish)."""
         hook = self._ready_hook()
         back = list(reversed(self.back))
         nback = len(back)
@@ -310,7 +346,8 @@ class Tape(object):
             self._learn_cuts(nback, frontiers)
         self.back = []
         self.stats_pending = False
-        self.rt.join_side()               # the weight gradients ran on the side stream
+        if join:
+            self.rt.join_side()           # the weight gradients ran on the side stream
 
     # batch_bias = False (class attribute): one segnb_bn_bwd_finalize launch per bias gradient (A/B)
     batch_bias = True
@@ -1197,7 +1234,7 @@ class HipNet(nn.Module):
                     nv.plan_record_begin()
                     paused[0] = False
             try:
-                tape.run_closures(around)
+                tape.run_closures(around, join=False)
             except BaseException:
                 # (KeyboardInterrupt / SystemExit too: an open recording would swallow every later ABI call of this thread and
                 # make segnb_plan_run / segnb_tune refuse -- a validation pass in a Ctrl-C handler would hit that)
@@ -1222,7 +1259,7 @@ class HipNet(nn.Module):
                 else:
                     ent.update(bwd=[(h, c) for h, _, c in segs], nbwd=sum(n for _, n, _ in segs), state='ready')
                     self._guard_mode = (id(ent), 'record')
-            table = tape.run_unpack()                                       # (7x7 / strided jobs take host tap arrays: eager)
+            table = tape.finish()                                           # (7x7 / strided jobs take host tap arrays: eager)
             if recording and ent['state'] == 'ready':
                 ent['unpack'] = table
         hook = getattr(self, '_grad_sync_hook', None)
