@@ -258,6 +258,8 @@ class Tape(object):
 
     # unpack_on_side = False (class attribute): the end-of-backward unpack runs on the main stream, after the join (A/B)
     unpack_on_side = True
+    # early_unpack = False: no partial unpacks in the middle of a single-GPU backward (the cuts of CUT_FRACTIONS, below) (A/B)
+    early_unpack = True
 
     def finish(self):
         """End of a backward whose closures ran with join=False: the batched bias gradients on the current stream; the batched
@@ -311,8 +313,11 @@ class Tape(object):
         hook = self._ready_hook()
         back = list(reversed(self.back))
         nback = len(back)
-        cuts = self._cuts.get(nback) if hook is not None else None
-        learn = hook is not None and cuts is None
+        # (without a data-parallel hook the cuts still pay: the weight gradients finished so far are unpacked on the side stream in
+        # the middle of backward instead of in one serial tail behind the last of them -- Tape.early_unpack)
+        want = hook is not None or self.early_unpack
+        cuts = self._cuts.get(nback) if want else None
+        learn = want and cuts is None
         if learn:
             flat = self.flat
             offs = sorted((flat._off[k][0], k) for k in flat._off)
@@ -336,7 +341,8 @@ class Tape(object):
                             table = self.run_unpack(group=i)
                     else:
                         table = self.run_unpack(group=i)
-                    hook(self.flat, cuts[i], (side,) if side is not None else ())
+                    if hook is not None:
+                        hook(self.flat, cuts[i], (side,) if side is not None else ())
                     return table, cuts[i], side is not None
                 if around_cut is not None:
                     around_cut(do)
