@@ -233,6 +233,14 @@ def _worker_hipnet(rank, world, port, out_dir, which):
             warnings.simplefilter('ignore')
             if which == 'unet16':
                 m = UNet16(num_filters=4)
+            elif which == 'linknet34':
+                # (its decoder convolutions' biases sit in front of BatchNorms: no closure ever writes their gradients, which used
+                # to hold the frontier of finished gradients at the top of the buffer -- no cuts, no early buckets)
+                from lib.models.linknet import LinkNet34
+                m = LinkNet34()
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.Dropout2d):
+                        mod.p = 0.0
             else:
                 m = FCDenseNet(in_channels=3, down_blocks=(2, 2), up_blocks=(2, 2), bottleneck_layers=2, growth_rate=8,
                                out_chans_first_conv=16, n_classes=1)
@@ -280,7 +288,7 @@ def _worker_hipnet(rank, world, port, out_dir, which):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('which', ['unet16', 'fcdensenet'])
+@pytest.mark.parametrize('which', ['unet16', 'fcdensenet', 'linknet34'])
 def test_executor_models_hand_over_gradients_during_backward(tmp_path, which):
     port = _free_port()
     mp.spawn(_worker_hipnet, args=(2, port, str(tmp_path), which), nprocs=2, join=True)
