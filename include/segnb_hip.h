@@ -409,6 +409,39 @@ typedef struct {
     float slope;
 } segnb_bn_reduce_epilogue;
 int segnb_conv_fprop_bnreduce_ok(const segnb_conv_geom* g, int dtype);
+/* A data gradient that is NEVER STORED (tiramisu.py:9-20: norm -> relu -> conv(C -> 16) of a dense layer -- its data gradient has
+ * K = 16 x 9 and C up to ~1100 output channels: the launch is the bytes of its output, which the BatchNorm backward then reads once
+ * for the reduction and once for the apply).  Two launches that each recompute the tile instead:
+ *   segnb_conv_fprop_bnsums   the reduction of segnb_conv_fprop_bnreduce, nothing written (reads in, y)
+ *   segnb_conv_fprop_bnapply  once the sums are complete: dz = round(round(g) * act'(z)) again, (a, c1, c2) from the sums (dgamma +=,
+ *                             dbeta +=, bcoef written: the fused finalize of segnb_bn_bwd_apply_fused), and
+ *                             dx = round(a * (dz - c1 - yhat * c2))  [accumulate: dx = round(dx + that)]
+ * = segnb_conv_fprop_bnreduce + segnb_bn_bwd_apply_fused_direct(_acc) bit for bit in dx, with 4 tensor transits instead of 6.
+ * gamma: [C] or NULL; C real BatchNorm channels (<= g->Co, the others give dx = 0); count = N * Ho * Wo; the sums are only READ
+ * (segnb_bn_fwd_fused clears them in the next forward).  _ok: served (bf16, stride-1 3x3, Ci <= 24, Co > 32: the general kernel). */
+typedef struct {
+    const void* y;
+    int ld_y;
+    const float* coef;
+    const double* sums;
+    const float* gamma;
+    int C;
+    double count;
+    float* bcoef;
+    float* dgamma;
+    float* dbeta;
+    int act;
+    float slope;
+    void* dx;
+    int ld_dx;
+    int accumulate;
+} segnb_bn_apply_epilogue;
+int segnb_conv_fprop_bnapply_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_fprop_bnsums(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                            const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream);
+int segnb_conv_fprop_bnapply(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                             const segnb_bn_apply_epilogue* ep, segnb_stream_t stream);
+
 /* coef == NULL: the producing layer is a convolution + activation WITHOUT BatchNorm (linknet.py:58-61 finaldeconv1 -> finalrelu1 ->
  * finalconv2, unet16.py:12-21) and y is its ACTIVATED output: the launch then stores out = dz = round(round(g) * act'(y)) (act' from
  * the sign of the activated value) and sums[r][0][c] += sum dz -- that layer's segnb_bn_act_bwd_reduce pass (y, coef NULL, dz) folded

@@ -284,6 +284,33 @@ class AbiEmulator(object):
             return 0
         return int(g.Ci % 32 == 0 and g.Ci <= 96 and g.Co <= 64 and not (g.Co > 32 and g.Ci > 32))
 
+    def segnb_conv_fprop_bnapply_ok(self, g, dtype):
+        g = _geom(g)
+        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
+                   and g.Co % 8 == 0 and g.Ci <= 24 and g.Co > 32)
+
+    def _dgrad_tmp(self, g, dtype, in_p, wp):
+        """the (rounded) data gradient of the two-launch forms, in a dense temporary; -> (tensor kept alive, pointer, stride)"""
+        gg = _geom(g)
+        tmp = torch.zeros(gg.N * gg.Ho * gg.Wo * gg.Co, dtype=_tdt(dtype))
+        g2 = self._regeom(gg, ld_out=gg.Co)
+        rc = self.segnb_conv_fprop(g2, dtype, in_p, wp, None, 0, tmp.data_ptr(), None, 0)
+        assert rc == 0
+        return tmp, gg
+
+    def segnb_conv_fprop_bnsums(self, g, dtype, in_p, wp, ep, stream):
+        tmp, gg = self._dgrad_tmp(g, dtype, in_p, wp)
+        e = _geom(ep)
+        return self.segnb_bn_act_bwd_reduce(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, gg.Co, e.coef, e.act, e.slope, None,
+                                            tmp.data_ptr(), gg.Co, None, 0, None, 0, None, 0, e.sums, None, 0, stream)
+
+    def segnb_conv_fprop_bnapply(self, g, dtype, in_p, wp, ep, stream):
+        tmp, gg = self._dgrad_tmp(g, dtype, in_p, wp)
+        e = _geom(ep)
+        fn = self.segnb_bn_bwd_apply_fused_direct_acc if e.accumulate else self.segnb_bn_bwd_apply_fused_direct
+        return fn(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, e.C, gg.Co, e.coef, e.sums, e.gamma, e.bcoef, e.dgamma, e.dbeta, 1, None,
+                  e.act, e.slope, tmp.data_ptr(), gg.Co, e.dx, e.ld_dx, stream)
+
     def segnb_conv_fprop_actmask_ok(self, g, dtype):
         g = _geom(g)
         return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo

@@ -56,6 +56,7 @@ hipEvent_t segnb_take_armed_event(hipStream_t stream);
 // executes as usual; segnb_plan_run replays the list from C (the Python launcher needs 10-14 us per launch).
 // ------------------------------------------------------------------------------------------------
 #include <functional>
+#include <type_traits>
 #include <tuple>
 bool segnb_plan_recording();
 void segnb_plan_push(std::function<int()> op, const char* name);
@@ -66,7 +67,13 @@ struct SegnbPlanScope {          // nested entry points (conv_wgrad_partial -> c
     ~SegnbPlanScope();
 };
 template <class T>
-inline T segnb_plan_keep(T v) { return v; }
+inline T segnb_plan_keep(T v) {
+    // (a HOST struct passed by pointer is copied into the plan by an overload below: without one the recorded call would replay
+    // with a dangling pointer -- the compiler refuses the entry point instead)
+    static_assert(!(std::is_pointer<T>::value && std::is_class<typename std::remove_pointer<T>::type>::value),
+                  "segnb_plan_keep: add an overload that copies this struct into the plan");
+    return v;
+}
 inline const segnb_conv_geom* segnb_plan_keep(const segnb_conv_geom* g) {
     return g ? (const segnb_conv_geom*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
@@ -75,6 +82,9 @@ inline const segnb_loss_spec* segnb_plan_keep(const segnb_loss_spec* g) {
 }
 inline const segnb_bn_reduce_epilogue* segnb_plan_keep(const segnb_bn_reduce_epilogue* g) {
     return g ? (const segnb_bn_reduce_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
+inline const segnb_bn_apply_epilogue* segnb_plan_keep(const segnb_bn_apply_epilogue* g) {
+    return g ? (const segnb_bn_apply_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
 inline const segnb_upcat_src* segnb_plan_keep(const segnb_upcat_src* g) {
     return g ? (const segnb_upcat_src*)segnb_plan_dup(g, sizeof(*g)) : g;

@@ -45,6 +45,19 @@ struct FpropArgs {
     double* bn_sums;                     // [SEGNB_STAT_REPLICAS][2][Co]
     int bn_act;
     float bn_slope;
+    // BNM 2 (segnb_conv_fprop_bnapply): the SECOND launch of a data gradient that is never stored -- the tile is recomputed (K is
+    // 144 deep for a dense layer: the launch is its output's bytes), dz = round(g * act'(z)) again, and what leaves is the
+    // BatchNorm-backward result dy = round(a * (dz - c1 - yhat * c2)) [+ the gradient already in bn_acc] with (a, c1, c2) from the
+    // sums the first launch (BNM 1: sums only, nothing stored) completed -- segnb_bn_bwd_apply_fused_direct(_acc) without g in memory
+    double bn_count;
+    const float* bn_gamma;               // [bn_C] or NULL
+    int bn_C;                            // real BatchNorm channels (<= Co)
+    float* bn_bcoef;                     // [3][Co] out (written by the blocks of pixel tile 0)
+    float* bn_dgamma;                    // [bn_C] +=
+    float* bn_dbeta;
+    void* bn_acc;                        // [N][Ho][Wo][bn_acc_ld] the BatchNorm input's gradient
+    int bn_acc_ld, bn_accumulate;
+    int bn_mode;                         // the BNM instantiation a BNR launch takes
 };
 
 struct WgradArgs {
@@ -127,9 +140,12 @@ constexpr int fprop_smem_bytes() {
 // ================================================================================================
 // forward / data-gradient
 // ================================================================================================
-template <typename T, int BM, int BN, int WM, int WN, bool EP = false, bool BNR = false>      // EP: affine + activation epilogue; BNR: FpropArgs::bn_y (separate instantiations)
+// BNM (with BNR): 0 the gradient is stored and reduced, 1 reduced only (nothing stored), 2 recomputed and APPLIED (FpropArgs::bn_acc)
+template <typename T, int BM, int BN, int WM, int WN, bool EP = false, bool BNR = false, int BNM = 0>      // EP: affine + activation epilogue; BNR: FpropArgs::bn_y (separate instantiations)
 __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
     static_assert(!BNR || (!EP && sizeof(T) == 2 && NT % (BN / 8) == 0 && NT >= 2 * BN), "BatchNorm-reduce store pass: bf16, one fixed channel chunk per thread");
+    static_assert(BNM == 0 || BNR, "BNM selects the form of the BatchNorm store pass");
+    __shared__ float sApp[BNM == 2 ? 4 * BN : 1];          // BNM 2: a, c1, c2, invstd of the block's channels
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int AI = BM / 32, BI = BN / 32;
@@ -189,6 +205,45 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
         bneg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
+        if constexpr (BNM == 2) {
+            // the fused finalize of bn_bwd_apply_kernel (norm_act.hip: bn_bwd_coef): every block derives (a, c1, c2) of its
+            // channels from the completed sums; the blocks of pixel tile 0 publish them and add dgamma / dbeta
+            for (int c2 = tid; c2 < BN; c2 += NT) {
+                const int ch = n_base + c2;
+                float av = 0.f, c1 = 0.f, c2v = 0.f, is = 0.f;
+                if (ch < a.bn_C) {
+                    double v1[SEGNB_STAT_REPLICAS], v2[SEGNB_STAT_REPLICAS];
+#pragma unroll
+                    for (int rp = 0; rp < SEGNB_STAT_REPLICAS; ++rp) {
+                        v1[rp] = a.bn_sums[(long long)(rp * 2) * g.Co + ch];
+                        v2[rp] = a.bn_sums[(long long)(rp * 2 + 1) * g.Co + ch];
+                    }
+                    double sdz = 0.0, sdzy = 0.0;
+#pragma unroll
+                    for (int rp = 0; rp < SEGNB_STAT_REPLICAS; ++rp) {
+                        sdz += v1[rp];
+                        sdzy += v2[rp];
+                    }
+                    is = a.bn_coef[3 * g.Co + ch];
+                    av = (a.bn_gamma != nullptr ? a.bn_gamma[ch] : 1.f) * is;
+                    c1 = (float)(sdz / a.bn_count);
+                    c2v = (float)(sdzy / a.bn_count);
+                    if (gq == 0) {
+                        if (a.bn_dgamma != nullptr) a.bn_dgamma[ch] += (float)sdzy;
+                        if (a.bn_dbeta != nullptr) a.bn_dbeta[ch] += (float)sdz;
+                    }
+                }
+                if (gq == 0 && ch < g.Co && a.bn_bcoef != nullptr) {
+                    a.bn_bcoef[ch] = av;
+                    a.bn_bcoef[g.Co + ch] = c1;
+                    a.bn_bcoef[2 * g.Co + ch] = c2v;
+                }
+                sApp[c2] = av;
+                sApp[BN + c2] = c1;
+                sApp[2 * BN + c2] = c2v;
+                sApp[3 * BN + c2] = is;
+            }
+        }
     }
 
     for (int mt = gq; mt < a.MT; mt += a.GM) {
@@ -293,7 +348,7 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
         // BNR: the y rows of the pixels this thread stores are requested NOW -- their latency runs under the staging below
         // (requested inside the store loop they were RPT dependent round trips per tile: the launch took 2.4 x as long)
         constexpr int RPT = BNR ? BM * (BN / 8) / NT : 1;
-        uint4 yq[RPT];
+        uint4 yq[RPT], xq[BNM == 2 ? RPT : 1];
         if constexpr (BNR) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
@@ -304,6 +359,11 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
                 yq[k] = make_uint4(0u, 0u, 0u, 0u);
                 if (opix >= 0 && co < g.Co)
                     yq[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bn_y) + (long long)opix * a.bn_ld + co);
+                if constexpr (BNM == 2) {
+                    xq[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (opix >= 0 && co < g.Co && a.bn_accumulate)
+                        xq[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.bn_acc) + (long long)opix * a.bn_acc_ld + co);
+                }
             }
         }
         // ---- epilogue: bias, round, stats, stage to LDS ------------------------------------------
@@ -373,7 +433,7 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
             const int co = n_base + cc * EPC;
             if (opix >= 0 && co < g.Co) {
                 const uint4 gv = *reinterpret_cast<const uint4*>(sOut + row * OUT_ROW + cc * 16);
-                *reinterpret_cast<uint4*>(outT + (long long)opix * g.ld_out + co) = gv;
+                if constexpr (BNM == 0) *reinterpret_cast<uint4*>(outT + (long long)opix * g.ld_out + co) = gv;
                 if constexpr (BNR) {
                     // dz = round(g * act'(z)), z = (y - mean) * scale + shift: bn_act_bwd_reduce_kernel's arithmetic on the
                     // ROUNDED gradient this launch stores
@@ -391,6 +451,31 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
                     load8(sStat + cc * 8, bmu);
                     load8(sStat + BN + cc * 8, bsc);
                     load8(sStat + 2 * BN + cc * 8, bsh);
+                    if constexpr (BNM == 2) {
+                        // bn_bwd_apply_kernel's arithmetic (norm_act.hip: bn_dz_elem, bn_apply_elem, the ACC form's rounded add)
+                        float aa[8], ac1[8], ac2[8], ais[8], old[8], o8[8];
+                        load8(sApp + cc * 8, aa);
+                        load8(sApp + BN + cc * 8, ac1);
+                        load8(sApp + 2 * BN + cc * 8, ac2);
+                        load8(sApp + 3 * BN + cc * 8, ais);
+                        const uint4 xv = xq[k];
+                        old[0] = __uint_as_float(xv.x << 16); old[1] = __uint_as_float(xv.x & 0xffff0000u);
+                        old[2] = __uint_as_float(xv.y << 16); old[3] = __uint_as_float(xv.y & 0xffff0000u);
+                        old[4] = __uint_as_float(xv.z << 16); old[5] = __uint_as_float(xv.z & 0xffff0000u);
+                        old[6] = __uint_as_float(xv.w << 16); old[7] = __uint_as_float(xv.w & 0xffff0000u);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float z = (yf[e] - bmu[e]) * bsc[e] + bsh[e] + 0.f;
+                            const float dv = bf16_bits_to_f32(f32_to_bf16_bits(gq8[e] * 1.f * (z > 0.f ? 1.f : bneg)));
+                            const float yh = (yf[e] - bmu[e]) * ais[e];
+                            const float dy = bf16_bits_to_f32(f32_to_bf16_bits(aa[e] * (dv - ac1[e] - yh * ac2[e])));
+                            o8[e] = a.bn_accumulate ? __fadd_rn(old[e], dy) : dy;
+                        }
+                        uint4 ov;
+                        ov.x = pack2bf(o8[0], o8[1]); ov.y = pack2bf(o8[2], o8[3]);
+                        ov.z = pack2bf(o8[4], o8[5]); ov.w = pack2bf(o8[6], o8[7]);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(a.bn_acc) + (long long)opix * a.bn_acc_ld + co) = ov;
+                    } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float yc = yf[e] - bmu[e];
@@ -399,11 +484,12 @@ __global__ __launch_bounds__(NT) void conv_fprop_kernel(const FpropArgs a) {
                         bs1[e] += dv;
                         bs2[e] += dv * yc;
                     }
+                    }
                 }
             }
         }
     }
-    if constexpr (BNR) {
+    if constexpr (BNR && BNM != 2) {
         // fixed-order block reduction (the threads of a channel chunk are tid = cc + k * OC), one fp64 atomic per channel
         constexpr int OC = BN / 8;
         __syncthreads();
@@ -1377,8 +1463,13 @@ int launch_fprop(FpropArgs& a, hipStream_t stream) {
     static int attr_rc = [] {
         int rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN>, smem);
         if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, true>, smem);
-        if constexpr (sizeof(T) == 2)
+        if constexpr (sizeof(T) == 2) {
             if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, false, true>, smem);
+            if constexpr (BN == 64) {         // (the two-launch form of a dense layer's data gradient: 64-channel tiles only)
+                if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, false, true, 1>, smem);
+                if (rc == 0) rc = set_smem(conv_fprop_kernel<T, BM, BN, WM, WN, false, true, 2>, smem);
+            }
+        }
         return rc;
     }();
     if (attr_rc) return attr_rc;
@@ -1394,10 +1485,20 @@ int launch_fprop(FpropArgs& a, hipStream_t stream) {
     a.GM = gm;
     const int grid = a.GM * a.NTL;
     if (a.bn_y != nullptr) {
-        if constexpr (sizeof(T) == 2)
-            hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, false, true>), dim3(grid), dim3(NT), smem, stream, a);
-        else
+        if constexpr (sizeof(T) == 2) {
+            if (a.bn_mode == 0) {
+                hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, false, true>), dim3(grid), dim3(NT), smem, stream, a);
+            } else if constexpr (BN == 64) {
+                if (a.bn_mode == 1)
+                    hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, false, true, 1>), dim3(grid), dim3(NT), smem, stream, a);
+                else
+                    hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, false, true, 2>), dim3(grid), dim3(NT), smem, stream, a);
+            } else {
+                return SEGNB_E_UNSUPPORTED;
+            }
+        } else {
             return SEGNB_E_UNSUPPORTED;
+        }
     } else if (a.ep_act >= 0)
         hipLaunchKernelGGL((conv_fprop_kernel<T, BM, BN, WM, WN, true>), dim3(grid), dim3(NT), smem, stream, a);
     else
@@ -1479,7 +1580,7 @@ int check_geom(const segnb_conv_geom* g) {
 
 static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
                            int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep,
-                           const segnb_bn_reduce_epilogue* bn = nullptr);
+                           const segnb_bn_reduce_epilogue* bn = nullptr, const segnb_bn_apply_epilogue* ap = nullptr, int bn_mode = 0);
 
 extern "C" int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
                                 const float* bias, int bias_n, void* out, double* stats,
@@ -1498,11 +1599,14 @@ extern "C" int segnb_conv_fprop_act(const segnb_conv_geom* g, int dtype, const v
 
 static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
                            int bias_n, void* out, double* stats, segnb_stream_t stream, const segnb_act_epilogue* ep,
-                           const segnb_bn_reduce_epilogue* bn) {
+                           const segnb_bn_reduce_epilogue* bn, const segnb_bn_apply_epilogue* ap, int bn_mode) {
     if (int rc = check_geom(g)) return rc;
-    SEGNB_CHECK_ARG(in && wpacked && out, "NULL tensor");
+    SEGNB_CHECK_ARG(in && wpacked && (out || bn_mode != 0), "NULL tensor");
     FpropArgs a;
     a.bn_y = nullptr;
+    a.bn_mode = bn_mode;
+    a.bn_acc = nullptr;
+    a.bn_accumulate = 0;
     if (bn != nullptr) {          // (the general kernel's BatchNorm-reduce store pass: segnb_conv_fprop_bnreduce)
         a.bn_y = bn->y;
         a.bn_ld = bn->ld_y;
@@ -1510,6 +1614,23 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         a.bn_sums = bn->sums;
         a.bn_act = bn->act;
         a.bn_slope = bn->slope;
+    }
+    if (ap != nullptr) {          // (segnb_conv_fprop_bnapply)
+        a.bn_y = ap->y;
+        a.bn_ld = ap->ld_y;
+        a.bn_coef = ap->coef;
+        a.bn_sums = const_cast<double*>(ap->sums);
+        a.bn_act = ap->act;
+        a.bn_slope = ap->slope;
+        a.bn_count = ap->count;
+        a.bn_gamma = ap->gamma;
+        a.bn_C = ap->C;
+        a.bn_bcoef = ap->bcoef;
+        a.bn_dgamma = ap->dgamma;
+        a.bn_dbeta = ap->dbeta;
+        a.bn_acc = ap->dx;
+        a.bn_acc_ld = ap->ld_dx;
+        a.bn_accumulate = ap->accumulate;
     }
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;
@@ -1535,7 +1656,7 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: image halo tile staged once in LDS, all taps from shifted rows (fprop_s1.hip)
         static const bool general_env = getenv("SEGNB_FPROP_GENERAL") != nullptr;   // A/B testing only
-        const bool general_only = general_env || bn != nullptr;
+        const bool general_only = general_env || bn != nullptr || ap != nullptr;
         // (the affine + activation epilogue lives in the c8, rw, ws and general kernels: s1 is skipped for it)
         rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
         if (rc == 0 && !general_only && ep == nullptr)
@@ -1811,6 +1932,39 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     }
     SEGNB_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- a dense layer's data gradient that is never stored (include/segnb_hip.h): two launches of the general kernel
+extern "C" int segnb_conv_fprop_bnapply_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || !segnb_knob_bnreduce_fused()) return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Co % 8 != 0 || g->Co <= 32) return 0;      // (64-channel tiles)
+    return bnreduce_general(g) ? 1 : 0;
+}
+
+extern "C" int segnb_conv_fprop_bnsums(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                                       const segnb_bn_reduce_epilogue* ep, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_bnsums, g, dtype, in, wpacked, ep, stream);
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && wpacked && ep && ep->y && ep->coef && ep->sums, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_bnapply_ok(g, dtype), "geometry not served (segnb_conv_fprop_bnapply_ok)");
+    SEGNB_CHECK_ARG(ep->ld_y >= g->Co && ep->ld_y % 8 == 0 && (((long long)g->N * g->Ho * g->Wo - 1) * ep->ld_y + g->Co) * 2 < (1ll << 31),
+                    "bad y");
+    return conv_fprop_impl(g, dtype, in, wpacked, nullptr, 0, nullptr, nullptr, stream, nullptr, ep, nullptr, 1);
+}
+
+extern "C" int segnb_conv_fprop_bnapply(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked,
+                                        const segnb_bn_apply_epilogue* ep, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_bnapply, g, dtype, in, wpacked, ep, stream);
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && wpacked && ep && ep->y && ep->coef && ep->sums && ep->dx, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_bnapply_ok(g, dtype), "geometry not served (segnb_conv_fprop_bnapply_ok)");
+    SEGNB_CHECK_ARG(ep->C > 0 && ep->C <= g->Co && ep->count > 0.0, "bad channel count / pixel count");
+    SEGNB_CHECK_ARG(ep->ld_y >= g->Co && ep->ld_y % 8 == 0 && (((long long)g->N * g->Ho * g->Wo - 1) * ep->ld_y + g->Co) * 2 < (1ll << 31),
+                    "bad y");
+    SEGNB_CHECK_ARG(ep->ld_dx >= g->Co && ep->ld_dx % 8 == 0 && (((long long)g->N * g->Ho * g->Wo - 1) * ep->ld_dx + g->Co) * 2 < (1ll << 31),
+                    "bad dx");
+    return conv_fprop_impl(g, dtype, in, wpacked, nullptr, 0, nullptr, nullptr, stream, nullptr, nullptr, ep, 2);
 }
 
 static bool wgrad_general_only() {

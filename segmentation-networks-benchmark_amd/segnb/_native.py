@@ -39,6 +39,13 @@ class BnReduceEpilogue(ctypes.Structure):
                 ('slope', c_float)]
 
 
+class BnApplyEpilogue(ctypes.Structure):
+    """segnb_bn_apply_epilogue"""
+    _fields_ = [('y', c_void_p), ('ld_y', c_int), ('coef', c_void_p), ('sums', c_void_p), ('gamma', c_void_p), ('C', c_int),
+                ('count', ctypes.c_double), ('bcoef', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('act', c_int),
+                ('slope', c_float), ('dx', c_void_p), ('ld_dx', c_int), ('accumulate', c_int)]
+
+
 class ActEpilogue(ctypes.Structure):
     """segnb_act_epilogue"""
     _fields_ = [('coef', c_void_p), ('act', c_int), ('slope', c_float)]
@@ -74,6 +81,8 @@ SIGNATURES = {
     'segnb_conv_fprop_upsum': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(UpcatSrc), _P],
     'segnb_conv_wgrad_upcat': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(UpcatSrc), _P, _P, c_int, _P],
     'segnb_conv_fprop_bnreduce': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
+    'segnb_conv_fprop_bnsums': [ctypes.POINTER(ConvGeom), c_int, _P, _P, ctypes.POINTER(BnReduceEpilogue), _P],
+    'segnb_conv_fprop_bnapply': [ctypes.POINTER(ConvGeom), c_int, _P, _P, ctypes.POINTER(BnApplyEpilogue), _P],
     'segnb_conv_fprop_tf': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(OperandTf), _P, _P, c_int, _P, _P,
                             ctypes.POINTER(BnReduceEpilogue), _P],
     'segnb_conv_wgrad_tf': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(OperandTf), _P, ctypes.POINTER(OperandTf), _P,
@@ -174,7 +183,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_pair_job_bytes': (c_int, []), 'segnb_pack_pair_job_blocks': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_pack_elem_job_blocks': (c_int, [c_int, c_int, c_int]), 'segnb_bias_grad_job_bytes': (c_int, []), 'segnb_head_fused_ok': (c_int, [c_int, c_int]), 'segnb_head_conv_ok': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_conv_fprop_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_actmask_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_pair_job_bytes': (c_int, []), 'segnb_pack_pair_job_blocks': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_pack_elem_job_blocks': (c_int, [c_int, c_int, c_int]), 'segnb_bias_grad_job_bytes': (c_int, []), 'segnb_head_fused_ok': (c_int, [c_int, c_int]), 'segnb_head_conv_ok': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_conv_fprop_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_actmask_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

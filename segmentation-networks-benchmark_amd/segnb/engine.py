@@ -529,6 +529,33 @@ class ConvOp(object):
         g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, dxv.H, dxv.W, self.Cip, dxv.ld)
         return bool(nv.query('segnb_conv_fprop_bnreduce_ok', g, self.rt.code))
 
+    def dgrad_bnapply_ok(self, dyv, N, H, W, ld):
+        """True when this data gradient can run as the two launches that never store it (segnb_conv_fprop_bnsums / _bnapply: a dense
+        layer's 16 -> prefix gradient); N, H, W, ld: the input tensor's geometry (the gradient itself gets no buffer)."""
+        p = self.plan(H, W)
+        if not self.need_dgrad or len(p['dg']) != 1 or not p['dg_full']:
+            return False
+        g = self._geom(p, 'd', 0, p['dg'][0], dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, H, W, self.Cip, ld)
+        return bool(nv.query('segnb_conv_fprop_bnapply_ok', g, self.rt.code))
+
+    def dgrad_bnsums(self, dyv, H, W, bn_reduce):
+        """first launch: the BatchNorm-backward sums of the layer whose activation gradient this data gradient is; nothing stored"""
+        p, rt = self.plan(H, W), self.rt
+        l = p['dg'][0]
+        yv, coef, sums, act, slope = bn_reduce
+        g = self._geom(p, 'd', 0, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, H, W, self.Cip, yv.ld)
+        ep = nv.BnReduceEpilogue(yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(sums), act, slope)
+        _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_bnsums', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][0]), ep, rt.stream))
+
+    def dgrad_bnapply(self, dyv, H, W, ep):
+        """second launch (ep: nv.BnApplyEpilogue): the gradient recomputed, BatchNorm backward applied, written / added to ep.dx"""
+        p, rt = self.plan(H, W), self.rt
+        l = p['dg'][0]
+        g = self._geom(p, 'd', 0, l, dyv.N, dyv.H, dyv.W, self.Cop, dyv.ld, H, W, self.Cip, ep.ld_dx)
+        _timed('conv_fprop', 2.0 * dyv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_bnapply', g, rt.code, dyv.ptr, nv.ptr(p['wp_dg'][0]), ep, rt.stream))
+
     def dgrad_actmask_ok(self, dyv, dxv):
         """True when this data gradient can apply the activation mask of the conv + activation (no BatchNorm) that produced its
         input and store dz (segnb_conv_fprop_bnreduce with coef None)."""
@@ -945,6 +972,9 @@ class UpCatConvOp(object):
         return False
 
     def dgrad_actmask_ok(self, dyv, dxv):
+        return False
+
+    def dgrad_bnapply_ok(self, *a):
         return False
 
     # ---- backward, by segment

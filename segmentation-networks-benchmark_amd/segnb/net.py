@@ -34,11 +34,15 @@ class Act(object):
     coef None: the tensor is act(conv) WITHOUT BatchNorm (y = the activated tensor itself); a consumer that can apply act' while it
     writes the gradient (the classifier heads: segnb_head_conv_bwd) then stores dz itself and sums it into `sums` -- g_is_dz then
     means .g IS dz and the producer's segnb_bn_act_bwd_reduce pass is skipped."""
-    __slots__ = ('v', '_g', '_g2', '_settle', 'needs_grad', 'consumers', 'producer', 'g_is_dz')
+    __slots__ = ('v', '_g', '_g2', '_settle', 'needs_grad', 'consumers', 'producer', 'g_is_dz', 'lazy_ok', 'lazy_dgrad')
 
     def __init__(self, v, needs_grad=True):
         self.v, self._g, self._g2, self._settle, self.needs_grad = v, None, None, None, needs_grad
         self.consumers, self.producer, self.g_is_dz = 0, None, False
+        # lazy_ok: the producer (a pre-activation BatchNorm, _bn_act_core) can take its gradient as "recompute it": lazy_dgrad =
+        # (ConvOp, dy View) set by the ONE consumer's _data_gradient, which then only ran the sums launch -- the gradient tensor
+        # itself never exists (segnb_conv_fprop_bnsums / _bnapply)
+        self.lazy_ok, self.lazy_dgrad = False, None
 
     # The gradient.  A SECOND contribution is held back (Tape.contribute: _g2 + the launch that would add it): the convolution units
     # hand both sources to their reduction pass (segnb_bn_act_bwd_reduce_add) instead of an add pass over three tensors; any other
@@ -206,6 +210,12 @@ class Tape(object):
     fold_head_mask = True
     # fuse_act_pool = False: conv -> ReLU -> MaxPool2d(2) without BatchNorm as convolution + one pass that activates and pools (A/B)
     fuse_act_pool = True
+    # two_launch_dgrad = True: a dense layer's 16 -> prefix data gradient is never stored -- one launch for the BatchNorm-backward sums,
+    # one that recomputes it and applies the BatchNorm backward (segnb_conv_fprop_bnsums / _bnapply).  OFF: measured on MI355X
+    # (profiles/r05_ab.txt) FCDenseNet103 16.23 ms per step with it against 15.74 without -- the general kernel is not a streaming
+    # engine at K = 144 (its plain launch writes at 1.8 TB/s, the reduction store pass adds 70 % whether or not it stores), so running
+    # it twice costs more than the two tensor transits it saves
+    two_launch_dgrad = False
 
     def consume(self, *acts):
         """An operator of the forward reads these tensors (each will receive one gradient contribution from it)."""
@@ -458,8 +468,14 @@ def _data_gradient(tape, conv, x, dy, site):
     (segnb_conv_fprop_bnreduce, as ZF_UNET's second convolutions do: linknet.py:41-62 via dilated_resnet's BasicBlock): the
     producer then skips its reduction pass."""
     xv = x.v
-    dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
     pr = x.producer
+    if (pr is not None and pr[1] is not None and x.lazy_ok and tape.fuse_reduce and Tape.two_launch_dgrad and x.consumers == 1
+            and x.g is None and x.needs_grad and conv.dgrad_bnapply_ok(dy, xv.N, xv.H, xv.W, xv.ld)):
+        conv.dgrad_bnsums(dy, xv.H, xv.W, pr)
+        x.lazy_dgrad = (conv, dy)
+        x.g_is_dz = True
+        return
+    dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
     if pr is not None and pr[1] is None:
         # activation without BatchNorm (linknet.py:58-61): the data gradient stores dz = g * act'(a) and sums it where a fused kernel
         # serves the shape; the producer then skips its mask pass (Act.g_is_dz)
@@ -765,9 +781,12 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None, stats_src
         # the ONE consumer's data gradient may do this layer's BatchNorm-backward reduction in its store pass (_data_gradient:
         # a dense layer's 16 -> prefix data gradient, tiramisu.py:9-20); the sums buffer was cleared by the fused forward above
         oa.producer = (xv, coef, tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64), act, slope)
+        # ... or never store that gradient at all: sums launch now, recompute + apply in this layer's backward (nothing else to
+        # clear there: the statistics are the concat buffer's cached ones)
+        oa.lazy_ok = cached
 
     def backward():
-        if oa.g is None:
+        if oa.lazy_dgrad is None and oa.g is None:
             if fused and not cached:
                 stats.zero_()
                 tape.unplannable = True
@@ -775,6 +794,18 @@ def _bn_act_core(tape, x, fields, grads_of, act, slope, tag, out=None, stats_src
         flat = tape.flat
         sums = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
         bcoef = tape.small(site + '/bcoef', (3, Cp), torch.float32)
+        if oa.lazy_dgrad is not None:
+            conv2, dyv = oa.lazy_dgrad
+            oa.lazy_dgrad, oa.g_is_dz = None, False
+            acc = x.needs_grad and x.g is not None
+            dst = x.g if acc else tape.view(site + '/dz', N, H, W, Cp)
+            ep = nv.BnApplyEpilogue(xv.ptr, xv.ld, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma.detach()), C, float(N * H * W),
+                                    nv.ptr(bcoef), nv.ptr(grads_of()[0]), nv.ptr(grads_of()[1]), act, slope, dst.ptr, dst.ld,
+                                    1 if acc else 0)
+            conv2.dgrad_bnapply(dyv, H, W, ep)
+            if not acc:
+                tape.contribute(x, dst)
+            return
         if fused:
             # ONE gradient source, no dropout, no residual: dz never goes to memory -- a sums-only reduction (done by the
             # consumer's data gradient where a fused kernel serves it: oa.g_is_dz), then the apply launch recomputes

@@ -1480,6 +1480,87 @@ def test_conv_dgrad_with_act_mask(shape):
         np.testing.assert_allclose(a[0] / scale, s_e[0] / scale, atol=2e-3)
 
 
+@pytest.mark.parametrize('accumulate', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 24, 40, 112, 16, 1), (3, 9, 11, 48, 16, 2), (8, 8, 8, 1072, 16, 1), (8, 16, 16, 656, 16, 1),
+                                   (2, 17, 23, 72, 12, 1), (8, 128, 128, 272, 16, 1)], ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_dgrad_never_stored(shape, accumulate):
+    """segnb_conv_fprop_bnsums + segnb_conv_fprop_bnapply (a dense layer's 16 -> prefix data gradient as two launches that never
+    store it, tiramisu.py:9-20) against segnb_conv_fprop_bnreduce + segnb_bn_bwd_apply_fused_direct(_acc): the same sums, the same
+    dx up to the rare element whose z or product rounds the other way in the other kernel, the same dgamma / dbeta / bcoef."""
+    N, H, W, C1, C2, act = shape           # layer 1: BatchNorm(C1) + act (pre-activation);  layer 2: conv C1 -> C2
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 7 + C1)
+    w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    op = ConvOp(rt, w2, None, [(C1, C1)], 1, 1, False, True)
+    op.pack(H, W)
+    dyv = View.alloc(rt, N, H, W, op.Cop)
+    dyv.t.normal_()
+    y1 = View.alloc(rt, N, H, W, C1)
+    y1.t.normal_()
+    coef = torch.stack([0.5 + torch.rand(C1, generator=gen), 0.3 * torch.randn(C1, generator=gen),
+                        0.2 * torch.randn(C1, generator=gen), 0.5 + torch.rand(C1, generator=gen)]).cuda().contiguous()
+    Creal = C1 - 3                          # (the last three channels are padding: dx = 0 there)
+    gamma = (0.5 + torch.rand(Creal, generator=gen)).cuda()
+    st = rt.stream
+    old = View.alloc(rt, N, H, W, C1)
+    old.t.normal_()
+    count = float(N * H * W)
+
+    # reference: stored gradient + reduction, then the fused apply
+    g_ref = View.alloc(rt, N, H, W, C1)
+    sums_ref = rt.zeros((16, 2, C1), torch.float64)
+    op.dgrad(dyv, g_ref, bn_reduce=(y1, coef, sums_ref, act, 0.01))
+    dx_ref = View.alloc(rt, N, H, W, C1)
+    dx_ref.t.copy_(old.t)
+    bc_ref, dg_ref, db_ref = rt.zeros((3, C1), torch.float32), torch.ones(Creal, device='cuda'), torch.ones(Creal, device='cuda')
+    nv.call('segnb_bn_bwd_apply_fused_direct_acc' if accumulate else 'segnb_bn_bwd_apply_fused_direct', rt.code, y1.ptr, y1.ld,
+            N, H, W, Creal, C1, nv.ptr(coef), nv.ptr(sums_ref), nv.ptr(gamma), nv.ptr(bc_ref), nv.ptr(dg_ref), nv.ptr(db_ref), 1, None,
+            act, 0.01, g_ref.ptr, g_ref.ld, dx_ref.ptr, dx_ref.ld, st)
+
+    # the two launches
+    assert op.dgrad_bnapply_ok(dyv, N, H, W, y1.ld)
+    sums = rt.zeros((16, 2, C1), torch.float64)
+    op.dgrad_bnsums(dyv, H, W, (y1, coef, sums, act, 0.01))
+    dx = View.alloc(rt, N, H, W, C1)
+    dx.t.copy_(old.t)
+    bc, dg, db = rt.zeros((3, C1), torch.float32), torch.ones(Creal, device='cuda'), torch.ones(Creal, device='cuda')
+    ep = nv.BnApplyEpilogue(y1.ptr, y1.ld, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma), Creal, count, nv.ptr(bc), nv.ptr(dg), nv.ptr(db),
+                            act, 0.01, dx.ptr, dx.ld, accumulate)
+    op.dgrad_bnapply(dyv, H, W, ep)
+    torch.cuda.synchronize()
+    a, b = sums.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * float(np.abs(b).max()))       # (the same code, another block order)
+    assert torch.equal(sums.sum(0), sums.sum(0)) and float(sums.abs().sum()) > 0           # (read, not cleared)
+    np.testing.assert_allclose(bc.cpu().numpy(), bc_ref.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    x, r = dx.t.float(), dx_ref.t.float()
+    diff = (x - r).abs()
+    nbad = int((diff > 0).sum())
+    assert nbad <= max(4, x.numel() // 2000), (nbad, x.numel())
+    assert float(diff.max()) <= 2.0 ** -6 * float(r.abs().max()) + 1e-6
+    assert float(x.view(N, H, W, C1)[..., Creal:].abs().max()) == (float(old.t.float().view(N, H, W, C1)[..., Creal:].abs().max()) if accumulate else 0.0)
+    if N * H * W <= 20000:
+        def run_emu():
+            r_ = Runtime('cpu', 'bf16')
+            ope = ConvOp(r_, w2.cpu(), None, [(C1, C1)], 1, 1, False, True)
+            ope.pack(H, W)
+            dye, ye, dxe = View.alloc(r_, N, H, W, ope.Cop), View.alloc(r_, N, H, W, C1), View.alloc(r_, N, H, W, C1)
+            dye.t.copy_(dyv.t.cpu()); ye.t.copy_(y1.t.cpu()); dxe.t.copy_(old.t.cpu())
+            se, ce, ge = r_.zeros((16, 2, C1), torch.float64), coef.cpu(), gamma.cpu()
+            ope.dgrad_bnsums(dye, H, W, (ye, ce, se, act, 0.01))
+            bce, dge, dbe = r_.zeros((3, C1), torch.float32), torch.ones(Creal), torch.ones(Creal)
+            epe = nv.BnApplyEpilogue(ye.ptr, ye.ld, nv.ptr(ce), nv.ptr(se), nv.ptr(ge), Creal, count, nv.ptr(bce), nv.ptr(dge),
+                                     nv.ptr(dbe), act, 0.01, dxe.ptr, dxe.ld, accumulate)
+            ope.dgrad_bnapply(dye, H, W, epe)
+            return dxe.t.float(), dge, dbe
+        with on_emulator():
+            dx_e, dg_e, db_e = run_emu()
+        check('dx vs emulator', dx.t, dx_e, 'bf16')
+        np.testing.assert_allclose(dg.cpu().numpy(), dg_e.numpy(), rtol=2e-3, atol=2e-3 * float(dg_e.abs().max()))
+        np.testing.assert_allclose(db.cpu().numpy(), db_e.numpy(), rtol=2e-3, atol=2e-3 * float(db_e.abs().max()))
+
+
 ACT_EP_CASES = [
     # name,                 N, H,  W,  segs,               Co, k, s, p, transposed
     ('ws 64->64 relu',      2, 24, 40, [(64, 64)],         64, 3, 1, 1, False),
