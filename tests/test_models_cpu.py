@@ -42,6 +42,45 @@ def test_tiramisu_product_vs_reference_golden(golden_dir):
     mc.check_tiramisu_golden(m, g, 'cpu')
 
 
+def test_tiramisu_with_never_stored_data_gradients(monkeypatch):
+    """The optional two-launch form of the dense layers' data gradients (Tape.two_launch_dgrad: segnb_conv_fprop_bnsums / _bnapply,
+    off by default) gives the gradients of the stored form, and is actually taken (prefixes of more than 32 channels)."""
+    from lib.models.tiramisu import FCDenseNet
+    from lib.losses import BCEWithSigmoidLoss
+    from segnb import net as NN
+    cfg = dict(in_channels=3, down_blocks=(2, 2), up_blocks=(2, 2), bottleneck_layers=2, growth_rate=16, out_chans_first_conv=48,
+               n_classes=1)
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    y = (torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(6)) > 0.5).long()
+
+    def run(flag):
+        monkeypatch.setattr(NN.Tape, 'two_launch_dgrad', flag)
+        torch.manual_seed(3)
+        m = FCDenseNet(**cfg)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout2d):
+                mod.p = 0.0
+        m.set_compute_dtype('bf16').train()          # (the two launches are bf16 kernels)
+        seen = []
+        orig = nv.call
+
+        def call(name, *a):
+            seen.append(name)
+            return orig(name, *a)
+        monkeypatch.setattr(nv, 'call', call)
+        (2 * BCEWithSigmoidLoss()(m(x), y)).backward()
+        monkeypatch.setattr(nv, 'call', orig)
+        return {n: p.grad.clone() for n, p in m.named_parameters()}, seen
+
+    g0, s0 = run(False)
+    g1, s1 = run(True)
+    assert s0.count('segnb_conv_fprop_bnsums') == 0
+    assert s1.count('segnb_conv_fprop_bnsums') >= 4 and s1.count('segnb_conv_fprop_bnsums') == s1.count('segnb_conv_fprop_bnapply')
+    for n in g0:
+        scale = max(float(g0[n].abs().max()), 1e-6)
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-5 * scale, n      # (the emulator composes both forms from the same passes)
+
+
 def test_fcdensenet57_product_vs_reference_golden(golden_dir):
     """FCDenseNet57(n_classes) of tiramisu.py:187-191 -- growth rate 12, every slice of the concat buffers padded to 16
     channels, BatchNorm per slice -- against the fixture the reference's own FCDenseNet57 produced (make_golden.py)"""
