@@ -123,6 +123,11 @@ int segnb_knob_fprop_nostats();   // 1: launches without statistics run the stat
 int segnb_knob_rw_store_waves();  // 2 or 4 store waves in conv_fprop_rw_kernel
 int segnb_knob_bnreduce_fused();  // 1: segnb_conv_fprop_bnreduce_ok may say yes
 int segnb_knob_fprop_deepk();     // 1: conv_fprop_deepk_kernel serves the shapes it applies to
+int segnb_knob_fprop_thin();      // 1: conv_thin_kernel (fprop_thin.hip) serves <= 16 -> >= 48 channel stride-1 3x3 launches
+// 1 = launched, 0 = not served (fprop_thin.hip); bn: the BatchNorm-backward reduction epilogue of segnb_conv_fprop_bnreduce or NULL
+int segnb_fprop_thin_try(const segnb_conv_geom* g, const void* in, const void* wpacked, void* out, hipStream_t stream,
+                         const segnb_bn_reduce_epilogue* bn);
+int segnb_fprop_thin_ok(const segnb_conv_geom* g);
 int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();

@@ -1659,6 +1659,8 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         const bool general_only = general_env || bn != nullptr || ap != nullptr;
         // (the affine + activation epilogue lives in the c8, rw, ws and general kernels: s1 is skipped for it)
         rc = general_only ? 0 : segnb_fprop_c8_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, ep);
+        if (rc == 0 && !general_env && ap == nullptr && bn_mode == 0 && out != nullptr && ep == nullptr && stats == nullptr && bias == nullptr)
+            rc = segnb_fprop_thin_try(g, in, wpacked, out, (hipStream_t)stream, bn);      // (thin input, wide output; bn or plain)
         if (rc == 0 && !general_only && ep == nullptr)
             rc = segnb_fprop_roll_try(g, in, a.in_bytes, wpacked, a.w_bytes, bias, bias_n, out, stats, (hipStream_t)stream);
         if (rc == 0 && !general_only)

@@ -303,6 +303,8 @@ int segnb_knob_fprop_deepk() {
     }
     return g_fprop_deepk;
 }
+static int g_fprop_thin = 1;       // thin input (<= 16 channels), wide output: conv_thin_kernel (tune key only: tests, A/B)
+int segnb_knob_fprop_thin() { return g_fprop_thin; }
 static int g_fprop_mf16 = -2;      // conv_fprop_ws_kernel on v_mfma_f32_16x16x32_bf16 (1, default) or 32x32x16 (0)
 int segnb_knob_fprop_mf16() {
     if (g_fprop_mf16 == -2) {
@@ -410,6 +412,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "fprop_deepk") == 0) {
         g_fprop_deepk = value ? 1 : 0;
+        return 0;
+    }
+    if (strcmp(key, "fprop_thin") == 0) {
+        g_fprop_thin = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_mf16") == 0) {

@@ -1506,10 +1506,16 @@ def test_conv_dgrad_never_stored(shape, accumulate):
     old.t.normal_()
     count = float(N * H * W)
 
-    # reference: stored gradient + reduction, then the fused apply
+    # reference: stored gradient + reduction, then the fused apply -- on the general kernel, which the two launches run on (the thin
+    # kernel that normally serves the stored form adds the products in another order)
     g_ref = View.alloc(rt, N, H, W, C1)
     sums_ref = rt.zeros((16, 2, C1), torch.float64)
-    op.dgrad(dyv, g_ref, bn_reduce=(y1, coef, sums_ref, act, 0.01))
+    nv.call('segnb_tune', b'fprop_thin', 0)
+    try:
+        op.dgrad(dyv, g_ref, bn_reduce=(y1, coef, sums_ref, act, 0.01))
+        torch.cuda.synchronize()
+    finally:
+        nv.call('segnb_tune', b'fprop_thin', 1)
     dx_ref = View.alloc(rt, N, H, W, C1)
     dx_ref.t.copy_(old.t)
     bc_ref, dg_ref, db_ref = rt.zeros((3, C1), torch.float32), torch.ones(Creal, device='cuda'), torch.ones(Creal, device='cuda')
@@ -1559,6 +1565,50 @@ def test_conv_dgrad_never_stored(shape, accumulate):
         check('dx vs emulator', dx.t, dx_e, 'bf16')
         np.testing.assert_allclose(dg.cpu().numpy(), dg_e.numpy(), rtol=2e-3, atol=2e-3 * float(dg_e.abs().max()))
         np.testing.assert_allclose(db.cpu().numpy(), db_e.numpy(), rtol=2e-3, atol=2e-3 * float(db_e.abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 40, 112, 16, 1), (3, 9, 11, 48, 16, 2), (8, 8, 8, 1072, 16, 1), (8, 16, 16, 656, 16, 1),
+                                   (2, 33, 17, 200, 8, 2), (8, 128, 128, 272, 16, 1), (8, 256, 256, 112, 16, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_thin_kernel_vs_general(shape):
+    """conv_thin_kernel (fprop_thin.hip: <= 16 -> >= 48 channels, a dense layer's data gradient, tiramisu.py:9-20) against the general
+    gather kernel: the gradient to bf16 rounding of another summation order, the BatchNorm-backward sums of its fused epilogue equal
+    to the reduction pass run on ITS output; plain and fused launches store the same bits; channel splits (few pixels) included."""
+    N, H, W, C1, C2, act = shape
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 5 + C1)
+    w2 = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    op = ConvOp(rt, w2, None, [(C1, C1)], 1, 1, False, True)
+    op.pack(H, W)
+    dyv = View.alloc(rt, N, H, W, op.Cop)
+    dyv.t.normal_()
+    y1 = View.alloc(rt, N, H, W, C1)
+    y1.t.normal_()
+    coef = torch.stack([0.5 + torch.rand(C1, generator=gen), 0.3 * torch.randn(C1, generator=gen),
+                        0.2 * torch.randn(C1, generator=gen), 0.5 + torch.rand(C1, generator=gen)]).cuda().contiguous()
+    st = rt.stream
+    g_gen = View.alloc(rt, N, H, W, C1)
+    nv.call('segnb_tune', b'fprop_thin', 0)
+    try:
+        op.dgrad(dyv, g_gen)
+        torch.cuda.synchronize()
+    finally:
+        nv.call('segnb_tune', b'fprop_thin', 1)
+    g_plain, g_f = View.alloc(rt, N, H, W, C1), View.alloc(rt, N, H, W, C1)
+    g_plain.t.fill_(3.0); g_f.t.fill_(5.0)
+    op.dgrad(dyv, g_plain)
+    sums_f, sums_f2 = rt.zeros((16, 2, C1), torch.float64), rt.zeros((16, 2, C1), torch.float64)
+    op.dgrad(dyv, g_f, bn_reduce=(y1, coef, sums_f, act, 0.01))
+    op.dgrad(dyv, g_f, bn_reduce=(y1, coef, sums_f2, act, 0.01))
+    sums_ref = rt.zeros((16, 2, C1), torch.float64)
+    nv.call('segnb_bn_act_bwd_reduce', rt.code, y1.ptr, y1.ld, N, H, W, C1, nv.ptr(coef), act, 0.01, None, g_plain.ptr, g_plain.ld,
+            None, 0, None, 0, None, 0, nv.ptr(sums_ref), None, 0, st)
+    torch.cuda.synchronize()
+    check('thin vs general', g_plain.t, g_gen.t, 'bf16')
+    assert torch.equal(g_plain.t, g_f.t)
+    a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
+    np.testing.assert_allclose(sums_f2.sum(0).cpu().numpy(), a, rtol=1e-12, atol=1e-9)       # fixed order inside a block
 
 
 ACT_EP_CASES = [
