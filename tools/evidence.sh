@@ -42,6 +42,8 @@ python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
 python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1
 python3 tools/c8_bench.py > $O/${TAG}_c8_bench.txt 2>&1
 python3 tools/pack_bench.py > $O/${TAG}_pack_bench.txt 2>&1
+python3 tools/head_bench.py > $O/${TAG}_head_bench.txt 2>&1
+python3 tools/dense_dgrad_bench.py > $O/${TAG}_dense_dgrad_bench.txt 2>&1
 python3 tools/step_ramp.py > $O/${TAG}_step_ramp.txt 2>&1
 # cross-stream fork: cost of the marker packet vs an event on the kernel's own dispatch, and the ordering check
 mkdir -p tools/_bin
