@@ -375,6 +375,12 @@ int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int H, int W, i
 int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
                       int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
                       segnb_stream_t stream);
+/* The same with TWO gradients of the pooled tensor (it has two consumers: the first BasicBlock's convolution and its identity
+ * branch, linknet.py:41-62 via resnet34): the routed value is round(g_out + g_out2), what segnb_add would have stored -- without
+ * that pass.  idx (the argmax positions segnb_maxpool_fwd recorded) is required. */
+int segnb_maxpool_bwd_add(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, const void* g_out2, int ld_go2, int N,
+                          int H, int W, int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
+                          segnb_stream_t stream);
 /* NHWC `dtype` -> fp32 NCHW (logits of a head that is not a 1x1 conv: linknet.py:62) */
 int segnb_nhwc_to_nchw_f32(int dtype, const void* a, int ld, int N, int H, int W, int C, float* out,
                            segnb_stream_t stream);

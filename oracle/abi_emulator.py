@@ -997,6 +997,12 @@ class AbiEmulator(object):
         _nhwc(dx, N, H, W, Cp, ld_dx, dt).copy_(X.grad.permute(0, 2, 3, 1).to(dt))
         return 0
 
+    def segnb_maxpool_bwd_add(self, dtype, x, ld_x, g_out, ld_go, g_out2, ld_go2, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream):
+        dt = _tdt(dtype)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        g = (_nhwc(g_out, N, Ho, Wo, Cp, ld_go, dt).float() + _nhwc(g_out2, N, Ho, Wo, Cp, ld_go2, dt).float()).to(dt).contiguous()
+        return self.segnb_maxpool_bwd(dtype, x, ld_x, g.data_ptr(), Cp, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream)
+
     def segnb_nhwc_to_nchw_f32(self, dtype, a, ld, N, H, W, C, out, stream):
         A = _nhwc(a, N, H, W, C, ld, _tdt(dtype)).float()
         _mem(out, N * C * H * W, torch.float32).view(N, C, H, W).copy_(A.permute(0, 3, 1, 2))

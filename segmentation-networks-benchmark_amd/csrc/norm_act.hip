@@ -1344,19 +1344,36 @@ __global__ __launch_bounds__(NTHR) void maxpool_bwd_kernel(const T* __restrict__
 // The same from the argmax positions the forward pass recorded (segnb_maxpool_fwd idx): a pixel reads one index vector and
 // one gradient vector per covering window (<= ceil(k / stride)^2 of them) instead of re-scanning every window --
 // 3x3 stride 2 at 256x256x64 (the ResNet stem of LinkNet34 at 512x512): 2.4 ms -> the price of a streaming pass.
-template <typename T>
+// I32: N * H * W * CPP < 2^31 -- the index decomposition on 32-bit integers with reciprocal divisions (three 64-bit divisions per
+// item were half of the kernel's issue slots: 89 -> 6x us on LinkNet34's stem, 16 x 256 x 256 x 64)
+template <typename T, bool I32>
 __global__ __launch_bounds__(NTHR) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ go,
                                                                int ld_go, int N, int H, int W, int CPP, int k, int st,
-                                                               int pd, int Ho, int Wo, T* __restrict__ dx, int ld_dx) {
+                                                               int pd, int Ho, int Wo, T* __restrict__ dx, int ld_dx,
+                                                               const T* __restrict__ go2, int ld_go2) {
+    // go2 (segnb_maxpool_bwd_add): a second gradient of the pooled tensor (two consumers: linknet.py:41-62's first BasicBlock and
+    // its identity branch); the routed value is round(go + go2), what segnb_add would have stored
     const long long total = (long long)N * H * W * CPP;
+    const FastDiv d_cpp(CPP), d_w(W), d_h(H);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % CPP) * 8;
-        long long q = i / CPP;
-        const int w = (int)(q % W);
-        q /= W;
-        const int h = (int)(q % H);
-        const int n = (int)(q / H);
+        int c0, w, h, n;
+        if constexpr (I32) {
+            const int ii = (int)i;
+            const int q0 = d_cpp.div(ii);
+            c0 = (ii - q0 * CPP) * 8;
+            const int q1 = d_w.div(q0);
+            w = q0 - q1 * W;
+            n = d_h.div(q1);
+            h = q1 - n * H;
+        } else {
+            c0 = (int)(i % CPP) * 8;
+            long long q = i / CPP;
+            w = (int)(q % W);
+            q /= W;
+            h = (int)(q % H);
+            n = (int)(q / H);
+        }
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -1372,6 +1389,12 @@ __global__ __launch_bounds__(NTHR) void maxpool_bwd_idx_kernel(const unsigned ch
                 const uint2 pk = *reinterpret_cast<const uint2*>(idx + wpix * (long long)(CPP * 8) + c0);
                 float gv[8];
                 load8(go + wpix * ld_go + c0, gv);
+                if (go2 != nullptr) {
+                    float g2[8];
+                    load8(go2 + wpix * ld_go2 + c0, g2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[e] = round_as(gv[e] + g2[e], (const T*)nullptr);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned a = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
@@ -2191,21 +2214,54 @@ extern "C" int segnb_maxpool_fwd(int dtype, const void* x, int ld_x, int N, int 
     return 0;
 }
 
+static int maxpool_bwd_impl(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W, int Cp, int k,
+                            int stride, int pad, void* dx, int ld_dx, const unsigned char* idx, const void* g_out2, int ld_go2,
+                            segnb_stream_t stream);
+
 extern "C" int segnb_maxpool_bwd(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W,
                                  int Cp, int k, int stride, int pad, void* dx, int ld_dx, const unsigned char* idx,
                                  segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_maxpool_bwd, dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream);
+    return maxpool_bwd_impl(dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, nullptr, 0, stream);
+}
+
+extern "C" int segnb_maxpool_bwd_add(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, const void* g_out2,
+                                     int ld_go2, int N, int H, int W, int Cp, int k, int stride, int pad, void* dx, int ld_dx,
+                                     const unsigned char* idx, segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_maxpool_bwd_add, dtype, x, ld_x, g_out, ld_go, g_out2, ld_go2, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, stream);
+    SEGNB_CHECK_ARG(g_out2 != nullptr && idx != nullptr, "the two-source form takes the recorded argmax positions");
+    return maxpool_bwd_impl(dtype, x, ld_x, g_out, ld_go, N, H, W, Cp, k, stride, pad, dx, ld_dx, idx, g_out2, ld_go2, stream);
+}
+
+static int maxpool_bwd_impl(int dtype, const void* x, int ld_x, const void* g_out, int ld_go, int N, int H, int W, int Cp, int k,
+                            int stride, int pad, void* dx, int ld_dx, const unsigned char* idx, const void* g_out2, int ld_go2,
+                            segnb_stream_t stream) {
     if (int rc = check_ew(N, H, W, Cp)) return rc;
     SEGNB_CHECK_ARG(x && g_out && dx && k >= 1 && stride >= 1 && pad >= 0 && pad < k && k * k < 255, "bad pooling arguments");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     int grid = ceil_div((long long)N * H * W * (Cp / 8), NTHR);
     if (grid > 8192) grid = 8192;
     if (idx != nullptr) {
+        const bool i32 = (long long)N * H * W * (Cp / 8) < (1ll << 31);
+        if (i32) {
+            SEGNB_DISPATCH_T(
+                hipLaunchKernelGGL((maxpool_bwd_idx_kernel<bf16_t, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                                   (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx,
+                                   (const bf16_t*)g_out2, ld_go2),
+                hipLaunchKernelGGL((maxpool_bwd_idx_kernel<float, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                                   (const float*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)dx, ld_dx,
+                                   (const float*)g_out2, ld_go2),
+                "segnb_maxpool_bwd")
+            SEGNB_LAUNCH_CHECK();
+            return 0;
+        }
         SEGNB_DISPATCH_T(
-            hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_t>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
-                               (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx),
-            hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
-                               (const float*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)dx, ld_dx),
+            hipLaunchKernelGGL((maxpool_bwd_idx_kernel<bf16_t, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                               (const bf16_t*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (bf16_t*)dx, ld_dx,
+                               (const bf16_t*)g_out2, ld_go2),
+            hipLaunchKernelGGL((maxpool_bwd_idx_kernel<float, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, idx,
+                               (const float*)g_out, ld_go, N, H, W, Cp / 8, k, stride, pad, Ho, Wo, (float*)dx, ld_dx,
+                               (const float*)g_out2, ld_go2),
             "segnb_maxpool_bwd")
         SEGNB_LAUNCH_CHECK();
         return 0;

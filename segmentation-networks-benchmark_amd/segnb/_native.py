@@ -146,6 +146,7 @@ SIGNATURES = {
     'segnb_upsample_bilinear2x_bwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     'segnb_maxpool_fwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     'segnb_maxpool_bwd': [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
+    'segnb_maxpool_bwd_add': [c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P],
     'segnb_nhwc_to_nchw_f32': [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     'segnb_bn_bwd_finalize': [_P, c_int, c_int, c_double, _P, _P, _P, _P, _P, c_int, _P],
     'segnb_bn_bwd_finalize_clear': [_P, c_int, c_int, c_double, _P, _P, _P, _P, _P, c_int, _P, _P],

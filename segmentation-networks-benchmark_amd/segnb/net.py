@@ -892,11 +892,17 @@ def maxpool(tape, x, k, stride, pad, tag='pool'):
     oa = Act(ov)
 
     def backward():
-        if oa.g is None or not x.needs_grad:
+        if oa._g is None or not x.needs_grad:
             return
         dx = tape.view(site + '/dx', xv.N, xv.H, xv.W, xv.Cp)
-        nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, oa.g.ptr, oa.g.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride,
-                pad, dx.ptr, dx.ld, nv.ptr(idx), rt.stream)
+        # (a held-back second gradient of the pooled tensor -- Tape.lazy_add -- is added on the way: segnb_maxpool_bwd_add)
+        g1, g2 = tape.sources(oa, idx is not None)
+        if g2 is not None:
+            nv.call('segnb_maxpool_bwd_add', rt.code, xv.ptr, xv.ld, g1.ptr, g1.ld, g2.ptr, g2.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride,
+                    pad, dx.ptr, dx.ld, nv.ptr(idx), rt.stream)
+        else:
+            nv.call('segnb_maxpool_bwd', rt.code, xv.ptr, xv.ld, g1.ptr, g1.ld, xv.N, xv.H, xv.W, xv.Cp, k, stride,
+                    pad, dx.ptr, dx.ld, nv.ptr(idx), rt.stream)
         tape.contribute(x, dx)
 
     tape.record(backward)

@@ -1611,6 +1611,32 @@ def test_conv_thin_kernel_vs_general(shape):
     np.testing.assert_allclose(sums_f2.sum(0).cpu().numpy(), a, rtol=1e-12, atol=1e-9)       # fixed order inside a block
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_maxpool_bwd_two_sources(dtype):
+    """segnb_maxpool_bwd_add(g1, g2) == segnb_add(g1, g2) followed by segnb_maxpool_bwd, bit for bit (the ResNet stem's MaxPool2d(3, 2, 1)
+    whose output has two consumers, linknet.py:41-62)."""
+    rt = Runtime('cuda', dtype)
+    N, H, W, C = 2, 37, 41, 24
+    x = View.alloc(rt, N, H, W, C)
+    x.t.normal_()
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    o, g1, g2, gs = (View.alloc(rt, N, Ho, Wo, C) for _ in range(4))
+    g1.t.normal_(); g2.t.normal_()
+    idx = torch.zeros(N, Ho, Wo, C, dtype=torch.uint8, device='cuda')
+    st = rt.stream
+    nv.call('segnb_maxpool_fwd', rt.code, x.ptr, x.ld, N, H, W, C, 3, 2, 1, o.ptr, o.ld, nv.ptr(idx), st)
+    nv.call('segnb_add', rt.code, g1.ptr, g1.ld, g2.ptr, g2.ld, gs.ptr, gs.ld, N, Ho, Wo, C, st)
+    dx_ref, dx = View.alloc(rt, N, H, W, C), View.alloc(rt, N, H, W, C)
+    nv.call('segnb_maxpool_bwd', rt.code, x.ptr, x.ld, gs.ptr, gs.ld, N, H, W, C, 3, 2, 1, dx_ref.ptr, dx_ref.ld, nv.ptr(idx), st)
+    nv.call('segnb_maxpool_bwd_add', rt.code, x.ptr, x.ld, g1.ptr, g1.ld, g2.ptr, g2.ld, N, H, W, C, 3, 2, 1, dx.ptr, dx.ld,
+            nv.ptr(idx), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.t, dx_ref.t)
+    xr = x.dense().float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(xr, 3, 2, 1).backward(gs.dense().float().permute(0, 3, 1, 2))
+    check('vs torch', dx.dense().float().permute(0, 3, 1, 2), xr.grad, dtype)
+
+
 ACT_EP_CASES = [
     # name,                 N, H,  W,  segs,               Co, k, s, p, transposed
     ('ws 64->64 relu',      2, 24, 40, [(64, 64)],         64, 3, 1, 1, False),
