@@ -114,6 +114,28 @@ int segnb_conv_fprop(const segnb_conv_geom* g, int dtype, const void* in, const 
 int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype);
 int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                      float* dwp, int nslab, segnb_stream_t stream);
+/* Where the NEXT weight-gradient launch of the calling thread (segnb_conv_wgrad / _upcat / _bnapply / _tf) delivers its result:
+ * straight into the parameter's own gradient -- nn.Conv2d.weight.grad of torch_train.py:188's backward(), fp32
+ * [Co_total][Ci_total][KH][KW] -- instead of slab 0 of the packed workspace:
+ *     gw[co * s_out + (ci_off + ci) * s_in + kpos[t]]  (+)=  sum_s dwp[s][co][t][ci]      for co < Co, ci < Ci
+ * The sum over the pixel-split slabs (fixed order: bitwise reproducible), the [Co][tap][Ci] -> [Co][Ci][tap] transposition and the
+ * accumulation into the flat gradient buffer are ONE pass (launches with a single slab write the gradient from their
+ * accumulator registers); the per-layer slab reduction, the batched segnb_unpack_wgrad_multi pass over every workspace (read,
+ * re-zero, read-modify-write of the gradient: 0.5 GB of a ZF_UNET step) and its job tables are not needed for such a layer.
+ * accumulate != 0: added to what gw holds (torch's .grad accumulation); 0: gw is overwritten.  The workspace keeps its
+ * contract (nslab slabs; scratch afterwards).  Recordable; consumed by the next weight-gradient entry point, whatever kernel
+ * serves it. */
+typedef struct {
+    float* gw;          /* first element of the parameter's gradient */
+    long long s_out;    /* floats between consecutive output channels of the parameter (Ci_total * KH * KW) */
+    int s_in;           /* floats between consecutive input channels (KH * KW) */
+    int ci_off;         /* input channel 0 of the launch is input channel ci_off of the parameter (a concat segment on its own) */
+    int Ci, Co;         /* real channel counts: the launch's channels beyond them are padding and are dropped */
+    int accumulate;
+    int ntaps;
+    int kpos[SEGNB_MAX_TAPS];     /* kernel position kh * KW + kw of packed tap t */
+} segnb_wgrad_target;
+int segnb_wgrad_target_arm(const segnb_wgrad_target* t);
 /* Weight gradient whose dout operand is not in memory: it is the BatchNorm-backward apply of the layer,
  *     dout = round(a * (round(g * act'(z)) - c1 - yhat * c2)),   z = (y - mean) * scale + shift,  yhat = (y - mean) * invstd
  * (lib/modules/abn/functions.py:118's dx, the arithmetic and roundings of segnb_bn_bwd_apply_direct), recomputed from the

@@ -406,6 +406,27 @@ class AbiEmulator(object):
             G[1:].fill_(float('nan'))      # ... and the others are scratch: poison them
         for t in range(g.ntaps):
             G[0, :, t, :] += d.t() @ _gather(X, g, t).reshape(-1, g.Ci)
+        tgt, self._wg_target = getattr(self, '_wg_target', None), None
+        if tgt is not None:
+            # segnb_wgrad_target: the result goes to the parameter's own gradient instead of staying in slab 0
+            assert tgt['ntaps'] == g.ntaps
+            co = torch.arange(tgt['Co'])[:, None, None]
+            ci = torch.arange(tgt['Ci'])[None, None, :]
+            kp = torch.tensor(tgt['kpos'], dtype=torch.long)[None, :, None]
+            idx = (co * tgt['s_out'] + (tgt['ci_off'] + ci) * tgt['s_in'] + kp).reshape(-1)
+            dst = _mem(tgt['gw'], int(idx.max()) + 1, torch.float32)
+            src = G[0, :tgt['Co'], :, :tgt['Ci']].reshape(-1)
+            if tgt['accumulate']:
+                dst.index_add_(0, idx, src)
+            else:
+                dst[idx] = src
+            G.fill_(float('nan')) if nslab > 1 else G.zero_()      # scratch afterwards (one slab: left zeroed for the atomics)
+        return 0
+
+    def segnb_wgrad_target_arm(self, t):
+        t = _geom(t)
+        self._wg_target = dict(gw=int(t.gw), s_out=int(t.s_out), s_in=int(t.s_in), ci_off=int(t.ci_off), Ci=int(t.Ci), Co=int(t.Co),
+                               accumulate=int(t.accumulate), ntaps=int(t.ntaps), kpos=[int(t.kpos[i]) for i in range(int(t.ntaps))])
         return 0
 
     def segnb_conv_wgrad_bnapply_ok(self, g, dtype):

@@ -92,6 +92,9 @@ inline const segnb_upcat_src* segnb_plan_keep(const segnb_upcat_src* g) {
 inline const segnb_operand_tf* segnb_plan_keep(const segnb_operand_tf* g) {
     return g ? (const segnb_operand_tf*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
+inline const segnb_wgrad_target* segnb_plan_keep(const segnb_wgrad_target* g) {
+    return g ? (const segnb_wgrad_target*)segnb_plan_dup(g, sizeof(*g)) : g;
+}
 inline const segnb_act_epilogue* segnb_plan_keep(const segnb_act_epilogue* g) {
     return g ? (const segnb_act_epilogue*)segnb_plan_dup(g, sizeof(*g)) : g;
 }
@@ -176,9 +179,18 @@ struct segnb_wgrad_bnapply {
     int act;
     float slope;
 };
+// tgt: the armed segnb_wgrad_target or NULL.  With a target a single-slab launch writes the parameter's gradient from its
+// accumulators (returns 2 instead of 1: nothing left to do); launches with several slabs leave them unreduced for
+// segnb_wgrad_to_param
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
                        hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna = nullptr,
-                       const segnb_upcat_src* uc = nullptr);      // partial: leave the nslab slabs unreduced
+                       const segnb_upcat_src* uc = nullptr, const segnb_wgrad_target* tgt = nullptr);      // partial: leave the nslab slabs unreduced
+// runtime.hip: the target armed by segnb_wgrad_target_arm on this thread (disarmed by the call), or NULL
+const segnb_wgrad_target* segnb_take_wgrad_target();
+// wgrad_s1.hip: sum the nslab slabs [Cop][ntaps][Cip] of dwp (fixed order) into the parameter-layout gradient of tgt; rezero: slab 0
+// is cleared afterwards (the atomics of the general kernel need a zeroed workspace)
+void segnb_wgrad_to_param(float* dwp, int Cop, int ntaps, int Cip, int nslab, const segnb_wgrad_target* tgt, bool rezero,
+                          hipStream_t stream);
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g);
 void segnb_slab_reduce(float* dwp, long long total, int nslab, hipStream_t stream);
 // rolling-window weight gradient of the thin layers (wgrad_roll.hip); tfx / tfd: operands recomputed on load (or NULL)

@@ -1862,11 +1862,13 @@ extern "C" int segnb_conv_fprop_upsum(const segnb_conv_geom* g, int dtype, const
 extern "C" int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const void* in, const segnb_upcat_src* src,
                                       const void* dout, float* dwp, int nslab, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_upcat, g, dtype, in, src, dout, dwp, nslab, stream);
+    const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     SEGNB_CHECK_ARG(in && src && src->u && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(upcat_geom_ok(g, dtype, src->Cu), "geometry not served (segnb_conv_upcat_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
-    const int rc = segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, nullptr, src);
-    if (rc == 1) {
+    const int rc = segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, nullptr, src, tgt);
+    if (rc == 1 || rc == 2) {
+        if (tgt != nullptr && rc == 1) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, nslab, tgt, false, (hipStream_t)stream);
         SEGNB_LAUNCH_CHECK();
         return 0;
     }
@@ -1988,7 +1990,9 @@ extern "C" int segnb_conv_wgrad_slabs(const segnb_conv_geom* g, int dtype) {
 extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void* in, const void* dout,
                                 float* dwp, int nslab, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad, g, dtype, in, dout, dwp, nslab, stream);
+    const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     WgradArgs a;
@@ -2001,18 +2005,22 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     int rc;
     if (dtype == SEGNB_BF16) {
         // stride-1 3x3: pixel-major LDS tiles + transposing LDS reads, all taps per block (wgrad_s1.hip)
-        rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
+        // (with a target the fast kernels leave their slabs unreduced: segnb_wgrad_to_param sums them into the parameter's gradient)
+        const bool part = tgt != nullptr;
+        rc = (wgrad_general_only() || !segnb_knob_wgrad_roll()) ? 0 : segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, part);
         if (rc == 0 && !wgrad_general_only() && segnb_knob_wgrad_c8roll() && segnb_wgrad_s1_slabs(g) > 0)
-            rc = segnb_wgrad_c8roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
+            rc = segnb_wgrad_c8roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, part);
         if (rc == 0)
-            rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
-        if (rc == 1) {
+            rc = wgrad_general_only() ? 0 : segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, nullptr, nullptr, tgt);
+        if (rc == 1 || rc == 2) {
+            if (tgt != nullptr && rc == 1) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, nslab, tgt, false, (hipStream_t)stream);
             SEGNB_LAUNCH_CHECK();
             return 0;
         }
         if (rc != 0) return rc;
-        rc = wgrad_general_only() ? 0 : segnb_wgrad_sx_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false);
+        rc = wgrad_general_only() ? 0 : segnb_wgrad_sx_try(g, in, dout, dwp, nslab, (hipStream_t)stream, part);
         if (rc == 1) {
+            if (tgt != nullptr) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, nslab, tgt, false, (hipStream_t)stream);
             SEGNB_LAUNCH_CHECK();
             return 0;
         }
@@ -2031,6 +2039,8 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
         return SEGNB_E_BADARG;
     }
     if (rc) return rc;
+    // general kernels: one slab, accumulated with atomics into the zeroed workspace -- delivered and re-zeroed in one pass
+    if (tgt != nullptr) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, 1, tgt, true, (hipStream_t)stream);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }
@@ -2051,15 +2061,18 @@ extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, con
                                         const void* y, int ld_y, const float* coef, const float* bcoef, int Cp, int act,
                                         float slope, float* dwp, int nslab, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_bnapply, g, dtype, in, gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope, dwp, nslab, stream);
+    const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
     SEGNB_CHECK_ARG(in && gsrc && y && coef && bcoef && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(segnb_conv_wgrad_bnapply_ok(g, dtype), "geometry not served (segnb_conv_wgrad_bnapply_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     SEGNB_CHECK_ARG(Cp >= g->Co && ld_g >= g->Co && ld_y >= g->Co, "bad strides");
     const segnb_wgrad_bnapply bna = {gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope};
-    int rc = segnb_knob_wgrad_c8roll() ? segnb_wgrad_c8roll_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna) : 0;
-    if (rc == 0) rc = segnb_wgrad_s1_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna);
-    if (rc == 1) {
+    int rc = segnb_knob_wgrad_c8roll() ? segnb_wgrad_c8roll_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, tgt != nullptr, &bna) : 0;
+    if (rc == 0) rc = segnb_wgrad_s1_try(g, in, nullptr, dwp, nslab, (hipStream_t)stream, false, &bna, nullptr, tgt);
+    if (rc == 1 || rc == 2) {
+        if (tgt != nullptr && rc == 1) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, nslab, tgt, false, (hipStream_t)stream);
         SEGNB_LAUNCH_CHECK();
         return 0;
     }
@@ -2080,15 +2093,18 @@ extern "C" int segnb_conv_wgrad_tf(const segnb_conv_geom* g, int dtype, const vo
                                    const void* dout, const segnb_operand_tf* tf_dout, float* dwp, int nslab,
                                    segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_tf, g, dtype, in, tf_in, dout, tf_dout, dwp, nslab, stream);
+    const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(segnb_conv_wgrad_tf_ok(g, dtype), "geometry not served (segnb_conv_wgrad_tf_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     SEGNB_CHECK_ARG(tf_in == nullptr || (tf_in->kind == SEGNB_TF_ACT && tf_in->coef != nullptr && tf_in->Cp >= g->Ci), "bad input transform");
     SEGNB_CHECK_ARG(tf_dout == nullptr || (tf_dout->kind == SEGNB_TF_BNBWD && tf_dout->coef && tf_dout->bcoef && tf_dout->y &&
                                            tf_dout->drop == nullptr && tf_dout->Cp >= g->Co), "bad dout transform");
-    const int rc = segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, tf_in, tf_dout);
+    const int rc = segnb_wgrad_roll_try(g, in, dout, dwp, nslab, (hipStream_t)stream, tgt != nullptr, tf_in, tf_dout);
     if (rc == 1) {
+        if (tgt != nullptr) segnb_wgrad_to_param(dwp, g->Co, g->ntaps, g->Ci, nslab, tgt, false, (hipStream_t)stream);
         SEGNB_LAUNCH_CHECK();
         return 0;
     }

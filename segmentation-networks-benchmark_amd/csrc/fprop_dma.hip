@@ -1087,7 +1087,8 @@ int ksplit_workspace(hipStream_t stream, size_t slab_bytes, int ntiles, float** 
             const int want = ntiles < 1024 ? 1024 : ntiles;
             int* c = nullptr;
             if (hipMalloc(&c, (size_t)want * sizeof(int)) != hipSuccess) return -1;
-            if (hipMemset(c, 0, (size_t)want * sizeof(int)) != hipSuccess) return -1;
+            // cleared IN the launching stream (a null-stream memset is not ordered with a non-blocking stream: ADVICE r5)
+            if (hipMemsetAsync(c, 0, (size_t)want * sizeof(int), stream) != hipSuccess) return -1;
             e->cnt = c;
             e->ncnt = want;
         }

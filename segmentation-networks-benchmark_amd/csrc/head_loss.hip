@@ -582,15 +582,27 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
     if constexpr (FIN) {
         __shared__ int last;
         if (ret == -1.2345e300) fin[7] = 1.f;           // (never: keeps the returned values alive)
-        // the sums are agent-scope atomics (performed at the device's coherence point, like the ticket and the last block's
-        // loads): what the hand-over needs is ORDER -- this block's adds performed before its ticket is drawn.  An explicit
-        // wait for the returned values, invisible to the compiler's passes, instead of relying on where it places its own
-        // (ADVICE r4); tests/test_hip_ops.py pins the result against the three-launch form at 512 .. 2048 blocks
+        // The hand-over, ONE recipe with the split K of conv_fprop_ws_kernel (fprop_dma.hip: ks_publish; MI355X_MICROARCH.md,
+        // inter-workgroup visibility):
+        //   release side  -- the block's contribution is performed at the device's coherence point (there: write-through `sc1`
+        //                    stores; here: RETURNING agent-scope atomics), every contributing wave drains (s_waitcnt vmcnt(0): the
+        //                    returned values have arrived, so the adds are done), a workgroup barrier, then ONE relaxed agent-scope
+        //                    add draws the ticket;
+        //   acquire side  -- the block whose ticket is the last one issues an agent-scope ACQUIRE fence (buffer_inv sc1 + wait)
+        //                    before it reads, and reads through coherent (agent-scope atomic) loads.
+        // A release FENCE per block instead (what __threadfence() compiles to) writes the XCD's L2 back: 52 us at 512 blocks / 125 us
+        // at 2048 for this launch (profiles/r04_ab.txt); tests/test_hip_ops.py pins the result against the three-launch form at
+        // 512 .. 2048 blocks
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned* ticket = reinterpret_cast<unsigned*>(sums + LOSS_REPL * 8);
-            last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+            const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = tk == gridDim.x - 1 ? 1 : 0;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __syncthreads();
         if (last) {
@@ -917,6 +929,8 @@ extern "C" int segnb_head_conv_bwd(int dtype, const void* a, int ld_a, int N, in
     SEGNB_CHECK_ARG(a && w && dlogits, "NULL tensor");
     SEGNB_CHECK_ARG(segnb_head_conv_ok(C, K, kh, kw), "classes x window positions <= 8 and C <= 64 (segnb_head_conv_ok)");
     SEGNB_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && pad >= 0 && Cp % 8 == 0 && Cp >= C && ld_a % 8 == 0 && ld_a >= Cp, "bad shape");
+    // (the kernel's LDS weight rows are 64 floats wide and indexed by padded channel chunk: a wider padded view would read past them)
+    SEGNB_CHECK_ARG(Cp <= 64, "padded channel count above 64 (the weight rows in LDS hold 64 channels)");
     SEGNB_CHECK_ARG(da == nullptr || (ld_da % 8 == 0 && ld_da >= Cp), "bad gradient stride");
     SEGNB_CHECK_ARG(act < 0 || ((act == SEGNB_ACT_NONE || act == SEGNB_ACT_RELU || act == SEGNB_ACT_LEAKY) && da != nullptr),
                     "act: -1 (plain gradient) or the producing layer's activation, with da");

@@ -354,6 +354,26 @@ extern "C" int segnb_wg_cu_share(int pct) {
     return 0;
 }
 
+// The armed weight-gradient target (include/segnb_hip.h): per thread, like the recording state; consumed by the next
+// segnb_conv_wgrad* entry point
+static thread_local segnb_wgrad_target g_wg_target;
+static thread_local bool g_wg_target_armed = false;
+extern "C" int segnb_wgrad_target_arm(const segnb_wgrad_target* t) {
+    SEGNB_PLAN_RECORD(segnb_wgrad_target_arm, t);
+    SEGNB_CHECK_ARG(t != nullptr && t->gw != nullptr, "NULL target");
+    SEGNB_CHECK_ARG(t->ntaps >= 1 && t->ntaps <= SEGNB_MAX_TAPS && t->Ci > 0 && t->Co > 0 && t->s_in >= t->ntaps && t->ci_off >= 0 &&
+                        t->s_out >= (long long)(t->ci_off + t->Ci) * t->s_in, "bad target layout");
+    for (int i = 0; i < t->ntaps; ++i) SEGNB_CHECK_ARG(t->kpos[i] >= 0 && t->kpos[i] < t->s_in, "bad kernel position");
+    g_wg_target = *t;
+    g_wg_target_armed = true;
+    return 0;
+}
+const segnb_wgrad_target* segnb_take_wgrad_target() {
+    if (!g_wg_target_armed) return nullptr;
+    g_wg_target_armed = false;
+    return &g_wg_target;
+}
+
 extern "C" int segnb_tune(const char* key, int value) {
     SEGNB_PLAN_REFUSE("segnb_tune inside a recorded plan");
     SEGNB_CHECK_ARG(key != nullptr, "NULL key");

@@ -93,6 +93,12 @@ struct WgS1Args {
     // -- x-tile pixel (hi, wi) of those channels is u pixel (hi >> 1, wi >> 1) -- channels Cu.. come from x (the skip tensor)
     const bf16_t* u;            // NULL: off
     int Cu, ld_u;
+    // segnb_wgrad_target of a SINGLE-slab launch (gw != NULL): the block's tile goes straight into the parameter's gradient
+    //     gw[co * gw_s_out + (gw_ci_off + ci) * gw_s_in + gw_kpos[t]]  (+)=  acc        co < gw_Co, ci < gw_Ci
+    float* gw;
+    long long gw_s_out;
+    int gw_s_in, gw_ci_off, gw_Ci, gw_Co, gw_acc;
+    int gw_kpos[9];
 };
 
 __device__ __forceinline__ float wg_round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
@@ -656,6 +662,92 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
         return;
     }
 #endif
+    if (a.gw != nullptr) {
+        // one slab (no pixel split): this block holds the FINAL sums of its tile -- they leave in the parameter's own layout
+        // [Co][Ci][3][3], no workspace, no unpack pass.
+        if constexpr (TS) {
+            // 64 x 64 tiles: four rounds of 16 output channels through LDS (the tiles are dead: the loop ended on a barrier; the
+            // fetch waves have left).  A lane's accumulators of a round -- input channel `ci`, 8 output channels, the taps its wave
+            // owns -- go to stg[co][ci][tap] (lane stride 9 floats: conflict-free), then the 256 threads move whole rows: 64 input
+            // channels x 9 taps of one output channel are 2304 contiguous bytes of the parameter.
+            float* const stg = reinterpret_cast<float*>(smem);
+            int civ = a.gw_Ci - ci0;
+            civ = civ > BCI ? BCI : civ;
+            const long long col0 = (long long)(a.gw_ci_off + ci0) * 9;
+            const bool vec = a.gw_s_in == 9 && (a.gw_s_out & 3) == 0 && (col0 & 3) == 0 && civ > 0 && ((civ * 9) & 3) == 0;
+            const int nrow4 = vec ? civ * 9 / 4 : 0;
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int c = rd >> 1, r = rd & 1;
+                if (rd > 0) __syncthreads();                     // the previous round has been copied out
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    if (((u + tg) & 1) == c) {                   // (wave-uniform)
+                        const int kp = a.gw_kpos[4 * tg + ((u + tg) >> 1)];
+#pragma unroll
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int e = 8 * r + e8;
+                            const int row = (e & 3) + 8 * ((e >> 2) & 1) + 4 * h;
+                            stg[(row * 64 + sci * 32 + (lane & 31)) * 9 + kp] = acc[u][e];
+                        }
+                    }
+                }
+                __syncthreads();
+                const int cobase = co0 + 16 * rd;
+                if (vec) {
+#pragma unroll 1
+                    for (int kb = 0; kb < 9; kb += 3) {          // three rows of float4 in flight (registers: the accumulators are live)
+                        float4 o[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int i = tid + 256 * (kb + k), row = i / 144, q = i - row * 144;
+                            o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (q < nrow4 && cobase + row < a.gw_Co && a.gw_acc)
+                                o[k] = *(reinterpret_cast<const float4*>(a.gw + (long long)(cobase + row) * a.gw_s_out + col0) + q);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int i = tid + 256 * (kb + k), row = i / 144, q = i - row * 144;
+                            if (q < nrow4 && cobase + row < a.gw_Co) {
+                                float4 w = *reinterpret_cast<const float4*>(stg + row * 576 + 4 * q);
+                                w.x += o[k].x; w.y += o[k].y; w.z += o[k].z; w.w += o[k].w;
+                                *(reinterpret_cast<float4*>(a.gw + (long long)(cobase + row) * a.gw_s_out + col0) + q) = w;
+                            }
+                        }
+                    }
+                } else {
+                    for (int i = tid; i < 16 * 576; i += 256) {
+                        const int row = i / 576, q = i - row * 576;
+                        const int cil = q / 9, kp = q - cil * 9;
+                        if (cil < civ && cobase + row < a.gw_Co) {
+                            float* const d = a.gw + (long long)(cobase + row) * a.gw_s_out + (long long)(a.gw_ci_off + ci0 + cil) * a.gw_s_in + kp;
+                            *d = a.gw_acc ? *d + stg[i] : stg[i];
+                        }
+                    }
+                }
+            }
+            return;
+        }
+        // (thin 32 x 32 tiles reach here only on inputs too small for a pixel split: element stores)
+        float* const gcol = a.gw + (long long)(a.gw_ci_off + ci) * a.gw_s_in;
+        const bool civ = ci < a.gw_Ci;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int kp = a.gw_kpos[u];
+            const int cob = co0 + sco * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < a.gw_Co && civ) {
+                    float* const dst = gcol + (long long)co * a.gw_s_out + kp;
+                    *dst = a.gw_acc ? *dst + acc[u][e] : acc[u][e];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
         // accumulator u: tap u of sub-tile sco, or (tap-split) unit u = (co half (u+tg)&1, tap 4*tg + ((u+tg)>>1))
@@ -665,6 +757,152 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
         for (int e = 0; e < 16; ++e) {
             const int co = cob + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (co < a.Co && ci < a.Ci) slab[(long long)co * a.Ktot + t * a.Ci + ci] = acc[u][e];
+        }
+    }
+}
+
+// ---- slabs -> the parameter's gradient (segnb_wgrad_target): sum of the nslab partial slabs [Cop][nt][Cip] in a fixed
+// order, transposed to the parameter's [Co][Ci][KH][KW] and added to (or stored into) the flat gradient buffer, ONE pass.
+// A thread owns one (co, ci) pair: for every tap its lanes read 64 consecutive input channels of a slab row (256 B) and
+// write the pair's taps as neighbours.  GROUPS: slab groups per block that sum concurrently (many slabs, few pairs: the
+// thin layers' 256 slabs x 1024 pairs), each with four independent partial sums; combined in group order.
+struct ParamReduceArgs {
+    float* dwp;
+    long long total;        // Cop * nt * Cip: floats per slab
+    int nslab, nt, Cip, Cop;
+    float* gw;
+    long long s_out;
+    int s_in, ci_off, Ci, Co, acc, rezero;
+    int kpos[SEGNB_MAX_TAPS];
+};
+
+// NT9: 3 x 3 windows (nt == 9 && s_in == 9) -- the loads of ALL nine taps of a slab batch are issued together (36 in flight per
+// thread: a thread's time is nslab / (4 GROUPS) round trips, not 9 x that), the block's output is staged as [pair][position] and
+// leaves as consecutive floats.  !NT9 (any window): tap by tap, element stores.
+template <int GROUPS, bool NT9>
+__global__ __launch_bounds__(GROUPS == 1 ? 256 : 64 * GROUPS) void slab_reduce_param_kernel(const ParamReduceArgs a) {
+    constexpr int PPB = GROUPS == 1 ? 256 : 64;                 // (co, ci) pairs per block
+    constexpr int NTH = GROUPS == 1 ? 256 : 64 * GROUPS;
+    __shared__ float part[GROUPS == 1 ? 1 : GROUPS][NT9 ? 9 : 1][64];
+    __shared__ float stg[NT9 ? PPB * 9 : 1];                     // [pair][kernel position]
+    const int lane = GROUPS == 1 ? threadIdx.x : (threadIdx.x & 63), grp = GROUPS == 1 ? 0 : (threadIdx.x >> 6);
+    const long long pair0 = (long long)blockIdx.x * PPB, pair = pair0 + lane;
+    const long long npair = (long long)a.Cop * a.Cip;
+    const bool in = pair < npair;
+    const int co = in ? (int)(pair / a.Cip) : 0, ci = in ? (int)(pair % a.Cip) : 0;
+    const float* const src = a.dwp + (long long)co * a.nt * a.Cip + ci;      // tap t of slab s: src[s * total + t * Cip]
+    if constexpr (NT9) {
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = 0.f;
+        if (in) {
+            if constexpr (GROUPS == 1) {
+                // few slabs: in slab order, four slabs x nine taps in flight
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v[t] = src[t * a.Cip];
+                int sl = 1;
+                for (; sl + 3 < a.nslab; sl += 4) {
+                    float b[4][9];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) b[k][t] = src[(long long)(sl + k) * a.total + t * a.Cip];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] = (((v[t] + b[0][t]) + b[1][t]) + b[2][t]) + b[3][t];
+                }
+                for (; sl < a.nslab; ++sl) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) v[t] += src[(long long)sl * a.total + t * a.Cip];
+                }
+            } else {
+                constexpr int KF = GROUPS >= 16 ? 2 : 4;           // slab loads in flight per tap (1024-thread blocks: 128 registers)
+                float w[KF][9];
+#pragma unroll
+                for (int k = 0; k < KF; ++k)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) w[k][t] = 0.f;
+                int sl = grp;
+                for (; sl + (KF - 1) * GROUPS < a.nslab; sl += KF * GROUPS) {
+#pragma unroll
+                    for (int k = 0; k < KF; ++k)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) w[k][t] += src[(long long)(sl + k * GROUPS) * a.total + t * a.Cip];
+                }
+                for (; sl < a.nslab; sl += GROUPS) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) w[0][t] += src[(long long)sl * a.total + t * a.Cip];
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v[t] = KF == 4 ? (w[0][t] + w[1][t]) + (w[2 % KF][t] + w[3 % KF][t]) : w[0][t] + w[1][t];
+            }
+        }
+        if constexpr (GROUPS > 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) part[grp][t][lane] = v[t];
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g2 = 0; g2 < GROUPS; ++g2) sum += part[g2][t][lane];
+                    v[t] = sum;
+                }
+            }
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (in && a.rezero) a.dwp[(long long)co * 9 * a.Cip + t * a.Cip + ci] = 0.f;
+                stg[lane * 9 + a.kpos[t]] = v[t];
+            }
+        }
+        __syncthreads();
+        // the block's pairs are consecutive (co, ci): their 3 x 3 windows are consecutive in the parameter wherever the channels are --
+        // consecutive threads write consecutive floats
+        for (int f = threadIdx.x; f < PPB * 9; f += NTH) {
+            const int pl = f / 9, k = f - pl * 9;
+            const long long pr = pair0 + pl;
+            if (pr >= npair) break;
+            const int co2 = (int)(pr / a.Cip), ci2 = (int)(pr % a.Cip);
+            if (co2 < a.Co && ci2 < a.Ci) {
+                float* const d = a.gw + (long long)co2 * a.s_out + (long long)(a.ci_off + ci2) * 9 + k;
+                *d = a.acc ? *d + stg[f] : stg[f];
+            }
+        }
+    } else {
+        const bool keep = in && co < a.Co && ci < a.Ci;
+        float* const dst = a.gw + (long long)co * a.s_out + (long long)(a.ci_off + ci) * a.s_in;
+        for (int t = 0; t < a.nt; ++t) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if (in) {
+                int sl = grp;
+                for (; sl + 3 * GROUPS < a.nslab; sl += 4 * GROUPS) {
+                    a0 += src[(long long)sl * a.total + t * a.Cip];
+                    a1 += src[(long long)(sl + GROUPS) * a.total + t * a.Cip];
+                    a2 += src[(long long)(sl + 2 * GROUPS) * a.total + t * a.Cip];
+                    a3 += src[(long long)(sl + 3 * GROUPS) * a.total + t * a.Cip];
+                }
+                for (; sl < a.nslab; sl += GROUPS) a0 += src[(long long)sl * a.total + t * a.Cip];
+            }
+            float v = (a0 + a1) + (a2 + a3);
+            if constexpr (GROUPS > 1) {
+                if (t > 0) __syncthreads();                        // the previous tap's sums were read
+                part[grp][0][lane] = v;
+                __syncthreads();
+                v = 0.f;
+                if (grp == 0) {
+#pragma unroll
+                    for (int g2 = 0; g2 < GROUPS; ++g2) v += part[g2][0][lane];
+                }
+            }
+            if (grp == 0) {
+                if (in && a.rezero) a.dwp[(long long)co * a.nt * a.Cip + t * a.Cip + ci] = 0.f;
+                if (keep) {
+                    float* const d = dst + a.kpos[t];
+                    *d = a.acc ? *d + v : v;
+                }
+            }
         }
     }
 }
@@ -762,7 +1000,7 @@ int s1_slabs(int tiles, bool thin, bool flat = false) {
 }
 
 template <int BCO, int BCI, int R, int WT, bool FLAT = false, bool BNA = false>
-int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
+int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial, const segnb_wgrad_target* tgt = nullptr) {
     using TL = WgTile<R, WT, FLAT>;
     constexpr int tile_bytes = TL::XROWS * lds_stride(BCI) + TL::YROWS * lds_stride(BCO);
     constexpr int smem = wg_ws_db<BCO, BCI, R, WT, FLAT>() ? 2 * tile_bytes : tile_bytes;
@@ -788,6 +1026,13 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
     }
     a.its_per_split = (a.IT + S - 1) / S;
     a.slab_stride = (long long)a.Co * a.Ktot;
+    a.gw = nullptr;
+    if (tgt != nullptr && S == 1) {
+        a.gw = tgt->gw;
+        a.gw_s_out = tgt->s_out;
+        a.gw_s_in = tgt->s_in; a.gw_ci_off = tgt->ci_off; a.gw_Ci = tgt->Ci; a.gw_Co = tgt->Co; a.gw_acc = tgt->accumulate;
+        for (int t = 0; t < 9; ++t) a.gw_kpos[t] = tgt->kpos[t];
+    }
     hipLaunchKernelGGL((conv_wgrad_s1x9_kernel<BCO, BCI, R, WT, FLAT, BNA>), dim3(tiles * S),
                        dim3(wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 256), smem, stream, a);
     if (S > 1 && !partial) {
@@ -799,7 +1044,7 @@ int launch_s1(WgS1Args& a, int nslab, hipStream_t stream, bool partial) {
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, a.dwp,
                                total, S);
     }
-    return 0;
+    return a.gw != nullptr ? -1000 : 0;       // (-1000: written to the target by the kernel itself)
 }
 
 // tile configuration of the fast path for a geometry: 0 = not handled here (general kernel, one slab)
@@ -1125,6 +1370,29 @@ void segnb_slab_reduce(float* dwp, long long total, int nslab, hipStream_t strea
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, dwp, total, nslab);
 }
 
+void segnb_wgrad_to_param(float* dwp, int Cop, int ntaps, int Cip, int nslab, const segnb_wgrad_target* tgt, bool rezero,
+                          hipStream_t stream) {
+    ParamReduceArgs p;
+    p.dwp = dwp;
+    p.total = (long long)Cop * ntaps * Cip;
+    p.nslab = nslab; p.nt = ntaps; p.Cip = Cip; p.Cop = Cop;
+    p.gw = tgt->gw;
+    p.s_out = tgt->s_out;
+    p.s_in = tgt->s_in; p.ci_off = tgt->ci_off; p.Ci = tgt->Ci; p.Co = tgt->Co; p.acc = tgt->accumulate;
+    p.rezero = rezero ? 1 : 0;
+    for (int t = 0; t < ntaps; ++t) p.kpos[t] = tgt->kpos[t];
+    const long long pairs = (long long)Cop * Cip;
+    const bool nt9 = ntaps == 9 && tgt->s_in == 9;
+    const int groups = nslab <= 16 ? 1 : ((nslab < 64 || pairs >= 16384) ? 4 : 16);
+#define SEGNB_PR_LAUNCH(G, N9)                                                                                            \
+    hipLaunchKernelGGL((slab_reduce_param_kernel<G, N9>), dim3((unsigned)((pairs + (G == 1 ? 255 : 63)) / (G == 1 ? 256 : 64))), \
+                       dim3(G == 1 ? 256 : 64 * G), 0, stream, p)
+    if (groups == 1) { if (nt9) SEGNB_PR_LAUNCH(1, true); else SEGNB_PR_LAUNCH(1, false); }
+    else if (groups == 4) { if (nt9) SEGNB_PR_LAUNCH(4, true); else SEGNB_PR_LAUNCH(4, false); }
+    else { if (nt9) SEGNB_PR_LAUNCH(16, true); else SEGNB_PR_LAUNCH(16, false); }
+#undef SEGNB_PR_LAUNCH
+}
+
 // partial slabs segnb_conv_wgrad writes for this geometry on the fast path (0: not a fast-path geometry)
 int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
     const S1Choice c = s1_choose(g);
@@ -1135,9 +1403,11 @@ int segnb_wgrad_s1_slabs(const segnb_conv_geom* g) {
 // returns 1 when the launch was handled here, 0 when the geometry is not a stride-1 3x3 bf16 case
 // (caller falls through to the general kernel), <0 / hipError on failure
 int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dout, float* dwp, int nslab,
-                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna, const segnb_upcat_src* uc) {
+                       hipStream_t stream, bool partial, const segnb_wgrad_bnapply* bna, const segnb_upcat_src* uc,
+                       const segnb_wgrad_target* tgt) {
     const S1Choice c = s1_choose(g);
     if (!c.cfg) return 0;
+    if (tgt != nullptr) partial = true;           // the slabs are summed by segnb_wgrad_to_param
     if (uc != nullptr && (uc->Cu % 8 != 0 || uc->Cu <= 0 || uc->Cu >= g->Ci || (g->Hi & 1) || (g->Wi & 1))) return 0;
     if (bna != nullptr && c.cfg != 1 && c.cfg != 6) return 0;      // (thin 32 x 32 tiles only)
     int dhmin = g->dh[0], dwmin = g->dw[0];
@@ -1164,19 +1434,19 @@ int segnb_wgrad_s1_try(const segnb_conv_geom* g, const void* in, const void* dou
     int rc;
     if (bna != nullptr) {
         a.bna = *bna;
-        rc = c.cfg == 1 ? launch_s1<32, 32, 8, 32, false, true>(a, nslab, stream, partial)
-                        : launch_s1<32, 32, 16, 32, false, true>(a, nslab, stream, partial);
-        return rc ? rc : 1;
+        rc = c.cfg == 1 ? launch_s1<32, 32, 8, 32, false, true>(a, nslab, stream, partial, tgt)
+                        : launch_s1<32, 32, 16, 32, false, true>(a, nslab, stream, partial, tgt);
+        return rc == -1000 ? 2 : (rc ? rc : 1);
     }
-    if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream, partial);
-    else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream, partial);
-    else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream, partial);
-    else if (c.cfg == 7) rc = launch_s1<64, 64, 8, 32>(a, nslab, stream, partial);
-    else if (c.cfg == 8) rc = launch_s1<64, 64, 7, 32>(a, nslab, stream, partial);
-    else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream, partial);
-    else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream, partial);
-    else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream, partial);
-    return rc ? rc : 1;
+    if (c.cfg == 1) rc = launch_s1<32, 32, 8, 32>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 6) rc = launch_s1<32, 32, 16, 32>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 2) rc = launch_s1<64, 64, 4, 32>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 7) rc = launch_s1<64, 64, 8, 32>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 8) rc = launch_s1<64, 64, 7, 32>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 3) rc = launch_s1<64, 64, 8, 16>(a, nslab, stream, partial, tgt);
+    else if (c.cfg == 4) rc = launch_s1<64, 64, 4, 7, true>(a, nslab, stream, partial, tgt);
+    else rc = launch_s1<64, 64, 1, 14, true>(a, nslab, stream, partial, tgt);
+    return rc == -1000 ? 2 : (rc ? rc : 1);           // 2: the single-slab launch wrote the target itself
 }
 
 

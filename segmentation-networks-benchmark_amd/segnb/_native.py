@@ -65,6 +65,12 @@ class UpcatSrc(ctypes.Structure):
     _fields_ = [('u', c_void_p), ('Cu', c_int), ('ld_u', c_int)]
 
 
+class WgradTarget(ctypes.Structure):
+    """segnb_wgrad_target"""
+    _fields_ = [('gw', c_void_p), ('s_out', c_ll), ('s_in', c_int), ('ci_off', c_int), ('Ci', c_int), ('Co', c_int),
+                ('accumulate', c_int), ('ntaps', c_int), ('kpos', c_int * MAX_TAPS)]
+
+
 class LossSpec(ctypes.Structure):
     """segnb_loss_spec"""
     _fields_ = [('w_bce', c_float), ('w_focal', c_float), ('w_jaccard', c_float), ('w_sjaccard', c_float),
@@ -88,6 +94,7 @@ SIGNATURES = {
     'segnb_conv_wgrad_tf': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(OperandTf), _P, ctypes.POINTER(OperandTf), _P,
                             c_int, _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
+    'segnb_wgrad_target_arm': [ctypes.POINTER(WgradTarget)],
     'segnb_upconv_fprop': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     'segnb_upconv_fprop_acc': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     'segnb_upconv_fprop_act': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int,
@@ -280,7 +287,9 @@ def census_read():
     call('segnb_debug_census', buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
-        k, v = line.rsplit(' ', 1)
+        k, _, v = line.rpartition(' ')
+        if not k or not v.isdigit():
+            continue                       # (a last line cut off by the fixed buffer: skipped, the census still compares)
         out[k] = int(v)
     return out
 

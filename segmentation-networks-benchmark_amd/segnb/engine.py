@@ -273,6 +273,7 @@ class ConvOp(object):
     # critical path; removed in round 5.)
 
     algo_scale = 1.0        # algorithmic / executed FLOPs of a launch (UpConvOp: 9 / 4)
+    _in_place, _ci_offset = False, 0      # (subclasses that build their own channel maps keep the workspace + unpack path)
     pack_fwd = True         # False: the forward matrix is never used (the owner runs the forward through another op)
 
     def __init__(self, rt, weight, bias, in_segments, stride=1, pad=1, transposed=False, need_dgrad=True,
@@ -306,6 +307,12 @@ class ConvOp(object):
         self.in_map = rt.int32(imap)
         self.out_map = rt.int32(list(range(self.Co)) + [-1] * (self.Cop - self.Co))
         self._plans = {}
+        # real input channel of padded channel j is ci_offset + j (padding only behind the real channels): the weight gradient
+        # can be delivered straight into the parameter's gradient (segnb_wgrad_target), no workspace unpack
+        self._in_place = (not transposed and
+                          all(m == ci_offset + j for j, m in enumerate(imap) if m >= 0) and
+                          all(m < 0 for m in imap[self.Ci:]))
+        self._ci_offset = ci_offset
 
     # ---- per-input-size plan: launches, packed buffers -----------------------------------------
     def plan(self, Hi, Wi):
@@ -419,6 +426,8 @@ class ConvOp(object):
         """Job records equivalent to the segnb_unpack_wgrad calls of wgrad(); use with wgrad(..., unpack=False)."""
         p = self.plan(Hi, Wi)
         jobs = []
+        if self.direct_ok():
+            return jobs          # (delivered by the weight-gradient launches themselves: segnb_wgrad_target)
         if self.transposed:
             for li, l in enumerate(p['dg']):
                 jobs.append(dict(w=grad_w, packed=p['dwp'][li], mmap=self.in_map, cmap=self.out_map, s_m=self.s_in,
@@ -642,15 +651,18 @@ class ConvOp(object):
         g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
         return bool(nv.query('segnb_conv_wgrad_tf_ok', g, self.rt.code))
 
-    def wgrad_tf(self, xv, tfx, dv, tfd):
+    def wgrad_tf(self, xv, tfx, dv, tfd, grad_w=None):
         """weight gradient with x = tfx(xv) and dy = tfd(dv) (either transform may be None); the result is left in the
-        packed workspace for the batched unpack, like wgrad(..., unpack=False)"""
+        packed workspace for the batched unpack, like wgrad(..., unpack=False), or delivered into grad_w (direct_ok)"""
         p, rt = self.plan(xv.H, xv.W), self.rt
         l = p['fwd'][0]
         g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dv.H, dv.W, self.Cop, dv.ld)
-        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-               lambda: self._under_wg_share(lambda: nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd,
-                                                            nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)))
+
+        def launch():
+            if self.direct_ok() and grad_w is not None:
+                self._arm_target(p, 0, grad_w)
+            nv.call('segnb_conv_wgrad_tf', g, rt.code, xv.ptr, tfx, dv.ptr, tfd, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)
+        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co, lambda: self._under_wg_share(launch))
 
     # share (%) of the CUs this convolution's weight gradient splits its pixels for; None = the library default.  Set before
     # the first plan (the workspace is sized under it); every launch is bracketed by segnb_wg_cu_share (recordable)
@@ -677,22 +689,60 @@ class ConvOp(object):
         g = self._geom(p, 'f', 0, p['fwd'][0], xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
         return bool(nv.query('segnb_conv_wgrad_bnapply_ok', g, self.rt.code))
 
-    def wgrad_bnapply(self, xv, gv, yv, coef, bcoef, act, slope):
-        """the weight gradient with dy = BatchNorm-backward apply of (gv, yv); result left in the packed workspace"""
+    def wgrad_bnapply(self, xv, gv, yv, coef, bcoef, act, slope, grad_w=None):
+        """the weight gradient with dy = BatchNorm-backward apply of (gv, yv); result left in the packed workspace, or delivered
+        into grad_w (direct_ok)"""
         p, rt = self.plan(xv.H, xv.W), self.rt
         l = p['fwd'][0]
         g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
-        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-               lambda: self._under_wg_share(lambda: nv.call(
-                   'segnb_conv_wgrad_bnapply', g, rt.code, xv.ptr, gv.ptr, gv.ld, yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(bcoef),
-                   self.Cop, act, slope, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)))
+
+        def launch():
+            if self.direct_ok() and grad_w is not None:
+                self._arm_target(p, 0, grad_w)
+            nv.call('segnb_conv_wgrad_bnapply', g, rt.code, xv.ptr, gv.ptr, gv.ld, yv.ptr, yv.ld, nv.ptr(coef), nv.ptr(bcoef),
+                    self.Cop, act, slope, nv.ptr(p['dwp'][0]), p['nslab'][0], rt.stream)
+        _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co, lambda: self._under_wg_share(launch))
+
+    # direct_dw = False (class attribute / SEGNB_DIRECT_DW=0): weight gradients through the packed workspace + batched unpack (A/B)
+    direct_dw = os.environ.get('SEGNB_DIRECT_DW', '1') != '0'
+
+    def direct_ok(self):
+        """Do this convolution's weight-gradient launches deliver into the parameter's gradient themselves?"""
+        return bool(self.direct_dw and self._in_place and self.rt.code == nv.BF16)
+
+    def _arm_target(self, p, li, grad_w):
+        """segnb_wgrad_target_arm for forward launch li: the next weight-gradient call adds its result to grad_w (the fp32
+        gradient of the whole parameter, reference layout [Co][Ci_total][KH][KW])"""
+        key = ('tgt', li, grad_w.data_ptr())
+        t = p.get(key)
+        if t is None:
+            l = p['fwd'][li]
+            t = nv.WgradTarget()
+            t.gw = grad_w.data_ptr()
+            t.s_out, t.s_in, t.ci_off = self.s_out, self.s_in, self._ci_offset
+            t.Ci, t.Co, t.accumulate, t.ntaps = self.Ci, self.Co, 1, len(l.taps)
+            for i, (_, _, a, b) in enumerate(l.taps):
+                t.kpos[i] = a * self.KW + b
+            p[key] = t
+        nv.call('segnb_wgrad_target_arm', t)
 
     def wgrad(self, xv, dyv, grad_w, unpack=True):
         """dW accumulated into grad_w (fp32, parameter layout).  unpack=False leaves the result in the packed
-        workspace (slab 0) for a later batched segnb_unpack_wgrad_multi (unpack_jobs)."""
+        workspace (slab 0) for a later batched segnb_unpack_wgrad_multi (unpack_jobs) -- unless the launches deliver into
+        grad_w themselves (direct_ok: no unpack job exists for them)."""
         p, rt = self.plan(xv.H, xv.W), self.rt
         gw = grad_w
         entry = 'segnb_conv_wgrad'
+        if self.direct_ok():
+            for li, l in enumerate(p['fwd']):
+                g = self._geom(p, 'f', li, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, dyv.H, dyv.W, self.Cop, dyv.ld)
+
+                def launch():
+                    self._arm_target(p, li, gw)
+                    nv.call(entry, g, rt.code, xv.ptr, dyv.ptr, nv.ptr(p['dwp'][li]), p['nslab'][li], rt.stream)
+                _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+                       lambda: self._under_wg_share(launch))
+            return
         if self.transposed:
             # dW[ci][co][k] = sum_hi x[hi][ci] * dy[hi*s - pad + k][co]: "dout" := x, gathered "in" := dy
             for li, l in enumerate(p['dg']):
@@ -1001,10 +1051,14 @@ class UpCatConvOp(object):
             assert not unpack
             p, l, sk, src = self._upcat_args(xv)
             g = self.full._geom(p, 'fv', 0, l, xv.N, xv.H, xv.W, self.full.Cip, sk.ld, dyv.H, dyv.W, self.full.Cop, dyv.ld)
+
+            def launch():
+                if self.full.direct_ok():
+                    self.full._arm_target(p, 0, grad_w)
+                nv.call('segnb_conv_wgrad_upcat', g, self.rt.code, sk.ptr, src, dyv.ptr, nv.ptr(p['dwp'][0]), p['nslab'][0],
+                        self.rt.stream)
             _timed('conv_wgrad', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
-                   lambda: self.full._under_wg_share(lambda: nv.call(
-                       'segnb_conv_wgrad_upcat', g, self.rt.code, sk.ptr, src, dyv.ptr, nv.ptr(p['dwp'][0]), p['nslab'][0],
-                       self.rt.stream)))
+                   lambda: self.full._under_wg_share(launch))
             return
         if not self.segment_wgrad:
             return self.full.wgrad(xv, dyv, grad_w, unpack)
@@ -1388,7 +1442,8 @@ class Stage(object):
                     nv.ptr(self.coef), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
                     nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), rt.stream)
             self._stats_stale = False
-            self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope)
+            self.conv.wgrad_bnapply(xv, g_direct, yv, self.coef, self.bcoef, self.act, self.slope,
+                                    grad_w=grads.grad_of(self.conv.weight))
             return False
         # the weight gradient is forked to the side stream right behind the apply pass: its event rides on that launch
         if self.defer_unpack and dx is not None and rt.side_stream() is not None:
@@ -1436,8 +1491,7 @@ class Stage(object):
             if x_tf is not None:
                 # the convolution's input is not in memory: recomputed from the producer's pre-BatchNorm output on load
                 assert self.defer_unpack and not unpack
-                grads.grad_of(self.conv.weight)                 # (noted as touched; the batched unpack writes it)
-                self.conv.wgrad_tf(xv, x_tf, dz, None)
+                self.conv.wgrad_tf(xv, x_tf, dz, None, grad_w=grads.grad_of(self.conv.weight))
             else:
                 self.conv.wgrad(xv, dz, grads.grad_of(self.conv.weight), unpack=unpack)
         side = rt.fork_side() if (self.defer_unpack and dx is not None) else None

@@ -149,6 +149,7 @@ class Tape(object):
         for t in self._zero_each_step.values():
             t.zero_()
         self.back, self._seq = [], 0
+        self._adopted_ranges = []          # (lazy_add: gradient views taken as accumulating first contributions, this step)
         self._bias_pending = []
         self.fused_stats = []
         for p, pool in self._drop_pools.items():
@@ -228,18 +229,34 @@ class Tape(object):
     # (FCDenseNet accumulates its dense blocks' contributions into slices of shared buffers, in place and in order: not there)
     lazy_add = False
 
+    def _adopted(self, gview):
+        """Does gview overlap a view some tensor took as its first gradient contribution (and accumulates into in place)?"""
+        lo, hi = self._span(gview)
+        for (p0, p1) in self._adopted_ranges:
+            if lo < p1 and p0 < hi:
+                return True
+        return False
+
+    @staticmethod
+    def _span(v):
+        return v.ptr, v.ptr + ((v.N * v.H * v.W - 1) * v.ld + v.Cp) * v.t.element_size()
+
     def contribute(self, act, gview):
         if not act.needs_grad:
             return
         if act._g is None:
             act.g = gview
+            if self.lazy_add:
+                self._adopted_ranges.append(self._span(gview))
             return
 
         def add(v=act._g):
             nv.call('segnb_add', self.rt.code, v.ptr, v.ld, gview.ptr, gview.ld, v.ptr, v.ld, v.N, v.H, v.W, v.Cp,
                     self.rt.stream)
-        if self.lazy_add and act._g2 is None and not act.g_is_dz:
-            # held back: gview is a buffer of its call site that nothing writes again during this backward
+        if self.lazy_add and act._g2 is None and not act.g_is_dz and not self._adopted(gview):
+            # held back: gview is a buffer of its call site that nothing writes again during this backward -- which is NOT true of
+            # a view another tensor adopted as its accumulating first contribution (add() / concat() hand the same gradient view,
+            # or slices of it, to several inputs: ADVICE r5); such a view is added at once
             act._g2, act._settle = gview, add
         else:
             act.g                      # (a third contribution: the pending one is added first, in arrival order)

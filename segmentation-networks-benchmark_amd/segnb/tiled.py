@@ -39,7 +39,11 @@ def _as_normalize(t, C):
     (segnb.engine.InputNorm has the same fields) or the reference's ``Sequential([ImageOnly(NormalizeImage(..))])`` of
     inria_submit.py:286-288 -- with one mean / std per channel; else None."""
     for _ in range(3):
-        if all(hasattr(t, a) for a in ('scale', 'mean', 'std')):
+        # by TYPE NAME, not by attribute names alone: another transform with fields called scale / mean / std must not be replaced
+        # silently by this arithmetic (ADVICE r5).  The fused form evaluates (x * scale - mean) * (1 / std) in fp32 where
+        # lib/augmentations.py:452-460 divides in float64: 1-2 ulp of the normalised fp32 input, below the bf16 / fp32 rounding of
+        # the first convolution's operand
+        if type(t).__name__ in ('NormalizeImage', 'InputNorm') and all(hasattr(t, a) for a in ('scale', 'mean', 'std')):
             mean, std = np.atleast_1d(np.asarray(t.mean, dtype=np.float32)), np.atleast_1d(np.asarray(t.std, dtype=np.float32))
             if len(mean) == C and len(std) == C and C <= 8 and np.all(std != 0):
                 return float(t.scale), nv.float_array(mean), nv.float_array(std)

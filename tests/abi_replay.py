@@ -135,6 +135,10 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
             rec.calls.append((name, pre, post, [a if isinstance(a, int) else None for a in args]))
             return
         idx = len(rec.calls)
+        # a weight gradient behind segnb_wgrad_target_arm delivers into the parameter's gradient (inside the target struct, not an
+        # argument): its workspace argument is scratch afterwards on both sides -- not compared; the published gradients are, at
+        # the end of the step
+        armed, rec.armed = getattr(rec, 'armed', False), name == 'segnb_wgrad_target_arm'
         rname, rpre, rpost, _ = rec.forced[idx]
         assert rname == name, 'call %d: emulator ran %s, product runs %s' % (idx, rname, name)
         for (p, t), (rp, (kind, rt)) in zip(targs, rpre):
@@ -153,6 +157,9 @@ def replay(make_model, x, y, loss_fn, dtype, device='cuda',
             loose = name in flip_ops
             if kind == 'skip' or (name == 'segnb_unpack_wgrad' and p == 0):
                 continue            # (the workspace after an unpack: zeros or dead partials, slab counts differ)
+            if armed and ((name in ('segnb_conv_wgrad',) and p == 4) or (name == 'segnb_conv_wgrad_tf' and p == 6) or
+                          (name == 'segnb_conv_wgrad_bnapply' and p == 12) or (name == 'segnb_conv_wgrad_upcat' and p == 5)):
+                continue            # (scratch: see above)
             if kind == 'sum':
                 got = rec.checksum(t)
                 if float((got - rt).abs().max()) > 5 * tol * float(rt[1]) + 1e-30:

@@ -49,6 +49,24 @@ class on_emulator(object):
         nv.set_backend_for_testing(None)
 
 
+def torch_bn_act_bwd(y, g, coef, act, slope, dtype, res=None):
+    """Oracle of the BatchNorm-backward reduction pass (lib/modules/abn/functions.py:107-112: dz through the activation, then
+    edz / eydz) with torch's own autograd on the CPU: z = (y - mean) * scale + shift (+ residual), a = act(z), dz = d a / d z * g
+    rounded to the activation dtype, sums in float64.  y, g, res: [N, H, W, C] tensors of the activation dtype; coef [4][C] =
+    scale, shift, mean, invstd.  -> (dz, sum dz, sum dz * yhat)"""
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    co = coef.detach().float().cpu()
+    yf = y.detach().float().cpu()
+    z = ((yf - co[2]) * co[0] + co[1]).requires_grad_(True)
+    zz = z if res is None else z + res.detach().float().cpu()
+    a = {nv.ACT_RELU: torch.relu, nv.ACT_LEAKY: lambda t: F.leaky_relu(t, slope), nv.ACT_NONE: lambda t: t}[act](zz)
+    a.backward(g.detach().float().cpu())
+    dz = z.grad.to(tdt)
+    dd = dz.double().reshape(-1, dz.shape[-1])
+    yh = ((yf - co[2]) * co[3]).double().reshape(-1, dz.shape[-1])
+    return dz, dd.sum(0), (dd * yh).sum(0)
+
+
 def test_library_loads_and_reports_device():
     lib = nv.load()
     assert lib.segnb_version() >= 1
@@ -808,6 +826,7 @@ def test_batched_pack_unpack_equals_single_job_calls(dtype):
         ci = sum(r for r, _ in segs)
         w = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=gen).cuda()
         op = ConvOp(rt, w, None, segs, 2 if tr else 1, 1, tr, True)
+        op.direct_dw = False               # (this test is about the workspace -> gradient unpack kernels themselves)
         op.plan(16, 16)
         g = torch.randn(w.shape, generator=gen).cuda()
         ops.append(op)
@@ -1141,6 +1160,67 @@ def test_conv_full_size_vs_torch(shape, wg_cu_pct):
         check(name + ' dx vs torch', dxv.dense().float().cpu()[..., :Ci].permute(0, 3, 1, 2), xr.grad, 'bf16')
 
 
+DIRECT_DW_SHAPES = [  # (N, H, W, input segments [(real, padded)], Co): what the launch is served by
+    (4, 32, 32, [(32, 32)], 32),          # thin 32 x 32 tiles, many slabs
+    (2, 64, 64, [(3, 8)], 32),            # first layer: rolling kernel, 3 real of 8 input channels
+    (2, 56, 56, [(64, 64)], 128),         # wave-specialised 64 x 64 tiles, pixel split
+    (8, 14, 14, [(256, 256)], 192),       # flattened 14 x 14 tiles: one slab, written from the accumulators
+    (8, 7, 7, [(128, 128)], 64),          # flattened 7 x 7 tiles
+    (2, 28, 28, [(192, 192)], 40),        # ragged output channels (40 of a 64-channel tile), 16-column tiles
+    (2, 24, 40, [(24, 24)], 24),          # ragged everything on thin tiles
+    (1, 16, 16, [(12, 16), (6, 8)], 16),  # padded concat segments: NOT in place -- stays on the workspace + unpack path
+]
+
+
+@pytest.mark.parametrize('accumulate', [False, True], ids=['fresh', 'accumulate'])
+@pytest.mark.parametrize('shape', DIRECT_DW_SHAPES, ids=lambda s: 'x'.join(str(v) for v in (s[0], s[1], s[2], sum(r for r, _ in s[3]), s[4])))
+def test_weight_gradient_delivered_into_the_parameter_gradient(shape, accumulate):
+    """segnb_wgrad_target: the weight-gradient launches add their result to the parameter's own fp32 gradient
+    ([Co][Ci][3][3], torch_train.py:188's .grad) -- slab sum, transposition and accumulation in one pass, or straight from the
+    accumulators of a single-slab launch -- instead of leaving it in the packed workspace for segnb_unpack_wgrad_multi.
+    Oracle: F.conv2d autograd on the CPU (fp32 on the same bf16 operands); also == the workspace + unpack path up to the
+    order of the slab sum, bitwise equal run to run, on top of what the gradient already held."""
+    N, H, W, segs, Co = shape
+    Ci = sum(r for r, _ in segs)
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 100 + Ci + Co)
+    w = (torch.randn(Co, Ci, 3, 3, generator=gen) * 0.1).bfloat16().float()
+    x = torch.randn(N, Ci, H, W, generator=gen).bfloat16().float()
+    dy = torch.randn(N, Co, H, W, generator=gen).bfloat16().float()
+    base = torch.randn(Co, Ci, 3, 3, generator=gen) if accumulate else torch.zeros(Co, Ci, 3, 3)
+
+    def run(direct):
+        op = ConvOp(rt, w.cuda(), None, segs, 1, 1, False, need_dgrad=False)
+        op.direct_dw = direct
+        xv = View.alloc(rt, N, H, W, op.Cip)
+        off, roff = 0, 0
+        for real, padded in segs:
+            xv.dense()[..., off:off + real] = x[:, roff:roff + real].permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+            off, roff = off + padded, roff + real
+        dyv = View.alloc(rt, N, H, W, op.Cop)
+        dyv.dense()[..., :Co] = dy.permute(0, 2, 3, 1).to('cuda', torch.bfloat16)
+        outs = []
+        for _ in range(2):
+            gw = base.clone().cuda()
+            op.wgrad(xv, dyv, gw)
+            torch.cuda.synchronize()
+            outs.append(gw)
+        return op, outs
+
+    op_d, (g1, g2) = run(True)
+    in_place = len(segs) == 1
+    assert op_d.direct_ok() == in_place
+    assert not in_place or op_d.unpack_jobs(H, W, g1) == []
+    assert torch.equal(g1, g2), 'not reproducible run to run'
+    _, (gu, _) = run(False)
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(dy)
+    name = 'direct dw ' + 'x'.join(map(str, (N, H, W, Ci, Co)))
+    check(name + ' vs torch', (g1.cpu() - base), wr.grad, 'f32')
+    scale = float(wr.grad.abs().max())
+    assert float((g1 - gu).abs().max()) <= 2e-6 * scale * max(1.0, (N * H * W) ** 0.5 / 16), 'differs from the workspace + unpack path'
+
+
 @pytest.mark.parametrize('shape', [(32, 224, 224, 3, 32, 1), (2, 40, 56, 3, 32, 2), (3, 33, 47, 8, 24, 1), (2, 64, 64, 32, 32, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
@@ -1155,6 +1235,7 @@ def test_conv_wgrad_with_recomputed_bn_apply(shape, monkeypatch):
     w = torch.randn(Co, Ci, 3, 3, generator=gen).cuda()
     Cip = cp.pad8(Ci)
     op = ConvOp(rt, w, None, [(Ci, Cip)], 1, 1, False, need_dgrad=False)
+    op.direct_dw = False                # (the two results are compared in the packed workspace)
     xv = View.alloc(rt, N, H, W, Cip)
     xv.dense()[..., :Ci].normal_()
     yv = View.alloc(rt, N, H, W, op.Cop)
@@ -1386,8 +1467,9 @@ def test_conv_dgrad_with_fused_bn_reduce(shape):
 @pytest.mark.parametrize('with_res', [False, True])
 @pytest.mark.parametrize('shape', [(2, 17, 23, 40), (1, 64, 64, 64), (16, 128, 128, 64)], ids=lambda s: 'x'.join(map(str, s)))
 def test_bn_act_bwd_reduce_two_sources(shape, with_res, dtype):
-    """segnb_bn_act_bwd_reduce_add(g1, g2) == segnb_add(g1, g2) followed by segnb_bn_act_bwd_reduce: dz bit for bit, the sums to
-    fp64 rounding of another block order (the identity branches of linknet.py:41-62: a tensor with two consumers)."""
+    """segnb_bn_act_bwd_reduce_add(g1, g2) against the oracle -- torch's activation backward of round(g1 + g2) on the CPU, float64
+    sums -- and == segnb_add(g1, g2) followed by segnb_bn_act_bwd_reduce: dz bit for bit, the sums to fp64 rounding of another
+    block order (the identity branches of linknet.py:41-62: a tensor with two consumers)."""
     N, H, W, C = shape
     rt = Runtime('cuda', dtype)
     y, g1, g2, r = (View.alloc(rt, N, H, W, C) for _ in range(4))
@@ -1407,8 +1489,17 @@ def test_bn_act_bwd_reduce_two_sources(shape, with_res, dtype):
     nv.call('segnb_bn_act_bwd_reduce_add', rt.code, y.ptr, y.ld, N, H, W, C, nv.ptr(coef), nv.ACT_LEAKY, 0.01, None, g1.ptr, g1.ld,
             g2.ptr, g2.ld, dz.ptr, dz.ld, nv.ptr(s_f), rp, rl, st)
     torch.cuda.synchronize()
+    # oracle: torch's own activation backward on g = round(g1 + g2) (what torch.add of two bf16 / fp32 gradients holds), float64 sums
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g_t = (g1.dense().float().cpu() + g2.dense().float().cpu()).to(tdt)
+    dz_t, s1_t, s2_t = torch_bn_act_bwd(y.dense(), g_t, coef, nv.ACT_LEAKY, 0.01, dtype, r.dense() if with_res else None)
+    check('dz vs torch', dz.dense(), dz_t, dtype)
+    a = s_f.sum(0).cpu().numpy()
+    np.testing.assert_allclose(a[0], s1_t.numpy(), rtol=1e-4, atol=1e-4 * float(s1_t.abs().max()) + 1e-3)
+    np.testing.assert_allclose(a[1], s2_t.numpy(), rtol=1e-4, atol=1e-4 * float(s2_t.abs().max()) + 1e-3)
+    # sibling: the two separate launches it replaces, bit for bit
     assert torch.equal(dz.t, dz_ref.t)
-    a, b = s_f.sum(0).cpu().numpy(), s_ref.sum(0).cpu().numpy()
+    b = s_ref.sum(0).cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * float(np.abs(b).max()))
     if N * H * W <= 20000:
         with on_emulator():
@@ -1571,9 +1662,10 @@ def test_conv_dgrad_never_stored(shape, accumulate):
                                    (2, 33, 17, 200, 8, 2), (8, 128, 128, 272, 16, 1), (8, 256, 256, 112, 16, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_thin_kernel_vs_general(shape):
-    """conv_thin_kernel (fprop_thin.hip: <= 16 -> >= 48 channels, a dense layer's data gradient, tiramisu.py:9-20) against the general
-    gather kernel: the gradient to bf16 rounding of another summation order, the BatchNorm-backward sums of its fused epilogue equal
-    to the reduction pass run on ITS output; plain and fused launches store the same bits; channel splits (few pixels) included."""
+    """conv_thin_kernel (fprop_thin.hip: <= 16 -> >= 48 channels, a dense layer's data gradient, tiramisu.py:9-20) against the
+    ORACLE -- F.conv2d's autograd on the CPU for the gradient, torch's activation backward + float64 sums for the fused
+    BatchNorm-backward reduction -- and then against its siblings: the general gather kernel (bf16 rounding of another summation
+    order), the reduction pass run on ITS output; plain and fused launches store the same bits; channel splits (few pixels)."""
     N, H, W, C1, C2, act = shape
     rt = Runtime('cuda', 'bf16')
     gen = torch.Generator().manual_seed(H * 5 + C1)
@@ -1604,17 +1696,29 @@ def test_conv_thin_kernel_vs_general(shape):
     nv.call('segnb_bn_act_bwd_reduce', rt.code, y1.ptr, y1.ld, N, H, W, C1, nv.ptr(coef), act, 0.01, None, g_plain.ptr, g_plain.ld,
             None, 0, None, 0, None, 0, nv.ptr(sums_ref), None, 0, st)
     torch.cuda.synchronize()
+    # the oracle first: the data gradient is F.conv2d's own autograd on the CPU (fp32 on the same bf16 operands) ...
+    xr = torch.zeros(N, C1, H, W, requires_grad=True)
+    wr = w2.detach().cpu().bfloat16().float()
+    F.conv2d(xr, wr, None, padding=1).backward(dyv.dense()[..., :C2].float().cpu().permute(0, 3, 1, 2))
+    check('thin vs F.conv2d backward', g_plain.dense().float().cpu().permute(0, 3, 1, 2), xr.grad, 'bf16')
+    # ... and the fused reduction's sums are torch's, taken over the gradient the launch STORED (the epilogue's own arithmetic:
+    # dz through the activation of the producing BatchNorm, edz / eydz of lib/modules/abn/functions.py:107-112)
+    _, s1_t, s2_t = torch_bn_act_bwd(y1.dense(), g_plain.dense(), coef, act, 0.01, 'bf16')
+    a = sums_f.sum(0).cpu().numpy()
+    for got, ref_t in ((a[0], s1_t.numpy()), (a[1], s2_t.numpy())):
+        assert np.abs(got - ref_t).max() <= 2e-5 * float(np.abs(ref_t).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(got - ref_t).max()
+    # then the siblings: the general gather kernel, the plain launch, the stand-alone reduction pass, a second run
     check('thin vs general', g_plain.t, g_gen.t, 'bf16')
     assert torch.equal(g_plain.t, g_f.t)
-    a, b = sums_f.sum(0).cpu().numpy(), sums_ref.sum(0).cpu().numpy()
+    b = sums_ref.sum(0).cpu().numpy()
     assert np.abs(a - b).max() <= 2e-5 * float(np.abs(b).max()) + 1e-6 * (N * H * W) ** 0.5, np.abs(a - b).max()
     np.testing.assert_allclose(sums_f2.sum(0).cpu().numpy(), a, rtol=1e-12, atol=1e-9)       # fixed order inside a block
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_maxpool_bwd_two_sources(dtype):
-    """segnb_maxpool_bwd_add(g1, g2) == segnb_add(g1, g2) followed by segnb_maxpool_bwd, bit for bit (the ResNet stem's MaxPool2d(3, 2, 1)
-    whose output has two consumers, linknet.py:41-62)."""
+    """segnb_maxpool_bwd_add(g1, g2) against F.max_pool2d's backward of round(g1 + g2) on the CPU (the oracle), and == segnb_add(g1, g2)
+    followed by segnb_maxpool_bwd, bit for bit (the ResNet stem's MaxPool2d(3, 2, 1) whose output has two consumers, linknet.py:41-62)."""
     rt = Runtime('cuda', dtype)
     N, H, W, C = 2, 37, 41, 24
     x = View.alloc(rt, N, H, W, C)
@@ -1631,10 +1735,13 @@ def test_maxpool_bwd_two_sources(dtype):
     nv.call('segnb_maxpool_bwd_add', rt.code, x.ptr, x.ld, g1.ptr, g1.ld, g2.ptr, g2.ld, N, H, W, C, 3, 2, 1, dx.ptr, dx.ld,
             nv.ptr(idx), st)
     torch.cuda.synchronize()
-    assert torch.equal(dx.t, dx_ref.t)
-    xr = x.dense().float().permute(0, 3, 1, 2).clone().requires_grad_(True)
-    F.max_pool2d(xr, 3, 2, 1).backward(gs.dense().float().permute(0, 3, 1, 2))
-    check('vs torch', dx.dense().float().permute(0, 3, 1, 2), xr.grad, dtype)
+    # oracle: F.max_pool2d's backward of round(g1 + g2) on the CPU
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    xr = x.dense().float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gsum = (g1.dense().float().cpu() + g2.dense().float().cpu()).to(tdt).float()
+    F.max_pool2d(xr, 3, 2, 1).backward(gsum.permute(0, 3, 1, 2))
+    check('vs torch', dx.dense().float().cpu().permute(0, 3, 1, 2), xr.grad, dtype)
+    assert torch.equal(dx.t, dx_ref.t)        # sibling: the two launches it replaces, bit for bit
 
 
 ACT_EP_CASES = [

@@ -263,6 +263,10 @@ def test_predict_tiled_uint8_image_normalised_by_the_gather():
     tf = Sequential([ImageOnly(NormalizeImage(mean=(0.41, 0.43, 0.39), std=(0.2, 0.19, 0.21)))])
     assert _as_normalize(tf, 3) is not None and _as_normalize(InputNorm(), 3) is not None
     assert _as_normalize(tf, 1) is None and _as_normalize(lambda im: (im, None), 3) is None
+
+    class Lookalike:                           # the same field names under another name: NOT replaced by the fused arithmetic
+        scale, mean, std = 1.0 / 255., (0.4, 0.4, 0.4), (0.2, 0.2, 0.2)
+    assert _as_normalize(Lookalike(), 3) is None
     model = _Lin(16)
     t = {}
     got = predict_tiled(img, model, tf, 16, 4)

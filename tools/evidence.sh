@@ -36,7 +36,7 @@ find $O/${TAG}_prof_stats -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {}
 python3 tools/layer_bench.py > $O/${TAG}_layers.txt 2>&1
 python3 tools/prologue_gap.py > $O/${TAG}_prologue_gap.txt 2>&1
 python3 tools/coresidency_probe.py > $O/${TAG}_coresidency.txt 2>&1
-python3 bench.py --model unet16 --tiled > $O/${TAG}_bench_tiled.json 2>/dev/null
+python3 bench.py --model unet16 --tiled > $O/${TAG}_bench_tiled.json 2> $O/${TAG}_bench_tiled.log
 python3 tools/bn_bench.py > $O/${TAG}_bn_passes.txt 2>&1
 python3 tools/step_timeline.py > $O/${TAG}_timeline.txt 2>&1
 python3 tools/upcat_bench.py > $O/${TAG}_upcat_layers.txt 2>&1
