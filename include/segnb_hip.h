@@ -651,6 +651,16 @@ int segnb_bn_fwd_fused_head(int dtype, const void* y, int ld_y, int N, int H, in
 int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef, int act,
                       float slope, const float* dropmul, const float* head_w, int K, const float* dlogits, void* dz, int ld_dz,
                       double* sums, float* dw, float* db, segnb_stream_t stream);
+/* The second pass of that layer when segnb_head_bn_bwd was given dz = NULL (sums only): dz is a function of the d(logits) map and y
+ * alone, so it is recomputed here -- the expressions and roundings of segnb_head_bn_bwd, bit for bit -- and
+ *     dy = round(a * (dz - c1 - yhat * c2))
+ * leaves, with (a, c1, c2) taken from the sums inside the launch (the fused finalize of segnb_bn_bwd_apply_fused: bcoef, dgamma /
+ * dbeta, the forward statistics cleared).  The Cp-channel dz tensor between the two passes (lib/models/zf_unet.py:56-58,91-93:
+ * 103 MB at 224 x 224, bs 32) is neither written nor read. */
+int segnb_head_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
+                            const double* sums, const float* gamma, float* bcoef, float* dgamma, float* dbeta, int accumulate,
+                            double* fwd_stats_to_clear, int act, float slope, const float* dropmul, const float* head_w, int K,
+                            const float* dlogits, void* dy, int ld_dy, segnb_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pixel binary losses and metrics (lib/losses.py:7-101, lib/metrics.py:9-43).

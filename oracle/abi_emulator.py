@@ -1080,6 +1080,24 @@ class AbiEmulator(object):
         return self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, da.data_ptr(), Cp, None, 0,
                                             None, 0, dz, ld_dz, sums, None, 0, stream)
 
+    def segnb_head_bn_bwd_apply(self, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate,
+                                clear_stats, act, slope, dropmul, head_w, K, dlogits, dy, ld_dy, stream):
+        """dz recomputed as segnb_head_bn_bwd computes it (into a temporary), then segnb_bn_bwd_apply_fused on it"""
+        if not self.segnb_head_fused_ok(K, Cp):
+            return -1
+        dt = _tdt(dtype)
+        da = torch.zeros(N * H * W * Cp, dtype=dt)
+        rc = self.segnb_head_bwd(dtype, None, Cp, N, H, W, C, Cp, head_w, K, dlogits, da.data_ptr(), Cp, None, None, stream)
+        if rc:
+            return rc
+        dz = torch.zeros(N * H * W * Cp, dtype=dt)
+        rc = self.segnb_bn_act_bwd_reduce(dtype, y, ld_y, N, H, W, Cp, coef, act, slope, dropmul, da.data_ptr(), Cp, None, 0,
+                                          None, 0, dz.data_ptr(), Cp, None, None, 0, stream)
+        if rc:
+            return rc
+        return self.segnb_bn_bwd_apply_fused(dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate,
+                                             clear_stats, dz.data_ptr(), Cp, dy, ld_dy, stream)
+
     def segnb_head_fwd(self, dtype, a, ld_a, N, H, W, C, w, bias, K, logits, stream):
         A = _nhwc(a, N, H, W, C, ld_a, _tdt(dtype)).float()
         Wm = _mem(w, K * C, torch.float32).view(K, C)
@@ -1091,7 +1109,7 @@ class AbiEmulator(object):
 
     def segnb_head_bwd(self, dtype, a, ld_a, N, H, W, C, Cp, w, K, dlogits, da, ld_da, dw, db, stream):
         dt = _tdt(dtype)
-        A = _nhwc(a, N, H, W, C, ld_a, dt).float()
+        A = _nhwc(a, N, H, W, C, ld_a, dt).float() if a is not None else None
         Wm = _mem(w, K * C, torch.float32).view(K, C)
         DL = _mem(dlogits, N * K * H * W, torch.float32).view(N, K, H, W).permute(0, 2, 3, 1)
         if da is not None:

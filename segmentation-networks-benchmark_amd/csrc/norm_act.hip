@@ -971,7 +971,8 @@ __global__ __launch_bounds__(NTHR) void head_bn_bwd_kernel(const T* __restrict__
                 round_store8((T*)nullptr, d);                    // da as segnb_head_bwd would have stored it
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d[e] = d[e] * dm[e] * act_grad(z[e] + 0.f, act, slope);
-                round_store8(dz + (long long)pix * ld_dz + c0, d);
+                // (dz == NULL: sums only -- segnb_head_bn_bwd_apply recomputes dz from the same operands with these expressions)
+                round_store8(dz != nullptr ? dz + (long long)pix * ld_dz + c0 : (T*)nullptr, d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     s1[e] += d[e];
@@ -1010,6 +1011,100 @@ __global__ __launch_bounds__(NTHR) void head_bn_bwd_kernel(const T* __restrict__
                 prow[k * (CT * 8 + 1) + CT * 8] = sum;
             }
         }
+}
+
+
+// Second pass of the LAST layer when segnb_head_bn_bwd did not store dz (dz = NULL there): dz is a function of the d(logits) map
+// (4 bytes per pixel and class) and y alone -- da = round(sum_k dlogits_k w_k), dz = round(da * drop * act'(z)), the expressions of
+// head_bn_bwd_kernel above, bit for bit -- so the 2 x Cp-bytes-per-pixel tensor in between need not exist: this pass reads y and
+// d(logits) again and leaves dy = round(a * (dz - c1 - yhat * c2)); (a, c1, c2) from the sums inside the launch (fused finalize,
+// as segnb_bn_bwd_apply_fused).  ZF_UNET's last layer at 224 x 224, bs 32: one 103 MB write and one 103 MB read less per step.
+template <typename T, int KM>
+__global__ __launch_bounds__(NTHR) void head_bn_apply_kernel(const T* __restrict__ y, int ld_y, EwShape s,
+                                                             const float* __restrict__ coef, int act, float slope,
+                                                             const float* __restrict__ dropmul, const float* __restrict__ w, int C,
+                                                             int K, const float* __restrict__ dl, T* __restrict__ dy, int ld_dy,
+                                                             const BnBwdParams bp) {
+    __shared__ float sred[SRED_FLOATS];
+    constexpr int U = 2;
+    const int tx = threadIdx.x % s.CT, ty = threadIdx.x / s.CT;
+    const int cc = blockIdx.y * s.CT + tx;
+    const bool active = cc < s.CPP;
+    const int c0 = active ? cc * 8 : 0;
+    const int stride = gridDim.x * s.PY;
+    const int npix = s.N * s.H * s.W, hw = s.H * s.W;
+    const FastDiv d_hw(hw);
+    Raw8<T> ry[U];
+    Raw8<float> rdm[U];
+    float g[U][KM];
+    auto issue = [&](int it0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pix = it0 + u * stride;
+            const int pc = pix < npix ? pix : it0;
+            load_raw(y + (long long)pc * ld_y + c0, ry[u]);
+            const int n = (dropmul != nullptr || KM > 1) ? d_hw.div(pc) : 0;
+            if (dropmul != nullptr) load_raw(dropmul + n * s.Cp + c0, rdm[u]);
+            if (KM == 1) {
+                g[u][0] = dl[pc];
+            } else {
+                const int r = pc - n * hw;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) g[u][k] = k < K ? dl[((long long)n * K + k) * hw + r] : 0.f;
+            }
+        }
+    };
+    int it0 = blockIdx.x * s.PY + ty;
+    if (active && it0 < npix) issue(it0);            // (before the coefficient prologue: two latency chains overlapped)
+    float ap[4][8];
+    apply_src_coefs(bp, coef, s, tx, c0, sred, ap);
+    float wv[KM][8];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[k][e] = (k < K && c0 + e < C) ? w[k * C + c0 + e] : 0.f;
+    float sc[8], sh[8], mu[8];
+    load8(coef + c0, sc);
+    load8(coef + s.Cp + c0, sh);
+    load8(coef + 2 * s.Cp + c0, mu);
+    if (!active) return;
+    while (it0 < npix) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pix = it0 + u * stride;
+            if (pix >= npix) break;
+            float yv[8], dm[8], d[8], yc[8], z[8];
+            unpack_raw(ry[u], yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dm[e] = 1.f;
+            if (dropmul != nullptr) unpack_raw(rdm[u], dm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                yc[e] = yv[e] - mu[e];
+                z[e] = yc[e] * sc[e] + sh[e];
+                d[e] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+                    const float gk = g[u][k];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] = fmaf(gk, wv[k][e], d[e]);
+                }
+            round_store8((T*)nullptr, d);                    // da as segnb_head_bwd would have stored it
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = d[e] * dm[e] * act_grad(z[e] + 0.f, act, slope);
+            round_store8((T*)nullptr, d);                    // dz as segnb_head_bn_bwd would have stored it
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yh = yc[e] * ap[3][e];
+                d[e] = ap[0][e] * (d[e] - ap[1][e] - yh * ap[2][e]);
+            }
+            round_store8(dy + (long long)pix * ld_dy + c0, d);
+        }
+        it0 += U * stride;
+        if (it0 < npix) issue(it0);
+    }
 }
 
 
@@ -1692,7 +1787,7 @@ extern "C" int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int 
                                  void* dz, int ld_dz, double* sums, float* dw, float* db, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_head_bn_bwd, dtype, y, ld_y, N, H, W, C, Cp, coef, act, slope, dropmul, head_w, K, dlogits, dz, ld_dz, sums, dw, db, stream);
     if (int rc = check_ew(N, H, W, Cp)) return rc;
-    SEGNB_CHECK_ARG(y && coef && head_w && dlogits && dz && sums && C > 0 && Cp >= C, "NULL tensor");
+    SEGNB_CHECK_ARG(y && coef && head_w && dlogits && sums && C > 0 && Cp >= C, "NULL tensor");      // (dz NULL: sums only)
     SEGNB_CHECK_ARG(segnb_head_fused_ok(K, Cp), "1..4 classes, Cp / 8 a power of two <= 32 (segnb_head_fused_ok)");
     const EwShape s = make_shape(N, H, W, Cp);
     const dim3 grid = make_grid(s, (long long)N * H * W);
@@ -1715,6 +1810,36 @@ extern "C" int segnb_head_bn_bwd(int dtype, const void* y, int ld_y, int N, int 
         segnb_head_bwd_finish(part, (int)grid.x, (int)grid.y, K, C, s.CT, dw, db, (hipStream_t)stream);
         SEGNB_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int segnb_head_bn_bwd_apply(int dtype, const void* y, int ld_y, int N, int H, int W, int C, int Cp, const float* coef,
+                                       const double* sums, const float* gamma, float* bcoef, float* dgamma, float* dbeta,
+                                       int accumulate, double* fwd_stats_to_clear, int act, float slope, const float* dropmul,
+                                       const float* head_w, int K, const float* dlogits, void* dy, int ld_dy,
+                                       segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_head_bn_bwd_apply, dtype, y, ld_y, N, H, W, C, Cp, coef, sums, gamma, bcoef, dgamma, dbeta, accumulate,
+                      fwd_stats_to_clear, act, slope, dropmul, head_w, K, dlogits, dy, ld_dy, stream);
+    if (int rc = check_ew(N, H, W, Cp)) return rc;
+    SEGNB_CHECK_ARG(y && coef && sums && bcoef && head_w && dlogits && dy && C > 0 && Cp >= C, "NULL tensor");
+    SEGNB_CHECK_ARG(segnb_head_fused_ok(K, Cp), "1..4 classes, Cp / 8 a power of two <= 32 (segnb_head_fused_ok)");
+    SEGNB_CHECK_ARG(ld_y % 8 == 0 && ld_dy % 8 == 0 && ld_y >= Cp && ld_dy >= Cp, "bad strides");
+    const EwShape s = make_shape(N, H, W, Cp);
+    const dim3 grid = make_grid(s, (long long)N * H * W);
+    const BnBwdParams bp = {sums, (double)N * H * W, gamma, dgamma, dbeta, C, accumulate, bcoef, fwd_stats_to_clear};
+#define SEGNB_HBA(TT, KMM)                                                                                                    \
+    SEGNB_LAUNCH_FORKABLE((head_bn_apply_kernel<TT, KMM>), grid, dim3(NTHR), 0, (hipStream_t)stream, (const TT*)y, ld_y, s, coef, \
+                          act, slope, dropmul, head_w, C, K, dlogits, (TT*)dy, ld_dy, bp)
+    if (dtype == SEGNB_BF16) {
+        if (K == 1) SEGNB_HBA(bf16_t, 1); else SEGNB_HBA(bf16_t, 4);
+    } else if (dtype == SEGNB_F32) {
+        if (K == 1) SEGNB_HBA(float, 1); else SEGNB_HBA(float, 4);
+    } else {
+        segnb_set_error("segnb_head_bn_bwd_apply: unknown dtype %d", dtype);
+        return SEGNB_E_BADARG;
+    }
+#undef SEGNB_HBA
+    SEGNB_LAUNCH_CHECK();
     return 0;
 }
 

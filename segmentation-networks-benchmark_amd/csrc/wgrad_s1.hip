@@ -871,9 +871,13 @@ __global__ __launch_bounds__(GROUPS == 1 ? 256 : 64 * GROUPS) void slab_reduce_p
             }
         }
     } else {
+        // tap by tap; gridDim.y > 1: the taps are spread over the blocks of a column too (many slabs, few pairs -- the thin layers'
+        // 128 - 256 slabs of 1024 - 4096 pairs: 16 - 64 blocks walking nine taps each took 40 - 90 us beside the dependent chain)
         const bool keep = in && co < a.Co && ci < a.Ci;
         float* const dst = a.gw + (long long)co * a.s_out + (long long)(a.ci_off + ci) * a.s_in;
-        for (int t = 0; t < a.nt; ++t) {
+        const int tpb = (a.nt + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int t_lo = (int)blockIdx.y * tpb, t_hi = t_lo + tpb < a.nt ? t_lo + tpb : a.nt;
+        for (int t = t_lo; t < t_hi; ++t) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             if (in) {
                 int sl = grp;
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(GROUPS == 1 ? 256 : 64 * GROUPS) void slab_reduce_p
             }
             float v = (a0 + a1) + (a2 + a3);
             if constexpr (GROUPS > 1) {
-                if (t > 0) __syncthreads();                        // the previous tap's sums were read
+                if (t > t_lo) __syncthreads();                     // the previous tap's sums were read
                 part[grp][0][lane] = v;
                 __syncthreads();
                 v = 0.f;
@@ -1382,14 +1386,19 @@ void segnb_wgrad_to_param(float* dwp, int Cop, int ntaps, int Cip, int nslab, co
     p.rezero = rezero ? 1 : 0;
     for (int t = 0; t < ntaps; ++t) p.kpos[t] = tgt->kpos[t];
     const long long pairs = (long long)Cop * Cip;
+    // few slabs (the layers with many channel tiles = most of the parameters): one thread per pair walks the slabs in order, the
+    // block's 3 x 3 windows leave as consecutive floats.  Many slabs (>= 32: few pairs): the slabs are summed by 4 / 16 groups per
+    // block AND the taps are spread over the grid's second dimension; the few outputs leave as element stores
     const bool nt9 = ntaps == 9 && tgt->s_in == 9;
-    const int groups = nslab <= 16 ? 1 : ((nslab < 64 || pairs >= 16384) ? 4 : 16);
+    const bool tappar = nslab >= 32;
+    const int groups = nslab <= 16 ? 1 : (nslab < 128 ? 4 : 16);      // (16 / 8 / 4 groups at >= 128 slabs: the same step time, r06_ab.txt)
+    const unsigned gy = tappar ? (unsigned)ntaps : 1u;
 #define SEGNB_PR_LAUNCH(G, N9)                                                                                            \
-    hipLaunchKernelGGL((slab_reduce_param_kernel<G, N9>), dim3((unsigned)((pairs + (G == 1 ? 255 : 63)) / (G == 1 ? 256 : 64))), \
+    hipLaunchKernelGGL((slab_reduce_param_kernel<G, N9>), dim3((unsigned)((pairs + (G == 1 ? 255 : 63)) / (G == 1 ? 256 : 64)), gy), \
                        dim3(G == 1 ? 256 : 64 * G), 0, stream, p)
     if (groups == 1) { if (nt9) SEGNB_PR_LAUNCH(1, true); else SEGNB_PR_LAUNCH(1, false); }
-    else if (groups == 4) { if (nt9) SEGNB_PR_LAUNCH(4, true); else SEGNB_PR_LAUNCH(4, false); }
-    else { if (nt9) SEGNB_PR_LAUNCH(16, true); else SEGNB_PR_LAUNCH(16, false); }
+    else if (groups == 4) { if (nt9 && !tappar) SEGNB_PR_LAUNCH(4, true); else SEGNB_PR_LAUNCH(4, false); }
+    else SEGNB_PR_LAUNCH(16, false);
 #undef SEGNB_PR_LAUNCH
 }
 

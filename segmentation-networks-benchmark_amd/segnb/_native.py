@@ -133,6 +133,8 @@ SIGNATURES = {
                               _P, _P, c_int, c_float, _P, _P, c_int, _P],
     'segnb_head_bn_bwd': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, c_int, _P, _P, c_int,
                           _P, _P, _P, _P],
+    'segnb_head_bn_bwd_apply': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_float,
+                                _P, _P, c_int, _P, _P, c_int, _P],
     'segnb_bn_bwd_apply_fused_acc': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P,
                                  _P, c_int, _P, c_int, _P],
     'segnb_bn_bwd_apply_fused_direct': [c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int,

@@ -1390,9 +1390,16 @@ class Stage(object):
         rt = self.rt
         xv, yv, dropmul, _ = self._saved
         dz = self.buffers(yv.N, yv.H, yv.W)['dz']
+        # head_dz_recompute: dz is NOT stored -- backward(dz_ready=True) recomputes it from d(logits) and y inside the apply pass
+        # (segnb_head_bn_bwd_apply): one tensor write and one tensor read less at the network's full resolution
+        self._head_src = (head_w, K, dlogits) if (self.head_dz_recompute and self.bn is not None and self.fuse_finalize) else None
         nv.call('segnb_head_bn_bwd', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef), self.act,
-                self.slope, nv.ptr(dropmul), nv.ptr(head_w), K, nv.ptr(dlogits), dz.ptr, dz.ld, nv.ptr(self.sums), nv.ptr(dw),
-                nv.ptr(db), rt.stream)
+                self.slope, nv.ptr(dropmul), nv.ptr(head_w), K, nv.ptr(dlogits), None if self._head_src is not None else dz.ptr,
+                dz.ld, nv.ptr(self.sums), nv.ptr(dw), nv.ptr(db), rt.stream)
+
+    # head_dz_recompute = False (class attribute / SEGNB_HEAD_DZ=0): the last layer's dz is stored by segnb_head_bn_bwd and read back (A/B)
+    head_dz_recompute = os.environ.get('SEGNB_HEAD_DZ', '1') != '0'
+    _head_src = None
 
     def tf_out(self):
         """the operand transform a consumer applies to this stage's pre-BatchNorm output (after forward(..., defer_act=True))"""
@@ -1448,7 +1455,14 @@ class Stage(object):
         # the weight gradient is forked to the side stream right behind the apply pass: its event rides on that launch
         if self.defer_unpack and dx is not None and rt.side_stream() is not None:
             rt.arm_fork()
-        if has_bn and self._fused_fwd and direct:
+        if dz_ready and self._head_src is not None and has_bn and self._fused_fwd:
+            head_w, K, dlogits = self._head_src
+            nv.call('segnb_head_bn_bwd_apply', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp, nv.ptr(self.coef),
+                    nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef), nv.ptr(grads.grad_of(self.bn.weight)),
+                    nv.ptr(grads.grad_of(self.bn.bias)), 1, nv.ptr(self.stats), self.act, self.slope, nv.ptr(dropmul),
+                    nv.ptr(head_w), K, nv.ptr(dlogits), dz.ptr, dz.ld, rt.stream)
+            self._stats_stale = False
+        elif has_bn and self._fused_fwd and direct:
             nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, yv.ptr, yv.ld, yv.N, yv.H, yv.W, self.C, self.Cp,
                     nv.ptr(self.coef), nv.ptr(self.sums), nv.ptr(self.bn.weight.detach()), nv.ptr(self.bcoef),
                     nv.ptr(grads.grad_of(self.bn.weight)), nv.ptr(grads.grad_of(self.bn.bias)), 1,

@@ -2386,6 +2386,83 @@ def test_last_layer_and_classifier_in_one_pass(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 20, 24, 32, 1, True), (3, 9, 7, 64, 3, False), (2, 16, 12, 16, 2, True), (1, 33, 40, 8, 4, True),
+                                   (32, 224, 224, 32, 1, True)],
+                         ids=lambda s: 'N%d_%dx%d_C%d_K%d_%s' % (s[:5] + ('drop' if s[5] else 'nodrop',)))
+def test_last_layer_dz_never_stored(shape, dtype):
+    """segnb_head_bn_bwd(dz = NULL) + segnb_head_bn_bwd_apply == segnb_head_bn_bwd(dz) + segnb_bn_bwd_apply_fused, bit for bit (dy,
+    the published coefficients, dgamma / dbeta, the cleared forward statistics): the last layer's dz (zf_unet.py:56-58,91-93) is a
+    function of d(logits) and y and is recomputed by the apply pass instead of being written and read back.  Oracle: torch autograd
+    of the same three modules (training-mode batch_norm on y -> ReLU -> Dropout2d multiplier -> 1 x 1 classifier) on the CPU; incl.
+    the timed configuration's 32 x 224 x 224 x 32."""
+    N, H, W, C, K, use_drop = shape
+    if dtype == 'f32' and N * H * W > 100000:
+        pytest.skip('the timed shape runs in the timed precision')
+    rt = Runtime('cuda', dtype)
+    Cp = cp.pad8(C)
+    gen = torch.Generator().manual_seed(17 * C + H + K)
+    y_host = torch.randn(N, H, W, C, generator=gen) * 1.5 + 0.3
+    yv = _view_from(rt, y_host, Cp)
+    gamma = (1 + 0.3 * torch.randn(C, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(C, generator=gen)).cuda()
+    hw_ = (0.3 * torch.randn(K, C, generator=gen)).cuda()
+    dl = (torch.randn(N, K, H, W, generator=gen) / (N * H * W) ** 0.5).cuda()
+    dm = None
+    if use_drop:
+        dm = torch.ones(N, Cp, device='cuda')
+        dm[:, :C] = ((torch.rand(N, C, generator=gen) > 0.3).float() / 0.7).cuda()
+    act = nv.ACT_RELU
+    out = {}
+    for recompute in (False, True):
+        stats = rt.zeros((16, 2, Cp), torch.float64)
+        nv.call('segnb_bn_stats', rt.code, yv.ptr, yv.ld, N, H, W, Cp, nv.ptr(stats), rt.stream)
+        keep_stats = stats.clone()
+        sums, coef, bcoef = rt.zeros((16, 2, Cp), torch.float64), rt.zeros((4, Cp), torch.float32), rt.zeros((3, Cp), torch.float32)
+        rm, rvv, nbt = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+        nv.call('segnb_bn_finalize_keep', nv.ptr(stats), C, Cp, float(N * H * W), nv.ptr(gamma), nv.ptr(beta), 1e-5, 0.1, nv.ptr(rm),
+                nv.ptr(rvv), nv.ptr(nbt), nv.ptr(coef), nv.ptr(sums), rt.stream)
+        dz = View.alloc(rt, N, H, W, Cp)
+        dz.t.fill_(3.0)
+        dw, db = torch.zeros(K, C, device='cuda'), torch.zeros(K, device='cuda')
+        dgam, dbet = torch.ones(C, device='cuda'), torch.ones(C, device='cuda')          # accumulate on top of 1
+        nv.call('segnb_head_bn_bwd', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), act, 0.01, nv.ptr(dm), nv.ptr(hw_), K,
+                nv.ptr(dl), None if recompute else dz.ptr, dz.ld, nv.ptr(sums), nv.ptr(dw), nv.ptr(db), rt.stream)
+        if recompute:
+            torch.cuda.synchronize()
+            assert float((dz.t.float() - 3.0).abs().max()) == 0.0, 'dz was written'
+            nv.call('segnb_head_bn_bwd_apply', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma),
+                    nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), act, 0.01, nv.ptr(dm), nv.ptr(hw_), K, nv.ptr(dl),
+                    dz.ptr, dz.ld, rt.stream)
+        else:
+            nv.call('segnb_bn_bwd_apply_fused', rt.code, yv.ptr, yv.ld, N, H, W, C, Cp, nv.ptr(coef), nv.ptr(sums), nv.ptr(gamma),
+                    nv.ptr(bcoef), nv.ptr(dgam), nv.ptr(dbet), 1, nv.ptr(stats), dz.ptr, dz.ld, dz.ptr, dz.ld, rt.stream)
+        torch.cuda.synchronize()
+        assert float(keep_stats.abs().max()) > 0 and float(stats.abs().max()) == 0.0       # forward statistics cleared
+        out[recompute] = dict(dy=dz.t.clone(), bcoef=bcoef.clone(), dgam=dgam.clone(), dbet=dbet.clone(), dw=dw.clone(), db=db.clone())
+    u, r = out[False], out[True]
+    for k in ('dy', 'bcoef', 'dgam', 'dbet', 'dw', 'db'):
+        assert torch.equal(u[k], r[k]), k
+    # oracle: torch autograd of batch_norm(training) -> relu -> dropout multiplier -> 1x1 classifier on the CPU
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    yr = yv.dense()[..., :C].float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    g_t, b_t = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    a = torch.relu(F.batch_norm(yr, None, None, g_t, b_t, True, 0.1, 1e-5))
+    if dm is not None:
+        a = a * dm[:, :C].cpu()[:, :, None, None]
+    logits = torch.einsum('nchw,kc->nkhw', a, hw_.cpu())
+    logits.backward(dl.cpu())
+    dy_t = yr.grad.permute(0, 2, 3, 1)
+    got = View(r['dy'], N, H, W, Cp).dense()[..., :C].float().cpu()
+    scale = float(dy_t.abs().max())
+    tolr = 3e-2 if dtype == 'bf16' else 2e-4             # (bf16: a, da and dz are each rounded to the storage type on the way)
+    assert float((got - dy_t).abs().max()) <= tolr * scale, float((got - dy_t).abs().max()) / scale
+    np.testing.assert_allclose((r['dgam'] - 1).cpu().numpy(), g_t.grad.numpy(), rtol=2e-2 if dtype == 'bf16' else 1e-3,
+                               atol=(2e-2 if dtype == 'bf16' else 1e-3) * float(g_t.grad.abs().max()))
+    np.testing.assert_allclose((r['dbet'] - 1).cpu().numpy(), b_t.grad.numpy(), rtol=2e-2 if dtype == 'bf16' else 1e-3,
+                               atol=(2e-2 if dtype == 'bf16' else 1e-3) * float(b_t.grad.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_prefix_statistics_table(dtype):
     """tiramisu.py:9-44: a DenseLayer's BatchNorm covers the whole concat prefix.  The statistics of the prefix are those of its
     slices: segnb_bn_act_fwd_stats sums the slice it writes into its range of the buffer's table, segnb_bn_stats_ld sums a slice
