@@ -995,7 +995,12 @@ int s1_slabs(int tiles, bool thin, bool flat = false) {
         const double r = e ? atof(e) : 0.5;
         return r <= 0.0 ? 1.0 : r;
     }();
-    constexpr double frac_thin = 1.0, frac_flat = -1.0;
+    static const double frac_thin = [] {
+        const char* e = getenv("SEGNB_WG_CU_FRACTION_THIN");
+        const double r = e ? atof(e) : 1.0;
+        return r <= 0.0 ? 1.0 : r;
+    }();
+    constexpr double frac_flat = -1.0;
     const int pct = segnb_knob_wg_cu_pct();
     const double wide = pct > 0 ? pct / 100.0 : frac_wide;
     const double frac = thin ? frac_thin : ((flat && frac_flat > 0.0) ? frac_flat : wide);

@@ -706,9 +706,13 @@ class ConvOp(object):
     # direct_dw = False (class attribute / SEGNB_DIRECT_DW=0): weight gradients through the packed workspace + batched unpack (A/B)
     direct_dw = os.environ.get('SEGNB_DIRECT_DW', '1') != '0'
 
+    # (only for parameters above a size -- the thin layers' 9 - 36 k weights through the workspace + batched unpack -- measured the same:
+    # ZF_UNET 4.729 / 4.736 / 4.746 ms at thresholds 0 / 30 k / 300 k, FCDenseNet103 and LinkNet34 +-0.2 %, profiles/r06_ab.txt)
+    direct_min_numel = 0
+
     def direct_ok(self):
         """Do this convolution's weight-gradient launches deliver into the parameter's gradient themselves?"""
-        return bool(self.direct_dw and self._in_place and self.rt.code == nv.BF16)
+        return bool(self.direct_dw and self._in_place and self.rt.code == nv.BF16 and self.weight.numel() >= self.direct_min_numel)
 
     def _arm_target(self, p, li, grad_w):
         """segnb_wgrad_target_arm for forward launch li: the next weight-gradient call adds its result to grad_w (the fp32
@@ -1284,10 +1288,12 @@ class Stage(object):
 
     # BatchNorm + activation of a block's FIRST convolution applied by the second one while it loads its rows (conv_roll_kernel,
     # segnb_conv_fprop_tf): the activated tensor between them is never written (-0.4 GB of HBM traffic per ZF_UNET step at
-    # bs=32).  OFF by default (SEGNB_CONSUMER_FUSION=1 enables): measured on MI355X, same box, alternating runs, 5.368 / 5.378
-    # ms per step with it against 5.373 / 5.384 without -- the two activation passes it removes (2 x ~38 us) come back as
-    # slower convolutions and weight gradients, whose loads now carry ~10 VALU operations per element (profiles/r04_ab.txt)
-    consumer_fusion = os.environ.get('SEGNB_CONSUMER_FUSION', '0') != '0'
+    # bs=32).  ON since round 6 (SEGNB_CONSUMER_FUSION=0 restores the passes): the two activation passes it removes (2 x ~38 us) come
+    # back as slower convolutions and weight gradients, whose loads carry ~10 VALU operations per element -- round 4 measured
+    # -0.1 % (5.368 / 5.378 against 5.373 / 5.384), round 6 on three boxes -0.35 % (4.774 / 4.797 / 4.795 against 4.805 / 4.805 / 4.807;
+    # 4.761 / 4.768 against 4.783 / 4.781: profiles/r06_ab.txt).  The teacher-forced replay that "failed" with it in round 5 compared
+    # the 16 statistics replicas of segnb_conv_fprop_tf one by one instead of their sum (tests/abi_replay.py: _REPLICATED).
+    consumer_fusion = os.environ.get('SEGNB_CONSUMER_FUSION', '1') != '0'
 
     def forward(self, xv, train, dropmul=None, out=None, pool_out=None, up_out=None, need_grad=True, u8=None, x_tf=None,
                 defer_act=False):

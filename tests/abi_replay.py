@@ -88,7 +88,8 @@ def _cmp(name, pos, ref, got, tol, max_outliers, atol=0.0, nslab=(1, 1)):
 # (argument position -> entry points) whose fp64 argument is a [REPL][2][Cp] replicated accumulator: the emulator
 # fills replica 0, the HIP kernels spread blocks over all 16; only the sum over replicas is defined by the ABI
 _REPLICATED = {7: ('segnb_conv_fprop', 'segnb_bn_stats', 'segnb_bn_stats_ld'), 19: ('segnb_bn_act_bwd_reduce',),
-               17: ('segnb_head_bn_bwd', 'segnb_bn_act_bwd_reduce_add'), 13: ('segnb_bn_act_fwd_stats',), 20: ('segnb_head_conv_bwd',), 0: ()}
+               17: ('segnb_head_bn_bwd', 'segnb_bn_act_bwd_reduce_add'), 13: ('segnb_bn_act_fwd_stats',), 20: ('segnb_head_conv_bwd',),
+               8: ('segnb_conv_fprop_tf',), 0: ()}
 
 
 def run_step(model, x, y, loss_fn, device, dtype):
