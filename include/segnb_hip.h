@@ -188,6 +188,16 @@ int segnb_pack_elem_job_blocks(int Mp, int Cp, int ntaps);
 int segnb_pack_pair_job_bytes(void);
 int segnb_pack_pair_job_blocks(int Co, int Ci, int Cop, int Cip);
 int segnb_pack_weight_pair_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
+/* torch.optim.SGD.step() -- plain SGD, w -= lr * g, torch_train.py:71,190 -- on the parameters of a pair-job table AND their weight pack
+ * in ONE pass: every tile of a parameter is read once, updated with segnb_sgd_step's expression (bit-identical parameters), written back,
+ * rounded and stored as both packed matrices.  flat_p / flat_g: the parallel flat fp32 parameter / gradient buffers the jobs' `w` point
+ * into.  Saves the second read of every parameter the next forward's segnb_pack_weight_pair_multi would make.  Not recordable
+ * (optimizer.step() is host code between the recorded lists).  The parameters the table does not cover: segnb_sgd_ranges -- the update
+ * over `nranges` element ranges, ranges = DEVICE int64 [nranges][3] = (start, length, index of the range's first element in the
+ * concatenation of all ranges), total = the sum of the lengths. */
+int segnb_sgd_pack_pair_multi(const void* jobs, int njobs, int total_blocks, float* flat_p, const float* flat_g, float lr,
+                              segnb_stream_t stream);
+int segnb_sgd_ranges(float* p, const float* g, const long long* ranges, int nranges, long long total, float lr, segnb_stream_t stream);
 int segnb_pack_weight_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 int segnb_unpack_wgrad_elem_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream);
 

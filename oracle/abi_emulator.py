@@ -588,6 +588,21 @@ class AbiEmulator(object):
                 D[:Ci, :, :Co] = W[:, :, tf[1]].permute(1, 2, 0).to(torch.bfloat16)
         return 0
 
+    def segnb_sgd_pack_pair_multi(self, jobs, njobs, total_blocks, flat_p, flat_g, lr, stream):
+        raw = bytes((ctypes.c_char * (njobs * self.PAIR_JOB.itemsize)).from_address(int(jobs)))
+        for j in np.frombuffer(raw, dtype=self.PAIR_JOB):
+            n = int(j['Co']) * int(j['Ci']) * 9
+            off = (int(j['w']) - int(flat_p)) // 4
+            W, G = _mem(int(j['w']), n, torch.float32), _mem(int(flat_g) + 4 * off, n, torch.float32)
+            W.sub_(lr * G)
+        return self.segnb_pack_weight_pair_multi(jobs, njobs, total_blocks, stream)
+
+    def segnb_sgd_ranges(self, p, g, ranges, nranges, total, lr, stream):
+        R = _mem(ranges, 3 * nranges, torch.int64).view(nranges, 3)
+        for start, n, _ in R.tolist():
+            _mem(int(p) + 4 * start, n, torch.float32).sub_(lr * _mem(int(g) + 4 * start, n, torch.float32))
+        return 0
+
     # element-wise batched forms (jobs segnb_pack_job_blocks refuses): the single-job calls, job by job
     def segnb_pack_elem_job_blocks(self, Mp, Cp, ntaps):
         if Mp <= 0 or Cp <= 0 or ntaps < 1 or ntaps > 64:

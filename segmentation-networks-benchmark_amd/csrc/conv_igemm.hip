@@ -1314,7 +1314,12 @@ constexpr int PP_CO = 32, PP_CI = 64;
 constexpr int PP_RS = PP_CI * 9 + 4;          // LDS row in bf16 elements (rows 8-byte aligned; 8 rows apart = 16 banks apart)
 constexpr int PP_LOADS = PP_CO * PP_CI * 9 / 4 / 256;
 
-__global__ __launch_bounds__(256) void pack_pair_kernel(const PackPairJob* __restrict__ jobs, int njobs) {
+// SGD (segnb_sgd_pack_pair_multi): the optimizer's update w -= lr * g is applied to the tile on its way through the registers --
+// sgd_kernel's expression, so the parameters are bit-identical to segnb_sgd_step's -- and written back; the packed matrices are
+// then those of the UPDATED parameters: the next forward's weight pack (a second read of every parameter) is already done.
+// g_delta: the gradient of element e of the flat parameter buffer sits g_delta floats behind it (flat_g - flat_p).
+template <bool SGD>
+__global__ __launch_bounds__(256) void pack_pair_kernel(const PackPairJob* __restrict__ jobs, int njobs, long long g_delta, float lr) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[PP_CO * PP_RS];
     const PackPairJob& j = jobs[find_job(jobs, njobs, (int)blockIdx.x)];
     const int tb = blockIdx.x - j.block_start;
@@ -1334,6 +1339,27 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(const PackPairJob* __res
             if (r < run4 && co0 + co_l < Co)
                 v[u] = *reinterpret_cast<const float4*>(j.w + ((long long)(co0 + co_l) * Ci + ci0) * 9 + 4 * r);
         }
+        if constexpr (SGD) {
+            float4 gv[PP_LOADS];
+#pragma unroll
+            for (int u = 0; u < PP_LOADS; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                const int co_l = i / ROW4, r = i - co_l * ROW4;
+                gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < run4 && co0 + co_l < Co)
+                    gv[u] = *reinterpret_cast<const float4*>(j.w + g_delta + ((long long)(co0 + co_l) * Ci + ci0) * 9 + 4 * r);
+            }
+#pragma unroll
+            for (int u = 0; u < PP_LOADS; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                const int co_l = i / ROW4, r = i - co_l * ROW4;
+                float4 pv = v[u];
+                pv.x -= lr * gv[u].x; pv.y -= lr * gv[u].y; pv.z -= lr * gv[u].z; pv.w -= lr * gv[u].w;
+                v[u] = pv;
+                if (r < run4 && co0 + co_l < Co)
+                    *reinterpret_cast<float4*>(const_cast<float*>(j.w) + ((long long)(co0 + co_l) * Ci + ci0) * 9 + 4 * r) = pv;
+            }
+        }
     } else {
         // rows that are not 16-byte aligned (the first layer: 3 input channels): element loads, same tile image
         const int runf = nv > 0 ? nv * 9 : 0;
@@ -1347,6 +1373,14 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(const PackPairJob* __res
             v[u].y = (in && 4 * r + 1 < runf) ? row[1] : 0.f;
             v[u].z = (in && 4 * r + 2 < runf) ? row[2] : 0.f;
             v[u].w = (in && 4 * r + 3 < runf) ? row[3] : 0.f;
+            if constexpr (SGD) {
+                float* wrow = const_cast<float*>(row);
+                const float* grow = row + g_delta;
+                if (in && 4 * r < runf) { v[u].x -= lr * grow[0]; wrow[0] = v[u].x; }
+                if (in && 4 * r + 1 < runf) { v[u].y -= lr * grow[1]; wrow[1] = v[u].y; }
+                if (in && 4 * r + 2 < runf) { v[u].z -= lr * grow[2]; wrow[2] = v[u].z; }
+                if (in && 4 * r + 3 < runf) { v[u].w -= lr * grow[3]; wrow[3] = v[u].w; }
+            }
         }
     }
 #pragma unroll
@@ -2217,7 +2251,48 @@ extern "C" int segnb_pack_pair_job_blocks(int Co, int Ci, int Cop, int Cip) {
 extern "C" int segnb_pack_weight_pair_multi(const void* jobs, int njobs, int total_blocks, segnb_stream_t stream) {
     SEGNB_PLAN_RECORD(segnb_pack_weight_pair_multi, jobs, njobs, total_blocks, stream);
     SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "bad job table");
-    hipLaunchKernelGGL(pack_pair_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackPairJob*)jobs, njobs);
+    hipLaunchKernelGGL(pack_pair_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackPairJob*)jobs, njobs,
+                       0ll, 0.f);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+// torch.optim.SGD.step() (torch_train.py:71,190: plain SGD) on the parameters of the job table AND their weight pack in one pass:
+// flat_p / flat_g are the flat parameter / gradient buffers every job's `w` points into (segnb.engine.FlatParams); the parameters the
+// table does not cover take segnb_sgd_ranges
+extern "C" int segnb_sgd_pack_pair_multi(const void* jobs, int njobs, int total_blocks, float* flat_p, const float* flat_g, float lr,
+                                         segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_sgd_pack_pair_multi belongs to optimizer.step(), outside the recorded lists");
+    SEGNB_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0 && flat_p && flat_g, "bad job table / buffers");
+    SEGNB_CHECK_ARG((((uintptr_t)flat_p | (uintptr_t)flat_g) & 15) == 0, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_pair_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackPairJob*)jobs, njobs,
+                       (long long)(flat_g - flat_p), lr);
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+// p[i] -= lr * g[i] over nranges element ranges of two parallel fp32 buffers: ranges = device int64 [nranges][3] (start, length,
+// first index of the range in the concatenation of all ranges), total = sum of the lengths.  What segnb_sgd_pack_pair_multi leaves
+// of a model's flat parameter buffer: convolution biases, BatchNorm parameters, the classifier (a few thousand elements)
+__global__ __launch_bounds__(256) void sgd_ranges_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         const long long* __restrict__ ranges, int nranges, long long total, float lr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = nranges - 1;                    // last range whose first index is <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ranges[3 * mid + 2] <= i) lo = mid; else hi = mid - 1;
+    }
+    const long long e = ranges[3 * lo] + (i - ranges[3 * lo + 2]);
+    p[e] -= lr * g[e];
+}
+
+extern "C" int segnb_sgd_ranges(float* p, const float* g, const long long* ranges, int nranges, long long total, float lr,
+                                segnb_stream_t stream) {
+    SEGNB_PLAN_REFUSE("segnb_sgd_ranges belongs to optimizer.step(), outside the recorded lists");
+    SEGNB_CHECK_ARG(p && g && ranges && nranges > 0 && total > 0, "bad arguments");
+    hipLaunchKernelGGL(sgd_ranges_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, ranges,
+                       nranges, total, lr);
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

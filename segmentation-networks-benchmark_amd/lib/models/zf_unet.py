@@ -315,16 +315,56 @@ class _ZFUnetPlan(object):
 
     _last_N = None
 
+    def _pack_key(self, H, W, N):
+        return (sum(p._version for p in self.flat.param_list()), self.flat.version, N, H, W, self.flat.flat_p.data_ptr())
+
+    # ---- optimizer.step() of plain SGD fused with this pack (segnb.optim.SGD -> FlatParams.sgd_pack_hook) --------------------------
+    _pairs_key = None          # the pack key under which the PAIRED matrices are already those of the current parameters
+    _sgd_geom = None
+
+    def _sgd_pack(self, lr):
+        """w -= lr * g on every parameter: the convolution weights of the pair-job table inside the pack kernel (their packed
+        matrices for the geometry of the last differentiated forward leave the same pass), everything else by segnb_sgd_ranges."""
+        if self._sgd_geom is None or self.rt.code != nv.BF16 or self.rt.device.type != 'cuda':
+            return False
+        N, H, W = self._sgd_geom
+        t = self._pack_tables.get((N, H, W))
+        if t is None or t[0] != (N, H, W, self.flat.flat_p.data_ptr(), self.flat.flat_g.data_ptr()):
+            return False
+        main = t[1][0]
+        if main.ptable is None:
+            return False
+        comp = getattr(main, '_sgd_complement', None)
+        if comp is None:
+            base, total = self.flat.flat_p.data_ptr(), self.flat.total
+            covered = sorted(((a - base) // 4, n) for a, n in main.pair_params)
+            rows, pos, acc = [], 0, 0
+            for start, n in covered + [(total, 0)]:
+                if start > pos:
+                    rows.append((pos, start - pos, acc))
+                    acc += start - pos
+                pos = max(pos, start + n)
+            tab = torch.tensor(rows, dtype=torch.int64, device=self.rt.device) if rows else None
+            comp = main._sgd_complement = (tab, len(rows), acc)
+        main.run_pairs_sgd(self.flat.flat_p, self.flat.flat_g, lr)
+        if comp[1]:
+            nv.call('segnb_sgd_ranges', nv.ptr(self.flat.flat_p), nv.ptr(self.flat.flat_g), nv.ptr(comp[0]), comp[1], comp[2],
+                    float(lr), self.rt.stream)
+        return True
+
+    def _sgd_pack_done(self):
+        N, H, W = self._sgd_geom
+        self._pairs_key = self._pack_key(H, W, N)
+
     def _pack_if_needed(self, H, W, N):
-        key = (sum(p._version for p in self.flat.param_list()), self.flat.version, N, H, W,
-               self.flat.flat_p.data_ptr())
+        key = self._pack_key(H, W, N)
         if key == self._packed_key:
             return False
         # ONE launch of pair jobs on the main stream; the single-form data-gradient matrices (segmented decoder levels) on the side
         # stream, joined at the start of backward.  (Packing the late 96 % of the parameters on the side stream beside the first
         # encoder levels was measured in round 3: 5.338 vs 5.356 ms, the pack is HBM-bound and so are those levels; removed.)
         main, late = self._tables(H, W, N)[1]
-        main.run()
+        main.run(skip_pairs=(key == self._pairs_key))       # (the optimizer step packed the pair jobs already: _sgd_pack)
         side = self.rt.side_stream() if late is not None else None
         self._dg_pack_on_side = side is not None
         if side is not None:
@@ -490,6 +530,9 @@ class _ZFUnetPlan(object):
         forked = self._pack_if_needed(H, W, N)
         if train and need_grad:
             self.flat.prezero(rt, forked=bool(forked))
+            # (the optimizer step that follows this step's backward may fuse its update with the next forward's pack)
+            self._sgd_geom = (N, H, W)
+            self.flat.sgd_pack_hook, self.flat.sgd_pack_done = self._sgd_pack, self._sgd_pack_done
         hf = self._head_fusable(train, need_grad)
         self._last_head_fused = hf
         ckey = None if u8 else self._cplan_key('fwd', N, H, W, train, need_grad, drop)

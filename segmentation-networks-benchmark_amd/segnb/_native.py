@@ -95,6 +95,8 @@ SIGNATURES = {
                             c_int, _P],
     'segnb_conv_wgrad': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P],
     'segnb_wgrad_target_arm': [ctypes.POINTER(WgradTarget)],
+    'segnb_sgd_pack_pair_multi': [_P, c_int, c_int, _P, _P, c_float, _P],
+    'segnb_sgd_ranges': [_P, _P, _P, c_int, c_ll, c_float, _P],
     'segnb_upconv_fprop': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     'segnb_upconv_fprop_acc': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     'segnb_upconv_fprop_act': [c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int,

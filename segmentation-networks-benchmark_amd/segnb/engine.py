@@ -1221,11 +1221,20 @@ class PackTable(object):
             tab = np.array(rows, dtype=PACK_PAIR_DTYPE)
             self.ptable = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(rt.device)
             self.pn, self.pblocks = len(rows), blocks
+            self.pair_params = [(int(r['w']), int(r['Co']) * int(r['Ci']) * 9) for r in rows]      # (address, elements) of every paired parameter
         self.paired_ids = taken
         return [j for j in jobs if id(j) not in taken]
 
-    def run(self):
-        if self.ptable is not None:
+    pair_params = ()
+
+    def run_pairs_sgd(self, flat_p, flat_g, lr):
+        """optimizer.step() of plain SGD on the paired parameters and their pack in one pass (segnb_sgd_pack_pair_multi); the rest of
+        the table (run(skip_pairs=True)) is packed at the next forward as usual"""
+        nv.call('segnb_sgd_pack_pair_multi', nv.ptr(self.ptable), self.pn, self.pblocks, nv.ptr(flat_p), nv.ptr(flat_g), float(lr),
+                self.rt.stream)
+
+    def run(self, skip_pairs=False):
+        if self.ptable is not None and not skip_pairs:
             nv.call('segnb_pack_weight_pair_multi', nv.ptr(self.ptable), self.pn, self.pblocks, self.rt.stream)
         if self.table is not None:
             nv.call(self.entry, nv.ptr(self.table), self.n, self.blocks, self.rt.stream)
@@ -1623,6 +1632,12 @@ class FlatParams(object):
         self.version += 1
         for p in params:
             FlatParams.registry[id(p)] = self
+
+    # optimizer.step() of plain SGD fused with the next forward's weight pack (segnb.optim.SGD -> the model plan's hook):
+    # sgd_pack_hook(lr) -> True when it applied the update to EVERY parameter (and packed what it could); sgd_pack_done() is called
+    # after the optimizer bumped `version`
+    sgd_pack_hook = None
+    sgd_pack_done = None
 
     def grad_of(self, p):
         if self.touch_log is not None:

@@ -2,6 +2,8 @@
 ``get_optimizer`` (torch_train.py:67-79: plain SGD, RMSprop and Adam with torch defaults) whose ``step`` is ONE
 launch over the model's flat parameter buffer when every parameter and gradient lives in segnb's FlatParams;
 anything else (momentum, weight decay, amsgrad, foreign params, sparse grads) takes torch's own implementation."""
+import os
+
 import torch
 
 from . import _native as nv
@@ -18,6 +20,9 @@ def _take_fused_token(flat):
 
 
 class SGD(torch.optim.SGD):
+    # fuse_pack = False (class attribute / SEGNB_SGD_PACK=0): the update as one launch over the flat buffers, the pack at the next forward (A/B)
+    fuse_pack = os.environ.get('SEGNB_SGD_PACK', '1') != '0'
+
     # ---- update of one contiguous range of the flat buffers (DataParallel.fuse_optimizer) -------------------------------
     def fusable_group(self, flat):
         """The param group this optimizer would update with its one-launch step over `flat`, else None (grad aliasing is
@@ -60,6 +65,13 @@ class SGD(torch.optim.SGD):
                 continue
             if _take_fused_token(flat):
                 flat.version += 1
+                continue
+            # the model plan may apply the update itself, fused with the weight pack of the next forward (one read of every
+            # convolution weight instead of two: segnb_sgd_pack_pair_multi); same arithmetic, bit-identical parameters
+            hook = flat.sgd_pack_hook if self.fuse_pack else None
+            if hook is not None and hook(float(group['lr'])):
+                flat.version += 1
+                flat.sgd_pack_done()
                 continue
             st = torch.cuda.current_stream(flat.flat_p.device).cuda_stream if flat.flat_p.is_cuda else 0
             nv.call('segnb_sgd_step', nv.ptr(flat.flat_p), nv.ptr(flat.flat_g), flat.total, float(group['lr']), st)

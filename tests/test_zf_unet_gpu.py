@@ -649,6 +649,50 @@ torch.distributed.destroy_process_group()
     assert res['lead_ms'] > 0.2 and np.isfinite(res['loss'])
 
 
+def test_sgd_step_fused_with_the_weight_pack_is_invisible():
+    """segnb.optim.SGD.step() through the plan's hook (segnb_sgd_pack_pair_multi + segnb_sgd_ranges: the update of every convolution
+    weight inside the pack kernel that writes the NEXT forward's matrices, the other parameters by ranges) == the one-launch
+    segnb_sgd_step followed by the pack at the next forward (torch_train.py:71,190: plain SGD): every parameter bit-identical after
+    each of three steps, the same losses, and a parameter edited by hand between two steps is packed again (the fused pack's key no
+    longer matches)."""
+    from lib.losses import BCEAndDiceLoss
+    from lib.models.zf_unet import ZF_UNET
+    from segnb import optim
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 3, 64, 96, generator=g).cuda()
+    y = (torch.rand(2, 1, 64, 96, generator=g) > 0.7).long().cuda()
+    keep = optim.SGD.fuse_pack
+    out = []
+    try:
+        for fused in (False, True):
+            optim.SGD.fuse_pack = fused
+            torch.manual_seed(5)
+            m = ZF_UNET(dropout_val=0.0).cuda().train()
+            opt = optim.SGD(m.parameters(), lr=0.05)
+            losses, snaps = [], []
+            for step in range(4):
+                if step == 3:
+                    with torch.no_grad():          # a hand edit between two steps: the next forward must see it
+                        m.conv_224.l1.conv.weight.mul_(0.5)
+                opt.zero_grad()
+                loss = BCEAndDiceLoss()(m(x), y)
+                (2 * loss).backward()
+                opt.step()
+                torch.cuda.synchronize()
+                losses.append(loss.item())
+                snaps.append({n: p.detach().clone() for n, p in m.named_parameters()})
+            if fused:
+                assert m._engine._pairs_key is not None, 'the fused path did not run'
+            out.append((losses, snaps))
+    finally:
+        optim.SGD.fuse_pack = keep
+    (l0, s0), (l1, s1) = out
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(s0, s1):
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_consumer_side_batchnorm_matches_the_activation_pass():
     """SEGNB_CONSUMER_FUSION: at the 224 x 224 level the second convolution of a block (and its weight gradient) applies the
     first one's BatchNorm + ReLU while it loads (segnb_conv_fprop_tf / segnb_conv_wgrad_tf) -- the activated tensor of
