@@ -352,12 +352,9 @@ def main():
     nv.load()
     torch.cuda.synchronize()
     ph.mark('library_load_and_gpu_init')
+    box = box_calibration(dev) if (rank == 0 and not args.no_box) else None
+    ph.mark('box_probes')
 
-    if os.environ.get('SEGNB_BENCH_PROBES_FIRST') == '1':
-        box_first = box_calibration(dev) if (rank == 0 and not args.no_box) else None
-        ph.mark('box_probes')
-    else:
-        box_first = None
     # (model constructor, images per GPU, size, algorithmic GFLOP per image fwd+bwd at that size -- SURVEY 8d)
     import warnings
     models = {'zf_unet': (ZF_UNET, 32, 224, GFLOP_PER_IMAGE_224),
@@ -409,19 +406,6 @@ def main():
     # (the dependent chain on a high-priority stream with the weight gradients on a normal-priority one was measured in rounds 2
     # and 4: the same step time either way, the dispatcher does not prefer the chain)
     ph.mark('model_and_inputs')
-    # The box probes (a library GEMM for ~200 ms and a device copy: NOT part of the product) run HERE, directly in front of the warm-up
-    # steps, not before the model is built: building the model is 0.6-0.9 s of host work during which the GPU idles and drops its
-    # clocks, and after 500 ms of idleness the first five steps of this workload take 5.58 / 5.19 / 4.96 / 4.90 / 4.80 ms against 4.79 in
-    # the steady state (tools/step_ramp.py, profiles/r06_step_ramp.txt) -- with `--warmup 5`, whose first step is the plan-recording one,
-    # a 20-step timed region would still contain the tail of that ramp.  The metric is steady-state training throughput.
-    # SEGNB_BENCH_PROBES_FIRST=1 restores the old order (A/B).
-    probes_first = os.environ.get('SEGNB_BENCH_PROBES_FIRST') == '1'
-    box = None
-    if not probes_first:
-        box = box_calibration(dev) if (rank == 0 and not args.no_box) else None
-        ph.mark('box_probes')
-    if probes_first:
-        box = box_first
     loss = step()                          # builds the plan, flat buffers
     torch.cuda.synchronize()
     ph.mark('first_step_plan_recording')
