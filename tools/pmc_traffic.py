@@ -77,6 +77,11 @@ def main():
     total_f = sum(v[1] for v in fe.values())
     total_w = sum(v[1] for v in wr.values())
     steps_f, steps_w = fe.get(step_kernel, [0, 0.0])[0], wr.get(step_kernel, [0, 0.0])[0]
+    if step_kernel == 'sgd_kernel':
+        # (r6) a step whose SGD update is fused with the weight pack ends with sgd_ranges_kernel instead (segnb_sgd_pack_pair_multi +
+        # segnb_sgd_ranges): every step runs exactly one of the two
+        steps_f += fe.get('sgd_ranges_kernel', [0, 0.0])[0]
+        steps_w += wr.get('sgd_ranges_kernel', [0, 0.0])[0]
     per_step = None
     if steps_f and steps_w:
         per_step = round((2.0 * total_f / steps_f + total_w / steps_w) * 1024.0)

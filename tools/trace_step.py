@@ -1,5 +1,5 @@
 """One steady-state training step from a rocprofv3 kernel trace (csv): per queue the busy time, the gaps between
-consecutive kernels and the time per kernel family, forward and backward apart (the step boundary = sgd_kernel, the
+consecutive kernels and the time per kernel family, forward and backward apart (the step boundary = sgd_kernel / sgd_ranges_kernel, the
 forward / backward boundary = loss_bwd_kernel).
 
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --steps 8 --warmup 3 ...
@@ -30,7 +30,7 @@ def main():
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), family(r['Kernel_Name']), r.get('Queue_Id', '0'),
                          r['Kernel_Name']))
     rows.sort()
-    sgd = [i for i, r in enumerate(rows) if r[2] == 'sgd_kernel']
+    sgd = [i for i, r in enumerate(rows) if r[2] in ('sgd_kernel', 'sgd_ranges_kernel')]      # (the step's last kernel, fused or not)
     lo, hi = sgd[-back - 1], sgd[-back]
     step = rows[lo + 1:hi + 1]
     t0, t1 = rows[lo][1], step[-1][1]
