@@ -214,6 +214,11 @@ def load():
         raise NativeLibraryMissing(
             'libsegnb_hip.so not found at %s -- build it with __graft_entry__.build() '
             '(segmentation-networks-benchmark_amd/csrc/build.sh); there is no non-HIP path' % LIB_PATH)
+    # torch FIRST: PyTorch-ROCm ships its own libamdhip64.so; if this library were the first to pull a HIP runtime into the process it
+    # would bind /opt/rocm's copy, torch would then load its own, and every launch made here fails with "no ROCm-capable device is
+    # detected" (two runtimes, the device context in the other one) -- seen when __graft_entry__.build() dlopen'ed the library before
+    # anything imported torch.  With torch's runtime already loaded the dynamic linker resolves this library's HIP symbols to it.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)         # AttributeError if the ABI and the header drift apart
