@@ -1898,6 +1898,8 @@ extern "C" int segnb_conv_wgrad_upcat(const segnb_conv_geom* g, int dtype, const
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_upcat, g, dtype, in, src, dout, dwp, nslab, stream);
     const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     SEGNB_CHECK_ARG(in && src && src->u && dout && dwp, "NULL tensor");
+    SEGNB_CHECK_ARG(tgt == nullptr || (tgt->ntaps == g->ntaps && tgt->Co <= g->Co && g->Co - tgt->Co < 8 && tgt->Ci <= g->Ci),
+                    "the armed segnb_wgrad_target does not belong to this geometry (taps / channel counts)");
     SEGNB_CHECK_ARG(upcat_geom_ok(g, dtype, src->Cu), "geometry not served (segnb_conv_upcat_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     const int rc = segnb_wgrad_s1_try(g, in, dout, dwp, nslab, (hipStream_t)stream, false, nullptr, src, tgt);
@@ -2026,7 +2028,8 @@ extern "C" int segnb_conv_wgrad(const segnb_conv_geom* g, int dtype, const void*
     SEGNB_PLAN_RECORD(segnb_conv_wgrad, g, dtype, in, dout, dwp, nslab, stream);
     const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
-    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
+    SEGNB_CHECK_ARG(tgt == nullptr || (tgt->ntaps == g->ntaps && tgt->Co <= g->Co && g->Co - tgt->Co < 8 && tgt->Ci <= g->Ci),
+                    "the armed segnb_wgrad_target does not belong to this geometry (taps / channel counts)");
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
     WgradArgs a;
@@ -2097,7 +2100,8 @@ extern "C" int segnb_conv_wgrad_bnapply(const segnb_conv_geom* g, int dtype, con
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_bnapply, g, dtype, in, gsrc, ld_g, y, ld_y, coef, bcoef, Cp, act, slope, dwp, nslab, stream);
     const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
-    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
+    SEGNB_CHECK_ARG(tgt == nullptr || (tgt->ntaps == g->ntaps && tgt->Co <= g->Co && g->Co - tgt->Co < 8 && tgt->Ci <= g->Ci),
+                    "the armed segnb_wgrad_target does not belong to this geometry (taps / channel counts)");
     SEGNB_CHECK_ARG(in && gsrc && y && coef && bcoef && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(segnb_conv_wgrad_bnapply_ok(g, dtype), "geometry not served (segnb_conv_wgrad_bnapply_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");
@@ -2129,7 +2133,8 @@ extern "C" int segnb_conv_wgrad_tf(const segnb_conv_geom* g, int dtype, const vo
     SEGNB_PLAN_RECORD(segnb_conv_wgrad_tf, g, dtype, in, tf_in, dout, tf_dout, dwp, nslab, stream);
     const segnb_wgrad_target* const tgt = segnb_take_wgrad_target();
     if (int rc = check_geom(g)) return rc;
-    SEGNB_CHECK_ARG(tgt == nullptr || tgt->ntaps == g->ntaps, "the armed segnb_wgrad_target has another tap count");
+    SEGNB_CHECK_ARG(tgt == nullptr || (tgt->ntaps == g->ntaps && tgt->Co <= g->Co && g->Co - tgt->Co < 8 && tgt->Ci <= g->Ci),
+                    "the armed segnb_wgrad_target does not belong to this geometry (taps / channel counts)");
     SEGNB_CHECK_ARG(in && dout && dwp, "NULL tensor");
     SEGNB_CHECK_ARG(segnb_conv_wgrad_tf_ok(g, dtype), "geometry not served (segnb_conv_wgrad_tf_ok)");
     SEGNB_CHECK_ARG(nslab == segnb_conv_wgrad_slabs(g, dtype), "nslab differs from segnb_conv_wgrad_slabs()");

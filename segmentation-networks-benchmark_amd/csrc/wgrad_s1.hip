@@ -674,7 +674,8 @@ __global__ __launch_bounds__((wg_specialised<BCO, BCI, R, WT, FLAT>() ? 512 : 25
             int civ = a.gw_Ci - ci0;
             civ = civ > BCI ? BCI : civ;
             const long long col0 = (long long)(a.gw_ci_off + ci0) * 9;
-            const bool vec = a.gw_s_in == 9 && (a.gw_s_out & 3) == 0 && (col0 & 3) == 0 && civ > 0 && ((civ * 9) & 3) == 0;
+            const bool vec = a.gw_s_in == 9 && (a.gw_s_out & 3) == 0 && (col0 & 3) == 0 && civ > 0 && ((civ * 9) & 3) == 0 &&
+                             (reinterpret_cast<uintptr_t>(a.gw) & 15) == 0;
             const int nrow4 = vec ? civ * 9 / 4 : 0;
 #pragma unroll
             for (int rd = 0; rd < 4; ++rd) {
