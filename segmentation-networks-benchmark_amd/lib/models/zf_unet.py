@@ -649,7 +649,11 @@ class _ZFUnetPlan(object):
     # ---- backward --------------------------------------------------------------------------------------
     def backward(self, dlogits):
         self._guard_mode, self._guard_active = (None, None), False
-        out = self._backward(dlogits)
+        from segnb import engine as _engine
+        try:
+            out = self._backward(dlogits)
+        finally:
+            _engine.DW_OVERWRITE = False
         self._guard_b.end(self._guard_active, *self._guard_mode)
         return out
 
@@ -665,10 +669,12 @@ class _ZFUnetPlan(object):
         N, H, W = self._last
         b = self.buffers(N, H, W)
         accumulate_in_place = flat.begin_backward()
+        from segnb import engine as _engine
+        _engine.DW_OVERWRITE = not accumulate_in_place           # (reset by backward(): see ConvOp._arm_target)
         drop_now = {n: self.stages[n][1]._saved[2] if self.stages[n][1]._saved is not None else None for n in ENCODER + DECODER}
         ckey = self._cplan_key('bwd', N, H, W, True, True, drop_now)
         if ckey is not None:
-            ckey = ckey + (bool(getattr(self, '_last_head_fused', False)),)
+            ckey = ckey + (bool(getattr(self, '_last_head_fused', False)), bool(accumulate_in_place))
         if ckey is not None:
             din = b['dlogits_in']
             if dlogits.data_ptr() != din.data_ptr():

@@ -260,6 +260,12 @@ def vld(v):
     return 0 if v is None else v.ld
 
 
+# Set by a model's backward driver for the duration of one backward: True when FlatParams.begin_backward() cleared the flat
+# gradient buffer (no .grad aliased it), i.e. every directly delivered weight gradient may be STORED; False (the default, and
+# whenever gradients accumulate in place across backward calls) = added.  Part of the recorded backward lists' keys.
+DW_OVERWRITE = False
+
+
 class ConvOp(object):
     """One nn.Conv2d / nn.ConvTranspose2d parameter set on the gather-conv kernels.
 
@@ -710,21 +716,28 @@ class ConvOp(object):
     # ZF_UNET 4.729 / 4.736 / 4.746 ms at thresholds 0 / 30 k / 300 k, FCDenseNet103 and LinkNet34 +-0.2 %, profiles/r06_ab.txt)
     direct_min_numel = 0
 
+    # dw_store = False (class attribute / SEGNB_DW_STORE=0): directly delivered weight gradients are always read-modify-written (A/B)
+    dw_store = os.environ.get('SEGNB_DW_STORE', '1') != '0'
+
     def direct_ok(self):
         """Do this convolution's weight-gradient launches deliver into the parameter's gradient themselves?"""
         return bool(self.direct_dw and self._in_place and self.rt.code == nv.BF16 and self.weight.numel() >= self.direct_min_numel)
 
     def _arm_target(self, p, li, grad_w):
         """segnb_wgrad_target_arm for forward launch li: the next weight-gradient call adds its result to grad_w (the fp32
-        gradient of the whole parameter, reference layout [Co][Ci_total][KH][KW])"""
-        key = ('tgt', li, grad_w.data_ptr())
+        gradient of the whole parameter, reference layout [Co][Ci_total][KH][KW]) -- or STORES it when the backward that is
+        running said the flat gradient buffer holds fresh zeros (DW_OVERWRITE: 0 + x == x, so the read half of the
+        read-modify-write -- a dependent round trip per output row of the delivering kernels -- is dropped; a forward
+        convolution has exactly one weight-gradient launch)"""
+        over = bool(DW_OVERWRITE and self.dw_store and len(p['fwd']) == 1)
+        key = ('tgt', li, grad_w.data_ptr(), over)
         t = p.get(key)
         if t is None:
             l = p['fwd'][li]
             t = nv.WgradTarget()
             t.gw = grad_w.data_ptr()
             t.s_out, t.s_in, t.ci_off = self.s_out, self.s_in, self._ci_offset
-            t.Ci, t.Co, t.accumulate, t.ntaps = self.Ci, self.Co, 1, len(l.taps)
+            t.Ci, t.Co, t.accumulate, t.ntaps = self.Ci, self.Co, 0 if over else 1, len(l.taps)
             for i, (_, _, a, b) in enumerate(l.taps):
                 t.kpos[i] = a * self.KW + b
             p[key] = t

@@ -1246,7 +1246,11 @@ class HipNet(nn.Module):
 
     def _run_backward(self, dlogits):
         self._guard_mode, self._guard_active = (None, None), False
-        out = self._run_backward_(dlogits)
+        from . import engine as _engine
+        try:
+            out = self._run_backward_(dlogits)
+        finally:
+            _engine.DW_OVERWRITE = False
         self._guards()[1].end(self._guard_active, *self._guard_mode)
         return out
 
@@ -1259,6 +1263,17 @@ class HipNet(nn.Module):
         ent = getattr(self, '_plan_live', None)
         self._plan_live = None
         acc = tape.flat.begin_backward()
+        # directly delivered weight gradients are STORED when the gradient buffer was just cleared, ADDED when gradients accumulate in
+        # place (engine.DW_OVERWRITE); the recorded backward lists carry the flag they were recorded under
+        from . import engine as _engine
+        _engine.DW_OVERWRITE = not acc
+        # a list recorded with STORES replayed by a backward that accumulates on top of earlier gradients: the fresh gradient goes to a
+        # cleared buffer and the earlier one is added back (rare: lib/train_utils.find_optimal_lr never zeroes; a list recorded with
+        # ADDS is right either way)
+        stash = None
+        if ent is not None and ent['state'] == 'ready' and acc and ent.get('acc') is False:
+            stash = tape.flat.flat_g.clone()
+            tape.flat.flat_g.zero_()
         if ent is not None:
             din = ent.get('dlogits_in')
             if din is None:
@@ -1325,11 +1340,13 @@ class HipNet(nn.Module):
                     self._plan_drop(ent)
                     ent['state'] = 'eager'
                 else:
-                    ent.update(bwd=[(h, c) for h, _, c in segs], nbwd=sum(n for _, n, _ in segs), state='ready')
+                    ent.update(bwd=[(h, c) for h, _, c in segs], nbwd=sum(n for _, n, _ in segs), state='ready', acc=acc)
                     self._guard_mode = (id(ent), 'record')
             table = tape.finish()                                           # (7x7 / strided jobs take host tap arrays: eager)
             if recording and ent['state'] == 'ready':
                 ent['unpack'] = table
+        if stash is not None:
+            tape.flat.flat_g.add_(stash)
         hook = getattr(self, '_grad_sync_hook', None)
         if hook is not None:
             hook(tape.flat)

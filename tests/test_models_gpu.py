@@ -105,6 +105,53 @@ def test_training_steps_reduce_loss_all_models():
         assert losses[-1] < losses[0], (type(m).__name__, losses)
 
 
+@pytest.mark.parametrize('which', ['unet16', 'zf_unet'])
+def test_stored_weight_gradients_accumulate_when_the_caller_does(which):
+    """Directly delivered weight gradients (segnb_wgrad_target) are STORED when the backward cleared the flat gradient buffer
+    (zero_grad() before every step, torch_train.py:180) and ADDED when gradients accumulate in place (lib/train_utils.py:54-65 never
+    zeroes them).  A recorded launch list carries the mode it was recorded under: three zeroed steps (eager, recorded, replayed), then
+    two backwards WITHOUT zero_grad on the same batch and weights -- the gradient must be exactly twice, then three times, the
+    single one (no dropout, no optimizer step) to fp32 rounding of the sums, whichever list serves the step."""
+    from lib.losses import BCEWithLogitsLossAndSmoothJaccard
+    crit = BCEWithLogitsLossAndSmoothJaccard()
+    if which == 'unet16':
+        m, _, x, y = mc.make_unet16()
+    else:
+        from lib.models.zf_unet import ZF_UNET
+        torch.manual_seed(2)
+        m = ZF_UNET(dropout_val=0.0, filters=8)
+        g = torch.Generator().manual_seed(4)
+        x, y = torch.randn(2, 3, 64, 96, generator=g), (torch.rand(2, 1, 64, 96, generator=g) > 0.7).long()
+    m = m.cuda().train()
+    x, y = x.cuda(), y.cuda()
+    for mod in m.modules():                       # (BatchNorm running statistics move with every forward: they do not enter the loss)
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
+
+    def backward():
+        loss = crit(m(x), y)
+        (x.size(0) * loss).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    for _ in range(3):
+        m.zero_grad()
+        single = backward()
+    twice = backward()                            # no zero_grad: every .grad aliases the flat buffer and is accumulated into
+    thrice = backward()
+    worst = 0.0
+    for n in single:
+        s = float(single[n].abs().max())
+        if s == 0.0:
+            assert float(twice[n].abs().max()) == 0.0
+            continue
+        worst = max(worst, float((twice[n] - 2 * single[n]).abs().max()) / s, float((thrice[n] - 3 * single[n]).abs().max()) / s)
+    assert worst < 1e-4, worst
+    m.zero_grad()                                 # and back: a zeroed step after the accumulating ones
+    again = backward()
+    for n in single:
+        torch.testing.assert_close(again[n], single[n], rtol=1e-5, atol=1e-6 * float(single[n].abs().max() + 1e-30))
+
+
 def test_weight_gradient_cu_share_is_local_to_the_model():
     """UNet16 takes ALL CUs for its weight gradients (HipNet.wg_cu_pct = 100 through segnb_wg_cu_share: its side stream is the
     longer one, unet16.py:50-108), LinkNet34 in the same process keeps the library's default half: the share is set around the
