@@ -483,8 +483,9 @@ int segnb_conv_fprop_bnapply(const segnb_conv_geom* g, int dtype, const void* in
 /* coef == NULL: the producing layer is a convolution + activation WITHOUT BatchNorm (linknet.py:58-61 finaldeconv1 -> finalrelu1 ->
  * finalconv2, unet16.py:12-21) and y is its ACTIVATED output: the launch then stores out = dz = round(round(g) * act'(y)) (act' from
  * the sign of the activated value) and sums[r][0][c] += sum dz -- that layer's segnb_bn_act_bwd_reduce pass (y, coef NULL, dz) folded
- * into the data gradient that produces g.  _actmask_ok: 1 when a fused kernel serves the geometry (32 -> <= 32 channels, stride-1
- * 3 x 3 window with any padding, width >= 32: conv_roll_kernel). */
+ * into the data gradient that produces g.  _actmask_ok: 1 when a fused kernel serves the geometry (stride-1 3 x 3 window; 32 -> <= 32
+ * channels with any padding, width >= 32: conv_roll_kernel;  Ci % 64 == 0 -> > 32 channels, width > 8: the MASK instantiation of
+ * conv_fprop_ws_kernel -- the VGG-style encoder / decoder convolutions of unet16.py:73-108). */
 int segnb_conv_fprop_actmask_ok(const segnb_conv_geom* g, int dtype);
 
 /* CONSUMER-SIDE BatchNorm: a convolution (or weight-gradient) operand that is NOT in memory -- it is recomputed from what the

@@ -313,8 +313,16 @@ class AbiEmulator(object):
 
     def segnb_conv_fprop_actmask_ok(self, g, dtype):
         g = _geom(g)
-        return int(dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
-                   and g.Ci == 32 and g.Co <= 32 and g.Co % 8 == 0 and g.Wo >= 32)
+        if not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo
+                and g.oh0 == 0 and g.ow0 == 0 and g.Co % 8 == 0):
+            return 0
+        if g.Ci == 32 and g.Co <= 32 and g.Wo >= 32:          # conv_roll_kernel
+            return 1
+        # the MASK instantiation of conv_fprop_ws_kernel: 64-channel input chunks, > 32 output channels, a row-major 3 x 3 window
+        dh, dw = [g.dh[t] for t in range(9)], [g.dw[t] for t in range(9)]
+        window = (all(dh[t] == dh[3 * (t // 3)] and dw[t] == dw[t % 3] for t in range(9))
+                  and sorted(set(d - min(dh) for d in dh)) == [0, 1, 2] and sorted(set(d - min(dw) for d in dw)) == [0, 1, 2])
+        return int(g.Ci % 64 == 0 and g.Co > 32 and g.Wo > 8 and window)
 
     def segnb_conv_fprop_bnreduce(self, g, dtype, in_p, wp, out_p, ep, stream):
         gg, e = _geom(g), _geom(ep)

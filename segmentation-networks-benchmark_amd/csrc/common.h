@@ -132,6 +132,9 @@ int segnb_fprop_thin_try(const segnb_conv_geom* g, const void* in, const void* w
                          const segnb_bn_reduce_epilogue* bn);
 int segnb_fprop_thin_ok(const segnb_conv_geom* g);
 int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
+int segnb_knob_fprop_mask();      // 1: conv_fprop_ws_kernel serves activation-mask data gradients (segnb_conv_fprop_bnreduce, coef NULL)
+int segnb_fprop_dma_actmask_ok(const segnb_conv_geom* g);
+int segnb_fprop_roll_actmask_ok(const segnb_conv_geom* g);     // fprop_roll.hip: conv_roll_kernel (EPI = 3) serves g      // fprop_dma.hip: the MASK instantiation serves g
 int segnb_knob_fprop_mf16();      // 1: conv_fprop_ws_kernel issues v_mfma_f32_16x16x32_bf16, 0: 32x32x16
 int segnb_knob_fprop_rw();
 int segnb_knob_fprop_ksplit();   // conv_fprop_ws_kernel split K: 0 off, 1 automatic (default), 2 / 4 forced where it applies

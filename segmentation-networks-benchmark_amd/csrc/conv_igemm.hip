@@ -1945,7 +1945,11 @@ extern "C" int segnb_conv_fprop_bnreduce(const segnb_conv_geom* g, int dtype, co
     if (ep->coef == nullptr) {
         // activation mask of a producing layer without BatchNorm: out = dz (conv_roll_kernel, EPI = 3)
         SEGNB_CHECK_ARG(segnb_conv_fprop_actmask_ok(g, dtype), "geometry not served by a fused kernel (segnb_conv_fprop_actmask_ok)");
-        rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+        if (segnb_fprop_roll_actmask_ok(g))
+            rc = segnb_fprop_roll_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, ep);
+        else      // 64-channel-chunk inputs: the MASK instantiation of conv_fprop_ws_kernel
+            rc = segnb_fprop_dma_try(g, in, (unsigned)inb, wpacked, (unsigned)wb, nullptr, 0, out, nullptr, (hipStream_t)stream, nullptr,
+                                     nullptr, ep);
         if (rc != 1) {
             segnb_set_error("segnb_conv_fprop_bnreduce: the fused kernel refused the launch (%d)", rc);
             return rc > 1 ? rc : SEGNB_E_BADARG;

@@ -136,9 +136,20 @@ struct WsCfg {
 // measured slower in the step, ZF_UNET +1.6 %, LinkNet34 +2.8 %: DESIGN 11.10; removed in round 5.  fprop_rw.hip / fprop_roll.hip
 // keep their fused reductions.)
 // SPLITK: FdArgs::KS blocks per (pixel tile, channel tile), every block owns ONE tile slice (grid = tiles x KS); see FdArgs::KS
-template <class C, bool DBG, bool EP = false, bool STATS = true, bool SPLITK = false>
+// MASK: a DATA GRADIENT whose output tile is the gradient g of a convolution + activation WITHOUT BatchNorm (FdArgs::bn_y = that
+// layer's ACTIVATED output, bn_coef NULL): the tile is stored as dz = round(round(g) * act'(y)) -- the layer's own pass over (g, y, dz)
+// never runs -- and the store pass's sums (the STATS machinery: sum of the stored values per channel) are its bias gradient.  The
+// activations of a tile are read by the two HALO waves (16 bytes x 16 rows per thread, requested behind the tile's first halo pieces
+// and in flight for the whole tile), folded into one bit per element and published as 8 bytes per tile row behind the LDS layout
+// (C::SMEM .. + 2 KB) during the tile's last tap; the matrix waves read their rows' bits when they stage the accumulators.
+// (In the matrix waves themselves -- 32 registers per tile in the accumulator layout, or 2 x 8 in flight three taps ahead of a
+// fold -- the loads either spilled or stalled the MFMA stream: 64 -> 64 @ 1024 x 1024 x 4 took 673 us against 486 plain.)
+template <class C, bool DBG, bool EP = false, bool STATS = true, bool SPLITK = false, bool MASK = false>
 __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     static_assert(!SPLITK || (!EP && !DBG && C::UP == 0 && C::NTAP == 9), "split K: plain 3 x 3 forward / data gradient");
+    static_assert(!MASK || (STATS && !EP && !DBG && !SPLITK && C::MF16 && C::UP == 0 && C::NTAP == 9 && !C::TALL && C::BM == 256 &&
+                            C::BN == 64 && C::WAVES_M == 4 && C::SMEM + 2048 <= 160 * 1024),
+                  "activation mask: plain 3 x 3 data gradient, 16x16x32 form, 256 x 64 tiles, 2 KB of mask bytes behind the LDS layout");
     constexpr int BN = C::BN, R = C::R, WT = C::WT, BM = C::BM, TM = C::TM, TN = C::TN, XC = C::XC;
     constexpr int NT = C::NT, NB = C::NB, APW = C::APW, APS = C::APS, BPW = C::BPW, OC = C::OC, NLW = C::NLW;
     constexpr int OUT_ROW = C::OUT_ROW, NF = TM + TN;
@@ -212,6 +223,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
     }
     const float ep_neg = a.ep_act == SEGNB_ACT_RELU ? 0.f : (a.ep_act == SEGNB_ACT_LEAKY ? a.ep_slope : 1.f);
     const float upf_neg = ep_neg;
+    const float mask_neg = a.bn_act == SEGNB_ACT_RELU ? 0.f : (a.bn_act == SEGNB_ACT_LEAKY ? a.bn_slope : 1.f);
     auto ep = [&](float acc, float sc, float sh) {
         if constexpr (EP) {
             const float v = acc * sc + sh;
@@ -464,6 +476,40 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                     go(std::integral_constant<int, 0>{});
                 }
             };
+            // MASK: thread t128 of the 128 halo-wave threads owns channel chunk t128 & 7 of the staged rows (t128 >> 3) + 16 k
+            typedef __attribute__((ext_vector_type(4))) unsigned mu32x4_t;
+            mu32x4_t mreg[MASK ? 16 : 1];
+            const __amdgpu_buffer_rsrc_t rs_y =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(MASK ? a.bn_y : a.x), 0, MASK ? (int)a.bn_y_bytes : 0, 0x00020000);
+            auto mask_request = [&](int table) {
+                const int t128 = (lw & 1) * 64 + lane;
+                const int ch = n_base + (t128 & 7) * 8;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int opix = sPix[table * BM + (t128 >> 3) + 16 * k];
+                    const unsigned voff = (opix >= 0 && ch < a.Co) ? (unsigned)opix * (unsigned)a.bn_ld * 2u + (unsigned)ch * 2u : OOB;
+                    mreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)voff, 0, 0);
+                }
+            };
+            auto mask_publish = [&]() {
+                const int t128 = (lw & 1) * 64 + lane;
+                unsigned char* const dst = smem + C::SMEM + (t128 >> 3) * 8 + (t128 & 7);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const mu32x4_t v = mreg[k];
+                    unsigned b = 0u;
+                    b |= __uint_as_float(v.x << 16) > 0.f ? 1u : 0u;
+                    b |= __uint_as_float(v.x & 0xffff0000u) > 0.f ? 2u : 0u;
+                    b |= __uint_as_float(v.y << 16) > 0.f ? 4u : 0u;
+                    b |= __uint_as_float(v.y & 0xffff0000u) > 0.f ? 8u : 0u;
+                    b |= __uint_as_float(v.z << 16) > 0.f ? 16u : 0u;
+                    b |= __uint_as_float(v.z & 0xffff0000u) > 0.f ? 32u : 0u;
+                    b |= __uint_as_float(v.w << 16) > 0.f ? 64u : 0u;
+                    b |= __uint_as_float(v.w & 0xffff0000u) > 0.f ? 128u : 0u;
+                    dst[16 * k * 8] = (unsigned char)b;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // published by this tap's barrier
+            };
             set_fetch_tile(it, 0);
             fetch_a(0, APW, 0, 0);
             // During a tile's LAST chunk the first chunk of the next tile is fetched, so the per-lane offsets must
@@ -487,6 +533,15 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 0);
                         if constexpr (t < C::A_STEPS)
                             if (!(SEGNB_EXP & 2) && !(DBG && (a.dbg & 2))) fetch_a(t * APS, (t + 1) * APS, cn, abuf ^ 1);
+                        if constexpr (MASK) {
+                            // the producing layer's activated output at THIS tile's pixels: 16 bytes (8 channels) x 16 rows per thread,
+                            // requested behind the first chunk's first halo pieces (in flight for the whole tile: the counted wait of
+                            // its last chunk's tap NTAP - 2 covers them), folded into one mask byte each during the tile's last tap
+                            if constexpr (t == 0)
+                                if (c == 0) mask_request(tile_no & 3);
+                            if constexpr (t == NTAP - 1)
+                                if (last) mask_publish();
+                        }
                         if constexpr (t == NTAP - 2)
                             if (next_last) set_fetch_tile(setup_it, setup_tab);
                         if (lw == C::NBW) FD_STAMP(2, cg * 9 + t, 1);
@@ -623,7 +678,7 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 for (int e = 0; e < 8; ++e) {
                     const float fm = f[e] * m;
                     s1[e] += fm;
-                    s2[e] += fm * fm;
+                    if constexpr (!MASK) s2[e] += fm * fm;      // (MASK: the sums are a bias gradient -- slot 1 stays zero)
                 }
             }
         };
@@ -844,9 +899,15 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                 // accumulator tile (i, j): this lane holds channels 16 j + 4 g4 + {0..3} of pixel 16 i + r16
                 const int r16 = lane & 15, g4 = lane >> 4;
                 float4 bv[TN16], sv[TN16];
+                uint2 mrow[MASK ? TM16 : 1];      // MASK: the 64 mask bits of this lane's pixel rows (written by the halo waves)
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int i = 0; i < TM16; ++i)
+                        mrow[i] = *reinterpret_cast<const uint2*>(smem + C::SMEM + (wm * C::WM + 16 * i + r16) * 8);
+                }
 #pragma unroll
                 for (int j = 0; j < TN16; ++j) {
-                    bv[j] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 16 * j + 4 * g4);
+                    if constexpr (!MASK) bv[j] = *reinterpret_cast<const float4*>(sBias + wn * C::WN + 16 * j + 4 * g4);
                     if constexpr (EP) sv[j] = *reinterpret_cast<const float4*>(sScale + wn * C::WN + 16 * j + 4 * g4);
                     else sv[j] = make_float4(1.f, 1.f, 1.f, 1.f);
                 }
@@ -867,6 +928,16 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
                             const float v3 = acc[i][j][3] + __uint_as_float(pv.y & 0xffff0000u) + bv[j].w;
                             pk.x = pack2bf(fmaxf(v0, v0 * upf_neg), fmaxf(v1, v1 * upf_neg));
                             pk.y = pack2bf(fmaxf(v2, v2 * upf_neg), fmaxf(v3, v3 * upf_neg));
+                        } else if constexpr (MASK) {
+                            // dz = round(round(g) * act'(y)), act' from the sign of the activated value (1 / mask_neg)
+                            // channel 16 j + 4 g4 + e: byte 2 j + (g4 >> 1) of the row's eight, bit 4 (g4 & 1) + e
+                            const unsigned mb = (j < 2 ? mrow[i].x : mrow[i].y) >> (8 * ((2 * j + (g4 >> 1)) & 3) + 4 * (g4 & 1));
+                            const unsigned g01 = pack2bf(acc[i][j][0], acc[i][j][1]);      // (a data gradient: no bias)
+                            const unsigned g23 = pack2bf(acc[i][j][2], acc[i][j][3]);
+                            const float g0 = __uint_as_float(g01 << 16), g1 = __uint_as_float(g01 & 0xffff0000u);
+                            const float g2 = __uint_as_float(g23 << 16), g3 = __uint_as_float(g23 & 0xffff0000u);
+                            pk.x = pack2bf((mb & 1u) ? g0 : g0 * mask_neg, (mb & 2u) ? g1 : g1 * mask_neg);
+                            pk.y = pack2bf((mb & 4u) ? g2 : g2 * mask_neg, (mb & 8u) ? g3 : g3 * mask_neg);
                         } else {
                         pk.x = pack2bf(ep(acc[i][j][0], sv[j].x, bv[j].x), ep(acc[i][j][1], sv[j].y, bv[j].y));
                         pk.y = pack2bf(ep(acc[i][j][2], sv[j].z, bv[j].z), ep(acc[i][j][3], sv[j].w, bv[j].w));
@@ -1031,11 +1102,11 @@ __global__ __launch_bounds__(512) void conv_fprop_ws_kernel(const FdArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 red[tid * 16 + e] = (double)s1[e];
-                red[tid * 16 + 8 + e] = (double)s2[e];
+                red[tid * 16 + 8 + e] = MASK ? 0.0 : (double)s2[e];
             }
         }
         lds_barrier();
-        if (STATS && a.stats != nullptr && tid < 2 * BN) {
+        if (STATS && a.stats != nullptr && tid < (MASK ? 1 : 2) * BN) {
             const double* red = reinterpret_cast<const double*>(smem);
             const int which = tid / BN, col = tid - which * BN;
             const int c8 = col >> 3, e = col & 7;
@@ -1120,8 +1191,11 @@ int ksplit_factor(const FdArgs& a, int it_total, int ntl, int nch) {
     return ks;
 }
 
+constexpr int NOT_HANDLED = -12345;
+
 template <class C>
 int launch_ws(FdArgs& a, hipStream_t stream) {
+    if (a.bn_y != nullptr && !(C::MF16 && !C::TALL && C::SMEM + 2048 <= 160 * 1024)) return NOT_HANDLED;      // (activation mask: 16 x 16 tiles, 16x16x32 form)
     static int attr_rc = [] {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
@@ -1134,6 +1208,11 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if constexpr (C::MF16 && !C::TALL && C::SMEM + 2048 <= 160 * 1024) {
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM + 2048);
+        }
         if constexpr (C::TALL) {
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fprop_ws_kernel<C, false, false, true, true>),
@@ -1177,6 +1256,15 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
     if (gm < 1) gm = 1;
     if (gm > a.IT) gm = a.IT;
     a.GM = gm;
+    if (a.bn_y != nullptr) {      // activation mask of the producing layer (MASK instantiation: 16x16x32 form only)
+        if constexpr (C::MF16 && !C::TALL && C::SMEM + 2048 <= 160 * 1024) {
+            hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, false, true, false, true>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM + 2048,
+                               stream, a);
+            return 0;
+        } else {
+            return NOT_HANDLED;
+        }
+    }
     if (a.ep_act >= 0)            // (never with statistics: segnb_conv_fprop_act takes none)
         hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false, true, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     else if (a.stats == nullptr && !a.dbg && segnb_knob_fprop_nostats())
@@ -1187,8 +1275,6 @@ int launch_ws(FdArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((conv_fprop_ws_kernel<C, false>), dim3(a.GM * a.NTL), dim3(C::NT), C::SMEM, stream, a);
     return 0;
 }
-
-constexpr int NOT_HANDLED = -12345;
 
 // the plane gather (data gradient of an upsampled segment): one instantiation (no statistics, no epilogue)
 template <class C>
@@ -1300,6 +1386,7 @@ int dispatch_fd(FdArgs& a, hipStream_t stream) {
         const long long it0 = (long long)a.N * ((a.H + 7) / 8) * ((a.W + 31) / 32);
         const long long it1 = (long long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16);
         cfg = (it0 + gm - 1) / gm < (it1 + gm - 1) / gm ? 0 : 1;
+        if (a.bn_y != nullptr) cfg = 1;      // (activation mask: the 16 x 16 tile form has the 2 KB of LDS left for the mask bytes)
     }
     bool row_major_taps = true;          // the 16x16x32 form indexes its address tables by (t / 3, t % 3)
     for (int t = 0; t < 9; ++t) row_major_taps = row_major_taps && a.dw[t] == a.dw[t % 3] && a.dh[t] == a.dh[3 * (t / 3)];
@@ -1370,6 +1457,33 @@ int segnb_fprop_upf_try(int N, int H, int W, int Ci, int ld_in, const void* in, 
     return rc ? rc : 1;
 }
 
+// 1 when the MASK instantiation serves the data gradient g (segnb_conv_fprop_actmask_ok): what segnb_fprop_dma_try + dispatch_fd accept
+int segnb_fprop_dma_actmask_ok(const segnb_conv_geom* g) {
+    if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_mask() || !segnb_knob_fprop_mf16() || segnb_knob_fprop_dma_cfg() >= 2 ||
+        getenv("SEGNB_FPROP_GENERAL") != nullptr)
+        return 0;
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Ci % 64 != 0 || g->Co <= 32 || g->Co % 8 != 0 || g->Wo <= 8) return 0;
+    int dhmin = g->dh[0], dwmin = g->dw[0];
+    for (int t = 1; t < 9; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+    }
+    for (int t = 0; t < 9; ++t) {        // row-major 3 x 3 window (either direction): the 16x16x32 form's address tables
+        if (g->dh[t] - dhmin != g->dh[3 * (t / 3)] - dhmin || g->dw[t] - dwmin != g->dw[t % 3] - dwmin) return 0;
+        if (g->dh[t] - dhmin > 2 || g->dw[t] - dwmin > 2) return 0;
+    }
+    bool seen[9] = {false, false, false, false, false, false, false, false, false};
+    for (int t = 0; t < 9; ++t) {
+        const int k = (g->dh[t] - dhmin) * 3 + (g->dw[t] - dwmin);
+        if (seen[k]) return 0;
+        seen[k] = true;
+    }
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
+    const long long ob = (((long long)g->N * g->Ho * g->Wo - 1) * g->ld_out + g->Co) * 2;
+    return inb < (1ll << 31) && ob < (1ll << 31) ? 1 : 0;
+}
+
 extern "C" int segnb_conv_fprop_upd_ok(const segnb_conv_geom* g, int dtype) {
     if (g == nullptr || dtype != SEGNB_BF16) return 0;
     if (!segnb_knob_fprop_dma() || !segnb_knob_fprop_upd() || getenv("SEGNB_FPROP_GENERAL") != nullptr) return 0;
@@ -1388,7 +1502,11 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
                         hipStream_t stream, const segnb_act_epilogue* ep, const segnb_upcat_src* uc,
                         const segnb_bn_reduce_epilogue* bn) {
     if (!segnb_knob_fprop_dma()) return 0;
-    if (bn != nullptr) return 0;      // (fused BatchNorm-backward reductions: fprop_rw.hip / fprop_roll.hip)
+    // (fused BatchNorm-backward REDUCTIONS: fprop_rw.hip / fprop_roll.hip; here only the activation mask of a layer without
+    // BatchNorm -- coef NULL -- on a plain data gradient: the MASK instantiation)
+    if (bn != nullptr && (bn->coef != nullptr || bn->y == nullptr || bn->sums == nullptr || ep != nullptr || uc != nullptr ||
+                          stats != nullptr || bias != nullptr || g->ntaps != 9 || !segnb_knob_fprop_mask()))
+        return 0;
     if (g->ntaps == 16 && ep == nullptr && stats == nullptr && bias == nullptr && segnb_knob_fprop_upd()) {
         FdArgs a;
         a.x = (const bf16_t*)in;
@@ -1465,6 +1583,20 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
         a.u_bytes = (unsigned)ub;
     }
     a.bn_y = nullptr;
+    a.bn_act = SEGNB_ACT_NONE;
+    a.bn_slope = 0.f;
+    if (bn != nullptr) {
+        const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;
+        if (bn->ld_y % 4 != 0 || yb >= (1ll << 31)) return 0;
+        a.bn_y = (const bf16_t*)bn->y;
+        a.bn_y_bytes = (unsigned)yb;
+        a.bn_ld = bn->ld_y;
+        a.bn_coef = nullptr;
+        a.bn_sums = bn->sums;
+        a.bn_act = bn->act;
+        a.bn_slope = bn->slope;
+        a.stats = bn->sums;          // [REPL][2][Co]: slot 0 = sum dz (the bias gradient's source), slot 1 = sum dz^2 (cleared with it)
+    }
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;
     a.ep_slope = ep != nullptr ? ep->slope : 0.f;

@@ -751,9 +751,13 @@ int segnb_fprop_roll_try(const segnb_conv_geom* g, const void* in, unsigned in_b
 
 // include/segnb_hip.h: segnb_conv_fprop_bnreduce with coef == NULL (the plain one-wave form of segnb_fprop_roll_try, any padding)
 extern "C" int segnb_conv_fprop_actmask_ok(const segnb_conv_geom* g, int dtype) {
-    if (g == nullptr || dtype != SEGNB_BF16 || !segnb_knob_fprop_roll() || !segnb_knob_bnreduce_fused() ||
-        getenv("SEGNB_FPROP_GENERAL") != nullptr)
-        return 0;
+    if (g == nullptr || dtype != SEGNB_BF16 || !segnb_knob_bnreduce_fused()) return 0;
+    return segnb_fprop_roll_actmask_ok(g) || segnb_fprop_dma_actmask_ok(g) ? 1 : 0;
+}
+
+// conv_roll_kernel, EPI = 3 (32 -> <= 32 channels)
+int segnb_fprop_roll_actmask_ok(const segnb_conv_geom* g) {
+    if (!segnb_knob_fprop_roll() || getenv("SEGNB_FPROP_GENERAL") != nullptr) return 0;
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci != 32 || g->Co > 32 || g->Co % 8 != 0 || g->Wo < 32) return 0;
     if (g->ld_in % 8 != 0 || g->ld_out % 8 != 0) return 0;

@@ -117,6 +117,8 @@ class Tape(object):
         self.fused_stats, self.stats_pending = [], False
         # share (%) of the CUs the model's weight gradients split their pixels for (HipNet.wg_cu_pct; None = the library default)
         self.wg_cu_pct = getattr(module, 'wg_cu_pct', None)
+        if os.environ.get('SEGNB_WG_CU_PCT'):          # (A/B: overrides the model's share)
+            self.wg_cu_pct = int(os.environ['SEGNB_WG_CU_PCT'])
         self.lazy_add = bool(getattr(module, 'lazy_add', False))
 
     # BatchNorm finalize folded into the activation / apply launches of a differentiated training forward (one launch less

@@ -1516,7 +1516,11 @@ def test_bn_act_bwd_reduce_two_sources(shape, with_res, dtype):
 
 @pytest.mark.parametrize('shape', [(2, 40, 56, 32, 32, nv.ACT_RELU, 1), (3, 33, 47, 24, 32, nv.ACT_LEAKY, 1),
                                    (2, 38, 45, 32, 32, nv.ACT_LEAKY, 0),       # linknet.py:60 finalconv2 = Conv2d(32, 32, 3): valid window
-                                   (16, 511, 511, 32, 32, nv.ACT_LEAKY, 0)],
+                                   (16, 511, 511, 32, 32, nv.ACT_LEAKY, 0),
+                                   # conv_fprop_ws_kernel's MASK instantiation (unet16.py:73-108: VGG-style conv + ReLU stacks)
+                                   (2, 40, 56, 64, 64, nv.ACT_RELU, 1), (3, 33, 47, 72, 128, nv.ACT_LEAKY, 1),
+                                   (2, 38, 45, 64, 64, nv.ACT_LEAKY, 0), (2, 20, 24, 40, 192, nv.ACT_RELU, 1),
+                                   (4, 128, 160, 256, 64, nv.ACT_RELU, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_dgrad_with_act_mask(shape):
     """segnb_conv_fprop_bnreduce with coef NULL: the data gradient whose store pass applies the activation mask of the conv +

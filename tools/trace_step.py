@@ -3,7 +3,7 @@ consecutive kernels and the time per kernel family, forward and backward apart (
 forward / backward boundary = loss_bwd_kernel).
 
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --steps 8 --warmup 3 ...
-    python tools/trace_step.py gpurun_out/trace [step index from the end, default 3]
+    python tools/trace_step.py gpurun_out/trace [step index from the end, default 3] [list | full]
 """
 import csv
 import glob
@@ -28,7 +28,7 @@ def main():
     with open(f, newline='') as fh:
         for r in csv.DictReader(fh):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), family(r['Kernel_Name']), r.get('Queue_Id', '0'),
-                         r['Kernel_Name']))
+                         r['Kernel_Name'] + '  grid ' + str(r.get('Grid_Size_X', r.get('Grid_Size', '?')))))
     rows.sort()
     sgd = [i for i, r in enumerate(rows) if r[2] in ('sgd_kernel', 'sgd_ranges_kernel')]      # (the step's last kernel, fused or not)
     lo, hi = sgd[-back - 1], sgd[-back]
@@ -70,7 +70,11 @@ def main():
         for (q, k), (n, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
             print('   q%-3s %-36s n=%3d %8.1f us' % (q, k, n, t / 1e3))
     if len(sys.argv) > 3:
-        for s, e, fam_, q, _ in step:
+        full = sys.argv[3] == 'full'        # (full: template arguments and grid size as well)
+        for s, e, fam_, q, name in step:
+            if full:
+                m = re.search(r'<(.*)>', name.replace('(anonymous namespace)::', ''))
+                fam_ = '%s  <%s>  %s' % (fam_, (m.group(1) if m else '')[:90], name[name.rindex('  grid '):].strip())
             print('%10.1f %8.1f q%s %s' % ((s - t0) / 1e3, (e - s) / 1e3, q, fam_))
 
 
