@@ -309,6 +309,9 @@ def main():
     ap.add_argument('--fuse-optimizer', action='store_true',
                     help='N > 1: SGD update of each gradient bucket behind its all-reduce (segnb.dist.DataParallel.fuse_optimizer)')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--timed-only', action='store_true',
+                    help='stop the GPU work after the timed region: no host-enqueue probe, no logged steps, no kernel timer, no CPU '
+                         'baseline, no box probes (for kernel traces: every step of the run is then a warm-up or a timed step)')
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the whole training step from one captured HIP graph (auto = off: eager launches overlap the weight-gradient stream better)')
     ap.add_argument('--wire', default='f32', choices=['f32', 'bf16'],
@@ -321,6 +324,8 @@ def main():
     ap.add_argument('--dry-run', action='store_true',
                     help='join the job, count the ranks (all-reduce of ones), print n_gpus / ranks_seen and stop')
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_kernel_timer = args.no_box = True
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # nothing above has touched the GPU (importing torch and parsing arguments do not)
@@ -457,7 +462,7 @@ def main():
     # host time to ENQUEUE one step (no synchronisation inside; the GPU is still busy with the first step when the last
     # one has been issued unless the host is the slower side) -- reported beside the step time, outside the timed region
     host_ms = None
-    if graph is None:
+    if graph is None and not args.timed_only:
         # three steps from an idle GPU, best of three: a longer unsynchronised run can fill the HIP queue, and the host
         # then waits for the GPU inside a launch call (seen as 2.1-2.3 ms "enqueue" time on some boxes)
         for _ in range(3):
@@ -474,7 +479,7 @@ def main():
     # abs-max ('train/grad/global_abs_max': one fused reduction over the flat gradient buffer here, a per-parameter loop of
     # .abs().max().cpu().item() there), and the two metrics -- every one a host sync.  SURVEY 8d / BASELINE.md section 2.
     logging_ms = None
-    if graph is None and ws == 1:
+    if graph is None and ws == 1 and not args.timed_only:
         import torch_train as tt
         mets = tt.default_metrics()
 

@@ -12,10 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 python3 $R/bench.py --size 512 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_512.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_stats -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-box > $O/${TAG}_prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmc_sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmc_sq2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --timed-only > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --timed-only > $O/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq1 -- python3 $R/bench.py --steps 4 --warmup 2 --timed-only > $O/${TAG}_pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/${TAG}_pmc_sq2 -- python3 $R/bench.py --steps 4 --warmup 2 --timed-only > $O/${TAG}_pmc_sq2.log 2>&1
 for m in linknet34 fcdensenet103 unet16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_$m -- python3 $R/bench.py --model $m --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_prof_$m.log 2>&1
   find $O/${TAG}_prof_$m -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $O/${TAG}_${m}_kernel_stats.csv
@@ -23,8 +23,8 @@ for m in linknet34 fcdensenet103 unet16; do
 done
 # HBM traffic of the other model rows: the same two PMC passes per model
 for m in linknet34 fcdensenet103 unet16; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcf_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmcf_$m.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcw_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_pmcw_$m.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcf_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --timed-only > $O/${TAG}_pmcf_$m.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmcw_$m -- python3 $R/bench.py --model $m --steps 4 --warmup 2 --timed-only > $O/${TAG}_pmcw_$m.log 2>&1
   (cd $R && python3 tools/pmc_traffic.py $O/${TAG}_pmcf_$m $O/${TAG}_pmcw_$m $O/${TAG}_pmc_traffic_$m.json > $O/${TAG}_pmc_traffic_$m.log 2>&1)
   rm -rf $O/${TAG}_pmcf_$m $O/${TAG}_pmcw_$m
 done
@@ -50,18 +50,20 @@ mkdir -p tools/_bin
 [ -x tools/_bin/fork_cost ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/_bin/fork_cost tools/fork_cost.hip > /dev/null 2>&1
 [ -x tools/_bin/fork_check ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/_bin/fork_check tools/fork_check.hip > /dev/null 2>&1
 (./tools/_bin/fork_cost; ./tools/_bin/fork_check) > $O/${TAG}_fork_cost.txt 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace.log 2>&1)
-python3 tools/trace_step.py $O/${TAG}_trace 12 list > $O/${TAG}_step_trace.txt 2>&1
+# (--timed-only: every step of the traced run is a warm-up or a TIMED step -- without it the steps counted from the end are the logged /
+# host-probe steps that follow the timed region, which start from an idle GPU and carry the logging's reductions)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace -- python3 $R/bench.py --steps 12 --warmup 3 --timed-only > $O/${TAG}_trace.log 2>&1)
+python3 tools/trace_step.py $O/${TAG}_trace 4 list > $O/${TAG}_step_trace.txt 2>&1
 rm -rf $O/${TAG}_trace
 # one traced step of each executor model (kernel families, queue gaps)
 for m in linknet34 fcdensenet103 unet16; do
-  (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_$m -- python3 $R/bench.py --model $m --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace_$m.log 2>&1)
-  python3 tools/trace_step.py $O/${TAG}_trace_$m 8 > $O/${TAG}_step_trace_$m.txt 2>&1
+  (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_$m -- python3 $R/bench.py --model $m --steps 8 --warmup 3 --timed-only > $O/${TAG}_trace_$m.log 2>&1)
+  python3 tools/trace_step.py $O/${TAG}_trace_$m 3 > $O/${TAG}_step_trace_$m.txt 2>&1
   rm -rf $O/${TAG}_trace_$m
 done
 # the same step replayed from ONE HIP graph (where does the two-branch overlap go?)
 python3 bench.py --graph on --no-cpu-baseline --no-kernel-timer > $O/${TAG}_bench_graph.json 2>/dev/null
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/bench.py --graph on --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timer --no-box > $O/${TAG}_trace_graph.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/bench.py --graph on --steps 12 --warmup 3 --timed-only > $O/${TAG}_trace_graph.log 2>&1)
 python3 tools/trace_step.py $O/${TAG}_trace_graph 4 list > $O/${TAG}_step_trace_graph.txt 2>&1
 rm -rf $O/${TAG}_trace_graph
 python3 tools/insitu.py > $O/${TAG}_insitu.txt 2>&1
