@@ -488,6 +488,20 @@ int segnb_conv_fprop_bnapply(const segnb_conv_geom* g, int dtype, const void* in
  * conv_fprop_ws_kernel -- the VGG-style encoder / decoder convolutions of unet16.py:73-108). */
 int segnb_conv_fprop_actmask_ok(const segnb_conv_geom* g, int dtype);
 
+/* conv -> Dropout2d -> [statistics of the result] in ONE launch (a dense layer of tiramisu.py:9-20: norm -> relu -> conv(C -> 16) ->
+ * Dropout2d(0.2), its 16 channels written into their slice of the block's concat buffer, whose later BatchNorms need the slice's
+ * batch statistics):
+ *     out[n, h, w, co] = round(round(acc + bias[co]) * dropmul[n * ld_drop + co])      -- the bits segnb_conv_fprop followed by
+ *                                                                                          segnb_bn_act_fwd(coef NULL, ACT_NONE, dropmul) stores
+ *     stats[r][0][co] += sum out,  stats[r][1][co] += sum out^2   over the pixels of the launch's blocks, rows stats_ld doubles apart
+ *                                                                  (a [REPLICAS][2][stats_ld] table: segnb_bn_stats_ld); stats NULL: none
+ * instead of the convolution + a 5 us pass over sixteen channels, ninety times per FCDenseNet103 forward.  dropmul: [N][ld_drop] fp32,
+ * required.  _ok: bf16, stride-1 3 x 3 window, <= 32 output channels behind > 96 input channels (conv_fprop_deepk_kernel /
+ * conv_fprop_s1x9_kernel). */
+int segnb_conv_fprop_drop_ok(const segnb_conv_geom* g, int dtype);
+int segnb_conv_fprop_drop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias, int bias_n,
+                          void* out, const float* dropmul, int ld_drop, double* stats, int stats_ld, segnb_stream_t stream);
+
 /* CONSUMER-SIDE BatchNorm: a convolution (or weight-gradient) operand that is NOT in memory -- it is recomputed from what the
  * producing layer left there while the kernel stages its input rows (conv_roll_kernel, fprop_roll.hip):
  *   SEGNB_TF_ACT    operand = round(drop * act((src - mean) * scale + shift)): what segnb_bn_act_fwd would have written from the

@@ -311,6 +311,30 @@ class AbiEmulator(object):
         return fn(dtype, e.y, e.ld_y, gg.N, gg.Ho, gg.Wo, e.C, gg.Co, e.coef, e.sums, e.gamma, e.bcoef, e.dgamma, e.dbeta, 1, None,
                   e.act, e.slope, tmp.data_ptr(), gg.Co, e.dx, e.ld_dx, stream)
 
+    def segnb_conv_fprop_drop_ok(self, g, dtype):
+        g = _geom(g)
+        dh, dw = [g.dh[t] for t in range(g.ntaps)], [g.dw[t] for t in range(g.ntaps)]
+        s1 = (g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.oh0 == 0 and g.ow0 == 0 and g.QH == g.Ho and g.QW == g.Wo
+              and g.Wo > 8 and max(dh) - min(dh) == 2 and max(dw) - min(dw) == 2)
+        M, Ktot = g.N * g.QH * g.QW, g.ntaps * g.Ci
+        general_blocks = -(-M // 128) * -(-g.Co // (32 if g.Co <= 32 else 64))
+        deepk = g.Ci % 16 == 0 and Ktot >= 2048 and general_blocks * 2 <= 256
+        return int(dtype == BF16 and g.Co <= 32 and g.Co % 8 == 0 and g.Ci > 96 and g.Ci % 8 == 0 and (s1 or deepk))
+
+    def segnb_conv_fprop_drop(self, g, dtype, in_p, wp, bias, bias_n, out_p, dropmul, ld_drop, stats, stats_ld, stream):
+        """segnb_conv_fprop, the Dropout2d multipliers on the stored (rounded) result, the statistics of what that leaves"""
+        gg = _geom(g)
+        rc = self.segnb_conv_fprop(g, dtype, in_p, wp, bias, bias_n, out_p, None, stream)
+        if rc:
+            return rc
+        dt = _tdt(dtype)
+        O = _nhwc(out_p, gg.N, gg.Ho, gg.Wo, gg.Co, gg.ld_out, dt)
+        m = _mem(dropmul, gg.N * ld_drop, torch.float32).view(gg.N, ld_drop)[:, :gg.Co]
+        O.copy_((O.float() * m[:, None, None, :]).to(dt))
+        if stats:
+            return self.segnb_bn_stats_ld(dtype, out_p, gg.ld_out, gg.N, gg.Ho, gg.Wo, gg.Co, stats, stats_ld, stream)
+        return 0
+
     def segnb_conv_fprop_actmask_ok(self, g, dtype):
         g = _geom(g)
         if not (dtype == BF16 and g.ntaps == 9 and g.in_step == 1 and g.out_step == 1 and g.QH == g.Ho and g.QW == g.Wo

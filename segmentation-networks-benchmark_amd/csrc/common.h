@@ -132,6 +132,7 @@ int segnb_fprop_thin_try(const segnb_conv_geom* g, const void* in, const void* w
                          const segnb_bn_reduce_epilogue* bn);
 int segnb_fprop_thin_ok(const segnb_conv_geom* g);
 int segnb_knob_fprop_upd();       // 1: 4x4 / stride-2 gathers (ntaps 16, in_step 2) on the plane-gather form of conv_fprop_ws_kernel
+int segnb_knob_fprop_drop();      // 1: segnb_conv_fprop_drop_ok may say yes
 int segnb_knob_fprop_mask();      // 1: conv_fprop_ws_kernel serves activation-mask data gradients (segnb_conv_fprop_bnreduce, coef NULL)
 int segnb_fprop_dma_actmask_ok(const segnb_conv_geom* g);
 int segnb_fprop_roll_actmask_ok(const segnb_conv_geom* g);     // fprop_roll.hip: conv_roll_kernel (EPI = 3) serves g      // fprop_dma.hip: the MASK instantiation serves g
@@ -147,8 +148,10 @@ int segnb_knob_wg_cu_pct();      // segnb_tune "wg_cu_pct": 0 = default share of
 int segnb_knob_conv_cus();        // CUs the persistent fprop / dgrad kernels size their grids for (segnb_tune "conv_cu_pct")
 int segnb_fprop_dma_read_stamps(unsigned long long* host_dst);
 // fast path of segnb_conv_wgrad (wgrad_s1.hip): 1 = handled, 0 = not applicable, else error
+// (drop / ld_drop / stats_ld: the Dropout2d multipliers and the statistics row stride of segnb_conv_fprop_drop; NULL / 0 / 0: off)
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
-                       void* out, double* stats, hipStream_t stream);
+                       void* out, double* stats, hipStream_t stream, const float* drop = nullptr, int ld_drop = 0,
+                       int stats_ld = 0);
 // direct-to-LDS pipeline for Ci % 64 == 0 (fprop_dma.hip): 1 = handled, 0 = not applicable, else error
 int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_bytes, const void* wpacked,
                         unsigned w_bytes, const float* bias, int bias_n, void* out, double* stats,

@@ -58,6 +58,9 @@ struct FpropArgs {
     void* bn_acc;                        // [N][Ho][Wo][bn_acc_ld] the BatchNorm input's gradient
     int bn_acc_ld, bn_accumulate;
     int bn_mode;                         // the BNM instantiation a BNR launch takes
+    // segnb_conv_fprop_drop (conv_fprop_deepk_kernel): out = round(round(acc + bias) * drop[n][co]); statistics rows stats_ld apart
+    const float* drop;
+    int ld_drop, stats_ld;
 };
 
 struct WgradArgs {
@@ -598,22 +601,47 @@ __global__ __launch_bounds__(DK_WAVES * 64) void conv_fprop_deepk_kernel(const F
     for (int w = 0; w < DK_WAVES; ++w) v += sAcc[w][e][lane];
     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
     const int mo = m_base + row;
+    float stored = 0.f;
     if (mo < a.M && co < g.Co) {
         if (a.bias != nullptr && co < a.bias_n) v += a.bias[co];
         const int no = mo / QHW;
         const int ro = mo - no * QHW;
         const int qho = ro / g.QW, qwo = ro - qho * g.QW;
         const long long opix = (long long)(no * g.Ho + qho * g.out_step + g.oh0) * g.Wo + qwo * g.out_step + g.ow0;
-        reinterpret_cast<bf16_t*>(a.out)[opix * g.ld_out + co] = Elem<bf16_t>::from_f32(v);
+        bf16_t tv = Elem<bf16_t>::from_f32(v);
+        if (a.drop != nullptr)       // Dropout2d multiplier of (image, channel): segnb_conv_fprop_drop
+            tv = Elem<bf16_t>::from_f32(Elem<bf16_t>::to_f32(tv) * a.drop[(long long)no * a.ld_drop + co]);
+        reinterpret_cast<bf16_t*>(a.out)[opix * g.ld_out + co] = tv;
+        stored = Elem<bf16_t>::to_f32(tv);
+    }
+    if (a.stats != nullptr) {        // statistics of the stored tile: 32 rows per channel through LDS, fixed order, one atomic each
+        __syncthreads();             // (every thread has read its partial sums)
+        float* red = &sAcc[0][0][0];                     // [32 rows][32 channels]
+        red[row * 32 + r] = stored;
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5, col = tid & 31;
+            double sum = 0.0;
+            for (int k = 0; k < 32; ++k) {
+                const float x = red[k * 32 + col];
+                sum += which ? (double)(x * x) : (double)x;
+            }
+            const int cc = n_base + col;
+            if (cc < g.Co)
+                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.stats_ld + cc], sum);
+        }
     }
 }
 
-static bool fprop_deepk_applies(const FpropArgs& a) {
-    if (!segnb_knob_fprop_deepk() || a.stats != nullptr || a.ep_act >= 0 || (a.g.Ci & 15) != 0 || a.Ktot < 2048) return false;
+static bool fprop_deepk_shape(const segnb_conv_geom& g) {
+    const int M = g.N * g.QH * g.QW, Ktot = g.ntaps * g.Ci;
+    if (!segnb_knob_fprop_deepk() || (g.Ci & 15) != 0 || Ktot < 2048) return false;
     // the block tiles of the general kernel would leave more than half of the CUs without a block
-    const long long general_blocks = (long long)ceil_div(a.M, 128) * ceil_div(a.g.Co, a.g.Co <= 32 ? 32 : 64);
+    const long long general_blocks = (long long)ceil_div(M, 128) * ceil_div(g.Co, g.Co <= 32 ? 32 : 64);
     return general_blocks * 2 <= segnb_num_cus();
 }
+// (plain launches: no statistics -- the kernel has them for segnb_conv_fprop_drop, which calls it directly -- and no epilogue forms)
+static bool fprop_deepk_applies(const FpropArgs& a) { return a.stats == nullptr && a.ep_act < 0 && fprop_deepk_shape(a.g); }
 
 // ================================================================================================
 // weight gradient:  dW[co][k'] += sum_pixels dy[pix][co] * im2col(x)[pix][k']
@@ -1669,6 +1697,9 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
     a.ep_act = ep != nullptr ? ep->act : -1;
     a.ep_coef = ep != nullptr ? ep->coef : nullptr;
     a.ep_slope = ep != nullptr ? ep->slope : 0.f;
+    a.drop = nullptr;
+    a.ld_drop = 0;
+    a.stats_ld = g->Co;
     a.g = *g;
     a.in = in;
     a.w = wpacked;
@@ -1728,6 +1759,77 @@ static int conv_fprop_impl(const segnb_conv_geom* g, int dtype, const void* in, 
         return SEGNB_E_BADARG;
     }
     if (rc) return rc;
+    SEGNB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- conv -> Dropout2d -> statistics in one launch (include/segnb_hip.h: segnb_conv_fprop_drop) -------------------------------------
+// served where the plain cascade above ends in conv_fprop_deepk_kernel or conv_fprop_s1x9_kernel: <= 32 output channels behind more
+// than 96 input channels (below that the rolling / LDS-DMA kernels take the launch), a stride-1 3 x 3 window
+static bool drop_s1_shape(const segnb_conv_geom* g) {
+    if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return false;
+    if (g->QH != g->Ho || g->QW != g->Wo || g->Wo <= 8) return false;
+    int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
+    for (int t = 1; t < 9; ++t) {
+        dhmin = g->dh[t] < dhmin ? g->dh[t] : dhmin;
+        dhmax = g->dh[t] > dhmax ? g->dh[t] : dhmax;
+        dwmin = g->dw[t] < dwmin ? g->dw[t] : dwmin;
+        dwmax = g->dw[t] > dwmax ? g->dw[t] : dwmax;
+    }
+    return dhmax - dhmin == 2 && dwmax - dwmin == 2;
+}
+
+extern "C" int segnb_conv_fprop_drop_ok(const segnb_conv_geom* g, int dtype) {
+    if (g == nullptr || dtype != SEGNB_BF16 || check_geom(g) || getenv("SEGNB_FPROP_GENERAL") != nullptr || !segnb_knob_fprop_drop()) return 0;
+    if (g->Co > 32 || g->Co % 8 != 0 || g->Ci <= 96 || g->Ci % 8 != 0) return 0;
+    const long long inb = (((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2;
+    const long long wb = (long long)g->Co * g->ntaps * g->Ci * 2;
+    if (inb >= (1ll << 31) || wb >= (1ll << 31)) return 0;
+    return (fprop_deepk_shape(*g) || drop_s1_shape(g)) ? 1 : 0;
+}
+
+extern "C" int segnb_conv_fprop_drop(const segnb_conv_geom* g, int dtype, const void* in, const void* wpacked, const float* bias,
+                                     int bias_n, void* out, const float* dropmul, int ld_drop, double* stats, int stats_ld,
+                                     segnb_stream_t stream) {
+    SEGNB_PLAN_RECORD(segnb_conv_fprop_drop, g, dtype, in, wpacked, bias, bias_n, out, dropmul, ld_drop, stats, stats_ld, stream);
+    if (int rc = check_geom(g)) return rc;
+    SEGNB_CHECK_ARG(in && wpacked && out && dropmul, "NULL argument");
+    SEGNB_CHECK_ARG(segnb_conv_fprop_drop_ok(g, dtype), "geometry not served (segnb_conv_fprop_drop_ok)");
+    SEGNB_CHECK_ARG(ld_drop >= g->Co && (stats == nullptr || stats_ld >= g->Co), "bad strides");
+    if (fprop_deepk_shape(*g)) {
+        FpropArgs a;
+        a.g = *g;
+        a.in = in;
+        a.w = wpacked;
+        a.in_bytes = (unsigned)((((long long)g->N * g->Hi * g->Wi - 1) * g->ld_in + g->Ci) * 2);
+        a.w_bytes = (unsigned)((long long)g->Co * g->ntaps * g->Ci * 2);
+        a.bias = bias;
+        a.bias_n = bias_n;
+        a.ep_coef = nullptr;
+        a.ep_act = -1;
+        a.ep_slope = 0.f;
+        a.out = out;
+        a.stats = stats;
+        a.M = g->N * g->QH * g->QW;
+        a.Ktot = g->ntaps * g->Ci;
+        a.ksteps = a.MT = a.NTL = a.GM = 0;
+        a.bn_y = nullptr;
+        a.bn_mode = 0;
+        a.bn_acc = nullptr;
+        a.bn_accumulate = 0;
+        a.drop = dropmul;
+        a.ld_drop = ld_drop;
+        a.stats_ld = stats_ld > 0 ? stats_ld : g->Co;
+        hipLaunchKernelGGL(conv_fprop_deepk_kernel, dim3(ceil_div(a.M, 32), ceil_div(g->Co, 32)), dim3(DK_WAVES * 64), 0,
+                           (hipStream_t)stream, a);
+        SEGNB_LAUNCH_CHECK();
+        return 0;
+    }
+    const int rc = segnb_fprop_s1_try(g, in, wpacked, bias, bias_n, out, stats, (hipStream_t)stream, dropmul, ld_drop, stats_ld);
+    if (rc != 1) {
+        segnb_set_error("segnb_conv_fprop_drop: the kernel refused the launch (%d)", rc);
+        return rc > 1 ? rc : SEGNB_E_BADARG;
+    }
     SEGNB_LAUNCH_CHECK();
     return 0;
 }

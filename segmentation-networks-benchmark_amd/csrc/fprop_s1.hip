@@ -29,6 +29,10 @@ struct FpS1Args {
     int dhmin, dwmin;
     int dh[9], dw[9];     // tap offsets minus (dhmin, dwmin): 0..2
     int HB, WB, IT, NTL, GM, NCH;
+    // segnb_conv_fprop_drop: out = round(round(acc + bias) * drop[n][co]) (Dropout2d multipliers, [N][ld_drop] fp32; NULL: off) and
+    // the statistics of THAT tensor go to a table whose rows are stats_ld doubles apart (a concat buffer's table: segnb_bn_stats_ld)
+    const float* drop;
+    int ld_drop, stats_ld;
 };
 
 __device__ __forceinline__ int xcd_remap_s1(int b, int G) {
@@ -238,18 +242,21 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
 
         // ---- epilogue ---------------------------------------------------------------------------------
         float cs1[TN], cs2[TN];
+        const int n_cur = it / (a.HB * a.WB);          // (n already belongs to the tile being loaded)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * C::WN + 32 * j + r;
             const int co = n_base + col;
             const float bv = bias_r[j];
+            // Dropout2d multiplier of (image, channel); 1 without: round(x * 1) == x, the plain launches store the same bits
+            const float mv = (a.drop != nullptr && co < a.Co) ? a.drop[(long long)n_cur * a.ld_drop + co] : 1.f;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = wm * C::WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const bf16_t tv = Elem<bf16_t>::from_f32(acc[i][j][e] + bv);
+                    const bf16_t tv = Elem<bf16_t>::from_f32(Elem<bf16_t>::to_f32(Elem<bf16_t>::from_f32(acc[i][j][e] + bv)) * mv);
                     *reinterpret_cast<bf16_t*>(sOut + row * OUT_ROW + col * 2) = tv;
                     if (sPix[row] >= 0) {
                         const float vr = Elem<bf16_t>::to_f32(tv);
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_fprop_s1x9_kernel(const FpS1Args a) 
     if (a.stats != nullptr && tid < 2 * BN) {
         const int which = tid / BN, col = tid - which * BN;
         const int co = n_base + col;
-        if (co < a.Co) atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], st);
+        if (co < a.Co) atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.stats_ld + co], st);
     }
 }
 
@@ -353,7 +360,7 @@ int dispatch_fs1(FpS1Args& a, hipStream_t stream) {
 
 // 1 = handled, 0 = not a stride-1 3x3 case (caller uses the general gather kernel), else error
 int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpacked, const float* bias, int bias_n,
-                       void* out, double* stats, hipStream_t stream) {
+                       void* out, double* stats, hipStream_t stream, const float* drop, int ld_drop, int stats_ld) {
     if (g->ntaps != 9 || g->in_step != 1 || g->out_step != 1 || g->oh0 != 0 || g->ow0 != 0) return 0;
     if (g->QH != g->Ho || g->QW != g->Wo || g->Ci < 32) return 0;
     int dhmin = g->dh[0], dhmax = g->dh[0], dwmin = g->dw[0], dwmax = g->dw[0];
@@ -371,6 +378,9 @@ int segnb_fprop_s1_try(const segnb_conv_geom* g, const void* in, const void* wpa
     a.bias_n = bias_n;
     a.out = (bf16_t*)out;
     a.stats = stats;
+    a.drop = drop;
+    a.ld_drop = ld_drop;
+    a.stats_ld = stats_ld > 0 ? stats_ld : g->Co;
     a.N = g->N; a.H = g->Ho; a.W = g->Wo; a.Hi = g->Hi; a.Wi = g->Wi;
     a.Ci = g->Ci; a.Co = g->Co; a.ld_x = g->ld_in; a.ld_out = g->ld_out;
     a.Ktot = 9 * g->Ci;

@@ -329,6 +329,14 @@ int segnb_knob_fprop_mask() {
     }
     return g_fprop_mask;
 }
+static int g_fprop_drop = -2;      // segnb_conv_fprop_drop_ok may say yes (A/B: SEGNB_FPROP_DROP=0)
+int segnb_knob_fprop_drop() {
+    if (g_fprop_drop == -2) {
+        const char* e = getenv("SEGNB_FPROP_DROP");
+        g_fprop_drop = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return g_fprop_drop;
+}
 static int g_fprop_nostats = 1;    // conv_fprop_ws_kernel: statistics-free instantiation for launches without statistics (A/B)
 int segnb_knob_fprop_nostats() { return g_fprop_nostats; }
 static int g_rw_store_waves = 4;   // store waves of conv_fprop_rw_kernel: 4 (default) or 2 (round 1)
@@ -424,6 +432,10 @@ extern "C" int segnb_tune(const char* key, int value) {
     }
     if (strcmp(key, "wg_cu_pct") == 0) {          // takes effect for plans made afterwards (segnb_conv_wgrad_slabs)
         g_wg_cu_pct = value < 0 ? 0 : (value > 100 ? 100 : value);
+        return 0;
+    }
+    if (strcmp(key, "fprop_drop") == 0) {
+        g_fprop_drop = value ? 1 : 0;
         return 0;
     }
     if (strcmp(key, "fprop_mask") == 0) {

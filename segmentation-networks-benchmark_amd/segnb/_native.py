@@ -83,6 +83,7 @@ _P = c_void_p
 SIGNATURES = {
     'segnb_conv_fprop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, _P],
     'segnb_conv_fprop_act': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, ctypes.POINTER(ActEpilogue), _P],
+    'segnb_conv_fprop_drop': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P],
     'segnb_conv_fprop_upcat': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(UpcatSrc), _P, _P, c_int, _P, _P, _P],
     'segnb_conv_fprop_upsum': [ctypes.POINTER(ConvGeom), c_int, _P, _P, _P, ctypes.POINTER(UpcatSrc), _P],
     'segnb_conv_wgrad_upcat': [ctypes.POINTER(ConvGeom), c_int, _P, ctypes.POINTER(UpcatSrc), _P, _P, c_int, _P],
@@ -195,7 +196,7 @@ SIGNATURES = {
     'segnb_rmsprop_step': [_P, _P, _P, c_ll, c_float, c_float, c_float, _P],
     'segnb_adam_step': [_P, _P, _P, _P, c_ll, c_float, c_float, c_float, c_float, c_int, _P],
 }
-PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_pair_job_bytes': (c_int, []), 'segnb_pack_pair_job_blocks': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_pack_elem_job_blocks': (c_int, [c_int, c_int, c_int]), 'segnb_bias_grad_job_bytes': (c_int, []), 'segnb_head_fused_ok': (c_int, [c_int, c_int]), 'segnb_head_conv_ok': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_conv_fprop_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_actmask_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
+PLAIN = {'segnb_version': (c_int, []), 'segnb_pack_pair_job_bytes': (c_int, []), 'segnb_pack_pair_job_blocks': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_pack_elem_job_blocks': (c_int, [c_int, c_int, c_int]), 'segnb_bias_grad_job_bytes': (c_int, []), 'segnb_head_fused_ok': (c_int, [c_int, c_int]), 'segnb_head_conv_ok': (c_int, [c_int, c_int, c_int, c_int]), 'segnb_conv_fprop_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_tf_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnreduce_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_actmask_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_drop_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_u8_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_fprop_upd_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_conv_upcat_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_fprop_upsum_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int, c_int]), 'segnb_conv_wgrad_bnapply_ok': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_upconv_fprop_acc_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_upconv_fprop_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]), 'segnb_conv_wgrad_slabs': (c_int, [ctypes.POINTER(ConvGeom), c_int]), 'segnb_pack_job_bytes': (c_int, []), 'segnb_pack_job_blocks': (c_int, [c_int, c_int, c_int, c_ll, c_ll]), 'segnb_device_cus': (c_int, []), 'segnb_last_error': (ctypes.c_char_p, [])}
 
 _lib = None
 _test_backend = None

@@ -513,6 +513,33 @@ class ConvOp(object):
             return N is not None and coef is None and self.upconv_act_ok(N, H, W, ld_out)
         return True
 
+    # fuse_drop = False (class attribute / SEGNB_FUSE_DROP=0): conv -> Dropout2d -> slice statistics as convolution + pass (A/B)
+    fuse_drop = os.environ.get('SEGNB_FUSE_DROP', '1') != '0'
+
+    def drop_epilogue_ok(self, N, H, W, ld_out):
+        """True when segnb_conv_fprop_drop serves this convolution: the Dropout2d multipliers (and the statistics of the result) in
+        the launch's store pass."""
+        p = self.plan(H, W)
+        if not self.fuse_drop or self.transposed or len(p['fwd']) != 1 or not p['fwd_full'] or self.rt.code != nv.BF16:
+            return False
+        Ho, Wo = p['out_hw']
+        g = self._geom(p, 'f', 0, p['fwd'][0], N, H, W, self.Cip, self.Cip, Ho, Wo, self.Cop, ld_out)
+        return bool(nv.query('segnb_conv_fprop_drop_ok', g, self.rt.code))
+
+    def fprop_drop(self, xv, yv, dropmul, out_stats=None):
+        """yv = Dropout2d multipliers x (conv + bias); out_stats: (fp64 table, element offset, row stride) -- the statistics of yv are
+        accumulated into that channel range -- or None.  Check drop_epilogue_ok first."""
+        p, rt = self.plan(xv.H, xv.W), self.rt
+        assert xv.Cp == self.Cip and yv.Cp == self.Cop and (yv.H, yv.W) == p['out_hw'] and dropmul.shape[1] >= self.Cop
+        l = p['fwd'][0]
+        g = self._geom(p, 'f', 0, l, xv.N, xv.H, xv.W, self.Cip, xv.ld, yv.H, yv.W, self.Cop, yv.ld)
+        b = self.bias.detach() if self.bias is not None else None
+        st = nv.ptr(out_stats[0], out_stats[1]) if out_stats is not None else None
+        _timed('conv_fprop', 2.0 * xv.N * l.QH * l.QW * len(l.taps) * self.Ci * self.Co,
+               lambda: nv.call('segnb_conv_fprop_drop', g, rt.code, xv.ptr, nv.ptr(p['wp_fwd'][0]), nv.ptr(b),
+                               self.Co if b is not None else 0, yv.ptr, nv.ptr(dropmul), int(dropmul.shape[1]), st,
+                               out_stats[2] if out_stats is not None else 0, rt.stream))
+
     def u8_direct_ok(self, N, H, W, ld_out):
         """True when segnb_conv_fprop_u8 serves this convolution as the network's first layer."""
         p = self.plan(H, W)

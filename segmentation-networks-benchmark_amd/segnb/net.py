@@ -640,38 +640,49 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         if not has_bn:
             tape.record(backward_fused)
         return (oa, pa) if pool else oa
-    conv.fprop(xv, y, stats if use_batch_stats else None)
-    coef = None
-    ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
-    pv = (pool_out if pool_out is not None else tape.view(site + '/p', N, Ho // 2, Wo // 2, Cp)) if pool else None
-    fused_bn = has_bn and tape.fuses_finalize()
-    if fused_bn:
-        # finalize + activation pass in one launch; the statistics stay for this layer's backward to clear, the
-        # backward sums are cleared here (segnb_bn_fwd_fused / segnb_bn_bwd_apply_fused, include/segnb_hip.h)
-        gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
-        sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
-        nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(stats), nv.ptr(eff_gamma()),
-                nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef_buf), nv.ptr(sums_f),
-                act, slope, nv.ptr(dropmul), ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0,
-                None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
-        tape.note_fused_stats(stats)
-        coef = coef_buf
+    # conv -> Dropout2d -> slice statistics (a dense layer of tiramisu.py:9-20) in ONE launch where segnb_conv_fprop_drop serves the
+    # shape: the raw convolution output is never stored (its backward only needs the multipliers)
+    drop_fused = (not has_bn and act == nv.ACT_NONE and dropmul is not None and not pool and res is None
+                  and conv.drop_epilogue_ok(N, xv.H, xv.W, out.ld if out is not None else Cp))
+    if drop_fused:
+        ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
+        conv.fprop_drop(xv, ov, dropmul, out_stats)
+        out_stats = None
+        y = ov                  # (the reduction pass of the backward takes y for act'(z) only: ACT_NONE never reads it)
+        coef, pv, fused_bn = None, None, False
     else:
-        if has_bn:
+        conv.fprop(xv, y, stats if use_batch_stats else None)
+        coef = None
+        ov = out if out is not None else tape.view(site + '/a', N, Ho, Wo, Cp)
+        pv = (pool_out if pool_out is not None else tape.view(site + '/p', N, Ho // 2, Wo // 2, Cp)) if pool else None
+        fused_bn = has_bn and tape.fuses_finalize()
+        if fused_bn:
+            # finalize + activation pass in one launch; the statistics stay for this layer's backward to clear, the
+            # backward sums are cleared here (segnb_bn_fwd_fused / segnb_bn_bwd_apply_fused, include/segnb_hip.h)
             gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
-            nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(eff_gamma()),
-                    nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
-                    nv.ptr(coef_buf), rt.stream)
+            sums_f = tape.small(site + '/sums', (STAT_REPLICAS, 2, Cp), torch.float64)
+            nv.call('segnb_bn_fwd_fused', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(stats), nv.ptr(eff_gamma()),
+                    nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), nv.ptr(coef_buf), nv.ptr(sums_f),
+                    act, slope, nv.ptr(dropmul), ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0,
+                    None if res is None else res.v.ptr, 0 if res is None else res.v.ld, rt.stream)
+            tape.note_fused_stats(stats)
             coef = coef_buf
-        if out_stats is not None and pv is None and res is None:
-            # the pass that writes the slice also sums it
-            nv.call('segnb_bn_act_fwd_stats', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
-                    ov.ptr, ov.ld, nv.ptr(out_stats[0], out_stats[1]), out_stats[2], rt.stream)
-            out_stats = None
         else:
-            nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
-                    ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
-                    0 if res is None else res.v.ld, rt.stream)
+            if has_bn:
+                gamma, beta, rm, rv, nbt, eps, mom = _bn_fields(bn)
+                nv.call('segnb_bn_finalize', nv.ptr(stats), C, Cp, float(N * Ho * Wo), nv.ptr(eff_gamma()),
+                        nv.ptr(beta.detach()), eps, mom, nv.ptr(rm), nv.ptr(rv), nv.ptr(nbt), 1 if tape.train else 0,
+                        nv.ptr(coef_buf), rt.stream)
+                coef = coef_buf
+            if out_stats is not None and pv is None and res is None:
+                # the pass that writes the slice also sums it
+                nv.call('segnb_bn_act_fwd_stats', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+                        ov.ptr, ov.ld, nv.ptr(out_stats[0], out_stats[1]), out_stats[2], rt.stream)
+                out_stats = None
+            else:
+                nv.call('segnb_bn_act_fwd', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope, nv.ptr(dropmul),
+                        ov.ptr, ov.ld, vptr(pv), vld(pv), None, 0, None if res is None else res.v.ptr,
+                        0 if res is None else res.v.ld, rt.stream)
     if out_stats is not None:
         _sum_into(tape, pv if pool else ov, out_stats)
     oa = Act(ov)

@@ -1575,6 +1575,56 @@ def test_conv_dgrad_with_act_mask(shape):
         np.testing.assert_allclose(a[0] / scale, s_e[0] / scale, atol=2e-3)
 
 
+@pytest.mark.parametrize('shape', [(8, 16, 16, 656, 16), (8, 8, 8, 1072, 16), (2, 64, 64, 112, 16), (2, 12, 14, 128, 16), (3, 40, 72, 160, 12),
+                                   (4, 32, 32, 256, 16)], ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_fprop_with_dropout_and_slice_statistics(shape):
+    """segnb_conv_fprop_drop (a dense layer of tiramisu.py:9-20: conv(C -> 16) -> Dropout2d, written into its slice of the concat buffer,
+    the slice's statistics into the buffer's table) == segnb_conv_fprop + segnb_bn_act_fwd_stats(coef NULL, ACT_NONE, dropmul): the same
+    bits in the slice, the same statistics up to summation order; and the emulator's."""
+    N, H, W, C1, C2 = shape
+    rt = Runtime('cuda', 'bf16')
+    gen = torch.Generator().manual_seed(H * 13 + C1)
+    w = (torch.randn(C2, C1, 3, 3, generator=gen) * (2.0 / (C1 * 9)) ** 0.5).cuda()
+    b = (0.1 * torch.randn(C2, generator=gen)).cuda()
+    C1p, C2p = cp.pad8(C1), cp.pad8(C2)
+    op = ConvOp(rt, w, b, [(C1, C1p)], 1, 1, False, True)
+    op.pack(H, W)
+    xv = View.alloc(rt, N, H, W, C1p)
+    xv.t.normal_()
+    LD, OFF = C1p + C2p + 24, C1p                       # the slice sits behind C1p channels of a wider buffer
+    cat_ref, cat_f = (View.alloc(rt, N, H, W, LD) for _ in range(2))
+    drop = (torch.rand(N, C2p, generator=gen) > 0.2).float().mul_(1.25).cuda()
+    table_ref, table_f = (rt.zeros((16, 2, LD), torch.float64) for _ in range(2))
+    y = View.alloc(rt, N, H, W, C2p)
+    st = rt.stream
+    assert op.drop_epilogue_ok(N, H, W, LD), 'shape not served'
+    op.fprop(xv, y, None)
+    sl = cat_ref.slice(OFF, C2p)
+    nv.call('segnb_bn_act_fwd_stats', rt.code, y.ptr, y.ld, N, H, W, C2p, None, nv.ACT_NONE, 0.0, nv.ptr(drop), sl.ptr, sl.ld,
+            nv.ptr(table_ref, OFF), LD, st)
+    op.fprop_drop(xv, cat_f.slice(OFF, C2p), drop, (table_f, OFF, LD))
+    torch.cuda.synchronize()
+    assert torch.equal(cat_f.t, cat_ref.t)
+    a, r = table_f.sum(0).cpu().numpy(), table_ref.sum(0).cpu().numpy()
+    assert np.abs(a[:, :OFF]).max() == 0.0 and np.abs(a[:, OFF + C2p:]).max() == 0.0          # nothing outside the slice's columns
+    np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-5 * float(np.abs(r).max()))
+    if N * H * W <= 20000:
+        def run_emu():
+            rc = Runtime('cpu', 'bf16')
+            ope = ConvOp(rc, w.cpu(), b.cpu(), [(C1, C1p)], 1, 1, False, True)
+            ope.pack(H, W)
+            xe, ce = View.alloc(rc, N, H, W, C1p), View.alloc(rc, N, H, W, LD)
+            xe.t.copy_(xv.t.cpu())
+            te = rc.zeros((16, 2, LD), torch.float64)
+            assert ope.drop_epilogue_ok(N, H, W, LD)
+            ope.fprop_drop(xe, ce.slice(OFF, C2p), drop.cpu(), (te, OFF, LD))
+            return ce.t.float(), te.sum(0).numpy()
+        with on_emulator():
+            ce, te = run_emu()
+        check('slice vs emulator', cat_f.t, ce, 'bf16')
+        np.testing.assert_allclose(a, te, rtol=2e-2, atol=2e-2 * float(np.abs(te).max()))
+
+
 @pytest.mark.parametrize('accumulate', [0, 1])
 @pytest.mark.parametrize('shape', [(2, 24, 40, 112, 16, 1), (3, 9, 11, 48, 16, 2), (8, 8, 8, 1072, 16, 1), (8, 16, 16, 656, 16, 1),
                                    (2, 17, 23, 72, 12, 1), (8, 128, 128, 272, 16, 1)], ids=lambda s: 'x'.join(map(str, s)))
