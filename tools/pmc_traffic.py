@@ -43,6 +43,29 @@ def read_counter(directory, counter):
     return per
 
 
+def steady_per_step(directory, counter, step_kernels, skip=2):
+    """Counter total of the STEADY-STATE steps / their number: the dispatches are walked in order, a step ends with one of
+    `step_kernels`; the first `skip` steps (plan recording, first-use packs and clears) are left out, and so is everything after the
+    last step kernel.  -> (total, steps) or (0.0, 0)"""
+    rows = []
+    for f in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        with open(f, newline='') as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') == counter:
+                    rows.append((int(row['Dispatch_Id']), family(row['Kernel_Name']), float(row['Counter_Value'])))
+    rows.sort()
+    total, steps, cur, seen = 0.0, 0, 0.0, 0
+    for _, fam, v in rows:
+        cur += v
+        if fam in step_kernels:
+            seen += 1
+            if seen > skip:
+                total += cur
+                steps += 1
+            cur = 0.0
+    return total, steps
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fe, wr = read_counter(fetch_dir, 'FETCH_SIZE'), read_counter(write_dir, 'WRITE_SIZE')
@@ -85,8 +108,17 @@ def main():
     per_step = None
     if steps_f and steps_w:
         per_step = round((2.0 * total_f / steps_f + total_w / steps_w) * 1024.0)
+    # (r6) the figure bench.py quotes: steady-state steps only -- the first two steps of a run (plan recording, first-use weight packs,
+    # buffer clears) are not a training step's traffic, and in a short profiled run they were 1/4 of the steps
+    marks = (step_kernel, 'sgd_ranges_kernel') if step_kernel == 'sgd_kernel' else (step_kernel,)
+    sf, nsf = steady_per_step(fetch_dir, 'FETCH_SIZE', marks)
+    sw, nsw = steady_per_step(write_dir, 'WRITE_SIZE', marks)
+    all_steps = per_step
+    if nsf and nsw:
+        per_step = round((2.0 * sf / nsf + sw / nsw) * 1024.0)
     doc = {'kernel_sources_digest': bench.kernel_sources_digest(),      # bench.py reports `traffic` only for this build
-           'bytes_per_step': per_step, 'steps_profiled': steps_f, 'step_kernel': step_kernel,
+           'bytes_per_step': per_step, 'bytes_per_step_all_steps_of_the_run': all_steps, 'steady_steps': nsf,
+           'steps_profiled': steps_f, 'step_kernel': step_kernel,
            'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch (gfx950 FETCH_SIZE correction x2); '
                    'separate --pmc passes; average over all launches of the kernel family in the profiled command',
            'kernels': res}
