@@ -213,6 +213,7 @@ class Tape(object):
     fold_head_mask = True
     # fuse_act_pool = False: conv -> ReLU -> MaxPool2d(2) without BatchNorm as convolution + one pass that activates and pools (A/B)
     fuse_act_pool = True
+    inline_last_wgrad = os.environ.get('SEGNB_INLINE_LAST_WGRAD', '1') != '0'
     # two_launch_dgrad = True: a dense layer's 16 -> prefix data gradient is never stored -- one launch for the BatchNorm-backward sums,
     # one that recomputes it and applies the BatchNorm backward (segnb_conv_fprop_bnsums / _bnapply).  OFF: measured on MI355X
     # (profiles/r05_ab.txt) FCDenseNet103 16.23 ms per step with it against 15.74 without -- the general kernel is not a streaming
@@ -540,6 +541,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     conv = tape.cached(site + '/op', make_op)
     tape.consume(x, res)
     xv = x.v
+    # The weight gradient of a layer WITHOUT a data gradient (the network's first convolution: nothing is left on the dependent chain
+    # behind it) runs on the chain's own stream -- which is idle by then while the weight-gradient stream still works through its
+    # queue (UNet16: 1.4 ms of it) -- instead of at the end of that queue (Tape.inline_last_wgrad = False: forked like the others, A/B)
+    forks = x.needs_grad or not Tape.inline_last_wgrad
     plan = conv.plan(xv.H, xv.W)
     tape.register_conv(conv, xv.H, xv.W)
     if plan.get('packed_key') != tape.pack_key:          # (first use of this plan: Tape.begin packs the known ones in one launch)
@@ -618,7 +623,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                 # dz = g * act'(a): the reduce pass with the activated tensor in the place of the raw one (the last launch before
                 # the weight gradient's fork: its event rides on this dispatch, engine.Runtime.arm_fork); the pooled gradient is
                 # routed to the window's first maximum of a, as the forward's pooling pass chose it
-                rt.arm_fork()
+                (rt.arm_fork() if forks else None)
                 if g2 is not None:
                     nv.call('segnb_bn_act_bwd_reduce_add', rt.code, ov.ptr, ov.ld, N, Ho, Wo, Cp, None, act, slope, None,
                             g1.ptr, g1.ld, g2.ptr, g2.ld, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
@@ -627,7 +632,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
                             vptr(g1), vld(g1), vptr(gp), vld(gp), None, 0, dz.ptr, dz.ld, nv.ptr(sums), None, 0, rt.stream)
             gb = flat.grad_of(bias) if bias is not None else None
             tape.defer_bias_grad(sums, C, Cp, gb, float(N * Ho * Wo), coef_buf, bcoef)
-            side = rt.fork_side()
+            side = rt.fork_side() if forks else None
             if side is not None:
                 with torch.cuda.stream(side):
                     conv.wgrad(xv, dz, flat.grad_of(weight), unpack=False)
@@ -715,7 +720,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             oa.g_is_dz = False
         else:
             if not has_bn and res is None:
-                rt.arm_fork()                # (no BatchNorm: this pass is the last launch before the weight gradient's fork)
+                (rt.arm_fork() if forks else None)                # (no BatchNorm: this pass is the last launch before the weight gradient's fork)
             if og2 is not None:
                 nv.call('segnb_bn_act_bwd_reduce_add', rt.code, y.ptr, y.ld, N, Ho, Wo, Cp, nv.ptr(coef), act, slope,
                         nv.ptr(dropmul), og.ptr, og.ld, og2.ptr, og2.ld, dz.ptr, dz.ld, nv.ptr(sums),
@@ -734,7 +739,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
             if res is None and not abs_form:
                 # the apply pass is the LAST launch before the weight gradient's fork below: its event rides on that dispatch
                 # (engine.Runtime.arm_fork: no marker packet between the pass and the data gradient on this queue)
-                rt.arm_fork()
+                (rt.arm_fork() if forks else None)
             if direct:
                 nv.call('segnb_bn_bwd_apply_fused_direct', rt.code, y.ptr, y.ld, N, Ho, Wo, C, Cp, nv.ptr(coef_buf),
                         nv.ptr(sums), nv.ptr(gamma.detach()), nv.ptr(bcoef), nv.ptr(dgamma_target()),
@@ -758,7 +763,7 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
         # the weight gradient (and its unpack) only READ x and dy, and nothing reads dW before the end of backward: side
         # stream, beside the dependent chain reduce -> apply -> data gradient (engine.Runtime.fork_side; dy is a buffer
         # of this call site that nothing writes again during this backward)
-        side = rt.fork_side()
+        side = rt.fork_side() if forks else None
         if side is not None:
             with torch.cuda.stream(side):
                 conv.wgrad(xv, dy, flat.grad_of(weight), unpack=False)
