@@ -543,8 +543,10 @@ def conv_unit(tape, x, weight, bias, in_segments, stride=1, pad=1, transposed=Fa
     xv = x.v
     # The weight gradient of a layer WITHOUT a data gradient (the network's first convolution: nothing is left on the dependent chain
     # behind it) runs on the chain's own stream -- which is idle by then while the weight-gradient stream still works through its
-    # queue (UNet16: 1.4 ms of it) -- instead of at the end of that queue (Tape.inline_last_wgrad = False: forked like the others, A/B)
-    forks = x.needs_grad or not Tape.inline_last_wgrad
+    # queue (UNet16: 1.4 ms of it) -- instead of at the end of that queue (Tape.inline_last_wgrad = False: forked like the others, A/B).
+    # Only where the launch delivers into the parameter's gradient itself (ConvOp.direct_ok): a result left in the packed workspace is
+    # picked up by the batched unpack BEHIND the weight gradients on the side stream (Tape.finish), which does not wait for this one
+    forks = x.needs_grad or not Tape.inline_last_wgrad or not conv.direct_ok()
     plan = conv.plan(xv.H, xv.W)
     tape.register_conv(conv, xv.H, xv.W)
     if plan.get('packed_key') != tape.pack_key:          # (first use of this plan: Tape.begin packs the known ones in one launch)
