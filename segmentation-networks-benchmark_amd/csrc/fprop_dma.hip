@@ -1587,7 +1587,7 @@ int segnb_fprop_dma_try(const segnb_conv_geom* g, const void* in, unsigned in_by
     a.bn_slope = 0.f;
     if (bn != nullptr) {
         const long long yb = (((long long)g->N * g->Ho * g->Wo - 1) * bn->ld_y + g->Co) * 2;
-        if (bn->ld_y % 4 != 0 || yb >= (1ll << 31)) return 0;
+        if (bn->ld_y % 8 != 0 || yb >= (1ll << 31)) return 0;      // (16-byte loads of 8-channel chunks)
         a.bn_y = (const bf16_t*)bn->y;
         a.bn_y_bytes = (unsigned)yb;
         a.bn_ld = bn->ld_y;

@@ -48,7 +48,7 @@ struct FxCfg {
     static constexpr int OFF_O = OFF_W + BCO * WROW;
     static constexpr int OFF_TAP = OFF_O + TP * OROW;
     static constexpr int OFF_STAT = OFF_TAP + 64 * 4;
-    static constexpr int SMEM = OFF_STAT + 2 * BCO * 4;
+    static constexpr int SMEM = OFF_STAT + 4 * 2 * BCO * 4;     // one statistics row per wave (summed in a fixed order)
     static_assert(TP == 128 || TP == 256, "tile pixels");
     static_assert(WT % 32 == 0 || (WT == 16 && R % 2 == 0), "an MFMA row tile is 32 consecutive grid pixels of a tile row (or two 16-pixel rows)");
     static_assert(BCI == 8 || BCI % 16 == 0, "channel chunk");
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_sx_kernel(const FxArgs a) {
     const int wpieces = BCO * a.ntaps * (BCI / 8);
 
     if (tid < 64) sTap[tid] = tid < a.ntaps ? ((int)a.dh[tid] * XC + (int)a.dw[tid]) * SXB : 0;
-    if (tid < 2 * BCO) sStat[tid] = 0.f;
+    for (int i = tid; i < 4 * 2 * BCO; i += 256) sStat[i] = 0.f;
     // weight rows end in zeros up to KPAD (+ pad): the K steps past the last tap multiply them
     for (int i = tid; i < BCO * (WROW / 16); i += 256) *reinterpret_cast<uint4*>(sW + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -250,15 +250,20 @@ __global__ __launch_bounds__(256, 1) void conv_fprop_sx_kernel(const FxArgs a) {
         for (int j = 0; j < TCO; ++j) {
             const float t1 = s1[j] + __shfl_xor(s1[j], 32), t2 = s2[j] + __shfl_xor(s2[j], 32);
             if (h == 0) {
-                atomicAdd(&sStat[32 * j + l31], t1);
-                atomicAdd(&sStat[BCO + 32 * j + l31], t2);
+                // one slot per (wave, column): plain stores, summed below in wave order -- LDS float atomics from the four waves
+                // arrive in any order, and the rounding of that sum reached the layer's scale / shift (LinkNet34's stem: one
+                // float ulp in a tenth of the channels, a handful of flipped bf16 roundings, two different gradients from the
+                // same step: profiles/r06_ab.txt section 19)
+                sStat[wave * 2 * BCO + 32 * j + l31] = t1;
+                sStat[wave * 2 * BCO + BCO + 32 * j + l31] = t2;
             }
         }
         __syncthreads();
         if (tid < 2 * BCO) {
             const int which = tid / BCO, co = co0 + tid - which * BCO;
+            const float sum = ((sStat[tid] + sStat[2 * BCO + tid]) + sStat[4 * BCO + tid]) + sStat[6 * BCO + tid];
             if (co < a.Co)
-                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], (double)sStat[tid]);
+                atomicAdd(&a.stats[((long long)(blockIdx.x % SEGNB_STAT_REPLICAS) * 2 + which) * a.Co + co], (double)sum);
         }
     }
 }
