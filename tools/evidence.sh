@@ -46,6 +46,7 @@ python3 tools/head_bench.py > $O/${TAG}_head_bench.txt 2>&1
 python3 tools/dense_dgrad_bench.py > $O/${TAG}_dense_dgrad_bench.txt 2>&1
 python3 tools/step_ramp.py > $O/${TAG}_step_ramp.txt 2>&1
 python3 tools/mask_bench.py > $O/${TAG}_mask_bench.txt 2>&1
+python3 tools/determinism_probe.py > $O/${TAG}_determinism.txt 2>&1
 # cross-stream fork: cost of the marker packet vs an event on the kernel's own dispatch, and the ordering check
 mkdir -p tools/_bin
 [ -x tools/_bin/fork_cost ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/_bin/fork_cost tools/fork_cost.hip > /dev/null 2>&1
