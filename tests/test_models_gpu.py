@@ -171,7 +171,8 @@ def test_weight_gradient_cu_share_is_local_to_the_model():
     default = list(probe.plan(64, 64)['nslab'])
     probe2 = ConvOp(rt, torch.randn(128, 128, 3, 3).cuda(), None, [(128, 128)], 1, 1, False, True)
     probe2.wg_cu_pct = 100
-    assert probe2.plan(64, 64)['nslab'][0] > default[0]          # (a full share is more pixel splits)
+    if Runtime.overlap_wgrad:           # (SEGNB_OVERLAP_WGRAD=0: one stream, the default share IS all of the CUs)
+        assert probe2.plan(64, 64)['nslab'][0] > default[0]          # (a full share is more pixel splits)
     x = torch.randn(2, 3, 128, 128).cuda()
     y = (torch.rand(2, 1, 128, 128) > 0.7).long().cuda()
     crit = BCEWithLogitsLossAndSmoothJaccard()
